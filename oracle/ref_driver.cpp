@@ -1,0 +1,131 @@
+/*
+ * ref_driver.cpp -- thin main() over the REFERENCE's own classes, compiled in place from
+ * /root/reference by oracle/Makefile into oracle/_ref/refdrv.
+ *
+ * TEST INFRASTRUCTURE ONLY.  No reference source is copied: this file only #includes the
+ * reference headers where they lie and dispatches to them, the way
+ * /root/reference/src/MdbgAssembler.cpp:97-172 dispatches its sub-commands.  It exists so the
+ * oracle restatement (mdbg_oracle.c) and the HIP path can be checked against the real
+ * reference, and so bench.py can time the reference's CPU path (cpu_baseline.kind="reference").
+ *
+ * Sub-commands that run reference tools unchanged (same argv as the reference executable):
+ *   refdrv readSelection <tmpDir> <out> <input.txt> --threads N --min-read-quality Q [...]
+ *   refdrv graph <tmpDir> --threads N [--min-abundance M] [--firstpass]
+ *   refdrv contig ... / refdrv toMinspace ...      (producers of the k>4 inputs)
+ * Function-level probes (text on stdin -> text on stdout), used by tests/golden/make_golden.py:
+ *   refdrv fn_scan <K> <density> <hpc>     : lines "<seq>"              -> "n v:pos:dir ..."
+ *   refdrv fn_purge <firstK> <lastK>       : lines "m0 m1 ..."          -> purged list
+ *   refdrv fn_kminmer <k>                  : lines "m0 .. m(k-1)"       -> "rev hi lo c0 .. c(k-1)"
+ *   refdrv fn_murmur                       : lines "<u64>"              -> Murmur3_x64_128(&v,8,42)
+ *   refdrv fn_lastk <density> <n50> <firstK> <maxK>
+ */
+#include "Commons.hpp"
+#include "readSelection/ReadSelection.hpp"
+#include "graph/CreateMdbg.hpp"
+#include "assembly/GenerateContigs.hpp"
+#include "toBasespace/ToMinspace.hpp"
+
+#include <iostream>
+#include <sstream>
+
+static std::vector<uint64_t> parse_u64s(const std::string &line)
+{
+    std::vector<uint64_t> v;
+    std::istringstream is(line);
+    uint64_t x;
+    while (is >> x) v.push_back(x);
+    return v;
+}
+
+static int fn_scan(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    size_t K = std::stoul(argv[2]);
+    float density = std::stof(argv[3]);
+    bool hpc = std::stoi(argv[4]) != 0;
+    unordered_set<MinimizerType> rep;
+    for (int i = 5; i < argc; i++) rep.insert((MinimizerType)std::stoul(argv[i]));
+    MinimizerParser parser(K, density, rep);
+    EncoderRLE enc;
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        std::string rle;
+        vector<u_int64_t> rlePos;
+        enc.execute(line.c_str(), line.size(), rle, rlePos, hpc);
+        vector<MinimizerType> m;
+        vector<u_int32_t> pos;
+        vector<u_int8_t> dir;
+        parser.parse(rle, m, pos, dir);
+        std::cout << m.size() << " " << rle.size();
+        for (size_t i = 0; i < m.size(); i++) std::cout << " " << m[i] << ":" << pos[i] << ":" << (int)dir[i];
+        std::cout << "\n";
+    }
+    return 0;
+}
+
+static int fn_purge(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    size_t firstK = std::stoul(argv[2]), lastK = std::stoul(argv[3]);
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        vector<MinimizerType> m;
+        for (uint64_t x : parse_u64s(line)) m.push_back((MinimizerType)x);
+        vector<MinimizerType> r = Commons::purgePalindrome(m, firstK, lastK);
+        for (size_t i = 0; i < r.size(); i++) std::cout << (i ? " " : "") << r[i];
+        std::cout << "\n";
+    }
+    return 0;
+}
+
+static int fn_kminmer(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        KmerVec vec;
+        for (uint64_t x : parse_u64s(line)) vec._kmers.push_back((MinimizerType)x);
+        bool rev;
+        KmerVec c = vec.normalize(rev);
+        u_int128_t h = c.hash128();
+        std::cout << (rev ? 1 : 0) << " " << (uint64_t)(h >> 64) << " " << (uint64_t)h;
+        for (auto m : c._kmers) std::cout << " " << m;
+        std::cout << "\n";
+    }
+    return 0;
+}
+
+static int fn_murmur()
+{
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        uint64_t v = std::stoull(line);
+        std::cout << MurmurHash3_x64_128((const char *)&v, sizeof(v), 42) << "\n";
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::cerr << "usage: refdrv <sub-command> ...\n"; return 2; }
+    std::string cmd = argv[1];
+    if (cmd == "fn_scan") return fn_scan(argc, argv);
+    if (cmd == "fn_purge") return fn_purge(argc, argv);
+    if (cmd == "fn_kminmer") return fn_kminmer(argc, argv);
+    if (cmd == "fn_murmur") return fn_murmur();
+    if (cmd == "fn_lastk") {
+        if (argc < 6) return 2;
+        std::cout << Commons::computeLastK(std::stof(argv[2]), std::stoul(argv[3]), std::stoul(argv[4]), std::stoul(argv[5])) << "\n";
+        return 0;
+    }
+    /* Tool dispatch: drop argv[1] like MdbgAssembler.cpp:106-110 */
+    std::vector<char *> args(argv, argv + argc);
+    args.erase(args.begin() + 1);
+    int n = argc - 1;
+    if (cmd == "readSelection") ReadSelection().run(n, args.data());
+    else if (cmd == "graph") CreateMdbg().run(n, args.data());
+    else if (cmd == "contig") GenerateContigs().run(n, args.data());
+    else if (cmd == "toMinspace") ToMinspace().run(n, args.data());
+    else { std::cerr << "unknown sub-command " << cmd << "\n"; return 2; }
+    return 0;
+}

@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE's own code.
+
+Runs in the build container only (needs /root/reference, compiled in place into
+oracle/_ref/refdrv by oracle/Makefile).  The fixtures are data: inputs (seeds / literal
+sequences) and the reference's outputs.  No reference source is stored here.
+
+    python tests/golden/make_golden.py            # regenerates everything
+
+Fixture sets:
+  hifi_200/   200 x 10 kb synthetic HiFi reads (FASTA), HPC on, l=15, density 0.005, k=4
+  ont_100/    100 x 20 kb synthetic ONT-like reads (FASTQ), no HPC, --skip-correction
+  edge/       hand-made reads: N, lowercase, < K, low complexity, homopolymers, K=16
+  fn/         function-level known answers: purgePalindrome, normalize+hash128, murmur, lastK
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from metamdbg_amd import formats, synth  # noqa: E402
+
+REFDRV = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+
+
+def run_ref_pipeline(workdir: str, fasta: str, params: formats.Parameters, threads: int = 1,
+                     extra_rs: list[str] | None = None, graph: bool = True) -> str:
+    """readSelection (+ graph --firstpass) exactly as AssemblyPipeline invokes them
+    (pipeline/AssemblyPipeline.hpp:733-737, :770-783).  Returns the tmp dir."""
+    tmp = os.path.join(workdir, "tmp")
+    for d in ("", "filter", "smallContigs", "checkpoints"):
+        os.makedirs(os.path.join(tmp, d), exist_ok=True)
+    params.save(os.path.join(tmp, "parameters.gz"))
+    with open(os.path.join(tmp, "input.txt"), "w") as f:
+        f.write(fasta + "\n")
+    cmd = [REFDRV, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
+           "--threads", str(threads), "--min-read-quality", "0.000000"] + (extra_rs or [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if graph:
+        cmd = [REFDRV, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return tmp
+
+
+def sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def store_outputs(tmp: str, dst: str, k: int, manifest: dict) -> None:
+    os.makedirs(dst, exist_ok=True)
+    for name in ("read_data_init.txt", "read_stats.txt", "repetitiveMinimizers.bin", "parameters.gz"):
+        shutil.copy(os.path.join(tmp, name), os.path.join(dst, name))
+    p = os.path.join(tmp, "read_data_corrected.txt")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, "read_data_corrected.txt"))  # threads=1 -> read order
+    ab = os.path.join(tmp, "kminmerData_abundance.txt")
+    if os.path.exists(ab):
+        raw = open(ab, "rb").read()
+        formats.sorted_abundance_records(raw).tofile(os.path.join(dst, "kminmerData_abundance.sorted.bin"))
+        raw = open(os.path.join(tmp, "kminmerData_min.txt"), "rb").read()
+        formats.sorted_vector_records(raw, k).astype("<u4").tofile(os.path.join(dst, "kminmerData_min.sorted.bin"))
+    with open(os.path.join(dst, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+def make_hifi(work: str) -> None:
+    spec = synth.hifi_spec(200, seed=7, coverage=40.0)
+    fasta = os.path.join(work, "hifi_200.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                last_k=0, hpc=True, data_type=0)
+    tmp = run_ref_pipeline(os.path.join(work, "hifi"), fasta, params)
+    store_outputs(tmp, os.path.join(HERE, "hifi_200"), 4, dict(
+        kind="hifi", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+        species_len=spec.species_len, species_weight=spec.species_weight, fasta_sha256=sha256(fasta),
+        K=15, density=0.005, hpc=True, k=4, min_abundance=0))
+
+
+def make_ont(work: str) -> None:
+    spec = synth.SynthSpec(n_reads=100, read_len=20_000, seed=11, sub_rate=0.02,
+                           species_len=[60_000, 50_000], species_weight=[0.7, 0.3], with_quality=True, name="ont")
+    fastq = os.path.join(work, "ont_100.fastq")
+    synth.write_fasta(fastq, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                last_k=0, hpc=False, data_type=1, correction_density=0.025)
+    tmp = run_ref_pipeline(os.path.join(work, "ont"), fastq, params, extra_rs=["--skip-correction"])
+    store_outputs(tmp, os.path.join(HERE, "ont_100"), 4, dict(
+        kind="ont", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+        species_len=spec.species_len, species_weight=spec.species_weight, with_quality=True,
+        fasta_sha256=sha256(fastq), K=15, density=0.005, hpc=False, k=4, min_abundance=0, skip_correction=True))
+
+
+def edge_reads() -> list[bytes]:
+    rng = np.random.default_rng(1234)
+
+    def rnd(n):
+        return bytes(synth.CODE2ASCII[rng.integers(0, 4, n)])
+    reads = [
+        rnd(3000),                                        # plain
+        # (reads containing N/n are NOT here: the reference's computeSequenceComplexity indexes
+        #  kmerCounts[-1] for them -- readSelection/ReadSelection.hpp:1196 -- and aborts with heap
+        #  corruption; N handling is pinned at function level by fn_scan below)
+        rnd(2000).lower(),                                # lowercase (same 2-bit code, different HPC chars)
+        rnd(14),                                          # shorter than K
+        rnd(15), rnd(16), rnd(17),                        # 1, 2, 3 k-mers -> loop [1, nK-1)
+        rnd(40),                                          # < 66: no full complexity window -> NaN
+        b"ACGT" * 700,                                    # periodic
+        b"A" * 500 + rnd(1000) + b"C" * 800 + rnd(1200),  # long homopolymers
+        b"AC" * 1500,                                     # low complexity (score > 5)
+        b"AAT" * 1200,                                    # low complexity
+        rnd(5000)[:4999],
+        b"A" * 64,                                        # HPC collapses to one base
+        rnd(1000) + b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA",  # ends in a run
+        b"TTTTTTTTTTTTTTTTTTTTTTTTTTTT" + rnd(1000),      # starts with a run
+    ]
+    # reverse-complement pair -> same canonical minimizers, opposite directions
+    a = rnd(4000)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads += [a, a.translate(comp)[::-1]]
+    return reads
+
+
+def make_edge(work: str) -> None:
+    reads = edge_reads()
+    dst = os.path.join(HERE, "edge")
+    os.makedirs(dst, exist_ok=True)
+    fasta = os.path.join(dst, "edge.fasta")
+    with open(fasta, "wb") as f:
+        for i, s in enumerate(reads):
+            f.write(b">e%d\n" % i + s + b"\n")
+    for tag, K, hpc in (("hpc_k15", 15, True), ("nohpc_k15", 15, False), ("hpc_k16", 16, True), ("nohpc_k13", 13, False)):
+        params = formats.Parameters(minimizer_size=K, kminmer_size=4, density=0.005 if K != 13 else 0.02,
+                                    first_k=4, prev_k=4, hpc=hpc, data_type=0 if hpc else 1)
+        tmp = run_ref_pipeline(os.path.join(work, "edge_" + tag), fasta, params,
+                               extra_rs=[] if hpc else ["--skip-correction"], graph=False)
+        shutil.copy(os.path.join(tmp, "read_data_init.txt"), os.path.join(dst, f"read_data_init.{tag}.txt"))
+        shutil.copy(os.path.join(tmp, "read_stats.txt"), os.path.join(dst, f"read_stats.{tag}.txt"))
+        shutil.copy(os.path.join(tmp, "repetitiveMinimizers.bin"), os.path.join(dst, f"repetitiveMinimizers.{tag}.bin"))
+    # FASTQ variant of the same reads (qualities exercise getMinQuality through rlePositions)
+    rng = np.random.default_rng(99)
+    fastq = os.path.join(dst, "edge.fastq")
+    with open(fastq, "wb") as f:
+        for i, s in enumerate(reads):
+            q = bytes((rng.integers(0, 60, len(s)) + 33).astype(np.uint8))
+            f.write(b"@e%d\n" % i + s + b"\n+\n" + q + b"\n")
+    for tag, hpc in (("fastq_hpc_k15", True), ("fastq_nohpc_k15", False)):
+        params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                    hpc=hpc, data_type=0 if hpc else 1)
+        tmp = run_ref_pipeline(os.path.join(work, "edge_" + tag), fastq, params,
+                               extra_rs=[] if hpc else ["--skip-correction"], graph=False)
+        shutil.copy(os.path.join(tmp, "read_data_init.txt"), os.path.join(dst, f"read_data_init.{tag}.txt"))
+        shutil.copy(os.path.join(tmp, "repetitiveMinimizers.bin"), os.path.join(dst, f"repetitiveMinimizers.{tag}.bin"))
+
+
+def refdrv_lines(args: list[str], lines: list[str]) -> list[str]:
+    r = subprocess.run([REFDRV] + args, input="\n".join(lines) + "\n", capture_output=True, text=True, check=True)
+    return r.stdout.strip("\n").split("\n")
+
+
+def make_fn() -> None:
+    dst = os.path.join(HERE, "fn")
+    os.makedirs(dst, exist_ok=True)
+    rng = np.random.default_rng(2024)
+    out = {}
+    # murmur
+    vals = [0, 1, 12345, 2**30 - 1, 2**32 - 1, 2**64 - 1] + [int(x) for x in rng.integers(0, 2**32, 64)]
+    out["murmur"] = dict(inputs=[str(v) for v in vals], outputs=refdrv_lines(["fn_murmur"], [str(v) for v in vals]))
+    # kminmer normalize + hash128 for k = 2..13 (all Murmur tail lengths), incl. palindromes/ties
+    km = {}
+    for k in range(2, 14):
+        vecs = [rng.integers(0, 2**32, k).tolist() for _ in range(8)]
+        half = rng.integers(0, 2**32, (k + 1) // 2).tolist()
+        vecs.append(half + half[: k // 2][::-1])                 # palindrome
+        v = rng.integers(0, 2**32, k).tolist(); v[-1] = v[0]      # tie on first compare
+        vecs.append(v)
+        vecs.append(sorted(rng.integers(0, 1000, k).tolist(), reverse=True))
+        lines = [" ".join(map(str, v)) for v in vecs]
+        km[str(k)] = dict(inputs=lines, outputs=refdrv_lines(["fn_kminmer", str(k)], lines))
+    out["kminmer"] = km
+    # purgePalindrome: crafted lists with palindromic windows, nested, overlapping
+    lists = [
+        [1, 2, 3, 4, 5, 6, 7, 8],
+        [1, 2, 2, 1, 5, 6, 7, 8],
+        [9, 1, 2, 3, 2, 1, 7, 8, 4],
+        [1, 2, 3, 3, 2, 1, 1, 2, 3, 3, 2, 1],
+        [5, 5, 5, 5, 5, 5, 5],
+        [1, 2, 1, 2, 1, 2, 1, 2, 1],
+        [7, 1, 2, 3, 4, 4, 3, 2, 1, 8, 9, 10],
+        [1, 2, 3],
+        [],
+        [4, 4],
+        [3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8, 9, 7, 9, 3, 2, 3, 8, 4, 6, 2, 6, 4, 3, 3, 8, 3, 2, 7, 9, 5],
+    ]
+    for _ in range(40):
+        n = int(rng.integers(4, 40))
+        lists.append(rng.integers(0, 4, n).tolist())          # tiny alphabet -> many palindromes
+    for _ in range(20):
+        n = int(rng.integers(4, 60))
+        lists.append(rng.integers(0, 12, n).tolist())
+    lines = [" ".join(map(str, v)) for v in lists]
+    out["purge"] = {}
+    for fk, lk in ((4, 100), (4, 6), (3, 9)):
+        out["purge"][f"{fk}_{lk}"] = dict(inputs=lines, outputs=refdrv_lines(["fn_purge", str(fk), str(lk)], lines))
+    # MinimizerParser on reads with invalid characters (N/n), both HPC settings
+    def rnd(n):
+        return bytes(synth.CODE2ASCII[rng.integers(0, 4, n)]).decode()
+    nreads = [rnd(1500) + "N" + rnd(1500), rnd(700) + "NNNNNNNNNN" + rnd(900) + "n" + rnd(400),
+              "N" + rnd(600), rnd(600) + "N", rnd(10) + "N" + rnd(10), "N" * 40, rnd(2000),
+              rnd(300) + "NN" + rnd(20) + "N" + rnd(300), rnd(800).lower() + "N" + rnd(800)]
+    out["scan_n"] = {}
+    for hpc in (0, 1):
+        for K, dens in ((15, 0.02), (16, 0.02), (11, 0.05)):
+            out["scan_n"][f"K{K}_hpc{hpc}"] = dict(
+                K=K, density=dens, hpc=hpc, inputs=nreads,
+                outputs=refdrv_lines(["fn_scan", str(K), str(dens), str(hpc)], nreads))
+    # lastK
+    cases = [(0.005, 10000, 4, 0), (0.005, 10000, 4, 11), (0.005, 20000, 4, 0), (0.005, 300, 4, 0),
+             (0.025, 9000, 4, 0), (0.005, 15431, 4, 0), (0.005, 100, 4, 0)]
+    out["lastk"] = [dict(args=list(c), out=int(subprocess.run(
+        [REFDRV, "fn_lastk"] + [str(x) for x in c], capture_output=True, text=True, check=True).stdout)) for c in cases]
+    with open(os.path.join(dst, "fn_golden.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
+def main() -> None:
+    if not os.path.exists(REFDRV):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+    work = tempfile.mkdtemp(prefix="mdbg_golden_")
+    try:
+        make_fn()
+        make_edge(work)
+        make_hifi(work)
+        make_ont(work)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    print("golden fixtures written under", HERE)
+
+
+if __name__ == "__main__":
+    main()

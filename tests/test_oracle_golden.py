@@ -1,0 +1,159 @@
+"""The CPU oracle (oracle/mdbg_oracle.c) against the golden vectors produced by the REFERENCE's
+own code (tests/golden/make_golden.py).  CPU only."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from metamdbg_amd import formats
+from oracle import pyoracle as orc
+from tests import helpers as H
+
+
+@pytest.fixture(scope="module")
+def fn_golden():
+    with open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")) as f:
+        return json.load(f)
+
+
+def test_known_answer_scalars():
+    # SURVEY.md section 8(c)
+    assert orc.kmer_hash(12345) == 8367407816444978832
+    assert orc.kmer_hash(2**64 - 1) == 13161889351522953593
+    assert orc.density_threshold(0.005) == 92233718306963448
+    assert orc.density_threshold(0.025) == 461168608714686432
+    rev, vec, hi, lo = orc.kminmer_normalize_hash([5, 9, 3, 7])
+    assert (rev, hi, lo) == (0, 13950843744880946374, 7379975562370095872)
+    rev, vec, _, _ = orc.kminmer_normalize_hash([3, 7, 7, 3])
+    assert rev == 1 and vec.tolist() == [3, 7, 7, 3]
+
+
+def test_density_threshold_is_exact_boundary():
+    for d in (0.005, 0.025, 0.02, 0.05, 0.001, 0.5):
+        T = orc.density_threshold(d)
+        bound = float(np.float32(d)) * 2.0**64
+        assert float(T) >= bound and float(T - 1) < bound
+
+
+def test_murmur(fn_golden):
+    g = fn_golden["murmur"]
+    for v, out in zip(g["inputs"], g["outputs"]):
+        assert orc.kmer_hash(int(v)) == int(out)
+
+
+def test_kminmer_normalize_hash(fn_golden):
+    for k, g in fn_golden["kminmer"].items():
+        for line, out in zip(g["inputs"], g["outputs"]):
+            vec = [int(x) for x in line.split()]
+            o = [int(x) for x in out.split()]
+            rev, cvec, hi, lo = orc.kminmer_normalize_hash(vec)
+            assert [rev, hi, lo] + cvec.tolist() == o, (k, line)
+
+
+def test_purge_palindrome(fn_golden):
+    for key, g in fn_golden["purge"].items():
+        fk, lk = map(int, key.split("_"))
+        for line, out in zip(g["inputs"], g["outputs"]):
+            got = orc.purge_palindrome([int(x) for x in line.split()], fk, lk).tolist()
+            assert got == [int(x) for x in out.split()], (key, line)
+
+
+def test_last_k(fn_golden):
+    for c in fn_golden["lastk"]:
+        d, n50, fk, mk = c["args"]
+        assert orc.lib().orc_compute_last_k(d, n50, fk, mk) == c["out"]
+
+
+def test_scan_with_invalid_characters(fn_golden):
+    for key, g in fn_golden["scan_n"].items():
+        for seq, out in zip(g["inputs"], g["outputs"]):
+            toks = out.split()
+            exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
+            # complexity filter is not part of fn_scan -> call the parser pieces directly
+            L = orc.lib()
+            s = seq.encode()
+            import ctypes as C
+            rle = C.create_string_buffer(len(s) + 2)
+            pos = (C.c_uint64 * (len(s) + 2))()
+            hl = L.orc_hpc_encode(s, C.c_size_t(len(s)), g["hpc"], rle, pos)
+            om = (C.c_uint32 * max(hl, 1))(); op = (C.c_uint32 * max(hl, 1))(); od = (C.c_uint8 * max(hl, 1))()
+            L.orc_minimizer_parse.restype = C.c_size_t
+            n = L.orc_minimizer_parse(rle, C.c_size_t(hl), g["K"], C.c_float(g["density"]), None, C.c_size_t(0), om, op, od)
+            got = [(om[i], op[i], od[i]) for i in range(n)]
+            assert hl == int(toks[1]) and got == exp, key
+
+
+@pytest.mark.parametrize("tag,K,dens,hpc", [("hpc_k15", 15, 0.005, True), ("nohpc_k15", 15, 0.005, False),
+                                            ("hpc_k16", 16, 0.005, True), ("nohpc_k13", 13, 0.02, False)])
+def test_edge_reads_fasta(tag, K, dens, hpc):
+    seqs = H.read_fasta(os.path.join(H.GOLDEN, "edge", "edge.fasta"))
+    rep = np.frombuffer(H.golden_bytes("edge", f"repetitiveMinimizers.{tag}.bin"), "<u4")
+    got = b"".join(orc.read_selection(s, None, K=K, density=dens, hpc=hpc, repetitive=rep)["record"] for s in seqs)
+    assert got == H.golden_bytes("edge", f"read_data_init.{tag}.txt")
+
+
+@pytest.mark.parametrize("tag,hpc", [("fastq_hpc_k15", True), ("fastq_nohpc_k15", False)])
+def test_edge_reads_fastq(tag, hpc):
+    seqs, quals = H.read_fastq(os.path.join(H.GOLDEN, "edge", "edge.fastq"))
+    rep = np.frombuffer(H.golden_bytes("edge", f"repetitiveMinimizers.{tag}.bin"), "<u4")
+    got = b"".join(orc.read_selection(s, q, K=15, density=0.005, hpc=hpc, repetitive=rep)["record"]
+                   for s, q in zip(seqs, quals))
+    assert got == H.golden_bytes("edge", f"read_data_init.{tag}.txt")
+
+
+def _check_set(name: str):
+    m = H.load_manifest(name)
+    seqs, quals = H.regenerate_reads(m)
+    rep = np.frombuffer(H.golden_bytes(name, "repetitiveMinimizers.bin"), "<u4")
+    recs = [orc.read_selection(s, quals[i] if quals else None, K=m["K"], density=m["density"], hpc=m["hpc"],
+                               repetitive=rep) for i, s in enumerate(seqs)]
+    assert b"".join(r["record"] for r in recs) == H.golden_bytes(name, "read_data_init.txt")
+    # read_stats.txt (readSelection/ReadSelection.hpp:305-384)
+    st = formats.parse_read_stats(H.golden_bytes(name, "read_stats.txt"))
+    lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+    assert st["n_reads"] == len(seqs) and st["n_bases"] == int(lens.sum())
+    assert st["n50"] == orc.lib().orc_compute_n50(lens.ctypes.data, len(lens))
+    assert st["mean_length"] == orc.lib().orc_compute_mean_length(lens.ctypes.data, len(lens))
+    assert st["n_minimizers"] == sum(len(r["minimizers"]) for r in recs)
+    # purgePalindromes -> read_data_corrected.txt
+    last_k = orc.lib().orc_compute_last_k(m["density"], st["n50"], 4, 0)
+    purged = [orc.purge_palindrome(r["minimizers"], 4, last_k) for r in recs]
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in purged])]).astype(np.uint64)
+    mins = np.concatenate(purged).astype(np.uint32)
+    assert formats.write_minimizer_reads(mins, offs) == H.golden_bytes(name, "read_data_corrected.txt")
+    # k-min-mer table, first pass
+    t = orc.kminmer_count_first(mins, offs, m["k"], m["min_abundance"])
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, name, "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    got_ab = formats.sorted_abundance_records(orc.table_abundance_records(t))
+    assert np.array_equal(got_ab, exp_ab)
+    exp_v = np.fromfile(os.path.join(H.GOLDEN, name, "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    got_v = formats.sorted_vector_records(t["vecs"].astype("<u4").tobytes(), m["k"])
+    assert np.array_equal(got_v, exp_v)
+    return m, seqs, rep
+
+
+def test_hifi_200_end_to_end():
+    _check_set("hifi_200")
+
+
+def test_ont_100_end_to_end():
+    m, seqs, rep = _check_set("ont_100")
+    # repetitive minimizer selection (readSelection/ReadSelection.hpp:497-561): the chosen minimizer must
+    # have the maximal count at correction density (ties are order-unstable in the reference).
+    import ctypes as C
+    L = orc.lib()
+    L.orc_minimizer_parse.restype = C.c_size_t
+    counts: dict[int, int] = {}
+    for s in seqs:
+        n = len(s)
+        om = (C.c_uint32 * n)(); op = (C.c_uint32 * n)(); od = (C.c_uint8 * n)()
+        k = L.orc_minimizer_parse(s, C.c_size_t(n), 15, C.c_float(0.025), None, C.c_size_t(0), om, op, od)
+        for i in range(k):
+            counts[om[i]] = counts.get(om[i], 0) + 1
+    n_keep = max(int(np.float32(0.00001) * len(counts)), 1)
+    assert len(rep) == n_keep
+    top = sorted(counts.values(), reverse=True)[n_keep - 1]
+    assert all(counts[int(r)] >= top for r in rep)
