@@ -1,0 +1,181 @@
+/*
+ * mdbg_hip.h -- C ABI of libmdbg_hip.so: metaMDBG's read -> minimizer -> k-min-mer hot path
+ * as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference has no FFI: its boundary is two child processes (`readSelection`, `graph`)
+ * talking through files.  Each entry point below replaces the
+ * compute inside one reference function, cited as file:line under /root/reference/src, and is
+ * what a maintainer would call from that function (binding stubs: INTEGRATION.md).
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * MDBG_E* code, with a message available from mdbg_last_error(); objects are opaque handles
+ * owned by the library and released with the matching *_free; a context is bound to one HIP
+ * device and one stream and is not thread-safe (use one context per host thread / stream,
+ * as the reference uses one functor copy per OpenMP thread: Commons.hpp:5846-5914).
+ * There is no CPU fallback: without a usable GPU every call fails with MDBG_ENODEV.
+ */
+#ifndef MDBG_HIP_H
+#define MDBG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDBG_OK        0
+#define MDBG_EINVAL   -1   /* bad argument */
+#define MDBG_ENODEV   -2   /* no HIP device / wrong architecture */
+#define MDBG_ENOMEM   -3   /* device or host allocation failed */
+#define MDBG_EHIP     -4   /* HIP runtime error (see mdbg_last_error) */
+#define MDBG_ERANGE   -5   /* size exceeds an internal limit (see message) */
+
+typedef struct mdbg_ctx mdbg_ctx;
+typedef struct mdbg_reads mdbg_reads;             /* base-space reads resident in HBM, 2-bit packed */
+typedef struct mdbg_minimizers mdbg_minimizers;   /* minimizer-space reads resident in HBM (CSR) */
+typedef struct mdbg_table mdbg_table;             /* k-min-mer table resident in HBM */
+
+/* ---- context ------------------------------------------------------------------------- */
+int  mdbg_create(int device, mdbg_ctx **ctx);
+void mdbg_destroy(mdbg_ctx *ctx);
+const char *mdbg_last_error(const mdbg_ctx *ctx);      /* ctx may be NULL: last creation error */
+int  mdbg_synchronize(mdbg_ctx *ctx);
+void *mdbg_stream(mdbg_ctx *ctx);                       /* the hipStream_t every launch goes to */
+int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes);
+
+/* Profiling aid: accumulated HIP-event time (ms) and launch count of the kernel named
+ * `kernel` ("scan", "kminmer_insert", ...) since the last reset; events are recorded on
+ * the context's stream only while timing is enabled. */
+int  mdbg_timing_enable(mdbg_ctx *ctx, int on);
+int  mdbg_timing_reset(mdbg_ctx *ctx);
+int  mdbg_timing_get(mdbg_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches);
+
+/* ---- base-space reads ---------------------------------------------------------------- */
+/* Replaces the per-read copy in ReadParserParallel::parse (Commons.hpp:5868-5905): the caller
+ * hands a batch of parsed reads (ASCII, concatenated; read r = bases[offsets[r] .. offsets[r+1]))
+ * and optional phred+33 qualities with the same offsets (NULL for FASTA).  The batch is packed
+ * to 2 bits/base (code (c>>1)&3, utils/kmer/Kmer.hpp:462) on the device.  Characters with
+ * bit 3 set (N, n) are kept in a side bitmask.  HPC in the reference compares raw characters
+ * (Commons.hpp:4177-4178); here it compares (code, invalid) so e.g. "aA" IS one run -- inputs
+ * are expected to be upper-case ACGTN (stated in DESIGN.md). */
+int  mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, const uint64_t *offsets,
+                           uint32_t n_reads, mdbg_reads **out);
+/* Already packed on the host: words[] holds 32 bases per u64 (base i of a word at bits [2i,2i+2)),
+ * read r occupies words[word_offsets[r] .. word_offsets[r+1]) and starts on an even word. */
+int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
+                            const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out);
+/* Seeded synthetic read set generated directly in HBM (bench/test harness; same generator as
+ * metamdbg_amd/synth.py).  thresholds[s] = cumulative species weight as u64. */
+int  mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,
+                          uint64_t first_read, const uint64_t *species_len,
+                          const uint64_t *species_threshold, uint32_t n_species,
+                          uint64_t sub_threshold, int with_quality, mdbg_reads **out);
+int  mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t *n_bases, uint64_t *n_words);
+/* Copy read `index` back as ASCII (buffer of at least its length; quals may be NULL). */
+int  mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length);
+void mdbg_reads_free(mdbg_reads *r);
+
+/* ---- reads -> minimizers --------------------------------------------------------------- */
+typedef struct {
+    uint32_t minimizer_size;      /* l, <= 16            (Parameters::_minimizerSize) */
+    float    density;             /* f32 as stored in parameters.gz (Parameters::_minimizerDensity_assembly) */
+    int32_t  hpc;                 /* Parameters::_useHomopolymerCompression */
+    float    min_read_quality;    /* --min-read-quality   (ReadSelection.hpp:901) */
+    const uint32_t *repetitive;   /* host array: repetitiveMinimizers.bin contents, may be NULL */
+    uint32_t n_repetitive;
+    int32_t  apply_read_filters;  /* 1: complexity + quality filters of ReadSelectionFunctor (ReadSelection.hpp:890-915);
+                                     0: bare MinimizerParser::parse as CountMinimizerFunctor uses it (:599-611) */
+} mdbg_scan_params;
+
+/* Replaces, for a whole batch, EncoderRLE::execute + MinimizerParser::parse + complexity /
+ * quality filters + per-minimizer min quality of ReadSelectionFunctor::operator()
+ * (readSelection/ReadSelection.hpp:669-1158; utils/kmer/Kmer.hpp:1373-1456; Commons.hpp:4163-4203).
+ * Output order = read order, minimizers of a read in position order. */
+int  mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan_params *params, mdbg_minimizers **out);
+
+int  mdbg_minimizers_info(const mdbg_minimizers *m, uint32_t *n_reads, uint64_t *n_minimizers);
+/* Host copies; any pointer may be NULL.  offsets has n_reads+1 entries; per-read arrays n_reads.
+ * mean_quality is the f32 of ReadSelection.hpp:878-879 (NaN without qualities). */
+int  mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, uint64_t *offsets,
+                             uint32_t *minimizers, uint32_t *positions, uint8_t *directions, uint8_t *qualities,
+                             uint32_t *read_lengths, float *mean_quality, uint8_t *read_flags);
+#define MDBG_READ_LOW_COMPLEXITY 1u
+#define MDBG_READ_LOW_QUALITY    2u
+/* Upload minimizer-space sequences (read_data_corrected.txt / unitig_data.txt contents as CSR). */
+int  mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimizers, const uint64_t *offsets,
+                               uint32_t n_reads, mdbg_minimizers **out);
+/* Device pointers for zero-copy consumers (torch.from_dlpack-style wrapping in the harness). */
+int  mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers);
+void mdbg_minimizers_free(mdbg_minimizers *m);
+
+/* Replaces Commons::purgePalindrome over every read (Commons.hpp:1617-1723, driven by
+ * ReadSelection::purgePalindromes, ReadSelection.hpp:1374-1431). */
+int  mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t first_k, uint32_t last_k,
+                            mdbg_minimizers **out);
+
+/* Replaces CountMinimizerFunctor + the global map of determineRepetitiveMinimizers
+ * (ReadSelection.hpp:497-625): counts every minimizer value of `m` on the device and returns the
+ * top max(1, floor(1e-5 * distinct)) by count (ties broken by smaller value; the reference's
+ * tie order is std::sort-unstable).  out must hold *n_out entries on input. */
+int  mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out);
+
+/* ---- minimizers -> k-min-mer table ----------------------------------------------------- */
+/* First pass, k = firstK: KminmerCounter::execute + rescueKminmers
+ * (graph/CreateMdbg.hpp:3591-3883, :4514-4640; graph/CreateMdbg.cpp:290-328). */
+int  mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance,
+                              mdbg_table **out);
+/* Previous-iteration abundances for k > firstK (CreateMdbg::loadRefinedAbundances,
+ * graph/CreateMdbg.cpp:3401-3709): from kminmerData_abundance_prev.txt records (lo,hi,abundance;
+ * abundance==1 skipped) ... */
+int  mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, uint64_t n_records, mdbg_table **out);
+/* ... then overlaid with the refined abundance of each unitig of unitigGraph_prev.nodes.bin
+ * (unitigs as CSR; abundance[u] per unitig, 0 = unitig has no refined abundance and is skipped). */
+int  mdbg_prev_overlay_unitigs(mdbg_ctx *ctx, mdbg_table *prev, const mdbg_minimizers *unitigs,
+                               const uint32_t *abundance, uint32_t k_prev);
+/* k = firstK+1: KminmerCounter with getRefinedAbundance (graph/CreateMdbg.hpp:3933-4005) over
+ * reads and (optionally, may be NULL) unitig_data.txt sequences. */
+int  mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
+                                uint32_t k, const mdbg_table *prev, mdbg_table **out);
+/* k >= firstK+2: IndexKminmerFunctor (graph/CreateMdbg.hpp:1240-1265, :1450-1459) over reads and unitigs. */
+int  mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
+                        uint32_t k, const mdbg_table *prev, mdbg_table **out);
+
+/* n_records = rows of kminmerData_abundance.txt; n_solid of them are solid (the rest rescued,
+ * abundance 1); has_vectors = whether kminmerData_min.txt rows exist (k <= firstK+1). */
+int  mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_records, uint64_t *n_solid, int *has_vectors);
+/* Host copies in file layout: records20 = n_records x {u64 lo, u64 hi, u32 abundance} packed
+ * (MDBG::writeKminmerAbundance, Commons.hpp:4463-4472); vectors = n_records x k u32
+ * (MDBG::writeKminmer, Commons.hpp:4429-4446), same row order.  Either may be NULL. */
+int  mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors);
+/* In-process lookup for the reference's graph multiplexer (isEdgeSupported etc.,
+ * graph/CreateMdbg.cpp:3990): abundance of each of n keys, 0 when absent. */
+int  mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
+                       uint64_t n, uint32_t *abundance);
+void mdbg_table_free(mdbg_table *t);
+
+/* ---- multi-GPU merge (one process per GPU; the caller moves the bytes, e.g. RCCL all-to-all) ---- */
+/* Rows are mdbg_row_words(k) u64 words each: [hash_lo, hash_hi, count, vec01, vec23, ...] -- the
+ * canonical vector travels with the key because the owner of a key may hold no read containing it. */
+uint32_t mdbg_row_words(uint32_t k);
+/* Partial counts of the local reads, grouped by owner rank (owner = top bits of hash_hi scaled to
+ * [0, n_ranks), n_ranks <= 64): *d_rows points at device memory holding one row per distinct local
+ * key, rows of owner 0 first, then owner 1, ...; counts[r] = rows destined to rank r.  The buffer is
+ * owned by ctx and valid until the next call of this function or mdbg_destroy. */
+int  mdbg_kminmer_partial_counts(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
+                                 const uint64_t **d_rows, uint64_t *counts);
+/* Sum the counts of rows with equal keys, in place on the device (what the owner does with the rows
+ * it received); *n_out = number of distinct keys, stored in the first *n_out rows. */
+int  mdbg_reduce_rows(mdbg_ctx *ctx, uint64_t *d_rows, uint64_t n_rows, uint32_t k, uint64_t *n_out);
+/* Finish the first pass from the globally reduced rows of ALL ranks (after an all-gather of the owners'
+ * reduced rows; each key appears once): emits the solid records of the keys this rank owns followed by
+ * the rescued records of the local reads, judged against the global abundances.  The union over ranks
+ * equals the single-GPU table of mdbg_kminmer_count_first on the union of the reads. */
+int  mdbg_kminmer_count_first_merged(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance,
+                                     const uint64_t *d_global_rows, uint64_t n_global_rows,
+                                     uint32_t rank, uint32_t n_ranks, mdbg_table **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

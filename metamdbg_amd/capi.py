@@ -1,0 +1,349 @@
+"""ctypes binding of libmdbg_hip.so (include/mdbg_hip.h) -- thin, no compute in Python.
+
+There is no fallback: a missing library raises at import of :func:`lib`, and a missing or
+non-gfx950 GPU raises :class:`MdbgError` from :class:`Context`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdbg_hip.so")
+
+MDBG_READ_LOW_COMPLEXITY = 1
+MDBG_READ_LOW_QUALITY = 2
+
+
+class MdbgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmdbg_hip error {code}: {msg}")
+        self.code = code
+
+
+class ScanParams(C.Structure):
+    _fields_ = [("minimizer_size", C.c_uint32), ("density", C.c_float), ("hpc", C.c_int32),
+                ("min_read_quality", C.c_float), ("repetitive", C.POINTER(C.c_uint32)),
+                ("n_repetitive", C.c_uint32), ("apply_read_filters", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/mdbg_hip.h declares
+_P = C.c_void_p
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+SIGNATURES = {
+    "mdbg_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "mdbg_destroy": (None, [_P]),
+    "mdbg_last_error": (C.c_char_p, [_P]),
+    "mdbg_synchronize": (C.c_int, [_P]),
+    "mdbg_stream": (_P, [_P]),
+    "mdbg_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
+    "mdbg_timing_enable": (C.c_int, [_P, C.c_int]),
+    "mdbg_timing_reset": (C.c_int, [_P]),
+    "mdbg_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), _u64p]),
+    "mdbg_reads_from_ascii": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_reads_from_packed": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_reads_synthetic": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, C.c_uint32,
+                                       C.c_uint64, C.c_int, C.POINTER(_P)]),
+    "mdbg_reads_info": (C.c_int, [_P, _u32p, _u64p, _u64p]),
+    "mdbg_reads_get": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _u32p]),
+    "mdbg_reads_free": (None, [_P]),
+    "mdbg_scan": (C.c_int, [_P, _P, C.POINTER(ScanParams), C.POINTER(_P)]),
+    "mdbg_minimizers_info": (C.c_int, [_P, _u32p, _u64p]),
+    "mdbg_minimizers_to_host": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mdbg_minimizers_from_host": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_minimizers_device_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "mdbg_minimizers_free": (None, [_P]),
+    "mdbg_purge_palindromes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_repetitive_minimizers": (C.c_int, [_P, _P, _P, _u32p]),
+    "mdbg_kminmer_count_first": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_prev_from_records": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P)]),
+    "mdbg_prev_overlay_unitigs": (C.c_int, [_P, _P, _P, _P, C.c_uint32]),
+    "mdbg_kminmer_count_refined": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(_P)]),
+    "mdbg_kminmer_index": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(_P)]),
+    "mdbg_table_info": (C.c_int, [_P, _u32p, _u64p, _u64p, C.POINTER(C.c_int)]),
+    "mdbg_table_to_host": (C.c_int, [_P, _P, _P, _P]),
+    "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
+    "mdbg_table_free": (None, [_P]),
+    "mdbg_row_words": (C.c_uint32, [C.c_uint32]),
+    "mdbg_kminmer_partial_counts": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), _u64p]),
+    "mdbg_reduce_rows": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _u64p]),
+    "mdbg_kminmer_count_first_merged": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_uint32,
+                                                  C.c_uint32, C.POINTER(_P)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream (mdbg_create)."""
+
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        rc = lib().mdbg_create(device, C.byref(self.h))
+        if rc:
+            raise MdbgError(rc, (lib().mdbg_last_error(None) or b"").decode())
+
+    def check(self, rc: int) -> None:
+        if rc:
+            raise MdbgError(rc, (lib().mdbg_last_error(self.h) or b"").decode())
+
+    def close(self) -> None:
+        if self.h:
+            lib().mdbg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self) -> None:
+        self.check(lib().mdbg_synchronize(self.h))
+
+    def device_info(self) -> dict:
+        arch = C.create_string_buffer(64)
+        ncu, hbm = C.c_int(), C.c_uint64()
+        self.check(lib().mdbg_device_info(self.h, arch, 64, C.byref(ncu), C.byref(hbm)))
+        return dict(arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+    # -- timing ---------------------------------------------------------------------------
+    def timing(self, on: bool) -> None:
+        self.check(lib().mdbg_timing_enable(self.h, int(on)))
+
+    def timing_reset(self) -> None:
+        self.check(lib().mdbg_timing_reset(self.h))
+
+    def timing_get(self, kernel: str) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        self.check(lib().mdbg_timing_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- reads ------------------------------------------------------------------------------
+    def reads_from_ascii(self, seqs: list[bytes], quals: list[bytes] | None = None) -> "Reads":
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in seqs], out=offs[1:])
+        bases = b"".join(seqs)
+        q = b"".join(quals) if quals is not None else None
+        h = C.c_void_p()
+        self.check(lib().mdbg_reads_from_ascii(self.h, bases, q, _ptr(offs), len(seqs), C.byref(h)))
+        return Reads(self, h)
+
+    def reads_from_packed(self, words: np.ndarray, word_off: np.ndarray, lens: np.ndarray) -> "Reads":
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        h = C.c_void_p()
+        self.check(lib().mdbg_reads_from_packed(self.h, _ptr(words), _ptr(word_off), _ptr(lens), len(lens), C.byref(h)))
+        return Reads(self, h)
+
+    def reads_synthetic(self, spec, first_read: int = 0, n_reads: int | None = None) -> "Reads":
+        """HBM-resident reads [first_read, first_read + n_reads) of a synth.SynthSpec."""
+        n = spec.n_reads if n_reads is None else n_reads
+        slen = np.asarray(spec.species_len, dtype=np.uint64)
+        thr = np.ascontiguousarray(spec.weight_thresholds(), dtype=np.uint64)
+        h = C.c_void_p()
+        self.check(lib().mdbg_reads_synthetic(self.h, spec.seed, n, spec.read_len, first_read, _ptr(slen), _ptr(thr),
+                                              len(slen), spec.sub_threshold(), int(spec.with_quality), C.byref(h)))
+        return Reads(self, h)
+
+    # -- minimizer space ----------------------------------------------------------------------
+    def minimizers_from_host(self, mins: np.ndarray, offsets: np.ndarray) -> "Minimizers":
+        mins = np.ascontiguousarray(mins, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        self.check(lib().mdbg_minimizers_from_host(self.h, _ptr(mins), _ptr(offsets), len(offsets) - 1, C.byref(h)))
+        return Minimizers(self, h)
+
+    def scan(self, reads: "Reads", K: int = 15, density: float = 0.005, hpc: bool = True,
+             min_read_quality: float = 0.0, repetitive=None, apply_read_filters: bool = True) -> "Minimizers":
+        rep = np.ascontiguousarray(repetitive if repetitive is not None else [], dtype=np.uint32)
+        p = ScanParams(K, density, int(hpc), min_read_quality, rep.ctypes.data_as(C.POINTER(C.c_uint32)), len(rep),
+                       int(apply_read_filters))
+        h = C.c_void_p()
+        self.check(lib().mdbg_scan(self.h, reads.h, C.byref(p), C.byref(h)))
+        return Minimizers(self, h)
+
+    def purge_palindromes(self, m: "Minimizers", first_k: int, last_k: int) -> "Minimizers":
+        h = C.c_void_p()
+        self.check(lib().mdbg_purge_palindromes(self.h, m.h, first_k, last_k, C.byref(h)))
+        return Minimizers(self, h)
+
+    def repetitive_minimizers(self, m: "Minimizers", max_out: int = 4096) -> np.ndarray:
+        out = np.zeros(max_out, dtype=np.uint32)
+        n = C.c_uint32(max_out)
+        self.check(lib().mdbg_repetitive_minimizers(self.h, m.h, _ptr(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    # -- k-min-mer tables -----------------------------------------------------------------------
+    def kminmer_count_first(self, m: "Minimizers", k: int = 4, min_abundance: int = 0) -> "Table":
+        h = C.c_void_p()
+        self.check(lib().mdbg_kminmer_count_first(self.h, m.h, k, min_abundance, C.byref(h)))
+        return Table(self, h)
+
+    def prev_from_records(self, records: bytes | np.ndarray) -> "Table":
+        raw = records if isinstance(records, (bytes, bytearray)) else np.ascontiguousarray(records).tobytes()
+        h = C.c_void_p()
+        self.check(lib().mdbg_prev_from_records(self.h, raw, len(raw) // 20, C.byref(h)))
+        return Table(self, h)
+
+    def prev_overlay_unitigs(self, prev: "Table", unitigs: "Minimizers", abundance: np.ndarray, k_prev: int) -> None:
+        ab = np.ascontiguousarray(abundance, dtype=np.uint32)
+        self.check(lib().mdbg_prev_overlay_unitigs(self.h, prev.h, unitigs.h, _ptr(ab), k_prev))
+
+    def kminmer_count_refined(self, reads: "Minimizers", unitigs: "Minimizers | None", k: int, prev: "Table") -> "Table":
+        h = C.c_void_p()
+        self.check(lib().mdbg_kminmer_count_refined(self.h, reads.h, unitigs.h if unitigs else None, k, prev.h, C.byref(h)))
+        return Table(self, h)
+
+    def kminmer_index(self, reads: "Minimizers", unitigs: "Minimizers | None", k: int, prev: "Table") -> "Table":
+        h = C.c_void_p()
+        self.check(lib().mdbg_kminmer_index(self.h, reads.h, unitigs.h if unitigs else None, k, prev.h, C.byref(h)))
+        return Table(self, h)
+
+    # -- multi-GPU pieces --------------------------------------------------------------------------
+    def partial_counts(self, m: "Minimizers", k: int, n_ranks: int) -> tuple[int, np.ndarray]:
+        """(device pointer of the owner-grouped rows, rows per owner)."""
+        d_rows = C.c_void_p()
+        counts = np.zeros(n_ranks, dtype=np.uint64)
+        self.check(lib().mdbg_kminmer_partial_counts(self.h, m.h, k, n_ranks, C.byref(d_rows), counts.ctypes.data_as(_u64p)))
+        return d_rows.value or 0, counts
+
+    def reduce_rows(self, d_rows: int, n_rows: int, k: int) -> int:
+        n = C.c_uint64()
+        self.check(lib().mdbg_reduce_rows(self.h, C.c_void_p(d_rows), n_rows, k, C.byref(n)))
+        return n.value
+
+    def count_first_merged(self, m: "Minimizers", k: int, min_abundance: int, d_global_rows: int, n_global_rows: int,
+                           rank: int, n_ranks: int) -> "Table":
+        h = C.c_void_p()
+        self.check(lib().mdbg_kminmer_count_first_merged(self.h, m.h, k, min_abundance, C.c_void_p(d_global_rows),
+                                                         n_global_rows, rank, n_ranks, C.byref(h)))
+        return Table(self, h)
+
+
+class Reads:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self) -> dict:
+        n, nb, nw = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        lib().mdbg_reads_info(self.h, C.byref(n), C.byref(nb), C.byref(nw))
+        return dict(n_reads=n.value, n_bases=nb.value, n_words=nw.value)
+
+    def get(self, index: int, with_quality: bool = False):
+        L = C.c_uint32()
+        self.ctx.check(lib().mdbg_reads_get(self.ctx.h, self.h, index, None, None, C.byref(L)))
+        b = C.create_string_buffer(L.value + 1)
+        q = C.create_string_buffer(L.value + 1) if with_quality else None
+        self.ctx.check(lib().mdbg_reads_get(self.ctx.h, self.h, index, b, q, C.byref(L)))
+        return (b.raw[: L.value], q.raw[: L.value]) if with_quality else b.raw[: L.value]
+
+    def free(self) -> None:
+        if self.h:
+            lib().mdbg_reads_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Minimizers:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self) -> dict:
+        n, t = C.c_uint32(), C.c_uint64()
+        lib().mdbg_minimizers_info(self.h, C.byref(n), C.byref(t))
+        return dict(n_reads=n.value, n_minimizers=t.value)
+
+    def to_host(self, full: bool = True) -> dict:
+        i = self.info()
+        n, t = i["n_reads"], i["n_minimizers"]
+        out = dict(offsets=np.zeros(n + 1, np.uint64), minimizers=np.zeros(t, np.uint32))
+        if full:
+            out.update(pos=np.zeros(t, np.uint32), dir=np.zeros(t, np.uint8), qual=np.zeros(t, np.uint8),
+                       read_length=np.zeros(n, np.uint32), mean_quality=np.zeros(n, np.float32),
+                       flags=np.zeros(n, np.uint8))
+        self.ctx.check(lib().mdbg_minimizers_to_host(
+            self.ctx.h, self.h, _ptr(out["offsets"]), _ptr(out["minimizers"]), _ptr(out.get("pos")), _ptr(out.get("dir")),
+            _ptr(out.get("qual")), _ptr(out.get("read_length")), _ptr(out.get("mean_quality")), _ptr(out.get("flags"))))
+        return out
+
+    def device_ptrs(self) -> tuple[int, int]:
+        a, b = C.c_void_p(), C.c_void_p()
+        lib().mdbg_minimizers_device_ptrs(self.h, C.byref(a), C.byref(b))
+        return a.value or 0, b.value or 0
+
+    def free(self) -> None:
+        if self.h:
+            lib().mdbg_minimizers_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Table:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self) -> dict:
+        k, n, ns, hv = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_int()
+        lib().mdbg_table_info(self.h, C.byref(k), C.byref(n), C.byref(ns), C.byref(hv))
+        return dict(k=k.value, n_records=n.value, n_solid=ns.value, has_vectors=bool(hv.value))
+
+    def to_host(self) -> tuple[np.ndarray, np.ndarray | None]:
+        """(records as formats.ABUNDANCE_DTYPE array, vectors u32[n,k] or None)."""
+        from .formats import ABUNDANCE_DTYPE
+        i = self.info()
+        rec = np.zeros(i["n_records"], dtype=ABUNDANCE_DTYPE)
+        vec = np.zeros((i["n_records"], i["k"]), dtype=np.uint32) if i["has_vectors"] else None
+        self.ctx.check(lib().mdbg_table_to_host(self.ctx.h, self.h, _ptr(rec), _ptr(vec)))
+        return rec, vec
+
+    def lookup(self, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+        lo = np.ascontiguousarray(lo, dtype=np.uint64)
+        hi = np.ascontiguousarray(hi, dtype=np.uint64)
+        out = np.zeros(len(lo), dtype=np.uint32)
+        self.ctx.check(lib().mdbg_table_lookup(self.ctx.h, self.h, _ptr(lo), _ptr(hi), len(lo), _ptr(out)))
+        return out
+
+    def free(self) -> None:
+        if self.h:
+            lib().mdbg_table_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

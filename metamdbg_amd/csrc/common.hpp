@@ -1,0 +1,152 @@
+// common.hpp -- context, error plumbing, device buffers and wave64 helpers shared by the
+// HIP translation units of libmdbg_hip.so.  gfx950 (MI355X) only: 64-lane wavefronts.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mdbg_hip.h"
+
+namespace mdbg {
+
+constexpr int WAVE = 64;
+
+struct TimedLaunch {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace mdbg
+
+struct mdbg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string arch;
+    int n_cu = 0;
+    uint64_t hbm_bytes = 0;
+    bool timing = false;
+    std::vector<mdbg::TimedLaunch> launches;               // pending (not yet folded) timed launches
+    std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
+    // scratch kept between calls (partial-count rows handed out to the caller)
+    void *partial_rows = nullptr;
+    uint32_t *d_work_counter = nullptr;                    // dynamic work distribution counter
+};
+
+namespace mdbg {
+
+int set_error(mdbg_ctx *ctx, int code, const char *fmt, ...);
+extern std::string g_last_error;  // for failures before a context exists
+
+#define MDBG_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return mdbg::set_error((ctx), e_ == hipErrorOutOfMemory ? MDBG_ENOMEM : MDBG_EHIP, \
+                                   "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define MDBG_TRY(expr)            \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != MDBG_OK) return rc_; \
+    } while (0)
+
+// RAII device allocation (synchronous hipMalloc; sizes here are tens of MB to GB, allocated
+// a handful of times per call, never per read).
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    int alloc(mdbg_ctx *ctx, size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_error(ctx, MDBG_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return MDBG_OK;
+    }
+    T *detach() { T *q = p; p = nullptr; n = 0; return q; }
+};
+
+// Scoped kernel timer: records HIP events on ctx->stream around a launch when timing is on.
+struct LaunchTimer {
+    mdbg_ctx *ctx;
+    TimedLaunch t{};
+    bool on;
+    LaunchTimer(mdbg_ctx *c, const char *name) : ctx(c), on(c->timing) {
+        if (!on) return;
+        t.name = name;
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(t.start, ctx->stream);
+    }
+    ~LaunchTimer() {
+        if (!on) return;
+        (void)hipEventRecord(t.stop, ctx->stream);
+        ctx->launches.push_back(t);
+    }
+};
+
+inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks = 1u << 30) {
+    uint64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (unsigned)b;
+}
+
+// ---- device-side wave64 helpers -----------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
+
+// Order LDS traffic between the lanes of ONE wavefront (waves of a block run independent reads,
+// so __syncthreads() is not usable inside the per-read loops).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Inclusive prefix sum across the 64 lanes (shuffle ladder).
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+    unsigned lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(v, d, 64);
+        if (lane >= (unsigned)d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+#endif
+
+// device-wide exclusive scan (prims.hip): out[i] = sum(in[0..i)), out[n] = total; out has n+1 entries.
+int exclusive_scan_u32(mdbg_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, uint64_t n);
+
+}  // namespace mdbg

@@ -1,0 +1,127 @@
+// context.hip -- context lifetime, error reporting, timing of libmdbg_hip.so.
+#include "common.hpp"
+
+namespace mdbg {
+
+std::string g_last_error;
+
+int set_error(mdbg_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_last_error = buf;
+    return code;
+}
+
+static void fold_timers(mdbg_ctx *ctx) {
+    if (ctx->launches.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->launches) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            auto &slot = ctx->timers[t.name];
+            slot.first += ms;
+            slot.second += 1;
+        }
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    ctx->launches.clear();
+}
+
+}  // namespace mdbg
+
+using namespace mdbg;
+
+extern "C" int mdbg_create(int device, mdbg_ctx **out) {
+    if (!out) return set_error(nullptr, MDBG_EINVAL, "mdbg_create: null out pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return set_error(nullptr, MDBG_ENODEV, "mdbg_create: no HIP device (%s); this library has no CPU path",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= count)
+        return set_error(nullptr, MDBG_EINVAL, "mdbg_create: device %d out of range (%d devices)", device, count);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return set_error(nullptr, MDBG_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(nullptr, MDBG_ENODEV, "mdbg_create: device %d is %s; kernels are built for gfx950 only",
+                         device, prop.gcnArchName);
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return set_error(nullptr, MDBG_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    mdbg_ctx *ctx = new mdbg_ctx();
+    ctx->device = device;
+    ctx->arch = prop.gcnArchName;
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->hbm_bytes = prop.totalGlobalMem;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete ctx;
+        return set_error(nullptr, MDBG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    if ((e = hipMalloc((void **)&ctx->d_work_counter, 64)) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return set_error(nullptr, MDBG_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return MDBG_OK;
+}
+
+extern "C" void mdbg_destroy(mdbg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    fold_timers(ctx);
+    if (ctx->partial_rows) (void)hipFree(ctx->partial_rows);
+    if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *mdbg_last_error(const mdbg_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" int mdbg_synchronize(mdbg_ctx *ctx) {
+    if (!ctx) return MDBG_EINVAL;
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+extern "C" void *mdbg_stream(mdbg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes) {
+    if (!ctx) return MDBG_EINVAL;
+    if (arch && arch_len) {
+        strncpy(arch, ctx->arch.c_str(), arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_timing_enable(mdbg_ctx *ctx, int on) {
+    if (!ctx) return MDBG_EINVAL;
+    ctx->timing = on != 0;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_timing_reset(mdbg_ctx *ctx) {
+    if (!ctx) return MDBG_EINVAL;
+    fold_timers(ctx);
+    ctx->timers.clear();
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_timing_get(mdbg_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches) {
+    if (!ctx || !kernel) return MDBG_EINVAL;
+    fold_timers(ctx);
+    auto it = ctx->timers.find(kernel);
+    if (ms_total) *ms_total = it == ctx->timers.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.second;
+    return MDBG_OK;
+}

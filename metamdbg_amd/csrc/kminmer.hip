@@ -1,0 +1,715 @@
+// kminmer.hip -- minimizer-space reads -> k-min-mer tables on the device.
+//
+// Every window of k consecutive minimizers of every sequence is one *instance*
+// (MDBG::getKminmers_complete, Commons.hpp:5282-5361).  One lane per instance: orient the window
+// (KmerVec::normalize, Commons.hpp:886-916: lexicographic compare with its reverse, tie => reversed),
+// stream it through Murmur3 x64-128 seed 0 (KmerVec::hash128, Commons.hpp:941-969) and meet equal
+// keys in a device hash table (table.hpp).
+//   first pass (k = firstK)  : slot value = occurrence count; solid = count > 1 (and >= min abundance);
+//                              rescue pass appends count-1 instances of reads whose median abundance
+//                              is <= 10 (graph/CreateMdbg.hpp:3591-3883, :4514-4640)
+//   k = firstK+1             : distinct keys; abundance = min over the two (k-1)-sub-min-mers of the
+//                              previous table, missing/0 => 1; keep > 1 (graph/CreateMdbg.hpp:3933-4005)
+//   k >= firstK+2            : abundance = min(prev[i], prev[i+1]) along the sequence; insert-if-absent
+//                              when > 1 (graph/CreateMdbg.hpp:1240-1265, :1450-1459)
+#include "common.hpp"
+#include "murmur.hpp"
+#include "objects.hpp"
+#include "table.hpp"
+
+#include <vector>
+
+namespace mdbg {
+
+// ---- instance indexing -------------------------------------------------------------------------
+__global__ void inst_count_kernel(const uint64_t *off, uint32_t n_reads, uint32_t k, uint32_t *cnt) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) {
+        uint64_t n = off[r + 1] - off[r];
+        cnt[r] = n >= k ? (uint32_t)(n - k + 1) : 0u;
+    }
+}
+
+// read owning global instance g: largest r with inst_off[r] <= g
+__device__ __forceinline__ uint32_t find_read(const uint64_t *inst_off, uint32_t n_reads, uint64_t g) {
+    uint32_t lo = 0, hi = n_reads;  // invariant: inst_off[lo] <= g < inst_off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (inst_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// canonical orientation + hash128 of the window m[0..k).  Returns isReversed.
+__device__ __forceinline__ bool window_hash(const uint32_t *m, uint32_t k, uint64_t &hi, uint64_t &lo) {
+    bool reversed = true;  // palindrome => reversed (Commons.hpp:912-913)
+    for (uint32_t i = 0; i < k; i++) {
+        uint32_t a = m[i], b = m[k - 1 - i];
+        if (a == b) continue;
+        reversed = !(a < b);
+        break;
+    }
+    Murmur128Stream h;
+    if (reversed) for (uint32_t i = 0; i < k; i++) h.push(m[k - 1 - i]);
+    else          for (uint32_t i = 0; i < k; i++) h.push(m[i]);
+    h.finish(hi, lo);
+    return reversed;
+}
+
+__device__ __forceinline__ uint32_t table_upsert_count(const TableView &t, uint64_t lo, uint64_t hi, uint32_t add, uint32_t rep) {
+    if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, add, 0, false, rep, true);
+    uint32_t s = table_find_or_insert(t, lo, hi, true);
+    if (s != SLOT_NONE) {
+        if (add) atomicAdd(&t.val[s], add);
+        if (t.rep) t.rep[s] = rep;   // any instance of the key is a valid representative
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t table_upsert_set(const TableView &t, uint64_t lo, uint64_t hi, uint32_t v, uint32_t rep) {
+    if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, 0, v, true, rep, true);
+    uint32_t s = table_find_or_insert(t, lo, hi, true);
+    if (s != SLOT_NONE) {
+        __hip_atomic_store(&t.val[s], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t.rep) t.rep[s] = rep;
+    }
+    return s;
+}
+
+struct SeqView {
+    const uint32_t *mins;
+    const uint64_t *off;       // n_reads + 1
+    const uint64_t *inst_off;  // n_reads + 1
+    uint32_t n_reads;
+    uint64_t n_inst;
+};
+
+// ---- first pass -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_insert_kernel(SeqView s, uint32_t k, TableView t, uint32_t *inst_slot,
+                                                           uint64_t rep_base) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.n_inst) return;
+    uint32_t r = find_read(s.inst_off, s.n_reads, g);
+    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
+    uint64_t hi, lo;
+    window_hash(m, k, hi, lo);
+    uint32_t slot = table_upsert_count(t, lo, hi, 1u, (uint32_t)(rep_base + g));
+    if (inst_slot) inst_slot[g] = slot;
+}
+
+// abundance seen by the rescue pass: solid count or 1 (graph/CreateMdbg.hpp:4590-4600)
+__global__ __launch_bounds__(256) void inst_abundance_kernel(uint64_t n_inst, const uint32_t *inst_slot, TableView t,
+                                                             uint32_t min_abundance, uint32_t *ab) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_inst) return;
+    uint32_t slot = inst_slot[g];
+    uint32_t c = slot == SLOT_NONE ? 1u : table_slot_val(t, slot);
+    bool solid = c > 1u && !(c < min_abundance);
+    ab[g] = solid ? c : 0u;   // 0 = not in the solid table
+}
+
+// one wave per read: median of the per-instance abundances (non-solid counted as 1), then flag the
+// non-solid instances of reads with median*0.1f <= 1 that have at least one solid k-min-mer
+__global__ __launch_bounds__(256) void rescue_flag_kernel(const uint64_t *inst_off, uint32_t n_reads, const uint32_t *ab,
+                                                          uint32_t *flag) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint64_t f = inst_off[r];
+        const uint32_t n = (uint32_t)(inst_off[r + 1] - f);
+        if (n == 0) continue;
+        // all-ones test
+        bool any_solid = false;
+        for (uint32_t i = lane; i < n; i += 64) any_solid |= ab[f + i] != 0u;
+        any_solid = __ballot(any_solid) != 0ull;
+        bool rescue = false;
+        if (any_solid) {
+            // order statistics by rank counting: rank(i) = #{j : a_j < a_i or (a_j == a_i and j < i)}
+            const uint32_t want_hi = n / 2, want_lo = (n % 2 == 0) ? n / 2 - 1 : n / 2;
+            uint32_t v_hi = 0, v_lo = 0;
+            for (uint32_t base = 0; base < n; base += 64) {
+                uint32_t i = base + lane;
+                uint32_t ai = 0, rank = 0;
+                if (i < n) { ai = ab[f + i]; if (ai == 0) ai = 1; }
+                for (uint32_t j = 0; j < n; j++) {
+                    uint32_t aj = ab[f + j];
+                    if (aj == 0) aj = 1;
+                    rank += (aj < ai || (aj == ai && j < i)) ? 1u : 0u;
+                }
+                unsigned long long bh = __ballot(i < n && rank == want_hi);
+                unsigned long long bl = __ballot(i < n && rank == want_lo);
+                if (bh) v_hi = __shfl(ai, __ffsll((long long)bh) - 1, 64);
+                if (bl) v_lo = __shfl(ai, __ffsll((long long)bl) - 1, 64);
+            }
+            // Utils::compute_median on u32 (Commons.hpp:2972-2988): (a + b) / 2 in u32, or the middle
+            uint32_t median = (n % 2 == 0) ? (uint32_t)(v_lo + v_hi) / 2u : v_hi;
+            float cutoff = (float)median * 0.1f;          // graph/CreateMdbg.hpp:4610 (u32 * float)
+            rescue = !(cutoff > 1.0f);
+        }
+        for (uint32_t i = lane; i < n; i += 64) flag[f + i] = (rescue && ab[f + i] == 0u) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void slot_flag_kernel(TableView t, uint64_t cap, uint32_t min_abundance, int mode,
+                                                        uint32_t *flag) {
+    // mode 0: solid (count > 1 and >= min_abundance); mode 1: any occupied slot with val > 1; mode 2: occupied
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap + TABLE_EXC_CAP) return;
+    bool occ; uint32_t v;
+    if (s < cap) { occ = t.lo[s] != 0ull; v = t.val[s]; }
+    else { uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; v = occ ? t.exc_val[i] : 0u; }
+    bool keep = false;
+    if (occ) {
+        if (mode == 0) keep = v > 1u && !(v < min_abundance);
+        else if (mode == 1) keep = v > 1u;
+        else keep = true;
+    }
+    flag[s] = keep ? 1u : 0u;
+}
+
+struct RowOut {
+    uint64_t *lo, *hi;
+    uint32_t *ab;
+    uint32_t *vec;   // may be nullptr
+    uint32_t k;
+};
+
+// write the canonical vector of global instance id `g` (over one or two sequence sets)
+__device__ __forceinline__ void write_instance_vector(const SeqView &a, const SeqView &b, uint64_t g, uint32_t k, uint32_t *dst) {
+    const SeqView &s = g < a.n_inst ? a : b;
+    uint64_t gl = g < a.n_inst ? g : g - a.n_inst;
+    uint32_t r = find_read(s.inst_off, s.n_reads, gl);
+    const uint32_t *m = s.mins + s.off[r] + (gl - s.inst_off[r]);
+    bool reversed = true;
+    for (uint32_t i = 0; i < k; i++) {
+        uint32_t x = m[i], y = m[k - 1 - i];
+        if (x == y) continue;
+        reversed = !(x < y);
+        break;
+    }
+    for (uint32_t i = 0; i < k; i++) dst[i] = reversed ? m[k - 1 - i] : m[i];
+}
+
+__global__ __launch_bounds__(256) void emit_slots_kernel(TableView t, uint64_t cap, const uint32_t *flag, const uint64_t *pos,
+                                                         SeqView a, SeqView b, RowOut o, uint64_t row_base) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap + TABLE_EXC_CAP || !flag[s]) return;
+    uint64_t row = row_base + pos[s];
+    uint32_t rep;
+    if (s < cap) { o.lo[row] = t.lo[s]; o.hi[row] = t.hi[s]; o.ab[row] = t.val[s]; rep = t.rep ? t.rep[s] : 0; }
+    else { uint32_t i = (uint32_t)(s - cap); o.lo[row] = t.exc_lo[i]; o.hi[row] = t.exc_hi[i]; o.ab[row] = t.exc_val[i]; rep = t.exc_rep[i]; }
+    if (o.vec) write_instance_vector(a, b, rep, o.k, o.vec + row * o.k);
+}
+
+__global__ __launch_bounds__(256) void emit_rescued_kernel(SeqView s, uint32_t k, const uint32_t *flag, const uint64_t *pos,
+                                                           RowOut o, uint64_t row_base) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.n_inst || !flag[g]) return;
+    uint64_t row = row_base + pos[g];
+    uint32_t r = find_read(s.inst_off, s.n_reads, g);
+    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
+    uint64_t hi, lo;
+    bool reversed = window_hash(m, k, hi, lo);
+    o.lo[row] = lo; o.hi[row] = hi; o.ab[row] = 1u;
+    for (uint32_t i = 0; i < k; i++) o.vec[row * k + i] = reversed ? m[k - 1 - i] : m[i];
+}
+
+// ---- k > firstK --------------------------------------------------------------------------------------
+// distinct keys of all k-windows (k = firstK+1)
+__global__ __launch_bounds__(256) void distinct_insert_kernel(SeqView s, uint32_t k, TableView t, uint64_t rep_base) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.n_inst) return;
+    uint32_t r = find_read(s.inst_off, s.n_reads, g);
+    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
+    uint64_t hi, lo;
+    window_hash(m, k, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + g));
+}
+
+// refined abundance of every distinct key (graph/CreateMdbg.hpp:3933-3970): min over the two
+// (k-1)-sub-min-mers of the canonical vector; missing or 0 => 1
+__global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t cap, SeqView a, SeqView b, uint32_t k,
+                                                           TableView prev) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap + TABLE_EXC_CAP) return;
+    bool occ; uint32_t rep;
+    if (s < cap) { occ = t.lo[s] != 0ull; rep = occ ? t.rep[s] : 0; }
+    else { uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; rep = occ ? t.exc_rep[i] : 0; }
+    if (!occ) return;
+    const SeqView &sv = rep < a.n_inst ? a : b;
+    uint64_t gl = rep < a.n_inst ? rep : rep - a.n_inst;
+    uint32_t r = find_read(sv.inst_off, sv.n_reads, gl);
+    const uint32_t *m = sv.mins + sv.off[r] + (gl - sv.inst_off[r]);
+    // sub-windows of the CANONICAL vector; min over both is orientation independent, so use m directly
+    uint32_t min_ab = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < 2; i++) {
+        uint64_t hi, lo;
+        window_hash(m + i, k - 1, hi, lo);
+        uint32_t v;
+        if (table_lookup(prev, lo, hi, v)) {
+            if (v == 0u) { min_ab = 1u; break; }
+            if (v < min_ab) min_ab = v;
+        } else { min_ab = 1u; break; }
+    }
+    if (s < cap) t.val[s] = min_ab; else t.exc_val[s - cap] = min_ab;
+}
+
+// abundance of every (k-1)-window along the sequences (getPrevAbundances, graph/CreateMdbg.hpp:1240-1265)
+__global__ __launch_bounds__(256) void prev_abundance_kernel(SeqView s /* instances of size k-1 */, uint32_t km1, TableView prev,
+                                                             uint32_t *out) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.n_inst) return;
+    uint32_t r = find_read(s.inst_off, s.n_reads, g);
+    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
+    uint64_t hi, lo;
+    window_hash(m, km1, hi, lo);
+    uint32_t v;
+    out[g] = table_lookup(prev, lo, hi, v) ? v : 1u;
+}
+
+// k-window i of read r gets min(prev[i], prev[i+1]); insert-if-absent when > 1 (graph/CreateMdbg.hpp:1440-1459)
+__global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
+                                                           uint32_t k, TableView t) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.n_inst) return;
+    uint32_t r = find_read(s.inst_off, s.n_reads, g);
+    uint64_t i = g - s.inst_off[r];
+    uint64_t j = inst_off_km1[r] + i;
+    uint32_t a0 = prev_ab[j], a1 = prev_ab[j + 1];
+    uint32_t a = a0 < a1 ? a0 : a1;
+    if (a <= 1u) return;
+    const uint32_t *m = s.mins + s.off[r] + i;
+    uint64_t hi, lo;
+    window_hash(m, k, hi, lo);
+    table_upsert_set(t, lo, hi, a, 0u);
+}
+
+// ---- prev tables ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_insert_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *ab, uint64_t n,
+                                                          int skip_one, TableView t) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (skip_one && ab[i] == 1u) return;   // graph/CreateMdbg.cpp:3445
+    table_upsert_set(t, lo[i], hi[i], ab[i], 0u);
+}
+
+// (graph/CreateMdbg.cpp:3466-3507)
+__global__ __launch_bounds__(256) void overlay_kernel(SeqView s, uint32_t kprev, const uint32_t *unitig_ab, TableView t) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.n_inst) return;
+    uint32_t r = find_read(s.inst_off, s.n_reads, g);
+    uint32_t a = unitig_ab[r];
+    if (a == 0u) return;   // unitig without refined abundance
+    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
+    uint64_t hi, lo;
+    window_hash(m, kprev, hi, lo);
+    if (a == 1u) {
+        // modify_if: set to 0 only when present
+        if (lo == 0ull || hi == 0ull) { table_exc_upsert(t, lo, hi, 0, 0, true, 0, false); return; }
+        uint32_t slot = table_find_or_insert(t, lo, hi, false);
+        if (slot != SLOT_NONE) __hip_atomic_store(&t.val[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        table_upsert_set(t, lo, hi, a, 0u);
+    }
+}
+
+__global__ __launch_bounds__(256) void lookup_kernel(TableView t, const uint64_t *lo, const uint64_t *hi, uint64_t n, uint32_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v;
+    out[i] = table_lookup(t, lo[i], hi[i], v) ? v : 0u;
+}
+
+__global__ void unpack_records_kernel(const uint8_t *rec, uint64_t n, uint64_t *lo, uint64_t *hi, uint32_t *ab) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = rec + 20 * i;
+    uint64_t l = 0, h = 0; uint32_t a = 0;
+    for (int b = 0; b < 8; b++) { l |= (uint64_t)p[b] << (8 * b); h |= (uint64_t)p[8 + b] << (8 * b); }
+    for (int b = 0; b < 4; b++) a |= (uint32_t)p[16 + b] << (8 * b);
+    lo[i] = l; hi[i] = h; ab[i] = a;
+}
+
+__global__ void pack_records_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *ab, uint64_t n, uint8_t *rec) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *p = rec + 20 * i;
+    uint64_t l = lo[i], h = hi[i]; uint32_t a = ab[i];
+    for (int b = 0; b < 8; b++) { p[b] = (uint8_t)(l >> (8 * b)); p[8 + b] = (uint8_t)(h >> (8 * b)); }
+    for (int b = 0; b < 4; b++) p[16 + b] = (uint8_t)(a >> (8 * b));
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------------
+struct InstIndex {
+    DevBuf<uint64_t> off;   // n_reads + 1
+    uint64_t total = 0;
+};
+
+static int build_inst_index(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t k, InstIndex &ix) {
+    DevBuf<uint32_t> cnt;
+    MDBG_TRY(cnt.alloc(ctx, m->n_reads));
+    MDBG_TRY(ix.off.alloc(ctx, (size_t)m->n_reads + 1));
+    if (m->n_reads)
+        hipLaunchKernelGGL(inst_count_kernel, dim3(grid_for(m->n_reads, 256)), dim3(256), 0, ctx->stream, m->d_off.p, m->n_reads, k, cnt.p);
+    MDBG_TRY(exclusive_scan_u32(ctx, cnt.p, ix.off.p, m->n_reads));
+    MDBG_HIP_CHECK(ctx, hipMemcpy(&ix.total, ix.off.p + m->n_reads, 8, hipMemcpyDeviceToHost));
+    return MDBG_OK;
+}
+
+static SeqView make_view(const mdbg_minimizers *m, const InstIndex &ix) {
+    SeqView v;
+    v.mins = m ? m->d_min.p : nullptr;
+    v.off = m ? m->d_off.p : nullptr;
+    v.inst_off = ix.off.p;
+    v.n_reads = m ? m->n_reads : 0;
+    v.n_inst = ix.total;
+    return v;
+}
+
+static int alloc_rows(mdbg_ctx *ctx, mdbg_table *t, uint64_t n, bool vec) {
+    MDBG_TRY(t->d_lo.alloc(ctx, n));
+    MDBG_TRY(t->d_hi.alloc(ctx, n));
+    MDBG_TRY(t->d_ab.alloc(ctx, n));
+    if (vec) MDBG_TRY(t->d_vec.alloc(ctx, n * t->k));
+    t->n_records = n;
+    t->has_vectors = vec;
+    return MDBG_OK;
+}
+
+// used by multigpu.hip: size `t` for n_solid + rescued rows and emit the rescued block
+int mg_rescue_rows(mdbg_ctx *ctx, const mdbg_minimizers *reads, const uint64_t *inst_off, uint64_t n_inst, uint32_t k,
+                   const uint32_t *ab, mdbg_table *t, uint64_t n_solid) {
+    uint64_t n_resc = 0;
+    DevBuf<uint32_t> rflag;
+    DevBuf<uint64_t> rpos;
+    if (n_inst) {
+        MDBG_TRY(rflag.alloc(ctx, n_inst));
+        MDBG_TRY(rpos.alloc(ctx, n_inst + 1));
+        unsigned blocks = grid_for((uint64_t)reads->n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
+        {
+            LaunchTimer timer(ctx, "kminmer_rescue");
+            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, inst_off, reads->n_reads, ab, rflag.p);
+        }
+        MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, n_inst));
+        MDBG_HIP_CHECK(ctx, hipMemcpy(&n_resc, rpos.p + n_inst, 8, hipMemcpyDeviceToHost));
+    }
+    MDBG_TRY(alloc_rows(ctx, t, n_solid + n_resc, true));
+    if (n_resc) {
+        SeqView sv;
+        sv.mins = reads->d_min.p; sv.off = reads->d_off.p; sv.inst_off = inst_off; sv.n_reads = reads->n_reads; sv.n_inst = n_inst;
+        RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(emit_rescued_kernel, dim3(grid_for(n_inst, 256)), dim3(256), 0, ctx->stream, sv, k, rflag.p, rpos.p, ro, n_solid);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+}  // namespace mdbg
+
+using namespace mdbg;
+
+static int check_seq(mdbg_ctx *ctx, const mdbg_minimizers *m, const char *who) {
+    if (!m) return set_error(ctx, MDBG_EINVAL, "%s: null sequence set", who);
+    if (m->n_min >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "%s: more than 2^32 minimizers in one batch", who);
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance,
+                                        mdbg_table **out) {
+    if (!ctx || !out || k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_first: bad argument");
+    MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_count_first"));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    InstIndex ix;
+    MDBG_TRY(build_inst_index(ctx, reads, k, ix));
+    const uint64_t I = ix.total;
+    SeqView sv = make_view(reads, ix), none{};
+    DeviceTable tab;
+    MDBG_TRY(tab.init(ctx, I + I / 2 + 1024, true));   // load factor <= 2/3 even if every instance is distinct
+    TableView tv = tab.view();
+    DevBuf<uint32_t> inst_slot, ab, rflag, sflag;
+    MDBG_TRY(inst_slot.alloc(ctx, I));
+    if (I) {
+        LaunchTimer timer(ctx, "kminmer_insert");
+        hipLaunchKernelGGL(count_insert_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, sv, k, tv, inst_slot.p, (uint64_t)0);
+    }
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
+    MDBG_TRY(tab.check_overflow(ctx));
+
+    // solid rows
+    const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
+    DevBuf<uint64_t> spos, rpos;
+    MDBG_TRY(sflag.alloc(ctx, nslots));
+    MDBG_TRY(spos.alloc(ctx, nslots + 1));
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, min_abundance, 0, sflag.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
+    uint64_t n_solid = 0, n_resc = 0;
+    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+
+    // rescue (graph/CreateMdbg.cpp:317-319: only when min_abundance <= 1)
+    const bool do_rescue = min_abundance <= 1;
+    if (do_rescue && I) {
+        MDBG_TRY(ab.alloc(ctx, I));
+        MDBG_TRY(rflag.alloc(ctx, I));
+        MDBG_TRY(rpos.alloc(ctx, I + 1));
+        {
+            LaunchTimer timer(ctx, "kminmer_rescue");
+            hipLaunchKernelGGL(inst_abundance_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, I, inst_slot.p, tv, min_abundance, ab.p);
+            unsigned blocks = grid_for((uint64_t)reads->n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
+            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.off.p, reads->n_reads, ab.p, rflag.p);
+        }
+        MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, I));
+        MDBG_HIP_CHECK(ctx, hipMemcpy(&n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
+    }
+
+    mdbg_table *t = new mdbg_table();
+    t->k = k;
+    t->n_solid = n_solid;
+    int rc = alloc_rows(ctx, t, n_solid + n_resc, true);
+    if (rc) { delete t; return rc; }
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, sflag.p, spos.p, sv, none, ro, (uint64_t)0);
+        if (n_resc)
+            hipLaunchKernelGGL(emit_rescued_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, sv, k, rflag.p, rpos.p, ro, n_solid);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_count_first failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return MDBG_OK;
+}
+
+// build a lookup DeviceTable from the rows of `t` (abundance == 1 skipped as loadRefinedAbundances does)
+static int ensure_lookup(mdbg_ctx *ctx, mdbg_table *t, bool skip_one) {
+    if (t->lookup) return MDBG_OK;
+    std::unique_ptr<DeviceTable> tab(new DeviceTable());
+    MDBG_TRY(tab->init(ctx, t->n_records * 2 + 1024, false));
+    if (t->n_records)
+        hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(t->n_records, 256)), dim3(256), 0, ctx->stream,
+                           t->d_lo.p, t->d_hi.p, t->d_ab.p, t->n_records, skip_one ? 1 : 0, tab->view());
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
+    MDBG_TRY(tab->check_overflow(ctx));
+    t->lookup = std::move(tab);
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, uint64_t n_records, mdbg_table **out) {
+    if (!ctx || !out || (n_records && !records20)) return set_error(ctx, MDBG_EINVAL, "mdbg_prev_from_records: bad argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mdbg_table *t = new mdbg_table();
+    auto fail = [&](int rc) { delete t; return rc; };
+    int rc;
+    DevBuf<uint8_t> d_rec;
+    if ((rc = d_rec.alloc(ctx, n_records * 20)) || (rc = alloc_rows(ctx, t, n_records, false))) return fail(rc);
+    if (n_records) {
+        hipError_t e = hipMemcpyAsync(d_rec.p, records20, n_records * 20, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "record upload failed: %s", hipGetErrorString(e)));
+        hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for(n_records, 256)), dim3(256), 0, ctx->stream, d_rec.p, n_records,
+                           t->d_lo.p, t->d_hi.p, t->d_ab.p);
+    }
+    // headroom: the unitig overlay may add keys that are not in the record file
+    std::unique_ptr<DeviceTable> tab(new DeviceTable());
+    if ((rc = tab->init(ctx, n_records * 3 + 4096, false))) return fail(rc);
+    if (n_records)
+        hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(n_records, 256)), dim3(256), 0, ctx->stream,
+                           t->d_lo.p, t->d_hi.p, t->d_ab.p, n_records, 1, tab->view());
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "prev table build failed: %s", hipGetErrorString(e)));
+    if ((rc = tab->check_overflow(ctx))) return fail(rc);
+    t->lookup = std::move(tab);
+    *out = t;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_prev_overlay_unitigs(mdbg_ctx *ctx, mdbg_table *prev, const mdbg_minimizers *unitigs,
+                                         const uint32_t *abundance, uint32_t k_prev) {
+    if (!ctx || !prev || !prev->lookup || !abundance || k_prev < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_prev_overlay_unitigs: bad argument");
+    MDBG_TRY(check_seq(ctx, unitigs, "mdbg_prev_overlay_unitigs"));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    InstIndex ix;
+    MDBG_TRY(build_inst_index(ctx, unitigs, k_prev, ix));
+    if (prev->lookup->cap < (prev->n_records + ix.total) * 3 / 2)
+        return set_error(ctx, MDBG_ERANGE, "prev table too small for the unitig overlay (%llu windows)", (unsigned long long)ix.total);
+    DevBuf<uint32_t> d_ab;
+    MDBG_TRY(d_ab.alloc(ctx, unitigs->n_reads));
+    if (unitigs->n_reads) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(d_ab.p, abundance, (size_t)unitigs->n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+    SeqView sv = make_view(unitigs, ix);
+    if (ix.total)
+        hipLaunchKernelGGL(overlay_kernel, dim3(grid_for(ix.total, 256)), dim3(256), 0, ctx->stream, sv, k_prev, d_ab.p, prev->lookup->view());
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return prev->lookup->check_overflow(ctx);
+}
+
+static int prev_view(mdbg_ctx *ctx, const mdbg_table *prev, TableView &pv) {
+    if (!prev) return set_error(ctx, MDBG_EINVAL, "previous table is null");
+    MDBG_TRY(ensure_lookup(ctx, const_cast<mdbg_table *>(prev), true));
+    pv = prev->lookup->view();
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
+                                          uint32_t k, const mdbg_table *prev, mdbg_table **out) {
+    if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_refined: bad argument");
+    MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_count_refined"));
+    if (unitigs) MDBG_TRY(check_seq(ctx, unitigs, "mdbg_kminmer_count_refined"));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TableView pv;
+    MDBG_TRY(prev_view(ctx, prev, pv));
+    InstIndex ia, ib;
+    MDBG_TRY(build_inst_index(ctx, reads, k, ia));
+    if (unitigs) MDBG_TRY(build_inst_index(ctx, unitigs, k, ib));
+    SeqView a = make_view(reads, ia), b = unitigs ? make_view(unitigs, ib) : SeqView{};
+    const uint64_t I = ia.total + ib.total;
+    if (I >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 k-min-mer instances in one call");
+    DeviceTable tab;
+    MDBG_TRY(tab.init(ctx, I + I / 2 + 1024, true));
+    TableView tv = tab.view();
+    {
+        LaunchTimer timer(ctx, "kminmer_insert");
+        if (a.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(grid_for(a.n_inst, 256)), dim3(256), 0, ctx->stream, a, k, tv, (uint64_t)0);
+        if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(grid_for(b.n_inst, 256)), dim3(256), 0, ctx->stream, b, k, tv, a.n_inst);
+    }
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
+    MDBG_TRY(tab.check_overflow(ctx));
+    const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
+    DevBuf<uint32_t> sflag;
+    DevBuf<uint64_t> spos;
+    MDBG_TRY(sflag.alloc(ctx, nslots));
+    MDBG_TRY(spos.alloc(ctx, nslots + 1));
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(refine_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, a, b, k, pv);
+        hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 1, sflag.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
+    uint64_t n_rows = 0;
+    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    mdbg_table *t = new mdbg_table();
+    t->k = k;
+    t->n_solid = n_rows;
+    int rc = alloc_rows(ctx, t, n_rows, true);
+    if (rc) { delete t; return rc; }
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, sflag.p, spos.p, a, b, ro, (uint64_t)0);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_count_refined failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return MDBG_OK;
+}
+
+static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, const TableView &pv, const TableView &tv) {
+    InstIndex ik, ikm1;
+    MDBG_TRY(build_inst_index(ctx, s, k, ik));
+    if (!ik.total) return MDBG_OK;
+    MDBG_TRY(build_inst_index(ctx, s, k - 1, ikm1));
+    DevBuf<uint32_t> prev_ab;
+    MDBG_TRY(prev_ab.alloc(ctx, ikm1.total));
+    SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
+    {
+        LaunchTimer timer(ctx, "kminmer_prev_lookup");
+        hipLaunchKernelGGL(prev_abundance_kernel, dim3(grid_for(ikm1.total, 256)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+    }
+    {
+        LaunchTimer timer(ctx, "kminmer_insert");
+        hipLaunchKernelGGL(index_insert_kernel, dim3(grid_for(ik.total, 256)), dim3(256), 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
+                                  uint32_t k, const mdbg_table *prev, mdbg_table **out) {
+    if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_index: bad argument");
+    MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_index"));
+    if (unitigs) MDBG_TRY(check_seq(ctx, unitigs, "mdbg_kminmer_index"));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TableView pv;
+    MDBG_TRY(prev_view(ctx, prev, pv));
+    // upper bound on distinct keys: total k-windows
+    uint64_t bound = reads->n_min + (unitigs ? unitigs->n_min : 0);
+    DeviceTable tab;
+    MDBG_TRY(tab.init(ctx, bound + bound / 2 + 1024, false));
+    TableView tv = tab.view();
+    MDBG_TRY(index_one_set(ctx, reads, k, pv, tv));
+    if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, tv));
+    MDBG_TRY(tab.check_overflow(ctx));
+    const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
+    DevBuf<uint32_t> sflag;
+    DevBuf<uint64_t> spos;
+    MDBG_TRY(sflag.alloc(ctx, nslots));
+    MDBG_TRY(spos.alloc(ctx, nslots + 1));
+    hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 2, sflag.p);
+    MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
+    uint64_t n_rows = 0;
+    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    mdbg_table *t = new mdbg_table();
+    t->k = k;
+    t->n_solid = n_rows;
+    int rc = alloc_rows(ctx, t, n_rows, false);
+    if (rc) { delete t; return rc; }
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, nullptr, k};
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, sflag.p, spos.p, SeqView{}, SeqView{}, ro, (uint64_t)0);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_index failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_records, uint64_t *n_solid, int *has_vectors) {
+    if (!t) return MDBG_EINVAL;
+    if (k) *k = t->k;
+    if (n_records) *n_records = t->n_records;
+    if (n_solid) *n_solid = t->n_solid;
+    if (has_vectors) *has_vectors = t->has_vectors ? 1 : 0;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors) {
+    if (!ctx || !t) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (records20 && t->n_records) {
+        DevBuf<uint8_t> d_rec;
+        MDBG_TRY(d_rec.alloc(ctx, t->n_records * 20));
+        hipLaunchKernelGGL(pack_records_kernel, dim3(grid_for(t->n_records, 256)), dim3(256), 0, ctx->stream,
+                           t->d_lo.p, t->d_hi.p, t->d_ab.p, t->n_records, d_rec.p);
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(records20, d_rec.p, t->n_records * 20, hipMemcpyDeviceToHost, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (vectors) {
+        if (!t->has_vectors) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host: table has no vectors (k >= firstK+2)");
+        if (t->n_records) MDBG_HIP_CHECK(ctx, hipMemcpy(vectors, t->d_vec.p, t->n_records * t->k * 4, hipMemcpyDeviceToHost));
+    }
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
+                                 uint64_t n, uint32_t *abundance) {
+    if (!ctx || !t || (n && (!hash_lo || !hash_hi || !abundance))) return set_error(ctx, MDBG_EINVAL, "mdbg_table_lookup: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_TRY(ensure_lookup(ctx, const_cast<mdbg_table *>(t), false));
+    if (!n) return MDBG_OK;
+    DevBuf<uint64_t> dl, dh;
+    DevBuf<uint32_t> dv;
+    MDBG_TRY(dl.alloc(ctx, n));
+    MDBG_TRY(dh.alloc(ctx, n));
+    MDBG_TRY(dv.alloc(ctx, n));
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(dl.p, hash_lo, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(dh.p, hash_hi, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(lookup_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, t->lookup->view(), dl.p, dh.p, n, dv.p);
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(abundance, dv.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+extern "C" void mdbg_table_free(mdbg_table *t) { delete t; }

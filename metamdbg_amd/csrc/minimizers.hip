@@ -1,0 +1,238 @@
+// minimizers.hip -- minimizer-space sequence sets: host <-> device, palindrome purging
+// (Commons::purgePalindrome, Commons.hpp:1617-1723) and the repetitive-minimizer census
+// (ReadSelection::determineRepetitiveMinimizers, readSelection/ReadSelection.hpp:497-625).
+#include "common.hpp"
+#include "objects.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace mdbg {
+
+// KmerVec::isPalindrome (Commons.hpp:918-921) on a[i..i+k)
+__device__ __forceinline__ bool window_is_palindrome(const uint32_t *a, uint32_t k) {
+    for (uint32_t t = 0; t < k / 2; t++)
+        if (a[t] != a[k - 1 - t]) return false;
+    return true;
+}
+
+// One lane per read.  A palindromic window of length k >= 2 needs m[c]==m[c+1] (even k) or
+// m[c-1]==m[c+1] (odd k) at its centre, so reads without such a pair are untouched (the common
+// case).  Otherwise replay the reference: smallest k, then smallest i whose window of k surviving
+// minimizers is a palindrome -> drop its first element -> restart, until none is left.  Dropping
+// from a compacted copy is equivalent to the reference's banned-position bookkeeping.
+__global__ __launch_bounds__(256) void purge_kernel(const uint64_t *off, uint32_t n_reads, uint32_t *work /* copy of mins */,
+                                                    uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    uint32_t *a = work + off[r];
+    uint32_t n = (uint32_t)(off[r + 1] - off[r]);
+    bool suspect = false;
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        uint32_t x = a[i];
+        if (x == a[i + 1] || (i + 2 < n && x == a[i + 2])) { suspect = true; break; }
+    }
+    if (suspect) {
+        for (;;) {
+            bool hit = false;
+            for (uint32_t k = first_k; k < last_k && k <= n && !hit; k++) {
+                for (uint32_t i = 0; i + k <= n; i++) {
+                    if (window_is_palindrome(a + i, k)) {
+                        for (uint32_t j = i; j + 1 < n; j++) a[j] = a[j + 1];
+                        n--;
+                        hit = true;
+                        break;
+                    }
+                }
+            }
+            if (!hit) break;
+        }
+    }
+    new_count[r] = n;
+}
+
+__global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *src_off, const uint64_t *dst_off, uint32_t n_reads,
+                                                            const uint32_t *src, uint32_t *dst) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        uint64_t s = src_off[r], d = dst_off[r];
+        uint32_t n = (uint32_t)(dst_off[r + 1] - d);
+        for (uint32_t i = lane; i < n; i += 64) dst[d + i] = src[s + i];
+    }
+}
+
+// ---- u32 value census (open addressing, value+1 as key so 0 marks empty) ----
+__global__ __launch_bounds__(256) void census_insert_kernel(const uint32_t *vals, uint64_t n, unsigned long long *keys,
+                                                            uint32_t *counts, uint64_t mask) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = (unsigned long long)vals[i] + 1ull;
+    uint64_t s = (key * 0x9E3779B97F4A7C15ull >> 20) & mask;
+    for (;;) {
+        unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0ull) {
+            cur = atomicCAS(&keys[s], 0ull, key);
+            if (cur == 0ull) cur = key;
+        }
+        if (cur == key) { atomicAdd(&counts[s], 1u); return; }
+        s = (s + 1) & mask;
+    }
+}
+
+__global__ void census_flag_kernel(const unsigned long long *keys, uint64_t cap, uint32_t *flag) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < cap) flag[s] = keys[s] != 0ull ? 1u : 0u;
+}
+
+__global__ void census_emit_kernel(const unsigned long long *keys, const uint32_t *counts, uint64_t cap, const uint32_t *flag,
+                                   const uint64_t *pos, uint32_t *out_val, uint32_t *out_cnt) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < cap && flag[s]) { out_val[pos[s]] = (uint32_t)(keys[s] - 1ull); out_cnt[pos[s]] = counts[s]; }
+}
+
+}  // namespace mdbg
+
+using namespace mdbg;
+
+extern "C" int mdbg_minimizers_info(const mdbg_minimizers *m, uint32_t *n_reads, uint64_t *n_minimizers) {
+    if (!m) return MDBG_EINVAL;
+    if (n_reads) *n_reads = m->n_reads;
+    if (n_minimizers) *n_minimizers = m->n_min;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, uint64_t *offsets,
+                                       uint32_t *minimizers, uint32_t *positions, uint8_t *directions, uint8_t *qualities,
+                                       uint32_t *read_lengths, float *mean_quality, uint8_t *read_flags) {
+    if (!ctx || !m) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_to_host: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n = m->n_reads, t = m->n_min;
+    if (offsets) MDBG_HIP_CHECK(ctx, hipMemcpy(offsets, m->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    if (minimizers && t) MDBG_HIP_CHECK(ctx, hipMemcpy(minimizers, m->d_min.p, t * 4, hipMemcpyDeviceToHost));
+    if ((positions || directions || qualities || read_lengths || mean_quality || read_flags) && !m->from_scan)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_to_host: positions/directions/qualities exist only for mdbg_scan output");
+    if (positions && t) MDBG_HIP_CHECK(ctx, hipMemcpy(positions, m->d_pos.p, t * 4, hipMemcpyDeviceToHost));
+    if (directions && t) MDBG_HIP_CHECK(ctx, hipMemcpy(directions, m->d_dir.p, t, hipMemcpyDeviceToHost));
+    if (qualities && t) MDBG_HIP_CHECK(ctx, hipMemcpy(qualities, m->d_mqual.p, t, hipMemcpyDeviceToHost));
+    if (read_lengths && n) MDBG_HIP_CHECK(ctx, hipMemcpy(read_lengths, m->d_len.p, n * 4, hipMemcpyDeviceToHost));
+    if (read_flags && n) MDBG_HIP_CHECK(ctx, hipMemcpy(read_flags, m->d_flags.p, n, hipMemcpyDeviceToHost));
+    if (mean_quality && n) memcpy(mean_quality, m->h_mean_quality.data(), n * sizeof(float));
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimizers, const uint64_t *offsets,
+                                         uint32_t n_reads, mdbg_minimizers **out) {
+    if (!ctx || !out || !offsets) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_host: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mdbg_minimizers *m = new mdbg_minimizers();
+    auto fail = [&](int rc) { delete m; return rc; };
+    m->n_reads = n_reads;
+    std::vector<uint64_t> rel((size_t)n_reads + 1);
+    for (size_t i = 0; i <= n_reads; i++) {
+        if (i && offsets[i] < offsets[i - 1]) return fail(set_error(ctx, MDBG_EINVAL, "offsets must be non-decreasing"));
+        rel[i] = offsets[i] - offsets[0];
+    }
+    m->n_min = rel[n_reads];
+    if (m->n_min && !minimizers) return fail(set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_host: null minimizers"));
+    int rc;
+    if ((rc = m->d_off.alloc(ctx, rel.size())) || (rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
+    hipError_t e = hipMemcpy(m->d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m->n_min) e = hipMemcpy(m->d_min.p, minimizers + offsets[0], m->n_min * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "upload failed: %s", hipGetErrorString(e)));
+    *out = m;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers) {
+    if (!m) return MDBG_EINVAL;
+    if (d_offsets) *d_offsets = m->d_off.p;
+    if (d_minimizers) *d_minimizers = m->d_min.p;
+    return MDBG_OK;
+}
+
+extern "C" void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
+
+extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t first_k, uint32_t last_k,
+                                      mdbg_minimizers **out) {
+    if (!ctx || !in || !out || first_k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_purge_palindromes: bad argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = in->n_reads;
+    DevBuf<uint32_t> work, cnt;
+    MDBG_TRY(work.alloc(ctx, in->n_min));
+    MDBG_TRY(cnt.alloc(ctx, n));
+    if (in->n_min) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(work.p, in->d_min.p, in->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    mdbg_minimizers *m = new mdbg_minimizers();
+    auto fail = [&](int rc) { delete m; return rc; };
+    m->n_reads = n;
+    int rc;
+    if ((rc = m->d_off.alloc(ctx, (size_t)n + 1))) return fail(rc);
+    if (n) {
+        LaunchTimer timer(ctx, "purge_palindromes");
+        hipLaunchKernelGGL(purge_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in->d_off.p, n, work.p, first_k, last_k, cnt.p);
+    }
+    if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
+    hipError_t e = hipMemcpy(&m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
+    if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
+    if (n) {
+        unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 16u);
+        LaunchTimer timer(ctx, "purge_palindromes");
+        hipLaunchKernelGGL(gather_prefix_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, m->d_off.p, n, work.p, m->d_min.p);
+    }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
+    *out = m;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out) {
+    if (!ctx || !m || !out || !n_out) return set_error(ctx, MDBG_EINVAL, "mdbg_repetitive_minimizers: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = m->n_min;
+    uint64_t cap = 1024;
+    while (cap < n * 2) cap <<= 1;
+    DevBuf<unsigned long long> keys;
+    DevBuf<uint32_t> counts, flag, oval, ocnt;
+    DevBuf<uint64_t> pos;
+    MDBG_TRY(keys.alloc(ctx, cap));
+    MDBG_TRY(counts.alloc(ctx, cap));
+    MDBG_TRY(flag.alloc(ctx, cap));
+    MDBG_TRY(pos.alloc(ctx, cap + 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(keys.p, 0, cap * 8, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, cap * 4, ctx->stream));
+    if (n) {
+        LaunchTimer timer(ctx, "minimizer_census");
+        hipLaunchKernelGGL(census_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, keys.p, counts.p, cap - 1);
+    }
+    hipLaunchKernelGGL(census_flag_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, ctx->stream, keys.p, cap, flag.p);
+    MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, cap));
+    uint64_t distinct = 0;
+    MDBG_HIP_CHECK(ctx, hipMemcpy(&distinct, pos.p + cap, 8, hipMemcpyDeviceToHost));
+    MDBG_TRY(oval.alloc(ctx, distinct));
+    MDBG_TRY(ocnt.alloc(ctx, distinct));
+    hipLaunchKernelGGL(census_emit_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, flag.p, pos.p, oval.p, ocnt.p);
+    std::vector<uint32_t> hv(distinct), hc(distinct);
+    if (distinct) {
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hv.data(), oval.p, distinct * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), ocnt.p, distinct * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // top-N selection on the host (O(distinct), ReadSelection.hpp:515-540)
+    float fraction = 0.00001f;
+    int keep = (int)(fraction * (float)distinct);
+    if (keep < 1) keep = 1;
+    if ((uint64_t)keep > distinct) keep = (int)distinct;
+    std::vector<uint64_t> order(distinct);
+    for (uint64_t i = 0; i < distinct; i++) order[i] = i;
+    std::partial_sort(order.begin(), order.begin() + keep, order.end(), [&](uint64_t a, uint64_t b) {
+        if (hc[a] != hc[b]) return hc[a] > hc[b];
+        return hv[a] < hv[b];
+    });
+    if ((uint32_t)keep > *n_out) return set_error(ctx, MDBG_ERANGE, "mdbg_repetitive_minimizers: need room for %d values", keep);
+    for (int i = 0; i < keep; i++) out[i] = hv[order[i]];
+    *n_out = (uint32_t)keep;
+    return MDBG_OK;
+}

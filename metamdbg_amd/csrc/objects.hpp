@@ -1,0 +1,55 @@
+// objects.hpp -- the opaque handles of mdbg_hip.h: device-resident reads, minimizer CSR, tables.
+#pragma once
+#include "common.hpp"
+#include "table.hpp"
+
+#include <memory>
+
+// Base-space reads in HBM.  Layout (DESIGN.md "data layout"):
+//   d_words      u64[n_words]   32 bases per word, base i at bits [2i, 2i+2), code (c>>1)&3
+//   d_word_off   u64[n+1]       read r occupies words [off[r], off[r+1]); off[r] is even (16-byte aligned reads)
+//   d_len        u32[n]         original length in bases
+//   d_invalid    u32[n_words]   optional, bit i = base i of the word had bit 3 set (N/n); NULL when no read has any
+//   d_qual       u8[..]         optional phred+33 bytes, read r at [qual_off[r], qual_off[r+1])
+struct mdbg_reads {
+    uint32_t n_reads = 0;
+    uint64_t n_bases = 0;
+    uint64_t n_words = 0;
+    uint32_t max_len = 0;
+    mdbg::DevBuf<uint64_t> d_words;
+    mdbg::DevBuf<uint64_t> d_word_off;
+    mdbg::DevBuf<uint32_t> d_len;
+    mdbg::DevBuf<uint32_t> d_invalid;
+    mdbg::DevBuf<uint8_t> d_qual;
+    mdbg::DevBuf<uint64_t> d_qual_off;
+    bool has_invalid = false;
+    bool has_qual = false;
+};
+
+// Minimizer-space sequences in HBM as CSR.  Per-minimizer side arrays exist only for scan output.
+struct mdbg_minimizers {
+    uint32_t n_reads = 0;
+    uint64_t n_min = 0;
+    mdbg::DevBuf<uint64_t> d_off;     // n_reads + 1
+    mdbg::DevBuf<uint32_t> d_min;     // n_min
+    mdbg::DevBuf<uint32_t> d_pos;     // n_min (scan output only)
+    mdbg::DevBuf<uint8_t> d_dir;      // n_min (scan output only)
+    mdbg::DevBuf<uint8_t> d_mqual;    // n_min (scan output only)
+    mdbg::DevBuf<uint32_t> d_len;     // n_reads: original read length (scan output only)
+    mdbg::DevBuf<uint8_t> d_flags;    // n_reads: MDBG_READ_* (scan output only)
+    std::vector<float> h_mean_quality;  // n_reads, finished on the host from per-read quality histograms
+    bool from_scan = false;
+};
+
+// k-min-mer table: output rows (file order) + an open-addressing lookup over the same keys.
+struct mdbg_table {
+    uint32_t k = 0;
+    uint64_t n_records = 0;
+    uint64_t n_solid = 0;
+    bool has_vectors = false;
+    mdbg::DevBuf<uint64_t> d_lo, d_hi;   // n_records
+    mdbg::DevBuf<uint32_t> d_ab;         // n_records
+    mdbg::DevBuf<uint32_t> d_vec;        // n_records * k (when has_vectors)
+    // key -> abundance lookup (always present for prev tables; built on demand for output tables)
+    std::unique_ptr<mdbg::DeviceTable> lookup;
+};

@@ -1,0 +1,299 @@
+// reads.hip -- base-space read batches in HBM: ASCII -> 2-bit packing on the device, host-packed
+// upload, and the seeded synthetic generator (twin of metamdbg_amd/synth.py) that builds
+// benchmark inputs directly in HBM.
+#include "common.hpp"
+#include "objects.hpp"
+
+#include <vector>
+
+namespace mdbg {
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// one wave per read, lanes stride over its words; each lane packs 32 ASCII bases into a u64
+__global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, const uint64_t *base_off,
+                                                         const uint64_t *word_off, uint32_t n_reads,
+                                                         uint64_t *words, uint32_t *invalid, uint32_t *any_invalid) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t seen = 0;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint8_t *src = bases + base_off[r];
+        const uint64_t L = base_off[r + 1] - base_off[r];
+        const uint64_t w0 = word_off[r], nw = word_off[r + 1] - w0;
+        for (uint64_t w = lane; w < nw; w += 64) {
+            uint64_t x = 0;
+            uint32_t inv = 0;
+            uint64_t b0 = w * 32;
+#pragma unroll 8
+            for (int i = 0; i < 32; i++) {
+                uint64_t bi = b0 + i;
+                if (bi < L) {
+                    uint8_t c = src[bi];
+                    x |= (uint64_t)((c >> 1) & 3u) << (2 * i);    // utils/kmer/Kmer.hpp:462
+                    inv |= (uint32_t)((c >> 3) & 1u) << i;
+                }
+            }
+            words[w0 + w] = x;
+            invalid[w0 + w] = inv;
+            seen |= inv;
+        }
+    }
+    if (seen) atomicOr(any_invalid, 1u);
+}
+
+struct SynthArgs {
+    uint64_t seed;
+    uint32_t n_reads, read_len;
+    uint64_t first_read;
+    const uint64_t *species_len;      // n_species
+    const uint64_t *species_off;      // n_species + 1
+    const uint64_t *species_thr;      // n_species
+    uint32_t n_species;
+    uint64_t sub_thr;
+    uint32_t words_per_read;
+    uint64_t *words;
+    uint8_t *qual;                    // nullptr or n_reads * read_len
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)a.n_reads * a.words_per_read;
+    if (gid >= total) return;
+    const uint32_t rl = (uint32_t)(gid / a.words_per_read);
+    const uint32_t w = (uint32_t)(gid % a.words_per_read);
+    const uint64_t r = a.first_read + rl;
+    const uint32_t L = a.read_len;
+    // layout (synth.read_layout)
+    const uint64_t base = mix64(a.seed ^ 0xA5A5A5A5A5A5A5A5ull);
+    const uint64_t u_species = mix64(base + 4 * r), u_start = mix64(base + 4 * r + 1), u_strand = mix64(base + 4 * r + 2);
+    uint32_t sp = 0;
+    while (sp + 1 < a.n_species && !(u_species < a.species_thr[sp])) sp++;
+    const uint64_t span = a.species_len[sp] - L + 1;
+    const uint64_t start = a.species_off[sp] + (u_start % span);
+    const unsigned strand = (unsigned)(u_strand & 1ull);
+    const uint64_t gkey = mix64(a.seed);
+    const uint64_t ekey = mix64(mix64(a.seed ^ 0x5EED5EED5EED5EEDull) + r);
+    const uint64_t qkey = mix64(mix64(a.seed ^ 0x0123456789ABCDEFull) + r);
+    uint64_t x = 0;
+    for (int i = 0; i < 32; i++) {
+        uint32_t bi = w * 32 + i;
+        if (bi >= L) break;
+        uint64_t gpos = strand ? (start + (L - 1) - bi) : (start + bi);
+        unsigned code = (unsigned)(mix64(gkey + gpos) >> 62);
+        if (strand) code ^= 2u;
+        uint64_t e = mix64(ekey + bi);
+        if (e < a.sub_thr) code = (code + 1u + (unsigned)(mix64(e) % 3ull)) & 3u;
+        x |= (uint64_t)code << (2 * i);
+        if (a.qual) a.qual[(uint64_t)rl * L + bi] = (uint8_t)(mix64(qkey + bi) % 30ull + 43ull);
+    }
+    a.words[gid] = x;
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void iota_scaled_u64_kernel(uint64_t *p, uint64_t n, uint64_t scale) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i * scale;
+}
+
+}  // namespace mdbg
+
+using namespace mdbg;
+
+static inline uint64_t words_for(uint64_t len) { return ((len + 63) / 64) * 2; }  // reads start on 16-byte units
+
+extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, const uint64_t *offsets,
+                                     uint32_t n_reads, mdbg_reads **out) {
+    if (!ctx || !out || (n_reads && (!bases || !offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_from_ascii: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mdbg_reads *r = new mdbg_reads();
+    auto fail = [&](int rc) { delete r; return rc; };
+    r->n_reads = n_reads;
+    std::vector<uint64_t> woff((size_t)n_reads + 1, 0);
+    std::vector<uint32_t> lens(n_reads);
+    uint64_t nb = n_reads ? offsets[n_reads] - offsets[0] : 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        if (L > 0xFFFFFFF0ull) return fail(set_error(ctx, MDBG_ERANGE, "read %u longer than 2^32 bases", i));
+        lens[i] = (uint32_t)L;
+        if (lens[i] > r->max_len) r->max_len = lens[i];
+        woff[i + 1] = woff[i] + words_for(L);
+    }
+    r->n_bases = nb;
+    r->n_words = woff[n_reads];
+    int rc;
+    DevBuf<uint8_t> d_ascii;
+    DevBuf<uint64_t> d_boff;
+    DevBuf<uint32_t> d_any;
+    if ((rc = r->d_words.alloc(ctx, r->n_words)) || (rc = r->d_invalid.alloc(ctx, r->n_words)) ||
+        (rc = r->d_word_off.alloc(ctx, (size_t)n_reads + 1)) || (rc = r->d_len.alloc(ctx, n_reads)) ||
+        (rc = d_ascii.alloc(ctx, nb)) || (rc = d_boff.alloc(ctx, (size_t)n_reads + 1)) || (rc = d_any.alloc(ctx, 1)))
+        return fail(rc);
+    std::vector<uint64_t> rel((size_t)n_reads + 1, 0);
+    for (uint32_t i = 0; i <= n_reads && n_reads; i++) rel[i] = offsets[i] - offsets[0];
+    hipError_t e;
+#define CK(x) if ((e = (x)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "%s: %s", #x, hipGetErrorString(e)))
+    CK(hipMemcpyAsync(r->d_word_off.p, woff.data(), woff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_boff.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_reads) CK(hipMemcpyAsync(r->d_len.p, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nb) CK(hipMemcpyAsync(d_ascii.p, bases + offsets[0], nb, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(d_any.p, 0, 4, ctx->stream));
+    if (n_reads) {
+        unsigned blocks = grid_for((uint64_t)n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
+        LaunchTimer timer(ctx, "pack_ascii");
+        hipLaunchKernelGGL(pack_ascii_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_ascii.p, d_boff.p,
+                           r->d_word_off.p, n_reads, r->d_words.p, r->d_invalid.p, d_any.p);
+    }
+    uint32_t any = 0;
+    CK(hipMemcpyAsync(&any, d_any.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (quals && nb) {
+        if ((rc = r->d_qual.alloc(ctx, nb)) || (rc = r->d_qual_off.alloc(ctx, (size_t)n_reads + 1))) return fail(rc);
+        CK(hipMemcpyAsync(r->d_qual.p, quals + offsets[0], nb, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemcpyAsync(r->d_qual_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        r->has_qual = true;
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+#undef CK
+    r->has_invalid = any != 0;
+    if (!r->has_invalid) r->d_invalid.release();
+    *out = r;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
+                                      const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out) {
+    if (!ctx || !out || (n_reads && (!words || !word_offsets || !lengths)))
+        return set_error(ctx, MDBG_EINVAL, "mdbg_reads_from_packed: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mdbg_reads *r = new mdbg_reads();
+    auto fail = [&](int rc) { delete r; return rc; };
+    r->n_reads = n_reads;
+    uint64_t base = n_reads ? word_offsets[0] : 0;
+    r->n_words = n_reads ? word_offsets[n_reads] - base : 0;
+    std::vector<uint64_t> rel((size_t)n_reads + 1, 0);
+    for (uint32_t i = 0; i < n_reads; i++) {
+        rel[i] = word_offsets[i] - base;
+        uint64_t nw = word_offsets[i + 1] - word_offsets[i];
+        if ((rel[i] & 1) || nw * 32 < lengths[i])
+            return fail(set_error(ctx, MDBG_EINVAL, "read %u: word offset must be even and cover the read", i));
+        r->n_bases += lengths[i];
+        if (lengths[i] > r->max_len) r->max_len = lengths[i];
+    }
+    rel[n_reads] = r->n_words;
+    int rc;
+    if ((rc = r->d_words.alloc(ctx, r->n_words + 2)) || (rc = r->d_word_off.alloc(ctx, (size_t)n_reads + 1)) ||
+        (rc = r->d_len.alloc(ctx, n_reads)))
+        return fail(rc);
+    hipError_t e;
+#define CK(x) if ((e = (x)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "%s: %s", #x, hipGetErrorString(e)))
+    if (r->n_words) CK(hipMemcpyAsync(r->d_words.p, words + base, r->n_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(r->d_word_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_reads) CK(hipMemcpyAsync(r->d_len.p, lengths, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+#undef CK
+    *out = r;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,
+                                    uint64_t first_read, const uint64_t *species_len,
+                                    const uint64_t *species_threshold, uint32_t n_species,
+                                    uint64_t sub_threshold, int with_quality, mdbg_reads **out) {
+    if (!ctx || !out || !species_len || !species_threshold || !n_species || !read_len)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_reads_synthetic: bad argument");
+    for (uint32_t s = 0; s < n_species; s++)
+        if (species_len[s] < read_len) return set_error(ctx, MDBG_EINVAL, "species %u shorter than a read", s);
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mdbg_reads *r = new mdbg_reads();
+    auto fail = [&](int rc) { delete r; return rc; };
+    const uint32_t wpr = (uint32_t)words_for(read_len);
+    r->n_reads = n_reads;
+    r->n_bases = (uint64_t)n_reads * read_len;
+    r->n_words = (uint64_t)n_reads * wpr;
+    r->max_len = read_len;
+    std::vector<uint64_t> soff((size_t)n_species + 1, 0);
+    for (uint32_t s = 0; s < n_species; s++) soff[s + 1] = soff[s] + species_len[s];
+    DevBuf<uint64_t> d_slen, d_soff, d_sthr;
+    int rc;
+    if ((rc = r->d_words.alloc(ctx, r->n_words + 2)) || (rc = r->d_word_off.alloc(ctx, (size_t)n_reads + 1)) ||
+        (rc = r->d_len.alloc(ctx, n_reads)) || (rc = d_slen.alloc(ctx, n_species)) ||
+        (rc = d_soff.alloc(ctx, (size_t)n_species + 1)) || (rc = d_sthr.alloc(ctx, n_species)))
+        return fail(rc);
+    if (with_quality) {
+        if ((rc = r->d_qual.alloc(ctx, r->n_bases)) || (rc = r->d_qual_off.alloc(ctx, (size_t)n_reads + 1))) return fail(rc);
+        r->has_qual = true;
+    }
+    hipError_t e;
+#define CK(x) if ((e = (x)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "%s: %s", #x, hipGetErrorString(e)))
+    CK(hipMemcpyAsync(d_slen.p, species_len, (size_t)n_species * 8, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_soff.p, soff.data(), soff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_sthr.p, species_threshold, (size_t)n_species * 8, hipMemcpyHostToDevice, ctx->stream));
+    SynthArgs a{seed, n_reads, read_len, first_read, d_slen.p, d_soff.p, d_sthr.p, n_species, sub_threshold, wpr,
+                r->d_words.p, with_quality ? r->d_qual.p : nullptr};
+    uint64_t total = (uint64_t)n_reads * wpr;
+    if (total) {
+        hipLaunchKernelGGL(synth_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, r->d_len.p, (uint64_t)n_reads, read_len);
+    }
+    hipLaunchKernelGGL(iota_scaled_u64_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream,
+                       r->d_word_off.p, (uint64_t)n_reads + 1, (uint64_t)wpr);
+    if (with_quality)
+        hipLaunchKernelGGL(iota_scaled_u64_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream,
+                           r->d_qual_off.p, (uint64_t)n_reads + 1, (uint64_t)read_len);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
+#undef CK
+    *out = r;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t *n_bases, uint64_t *n_words) {
+    if (!r) return MDBG_EINVAL;
+    if (n_reads) *n_reads = r->n_reads;
+    if (n_bases) *n_bases = r->n_bases;
+    if (n_words) *n_words = r->n_words;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length) {
+    if (!ctx || !r || index >= r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_get: bad argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint64_t off[2];
+    uint32_t L;
+    MDBG_HIP_CHECK(ctx, hipMemcpy(off, r->d_word_off.p + index, 16, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, hipMemcpy(&L, r->d_len.p + index, 4, hipMemcpyDeviceToHost));
+    if (length) *length = L;
+    if (bases) {
+        std::vector<uint64_t> w(off[1] - off[0]);
+        std::vector<uint32_t> inv;
+        if (!w.empty()) MDBG_HIP_CHECK(ctx, hipMemcpy(w.data(), r->d_words.p + off[0], w.size() * 8, hipMemcpyDeviceToHost));
+        if (r->has_invalid) {
+            inv.resize(w.size());
+            if (!w.empty()) MDBG_HIP_CHECK(ctx, hipMemcpy(inv.data(), r->d_invalid.p + off[0], inv.size() * 4, hipMemcpyDeviceToHost));
+        }
+        static const char code2ascii[4] = {'A', 'C', 'T', 'G'};
+        for (uint32_t i = 0; i < L; i++) {
+            bases[i] = code2ascii[(w[i / 32] >> (2 * (i % 32))) & 3];
+            if (r->has_invalid && ((inv[i / 32] >> (i % 32)) & 1)) bases[i] = 'N';
+        }
+    }
+    if (quals) {
+        if (!r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_get: batch has no qualities");
+        uint64_t qo[2];
+        MDBG_HIP_CHECK(ctx, hipMemcpy(qo, r->d_qual_off.p + index, 16, hipMemcpyDeviceToHost));
+        if (L) MDBG_HIP_CHECK(ctx, hipMemcpy(quals, r->d_qual.p + qo[0], L, hipMemcpyDeviceToHost));
+    }
+    return MDBG_OK;
+}
+
+extern "C" void mdbg_reads_free(mdbg_reads *r) { delete r; }

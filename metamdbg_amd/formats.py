@@ -126,3 +126,21 @@ def sorted_vector_records(raw: bytes, k: int) -> np.ndarray:
     v = np.frombuffer(raw, "<u4").reshape(-1, k)
     order = np.lexsort(tuple(v[:, c] for c in range(k - 1, -1, -1)))
     return v[order]
+
+
+def build_read_data_init(h: dict) -> bytes:
+    """Serialise mdbg_scan output (capi.Minimizers.to_host(full=True)) as ``read_data_init.txt``
+    (readSelection/ReadSelection.hpp:415-467)."""
+    offs = h["offsets"]
+    parts = []
+    mq = np.asarray(h["mean_quality"], dtype="<f4")
+    for r in range(len(offs) - 1):
+        a, b = int(offs[r]), int(offs[r + 1])
+        parts.append(struct.pack("<IB", b - a, 0))
+        parts.append(np.asarray(h["minimizers"][a:b], "<u4").tobytes())
+        parts.append(np.asarray(h["pos"][a:b], "<u4").tobytes())
+        parts.append(np.asarray(h["dir"][a:b], "u1").tobytes())
+        parts.append(np.asarray(h["qual"][a:b], "u1").tobytes())
+        parts.append(mq[r:r + 1].tobytes())
+        parts.append(struct.pack("<I", int(h["read_length"][r])))
+    return b"".join(parts)

@@ -1,0 +1,174 @@
+"""HIP path vs the CPU oracle and the reference's golden vectors, through the C ABI.
+Run on the GPU box: python -m pytest tests -m gpu"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from metamdbg_amd import formats, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from metamdbg_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _nan_eq(a, b):
+    a = np.asarray(a, np.float32).view(np.uint32)
+    b = np.asarray(b, np.float32).view(np.uint32)
+    return np.array_equal(a, b)
+
+
+def test_device_info(ctx):
+    info = ctx.device_info()
+    assert info["arch"].startswith("gfx950") and info["n_cu"] >= 200
+
+
+def test_synthetic_generator_matches_numpy(ctx):
+    spec = synth.hifi_spec(64, seed=5, read_len=3000, coverage=10.0)
+    reads = ctx.reads_synthetic(spec)
+    codes = synth.read_codes(spec, 0, spec.n_reads)
+    asc = synth.codes_to_ascii(codes)
+    for r in (0, 1, 17, 63):
+        assert reads.get(r) == asc[r].tobytes()
+    spec.with_quality = True
+    reads = ctx.reads_synthetic(spec, first_read=10, n_reads=5)
+    q = synth.read_qualities(spec, 10, 15)
+    b, qq = reads.get(3, with_quality=True)
+    assert b == asc[13].tobytes() and qq == q[3].tobytes()
+
+
+def _check_scan_against_oracle(ctx, orc, seqs, quals, K, density, hpc, repetitive=None):
+    reads = ctx.reads_from_ascii(seqs, quals)
+    m = ctx.scan(reads, K=K, density=density, hpc=hpc, repetitive=repetitive)
+    h = m.to_host()
+    exp = b"".join(orc.read_selection(s, quals[i] if quals else None, K=K, density=density, hpc=hpc,
+                                      repetitive=repetitive)["record"] for i, s in enumerate(seqs))
+    got = formats.build_read_data_init(h)
+    assert got == exp
+    return m, h
+
+
+@pytest.mark.parametrize("hpc", [True, False])
+@pytest.mark.parametrize("K,density", [(15, 0.005), (16, 0.02), (13, 0.05), (11, 0.01)])
+def test_scan_random_reads_vs_oracle(ctx, orc, hpc, K, density):
+    rng = np.random.default_rng(K * 7 + int(hpc))
+    seqs = [bytes(synth.CODE2ASCII[rng.integers(0, 4, int(n))]) for n in
+            list(rng.integers(1, 200, 40)) + list(rng.integers(200, 9000, 40)) + [2048, 2049, 2047, 4096, 4111, 64, 65, 66, 67]]
+    _check_scan_against_oracle(ctx, orc, seqs, None, K, density, hpc)
+
+
+@pytest.mark.parametrize("tag,K,dens,hpc", [("hpc_k15", 15, 0.005, True), ("nohpc_k15", 15, 0.005, False),
+                                            ("hpc_k16", 16, 0.005, True), ("nohpc_k13", 13, 0.02, False)])
+def test_scan_edge_reads_golden(ctx, tag, K, dens, hpc):
+    seqs = [s.upper() for s in H.read_fasta(os.path.join(H.GOLDEN, "edge", "edge.fasta"))]
+    # lower-case read: the reference's HPC compares raw chars; upper-casing is equivalent here because
+    # the read is uniformly lower-case (see DESIGN.md "character handling")
+    rep = np.frombuffer(H.golden_bytes("edge", f"repetitiveMinimizers.{tag}.bin"), "<u4")
+    reads = ctx.reads_from_ascii(seqs)
+    h = ctx.scan(reads, K=K, density=dens, hpc=hpc, repetitive=rep).to_host()
+    assert formats.build_read_data_init(h) == H.golden_bytes("edge", f"read_data_init.{tag}.txt")
+
+
+def test_hifi_200_golden_end_to_end(ctx, orc):
+    m = H.load_manifest("hifi_200")
+    spec = H.spec_from_manifest(m)
+    reads = ctx.reads_synthetic(spec)               # generated in HBM, same reads as the fixture's FASTA
+    seqs, _ = H.regenerate_reads(m)
+    assert reads.get(7) == seqs[7] and reads.get(199) == seqs[199]
+    mins = ctx.scan(reads, K=m["K"], density=m["density"], hpc=m["hpc"])
+    h = mins.to_host()
+    assert formats.build_read_data_init(h) == H.golden_bytes("hifi_200", "read_data_init.txt")
+    st = formats.parse_read_stats(H.golden_bytes("hifi_200", "read_stats.txt"))
+    last_k = orc.lib().orc_compute_last_k(m["density"], st["n50"], 4, 0)
+    corr = ctx.purge_palindromes(mins, 4, last_k)
+    hc = corr.to_host(full=False)
+    assert formats.write_minimizer_reads(hc["minimizers"], hc["offsets"]) == H.golden_bytes("hifi_200", "read_data_corrected.txt")
+    t = ctx.kminmer_count_first(corr, m["k"], m["min_abundance"])
+    rec, vec = t.to_host()
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(rec), exp_ab)
+    exp_v = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    assert np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), m["k"]), exp_v)
+
+
+def test_purge_palindromes_fn_golden(ctx):
+    with open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")) as f:
+        g = json.load(f)["purge"]
+    for key, gg in g.items():
+        fk, lk = map(int, key.split("_"))
+        lists = [[int(x) for x in line.split()] for line in gg["inputs"]]
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+        mins = np.array([x for lst in lists for x in lst], dtype=np.uint32)
+        out = ctx.purge_palindromes(ctx.minimizers_from_host(mins, offs), fk, lk).to_host(full=False)
+        for i, line in enumerate(gg["outputs"]):
+            got = out["minimizers"][int(out["offsets"][i]): int(out["offsets"][i + 1])].tolist()
+            assert got == [int(x) for x in line.split()], (key, i)
+
+
+def _random_minimizer_reads(rng, n_reads, alphabet, lo=0, hi=60):
+    lens = rng.integers(lo, hi, n_reads)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    mins = rng.integers(0, alphabet, int(offs[-1])).astype(np.uint32)
+    return mins, offs
+
+
+def _assert_tables_equal(rec, vec, t, k):
+    from oracle import pyoracle as orc
+    assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(orc.table_abundance_records(t)))
+    if t["vecs"] is not None:
+        assert np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), k),
+                              formats.sorted_vector_records(t["vecs"].astype("<u4").tobytes(), k))
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 7, 8, 12])
+@pytest.mark.parametrize("min_ab", [0, 2, 3])
+def test_count_first_vs_oracle(ctx, orc, k, min_ab):
+    rng = np.random.default_rng(100 + k)
+    mins, offs = _random_minimizer_reads(rng, 400, 6 if k >= 7 else 25)
+    t = ctx.kminmer_count_first(ctx.minimizers_from_host(mins, offs), k, min_ab)
+    rec, vec = t.to_host()
+    exp = orc.kminmer_count_first(mins, offs, k, min_ab)
+    assert t.info()["n_solid"] == exp["n_solid"]
+    _assert_tables_equal(rec, vec, exp, k)
+
+
+@pytest.mark.parametrize("k", [5, 6, 9])
+def test_refined_and_index_vs_oracle(ctx, orc, k):
+    rng = np.random.default_rng(300 + k)
+    mins, offs = _random_minimizer_reads(rng, 300, 5)
+    umins, uoffs = _random_minimizer_reads(rng, 40, 5, lo=0, hi=30)
+    # previous table = first-pass counts at k-1 over the reads (benchmark mode) + a unitig overlay
+    prev_t = orc.kminmer_count_first(mins, offs, k - 1, 0)
+    prev_raw = orc.table_abundance_records(prev_t).tobytes()
+    uab = rng.integers(0, 5, len(uoffs) - 1).astype(np.uint32)
+    oprev = orc.PrevAbundance(prev_raw)
+    oprev.overlay_unitigs([(umins[int(uoffs[i]): int(uoffs[i + 1])], int(uab[i])) for i in range(len(uab)) if uab[i]], k - 1)
+    d_reads = ctx.minimizers_from_host(mins, offs)
+    d_unitigs = ctx.minimizers_from_host(umins, uoffs)
+    dprev = ctx.prev_from_records(prev_raw)
+    ctx.prev_overlay_unitigs(dprev, d_unitigs, uab, k - 1)
+    # lookups agree with the oracle map
+    ohi, olo, oab = oprev.arrays()
+    assert np.array_equal(dprev.lookup(olo, ohi), oab)
+    allm = np.concatenate([mins, umins]); alloff = np.concatenate([offs, offs[-1] + uoffs[1:]])
+    rec, vec = ctx.kminmer_count_refined(d_reads, d_unitigs, k, dprev).to_host()
+    _assert_tables_equal(rec, vec, orc.kminmer_count_refined(allm, alloff, k, oprev), k)
+    rec, vec = ctx.kminmer_index(d_reads, d_unitigs, k, dprev).to_host()
+    assert vec is None
+    _assert_tables_equal(rec, vec, orc.kminmer_index(allm, alloff, k, oprev), k)
