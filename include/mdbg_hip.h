@@ -74,6 +74,11 @@ int  mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32
 int  mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t *n_bases, uint64_t *n_words);
 /* Copy read `index` back as ASCII (buffer of at least its length; quals may be NULL). */
 int  mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length);
+/* Bulk export of reads [first, first+count) as concatenated ASCII: offsets gets count+1 entries
+ * (relative to bases[0]); bases must hold the sum of their lengths (use mdbg_reads_info / a first
+ * call with bases == NULL to size it: *n_bytes is always set). */
+int  mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t first, uint32_t count,
+                             char *bases, uint64_t *offsets, uint64_t *n_bytes);
 void mdbg_reads_free(mdbg_reads *r);
 
 /* ---- reads -> minimizers --------------------------------------------------------------- */
@@ -153,6 +158,10 @@ int  mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, 
 int  mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
                        uint64_t n, uint32_t *abundance);
 void mdbg_table_free(mdbg_table *t);
+
+/* Stream-ordered device-to-device copy on the context stream followed by a synchronize; lets a
+ * harness move library-owned rows into buffers it owns (e.g. torch tensors for RCCL). */
+int  mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 
 /* ---- multi-GPU merge (one process per GPU; the caller moves the bytes, e.g. RCCL all-to-all) ---- */
 /* Rows are mdbg_row_words(k) u64 words each: [hash_lo, hash_hi, count, vec01, vec23, ...] -- the

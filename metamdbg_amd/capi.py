@@ -49,6 +49,8 @@ SIGNATURES = {
                                        C.c_uint64, C.c_int, C.POINTER(_P)]),
     "mdbg_reads_info": (C.c_int, [_P, _u32p, _u64p, _u64p]),
     "mdbg_reads_get": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _u32p]),
+    "mdbg_reads_export_ascii": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _u64p]),
+    "mdbg_memcpy_device": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "mdbg_reads_free": (None, [_P]),
     "mdbg_scan": (C.c_int, [_P, _P, C.POINTER(ScanParams), C.POINTER(_P)]),
     "mdbg_minimizers_info": (C.c_int, [_P, _u32p, _u64p]),
@@ -223,6 +225,9 @@ class Context:
         self.check(lib().mdbg_kminmer_index(self.h, reads.h, unitigs.h if unitigs else None, k, prev.h, C.byref(h)))
         return Table(self, h)
 
+    def memcpy_device(self, dst_ptr: int, src_ptr: int, nbytes: int) -> None:
+        self.check(lib().mdbg_memcpy_device(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
+
     # -- multi-GPU pieces --------------------------------------------------------------------------
     def partial_counts(self, m: "Minimizers", k: int, n_ranks: int) -> tuple[int, np.ndarray]:
         """(device pointer of the owner-grouped rows, rows per owner)."""
@@ -260,6 +265,15 @@ class Reads:
         q = C.create_string_buffer(L.value + 1) if with_quality else None
         self.ctx.check(lib().mdbg_reads_get(self.ctx.h, self.h, index, b, q, C.byref(L)))
         return (b.raw[: L.value], q.raw[: L.value]) if with_quality else b.raw[: L.value]
+
+    def export_ascii(self, first: int, count: int) -> tuple[np.ndarray, np.ndarray]:
+        """(bases u8[], offsets u64[count+1]) of reads [first, first+count)."""
+        nb = C.c_uint64()
+        self.ctx.check(lib().mdbg_reads_export_ascii(self.ctx.h, self.h, first, count, None, None, C.byref(nb)))
+        bases = np.zeros(nb.value, dtype=np.uint8)
+        offs = np.zeros(count + 1, dtype=np.uint64)
+        self.ctx.check(lib().mdbg_reads_export_ascii(self.ctx.h, self.h, first, count, _ptr(bases), _ptr(offs), C.byref(nb)))
+        return bases, offs
 
     def free(self) -> None:
         if self.h:

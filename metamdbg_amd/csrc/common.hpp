@@ -60,6 +60,14 @@ extern std::string g_last_error;  // for failures before a context exists
         if (rc_ != MDBG_OK) return rc_; \
     } while (0)
 
+// Blocking copy ORDERED ON THE CONTEXT STREAM.  The stream is created non-blocking, so the legacy
+// null-stream hipMemcpy would not wait for kernels queued on it.
+inline hipError_t memcpy_sync(mdbg_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(ctx->stream);
+}
+
 // RAII device allocation (synchronous hipMalloc; sizes here are tens of MB to GB, allocated
 // a handful of times per call, never per read).
 template <typename T>

@@ -353,7 +353,7 @@ static int build_inst_index(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t k,
     if (m->n_reads)
         hipLaunchKernelGGL(inst_count_kernel, dim3(grid_for(m->n_reads, 256)), dim3(256), 0, ctx->stream, m->d_off.p, m->n_reads, k, cnt.p);
     MDBG_TRY(exclusive_scan_u32(ctx, cnt.p, ix.off.p, m->n_reads));
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&ix.total, ix.off.p + m->n_reads, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ix.total, ix.off.p + m->n_reads, 8, hipMemcpyDeviceToHost));
     return MDBG_OK;
 }
 
@@ -392,7 +392,7 @@ int mg_rescue_rows(mdbg_ctx *ctx, const mdbg_minimizers *reads, const uint64_t *
             hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, inst_off, reads->n_reads, ab, rflag.p);
         }
         MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, n_inst));
-        MDBG_HIP_CHECK(ctx, hipMemcpy(&n_resc, rpos.p + n_inst, 8, hipMemcpyDeviceToHost));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + n_inst, 8, hipMemcpyDeviceToHost));
     }
     MDBG_TRY(alloc_rows(ctx, t, n_solid + n_resc, true));
     if (n_resc) {
@@ -448,7 +448,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     }
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
     uint64_t n_solid = 0, n_resc = 0;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
 
     // rescue (graph/CreateMdbg.cpp:317-319: only when min_abundance <= 1)
     const bool do_rescue = min_abundance <= 1;
@@ -463,7 +463,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
             hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.off.p, reads->n_reads, ab.p, rflag.p);
         }
         MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, I));
-        MDBG_HIP_CHECK(ctx, hipMemcpy(&n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
     }
 
     mdbg_table *t = new mdbg_table();
@@ -588,7 +588,7 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     }
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
     uint64_t n_rows = 0;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_rows;
@@ -649,7 +649,7 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 2, sflag.p);
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
     uint64_t n_rows = 0;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_rows;
@@ -688,7 +688,7 @@ extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *r
     }
     if (vectors) {
         if (!t->has_vectors) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host: table has no vectors (k >= firstK+2)");
-        if (t->n_records) MDBG_HIP_CHECK(ctx, hipMemcpy(vectors, t->d_vec.p, t->n_records * t->k * 4, hipMemcpyDeviceToHost));
+        if (t->n_records) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, vectors, t->d_vec.p, t->n_records * t->k * 4, hipMemcpyDeviceToHost));
     }
     return MDBG_OK;
 }

@@ -110,15 +110,15 @@ extern "C" int mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, 
     if (!ctx || !m) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_to_host: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = m->n_reads, t = m->n_min;
-    if (offsets) MDBG_HIP_CHECK(ctx, hipMemcpy(offsets, m->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
-    if (minimizers && t) MDBG_HIP_CHECK(ctx, hipMemcpy(minimizers, m->d_min.p, t * 4, hipMemcpyDeviceToHost));
+    if (offsets) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, offsets, m->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    if (minimizers && t) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, minimizers, m->d_min.p, t * 4, hipMemcpyDeviceToHost));
     if ((positions || directions || qualities || read_lengths || mean_quality || read_flags) && !m->from_scan)
         return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_to_host: positions/directions/qualities exist only for mdbg_scan output");
-    if (positions && t) MDBG_HIP_CHECK(ctx, hipMemcpy(positions, m->d_pos.p, t * 4, hipMemcpyDeviceToHost));
-    if (directions && t) MDBG_HIP_CHECK(ctx, hipMemcpy(directions, m->d_dir.p, t, hipMemcpyDeviceToHost));
-    if (qualities && t) MDBG_HIP_CHECK(ctx, hipMemcpy(qualities, m->d_mqual.p, t, hipMemcpyDeviceToHost));
-    if (read_lengths && n) MDBG_HIP_CHECK(ctx, hipMemcpy(read_lengths, m->d_len.p, n * 4, hipMemcpyDeviceToHost));
-    if (read_flags && n) MDBG_HIP_CHECK(ctx, hipMemcpy(read_flags, m->d_flags.p, n, hipMemcpyDeviceToHost));
+    if (positions && t) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, positions, m->d_pos.p, t * 4, hipMemcpyDeviceToHost));
+    if (directions && t) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, directions, m->d_dir.p, t, hipMemcpyDeviceToHost));
+    if (qualities && t) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, qualities, m->d_mqual.p, t, hipMemcpyDeviceToHost));
+    if (read_lengths && n) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, read_lengths, m->d_len.p, n * 4, hipMemcpyDeviceToHost));
+    if (read_flags && n) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, read_flags, m->d_flags.p, n, hipMemcpyDeviceToHost));
     if (mean_quality && n) memcpy(mean_quality, m->h_mean_quality.data(), n * sizeof(float));
     return MDBG_OK;
 }
@@ -139,8 +139,8 @@ extern "C" int mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimize
     if (m->n_min && !minimizers) return fail(set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_host: null minimizers"));
     int rc;
     if ((rc = m->d_off.alloc(ctx, rel.size())) || (rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
-    hipError_t e = hipMemcpy(m->d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && m->n_min) e = hipMemcpy(m->d_min.p, minimizers + offsets[0], m->n_min * 4, hipMemcpyHostToDevice);
+    hipError_t e = memcpy_sync(ctx, m->d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m->n_min) e = memcpy_sync(ctx, m->d_min.p, minimizers + offsets[0], m->n_min * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "upload failed: %s", hipGetErrorString(e)));
     *out = m;
     return MDBG_OK;
@@ -174,7 +174,7 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
         hipLaunchKernelGGL(purge_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in->d_off.p, n, work.p, first_k, last_k, cnt.p);
     }
     if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
-    hipError_t e = hipMemcpy(&m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
+    hipError_t e = memcpy_sync(ctx, &m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
     if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
     if (n) {
@@ -210,7 +210,7 @@ extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *
     hipLaunchKernelGGL(census_flag_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, ctx->stream, keys.p, cap, flag.p);
     MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, cap));
     uint64_t distinct = 0;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&distinct, pos.p + cap, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &distinct, pos.p + cap, 8, hipMemcpyDeviceToHost));
     MDBG_TRY(oval.alloc(ctx, distinct));
     MDBG_TRY(ocnt.alloc(ctx, distinct));
     hipLaunchKernelGGL(census_emit_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, flag.p, pos.p, oval.p, ocnt.p);

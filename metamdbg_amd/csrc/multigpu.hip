@@ -198,7 +198,7 @@ static int mg_inst_index(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t k, De
     if (m->n_reads)
         hipLaunchKernelGGL(mg_inst_count_kernel, dim3(grid_for(m->n_reads, 256)), dim3(256), 0, ctx->stream, m->d_off.p, m->n_reads, k, cnt.p);
     MDBG_TRY(exclusive_scan_u32(ctx, cnt.p, off.p, m->n_reads));
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&total, off.p + m->n_reads, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &total, off.p + m->n_reads, 8, hipMemcpyDeviceToHost));
     return MDBG_OK;
 }
 
@@ -229,11 +229,11 @@ extern "C" int mdbg_kminmer_partial_counts(mdbg_ctx *ctx, const mdbg_minimizers 
     MDBG_HIP_CHECK(ctx, hipMemsetAsync(hist.p, 0, 64 * 8, ctx->stream));
     hipLaunchKernelGGL(owner_hist_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, n_ranks, hist.p);
     unsigned long long h[64];
-    MDBG_HIP_CHECK(ctx, hipMemcpy(h, hist.p, 64 * 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h, hist.p, 64 * 8, hipMemcpyDeviceToHost));
     unsigned long long cur[64];
     uint64_t total = 0;
     for (uint32_t r = 0; r < 64; r++) { cur[r] = total; if (r < n_ranks) { counts[r] = h[r]; total += h[r]; } }
-    MDBG_HIP_CHECK(ctx, hipMemcpy(hist.p, cur, 64 * 8, hipMemcpyHostToDevice));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, hist.p, cur, 64 * 8, hipMemcpyHostToDevice));
     if (ctx->partial_rows) { (void)hipFree(ctx->partial_rows); ctx->partial_rows = nullptr; }
     const uint32_t rw = row_words_for(k);
     hipError_t e = hipMalloc(&ctx->partial_rows, (total ? total : 1) * rw * 8);
@@ -267,7 +267,7 @@ extern "C" int mdbg_reduce_rows(mdbg_ctx *ctx, uint64_t *d_rows, uint64_t n_rows
     hipLaunchKernelGGL(mg_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 0, 0u, 1u, flag.p);
     MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, nslots));
     uint64_t n = 0;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&n, pos.p + nslots, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n, pos.p + nslots, 8, hipMemcpyDeviceToHost));
     MDBG_TRY(tmp.alloc(ctx, n * rw));
     hipLaunchKernelGGL(mg_emit_rows_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, flag.p, pos.p, d_rows, rw, tmp.p);
     if (n) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(d_rows, tmp.p, n * rw * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -300,7 +300,7 @@ extern "C" int mdbg_kminmer_count_first_merged(mdbg_ctx *ctx, const mdbg_minimiz
     hipLaunchKernelGGL(mg_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, min_abundance, 1, rank, n_ranks, flag.p);
     MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, nslots));
     uint64_t n_solid = 0;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&n_solid, pos.p + nslots, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, pos.p + nslots, 8, hipMemcpyDeviceToHost));
 
     // rescue over the local reads against GLOBAL abundances
     DevBuf<uint64_t> inst_off;

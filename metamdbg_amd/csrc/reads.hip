@@ -270,16 +270,16 @@ extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     uint64_t off[2];
     uint32_t L;
-    MDBG_HIP_CHECK(ctx, hipMemcpy(off, r->d_word_off.p + index, 16, hipMemcpyDeviceToHost));
-    MDBG_HIP_CHECK(ctx, hipMemcpy(&L, r->d_len.p + index, 4, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, off, r->d_word_off.p + index, 16, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &L, r->d_len.p + index, 4, hipMemcpyDeviceToHost));
     if (length) *length = L;
     if (bases) {
         std::vector<uint64_t> w(off[1] - off[0]);
         std::vector<uint32_t> inv;
-        if (!w.empty()) MDBG_HIP_CHECK(ctx, hipMemcpy(w.data(), r->d_words.p + off[0], w.size() * 8, hipMemcpyDeviceToHost));
+        if (!w.empty()) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, w.data(), r->d_words.p + off[0], w.size() * 8, hipMemcpyDeviceToHost));
         if (r->has_invalid) {
             inv.resize(w.size());
-            if (!w.empty()) MDBG_HIP_CHECK(ctx, hipMemcpy(inv.data(), r->d_invalid.p + off[0], inv.size() * 4, hipMemcpyDeviceToHost));
+            if (!w.empty()) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, inv.data(), r->d_invalid.p + off[0], inv.size() * 4, hipMemcpyDeviceToHost));
         }
         static const char code2ascii[4] = {'A', 'C', 'T', 'G'};
         for (uint32_t i = 0; i < L; i++) {
@@ -290,9 +290,43 @@ extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index
     if (quals) {
         if (!r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_get: batch has no qualities");
         uint64_t qo[2];
-        MDBG_HIP_CHECK(ctx, hipMemcpy(qo, r->d_qual_off.p + index, 16, hipMemcpyDeviceToHost));
-        if (L) MDBG_HIP_CHECK(ctx, hipMemcpy(quals, r->d_qual.p + qo[0], L, hipMemcpyDeviceToHost));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, qo, r->d_qual_off.p + index, 16, hipMemcpyDeviceToHost));
+        if (L) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, quals, r->d_qual.p + qo[0], L, hipMemcpyDeviceToHost));
     }
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t first, uint32_t count,
+                                       char *bases, uint64_t *offsets, uint64_t *n_bytes) {
+    if (!ctx || !r || (uint64_t)first + count > r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_ascii: bad range");
+    if (r->has_invalid) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_ascii: batch holds N bases; use mdbg_reads_get");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> woff((size_t)count + 1);
+    std::vector<uint32_t> lens(count);
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, woff.data(), r->d_word_off.p + first, woff.size() * 8, hipMemcpyDeviceToHost));
+    if (count) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, lens.data(), r->d_len.p + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < count; i++) total += lens[i];
+    if (n_bytes) *n_bytes = total;
+    if (!bases) return MDBG_OK;
+    std::vector<uint64_t> w(woff[count] - woff[0]);
+    if (!w.empty()) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, w.data(), r->d_words.p + woff[0], w.size() * 8, hipMemcpyDeviceToHost));
+    static const char code2ascii[4] = {'A', 'C', 'T', 'G'};
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        if (offsets) offsets[i] = o;
+        const uint64_t *rw = w.data() + (woff[i] - woff[0]);
+        for (uint32_t b = 0; b < lens[i]; b++) bases[o + b] = code2ascii[(rw[b >> 5] >> (2 * (b & 31))) & 3];
+        o += lens[i];
+    }
+    if (offsets) offsets[count] = o;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return set_error(ctx, MDBG_EINVAL, "mdbg_memcpy_device: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (bytes) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, dst, src, bytes, hipMemcpyDeviceToDevice));
     return MDBG_OK;
 }
 

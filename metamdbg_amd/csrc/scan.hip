@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace mdbg {
 
@@ -190,11 +191,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(ScanArgs a) {
     const uint32_t kmask = (K >= 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
     const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
 
-    for (;;) {
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(a.work_counter, 1u);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= a.n_reads) break;
+    // reads are dealt round-robin to the resident waves (grid-stride); lengths are similar within a
+    // batch, and the grid holds 8 waves per SIMD so a long read only delays its own wave
+    const uint32_t wave_global = (blockIdx.x * SCAN_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * SCAN_BLOCK) >> 6;
+    for (uint32_t slot = wave_global; slot < a.n_reads; slot += n_waves) {
         const uint32_t r = a.subset ? a.subset[slot] : slot;
 
         const uint32_t L = a.len[r];
@@ -421,6 +422,8 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, uint32_t n_items) {
     return MDBG_OK;
 }
 
+#define TRACE(msg) do { if (getenv("MDBG_TRACE")) { fprintf(stderr, "[mdbg_scan] %s\n", msg); fflush(stderr); } } while (0)
+
 extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan_params *p, mdbg_minimizers **out) {
     if (!ctx || !reads || !p || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_scan: null argument");
     if (p->minimizer_size < 2 || p->minimizer_size > 16)
@@ -453,9 +456,11 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
 
     if (n) hipLaunchKernelGGL(capacity_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
                               reads->d_len.p, n, p->density, d_cap.p);
+    TRACE("capacity launched");
     if ((rc = exclusive_scan_u32(ctx, d_cap.p, d_cap_off.p, n))) return fail(rc);
+    TRACE("capacity scanned");
     uint64_t cap_total = 0;
-    e = hipMemcpy(&cap_total, d_cap_off.p + n, 8, hipMemcpyDeviceToHost);
+    e = memcpy_sync(ctx, &cap_total, d_cap_off.p + n, 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "cap total copy failed"));
 
     DevBuf<uint32_t> p_min, p_pos;
@@ -474,7 +479,9 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     a.cap_off = d_cap_off.p;
     a.out_min = p_min.p; a.out_pos = p_pos.p; a.out_dir = p_dir.p;
     a.out_count = d_count.p; a.out_flags = m->d_flags.p;
+    TRACE("launching scan kernel");
     if (n && (rc = launch_scan(ctx, a, p->hpc != 0, n))) return fail(rc);
+    if (getenv("MDBG_TRACE")) { hipError_t se = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mdbg_scan] scan kernel done: %s\n", hipGetErrorString(se)); }
 
     // overflow handling: reads that selected more than their padded capacity are re-run with exact room
     DevBuf<uint32_t> d_list, d_nlist;
@@ -483,13 +490,14 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     if (n) hipLaunchKernelGGL(overflow_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
                               d_count.p, d_cap.p, n, d_list.p, d_nlist.p);
     uint32_t n_over = 0;
-    e = hipMemcpy(&n_over, d_nlist.p, 4, hipMemcpyDeviceToHost);
+    e = memcpy_sync(ctx, &n_over, d_nlist.p, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "overflow count copy failed: %s", hipGetErrorString(e)));
 
+    TRACE("overflow list done");
     // dense offsets from the true counts
     if ((rc = exclusive_scan_u32(ctx, d_count.p, m->d_off.p, n))) return fail(rc);
     uint64_t total = 0;
-    e = hipMemcpy(&total, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
+    e = memcpy_sync(ctx, &total, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "total copy failed"));
     m->n_min = total;
     if ((rc = m->d_min.alloc(ctx, total)) || (rc = m->d_pos.alloc(ctx, total)) || (rc = m->d_dir.alloc(ctx, total)) ||

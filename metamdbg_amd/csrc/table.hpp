@@ -166,7 +166,7 @@ struct DeviceTable {
     }
     int check_overflow(mdbg_ctx *ctx) {
         uint32_t c[4];
-        MDBG_HIP_CHECK(ctx, hipMemcpy(c, ctl.p, 16, hipMemcpyDeviceToHost));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, c, ctl.p, 16, hipMemcpyDeviceToHost));
         if (c[2]) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow (cap %llu)", (unsigned long long)cap);
         return MDBG_OK;
     }

@@ -151,8 +151,24 @@ def test_count_first_vs_oracle(ctx, orc, k, min_ab):
 @pytest.mark.parametrize("k", [5, 6, 9])
 def test_refined_and_index_vs_oracle(ctx, orc, k):
     rng = np.random.default_rng(300 + k)
-    mins, offs = _random_minimizer_reads(rng, 300, 5)
-    umins, uoffs = _random_minimizer_reads(rng, 40, 5, lo=0, hi=30)
+    # a "genome" of distinct minimizers; reads = random substrings in either orientation; unitigs =
+    # disjoint genome segments (as in a compacted graph every k-min-mer belongs to ONE unitig, so the
+    # overlay has no write conflicts -- the reference's own overlay is order-dependent otherwise)
+    genome = rng.permutation(5000).astype(np.uint32)
+    rl = []
+    for _ in range(600):
+        a = int(rng.integers(0, 4900)); n = int(rng.integers(0, 80))
+        seg = genome[a:a + n]
+        if rng.integers(0, 2): seg = seg[::-1]
+        seg = seg.copy()
+        if n and rng.integers(0, 4) == 0: seg[int(rng.integers(0, n))] = 6000 + int(rng.integers(0, 50))   # "errors"
+        rl.append(seg)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in rl])]).astype(np.uint64)
+    mins = np.concatenate(rl).astype(np.uint32)
+    cuts = np.sort(rng.choice(np.arange(1, 5000), 60, replace=False))
+    ul = [genome[a:b] for a, b in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [5000]]))][:50]
+    uoffs = np.concatenate([[0], np.cumsum([len(x) for x in ul])]).astype(np.uint64)
+    umins = np.concatenate(ul).astype(np.uint32)
     # previous table = first-pass counts at k-1 over the reads (benchmark mode) + a unitig overlay
     prev_t = orc.kminmer_count_first(mins, offs, k - 1, 0)
     prev_raw = orc.table_abundance_records(prev_t).tobytes()
