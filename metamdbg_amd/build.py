@@ -27,8 +27,12 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    objdir = os.path.join(HERE, "build")
+def build_lib(force: bool = False, verbose: bool = False, tag: str = "", extra_flags: list[str] | None = None) -> str:
+    """tag/extra_flags build an experimental variant libmdbg_hip_<tag>.so (select it with MDBG_LIB=<path>)."""
+    global LIB
+    lib_path = LIB if not tag else os.path.join(HERE, f"libmdbg_hip_{tag}.so")
+    flags = FLAGS + (extra_flags or [])
+    objdir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
@@ -36,7 +40,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         src = os.path.join(CSRC, s + ".hip")
         obj = os.path.join(objdir, s + ".o")
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([_hipcc()] + flags + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             for cmd, r in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
@@ -45,14 +49,18 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 if r.returncode:
                     raise RuntimeError("hipcc failed for " + cmd[-3])
     objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _stale(lib_path, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             print(r.stdout, r.stderr)
             raise RuntimeError("link of libmdbg_hip.so failed")
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_lib(verbose=True))
+    import sys
+    if len(sys.argv) > 1:   # python build.py <tag> <extra flags...>
+        print(build_lib(verbose=True, tag=sys.argv[1], extra_flags=sys.argv[2:]))
+    else:
+        print(build_lib(verbose=True))

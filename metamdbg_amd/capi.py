@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdbg_hip.so")
+LIB_PATH = os.environ.get("MDBG_LIB") or os.path.join(_HERE, "libmdbg_hip.so")   # MDBG_LIB: experimental variant
 
 MDBG_READ_LOW_COMPLEXITY = 1
 MDBG_READ_LOW_QUALITY = 2

@@ -32,6 +32,7 @@ constexpr int SCAN_WAVES = SCAN_BLOCK / 64;
 constexpr int TILE_WORDS = 64;                 // u64 words per tile (one per lane)
 constexpr int STREAM_WORDS = 136;              // u32: (16 carry + 2048 new bases) / 16 = 129, + slack for the w+1 read
 constexpr uint64_t M5 = 0x5555555555555555ull;
+constexpr uint8_t READ_SUSPECT = 0x80;         // internal: 2-mer complexity bound exceeded, exact pass pending
 
 struct ScanArgs {
     const uint64_t *words;
@@ -182,8 +183,28 @@ __device__ int exact_low_complexity(const uint64_t *rw, uint32_t L, unsigned lan
     return (acc / (double)nW) > 5.0;
 }
 
+// one wave per suspect read: exact decision; low-complexity reads lose their minimizers but keep
+// their (empty) record (ReadSelection.hpp:890-899)
+__global__ __launch_bounds__(256) void complexity_exact_kernel(const uint64_t *words, const uint64_t *word_off, const uint32_t *len,
+                                                               const uint32_t *list, uint32_t n_list, uint32_t *count, uint8_t *flags) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    for (uint32_t i = wave; i < n_list; i += n_waves) {
+        const uint32_t r = list[i];
+        int low = exact_low_complexity(words + word_off[r], len[r], lane);
+        if (lane == 0) {
+            flags[r] = low ? (uint8_t)MDBG_READ_LOW_COMPLEXITY : (uint8_t)0;
+            if (low) count[r] = 0;
+        }
+    }
+}
+
+#ifndef SCAN_MIN_WAVES
+#define SCAN_MIN_WAVES 1   // waves per SIMD the register allocator must allow (tuning knob)
+#endif
+
 template <bool HPC>
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanArgs a) {
     __shared__ uint32_t lds_stream[SCAN_WAVES][STREAM_WORDS];
     const unsigned lane = threadIdx.x & 63u;
     uint32_t *S = lds_stream[threadIdx.x >> 6];
@@ -322,13 +343,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(ScanArgs a) {
         if (a.apply_filters && L >= 66) {
             uint32_t nW = (L - 66u) / 32u + 1u;
             uint64_t bound = wave_sum_u64(cx_bound);
-            // bound/(61 nW) >= true mean score; only reads whose bound exceeds ~4.9 need the exact pass
-            if (bound > 300ull * nW) {
-                if (exact_low_complexity(rw, L, lane)) flags |= MDBG_READ_LOW_COMPLEXITY;
-            }
+            // bound/(61 nW) >= true mean score; only reads whose bound exceeds ~4.9 need the exact pass,
+            // which runs as its own (rare) kernel so its registers do not cap this kernel's occupancy
+            if (bound > 300ull * nW) flags |= READ_SUSPECT;
         }
         if (lane == 0) {
-            a.out_count[r] = (flags & MDBG_READ_LOW_COMPLEXITY) ? 0u : nout;   // ReadSelection.hpp:890-899
+            a.out_count[r] = nout;
             a.out_flags[r] = flags;
         }
     }
@@ -368,10 +388,13 @@ __global__ void capacity_kernel(const uint32_t *len, uint32_t n_reads, float den
     }
 }
 
-__global__ void overflow_list_kernel(const uint32_t *count, const uint32_t *cap, uint32_t n_reads,
-                                     uint32_t *list, uint32_t *n_list) {
+// after the main launch: list the reads that overflowed their padded slots and the complexity suspects
+__global__ void post_scan_lists_kernel(const uint32_t *count, const uint32_t *cap, const uint8_t *flags, uint32_t n_reads,
+                                       uint32_t *over_list, uint32_t *suspect_list, uint32_t *counters /* [0]=over [1]=suspect */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_reads && count[i] > cap[i]) list[atomicAdd(n_list, 1u)] = (uint32_t)i;
+    if (i >= n_reads) return;
+    if (count[i] > cap[i]) over_list[atomicAdd(&counters[0], 1u)] = (uint32_t)i;
+    if (flags[i] & READ_SUSPECT) suspect_list[atomicAdd(&counters[1], 1u)] = (uint32_t)i;
 }
 
 __global__ void gather_u32_kernel(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *dst) {
@@ -483,16 +506,23 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     if (n && (rc = launch_scan(ctx, a, p->hpc != 0, n))) return fail(rc);
     if (getenv("MDBG_TRACE")) { hipError_t se = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mdbg_scan] scan kernel done: %s\n", hipGetErrorString(se)); }
 
-    // overflow handling: reads that selected more than their padded capacity are re-run with exact room
-    DevBuf<uint32_t> d_list, d_nlist;
-    if ((rc = d_list.alloc(ctx, n)) || (rc = d_nlist.alloc(ctx, 1))) return fail(rc);
-    (void)hipMemsetAsync(d_nlist.p, 0, 4, ctx->stream);
-    if (n) hipLaunchKernelGGL(overflow_list_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-                              d_count.p, d_cap.p, n, d_list.p, d_nlist.p);
-    uint32_t n_over = 0;
-    e = memcpy_sync(ctx, &n_over, d_nlist.p, 4, hipMemcpyDeviceToHost);
+    // overflow handling (reads that selected more than their padded capacity are re-run with exact room)
+    // and the exact complexity pass over the few reads the 2-mer bound could not clear
+    DevBuf<uint32_t> d_list, d_suspects, d_nlist;
+    if ((rc = d_list.alloc(ctx, n)) || (rc = d_suspects.alloc(ctx, n)) || (rc = d_nlist.alloc(ctx, 2))) return fail(rc);
+    (void)hipMemsetAsync(d_nlist.p, 0, 8, ctx->stream);
+    if (n) hipLaunchKernelGGL(post_scan_lists_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                              d_count.p, d_cap.p, m->d_flags.p, n, d_list.p, d_suspects.p, d_nlist.p);
+    uint32_t h_counters[2] = {0, 0};
+    e = memcpy_sync(ctx, h_counters, d_nlist.p, 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "overflow count copy failed: %s", hipGetErrorString(e)));
-
+    const uint32_t n_over = h_counters[0], n_suspect = h_counters[1];
+    if (n_suspect) {
+        LaunchTimer timer(ctx, "complexity_exact");
+        hipLaunchKernelGGL(complexity_exact_kernel, dim3(grid_for((uint64_t)n_suspect * 64, 256, (unsigned)ctx->n_cu * 8u)), dim3(256), 0,
+                           ctx->stream, reads->d_words.p, reads->d_word_off.p, reads->d_len.p, d_suspects.p, n_suspect,
+                           d_count.p, m->d_flags.p);
+    }
     TRACE("overflow list done");
     // dense offsets from the true counts
     if ((rc = exclusive_scan_u32(ctx, d_count.p, m->d_off.p, n))) return fail(rc);
