@@ -1,0 +1,75 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol the header
+declares, the ctypes table covers the header, and there is no silent CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mdbg_hip.h")
+
+
+def declared_functions() -> list[str]:
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdbg_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from metamdbg_amd import build, capi
+    build.build_lib()
+    return capi.LIB_PATH
+
+
+def test_header_declares_a_c_abi():
+    src = open(HEADER).read()
+    assert 'extern "C"' in src
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert "torch" not in code.lower() and "at::" not in code and "std::" not in code   # plain C types at the boundary
+    assert len(declared_functions()) >= 30
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mdbg_[a-z0-9_]+)", out))
+    missing = [f for f in declared_functions() if f not in exported]
+    assert not missing, f"declared in include/mdbg_hip.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header(lib_path):
+    from metamdbg_amd import capi
+    assert sorted(capi.SIGNATURES) == declared_functions()
+    lib = capi.lib()                      # loads the .so and binds every symbol
+    for name in capi.SIGNATURES:
+        assert hasattr(lib, name)
+
+
+def test_no_cpu_fallback_without_gpu(lib_path):
+    """Without a GPU (this container) context creation must fail loudly, not fall back."""
+    from metamdbg_amd import capi
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    with pytest.raises(capi.MdbgError) as ei:
+        capi.Context(0)
+    assert ei.value.code == -2 and "no CPU path" in str(ei.value)
+
+
+def test_product_package_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under metamdbg_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "metamdbg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath).startswith("build"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "liboracle" not in text and "mdbg_oracle.h" not in text, f

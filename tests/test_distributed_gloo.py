@@ -1,0 +1,102 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU exchange step (metamdbg_amd/distributed.py):
+partial count rows -> all-to-all by owner -> reduce -> all-gather == counts over the union of reads.
+The per-rank partial rows are produced here by the CPU oracle (test infrastructure); on the GPU box
+they come from mdbg_kminmer_partial_counts (tests/test_gpu_parity.py::test_multi_gpu_pieces)."""
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def owner_of(hi: np.ndarray, n_ranks: int) -> np.ndarray:
+    """Same owner function as csrc/multigpu.hip: top 32 bits of hash_hi scaled to [0, n_ranks)."""
+    return (((hi >> np.uint64(32)) * np.uint64(n_ranks)) >> np.uint64(32)).astype(np.int64)
+
+
+def partial_rows(orc, mins, offs, k, n_ranks):
+    """(rows int64[n, 3 + ceil(k/2)] grouped by owner, counts per owner) of one shard."""
+    rw = 3 + (k + 1) // 2
+    keys = {}
+    for r in range(len(offs) - 1):
+        m = mins[int(offs[r]): int(offs[r + 1])]
+        for i in range(len(m) - k + 1):
+            rev, vec, hi, lo = orc.kminmer_normalize_hash(m[i:i + k])
+            e = keys.setdefault((hi, lo), [0, vec])
+            e[0] += 1
+    rows = np.zeros((len(keys), rw), dtype=np.uint64)
+    for j, ((hi, lo), (c, vec)) in enumerate(keys.items()):
+        rows[j, 0], rows[j, 1], rows[j, 2] = lo, hi, c
+        v = np.zeros(2 * ((k + 1) // 2), dtype=np.uint64)
+        v[:k] = vec
+        rows[j, 3:] = v[0::2] | (v[1::2] << np.uint64(32))
+    own = owner_of(rows[:, 1], n_ranks) if len(rows) else np.zeros(0, np.int64)
+    order = np.argsort(own, kind="stable")
+    counts = [int((own == r).sum()) for r in range(n_ranks)]
+    return rows[order].view(np.int64), counts
+
+
+def reduce_rows(rows: np.ndarray) -> np.ndarray:
+    u = rows.view(np.uint64)
+    out = {}
+    for row in u:
+        key = (int(row[1]), int(row[0]))
+        if key in out:
+            out[key][2] += row[2]
+        else:
+            out[key] = row.copy()
+    return np.array(list(out.values()), dtype=np.uint64).reshape(-1, rows.shape[1]).view(np.int64)
+
+
+def _worker(rank, world, port, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metamdbg_amd import distributed as D
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(7)                      # same data on every rank, each takes its shard
+    lens = rng.integers(0, 40, 120)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    mins = rng.integers(0, 9, int(offs[-1])).astype(np.uint32)
+    lo_r, hi_r = rank * 60, (rank + 1) * 60
+    soffs = offs[lo_r: hi_r + 1] - offs[lo_r]
+    smins = mins[int(offs[lo_r]): int(offs[hi_r])]
+    rows, counts = partial_rows(orc, smins, soffs, k, world)
+    mine = D.exchange_by_owner(torch.from_numpy(rows.copy()), counts)
+    mine_np = mine.numpy()
+    if len(mine_np):
+        assert (owner_of(mine_np.view(np.uint64)[:, 1], world) == rank).all()     # only keys this rank owns arrive
+    red = reduce_rows(mine_np) if len(mine_np) else mine_np
+    glob = D.all_gather_rows(torch.from_numpy(np.ascontiguousarray(red))).numpy().view(np.uint64)
+    # expected: counts over ALL reads
+    exp_rows, _ = partial_rows(orc, mins, offs, k, 1)
+    exp = {(int(r[1]), int(r[0])): int(r[2]) for r in exp_rows.view(np.uint64)}
+    got = {(int(r[1]), int(r[0])): int(r[2]) for r in glob}
+    ok = exp == got and len(got) == len(glob)
+    q.put((rank, bool(ok), len(glob)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [4, 5])
+def test_exchange_reduce_gather_world2(k):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2] and res[0][2] > 0

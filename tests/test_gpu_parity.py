@@ -188,3 +188,63 @@ def test_refined_and_index_vs_oracle(ctx, orc, k):
     rec, vec = ctx.kminmer_index(d_reads, d_unitigs, k, dprev).to_host()
     assert vec is None
     _assert_tables_equal(rec, vec, orc.kminmer_index(allm, alloff, k, oprev), k)
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_multi_gpu_pieces_on_one_gpu(ctx, orc, n_ranks):
+    """All kernels of the sharded first pass, with the exchange emulated on one device: shard the reads,
+    partial counts per shard, concatenate the rows per owner (the all-to-all), reduce per owner, gather,
+    finish per (rank, shard); the union of the per-rank tables must equal the single-GPU table."""
+    import ctypes as C
+    k = 4
+    rng = np.random.default_rng(11 + n_ranks)
+    mins, offs = _random_minimizer_reads(rng, 600, 30)
+    n_reads = len(offs) - 1
+    cuts = np.linspace(0, n_reads, n_ranks + 1).astype(int)
+    shards = []
+    for r in range(n_ranks):
+        so = offs[cuts[r]: cuts[r + 1] + 1] - offs[cuts[r]]
+        sm = mins[int(offs[cuts[r]]): int(offs[cuts[r + 1]])]
+        shards.append(ctx.minimizers_from_host(sm, so))
+    from metamdbg_amd import capi
+    rw = capi.lib().mdbg_row_words(k)
+    hip = C.CDLL("libamdhip64.so.7")   # already loaded by libmdbg_hip.so (same SONAME)
+    # rows destined to each owner, copied to the host (stands in for the all-to-all)
+    per_owner = [[] for _ in range(n_ranks)]
+    for r in range(n_ranks):
+        d_rows, counts = ctx.partial_counts(shards[r], k, n_ranks)
+        total = int(counts.sum())
+        host = np.zeros((total, rw), dtype=np.uint64)
+        if total:
+            assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(d_rows), C.c_size_t(total * rw * 8), 2) == 0
+        o = 0
+        for dst in range(n_ranks):
+            per_owner[dst].append(host[o: o + int(counts[dst])]); o += int(counts[dst])
+    # each owner reduces what it received; then everyone gathers all reduced rows
+    reduced = []
+    for dst in range(n_ranks):
+        rows = np.ascontiguousarray(np.concatenate(per_owner[dst]))
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), C.c_size_t(max(rows.nbytes, 8))) == 0
+        if rows.nbytes:
+            assert hip.hipMemcpy(buf, rows.ctypes.data_as(C.c_void_p), C.c_size_t(rows.nbytes), 1) == 0
+        n = ctx.reduce_rows(buf.value, len(rows), k)
+        out = np.zeros((n, rw), dtype=np.uint64)
+        if n:
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), buf, C.c_size_t(out.nbytes), 2) == 0
+        hip.hipFree(buf)
+        reduced.append(out)
+    glob = np.ascontiguousarray(np.concatenate(reduced))
+    gbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(gbuf), C.c_size_t(max(glob.nbytes, 8))) == 0
+    if glob.nbytes:
+        assert hip.hipMemcpy(gbuf, glob.ctypes.data_as(C.c_void_p), C.c_size_t(glob.nbytes), 1) == 0
+    recs, vecs, n_solid = [], [], 0
+    for r in range(n_ranks):
+        t = ctx.count_first_merged(shards[r], k, 0, gbuf.value, len(glob), r, n_ranks)
+        rec, vec = t.to_host()
+        recs.append(rec); vecs.append(vec); n_solid += t.info()["n_solid"]
+    hip.hipFree(gbuf)
+    exp = orc.kminmer_count_first(mins, offs, k, 0)
+    assert n_solid == exp["n_solid"]
+    _assert_tables_equal(np.concatenate(recs), np.concatenate(vecs), exp, k)
