@@ -87,6 +87,21 @@ def cpu_baseline(ctx, reads, n_sample: int) -> dict | None:
         shutil.rmtree(work, ignore_errors=True)
 
 
+def measured_traffic(reads: int, read_len: int):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/rNN_scan_traffic.json),
+    valid only for the workload they were collected on; None otherwise."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scan_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("reads") == reads and d.get("read_len") == read_len:
+            best = d
+    return None if best is None else best["traffic_bytes_per_launch"]
+
+
 def main() -> None:
     args = parse_args()
     import numpy as np
@@ -182,7 +197,7 @@ def main() -> None:
                        "kminmer_records": int(ti["n_records"]), "solid": int(ti["n_solid"]),
                        "device": info["arch"], "cus": info["n_cu"]},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "note": "integer-hash kernel: 3 x 64-bit Murmur3 multiplies chains per position put the ceiling at the "
                                  "VALU integer-multiply rate, far below HBM (DESIGN.md)"},
