@@ -17,6 +17,11 @@
 // read exactly as the reference's loop bound (pos < nK-1) does, for any homopolymer tail.
 // Low-complexity reads (computeSequenceComplexity, ReadSelection.hpp:1171-1228) are detected with a
 // 2-mer upper bound per 64-position window and confirmed by an exact 3-mer pass only when needed.
+//
+// Template variants: HAS_N adds a 1-bit "invalid" stream (characters with bit 3 set, Kmer.hpp:462;
+// k-mers touching one are never selected, :574-580); HAS_QUAL records, for every selected minimizer,
+// the ORIGINAL coordinates [rle[pos], rle[pos+K]) its per-minimizer minimum quality spans
+// (ReadSelection.hpp:1047-1142) -- the quality bytes themselves are read by the gather kernel.
 #include "common.hpp"
 #include "murmur.hpp"
 #include "objects.hpp"
@@ -31,6 +36,7 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_WAVES = SCAN_BLOCK / 64;
 constexpr int TILE_WORDS = 64;                 // u64 words per tile (one per lane)
 constexpr int STREAM_WORDS = 136;              // u32: (16 carry + 2048 new bases) / 16 = 129, + slack for the w+1 read
+constexpr int ISTREAM_WORDS = 68;              // u32: 1 bit per compressed base (HAS_N)
 constexpr uint64_t M5 = 0x5555555555555555ull;
 constexpr uint8_t READ_SUSPECT = 0x80;         // internal: 2-mer complexity bound exceeded, exact pass pending
 
@@ -38,7 +44,9 @@ struct ScanArgs {
     const uint64_t *words;
     const uint64_t *word_off;
     const uint32_t *len;
-    const uint32_t *invalid;      // per word mask or nullptr
+    const uint32_t *invalid;      // per word mask (HAS_N)
+    const uint8_t *qual;          // phred+33 bytes (inline min-quality in the overflow re-run)
+    const uint64_t *qual_off;
     uint32_t n_reads;
     uint32_t K;
     uint64_t threshold;           // hash < threshold  <=>  (double)hash < density * 2^64
@@ -51,32 +59,59 @@ struct ScanArgs {
     uint32_t *out_min;
     uint32_t *out_pos;
     uint8_t *out_dir;
+    uint32_t *out_os;             // HAS_QUAL: original start of the minimizer's span
+    uint32_t *out_oe;             // HAS_QUAL: original end (exclusive)
+    uint8_t *out_mqual;           // HAS_QUAL && inline_minq: min quality written directly
+    int inline_minq;
     uint32_t *out_count;          // per read: number selected (may exceed capacity -> overflow)
-    uint8_t *out_flags;           // per read: MDBG_READ_*
-    uint32_t *work_counter;
+    uint8_t *out_flags;           // per read: MDBG_READ_* | READ_SUSPECT
 };
 
 // squeeze the 2-bit fields of x whose flag bit (bit 2i of d) is set down to the low end
 __device__ __forceinline__ uint64_t compress_pairs(uint64_t x, uint64_t d) {
-    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    // zero the dropped fields once, then deposit field i at 2 * (number of kept fields below it)
+    uint64_t xm = x & (d | (d << 1));
+    uint32_t xl = (uint32_t)xm, xh = (uint32_t)(xm >> 32);
     uint32_t dl = (uint32_t)d, dh = (uint32_t)(d >> 32);
-    uint64_t out = 0;
+    uint32_t lo = 0, hi = 0;
     unsigned n = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        unsigned f = (dl >> (2 * i)) & 1u;
-        uint64_t b = (uint64_t)(((xl >> (2 * i)) & 3u) & (0u - f));
-        out |= b << (2 * n);
-        n += f;
+        lo |= ((xl >> (2 * i)) & 3u) << n;
+        n += (dl >> (2 * i) & 1u) << 1;
     }
+    const unsigned nlo = n;
+    n = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        unsigned f = (dh >> (2 * i)) & 1u;
-        uint64_t b = (uint64_t)(((xh >> (2 * i)) & 3u) & (0u - f));
-        out |= b << (2 * n);
+        hi |= ((xh >> (2 * i)) & 3u) << n;
+        n += (dh >> (2 * i) & 1u) << 1;
+    }
+    return (uint64_t)lo | ((uint64_t)hi << nlo);
+}
+
+// same for 1-bit fields: keep bit i of v where bit 2i of d is set
+__device__ __forceinline__ uint32_t compress_bits(uint32_t v, uint64_t d) {
+    uint32_t out = 0;
+    unsigned n = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        unsigned f = (unsigned)(d >> (2 * i)) & 1u;
+        out |= ((v >> i) & f) << n;
         n += f;
     }
     return out;
+}
+
+// bit i of v -> bit 2i
+__device__ __forceinline__ uint64_t spread_bits(uint32_t v) {
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
 }
 
 // K bases starting at stream position j, LSB-first
@@ -84,6 +119,12 @@ __device__ __forceinline__ uint32_t stream_extract(const uint32_t *S, unsigned j
     unsigned b = 2u * j, w = b >> 5, sh = b & 31u;
     uint32_t lo = S[w], hi = S[w + 1];
     return __builtin_amdgcn_alignbit(hi, lo, sh) & kmask;
+}
+
+__device__ __forceinline__ uint32_t istream_extract(const uint32_t *SI, unsigned j, uint32_t mask) {
+    unsigned w = j >> 5, sh = j & 31u;
+    uint32_t lo = SI[w], hi = SI[w + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, sh) & mask;
 }
 
 // reverse the order of the K 2-bit digits of e
@@ -199,38 +240,68 @@ __global__ __launch_bounds__(256) void complexity_exact_kernel(const uint64_t *w
     }
 }
 
+// per-wave LDS used by the HAS_QUAL variant to map a stream position back to original coordinates
+struct QualMap {
+    uint32_t lane_off[64];     // stream position of the first new base of each lane (cb + prefix)
+    uint64_t lane_flags[64];   // run-start flags of each lane's word (spread form)
+    uint32_t carry_orig[16];   // original coordinate of each carried base
+};
+
+// original coordinate of stream position s (HPC: start of its run == rlePositions[hpc index])
+__device__ __forceinline__ uint32_t orig_of(const QualMap *q, unsigned s, unsigned cb, uint32_t tile_base) {
+    if (s < cb) return q->carry_orig[s];
+    unsigned lo = 0, hi = 64;  // largest lane with lane_off <= s
+    while (hi - lo > 1) {
+        unsigned mid = (lo + hi) >> 1;
+        if (q->lane_off[mid] <= s) lo = mid; else hi = mid;
+    }
+    unsigned idx = s - q->lane_off[lo];
+    uint64_t d = q->lane_flags[lo];
+    for (unsigned t = 0; t < idx; t++) d &= d - 1;   // drop idx lowest set bits
+    unsigned bit = (unsigned)__ffsll((long long)d) - 1u;
+    return tile_base + lo * 32u + (bit >> 1);
+}
+
 #ifndef SCAN_MIN_WAVES
 #define SCAN_MIN_WAVES 1   // waves per SIMD the register allocator must allow (tuning knob)
 #endif
 
-template <bool HPC>
+template <bool HPC, bool HAS_QUAL, bool HAS_N>
 __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanArgs a) {
     __shared__ uint32_t lds_stream[SCAN_WAVES][STREAM_WORDS];
+    __shared__ uint32_t lds_istream[HAS_N ? SCAN_WAVES : 1][HAS_N ? ISTREAM_WORDS : 1];
+    __shared__ QualMap lds_qmap[(HAS_QUAL && HPC) ? SCAN_WAVES : 1];
     const unsigned lane = threadIdx.x & 63u;
-    uint32_t *S = lds_stream[threadIdx.x >> 6];
+    const unsigned wv = threadIdx.x >> 6;
+    uint32_t *S = lds_stream[wv];
+    uint32_t *SI = lds_istream[HAS_N ? wv : 0];
+    QualMap *Q = &lds_qmap[(HAS_QUAL && HPC) ? wv : 0];
     const unsigned K = a.K;
     const uint32_t kmask = (K >= 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+    const uint32_t kbits = (1u << K) - 1u;
     const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
 
-    // reads are dealt round-robin to the resident waves (grid-stride); lengths are similar within a
-    // batch, and the grid holds 8 waves per SIMD so a long read only delays its own wave
+    // reads are dealt round-robin to the resident waves (grid-stride)
     const uint32_t wave_global = (blockIdx.x * SCAN_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SCAN_BLOCK) >> 6;
     for (uint32_t slot = wave_global; slot < a.n_reads; slot += n_waves) {
         const uint32_t r = a.subset ? a.subset[slot] : slot;
 
         const uint32_t L = a.len[r];
-        const uint64_t *rw = a.words + a.word_off[r];
+        const uint64_t w_base = a.word_off[r];
+        const uint64_t *rw = a.words + w_base;
         const uint32_t nwords = (L + 31u) / 32u;
         const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
         const uint64_t cap0 = a.cap_off[r];
         const uint32_t cap = (uint32_t)(a.cap_off[r + 1] - cap0);
 
         uint32_t carry = 0;        // last cb bases of the compressed stream, LSB-first
+        uint32_t icarry = 0;       // their invalid bits (HAS_N)
         unsigned cb = 0;
         uint32_t hp_total = 0;     // compressed bases seen so far
         uint32_t nout = 0;
         uint32_t prev_last = 0;    // last base of the previous tile's last word
+        uint32_t prev_inv = 0;     // its invalid bit (HAS_N)
         uint64_t cx_bound = 0;     // sum over windows of the 2-mer bound numerator
 
         uint64_t x_next = (lane < nwords) ? rw[lane] : 0;
@@ -245,6 +316,8 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             const int rem = (int)L - (int)(wi * 32u);
             const unsigned nvalid = rem <= 0 ? 0u : (rem >= 32 ? 32u : (unsigned)rem);
             const uint64_t vspread = nvalid == 32 ? M5 : (((1ull << (2 * nvalid)) - 1ull) & M5);
+            uint32_t iv = 0;
+            if (HAS_N) iv = (wi < nwords) ? a.invalid[w_base + wi] : 0u;
 
             // ---- complexity: 2-mer upper bound of the window starting at this word -------------
             if (a.apply_filters) {
@@ -258,19 +331,26 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             }
 
             // ---- 1. run starts / compaction ---------------------------------------------------
-            uint64_t y;
+            uint64_t y, d;
             unsigned c;
             if (HPC) {
                 uint32_t pl = (uint32_t)__shfl_up((uint32_t)(x >> 62), 1, 64);
                 if (lane == 0) pl = prev_last;
                 uint64_t diff = x ^ ((x << 2) | (uint64_t)pl);
-                uint64_t d = (diff | (diff >> 1)) & M5;
+                d = (diff | (diff >> 1)) & M5;
+                if (HAS_N) {   // a change of the invalid bit also starts a run (N vs G share code 3)
+                    uint32_t pi = (uint32_t)__shfl_up(iv >> 31, 1, 64);
+                    if (lane == 0) pi = prev_inv;
+                    d |= spread_bits(iv ^ ((iv << 1) | pi));
+                    prev_inv = (uint32_t)__shfl(iv >> 31, 63, 64);
+                }
                 if (wi == 0) d |= 1ull;
                 d &= vspread;
                 c = (unsigned)__popcll(d);
                 y = compress_pairs(x, d);
                 prev_last = (uint32_t)__shfl((uint32_t)(x >> 62), 63, 64);
             } else {
+                d = vspread;
                 c = nvalid;
                 y = x & (vspread | (vspread << 1));
             }
@@ -282,8 +362,10 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             S[lane] = 0;
             S[lane + 64] = 0;
             if (lane < STREAM_WORDS - 128) S[lane + 128] = 0;
+            if (HAS_N) { SI[lane] = 0; if (lane < ISTREAM_WORDS - 64) SI[lane + 64] = 0; }
+            if (HAS_QUAL && HPC) { Q->lane_off[lane] = cb + o; Q->lane_flags[lane] = d; }
             wave_lds_sync();
-            if (lane == 0 && cb) atomicOr(&S[0], carry);
+            if (lane == 0 && cb) { atomicOr(&S[0], carry); if (HAS_N && icarry) atomicOr(&SI[0], icarry); }
             if (c) {
                 unsigned dst = 2u * (cb + o), w = dst >> 5, sh = dst & 31u;
                 uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
@@ -293,6 +375,14 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
                 atomicOr(&S[w], p0);
                 if (p1) atomicOr(&S[w + 1], p1);
                 if (p2) atomicOr(&S[w + 2], p2);
+                if (HAS_N) {
+                    uint32_t ic = HPC ? compress_bits(iv, d) : (iv & (nvalid == 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u)));
+                    if (ic) {
+                        unsigned di = cb + o, wq = di >> 5, sq = di & 31u;
+                        atomicOr(&SI[wq], ic << sq);
+                        if (sq && (ic >> (32u - sq))) atomicOr(&SI[wq + 1], ic >> (32u - sq));
+                    }
+                }
             }
             wave_lds_sync();
 
@@ -300,6 +390,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             const unsigned tot = cb + C;
             const unsigned nk = tot > K ? tot - K : 0u;
             const uint32_t hp_base = hp_total - cb;    // compressed-stream position of S base 0
+            const uint32_t tile_base = t * TILE_WORDS * 32u;
             for (unsigned j0 = 0; j0 < nk; j0 += 64) {
                 const unsigned j = j0 + lane;
                 const uint32_t p = hp_base + j;
@@ -313,7 +404,8 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
                     val = dir ? rev : fwd;
                     uint64_t h = kmer_hash32(val);
                     sel = (h < a.threshold) && (p >= 1u);     // first k-mer skipped (Kmer.hpp:1395)
-                    if (sel && a.n_rep) sel = !rep_contains(a.rep, a.n_rep, val);   // Kmer.hpp:1437
+                    if (HAS_N) sel = sel && (istream_extract(SI, j, kbits) == 0u);   // Kmer.hpp:574-580
+                    if (sel && a.n_rep) sel = !rep_contains(a.rep, a.n_rep, val);    // Kmer.hpp:1437
                 }
                 unsigned long long bal = __ballot(sel);
                 if (bal) {
@@ -323,6 +415,20 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
                             a.out_min[cap0 + idx] = val;
                             a.out_pos[cap0 + idx] = p;
                             a.out_dir[cap0 + idx] = (uint8_t)dir;
+                            if (HAS_QUAL) {
+                                uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
+                                if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
+                                else { os = p; oe = p + K; }
+                                if (a.inline_minq) {
+                                    const uint8_t *qq = a.qual + a.qual_off[r];
+                                    uint8_t mq = 255;   // getMinQuality (ReadSelection.hpp:1302-1320)
+                                    for (uint32_t b = os; b < oe; b++) { uint8_t q = (uint8_t)(qq[b] - 33); if (q < mq) mq = q; }
+                                    a.out_mqual[cap0 + idx] = mq;
+                                } else {
+                                    a.out_os[cap0 + idx] = os;
+                                    a.out_oe[cap0 + idx] = oe;
+                                }
+                            }
                         }
                     }
                     nout += (uint32_t)__popcll(bal);
@@ -333,9 +439,13 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             const unsigned cbn = tot < K ? tot : K;
             const uint32_t cmask = (cbn >= 16) ? 0xFFFFFFFFu : ((1u << (2 * cbn)) - 1u);
             carry = cbn ? stream_extract(S, tot - cbn, cmask) : 0u;
+            if (HAS_N) icarry = cbn ? istream_extract(SI, tot - cbn, (1u << cbn) - 1u) : 0u;
+            uint32_t my_orig = 0;
+            if (HAS_QUAL && HPC) { if (lane < cbn) my_orig = orig_of(Q, tot - cbn + lane, cb, tile_base); }
             cb = cbn;
             hp_total += C;
-            wave_lds_sync();   // all reads of S done before the next tile zeroes it
+            wave_lds_sync();   // all reads of S / Q done before the next tile rewrites them
+            if (HAS_QUAL && HPC) { if (lane < cbn) Q->carry_orig[lane] = my_orig; }
         }
 
         // ---- per-read epilogue -----------------------------------------------------------------
@@ -354,10 +464,12 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
     }
 }
 
-// ---- padded -> dense CSR ------------------------------------------------------------------------
+// ---- padded -> dense CSR (+ per-minimizer minimum quality) -------------------------------------
+template <bool HAS_QUAL>
 __global__ __launch_bounds__(256) void compact_minimizers_kernel(
     const uint64_t *cap_off, const uint64_t *off, uint32_t n_reads,
-    const uint32_t *pmin, const uint32_t *ppos, const uint8_t *pdir,
+    const uint32_t *pmin, const uint32_t *ppos, const uint8_t *pdir, const uint32_t *pos_s, const uint32_t *pos_e,
+    const uint8_t *qual, const uint64_t *qual_off,
     uint32_t *omin, uint32_t *opos, uint8_t *odir, uint8_t *oqual) {
     // one wave per read (reads hold a few dozen to a few thousand minimizers)
     const unsigned lane = threadIdx.x & 63u;
@@ -369,13 +481,62 @@ __global__ __launch_bounds__(256) void compact_minimizers_kernel(
         uint32_t ncopy = (uint32_t)(cap_off[r + 1] - src);   // padded capacity (overflowed reads are re-run)
         if (ncopy > n) ncopy = n;
         for (uint32_t i = lane; i < n; i += 64) {
+            uint8_t mq = 1;   // no qualities: ReadSelection.hpp:1047-1051
             if (i < ncopy) {
                 omin[dst + i] = pmin[src + i];
                 opos[dst + i] = ppos[src + i];
                 odir[dst + i] = pdir[src + i];
+                if (HAS_QUAL) {   // getMinQuality over the original span (ReadSelection.hpp:1302-1320)
+                    const uint8_t *qq = qual + qual_off[r];
+                    mq = 255;
+                    for (uint32_t b = pos_s[src + i], e = pos_e[src + i]; b < e; b++) {
+                        uint8_t q = (uint8_t)(qq[b] - 33);
+                        if (q < mq) mq = q;
+                    }
+                }
             }
-            oqual[dst + i] = 1;   // no qualities: ReadSelection.hpp:1047-1051
+            oqual[dst + i] = mq;
         }
+    }
+}
+
+// Exact sum of per-base error probabilities as a 128-bit fixed-point integer (units of 2^-64):
+// one wave per read, conflict-free per-lane LDS histogram of the quality bytes, then
+// sum_q count[q] * T[q] with T[q] = float table entry * 2^64 (exact).  The host turns it into the
+// reference's long double error sum (ReadSelection.hpp:870-879).
+constexpr int QBINS = 96;   // bins 0..94 = chars 33..127, bin 95 = everything else (contributes 0)
+__global__ __launch_bounds__(64) void quality_sum_kernel(const uint8_t *qual, const uint64_t *qual_off, const uint32_t *len,
+                                                         uint32_t n_reads, const uint64_t *tab_lo, const uint64_t *tab_hi,
+                                                         uint64_t *sum_lo, uint64_t *sum_hi) {
+    __shared__ uint32_t hist[QBINS][64];   // hist[bin][lane]: lanes never collide
+    const unsigned lane = threadIdx.x;
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        for (int b = 0; b < QBINS; b++) hist[b][lane] = 0;
+        const uint8_t *q = qual + qual_off[r];
+        const uint32_t L = len[r];
+        for (uint32_t i = lane; i < L; i += 64) {
+            unsigned c = q[i];
+            unsigned bin = (c >= 33u && c <= 127u) ? c - 33u : (unsigned)(QBINS - 1);
+            hist[bin][lane] += 1;
+        }
+        __syncthreads();
+        unsigned __int128 acc = 0;
+        for (int b = lane; b < QBINS - 1; b += 64) {
+            uint64_t cnt = 0;
+            for (int l = 0; l < 64; l++) cnt += hist[b][l];
+            unsigned __int128 t = ((unsigned __int128)tab_hi[b] << 64) | tab_lo[b];
+            acc += t * cnt;
+        }
+        uint64_t lo = (uint64_t)acc, hi = (uint64_t)(acc >> 64);
+        // 128-bit wave reduction
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            uint64_t olo = __shfl_xor(lo, dlt, 64), ohi = __shfl_xor(hi, dlt, 64);
+            uint64_t nlo = lo + olo;
+            hi = hi + ohi + (nlo < lo ? 1ull : 0ull);
+            lo = nlo;
+        }
+        if (lane == 0) { sum_lo[r] = lo; sum_hi[r] = hi; }
+        __syncthreads();
     }
 }
 
@@ -397,9 +558,9 @@ __global__ void post_scan_lists_kernel(const uint32_t *count, const uint32_t *ca
     if (flags[i] & READ_SUSPECT) suspect_list[atomicAdd(&counters[1], 1u)] = (uint32_t)i;
 }
 
-__global__ void gather_u32_kernel(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *dst) {
+__global__ void apply_low_quality_kernel(const uint8_t *low, uint32_t n_reads, uint32_t *count, uint8_t *flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
+    if (i < n_reads && low[i]) { count[i] = 0; flags[i] |= (uint8_t)MDBG_READ_LOW_QUALITY; }
 }
 
 }  // namespace mdbg
@@ -418,47 +579,58 @@ static uint64_t density_threshold(float density) {
     return lo;
 }
 
-// ReadSelection.hpp:870-879 with an empty quality string: long double 0 / size_t 0, narrowed to
-// float, through log10f -- evaluated at run time so the NaN carries the same sign bit (0xFFC00000
-// on x86-64) the reference writes into read_data_init.txt.
-static float mean_quality_without_qualities() {
-    volatile long double error_sum = 0;
-    volatile size_t n = 0;
+// ReadSelection.hpp:870-879: float meanReadError = errorSum / n; meanReadQuality = -10.0f * log10(meanReadError).
+// Evaluated at run time (volatile) so that n == 0 yields the same NaN bits (0xFFC00000 on x86-64)
+// the reference writes into read_data_init.txt.
+static float mean_quality_from_sum(long double error_sum_in, size_t n_in) {
+    volatile long double error_sum = error_sum_in;
+    volatile size_t n = n_in;
     volatile float mean_err = (float)(error_sum / n);
     return -10.0f * log10f(mean_err);
 }
 
-static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, uint32_t n_items) {
-    MDBG_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));
-    a.work_counter = ctx->d_work_counter;
-    a.n_reads = n_items;
-    // persistent-style grid: enough waves to fill every SIMD 8 deep, reads handed out dynamically
-    unsigned blocks = (unsigned)ctx->n_cu * 8u;
+template <bool HPC, bool Q, bool N>
+static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks, uint32_t n_items) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_kernel<HPC, Q, N>, SCAN_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    // exactly one resident generation of waves: reads are dealt grid-stride, so a partial second
+    // generation would leave SIMDs under-filled for the tail
+    unsigned blocks = (unsigned)ctx->n_cu * (unsigned)per_cu;
+    if (blocks > max_blocks) blocks = max_blocks;
     uint64_t need = ((uint64_t)n_items + SCAN_WAVES - 1) / SCAN_WAVES;
     if (need < blocks) blocks = (unsigned)(need ? need : 1);
+    hipLaunchKernelGGL((scan_kernel<HPC, Q, N>), dim3(blocks), dim3(SCAN_BLOCK), 0, ctx->stream, a);
+}
+
+static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool has_n, uint32_t n_items) {
+    a.n_reads = n_items;
+    const unsigned max_blocks = (unsigned)ctx->n_cu * 8u;
     {
         LaunchTimer timer(ctx, "scan");
-        if (hpc) hipLaunchKernelGGL(scan_kernel<true>, dim3(blocks), dim3(SCAN_BLOCK), 0, ctx->stream, a);
-        else     hipLaunchKernelGGL(scan_kernel<false>, dim3(blocks), dim3(SCAN_BLOCK), 0, ctx->stream, a);
+        if (hpc) {
+            if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }
+            else { if (has_q) launch_variant<true, true, false>(ctx, a, max_blocks, n_items); else launch_variant<true, false, false>(ctx, a, max_blocks, n_items); }
+        } else {
+            if (has_n) { if (has_q) launch_variant<false, true, true>(ctx, a, max_blocks, n_items); else launch_variant<false, false, true>(ctx, a, max_blocks, n_items); }
+            else { if (has_q) launch_variant<false, true, false>(ctx, a, max_blocks, n_items); else launch_variant<false, false, false>(ctx, a, max_blocks, n_items); }
+        }
     }
     MDBG_HIP_CHECK(ctx, hipGetLastError());
     return MDBG_OK;
 }
 
-#define TRACE(msg) do { if (getenv("MDBG_TRACE")) { fprintf(stderr, "[mdbg_scan] %s\n", msg); fflush(stderr); } } while (0)
-
 extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan_params *p, mdbg_minimizers **out) {
     if (!ctx || !reads || !p || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_scan: null argument");
     if (p->minimizer_size < 2 || p->minimizer_size > 16)
         return set_error(ctx, MDBG_EINVAL, "mdbg_scan: minimizer_size %u outside [2,16]", p->minimizer_size);
-    if (reads->has_invalid)
-        return set_error(ctx, MDBG_ERANGE, "mdbg_scan: reads with N are not supported by this build yet");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = reads->n_reads;
+    const bool hpc = p->hpc != 0, has_q = reads->has_qual, has_n = reads->has_invalid;
     mdbg_minimizers *m = new mdbg_minimizers();
     m->n_reads = n;
     m->from_scan = true;
     auto fail = [&](int rc) { delete m; return rc; };
+    hipError_t e;
 
     DevBuf<uint32_t> d_cap, d_count, d_rep;
     DevBuf<uint64_t> d_cap_off;
@@ -470,30 +642,73 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         std::vector<uint32_t> rep(p->repetitive, p->repetitive + p->n_repetitive);
         std::sort(rep.begin(), rep.end());
         if ((rc = d_rep.alloc(ctx, rep.size()))) return fail(rc);
-        hipError_t e = hipMemcpyAsync(d_rep.p, rep.data(), rep.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        e = memcpy_sync(ctx, d_rep.p, rep.data(), rep.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "copy of repetitive set failed"));
-        (void)hipStreamSynchronize(ctx->stream);
     }
-    hipError_t e = hipMemcpyAsync(m->d_len.p, reads->d_len.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    e = hipMemcpyAsync(m->d_len.p, reads->d_len.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "len copy failed: %s", hipGetErrorString(e)));
+
+    // ---- mean read quality (exact 128-bit sums on the device, long double finish on the host) ----
+    std::vector<uint8_t> low_quality;
+    bool any_low_quality = false;
+    if (has_q && n) {
+        // table exactly as the reference builds it (ReadSelection.hpp:101-104, Commons.hpp:2338-2341)
+        std::vector<uint64_t> tlo(QBINS, 0), thi(QBINS, 0);
+        for (int q = 33; q <= 127; q++) {
+            float qq = (float)(uint8_t)(q - 33);
+            float t = powf(10.0f, -qq / 10.0f);
+            long double scaled = (long double)t * 18446744073709551616.0L;   // * 2^64, exact (24-bit mantissa)
+            unsigned __int128 v = (unsigned __int128)scaled;
+            tlo[q - 33] = (uint64_t)v; thi[q - 33] = (uint64_t)(v >> 64);
+        }
+        DevBuf<uint64_t> d_tlo, d_thi, d_slo, d_shi;
+        if ((rc = d_tlo.alloc(ctx, QBINS)) || (rc = d_thi.alloc(ctx, QBINS)) || (rc = d_slo.alloc(ctx, n)) || (rc = d_shi.alloc(ctx, n)))
+            return fail(rc);
+        if ((e = memcpy_sync(ctx, d_tlo.p, tlo.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = memcpy_sync(ctx, d_thi.p, thi.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(set_error(ctx, MDBG_EHIP, "quality table upload failed: %s", hipGetErrorString(e)));
+        {
+            LaunchTimer timer(ctx, "quality_sum");
+            unsigned blocks = n < (unsigned)ctx->n_cu * 16u ? n : (unsigned)ctx->n_cu * 16u;
+            hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(64), 0, ctx->stream, reads->d_qual.p, reads->d_qual_off.p,
+                               reads->d_len.p, n, d_tlo.p, d_thi.p, d_slo.p, d_shi.p);
+        }
+        std::vector<uint64_t> slo(n), shi(n);
+        std::vector<uint32_t> lens(n);
+        if ((e = memcpy_sync(ctx, slo.data(), d_slo.p, (size_t)n * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
+            (e = memcpy_sync(ctx, shi.data(), d_shi.p, (size_t)n * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
+            (e = memcpy_sync(ctx, lens.data(), reads->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+            return fail(set_error(ctx, MDBG_EHIP, "quality sums download failed: %s", hipGetErrorString(e)));
+        m->h_mean_quality.resize(n);
+        low_quality.assign(n, 0);
+        for (uint32_t r = 0; r < n; r++) {
+            long double s = ((long double)shi[r] * 18446744073709551616.0L + (long double)slo[r]) / 18446744073709551616.0L;
+            float mq = mean_quality_from_sum(s, lens[r]);
+            m->h_mean_quality[r] = mq;
+            if (p->apply_read_filters && mq < p->min_read_quality) { low_quality[r] = 1; any_low_quality = true; }   // ReadSelection.hpp:901-909
+        }
+    } else {
+        m->h_mean_quality.assign(n, mean_quality_from_sum(0, 0));
+    }
 
     if (n) hipLaunchKernelGGL(capacity_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
                               reads->d_len.p, n, p->density, d_cap.p);
-    TRACE("capacity launched");
     if ((rc = exclusive_scan_u32(ctx, d_cap.p, d_cap_off.p, n))) return fail(rc);
-    TRACE("capacity scanned");
     uint64_t cap_total = 0;
     e = memcpy_sync(ctx, &cap_total, d_cap_off.p + n, 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "cap total copy failed"));
 
-    DevBuf<uint32_t> p_min, p_pos;
+    DevBuf<uint32_t> p_min, p_pos, p_os, p_oe;
     DevBuf<uint8_t> p_dir;
     if ((rc = p_min.alloc(ctx, cap_total)) || (rc = p_pos.alloc(ctx, cap_total)) || (rc = p_dir.alloc(ctx, cap_total)))
         return fail(rc);
+    if (has_q && ((rc = p_os.alloc(ctx, cap_total)) || (rc = p_oe.alloc(ctx, cap_total)))) return fail(rc);
 
     ScanArgs a{};
     a.words = reads->d_words.p; a.word_off = reads->d_word_off.p; a.len = reads->d_len.p;
-    a.invalid = nullptr;
+    a.invalid = has_n ? reads->d_invalid.p : nullptr;
+    a.qual = has_q ? reads->d_qual.p : nullptr;
+    a.qual_off = has_q ? reads->d_qual_off.p : nullptr;
     a.K = p->minimizer_size;
     a.threshold = density_threshold(p->density);
     a.rep = d_rep.p; a.n_rep = p->n_repetitive;
@@ -501,10 +716,9 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     a.subset = nullptr;
     a.cap_off = d_cap_off.p;
     a.out_min = p_min.p; a.out_pos = p_pos.p; a.out_dir = p_dir.p;
+    a.out_os = p_os.p; a.out_oe = p_oe.p; a.out_mqual = nullptr; a.inline_minq = 0;
     a.out_count = d_count.p; a.out_flags = m->d_flags.p;
-    TRACE("launching scan kernel");
-    if (n && (rc = launch_scan(ctx, a, p->hpc != 0, n))) return fail(rc);
-    if (getenv("MDBG_TRACE")) { hipError_t se = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mdbg_scan] scan kernel done: %s\n", hipGetErrorString(se)); }
+    if (n && (rc = launch_scan(ctx, a, hpc, has_q, has_n, n))) return fail(rc);
 
     // overflow handling (reads that selected more than their padded capacity are re-run with exact room)
     // and the exact complexity pass over the few reads the 2-mer bound could not clear
@@ -523,7 +737,15 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
                            ctx->stream, reads->d_words.p, reads->d_word_off.p, reads->d_len.p, d_suspects.p, n_suspect,
                            d_count.p, m->d_flags.p);
     }
-    TRACE("overflow list done");
+    if (any_low_quality) {
+        DevBuf<uint8_t> d_low;
+        if ((rc = d_low.alloc(ctx, n))) return fail(rc);
+        if ((e = memcpy_sync(ctx, d_low.p, low_quality.data(), n, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(set_error(ctx, MDBG_EHIP, "low-quality flags upload failed: %s", hipGetErrorString(e)));
+        hipLaunchKernelGGL(apply_low_quality_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_low.p, n, d_count.p, m->d_flags.p);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "low-quality pass failed"));
+    }
+
     // dense offsets from the true counts
     if ((rc = exclusive_scan_u32(ctx, d_count.p, m->d_off.p, n))) return fail(rc);
     uint64_t total = 0;
@@ -537,9 +759,14 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     if (n) {
         unsigned blocks = (unsigned)ctx->n_cu * 8u;
         LaunchTimer timer(ctx, "scan_compact");
-        hipLaunchKernelGGL(compact_minimizers_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p,
-                           m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+        if (has_q)
+            hipLaunchKernelGGL(compact_minimizers_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, p_os.p, p_oe.p, reads->d_qual.p, reads->d_qual_off.p,
+                               m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+        else
+            hipLaunchKernelGGL(compact_minimizers_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, nullptr, nullptr, nullptr, nullptr,
+                               m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
     }
     if (n_over) {
         // reads that overflowed their padded slots are re-run straight into their dense slots
@@ -548,16 +775,16 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         b.subset = d_list.p;
         b.cap_off = m->d_off.p;
         b.out_min = m->d_min.p; b.out_pos = m->d_pos.p; b.out_dir = m->d_dir.p;
+        b.out_mqual = m->d_mqual.p; b.inline_minq = 1;
         DevBuf<uint32_t> scratch_count;
         DevBuf<uint8_t> scratch_flags;
         if ((rc = scratch_count.alloc(ctx, n)) || (rc = scratch_flags.alloc(ctx, n))) return fail(rc);
         b.out_count = scratch_count.p; b.out_flags = scratch_flags.p;
-        if ((rc = launch_scan(ctx, b, p->hpc != 0, n_over))) return fail(rc);
+        if ((rc = launch_scan(ctx, b, hpc, has_q, has_n, n_over))) return fail(rc);
         (void)hipStreamSynchronize(ctx->stream);
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan failed: %s", hipGetErrorString(e)));
-    m->h_mean_quality.assign(n, mean_quality_without_qualities());
     *out = m;
     return MDBG_OK;
 }

@@ -204,7 +204,10 @@ double orc_sequence_complexity(const char *seq, size_t len)
                 v = (v << 2) + ((ch >> 1) & 3);
                 badc |= (ch >> 3) & 1;
             }
-            kmers[i] = badc ? -1 : (int16_t)v;
+            /* the reference stores -1 for a 3-mer touching N and then indexes kmerCounts[-1] (heap
+             * corruption, :1196); with no defined behaviour to restate, N counts with its 2-bit code */
+            (void)badc;
+            kmers[i] = (int16_t)v;
         }
         for (size_t ii = 0; ii < nk; ii += step) {
             double counts[64];

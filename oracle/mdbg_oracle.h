@@ -5,7 +5,7 @@
  * metamdbg_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may link or call it.  The product path never does.
  *
- * Parity status: PINNED.  Every function here is checked (tests/test_oracle_vs_ref.py,
+ * Parity status: PINNED.  Every function here is checked (tests/test_oracle_golden.py,
  * tests/golden/) against output of the reference's own code compiled from
  * /root/reference by oracle/Makefile into oracle/_ref/ (see oracle/ref_driver.cpp),
  * and against the known-answer scalars in SURVEY.md section 8(c).
@@ -60,7 +60,8 @@ size_t orc_minimizer_parse(const char *seq, size_t len, unsigned K, float densit
 
 /* ReadSelectionFunctor::computeSequenceComplexity (readSelection/ReadSelection.hpp:1171-1228)
  * with w=64, step=32 on the ORIGINAL (not HPC) sequence.  NaN when there is no full window.
- * 3-mers overlapping an N index kmerCounts[-1] in the reference (UB); here they are skipped. */
+ * 3-mers overlapping an N index kmerCounts[-1] in the reference (UB, it aborts); here N counts
+ * with its 2-bit code (c>>1)&3 like any other character. */
 double orc_sequence_complexity(const char *seq, size_t len);
 
 /* Mean read quality (readSelection/ReadSelection.hpp:870-879; table :101-104;

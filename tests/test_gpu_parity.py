@@ -248,3 +248,90 @@ def test_multi_gpu_pieces_on_one_gpu(ctx, orc, n_ranks):
     exp = orc.kminmer_count_first(mins, offs, k, 0)
     assert n_solid == exp["n_solid"]
     _assert_tables_equal(np.concatenate(recs), np.concatenate(vecs), exp, k)
+
+
+# ---- qualities (FASTQ) and invalid characters (N) -------------------------------------------------
+@pytest.mark.parametrize("tag,hpc", [("fastq_hpc_k15", True), ("fastq_nohpc_k15", False)])
+def test_scan_edge_reads_fastq_golden(ctx, tag, hpc):
+    seqs, quals = H.read_fastq(os.path.join(H.GOLDEN, "edge", "edge.fastq"))
+    seqs = [s.upper() for s in seqs]
+    rep = np.frombuffer(H.golden_bytes("edge", f"repetitiveMinimizers.{tag}.bin"), "<u4")
+    reads = ctx.reads_from_ascii(seqs, quals)
+    h = ctx.scan(reads, K=15, density=0.005, hpc=hpc, repetitive=rep).to_host()
+    assert formats.build_read_data_init(h) == H.golden_bytes("edge", f"read_data_init.{tag}.txt")
+
+
+def test_ont_100_golden_end_to_end(ctx, orc):
+    m = H.load_manifest("ont_100")
+    spec = H.spec_from_manifest(m)
+    reads = ctx.reads_synthetic(spec)                      # bases + qualities generated in HBM
+    seqs, quals = H.regenerate_reads(m)
+    b, q = reads.get(42, with_quality=True)
+    assert b == seqs[42] and q == quals[42]
+    # repetitive-minimizer pre-pass (ReadSelection.hpp:497-561): bare parse at the correction density
+    pre = ctx.scan(reads, K=m["K"], density=0.025, hpc=False, apply_read_filters=False)
+    rep_gpu = ctx.repetitive_minimizers(pre)
+    rep = np.frombuffer(H.golden_bytes("ont_100", "repetitiveMinimizers.bin"), "<u4")
+    assert len(rep_gpu) == len(rep)                        # which of the tied top minimizers is unstable in the reference
+    mins = ctx.scan(reads, K=m["K"], density=m["density"], hpc=False, repetitive=rep)
+    h = mins.to_host()
+    assert formats.build_read_data_init(h) == H.golden_bytes("ont_100", "read_data_init.txt")
+    st = formats.parse_read_stats(H.golden_bytes("ont_100", "read_stats.txt"))
+    last_k = orc.lib().orc_compute_last_k(m["density"], st["n50"], 4, 0)
+    corr = ctx.purge_palindromes(mins, 4, last_k)
+    hc = corr.to_host(full=False)
+    assert formats.write_minimizer_reads(hc["minimizers"], hc["offsets"]) == H.golden_bytes("ont_100", "read_data_corrected.txt")
+    rec, vec = ctx.kminmer_count_first(corr, m["k"], m["min_abundance"]).to_host()
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "ont_100", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(rec), exp_ab)
+    exp_v = np.fromfile(os.path.join(H.GOLDEN, "ont_100", "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    assert np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), m["k"]), exp_v)
+
+
+@pytest.mark.parametrize("hpc", [True, False])
+def test_scan_with_qualities_vs_oracle(ctx, orc, hpc):
+    rng = np.random.default_rng(77 + int(hpc))
+    lens = list(rng.integers(1, 300, 30)) + list(rng.integers(300, 12000, 40)) + [2048, 2049, 4096, 6144 + 15]
+    seqs, quals = [], []
+    for n in lens:
+        n = int(n)
+        s = synth.CODE2ASCII[rng.integers(0, 4, n)]
+        if rng.integers(0, 3) == 0 and n > 50:                    # homopolymer stretches across tile borders
+            a = int(rng.integers(0, n - 40)); s[a: a + int(rng.integers(5, 40))] = s[a]
+        seqs.append(bytes(s))
+        qmax = 94 if len(seqs) % 2 else 12                        # every other read is low quality
+        quals.append(bytes((rng.integers(0, qmax, n) + 33).astype(np.uint8)))
+    _check_scan_against_oracle(ctx, orc, seqs, quals, 15, 0.02, hpc)
+    # quality filter (ReadSelection.hpp:901-909)
+    reads = ctx.reads_from_ascii(seqs, quals)
+    h = ctx.scan(reads, K=15, density=0.02, hpc=hpc, min_read_quality=9.0).to_host()
+    exp = b"".join(orc.read_selection(s, q, K=15, density=0.02, hpc=hpc, min_read_quality=9.0)["record"] for s, q in zip(seqs, quals))
+    assert formats.build_read_data_init(h) == exp
+    assert (h["flags"] & 2).any() and not (h["flags"] & 2).all()
+
+
+def test_scan_reads_with_n(ctx, orc):
+    with open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")) as f:
+        g = json.load(f)["scan_n"]
+    for key, gg in g.items():
+        seqs = [s.upper().encode() for s in gg["inputs"]]
+        reads = ctx.reads_from_ascii(seqs)
+        h = ctx.scan(reads, K=gg["K"], density=gg["density"], hpc=bool(gg["hpc"]), apply_read_filters=False).to_host()
+        for i, out in enumerate(gg["outputs"]):
+            toks = out.split()
+            exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
+            a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
+            got = list(zip(h["minimizers"][a:b].tolist(), h["pos"][a:b].tolist(), h["dir"][a:b].tolist()))
+            if gg["inputs"][i] != gg["inputs"][i].upper():
+                continue        # lower-case input: HPC on raw characters differs from the packed form
+            assert got == exp, (key, i)
+    # random reads with N against the oracle, filters on (N counts with its 2-bit code in the complexity score)
+    rng = np.random.default_rng(5)
+    seqs = []
+    for n in list(rng.integers(20, 400, 20)) + list(rng.integers(400, 9000, 20)):
+        s = synth.CODE2ASCII[rng.integers(0, 4, int(n))]
+        for _ in range(int(rng.integers(0, 6))):
+            a = int(rng.integers(0, n)); s[a: a + int(rng.integers(1, 5))] = ord("N")
+        seqs.append(bytes(s))
+    for hpc in (True, False):
+        _check_scan_against_oracle(ctx, orc, seqs, None, 15, 0.02, hpc)
