@@ -187,6 +187,24 @@ __device__ __forceinline__ uint32_t window_sq_sum(uint64_t x0, uint64_t x1, uint
     return sum;
 }
 
+// sum over the 16 2-mers of (count among the 32 positions of word x)^2; nb = first base of the next word
+__device__ __forceinline__ uint32_t word_pair_sq_sum(uint64_t x, uint32_t nb) {
+    uint64_t eq[4], sh[4];
+    base_eq_masks(x, eq);
+#pragma unroll
+    for (int c = 0; c < 4; c++) sh[c] = (eq[c] >> 2) | ((uint64_t)(nb == (uint32_t)c) << 62);   // base(i+1) == c
+    uint32_t sum = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < 4; c0++) {
+#pragma unroll
+        for (int c1 = 0; c1 < 4; c1++) {
+            uint32_t c = (uint32_t)__popcll(eq[c0] & sh[c1]);
+            sum += c * c;
+        }
+    }
+    return sum;
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -319,15 +337,19 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             uint32_t iv = 0;
             if (HAS_N) iv = (wi < nwords) ? a.invalid[w_base + wi] : 0u;
 
-            // ---- complexity: 2-mer upper bound of the window starting at this word -------------
+            // ---- complexity: upper bound from per-word 2-mer counts --------------------------------
+            // window w = words w, w+1 (64 positions).  With a_v / b_v the 2-mer counts of the two words,
+            // sum_v (a_v + b_v)^2 <= 2 (Q_w + Q_{w+1}),  Q = sum_v count^2, and 3-mer collisions <= 2-mer
+            // collisions, so  S_w <= Q_w + Q_{w+1} - 32.  Each word's Q enters at most two windows.
             if (a.apply_filters) {
-                uint64_t x1 = __shfl_down(x, 1, 64), x2 = __shfl_down(x, 2, 64);
-                uint64_t n0 = __shfl(x_next, 0, 64), n1 = __shfl(x_next, 1, 64);
-                if (lane == 63) { x1 = n0; x2 = n1; }
-                if (lane == 62) { x2 = n0; }
-                uint64_t s = 0;
-                if ((uint64_t)wi * 32u + 66u <= L) s = (window_sq_sum<2>(x, x1, x2) - 64u) / 2u;
-                cx_bound += s;   // per lane partial; reduced at the end of the read
+                uint32_t nb = (uint32_t)__shfl_down((uint32_t)x & 3u, 1, 64);      // first base of the next word
+                uint32_t nb0 = (uint32_t)__shfl((uint32_t)x_next & 3u, 0, 64);
+                if (lane == 63) nb = nb0;
+                if ((uint64_t)wi * 32u + 33u <= L) {
+                    const uint32_t nW = L >= 66u ? (L - 66u) / 32u + 1u : 0u;
+                    uint32_t mult = (wi < nW ? 1u : 0u) + ((wi >= 1u && wi - 1u < nW) ? 1u : 0u);
+                    if (mult) cx_bound += (uint64_t)mult * word_pair_sq_sum(x, nb);
+                }
             }
 
             // ---- 1. run starts / compaction ---------------------------------------------------
@@ -391,47 +413,68 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             const unsigned nk = tot > K ? tot - K : 0u;
             const uint32_t hp_base = hp_total - cb;    // compressed-stream position of S base 0
             const uint32_t tile_base = t * TILE_WORDS * 32u;
-            for (unsigned j0 = 0; j0 < nk; j0 += 64) {
-                const unsigned j = j0 + lane;
-                const uint32_t p = hp_base + j;
-                bool sel = false;
-                uint32_t val = 0, dir = 0;
-                if (j < nk) {
-                    uint32_t e = stream_extract(S, j, kmask);
+            // two independent positions per lane and trip: the two hash chains interleave (ILP) and the
+            // loop / ballot overhead is paid once per 128 positions
+            for (unsigned j0 = 0; j0 < nk; j0 += 128) {
+                const unsigned jA = j0 + lane, jB = jA + 64;
+                bool selA = false, selB = false;
+                uint32_t valA = 0, dirA = 0, valB = 0, dirB = 0;
+                if (jA < nk) {
+                    uint32_t e = stream_extract(S, jA, kmask);
                     uint32_t rev = e ^ comp_mask;
                     uint32_t fwd = digit_reverse(e, K);
-                    dir = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
-                    val = dir ? rev : fwd;
-                    uint64_t h = kmer_hash32(val);
-                    sel = (h < a.threshold) && (p >= 1u);     // first k-mer skipped (Kmer.hpp:1395)
-                    if (HAS_N) sel = sel && (istream_extract(SI, j, kbits) == 0u);   // Kmer.hpp:574-580
-                    if (sel && a.n_rep) sel = !rep_contains(a.rep, a.n_rep, val);    // Kmer.hpp:1437
+                    dirA = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
+                    valA = dirA ? rev : fwd;
+                    selA = (kmer_hash32(valA) < a.threshold) && (hp_base + jA >= 1u);   // first k-mer skipped (Kmer.hpp:1395)
+                    if (HAS_N) selA = selA && (istream_extract(SI, jA, kbits) == 0u);   // Kmer.hpp:574-580
                 }
-                unsigned long long bal = __ballot(sel);
-                if (bal) {
-                    if (sel) {
-                        uint32_t idx = nout + (uint32_t)__popcll(bal & lanemask_lt());
-                        if (idx < cap) {
-                            a.out_min[cap0 + idx] = val;
-                            a.out_pos[cap0 + idx] = p;
-                            a.out_dir[cap0 + idx] = (uint8_t)dir;
-                            if (HAS_QUAL) {
-                                uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
-                                if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
-                                else { os = p; oe = p + K; }
-                                if (a.inline_minq) {
-                                    const uint8_t *qq = a.qual + a.qual_off[r];
-                                    uint8_t mq = 255;   // getMinQuality (ReadSelection.hpp:1302-1320)
-                                    for (uint32_t b = os; b < oe; b++) { uint8_t q = (uint8_t)(qq[b] - 33); if (q < mq) mq = q; }
-                                    a.out_mqual[cap0 + idx] = mq;
-                                } else {
-                                    a.out_os[cap0 + idx] = os;
-                                    a.out_oe[cap0 + idx] = oe;
+                if (jB < nk) {
+                    uint32_t e = stream_extract(S, jB, kmask);
+                    uint32_t rev = e ^ comp_mask;
+                    uint32_t fwd = digit_reverse(e, K);
+                    dirB = fwd < rev ? 0u : 1u;
+                    valB = dirB ? rev : fwd;
+                    selB = kmer_hash32(valB) < a.threshold;
+                    if (HAS_N) selB = selB && (istream_extract(SI, jB, kbits) == 0u);
+                }
+                unsigned long long balA = __ballot(selA), balB = __ballot(selB);
+                if (balA | balB) {
+                    if (a.n_rep) {   // Kmer.hpp:1437
+                        if (selA) selA = !rep_contains(a.rep, a.n_rep, valA);
+                        if (selB) selB = !rep_contains(a.rep, a.n_rep, valB);
+                        balA = __ballot(selA); balB = __ballot(selB);
+                    }
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const bool sel = half ? selB : selA;
+                        const unsigned long long bal = half ? balB : balA;
+                        const unsigned j = half ? jB : jA;
+                        const uint32_t val = half ? valB : valA, dir = half ? dirB : dirA;
+                        const uint32_t p = hp_base + j;
+                        if (sel) {
+                            uint32_t idx = nout + (uint32_t)__popcll(bal & lanemask_lt());
+                            if (idx < cap) {
+                                a.out_min[cap0 + idx] = val;
+                                a.out_pos[cap0 + idx] = p;
+                                a.out_dir[cap0 + idx] = (uint8_t)dir;
+                                if (HAS_QUAL) {
+                                    uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
+                                    if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
+                                    else { os = p; oe = p + K; }
+                                    if (a.inline_minq) {
+                                        const uint8_t *qq = a.qual + a.qual_off[r];
+                                        uint8_t mq = 255;   // getMinQuality (ReadSelection.hpp:1302-1320)
+                                        for (uint32_t b = os; b < oe; b++) { uint8_t q = (uint8_t)(qq[b] - 33); if (q < mq) mq = q; }
+                                        a.out_mqual[cap0 + idx] = mq;
+                                    } else {
+                                        a.out_os[cap0 + idx] = os;
+                                        a.out_oe[cap0 + idx] = oe;
+                                    }
                                 }
                             }
                         }
+                        nout += (uint32_t)__popcll(bal);
                     }
-                    nout += (uint32_t)__popcll(bal);
                 }
             }
 
@@ -452,10 +495,10 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
         uint8_t flags = 0;
         if (a.apply_filters && L >= 66) {
             uint32_t nW = (L - 66u) / 32u + 1u;
-            uint64_t bound = wave_sum_u64(cx_bound);
-            // bound/(61 nW) >= true mean score; only reads whose bound exceeds ~4.9 need the exact pass,
-            // which runs as its own (rare) kernel so its registers do not cap this kernel's occupancy
-            if (bound > 300ull * nW) flags |= READ_SUSPECT;
+            uint64_t bound = wave_sum_u64(cx_bound);    // sum_w (Q_w + Q_{w+1}); subtract 32 per window
+            // (bound - 32 nW)/(61 nW) >= true mean score; only reads whose bound exceeds ~4.9 need the exact
+            // pass, which runs as its own (rare) kernel so its registers do not cap this kernel's occupancy
+            if (bound > (300ull + 32ull) * nW) flags |= READ_SUSPECT;
         }
         if (lane == 0) {
             a.out_count[r] = nout;
