@@ -135,7 +135,7 @@ int  mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint3
  * abundance==1 skipped) ... */
 int  mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, uint64_t n_records, mdbg_table **out);
 /* ... then overlaid with the refined abundance of each unitig of unitigGraph_prev.nodes.bin
- * (unitigs as CSR; abundance[u] per unitig, 0 = unitig has no refined abundance and is skipped). */
+ * (unitigs as CSR; abundance[u] per unitig, 0xFFFFFFFF = unitig has no refined abundance and is skipped). */
 int  mdbg_prev_overlay_unitigs(mdbg_ctx *ctx, mdbg_table *prev, const mdbg_minimizers *unitigs,
                                const uint32_t *abundance, uint32_t k_prev);
 /* k = firstK+1: KminmerCounter with getRefinedAbundance (graph/CreateMdbg.hpp:3933-4005) over

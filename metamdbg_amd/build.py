@@ -55,7 +55,25 @@ def build_lib(force: bool = False, verbose: bool = False, tag: str = "", extra_f
         if r.returncode:
             print(r.stdout, r.stderr)
             raise RuntimeError("link of libmdbg_hip.so failed")
+    if not tag:
+        build_tool()
     return lib_path
+
+
+def build_tool() -> str:
+    """The C++ host tool (drop-in readSelection / graph over the C ABI), in-tree at metamdbg_amd/bin/mdbg_tool."""
+    src = os.path.join(HERE, "host", "mdbg_tool.cpp")
+    deps = [src, os.path.join(HERE, "host", "fastx.hpp"), os.path.join(HERE, "..", "include", "mdbg_hip.h"), LIB]
+    out = os.path.join(HERE, "bin", "mdbg_tool")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if _stale(out, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", src, "-o", out, "-L" + HERE, "-lmdbg_hip", "-lz",
+               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            print(r.stdout, r.stderr)
+            raise RuntimeError("g++ failed for mdbg_tool")
+    return out
 
 
 if __name__ == "__main__":

@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -18,6 +21,79 @@
 namespace mdbg {
 
 constexpr int WAVE = 64;
+
+// Size-class cache of device allocations.  hipMalloc / hipFree of GB-sized buffers cost milliseconds and
+// hipFree synchronises the device; a step of the hot path allocates the same few dozen buffers every
+// time, so freed blocks are kept and handed out again.  Everything a context launches goes to ONE
+// stream, so reusing a block is ordered after its previous users by stream order.  The pool is shared
+// (shared_ptr) by the context and every buffer it handed out, so handles may outlive the context.
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_list;        // capacity -> block
+    std::unordered_map<void *, size_t> capacity;    // every block this pool owns (free or handed out)
+    size_t cached_bytes = 0;
+    size_t cache_limit = (size_t)96 << 30;
+    int device = 0;
+    bool closed = false;
+
+    static size_t size_class(size_t bytes) {
+        if (bytes < 256) return 256;
+        size_t p2 = 256;
+        while (p2 * 2 <= bytes) p2 *= 2;            // largest power of two <= bytes
+        size_t step = p2 / 8;                       // 12.5 % granularity
+        return (bytes + step - 1) / step * step;
+    }
+    hipError_t get(size_t bytes, void **out) {
+        const size_t cap = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = free_list.lower_bound(cap);
+            if (it != free_list.end() && it->first <= cap + cap / 4) {
+                *out = it->second;
+                cached_bytes -= it->first;
+                free_list.erase(it);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, cap);
+        if (e != hipSuccess) {                      // out of memory: drop the cache and retry once
+            trim();
+            (void)hipGetLastError();
+            e = hipMalloc(out, cap);
+        }
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> g(mu);
+            capacity[*out] = cap;
+        }
+        return e;
+    }
+    void put(void *p) {
+        if (!p) return;
+        std::unique_lock<std::mutex> g(mu);
+        auto it = capacity.find(p);
+        size_t cap = it == capacity.end() ? 0 : it->second;
+        if (closed || cap == 0 || cached_bytes + cap > cache_limit) {
+            if (it != capacity.end()) capacity.erase(it);
+            g.unlock();
+            (void)hipFree(p);
+            return;
+        }
+        free_list.emplace(cap, p);
+        cached_bytes += cap;
+    }
+    void trim() {
+        std::vector<void *> victims;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto &kv : free_list) { victims.push_back(kv.second); capacity.erase(kv.second); }
+            free_list.clear();
+            cached_bytes = 0;
+        }
+        for (void *p : victims) (void)hipFree(p);
+    }
+    void close() { { std::lock_guard<std::mutex> g(mu); closed = true; } trim(); }
+    ~DevPool() { trim(); }
+};
 
 struct TimedLaunch {
     const char *name;
@@ -38,7 +114,8 @@ struct mdbg_ctx {
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
     // scratch kept between calls (partial-count rows handed out to the caller)
     void *partial_rows = nullptr;
-    uint32_t *d_work_counter = nullptr;                    // dynamic work distribution counter
+    double key_ratio_hint = 0.0625;                        // distinct keys per k-min-mer instance seen last time (table sizing)
+    std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out
 };
 
 namespace mdbg {
@@ -74,31 +151,32 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    std::shared_ptr<DevPool> pool;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), pool(std::move(o.pool)) { o.p = nullptr; o.n = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; pool = std::move(o.pool); o.p = nullptr; o.n = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) { if (pool) pool->put(p); else (void)hipFree(p); }
         p = nullptr; n = 0;
     }
     int alloc(mdbg_ctx *ctx, size_t count) {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        pool = ctx->pool;
+        hipError_t e = pool->get(count * sizeof(T), (void **)&p);
         if (e != hipSuccess) {
             p = nullptr;
-            return set_error(ctx, MDBG_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return set_error(ctx, MDBG_ENOMEM, "device allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
         }
         n = count;
         return MDBG_OK;
     }
-    T *detach() { T *q = p; p = nullptr; n = 0; return q; }
 };
 
 // Scoped kernel timer: records HIP events on ctx->stream around a launch when timing is on.

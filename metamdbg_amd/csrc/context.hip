@@ -62,11 +62,8 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) {
         delete ctx;
         return set_error(nullptr, MDBG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    if ((e = hipMalloc((void **)&ctx->d_work_counter, 64)) != hipSuccess) {
-        (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return set_error(nullptr, MDBG_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    }
+    ctx->pool = std::make_shared<DevPool>();
+    ctx->pool->device = device;
     *out = ctx;
     return MDBG_OK;
 }
@@ -76,7 +73,8 @@ extern "C" void mdbg_destroy(mdbg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     fold_timers(ctx);
     if (ctx->partial_rows) (void)hipFree(ctx->partial_rows);
-    if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pool) ctx->pool->close();      // cached blocks are freed now; blocks still handed out free themselves
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -60,8 +60,8 @@ __device__ __forceinline__ uint32_t table_upsert_count(const TableView &t, uint6
     if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, add, 0, false, rep, true);
     uint32_t s = table_find_or_insert(t, lo, hi, true);
     if (s != SLOT_NONE) {
-        if (add) atomicAdd(&t.val[s], add);
-        if (t.rep) t.rep[s] = rep;   // any instance of the key is a valid representative
+        if (add) atomicAdd(&t.slots[s].val, add);
+        t.slots[s].rep = rep;   // any instance of the key is a valid representative
     }
     return s;
 }
@@ -70,8 +70,8 @@ __device__ __forceinline__ uint32_t table_upsert_set(const TableView &t, uint64_
     if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, 0, v, true, rep, true);
     uint32_t s = table_find_or_insert(t, lo, hi, true);
     if (s != SLOT_NONE) {
-        __hip_atomic_store(&t.val[s], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t.rep) t.rep[s] = rep;
+        __hip_atomic_store(&t.slots[s].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t.slots[s].rep = rep;
     }
     return s;
 }
@@ -84,17 +84,35 @@ struct SeqView {
     uint64_t n_inst;
 };
 
+// Visit every instance with 16 lanes per sequence (4 sequences per wave): sequences hold a few dozen
+// windows, the minimizers of neighbouring windows are loaded coalesced, and no per-instance binary search
+// over the offsets is needed.  f(read, global instance id, pointer to the window's first minimizer).
+template <typename F>
+__device__ __forceinline__ void for_each_instance(const SeqView &s, F f) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        const uint64_t base = s.inst_off[r];
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - base);
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i = sub; i < n; i += 16) f((uint32_t)r, base + i, m0 + i);
+    }
+}
+
+static unsigned instance_grid(const mdbg_ctx *ctx, uint32_t n_reads) {
+    return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 32u);
+}
+
 // ---- first pass -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void count_insert_kernel(SeqView s, uint32_t k, TableView t, uint32_t *inst_slot,
                                                            uint64_t rep_base) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= s.n_inst) return;
-    uint32_t r = find_read(s.inst_off, s.n_reads, g);
-    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
-    uint64_t hi, lo;
-    window_hash(m, k, hi, lo);
-    uint32_t slot = table_upsert_count(t, lo, hi, 1u, (uint32_t)(rep_base + g));
-    if (inst_slot) inst_slot[g] = slot;
+    for_each_instance(s, [&](uint32_t, uint64_t g, const uint32_t *m) {
+        uint64_t hi, lo;
+        window_hash(m, k, hi, lo);
+        uint32_t slot = table_upsert_count(t, lo, hi, 1u, (uint32_t)(rep_base + g));
+        if (inst_slot) inst_slot[g] = slot;
+    });
 }
 
 // abundance seen by the rescue pass: solid count or 1 (graph/CreateMdbg.hpp:4590-4600)
@@ -108,46 +126,47 @@ __global__ __launch_bounds__(256) void inst_abundance_kernel(uint64_t n_inst, co
     ab[g] = solid ? c : 0u;   // 0 = not in the solid table
 }
 
-// one wave per read: median of the per-instance abundances (non-solid counted as 1), then flag the
-// non-solid instances of reads with median*0.1f <= 1 that have at least one solid k-min-mer
+// Rescue decision per read (graph/CreateMdbg.hpp:4590-4640) without sorting.  With m* the largest u32
+// whose float product m * 0.1f is not > 1 (computed on the host: 10), "median * 0.1f > 1" is false
+//   odd n : iff at least n/2+1 abundances are <= m*
+//   even n: iff at least n/2+1 are <= m*, or exactly n/2 are and (max{<= m*} + min{> m*}) / 2 passes the
+//           same float test (Utils::compute_median on u32, Commons.hpp:2972-2988)
+// 16 lanes per read (4 reads per wave): reads hold a few dozen k-min-mers.
 __global__ __launch_bounds__(256) void rescue_flag_kernel(const uint64_t *inst_off, uint32_t n_reads, const uint32_t *ab,
-                                                          uint32_t *flag) {
-    const unsigned lane = threadIdx.x & 63u;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t r = wave; r < n_reads; r += nwaves) {
-        const uint64_t f = inst_off[r];
-        const uint32_t n = (uint32_t)(inst_off[r + 1] - f);
-        if (n == 0) continue;
-        // all-ones test
-        bool any_solid = false;
-        for (uint32_t i = lane; i < n; i += 64) any_solid |= ab[f + i] != 0u;
-        any_solid = __ballot(any_solid) != 0ull;
-        bool rescue = false;
-        if (any_solid) {
-            // order statistics by rank counting: rank(i) = #{j : a_j < a_i or (a_j == a_i and j < i)}
-            const uint32_t want_hi = n / 2, want_lo = (n % 2 == 0) ? n / 2 - 1 : n / 2;
-            uint32_t v_hi = 0, v_lo = 0;
-            for (uint32_t base = 0; base < n; base += 64) {
-                uint32_t i = base + lane;
-                uint32_t ai = 0, rank = 0;
-                if (i < n) { ai = ab[f + i]; if (ai == 0) ai = 1; }
-                for (uint32_t j = 0; j < n; j++) {
-                    uint32_t aj = ab[f + j];
-                    if (aj == 0) aj = 1;
-                    rank += (aj < ai || (aj == ai && j < i)) ? 1u : 0u;
-                }
-                unsigned long long bh = __ballot(i < n && rank == want_hi);
-                unsigned long long bl = __ballot(i < n && rank == want_lo);
-                if (bh) v_hi = __shfl(ai, __ffsll((long long)bh) - 1, 64);
-                if (bl) v_lo = __shfl(ai, __ffsll((long long)bl) - 1, 64);
-            }
-            // Utils::compute_median on u32 (Commons.hpp:2972-2988): (a + b) / 2 in u32, or the middle
-            uint32_t median = (n % 2 == 0) ? (uint32_t)(v_lo + v_hi) / 2u : v_hi;
-            float cutoff = (float)median * 0.1f;          // graph/CreateMdbg.hpp:4610 (u32 * float)
-            rescue = !(cutoff > 1.0f);
+                                                          uint32_t m_star, uint32_t *flag) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r0 = 0; r0 < n_reads; r0 += ngroups) {     // uniform trip count: shuffles need all lanes
+        const uint64_t r = r0 + group;
+        const bool live = r < n_reads;
+        const uint64_t f = live ? inst_off[r] : 0;
+        const uint32_t n = live ? (uint32_t)(inst_off[r + 1] - f) : 0u;
+        uint32_t c_le = 0, mx_le = 0, mn_gt = 0xFFFFFFFFu, any_solid = 0;
+        for (uint32_t i = sub; i < n; i += 16) {
+            uint32_t a = ab[f + i];
+            any_solid |= (a != 0u);
+            if (a == 0u) a = 1u;                               // non-solid counts as 1 (CreateMdbg.hpp:4598)
+            if (a <= m_star) { c_le++; mx_le = a > mx_le ? a : mx_le; }
+            else mn_gt = a < mn_gt ? a : mn_gt;
         }
-        for (uint32_t i = lane; i < n; i += 64) flag[f + i] = (rescue && ab[f + i] == 0u) ? 1u : 0u;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {                     // reduce within the 16-lane group
+            c_le += __shfl_xor(c_le, d, 64);
+            uint32_t t = __shfl_xor(mx_le, d, 64); mx_le = t > mx_le ? t : mx_le;
+            t = __shfl_xor(mn_gt, d, 64); mn_gt = t < mn_gt ? t : mn_gt;
+            any_solid |= __shfl_xor(any_solid, d, 64);
+        }
+        bool rescue = false;
+        if (n && any_solid) {                                  // all-ones reads are skipped (:4612)
+            const uint32_t half = n / 2;
+            if (c_le >= half + 1) rescue = true;
+            else if ((n & 1u) == 0u && c_le == half) {
+                uint32_t median = (uint32_t)(mx_le + mn_gt) / 2u;
+                rescue = !((float)median * 0.1f > 1.0f);       // :4610
+            }
+        }
+        for (uint32_t i = sub; i < n; i += 16) flag[f + i] = (rescue && ab[f + i] == 0u) ? 1u : 0u;
     }
 }
 
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(256) void slot_flag_kernel(TableView t, uint64_t ca
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= cap + TABLE_EXC_CAP) return;
     bool occ; uint32_t v;
-    if (s < cap) { occ = t.lo[s] != 0ull; v = t.val[s]; }
+    if (s < cap) { occ = t.slots[s].lo != 0ull; v = t.slots[s].val; }
     else { uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; v = occ ? t.exc_val[i] : 0u; }
     bool keep = false;
     if (occ) {
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(256) void emit_slots_kernel(TableView t, uint64_t c
     if (s >= cap + TABLE_EXC_CAP || !flag[s]) return;
     uint64_t row = row_base + pos[s];
     uint32_t rep;
-    if (s < cap) { o.lo[row] = t.lo[s]; o.hi[row] = t.hi[s]; o.ab[row] = t.val[s]; rep = t.rep ? t.rep[s] : 0; }
+    if (s < cap) { const TableSlot &sl = t.slots[s]; o.lo[row] = sl.lo; o.hi[row] = sl.hi; o.ab[row] = sl.val; rep = sl.rep; }
     else { uint32_t i = (uint32_t)(s - cap); o.lo[row] = t.exc_lo[i]; o.hi[row] = t.exc_hi[i]; o.ab[row] = t.exc_val[i]; rep = t.exc_rep[i]; }
     if (o.vec) write_instance_vector(a, b, rep, o.k, o.vec + row * o.k);
 }
@@ -218,13 +237,11 @@ __global__ __launch_bounds__(256) void emit_rescued_kernel(SeqView s, uint32_t k
 // ---- k > firstK --------------------------------------------------------------------------------------
 // distinct keys of all k-windows (k = firstK+1)
 __global__ __launch_bounds__(256) void distinct_insert_kernel(SeqView s, uint32_t k, TableView t, uint64_t rep_base) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= s.n_inst) return;
-    uint32_t r = find_read(s.inst_off, s.n_reads, g);
-    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
-    uint64_t hi, lo;
-    window_hash(m, k, hi, lo);
-    table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + g));
+    for_each_instance(s, [&](uint32_t, uint64_t g, const uint32_t *m) {
+        uint64_t hi, lo;
+        window_hash(m, k, hi, lo);
+        table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + g));
+    });
 }
 
 // refined abundance of every distinct key (graph/CreateMdbg.hpp:3933-3970): min over the two
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t
     uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= cap + TABLE_EXC_CAP) return;
     bool occ; uint32_t rep;
-    if (s < cap) { occ = t.lo[s] != 0ull; rep = occ ? t.rep[s] : 0; }
+    if (s < cap) { occ = t.slots[s].lo != 0ull; rep = occ ? t.slots[s].rep : 0; }
     else { uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; rep = occ ? t.exc_rep[i] : 0; }
     if (!occ) return;
     const SeqView &sv = rep < a.n_inst ? a : b;
@@ -252,37 +269,32 @@ __global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t
             if (v < min_ab) min_ab = v;
         } else { min_ab = 1u; break; }
     }
-    if (s < cap) t.val[s] = min_ab; else t.exc_val[s - cap] = min_ab;
+    if (s < cap) t.slots[s].val = min_ab; else t.exc_val[s - cap] = min_ab;
 }
 
 // abundance of every (k-1)-window along the sequences (getPrevAbundances, graph/CreateMdbg.hpp:1240-1265)
 __global__ __launch_bounds__(256) void prev_abundance_kernel(SeqView s /* instances of size k-1 */, uint32_t km1, TableView prev,
                                                              uint32_t *out) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= s.n_inst) return;
-    uint32_t r = find_read(s.inst_off, s.n_reads, g);
-    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
-    uint64_t hi, lo;
-    window_hash(m, km1, hi, lo);
-    uint32_t v;
-    out[g] = table_lookup(prev, lo, hi, v) ? v : 1u;
+    for_each_instance(s, [&](uint32_t, uint64_t g, const uint32_t *m) {
+        uint64_t hi, lo;
+        window_hash(m, km1, hi, lo);
+        uint32_t v;
+        out[g] = table_lookup(prev, lo, hi, v) ? v : 1u;
+    });
 }
 
 // k-window i of read r gets min(prev[i], prev[i+1]); insert-if-absent when > 1 (graph/CreateMdbg.hpp:1440-1459)
 __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
                                                            uint32_t k, TableView t) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= s.n_inst) return;
-    uint32_t r = find_read(s.inst_off, s.n_reads, g);
-    uint64_t i = g - s.inst_off[r];
-    uint64_t j = inst_off_km1[r] + i;
-    uint32_t a0 = prev_ab[j], a1 = prev_ab[j + 1];
-    uint32_t a = a0 < a1 ? a0 : a1;
-    if (a <= 1u) return;
-    const uint32_t *m = s.mins + s.off[r] + i;
-    uint64_t hi, lo;
-    window_hash(m, k, hi, lo);
-    table_upsert_set(t, lo, hi, a, 0u);
+    for_each_instance(s, [&](uint32_t r, uint64_t g, const uint32_t *m) {
+        uint64_t j = inst_off_km1[r] + (g - s.inst_off[r]);
+        uint32_t a0 = prev_ab[j], a1 = prev_ab[j + 1];
+        uint32_t a = a0 < a1 ? a0 : a1;
+        if (a <= 1u) return;
+        uint64_t hi, lo;
+        window_hash(m, k, hi, lo);
+        table_upsert_set(t, lo, hi, a, 0u);
+    });
 }
 
 // ---- prev tables ---------------------------------------------------------------------------------------
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256) void overlay_kernel(SeqView s, uint32_t kprev,
     if (g >= s.n_inst) return;
     uint32_t r = find_read(s.inst_off, s.n_reads, g);
     uint32_t a = unitig_ab[r];
-    if (a == 0u) return;   // unitig without refined abundance
+    if (a == 0xFFFFFFFFu) return;   // unitig without refined abundance
     const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
     uint64_t hi, lo;
     window_hash(m, kprev, hi, lo);
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(256) void overlay_kernel(SeqView s, uint32_t kprev,
         // modify_if: set to 0 only when present
         if (lo == 0ull || hi == 0ull) { table_exc_upsert(t, lo, hi, 0, 0, true, 0, false); return; }
         uint32_t slot = table_find_or_insert(t, lo, hi, false);
-        if (slot != SLOT_NONE) __hip_atomic_store(&t.val[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot != SLOT_NONE) __hip_atomic_store(&t.slots[slot].val, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         table_upsert_set(t, lo, hi, a, 0u);
     }
@@ -341,6 +353,17 @@ __global__ void pack_records_kernel(const uint64_t *lo, const uint64_t *hi, cons
 }
 
 // ---- host helpers ------------------------------------------------------------------------------------------
+// largest median for which the reference's `double cutoff = median * 0.1f; if (cutoff > 1) return;` does not skip
+static uint32_t rescue_m_star() {
+    uint32_t m = 0;
+    for (;;) {
+        volatile float c = (float)(m + 1) * 0.1f;
+        if (c > 1.0f) break;
+        m++;
+    }
+    return m;
+}
+
 struct InstIndex {
     DevBuf<uint64_t> off;   // n_reads + 1
     uint64_t total = 0;
@@ -386,10 +409,10 @@ int mg_rescue_rows(mdbg_ctx *ctx, const mdbg_minimizers *reads, const uint64_t *
     if (n_inst) {
         MDBG_TRY(rflag.alloc(ctx, n_inst));
         MDBG_TRY(rpos.alloc(ctx, n_inst + 1));
-        unsigned blocks = grid_for((uint64_t)reads->n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
+        unsigned blocks = grid_for((uint64_t)reads->n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
         {
             LaunchTimer timer(ctx, "kminmer_rescue");
-            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, inst_off, reads->n_reads, ab, rflag.p);
+            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, inst_off, reads->n_reads, ab, rescue_m_star(), rflag.p);
         }
         MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, n_inst));
         MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + n_inst, 8, hipMemcpyDeviceToHost));
@@ -426,16 +449,19 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     const uint64_t I = ix.total;
     SeqView sv = make_view(reads, ix), none{};
     DeviceTable tab;
-    MDBG_TRY(tab.init(ctx, I + I / 2 + 1024, true));   // load factor <= 2/3 even if every instance is distinct
-    TableView tv = tab.view();
     DevBuf<uint32_t> inst_slot, ab, rflag, sflag;
     MDBG_TRY(inst_slot.alloc(ctx, I));
-    if (I) {
-        LaunchTimer timer(ctx, "kminmer_insert");
-        hipLaunchKernelGGL(count_insert_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, sv, k, tv, inst_slot.p, (uint64_t)0);
-    }
-    MDBG_HIP_CHECK(ctx, hipGetLastError());
-    MDBG_TRY(tab.check_overflow(ctx));
+    // distinct keys are usually a small fraction of the instances (coverage): start small so the table
+    // stays cache-resident, grow and rebuild when a probe sequence gets long
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
+        if (I) {
+            LaunchTimer timer(ctx, "kminmer_insert");
+            hipLaunchKernelGGL(count_insert_kernel, dim3(instance_grid(ctx, sv.n_reads)), dim3(256), 0, ctx->stream, sv, k, v, inst_slot.p, (uint64_t)0);
+        }
+        return MDBG_OK;
+    }));
+    if (I) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)I;
+    TableView tv = tab.view();
 
     // solid rows
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
@@ -459,8 +485,8 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
         {
             LaunchTimer timer(ctx, "kminmer_rescue");
             hipLaunchKernelGGL(inst_abundance_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, I, inst_slot.p, tv, min_abundance, ab.p);
-            unsigned blocks = grid_for((uint64_t)reads->n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
-            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.off.p, reads->n_reads, ab.p, rflag.p);
+            unsigned blocks = grid_for((uint64_t)reads->n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
+            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.off.p, reads->n_reads, ab.p, rescue_m_star(), rflag.p);
         }
         MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, I));
         MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
@@ -488,7 +514,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
 static int ensure_lookup(mdbg_ctx *ctx, mdbg_table *t, bool skip_one) {
     if (t->lookup) return MDBG_OK;
     std::unique_ptr<DeviceTable> tab(new DeviceTable());
-    MDBG_TRY(tab->init(ctx, t->n_records * 2 + 1024, false));
+    MDBG_TRY(tab->init(ctx, t->n_records * 2 + 1024));
     if (t->n_records)
         hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(t->n_records, 256)), dim3(256), 0, ctx->stream,
                            t->d_lo.p, t->d_hi.p, t->d_ab.p, t->n_records, skip_one ? 1 : 0, tab->view());
@@ -514,7 +540,7 @@ extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, u
     }
     // headroom: the unitig overlay may add keys that are not in the record file
     std::unique_ptr<DeviceTable> tab(new DeviceTable());
-    if ((rc = tab->init(ctx, n_records * 3 + 4096, false))) return fail(rc);
+    if ((rc = tab->init(ctx, n_records * 3 + 4096))) return fail(rc);
     if (n_records)
         hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(n_records, 256)), dim3(256), 0, ctx->stream,
                            t->d_lo.p, t->d_hi.p, t->d_ab.p, n_records, 1, tab->view());
@@ -567,15 +593,14 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     const uint64_t I = ia.total + ib.total;
     if (I >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 k-min-mer instances in one call");
     DeviceTable tab;
-    MDBG_TRY(tab.init(ctx, I + I / 2 + 1024, true));
-    TableView tv = tab.view();
-    {
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
         LaunchTimer timer(ctx, "kminmer_insert");
-        if (a.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(grid_for(a.n_inst, 256)), dim3(256), 0, ctx->stream, a, k, tv, (uint64_t)0);
-        if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(grid_for(b.n_inst, 256)), dim3(256), 0, ctx->stream, b, k, tv, a.n_inst);
-    }
-    MDBG_HIP_CHECK(ctx, hipGetLastError());
-    MDBG_TRY(tab.check_overflow(ctx));
+        if (a.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, a.n_reads)), dim3(256), 0, ctx->stream, a, k, v, (uint64_t)0);
+        if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, b.n_reads)), dim3(256), 0, ctx->stream, b, k, v, a.n_inst);
+        return MDBG_OK;
+    }));
+    if (I) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)I;
+    TableView tv = tab.view();
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
     DevBuf<uint64_t> spos;
@@ -615,11 +640,11 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
     {
         LaunchTimer timer(ctx, "kminmer_prev_lookup");
-        hipLaunchKernelGGL(prev_abundance_kernel, dim3(grid_for(ikm1.total, 256)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        hipLaunchKernelGGL(prev_abundance_kernel, dim3(instance_grid(ctx, vkm1.n_reads)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
     }
     {
         LaunchTimer timer(ctx, "kminmer_insert");
-        hipLaunchKernelGGL(index_insert_kernel, dim3(grid_for(ik.total, 256)), dim3(256), 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        hipLaunchKernelGGL(index_insert_kernel, dim3(instance_grid(ctx, vk.n_reads)), dim3(256), 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;
@@ -636,11 +661,13 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     // upper bound on distinct keys: total k-windows
     uint64_t bound = reads->n_min + (unitigs ? unitigs->n_min : 0);
     DeviceTable tab;
-    MDBG_TRY(tab.init(ctx, bound + bound / 2 + 1024, false));
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)bound * ctx->key_ratio_hint), bound, [&](TableView v) {
+        MDBG_TRY(index_one_set(ctx, reads, k, pv, v));
+        if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, v));
+        return MDBG_OK;
+    }));
+    if (bound) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)bound;
     TableView tv = tab.view();
-    MDBG_TRY(index_one_set(ctx, reads, k, pv, tv));
-    if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, tv));
-    MDBG_TRY(tab.check_overflow(ctx));
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
     DevBuf<uint64_t> spos;

@@ -17,37 +17,57 @@ __device__ __forceinline__ bool window_is_palindrome(const uint32_t *a, uint32_t
     return true;
 }
 
-// One lane per read.  A palindromic window of length k >= 2 needs m[c]==m[c+1] (even k) or
-// m[c-1]==m[c+1] (odd k) at its centre, so reads without such a pair are untouched (the common
-// case).  Otherwise replay the reference: smallest k, then smallest i whose window of k surviving
-// minimizers is a palindrome -> drop its first element -> restart, until none is left.  Dropping
-// from a compacted copy is equivalent to the reference's banned-position bookkeeping.
-__global__ __launch_bounds__(256) void purge_kernel(const uint64_t *off, uint32_t n_reads, uint32_t *work /* copy of mins */,
-                                                    uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+// A palindromic window of length k >= 2 needs m[c]==m[c+1] (even k) or m[c-1]==m[c+1] (odd k) at its
+// centre, so reads without such a pair are untouched (the common case).  16 lanes per read look for
+// one; suspects are listed for the serial pass.
+__global__ __launch_bounds__(256) void purge_detect_kernel(const uint64_t *off, uint32_t n_reads, const uint32_t *mins,
+                                                           uint32_t *new_count, uint32_t *list, uint32_t *n_list) {
+    const unsigned sub = threadIdx.x & 15u;
+    const unsigned gshift = (threadIdx.x & 63u) & ~15u;           // first lane of this 16-lane group in the wave
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r0 = 0; r0 < n_reads; r0 += ngroups) {
+        const uint64_t r = r0 + group;
+        const bool live = r < n_reads;
+        const uint64_t f = live ? off[r] : 0;
+        const uint32_t n = live ? (uint32_t)(off[r + 1] - f) : 0u;
+        bool suspect = false;
+        for (uint32_t i = sub; i + 1 < n; i += 16) {
+            uint32_t x = mins[f + i];
+            suspect |= (x == mins[f + i + 1]) || (i + 2 < n && x == mins[f + i + 2]);
+        }
+        unsigned long long bal = __ballot(suspect);
+        bool any = ((bal >> gshift) & 0xFFFFull) != 0ull;
+        if (live && sub == 0) {
+            new_count[r] = n;
+            if (any) list[atomicAdd(n_list, 1u)] = (uint32_t)r;
+        }
+    }
+}
+
+// Serial replay of the reference for the listed reads: smallest k, then smallest i whose window of k
+// surviving minimizers is a palindrome -> drop its first element -> restart, until none is left.
+// Dropping from a compacted copy is equivalent to the reference's banned-position bookkeeping.
+__global__ __launch_bounds__(64) void purge_fix_kernel(const uint64_t *off, const uint32_t *list, uint32_t n_list, uint32_t *work,
+                                                       uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
+    uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    const uint32_t r = list[li];
     uint32_t *a = work + off[r];
     uint32_t n = (uint32_t)(off[r + 1] - off[r]);
-    bool suspect = false;
-    for (uint32_t i = 0; i + 1 < n; i++) {
-        uint32_t x = a[i];
-        if (x == a[i + 1] || (i + 2 < n && x == a[i + 2])) { suspect = true; break; }
-    }
-    if (suspect) {
-        for (;;) {
-            bool hit = false;
-            for (uint32_t k = first_k; k < last_k && k <= n && !hit; k++) {
-                for (uint32_t i = 0; i + k <= n; i++) {
-                    if (window_is_palindrome(a + i, k)) {
-                        for (uint32_t j = i; j + 1 < n; j++) a[j] = a[j + 1];
-                        n--;
-                        hit = true;
-                        break;
-                    }
+    for (;;) {
+        bool hit = false;
+        for (uint32_t k = first_k; k < last_k && k <= n && !hit; k++) {
+            for (uint32_t i = 0; i + k <= n; i++) {
+                if (window_is_palindrome(a + i, k)) {
+                    for (uint32_t j = i; j + 1 < n; j++) a[j] = a[j + 1];
+                    n--;
+                    hit = true;
+                    break;
                 }
             }
-            if (!hit) break;
         }
+        if (!hit) break;
     }
     new_count[r] = n;
 }
@@ -160,10 +180,11 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
     if (!ctx || !in || !out || first_k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_purge_palindromes: bad argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = in->n_reads;
-    DevBuf<uint32_t> work, cnt;
-    MDBG_TRY(work.alloc(ctx, in->n_min));
+    DevBuf<uint32_t> cnt, list, n_list;
     MDBG_TRY(cnt.alloc(ctx, n));
-    if (in->n_min) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(work.p, in->d_min.p, in->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    MDBG_TRY(list.alloc(ctx, n));
+    MDBG_TRY(n_list.alloc(ctx, 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(n_list.p, 0, 4, ctx->stream));
     mdbg_minimizers *m = new mdbg_minimizers();
     auto fail = [&](int rc) { delete m; return rc; };
     m->n_reads = n;
@@ -171,16 +192,39 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
     if ((rc = m->d_off.alloc(ctx, (size_t)n + 1))) return fail(rc);
     if (n) {
         LaunchTimer timer(ctx, "purge_palindromes");
-        hipLaunchKernelGGL(purge_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in->d_off.p, n, work.p, first_k, last_k, cnt.p);
+        unsigned blocks = grid_for((uint64_t)n * 16, 256, (unsigned)ctx->n_cu * 16u);
+        hipLaunchKernelGGL(purge_detect_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, n, in->d_min.p, cnt.p, list.p, n_list.p);
     }
-    if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
-    hipError_t e = memcpy_sync(ctx, &m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
-    if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
-    if (n) {
+    uint32_t n_suspect = 0;
+    hipError_t e = memcpy_sync(ctx, &n_suspect, n_list.p, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge suspect count copy failed: %s", hipGetErrorString(e)));
+    if (n_suspect == 0) {
+        // nothing to purge: the output is a copy of the input
+        m->n_min = in->n_min;
+        if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
+        LaunchTimer timer(ctx, "purge_palindromes");
+        e = hipMemcpyAsync(m->d_off.p, in->d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && m->n_min) e = hipMemcpyAsync(m->d_min.p, in->d_min.p, m->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
+    } else {
+        DevBuf<uint32_t> work;
+        if ((rc = work.alloc(ctx, in->n_min))) return fail(rc);
+        {
+            LaunchTimer timer(ctx, "purge_palindromes");
+            e = hipMemcpyAsync(work.p, in->d_min.p, in->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
+            hipLaunchKernelGGL(purge_fix_kernel, dim3(grid_for(n_suspect, 64)), dim3(64), 0, ctx->stream, in->d_off.p, list.p, n_suspect,
+                               work.p, first_k, last_k, cnt.p);
+        }
+        if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
+        e = memcpy_sync(ctx, &m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
+        if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
         unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 16u);
         LaunchTimer timer(ctx, "purge_palindromes");
         hipLaunchKernelGGL(gather_prefix_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, m->d_off.p, n, work.p, m->d_min.p);
+        e = hipStreamSynchronize(ctx->stream);   // `work` goes back to the pool on return
+        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));

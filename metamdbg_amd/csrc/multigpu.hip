@@ -63,14 +63,15 @@ __global__ __launch_bounds__(256) void mg_count_insert_kernel(const uint32_t *mi
     mg_window_hash(m, k, hi, lo);
     if (lo == 0ull || hi == 0ull) { table_exc_upsert(t, lo, hi, 1u, 0, false, (uint32_t)g, true); return; }
     uint32_t s = table_find_or_insert(t, lo, hi, true);
-    if (s != SLOT_NONE) { atomicAdd(&t.val[s], 1u); t.rep[s] = (uint32_t)g; }
+    if (s != SLOT_NONE) { atomicAdd(&t.slots[s].val, 1u); t.slots[s].rep = (uint32_t)g; }
 }
 
 __device__ __forceinline__ bool slot_read(const TableView &t, uint64_t cap, uint64_t s, uint64_t &lo, uint64_t &hi, uint32_t &v, uint32_t &rep) {
     if (s < cap) {
-        lo = t.lo[s];
+        const TableSlot &sl = t.slots[s];
+        lo = sl.lo;
         if (lo == 0ull) return false;
-        hi = t.hi[s]; v = t.val[s]; rep = t.rep ? t.rep[s] : 0u;
+        hi = sl.hi; v = sl.val; rep = sl.rep;
         return true;
     }
     uint32_t i = (uint32_t)(s - cap);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void rows_add_kernel(const uint64_t *rows, uin
     uint32_t c = (uint32_t)r[2];
     if (lo == 0ull || hi == 0ull) { table_exc_upsert(t, lo, hi, c, 0, false, (uint32_t)i, true); return; }
     uint32_t s = table_find_or_insert(t, lo, hi, true);
-    if (s != SLOT_NONE) { atomicAdd(&t.val[s], c); t.rep[s] = (uint32_t)i; }
+    if (s != SLOT_NONE) { atomicAdd(&t.slots[s].val, c); t.slots[s].rep = (uint32_t)i; }
 }
 
 __global__ __launch_bounds__(256) void mg_flag_kernel(TableView t, uint64_t cap, uint32_t min_abundance, int solid_only,
@@ -214,15 +215,16 @@ extern "C" int mdbg_kminmer_partial_counts(mdbg_ctx *ctx, const mdbg_minimizers 
     uint64_t I = 0;
     MDBG_TRY(mg_inst_index(ctx, reads, k, inst_off, I));
     DeviceTable tab;
-    MDBG_TRY(tab.init(ctx, I + I / 2 + 1024, true));
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
+        if (I) {
+            LaunchTimer timer(ctx, "kminmer_insert");
+            hipLaunchKernelGGL(mg_count_insert_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, reads->d_min.p, reads->d_off.p,
+                               inst_off.p, reads->n_reads, I, k, v);
+        }
+        return MDBG_OK;
+    }));
+    if (I) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)I;
     TableView tv = tab.view();
-    if (I) {
-        LaunchTimer timer(ctx, "kminmer_insert");
-        hipLaunchKernelGGL(mg_count_insert_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, reads->d_min.p, reads->d_off.p,
-                           inst_off.p, reads->n_reads, I, k, tv);
-    }
-    MDBG_HIP_CHECK(ctx, hipGetLastError());
-    MDBG_TRY(tab.check_overflow(ctx));
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<unsigned long long> hist;
     MDBG_TRY(hist.alloc(ctx, 64));
@@ -254,7 +256,7 @@ extern "C" int mdbg_reduce_rows(mdbg_ctx *ctx, uint64_t *d_rows, uint64_t n_rows
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t rw = row_words_for(k);
     DeviceTable tab;
-    MDBG_TRY(tab.init(ctx, n_rows + n_rows / 2 + 1024, true));
+    MDBG_TRY(tab.init(ctx, n_rows * 2 + 1024));
     TableView tv = tab.view();
     if (n_rows) hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, ctx->stream, d_rows, n_rows, rw, tv);
     MDBG_HIP_CHECK(ctx, hipGetLastError());
@@ -286,7 +288,7 @@ extern "C" int mdbg_kminmer_count_first_merged(mdbg_ctx *ctx, const mdbg_minimiz
     const uint32_t rw = row_words_for(k);
     // global key -> count table (every key appears once in the reduced rows; duplicates would be summed)
     DeviceTable tab;
-    MDBG_TRY(tab.init(ctx, n_global_rows * 2 + 1024, true));
+    MDBG_TRY(tab.init(ctx, n_global_rows * 2 + 1024));
     TableView tv = tab.view();
     if (n_global_rows)
         hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_global_rows, 256)), dim3(256), 0, ctx->stream, d_global_rows, n_global_rows, rw, tv);

@@ -280,6 +280,9 @@ __device__ __forceinline__ uint32_t orig_of(const QualMap *q, unsigned s, unsign
     return tile_base + lo * 32u + (bit >> 1);
 }
 
+#ifndef SCAN_UNROLL
+#define SCAN_UNROLL 2      // k-mer positions per lane per trip of the hash loop
+#endif
 #ifndef SCAN_MIN_WAVES
 #define SCAN_MIN_WAVES 1   // waves per SIMD the register allocator must allow (tuning knob)
 #endif
@@ -341,7 +344,11 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             // window w = words w, w+1 (64 positions).  With a_v / b_v the 2-mer counts of the two words,
             // sum_v (a_v + b_v)^2 <= 2 (Q_w + Q_{w+1}),  Q = sum_v count^2, and 3-mer collisions <= 2-mer
             // collisions, so  S_w <= Q_w + Q_{w+1} - 32.  Each word's Q enters at most two windows.
+#if defined(SCAN_ABLATE) && SCAN_ABLATE == 3
+            if (false) {                                                                          // ablation: no complexity bound
+#else
             if (a.apply_filters) {
+#endif
                 uint32_t nb = (uint32_t)__shfl_down((uint32_t)x & 3u, 1, 64);      // first base of the next word
                 uint32_t nb0 = (uint32_t)__shfl((uint32_t)x_next & 3u, 0, 64);
                 if (lane == 63) nb = nb0;
@@ -413,50 +420,55 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             const unsigned nk = tot > K ? tot - K : 0u;
             const uint32_t hp_base = hp_total - cb;    // compressed-stream position of S base 0
             const uint32_t tile_base = t * TILE_WORDS * 32u;
-            // two independent positions per lane and trip: the two hash chains interleave (ILP) and the
-            // loop / ballot overhead is paid once per 128 positions
-            for (unsigned j0 = 0; j0 < nk; j0 += 128) {
-                const unsigned jA = j0 + lane, jB = jA + 64;
-                bool selA = false, selB = false;
-                uint32_t valA = 0, dirA = 0, valB = 0, dirB = 0;
-                if (jA < nk) {
-                    uint32_t e = stream_extract(S, jA, kmask);
+            // SCAN_UNROLL independent positions per lane and trip: the hash chains interleave (ILP) and the
+            // loop / ballot overhead is paid once per 64 * SCAN_UNROLL positions.  Branch-free: out-of-range
+            // lanes recompute the last valid position and are masked.
+#if defined(SCAN_ABLATE) && SCAN_ABLATE == 2
+            for (unsigned j0 = 0; j0 < 0; j0 += 64 * SCAN_UNROLL) {                              // ablation: no k-mer loop
+#else
+            for (unsigned j0 = 0; j0 < nk; j0 += 64 * SCAN_UNROLL) {
+#endif
+                bool sel[SCAN_UNROLL];
+                uint32_t val[SCAN_UNROLL], dir[SCAN_UNROLL];
+                unsigned long long bal[SCAN_UNROLL];
+                unsigned long long any = 0;
+#pragma unroll
+                for (int u = 0; u < SCAN_UNROLL; u++) {
+                    const unsigned j = j0 + 64u * u + lane;
+                    const unsigned jc = j < nk ? j : nk - 1u;
+                    uint32_t e = stream_extract(S, jc, kmask);
                     uint32_t rev = e ^ comp_mask;
                     uint32_t fwd = digit_reverse(e, K);
-                    dirA = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
-                    valA = dirA ? rev : fwd;
-                    selA = (kmer_hash32(valA) < a.threshold) && (hp_base + jA >= 1u);   // first k-mer skipped (Kmer.hpp:1395)
-                    if (HAS_N) selA = selA && (istream_extract(SI, jA, kbits) == 0u);   // Kmer.hpp:574-580
+                    dir[u] = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
+                    val[u] = dir[u] ? rev : fwd;
+                    // first k-mer of the read skipped (Kmer.hpp:1395)
+#if defined(SCAN_ABLATE) && SCAN_ABLATE == 1
+                    sel[u] = (val[u] == 0x12345u) && (j < nk);                                  // ablation: no hash
+#else
+                    sel[u] = (kmer_hash32(val[u]) < a.threshold) && (hp_base + j >= 1u) && (j < nk);
+#endif
+                    if (HAS_N) sel[u] = sel[u] && (istream_extract(SI, jc, kbits) == 0u);   // Kmer.hpp:574-580
                 }
-                if (jB < nk) {
-                    uint32_t e = stream_extract(S, jB, kmask);
-                    uint32_t rev = e ^ comp_mask;
-                    uint32_t fwd = digit_reverse(e, K);
-                    dirB = fwd < rev ? 0u : 1u;
-                    valB = dirB ? rev : fwd;
-                    selB = kmer_hash32(valB) < a.threshold;
-                    if (HAS_N) selB = selB && (istream_extract(SI, jB, kbits) == 0u);
-                }
-                unsigned long long balA = __ballot(selA), balB = __ballot(selB);
-                if (balA | balB) {
+#pragma unroll
+                for (int u = 0; u < SCAN_UNROLL; u++) { bal[u] = __ballot(sel[u]); any |= bal[u]; }
+                if (any) {
                     if (a.n_rep) {   // Kmer.hpp:1437
-                        if (selA) selA = !rep_contains(a.rep, a.n_rep, valA);
-                        if (selB) selB = !rep_contains(a.rep, a.n_rep, valB);
-                        balA = __ballot(selA); balB = __ballot(selB);
+#pragma unroll
+                        for (int u = 0; u < SCAN_UNROLL; u++) {
+                            if (sel[u]) sel[u] = !rep_contains(a.rep, a.n_rep, val[u]);
+                            bal[u] = __ballot(sel[u]);
+                        }
                     }
 #pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        const bool sel = half ? selB : selA;
-                        const unsigned long long bal = half ? balB : balA;
-                        const unsigned j = half ? jB : jA;
-                        const uint32_t val = half ? valB : valA, dir = half ? dirB : dirA;
+                    for (int u = 0; u < SCAN_UNROLL; u++) {
+                        const unsigned j = j0 + 64u * u + lane;
                         const uint32_t p = hp_base + j;
-                        if (sel) {
-                            uint32_t idx = nout + (uint32_t)__popcll(bal & lanemask_lt());
+                        if (sel[u]) {
+                            uint32_t idx = nout + (uint32_t)__popcll(bal[u] & lanemask_lt());
                             if (idx < cap) {
-                                a.out_min[cap0 + idx] = val;
+                                a.out_min[cap0 + idx] = val[u];
                                 a.out_pos[cap0 + idx] = p;
-                                a.out_dir[cap0 + idx] = (uint8_t)dir;
+                                a.out_dir[cap0 + idx] = (uint8_t)dir[u];
                                 if (HAS_QUAL) {
                                     uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
                                     if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
                                 }
                             }
                         }
-                        nout += (uint32_t)__popcll(bal);
+                        nout += (uint32_t)__popcll(bal[u]);
                     }
                 }
             }

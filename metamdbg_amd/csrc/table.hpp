@@ -18,11 +18,20 @@ namespace mdbg {
 constexpr uint32_t TABLE_EXC_CAP = 64;
 constexpr uint32_t SLOT_NONE = 0xFFFFFFFFu;
 
+// One slot = 32 bytes, half a 64-byte sector: key, value and representative arrive with ONE memory
+// transaction per probe (the SoA layout of round 1 touched four sectors per insert).
+struct alignas(32) TableSlot {
+    unsigned long long lo;    // 0 = empty
+    unsigned long long hi;    // 0 = not yet published
+    uint32_t val;             // count / abundance
+    uint32_t rep;             // a representative instance id
+    uint32_t pad[2];
+};
+
+constexpr uint32_t TABLE_MAX_PROBES = 96;   // longer probe sequences mean the table is too full: grow and rebuild
+
 struct TableView {
-    unsigned long long *lo;   // cap
-    unsigned long long *hi;   // cap
-    uint32_t *val;            // cap: count / abundance
-    uint32_t *rep;            // cap: a representative instance id (may be nullptr)
+    TableSlot *slots;         // cap
     uint64_t mask;            // cap - 1
     // side list for keys with a zero word
     unsigned long long *exc_lo, *exc_hi;
@@ -84,22 +93,23 @@ __device__ inline uint32_t table_exc_upsert(const TableView &t, uint64_t lo, uin
 // or SLOT_NONE when create == false and the key is absent / the table is full.
 __device__ __forceinline__ uint32_t table_find_or_insert(const TableView &t, uint64_t lo, uint64_t hi, bool create) {
     uint64_t s = table_home(lo, hi, t.mask);
-    for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
-        unsigned long long cur = __hip_atomic_load(&t.lo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
+    for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
+        unsigned long long cur = __hip_atomic_load(&t.slots[s].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0ull) {
             if (!create) return SLOT_NONE;
-            cur = atomicCAS(&t.lo[s], 0ull, (unsigned long long)lo);
+            cur = atomicCAS(&t.slots[s].lo, 0ull, (unsigned long long)lo);
             if (cur == 0ull) cur = lo;
         }
         if (cur != lo) continue;
-        unsigned long long h = __hip_atomic_load(&t.hi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long h = __hip_atomic_load(&t.slots[s].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (h == 0ull) {
             if (!create) {
                 // slot claimed by a concurrent inserter of some key with the same low word: during a
                 // build this cannot be told apart from "absent"; pure lookups never race with builds
                 return SLOT_NONE;
             }
-            h = atomicCAS(&t.hi[s], 0ull, (unsigned long long)hi);
+            h = atomicCAS(&t.slots[s].hi, 0ull, (unsigned long long)hi);
             if (h == 0ull) h = hi;
         }
         if (h == hi) return (uint32_t)s;
@@ -117,16 +127,18 @@ __device__ __forceinline__ bool table_lookup(const TableView &t, uint64_t lo, ui
         return false;
     }
     uint64_t s = table_home(lo, hi, t.mask);
-    for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
-        unsigned long long cur = t.lo[s];
+    const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
+    for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
+        const TableSlot &sl = t.slots[s];
+        unsigned long long cur = sl.lo;
         if (cur == 0ull) return false;
-        if (cur == lo && t.hi[s] == hi) { val = t.val[s]; return true; }
+        if (cur == lo && sl.hi == hi) { val = sl.val; return true; }
     }
-    return false;
+    return false;   // inserts never place a key beyond the probe limit
 }
 
 __device__ __forceinline__ uint32_t table_slot_val(const TableView &t, uint32_t slot) {
-    return (slot & 0x80000000u) ? t.exc_val[slot & 0x7FFFFFFFu] : t.val[slot];
+    return (slot & 0x80000000u) ? t.exc_val[slot & 0x7FFFFFFFu] : t.slots[slot].val;
 }
 
 #endif  // __HIPCC__
@@ -134,42 +146,67 @@ __device__ __forceinline__ uint32_t table_slot_val(const TableView &t, uint32_t 
 // Host-side owner of the table storage.
 struct DeviceTable {
     uint64_t cap = 0;
-    DevBuf<unsigned long long> lo, hi, exc_lo, exc_hi;
-    DevBuf<uint32_t> val, rep, exc_val, exc_rep, ctl;  // ctl: [0]=exc_n [1]=exc_lock [2]=overflow
+    DevBuf<TableSlot> slots;
+    DevBuf<unsigned long long> exc_lo, exc_hi;
+    DevBuf<uint32_t> exc_val, exc_rep, ctl;  // ctl: [0]=exc_n [1]=exc_lock [2]=overflow
 
-    int init(mdbg_ctx *ctx, uint64_t min_slots, bool with_rep) {
+    int init(mdbg_ctx *ctx, uint64_t min_slots) {
         cap = 1024;
         while (cap < min_slots) cap <<= 1;
         if (cap > (1ull << 31)) return set_error(ctx, MDBG_ERANGE, "hash table of %llu slots exceeds 2^31", (unsigned long long)cap);
-        MDBG_TRY(lo.alloc(ctx, cap));
-        MDBG_TRY(hi.alloc(ctx, cap));
-        MDBG_TRY(val.alloc(ctx, cap));
-        if (with_rep) MDBG_TRY(rep.alloc(ctx, cap));
+        MDBG_TRY(slots.alloc(ctx, cap));
         MDBG_TRY(exc_lo.alloc(ctx, TABLE_EXC_CAP));
         MDBG_TRY(exc_hi.alloc(ctx, TABLE_EXC_CAP));
         MDBG_TRY(exc_val.alloc(ctx, TABLE_EXC_CAP));
         MDBG_TRY(exc_rep.alloc(ctx, TABLE_EXC_CAP));
         MDBG_TRY(ctl.alloc(ctx, 4));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(lo.p, 0, cap * 8, ctx->stream));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(hi.p, 0, cap * 8, ctx->stream));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(val.p, 0, cap * 4, ctx->stream));
+        return clear(ctx);
+    }
+    int clear(mdbg_ctx *ctx) {
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(slots.p, 0, cap * sizeof(TableSlot), ctx->stream));
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(exc_val.p, 0, TABLE_EXC_CAP * 4, ctx->stream));
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(ctl.p, 0, 16, ctx->stream));
         return MDBG_OK;
     }
     TableView view() const {
         TableView v;
-        v.lo = lo.p; v.hi = hi.p; v.val = val.p; v.rep = rep.p; v.mask = cap - 1;
+        v.slots = slots.p; v.mask = cap - 1;
         v.exc_lo = exc_lo.p; v.exc_hi = exc_hi.p; v.exc_val = exc_val.p; v.exc_rep = exc_rep.p;
         v.exc_n = ctl.p; v.exc_lock = ctl.p + 1; v.overflow = ctl.p + 2;
         return v;
     }
-    int check_overflow(mdbg_ctx *ctx) {
+    // 0 = fine, 1 = too full (caller grows and rebuilds), negative = error
+    int overflowed(mdbg_ctx *ctx) {
         uint32_t c[4];
         MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, c, ctl.p, 16, hipMemcpyDeviceToHost));
-        if (c[2]) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow (cap %llu)", (unsigned long long)cap);
+        return c[2] ? 1 : 0;
+    }
+    int check_overflow(mdbg_ctx *ctx) {
+        int o = overflowed(ctx);
+        if (o < 0) return o;
+        if (o) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow (cap %llu)", (unsigned long long)cap);
         return MDBG_OK;
     }
 };
+
+// Build a table with a capacity guessed from `expected` keys and grow x4 until `fill` (which launches
+// the insert kernels) completes without a probe sequence exceeding TABLE_MAX_PROBES.
+template <typename Fill>
+int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uint64_t upper_bound, Fill fill) {
+    uint64_t want = expected * 2 + 1024;
+    const uint64_t most = upper_bound + upper_bound / 2 + 1024;   // load <= 2/3 even if every key is distinct
+    if (want > most) want = most;
+    for (;;) {
+        MDBG_TRY(tab.init(ctx, want));
+        MDBG_TRY(fill(tab.view()));
+        MDBG_HIP_CHECK(ctx, hipGetLastError());
+        int o = tab.overflowed(ctx);
+        if (o < 0) return o;
+        if (!o) return MDBG_OK;
+        if (tab.cap >= most) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow at %llu slots", (unsigned long long)tab.cap);
+        want = tab.cap * 4;
+        if (want > most) want = most;
+    }
+}
 
 }  // namespace mdbg

@@ -1,0 +1,455 @@
+// mdbg_tool.cpp -- C++ host side over the C ABI (include/mdbg_hip.h): drop-in producers of the
+// reference's on-disk products for the minimizer + k-min-mer path, same argv as the reference's
+// sub-commands:
+//
+//   mdbg_tool readSelection <tmpDir> <outFile> <inputList> --threads N --min-read-quality F
+//                           [--output-quality] [--skip-correction]
+//       (readSelection/ReadSelection.hpp:113-246, :251-303)  writes read_data_init.txt, read_stats.txt,
+//       repetitiveMinimizers.bin and, for HiFi or --skip-correction, read_data_corrected.txt
+//   mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass]
+//       (graph/CreateMdbg.cpp:11-166, :199-598 up to the tables) writes kminmerData_min.txt,
+//       kminmerData_abundance.txt (+ _init copies); it stops where the reference goes on to build
+//       the graph (createGfa / computeNextUnitigGraph are out of scope).
+//
+// Both read <tmpDir>/parameters.gz and write <tmpDir>/perf.bin like Tool::end (Commons.hpp:8088-8107).
+// Exit status: 0 on success, 1 on any failure (the parent aborts on non-zero, Commons.hpp:2862-2876).
+// All compute goes through libmdbg_hip.so; there is no CPU fallback.
+#include <sys/resource.h>
+#include <sys/time.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/mdbg_hip.h"
+#include "fastx.hpp"
+
+namespace {
+
+[[noreturn]] void die(const std::string &msg) {
+    fprintf(stderr, "mdbg_tool: %s\n", msg.c_str());
+    exit(1);
+}
+
+mdbg_ctx *g_ctx = nullptr;
+void check(int rc, const char *what) {
+    if (rc != MDBG_OK) die(std::string(what) + ": " + mdbg_last_error(g_ctx));
+}
+
+// ---- parameters.gz (pipeline/AssemblyPipeline.hpp:1479-1517 / Commons.hpp:1475-1497) -----------------
+struct Parameters {
+    size_t minimizerSize = 0, kminmerSize = 0;
+    float densityAssembly = 0;
+    size_t firstK = 0;
+    float spacingMean = 0, kLenMean = 0, kOvlMean = 0;
+    size_t prevK = 0, lastK = 0, meanReadLength = 0;
+    float densityCorrection = 0;
+    bool hpc = false;
+    int dataType = 0;
+    size_t snpmerSize = 0;
+
+    void load(const std::string &path) {
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) die("cannot open " + path);
+        auto rd = [&](void *p, unsigned n) { if (gzread(f, p, n) != (int)n) die("short read of " + path); };
+        rd(&minimizerSize, sizeof(size_t)); rd(&kminmerSize, sizeof(size_t)); rd(&densityAssembly, sizeof(float));
+        rd(&firstK, sizeof(size_t)); rd(&spacingMean, sizeof(float)); rd(&kLenMean, sizeof(float)); rd(&kOvlMean, sizeof(float));
+        rd(&prevK, sizeof(size_t)); rd(&lastK, sizeof(size_t)); rd(&meanReadLength, sizeof(size_t));
+        rd(&densityCorrection, sizeof(float)); rd(&hpc, sizeof(bool)); rd(&dataType, sizeof(int)); rd(&snpmerSize, sizeof(size_t));
+        gzclose(f);
+    }
+};
+
+std::vector<uint8_t> read_file(const std::string &path, bool required = true) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { if (required) die("File not found: " + path); return {}; }
+    f.seekg(0, std::ios::end);
+    std::vector<uint8_t> v((size_t)f.tellg());
+    f.seekg(0);
+    if (!v.empty()) f.read((char *)v.data(), (std::streamsize)v.size());
+    return v;
+}
+
+// Utils::computeN50 / computeMeanLength / Commons::computeLastK (Commons.hpp:2291-2336, :1726-1741)
+uint32_t compute_n50(std::vector<uint32_t> len) {
+    if (len.empty()) return 0;
+    std::sort(len.begin(), len.end(), std::greater<uint32_t>());
+    std::vector<uint64_t> cum(len.size());
+    uint64_t c = 0;
+    for (size_t i = 0; i < len.size(); i++) { c += len[i]; cum[i] = c; }
+    const size_t n = len.size();
+    uint32_t n50 = len[0];
+    const uint64_t half = cum[n - 1] / 2;
+    for (size_t i = 0; i < n; i++) if (cum[n - 1 - i] < half) { n50 = len[n - 1 - i]; break; }
+    return n50;
+}
+uint32_t compute_mean_length(const std::vector<uint32_t> &len) {
+    long double sum = 0, n = 0;
+    for (uint32_t l : len) { sum += l; n += 1; }
+    return (uint32_t)(uint64_t)(sum / n);
+}
+int compute_last_k(float density, size_t n50, size_t firstK, size_t maxK) {
+    size_t lastK = (size_t)(n50 * density * 2.0f);
+    if (maxK > 0) lastK = maxK;
+    lastK = std::max(lastK, firstK + 2);
+    return (int)lastK;
+}
+
+void write_perf(const std::string &tmpDir) {   // Tool::end
+    struct rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    double cpu = r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+    double rss = (double)r.ru_maxrss * 1024.0 / 1024.0 / 1024.0 / 1024.0;   // ru_maxrss is kB -> GB
+    std::ofstream f(tmpDir + "/perf.bin", std::ios::binary);
+    f.write((const char *)&cpu, sizeof(cpu));
+    f.write((const char *)&rss, sizeof(rss));
+}
+
+// ---- argv ---------------------------------------------------------------------------------------------
+struct Args {
+    std::vector<std::string> pos;
+    int threads = 1;
+    float minReadQuality = 0;
+    bool skipCorrection = false, outputQuality = false, firstPass = false;
+    uint32_t minAbundance = 0;
+    size_t batchBases = (size_t)1 << 30;   // bases per device batch (not a reference flag)
+};
+Args parse_args(int argc, char **argv, int first) {
+    Args a;
+    for (int i = first; i < argc; i++) {
+        std::string s = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + s); return argv[++i]; };
+        if (s == "--threads") a.threads = atoi(val().c_str());
+        else if (s == "--min-read-quality") a.minReadQuality = (float)atof(val().c_str());
+        else if (s == "--min-abundance") a.minAbundance = (uint32_t)atoi(val().c_str());
+        else if (s == "--skip-correction") a.skipCorrection = true;
+        else if (s == "--output-quality") a.outputQuality = true;
+        else if (s == "--firstpass") a.firstPass = true;
+        else if (s == "--batch-bases") a.batchBases = (size_t)atoll(val().c_str());
+        else if (s.rfind("--", 0) == 0) die("unknown flag " + s);
+        else a.pos.push_back(s);
+    }
+    return a;
+}
+
+// ---- a batch of parsed reads ------------------------------------------------------------------------------
+struct Batch {
+    std::string bases, quals;
+    std::vector<uint64_t> offsets{0};
+    bool anyQual = false;
+    uint32_t n() const { return (uint32_t)(offsets.size() - 1); }
+    void clear() { bases.clear(); quals.clear(); offsets.assign(1, 0); anyQual = false; }
+};
+
+// Feeds `fn` with batches of reads from the files listed in inputList; at most maxReadsPerFile + 1 reads of
+// each file when maxReadsPerFile > 0 (the reference's `_maxReads` check, Commons.hpp:5873).
+void for_each_batch(const std::string &inputList, size_t batchBases, uint64_t maxReadsPerFile, const std::function<void(Batch &)> &fn) {
+    std::ifstream lst(inputList);
+    if (!lst) die("File not found: " + inputList);
+    std::string path;
+    Batch b;
+    while (std::getline(lst, path)) {
+        if (path.empty()) continue;
+        mdbg_host::FastxReader rd(path);
+        if (!rd.ok()) die("File not found: " + path);
+        uint64_t perFile = 0;
+        for (;;) {
+            if (maxReadsPerFile > 0 && perFile > maxReadsPerFile) break;
+            bool hasQ = false;
+            const size_t q0 = b.quals.size();
+            if (!rd.next(b.bases, b.quals, hasQ)) break;
+            perFile++;
+            if (hasQ != b.anyQual && b.n() > 0) {
+                // FASTA and FASTQ records never share a batch: cut before this read
+                std::string seq = b.bases.substr(b.offsets.back()), ql = b.quals.substr(q0);
+                b.bases.resize(b.offsets.back()); b.quals.resize(q0);
+                fn(b);
+                b.clear();
+                b.bases = seq; b.quals = ql;
+            }
+            b.anyQual = hasQ;
+            b.offsets.push_back(b.bases.size());
+            if (b.bases.size() >= batchBases) { fn(b); b.clear(); }
+        }
+    }
+    if (b.n() > 0) fn(b);
+}
+
+mdbg_scan_params scan_params(const Parameters &P, float density, const std::vector<uint32_t> &rep, float minQ, bool filters) {
+    mdbg_scan_params p{};
+    p.minimizer_size = (uint32_t)P.minimizerSize;
+    p.density = density;
+    p.hpc = P.hpc ? 1 : 0;
+    p.min_read_quality = minQ;
+    p.repetitive = rep.empty() ? nullptr : rep.data();
+    p.n_repetitive = (uint32_t)rep.size();
+    p.apply_read_filters = filters ? 1 : 0;
+    return p;
+}
+
+// ---- readSelection --------------------------------------------------------------------------------------------
+int run_read_selection(int argc, char **argv) {
+    Args a = parse_args(argc, argv, 2);
+    if (a.pos.size() != 3) die("usage: mdbg_tool readSelection <tmpDir> <outFile> <inputList> --threads N --min-read-quality F [--skip-correction]");
+    const std::string tmpDir = a.pos[0], outFile = a.pos[1], inputList = a.pos[2];
+    Parameters P;
+    P.load(tmpDir + "/parameters.gz");
+    check(mdbg_create(0, &g_ctx), "mdbg_create");
+
+    // repetitive minimizers (ReadSelection.hpp:497-561): HiFi writes an empty file
+    std::vector<uint32_t> rep;
+    {
+        std::ofstream repFile(tmpDir + "/repetitiveMinimizers.bin", std::ios::binary);
+        if (!P.hpc) {
+            std::vector<uint32_t> all;
+            std::vector<uint64_t> offs{0};
+            for_each_batch(inputList, a.batchBases, 1000000, [&](Batch &b) {
+                mdbg_reads *reads = nullptr;
+                mdbg_minimizers *mins = nullptr;
+                check(mdbg_reads_from_ascii(g_ctx, b.bases.data(), nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+                mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
+                check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
+                uint32_t n; uint64_t t;
+                mdbg_minimizers_info(mins, &n, &t);
+                std::vector<uint64_t> o((size_t)n + 1);
+                const size_t base = all.size();
+                all.resize(base + t);
+                check(mdbg_minimizers_to_host(g_ctx, mins, o.data(), all.data() + base, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
+                for (uint32_t r = 1; r <= n; r++) offs.push_back(base + o[r]);
+                mdbg_minimizers_free(mins);
+                mdbg_reads_free(reads);
+            });
+            mdbg_minimizers *census = nullptr;
+            check(mdbg_minimizers_from_host(g_ctx, all.data(), offs.data(), (uint32_t)(offs.size() - 1), &census), "mdbg_minimizers_from_host");
+            uint32_t cap = 1u << 16;
+            rep.resize(cap);
+            check(mdbg_repetitive_minimizers(g_ctx, census, rep.data(), &cap), "mdbg_repetitive_minimizers");
+            rep.resize(cap);
+            mdbg_minimizers_free(census);
+            // test hook: ties among equally frequent minimizers are broken arbitrarily by the reference
+            // (std::sort on counts, ReadSelection.hpp:522-524); a fixture can pin the reference's pick
+            if (const char *forced = getenv("MDBG_TOOL_REPETITIVE")) {
+                std::vector<uint8_t> raw = read_file(forced);
+                rep.assign(raw.size() / 4, 0);
+                if (!raw.empty()) memcpy(rep.data(), raw.data(), rep.size() * 4);
+            }
+            repFile.write((const char *)rep.data(), (std::streamsize)(rep.size() * 4));
+        }
+    }
+
+    // main pass: read_data_init.txt in read order (ReadSelection.hpp:386-491)
+    std::ofstream out(outFile, std::ios::binary);
+    if (!out) die("cannot write " + outFile);
+    std::vector<uint32_t> allReadSizes;
+    uint64_t nbKmers = 0, nbBases = 0, nbSelected = 0;
+    long double qualitySum = 0, qualityN = 0;
+    std::vector<mdbg_minimizers *> kept;   // device-resident minimizer reads, purged once N50 is known
+    const bool needCorrected = P.hpc || a.skipCorrection;
+    for_each_batch(inputList, a.batchBases, 0, [&](Batch &b) {
+        mdbg_reads *reads = nullptr;
+        mdbg_minimizers *mins = nullptr;
+        check(mdbg_reads_from_ascii(g_ctx, b.bases.data(), b.anyQual ? b.quals.data() : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+        mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
+        check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
+        mdbg_reads_free(reads);
+        uint32_t n; uint64_t t;
+        mdbg_minimizers_info(mins, &n, &t);
+        std::vector<uint64_t> off((size_t)n + 1);
+        std::vector<uint32_t> m(t), pos(t), len(n);
+        std::vector<uint8_t> dir(t), qual(t), flags(n);
+        std::vector<float> meanQ(n);
+        check(mdbg_minimizers_to_host(g_ctx, mins, off.data(), m.data(), pos.data(), dir.data(), qual.data(), len.data(), meanQ.data(), flags.data()), "to_host");
+        std::string rec;
+        rec.reserve(t * 10 + (size_t)n * 13);
+        for (uint32_t r = 0; r < n; r++) {
+            const uint64_t s = off[r];
+            const uint32_t k = (uint32_t)(off[r + 1] - s);
+            const uint8_t circ = 0;
+            rec.append((const char *)&k, 4); rec.append((const char *)&circ, 1);
+            rec.append((const char *)(m.data() + s), (size_t)k * 4);
+            rec.append((const char *)(pos.data() + s), (size_t)k * 4);
+            rec.append((const char *)(dir.data() + s), k);
+            rec.append((const char *)(qual.data() + s), k);
+            rec.append((const char *)&meanQ[r], 4);
+            rec.append((const char *)&len[r], 4);
+            allReadSizes.push_back(len[r]);
+            nbSelected += k;
+            nbKmers += (uint64_t)((size_t)len[r] - P.minimizerSize + 1);   // size_t arithmetic as in :480
+            nbBases += len[r];
+            if (!(flags[r] & MDBG_READ_LOW_QUALITY)) { qualitySum += meanQ[r]; qualityN += 1; }   // :911-914
+        }
+        out.write(rec.data(), (std::streamsize)rec.size());
+        if (needCorrected) kept.push_back(mins); else mdbg_minimizers_free(mins);
+    });
+    out.close();
+
+    // read_stats.txt (ReadSelection.hpp:305-384)
+    const uint64_t nbReads = allReadSizes.size();
+    const uint32_t n50 = compute_n50(allReadSizes);
+    const uint32_t meanLen = nbReads ? compute_mean_length(allReadSizes) : 0;
+    {
+        float density = (float)((long double)nbSelected / (long double)nbKmers);
+        float avgQ = (float)(qualitySum / qualityN);
+        std::ofstream st(tmpDir + "/read_stats.txt", std::ios::binary);
+        st.write((const char *)&nbReads, 8); st.write((const char *)&n50, 4); st.write((const char *)&density, 4);
+        st.write((const char *)&nbBases, 8); st.write((const char *)&avgQ, 4); st.write((const char *)&meanLen, 4);
+        st.write((const char *)&nbSelected, 8);
+    }
+
+    // purgePalindromes (ReadSelection.hpp:1374-1431): lastK from the N50, --max-k ignored
+    if (needCorrected) {
+        const int lastK = compute_last_k(P.densityAssembly, n50, P.firstK, 0);
+        std::ofstream corr(tmpDir + "/read_data_corrected.txt", std::ios::binary);
+        for (mdbg_minimizers *mins : kept) {
+            mdbg_minimizers *pur = nullptr;
+            check(mdbg_purge_palindromes(g_ctx, mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+            uint32_t n; uint64_t t;
+            mdbg_minimizers_info(pur, &n, &t);
+            std::vector<uint64_t> off((size_t)n + 1);
+            std::vector<uint32_t> m(t);
+            check(mdbg_minimizers_to_host(g_ctx, pur, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
+            std::string rec;
+            rec.reserve(t * 4 + (size_t)n * 5);
+            for (uint32_t r = 0; r < n; r++) {
+                const uint32_t k = (uint32_t)(off[r + 1] - off[r]);
+                const uint8_t circ = 0;
+                rec.append((const char *)&k, 4); rec.append((const char *)&circ, 1);
+                rec.append((const char *)(m.data() + off[r]), (size_t)k * 4);
+            }
+            corr.write(rec.data(), (std::streamsize)rec.size());
+            mdbg_minimizers_free(pur);
+            mdbg_minimizers_free(mins);
+        }
+    }
+    write_perf(tmpDir);
+    mdbg_destroy(g_ctx);
+    return 0;
+}
+
+// ---- graph ---------------------------------------------------------------------------------------------------------
+// "u32 n; u8 circ; u32 m[n]" records (read_data_corrected.txt, unitig_data.txt) -> CSR
+void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs) {
+    offs.assign(1, 0);
+    size_t o = 0;
+    while (o + 5 <= raw.size()) {
+        uint32_t n;
+        memcpy(&n, raw.data() + o, 4);
+        o += 5;
+        if (o + (size_t)n * 4 > raw.size()) die("truncated minimizer read file");
+        const size_t base = mins.size();
+        mins.resize(base + n);
+        if (n) memcpy(mins.data() + base, raw.data() + o, (size_t)n * 4);
+        o += (size_t)n * 4;
+        offs.push_back(mins.size());
+    }
+}
+
+mdbg_minimizers *upload_reads(const std::string &path, bool required) {
+    std::vector<uint8_t> raw = read_file(path, required);
+    std::vector<uint32_t> mins;
+    std::vector<uint64_t> offs;
+    parse_minimizer_reads(raw, mins, offs);
+    mdbg_minimizers *m = nullptr;
+    check(mdbg_minimizers_from_host(g_ctx, mins.data(), offs.data(), (uint32_t)(offs.size() - 1), &m), "mdbg_minimizers_from_host");
+    return m;
+}
+
+int run_graph(int argc, char **argv) {
+    Args a = parse_args(argc, argv, 2);
+    if (a.pos.size() != 1) die("usage: mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass]");
+    const std::string dir = a.pos[0];
+    Parameters P;
+    P.load(dir + "/parameters.gz");
+    check(mdbg_create(0, &g_ctx), "mdbg_create");
+    const uint32_t k = (uint32_t)P.kminmerSize;
+    mdbg_minimizers *reads = upload_reads(dir + "/read_data_corrected.txt", true);
+    mdbg_table *table = nullptr;
+    if (a.firstPass) {
+        check(mdbg_kminmer_count_first(g_ctx, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first");
+    } else {
+        // loadRefinedAbundances (graph/CreateMdbg.cpp:3401-3709)
+        std::vector<uint8_t> prevRec = read_file(dir + "/kminmerData_abundance_prev.txt");
+        mdbg_table *prev = nullptr;
+        check(mdbg_prev_from_records(g_ctx, prevRec.data(), prevRec.size() / 20, &prev), "mdbg_prev_from_records");
+        // unitigGraph.nodes.refined_abundances.bin: (u32 unitigName, u32 abundance)*
+        std::vector<uint8_t> ab = read_file(dir + "/unitigGraph.nodes.refined_abundances.bin", false);
+        std::vector<std::pair<uint32_t, uint32_t>> name2ab(ab.size() / 8);
+        for (size_t i = 0; i < name2ab.size(); i++) { memcpy(&name2ab[i].first, ab.data() + 8 * i, 4); memcpy(&name2ab[i].second, ab.data() + 8 * i + 4, 4); }
+        std::sort(name2ab.begin(), name2ab.end());
+        // unitigGraph_prev.nodes.bin: (u32 size; u32 m[size]; u32 unitigIndex)*, name = index / 2
+        std::vector<uint8_t> nodes = read_file(dir + "/unitigGraph_prev.nodes.bin", false);
+        std::vector<uint32_t> um, uab;
+        std::vector<uint64_t> uoff{0};
+        for (size_t o = 0; o + 4 <= nodes.size();) {
+            uint32_t n; memcpy(&n, nodes.data() + o, 4); o += 4;
+            if (o + (size_t)n * 4 + 4 > nodes.size()) die("truncated unitigGraph_prev.nodes.bin");
+            const size_t base = um.size();
+            um.resize(base + n);
+            if (n) memcpy(um.data() + base, nodes.data() + o, (size_t)n * 4);
+            o += (size_t)n * 4;
+            uint32_t idx; memcpy(&idx, nodes.data() + o, 4); o += 4;
+            uoff.push_back(um.size());
+            auto it = std::lower_bound(name2ab.begin(), name2ab.end(), std::make_pair(idx / 2, 0u));
+            // several entries for one name: the reference's map keeps the last one
+            uint32_t v = 0; bool found = false;
+            for (; it != name2ab.end() && it->first == idx / 2; ++it) { v = it->second; found = true; }
+            uab.push_back(found ? v : 0xFFFFFFFFu);   // 0xFFFFFFFF = no refined abundance: skipped (CreateMdbg.cpp:3483)
+        }
+        if (!uab.empty()) {
+            mdbg_minimizers *un = nullptr;
+            check(mdbg_minimizers_from_host(g_ctx, um.data(), uoff.data(), (uint32_t)uab.size(), &un), "mdbg_minimizers_from_host");
+            check(mdbg_prev_overlay_unitigs(g_ctx, prev, un, uab.data(), (uint32_t)P.prevK), "mdbg_prev_overlay_unitigs");
+            mdbg_minimizers_free(un);
+        }
+        mdbg_minimizers *unitigs = nullptr;
+        {
+            std::ifstream probe(dir + "/unitig_data.txt", std::ios::binary);
+            if (probe) unitigs = upload_reads(dir + "/unitig_data.txt", true);
+        }
+        if (k == P.firstK + 1) check(mdbg_kminmer_count_refined(g_ctx, reads, unitigs, k, prev, &table), "mdbg_kminmer_count_refined");
+        else check(mdbg_kminmer_index(g_ctx, reads, unitigs, k, prev, &table), "mdbg_kminmer_index");
+        if (unitigs) mdbg_minimizers_free(unitigs);
+        mdbg_table_free(prev);
+    }
+    uint64_t n = 0;
+    int hasVec = 0;
+    mdbg_table_info(table, nullptr, &n, nullptr, &hasVec);
+    std::vector<uint8_t> rec(n * 20);
+    std::vector<uint32_t> vec(hasVec ? n * k : 0);
+    check(mdbg_table_to_host(g_ctx, table, rec.data(), hasVec ? vec.data() : nullptr), "mdbg_table_to_host");
+    {
+        std::ofstream f(dir + "/kminmerData_abundance.txt", std::ios::binary);
+        f.write((const char *)rec.data(), (std::streamsize)rec.size());
+    }
+    if (hasVec) {
+        std::ofstream f(dir + "/kminmerData_min.txt", std::ios::binary);
+        f.write((const char *)vec.data(), (std::streamsize)(vec.size() * 4));
+    }
+    // graph/CreateMdbg.cpp:515-522
+    auto copy = [&](const std::string &to) { std::ofstream f(dir + to, std::ios::binary); f.write((const char *)rec.data(), (std::streamsize)rec.size()); };
+    if (a.firstPass) copy("/kminmerData_abundance_init.txt");
+    if (k == P.firstK + 1) copy("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
+    mdbg_table_free(table);
+    mdbg_minimizers_free(reads);
+    write_perf(dir);
+    mdbg_destroy(g_ctx);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) die("usage: mdbg_tool <readSelection|graph> ...");
+    const std::string cmd = argv[1];
+    if (cmd == "readSelection") return run_read_selection(argc, argv);
+    if (cmd == "graph") return run_graph(argc, argv);
+    die("unknown sub-command " + cmd + " (only the hot-path tools exist here: readSelection, graph)");
+}

@@ -174,7 +174,9 @@ def test_refined_and_index_vs_oracle(ctx, orc, k):
     prev_raw = orc.table_abundance_records(prev_t).tobytes()
     uab = rng.integers(0, 5, len(uoffs) - 1).astype(np.uint32)
     oprev = orc.PrevAbundance(prev_raw)
-    oprev.overlay_unitigs([(umins[int(uoffs[i]): int(uoffs[i + 1])], int(uab[i])) for i in range(len(uab)) if uab[i]], k - 1)
+    # 4 stands for "unitig without a refined abundance" (skipped); 0 and 1 are real values
+    oprev.overlay_unitigs([(umins[int(uoffs[i]): int(uoffs[i + 1])], int(uab[i])) for i in range(len(uab)) if uab[i] != 4], k - 1)
+    uab = np.where(uab == 4, 0xFFFFFFFF, uab).astype(np.uint32)
     d_reads = ctx.minimizers_from_host(mins, offs)
     d_unitigs = ctx.minimizers_from_host(umins, uoffs)
     dprev = ctx.prev_from_records(prev_raw)

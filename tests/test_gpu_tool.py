@@ -1,0 +1,201 @@
+"""The C++ host tool (metamdbg_amd/bin/mdbg_tool) as a drop-in producer of the reference's files:
+golden fixtures, and live side-by-side runs against the reference's own code (oracle/_ref/refdrv)."""
+from __future__ import annotations
+
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from metamdbg_amd import formats, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "metamdbg_amd", "bin", "mdbg_tool")
+REFDRV = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+
+
+def make_tmp(base, params: formats.Parameters, inputs: list[str]) -> str:
+    tmp = os.path.join(str(base), "tmp")
+    for d in ("", "filter", "smallContigs", "checkpoints"):
+        os.makedirs(os.path.join(tmp, d), exist_ok=True)
+    params.save(os.path.join(tmp, "parameters.gz"))
+    with open(os.path.join(tmp, "input.txt"), "w") as f:
+        f.write("\n".join(inputs) + "\n")
+    return tmp
+
+
+def run(exe, *args, env=None):
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    r = subprocess.run([exe, *args], capture_output=True, text=True, env=e, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def read_selection(exe, tmp, extra=(), env=None):
+    run(exe, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
+        "--threads", "1", "--min-read-quality", "0.000000", *extra, env=env)
+
+
+def fbytes(tmp, name):
+    with open(os.path.join(tmp, name), "rb") as f:
+        return f.read()
+
+
+def assert_tables_equal(tmp_a, tmp_b, k):
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp_a, "kminmerData_abundance.txt")),
+                          formats.sorted_abundance_records(fbytes(tmp_b, "kminmerData_abundance.txt")))
+    assert np.array_equal(formats.sorted_vector_records(fbytes(tmp_a, "kminmerData_min.txt"), k),
+                          formats.sorted_vector_records(fbytes(tmp_b, "kminmerData_min.txt"), k))
+
+
+def test_tool_hifi_200_golden(tmp_path):
+    m = H.load_manifest("hifi_200")
+    spec = H.spec_from_manifest(m)
+    fasta = str(tmp_path / "hifi.fasta")
+    synth.write_fasta(fasta, spec)
+    tmp = make_tmp(tmp_path, formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                                hpc=True, data_type=0), [fasta])
+    read_selection(TOOL, tmp)
+    for name in ("read_data_init.txt", "read_stats.txt", "read_data_corrected.txt", "repetitiveMinimizers.bin"):
+        assert fbytes(tmp, name) == H.golden_bytes("hifi_200", name), name
+    run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass")
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
+    assert fbytes(tmp, "kminmerData_abundance_init.txt") == fbytes(tmp, "kminmerData_abundance.txt")
+    assert len(fbytes(tmp, "perf.bin")) == 16
+
+
+def test_tool_ont_100_golden(tmp_path):
+    m = H.load_manifest("ont_100")
+    spec = H.spec_from_manifest(m)
+    fastq = str(tmp_path / "ont.fastq")
+    synth.write_fasta(fastq, spec)
+    tmp = make_tmp(tmp_path, formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                                hpc=False, data_type=1, correction_density=0.025), [fastq])
+    # first with the tool's own tie-break: one repetitive minimizer with the maximal count
+    read_selection(TOOL, tmp, extra=["--skip-correction"])
+    assert len(fbytes(tmp, "repetitiveMinimizers.bin")) == len(H.golden_bytes("ont_100", "repetitiveMinimizers.bin"))
+    # then pinned to the reference's pick: every file must match
+    read_selection(TOOL, tmp, extra=["--skip-correction"],
+                   env={"MDBG_TOOL_REPETITIVE": os.path.join(H.GOLDEN, "ont_100", "repetitiveMinimizers.bin")})
+    for name in ("read_data_init.txt", "read_data_corrected.txt", "repetitiveMinimizers.bin"):
+        assert fbytes(tmp, name) == H.golden_bytes("ont_100", name), name
+    got, exp = formats.parse_read_stats(fbytes(tmp, "read_stats.txt")), formats.parse_read_stats(H.golden_bytes("ont_100", "read_stats.txt"))
+    assert got == exp
+    run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass")
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "ont_100", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
+def test_tool_vs_reference_live_multifile(tmp_path):
+    """Two input files (one gzipped with wrapped lines, one plain), small batches so reads span several device
+    batches: every product byte-equal (tables as multisets) to the reference run on the same files."""
+    rng = np.random.default_rng(21)
+    genome = synth.CODE2ASCII[rng.integers(0, 4, 60000)]
+    def reads(n):
+        out = []
+        for _ in range(n):
+            a = int(rng.integers(0, 50000)); L = int(rng.integers(500, 9000))
+            s = genome[a:a + L].copy()
+            if rng.integers(0, 2):
+                s = synth.CODE2ASCII[synth.ascii_to_codes(s)[::-1] ^ 2]
+            out.append(bytes(s))
+        return out
+    f1, f2 = str(tmp_path / "a.fasta.gz"), str(tmp_path / "b.fasta")
+    with gzip.open(f1, "wb") as f:
+        for i, s in enumerate(reads(150)):
+            f.write(b">a%d some comment\n" % i)
+            for o in range(0, len(s), 70):
+                f.write(s[o:o + 70] + b"\n")
+    with open(f2, "wb") as f:
+        for i, s in enumerate(reads(120)):
+            f.write(b">b%d\n" % i + s + b"\n")
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+    t_ref = make_tmp(tmp_path / "ref", P, [f1, f2])
+    t_gpu = make_tmp(tmp_path / "gpu", P, [f1, f2])
+    read_selection(REFDRV, t_ref)
+    read_selection(TOOL, t_gpu, extra=["--batch-bases", "200000"])
+    for name in ("read_data_init.txt", "read_stats.txt", "read_data_corrected.txt", "repetitiveMinimizers.bin"):
+        assert fbytes(t_gpu, name) == fbytes(t_ref, name), name
+    run(REFDRV, "graph", t_ref, "--threads", "1", "--min-abundance", "0", "--firstpass")
+    run(TOOL, "graph", t_gpu, "--threads", "1", "--min-abundance", "0", "--firstpass")
+    assert_tables_equal(t_gpu, t_ref, 4)
+    # min-abundance 2: no rescue (graph/CreateMdbg.cpp:317-319)
+    run(REFDRV, "graph", t_ref, "--threads", "1", "--min-abundance", "2", "--firstpass")
+    run(TOOL, "graph", t_gpu, "--threads", "1", "--min-abundance", "2", "--firstpass")
+    assert_tables_equal(t_gpu, t_ref, 4)
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
+def test_tool_vs_reference_live_fastq_hpc(tmp_path):
+    """HiFi-style FASTQ (HPC on, qualities): per-minimizer min quality through the run starts and mean quality."""
+    rng = np.random.default_rng(33)
+    fq = str(tmp_path / "r.fastq")
+    with open(fq, "wb") as f:
+        for i in range(120):
+            L = int(rng.integers(200, 12000))
+            s = synth.CODE2ASCII[rng.integers(0, 4, L)]
+            q = (rng.integers(2, 94, L) + 33).astype(np.uint8)
+            f.write(b"@r%d\n" % i + bytes(s) + b"\n+\n" + bytes(q) + b"\n")
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+    t_ref = make_tmp(tmp_path / "ref", P, [fq])
+    t_gpu = make_tmp(tmp_path / "gpu", P, [fq])
+    read_selection(REFDRV, t_ref)
+    read_selection(TOOL, t_gpu, extra=["--batch-bases", "300000"])
+    for name in ("read_data_init.txt", "read_data_corrected.txt"):
+        assert fbytes(t_gpu, name) == fbytes(t_ref, name), name
+    assert fbytes(t_gpu, "read_stats.txt") == fbytes(t_ref, "read_stats.txt")
+
+
+def test_tool_graph_next_k_vs_oracle(tmp_path):
+    """k = firstK+1 and firstK+2 through the tool's file interface, inputs synthesised (the stages that
+    produce them in the reference -- contig, toMinspace -- are out of scope), expected tables from the oracle."""
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(8)
+    genome = rng.permutation(4000).astype(np.uint32)
+    rl = []
+    for _ in range(500):
+        a = int(rng.integers(0, 3900)); n = int(rng.integers(0, 70))
+        seg = genome[a:a + n]
+        rl.append(seg[::-1].copy() if rng.integers(0, 2) else seg.copy())
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in rl])]).astype(np.uint64)
+    mins = np.concatenate(rl).astype(np.uint32)
+    cuts = np.sort(rng.choice(np.arange(1, 4000), 40, replace=False))
+    ul = [genome[a:b] for a, b in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [4000]]))]
+    uab = rng.integers(0, 6, len(ul)).astype(np.uint32)        # 5 = unitig without refined abundance
+    for k in (5, 6):
+        prev_t = orc.kminmer_count_first(mins, offs, k - 1, 0)
+        prev_raw = orc.table_abundance_records(prev_t).tobytes()
+        d = tmp_path / f"k{k}"
+        tmp = make_tmp(d, formats.Parameters(minimizer_size=15, kminmer_size=k, density=0.005, first_k=4, prev_k=k - 1,
+                                             hpc=True, data_type=0), ["unused"])
+        open(os.path.join(tmp, "read_data_corrected.txt"), "wb").write(formats.write_minimizer_reads(mins, offs))
+        open(os.path.join(tmp, "kminmerData_abundance_prev.txt"), "wb").write(prev_raw)
+        uoffs = np.concatenate([[0], np.cumsum([len(x) for x in ul])]).astype(np.uint64)
+        umins = np.concatenate(ul).astype(np.uint32)
+        open(os.path.join(tmp, "unitig_data.txt"), "wb").write(formats.write_minimizer_reads(umins, uoffs))
+        with open(os.path.join(tmp, "unitigGraph_prev.nodes.bin"), "wb") as f:
+            for i, u in enumerate(ul):
+                f.write(struct.pack("<I", len(u)) + u.astype("<u4").tobytes() + struct.pack("<I", 2 * i))
+        with open(os.path.join(tmp, "unitigGraph.nodes.refined_abundances.bin"), "wb") as f:
+            for i, a in enumerate(uab):
+                if a != 5:
+                    f.write(struct.pack("<II", i, int(a)))
+        run(TOOL, "graph", tmp, "--threads", "1")
+        oprev = orc.PrevAbundance(prev_raw)
+        oprev.overlay_unitigs([(ul[i], int(uab[i])) for i in range(len(ul)) if uab[i] != 5], k - 1)
+        allm = np.concatenate([mins, umins]); alloff = np.concatenate([offs, offs[-1] + uoffs[1:]])
+        exp = (orc.kminmer_count_refined if k == 5 else orc.kminmer_index)(allm, alloff, k, oprev)
+        got = formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt"))
+        assert np.array_equal(got, formats.sorted_abundance_records(orc.table_abundance_records(exp)))
+        if k == 5:
+            assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k),
+                                  formats.sorted_vector_records(exp["vecs"].astype("<u4").tobytes(), k))
+            assert fbytes(tmp, "kminmerData_abundance_init_k5.txt") == fbytes(tmp, "kminmerData_abundance.txt")
