@@ -337,3 +337,49 @@ def test_scan_reads_with_n(ctx, orc):
         seqs.append(bytes(s))
     for hpc in (True, False):
         _check_scan_against_oracle(ctx, orc, seqs, None, 15, 0.02, hpc)
+
+
+def test_multi_k_loop_benchmark_mode(ctx, orc):
+    """BASELINE.json configs[2] at test scale: k = 4 .. 11 over the same minimizer-space reads, reads only,
+    previous table = own k-1 output (SURVEY.md 8(d) "benchmark mode"); every k must equal the oracle's loop."""
+    spec = synth.hifi_spec(400, seed=9, read_len=8000, coverage=30.0)
+    reads = ctx.reads_synthetic(spec)
+    mins = ctx.scan(reads, K=15, density=0.005, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    hc = corr.to_host(full=False)
+    m, o = hc["minimizers"], hc["offsets"]
+    t_gpu = ctx.kminmer_count_first(corr, 4, 0)
+    t_orc = orc.kminmer_count_first(m, o, 4, 0)
+    rec, vec = t_gpu.to_host()
+    _assert_tables_equal(rec, vec, t_orc, 4)
+    for k in range(5, 12):
+        prev_raw = rec.tobytes()
+        oprev = orc.PrevAbundance(prev_raw)
+        oprev.overlay_unitigs([], k - 1)
+        if k == 5:
+            t_gpu2 = ctx.kminmer_count_refined(corr, None, k, t_gpu)
+            t_orc = orc.kminmer_count_refined(m, o, k, oprev)
+        else:
+            t_gpu2 = ctx.kminmer_index(corr, None, k, t_gpu)
+            t_orc = orc.kminmer_index(m, o, k, oprev)
+        rec, vec = t_gpu2.to_host()
+        assert len(rec) > 0
+        _assert_tables_equal(rec, vec, t_orc, k)
+        t_gpu = t_gpu2
+
+
+def test_ont_like_reads_vs_oracle(ctx, orc):
+    """BASELINE.json configs[3] at test scale: 20 kb reads, 2 % errors, qualities, no HPC, nanoMDBG densities,
+    repetitive filter from the 0.025 pre-pass."""
+    spec = synth.SynthSpec(n_reads=300, read_len=20_000, seed=31, sub_rate=0.02, species_len=[150_000, 90_000],
+                           species_weight=[0.6, 0.4], with_quality=True, name="ont")
+    reads = ctx.reads_synthetic(spec)
+    pre = ctx.scan(reads, K=15, density=0.025, hpc=False, apply_read_filters=False)
+    rep = ctx.repetitive_minimizers(pre)
+    assert len(rep) >= 1
+    asc = synth.codes_to_ascii(synth.read_codes(spec, 0, spec.n_reads))
+    q = synth.read_qualities(spec, 0, spec.n_reads)
+    h = ctx.scan(reads, K=15, density=0.005, hpc=False, repetitive=rep).to_host()
+    exp = b"".join(orc.read_selection(asc[r].tobytes(), q[r].tobytes(), K=15, density=0.005, hpc=False, repetitive=rep)["record"]
+                   for r in range(spec.n_reads))
+    assert formats.build_read_data_init(h) == exp
