@@ -90,6 +90,45 @@ __device__ __forceinline__ uint64_t compress_pairs(uint64_t x, uint64_t d) {
     return (uint64_t)lo | ((uint64_t)hi << nlo);
 }
 
+// Table-driven homopolymer compaction.  For 4 bases (8 bits) and the base before them, which bases
+// start a run depends on those 10 bits only, so a 1024-entry table gives the squeezed bits (low byte)
+// and twice the number kept (high byte) in one LDS lookup per 4 bases.
+constexpr int HPC_LUT_SIZE = 1024;
+__device__ __forceinline__ uint16_t hpc_lut_entry(unsigned idx) {
+    unsigned prev = idx & 3u, out = 0, n = 0;
+    for (int i = 0; i < 4; i++) {
+        unsigned b = (idx >> (2 + 2 * i)) & 3u;
+        if (b != prev) { out |= b << n; n += 2; }
+        prev = b;
+    }
+    return (uint16_t)(out | (n << 8));
+}
+
+// x squeezed to its run starts given the base `pl` preceding the word; *nbits = 2 * kept
+__device__ __forceinline__ uint64_t compress_pairs_lut(const uint16_t *lut, uint64_t x, uint32_t pl, unsigned *nbits) {
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    const uint32_t e0 = lut[((xl & 0xFFu) << 2) | pl];
+    const uint32_t e1 = lut[(xl >> 6) & 0x3FFu];
+    const uint32_t e2 = lut[(xl >> 14) & 0x3FFu];
+    const uint32_t e3 = lut[xl >> 22];
+    const uint32_t e4 = lut[__builtin_amdgcn_alignbit(xh, xl, 30) & 0x3FFu];
+    const uint32_t e5 = lut[(xh >> 6) & 0x3FFu];
+    const uint32_t e6 = lut[(xh >> 14) & 0x3FFu];
+    const uint32_t e7 = lut[xh >> 22];
+    uint32_t lo = e0 & 0xFFu;
+    unsigned n = e0 >> 8;
+    lo |= (e1 & 0xFFu) << n; n += e1 >> 8;
+    lo |= (e2 & 0xFFu) << n; n += e2 >> 8;
+    lo |= (e3 & 0xFFu) << n; n += e3 >> 8;
+    uint32_t hi = e4 & 0xFFu;
+    unsigned m = e4 >> 8;
+    hi |= (e5 & 0xFFu) << m; m += e5 >> 8;
+    hi |= (e6 & 0xFFu) << m; m += e6 >> 8;
+    hi |= (e7 & 0xFFu) << m; m += e7 >> 8;
+    *nbits = n + m;
+    return (uint64_t)lo | ((uint64_t)hi << n);
+}
+
 // same for 1-bit fields: keep bit i of v where bit 2i of d is set
 __device__ __forceinline__ uint32_t compress_bits(uint32_t v, uint64_t d) {
     uint32_t out = 0;
@@ -280,9 +319,105 @@ __device__ __forceinline__ uint32_t orig_of(const QualMap *q, unsigned s, unsign
     return tile_base + lo * 32u + (bit >> 1);
 }
 
-#ifndef SCAN_UNROLL
-#define SCAN_UNROLL 2      // k-mer positions per lane per trip of the hash loop
+#ifndef SCAN_PP
+#define SCAN_PP 4          // adjacent k-mer positions per lane per trip of the hash loop (1..4)
 #endif
+
+// One trip of the hash loop: PP adjacent stream positions per lane, j = j0 + PP * lane + u.
+template <bool HPC, bool HAS_QUAL, bool HAS_N>
+struct KmerTrip {
+    const ScanArgs &a;
+    const uint32_t *S, *SI;
+    const QualMap *Q;
+    unsigned K;
+    uint32_t kmask, kbits, comp_mask;
+    unsigned lane, nk;
+    uint32_t hp_base;
+    unsigned cb;
+    uint32_t tile_base;
+    uint64_t cap0;
+    uint32_t cap, r;
+
+    template <int PP>
+    __device__ __forceinline__ uint32_t run(unsigned j0, uint32_t nout) const {
+        const unsigned jb = j0 + (unsigned)PP * lane;
+        // 64 stream bits from position jb (enough for K + PP - 1 <= 19 bases)
+        const unsigned b = 2u * jb, w = b >> 5, sh = b & 31u;
+        uint32_t a0, a1;
+        if (w + 2 < STREAM_WORDS) {
+            const uint32_t w0 = S[w], w1 = S[w + 1], w2 = S[w + 2];
+            a0 = __builtin_amdgcn_alignbit(w1, w0, sh);
+            a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+        } else { a0 = 0; a1 = 0; }   // lanes far beyond nk in a short last trip
+        bool sel[PP];
+        uint32_t val[PP], dir[PP];
+        uint32_t fwd = 0;
+#pragma unroll
+        for (int u = 0; u < PP; u++) {
+            const unsigned j = jb + u;
+            const uint32_t e = (u == 0 ? a0 : __builtin_amdgcn_alignbit(a1, a0, 2 * u)) & kmask;
+            const uint32_t rev = e ^ comp_mask;
+            // forward k-mer: full digit reversal once, then shift in the newest base (top digit of e)
+            fwd = u == 0 ? digit_reverse(e, K) : (((fwd << 2) | (e >> (2u * K - 2u))) & kmask);
+            dir[u] = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
+            val[u] = dir[u] ? rev : fwd;
+#if defined(SCAN_ABLATE) && SCAN_ABLATE == 1
+            sel[u] = (val[u] == 0x12345u) && (j < nk);                                  // ablation: no hash
+#else
+            // first k-mer of the read skipped (Kmer.hpp:1395)
+            sel[u] = (kmer_hash32(val[u]) < a.threshold) && (hp_base + j >= 1u) && (j < nk);
+#endif
+            if (HAS_N) sel[u] = sel[u] && (istream_extract(SI, j < nk ? j : nk - 1u, kbits) == 0u);   // Kmer.hpp:574-580
+        }
+        unsigned long long bal[PP];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int u = 0; u < PP; u++) { bal[u] = __ballot(sel[u]); any |= bal[u]; }
+        if (any) {
+            if (a.n_rep) {   // Kmer.hpp:1437
+#pragma unroll
+                for (int u = 0; u < PP; u++) {
+                    if (sel[u]) sel[u] = !rep_contains(a.rep, a.n_rep, val[u]);
+                    bal[u] = __ballot(sel[u]);
+                }
+            }
+            // output order = position order = (lane, u): everything selected by lower lanes comes first
+            const unsigned long long lt = lanemask_lt();
+            uint32_t idx = nout, total = 0;
+#pragma unroll
+            for (int u = 0; u < PP; u++) { idx += (uint32_t)__popcll(bal[u] & lt); total += (uint32_t)__popcll(bal[u]); }
+#pragma unroll
+            for (int u = 0; u < PP; u++) {
+                if (sel[u]) {
+                    const unsigned j = jb + u;
+                    const uint32_t p = hp_base + j;
+                    if (idx < cap) {
+                        a.out_min[cap0 + idx] = val[u];
+                        a.out_pos[cap0 + idx] = p;
+                        a.out_dir[cap0 + idx] = (uint8_t)dir[u];
+                        if (HAS_QUAL) {
+                            uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
+                            if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
+                            else { os = p; oe = p + K; }
+                            if (a.inline_minq) {
+                                const uint8_t *qq = a.qual + a.qual_off[r];
+                                uint8_t mq = 255;   // getMinQuality (ReadSelection.hpp:1302-1320)
+                                for (uint32_t bq = os; bq < oe; bq++) { uint8_t q = (uint8_t)(qq[bq] - 33); if (q < mq) mq = q; }
+                                a.out_mqual[cap0 + idx] = mq;
+                            } else {
+                                a.out_os[cap0 + idx] = os;
+                                a.out_oe[cap0 + idx] = oe;
+                            }
+                        }
+                    }
+                    idx++;
+                }
+            }
+            nout += total;
+        }
+        return nout;
+    }
+};
 #ifndef SCAN_MIN_WAVES
 #define SCAN_MIN_WAVES 1   // waves per SIMD the register allocator must allow (tuning knob)
 #endif
@@ -292,6 +427,11 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
     __shared__ uint32_t lds_stream[SCAN_WAVES][STREAM_WORDS];
     __shared__ uint32_t lds_istream[HAS_N ? SCAN_WAVES : 1][HAS_N ? ISTREAM_WORDS : 1];
     __shared__ QualMap lds_qmap[(HAS_QUAL && HPC) ? SCAN_WAVES : 1];
+    __shared__ uint16_t lds_lut[(HPC && !HAS_N) ? HPC_LUT_SIZE : 1];
+    if (HPC && !HAS_N) {
+        for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += SCAN_BLOCK) lds_lut[i] = hpc_lut_entry(i);
+        __syncthreads();
+    }
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wv = threadIdx.x >> 6;
     uint32_t *S = lds_stream[wv];
@@ -324,6 +464,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
         uint32_t prev_last = 0;    // last base of the previous tile's last word
         uint32_t prev_inv = 0;     // its invalid bit (HAS_N)
         uint64_t cx_bound = 0;     // sum over windows of the 2-mer bound numerator
+        uint64_t prev_word = 0;    // last word of the previous tile (complexity bound of lane 0)
 
         uint64_t x_next = (lane < nwords) ? rw[lane] : 0;
 
@@ -344,18 +485,21 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             // window w = words w, w+1 (64 positions).  With a_v / b_v the 2-mer counts of the two words,
             // sum_v (a_v + b_v)^2 <= 2 (Q_w + Q_{w+1}),  Q = sum_v count^2, and 3-mer collisions <= 2-mer
             // collisions, so  S_w <= Q_w + Q_{w+1} - 32.  Each word's Q enters at most two windows.
+            // Lane l evaluates the word BEFORE its own (lane 0: the last word of the previous tile): the base
+            // after that word is the lane's own first base, so nothing here waits for the prefetched tile.
 #if defined(SCAN_ABLATE) && SCAN_ABLATE == 3
             if (false) {                                                                          // ablation: no complexity bound
 #else
             if (a.apply_filters) {
 #endif
-                uint32_t nb = (uint32_t)__shfl_down((uint32_t)x & 3u, 1, 64);      // first base of the next word
-                uint32_t nb0 = (uint32_t)__shfl((uint32_t)x_next & 3u, 0, 64);
-                if (lane == 63) nb = nb0;
-                if ((uint64_t)wi * 32u + 33u <= L) {
+                uint64_t xp = __shfl_up(x, 1, 64);
+                if (lane == 0) xp = prev_word;
+                prev_word = __shfl(x, 63, 64);
+                if (wi >= 1u && (uint64_t)wi * 32u + 1u <= L) {          // word wi-1 is full and has a successor base
+                    const uint32_t wq = wi - 1u;
                     const uint32_t nW = L >= 66u ? (L - 66u) / 32u + 1u : 0u;
-                    uint32_t mult = (wi < nW ? 1u : 0u) + ((wi >= 1u && wi - 1u < nW) ? 1u : 0u);
-                    if (mult) cx_bound += (uint64_t)mult * word_pair_sq_sum(x, nb);
+                    uint32_t mult = (wq < nW ? 1u : 0u) + ((wq >= 1u && wq - 1u < nW) ? 1u : 0u);
+                    if (mult) cx_bound += (uint64_t)mult * word_pair_sq_sum(xp, (uint32_t)x & 3u);
                 }
             }
 
@@ -365,18 +509,34 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             if (HPC) {
                 uint32_t pl = (uint32_t)__shfl_up((uint32_t)(x >> 62), 1, 64);
                 if (lane == 0) pl = prev_last;
-                uint64_t diff = x ^ ((x << 2) | (uint64_t)pl);
-                d = (diff | (diff >> 1)) & M5;
-                if (HAS_N) {   // a change of the invalid bit also starts a run (N vs G share code 3)
+                if (!HAS_N) {
+                    // the first base of the read starts a run whatever precedes it: pretend a different base does
+                    if (wi == 0) pl = ((uint32_t)x & 3u) ^ 1u;
+                    unsigned nbits;
+                    y = compress_pairs_lut(lds_lut, x, pl, &nbits);
+                    c = nbits >> 1;
+                    d = 0;
+                    if (HAS_QUAL || nvalid < 32) {
+                        // run-start flags themselves: needed for the coordinate map, and to cut a partial word
+                        // (zero padding after the last base may look like one more run start)
+                        uint64_t diff = x ^ ((x << 2) | (uint64_t)pl);
+                        d = (diff | (diff >> 1)) & vspread;
+                        c = (unsigned)__popcll(d);
+                        y &= c >= 32 ? ~0ull : ((1ull << (2 * c)) - 1ull);
+                    }
+                } else {
+                    uint64_t diff = x ^ ((x << 2) | (uint64_t)pl);
+                    d = (diff | (diff >> 1)) & M5;
+                    // a change of the invalid bit also starts a run (N vs G share code 3)
                     uint32_t pi = (uint32_t)__shfl_up(iv >> 31, 1, 64);
                     if (lane == 0) pi = prev_inv;
                     d |= spread_bits(iv ^ ((iv << 1) | pi));
                     prev_inv = (uint32_t)__shfl(iv >> 31, 63, 64);
+                    if (wi == 0) d |= 1ull;
+                    d &= vspread;
+                    c = (unsigned)__popcll(d);
+                    y = compress_pairs(x, d);
                 }
-                if (wi == 0) d |= 1ull;
-                d &= vspread;
-                c = (unsigned)__popcll(d);
-                y = compress_pairs(x, d);
                 prev_last = (uint32_t)__shfl((uint32_t)(x >> 62), 63, 64);
             } else {
                 d = vspread;
@@ -420,73 +580,18 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             const unsigned nk = tot > K ? tot - K : 0u;
             const uint32_t hp_base = hp_total - cb;    // compressed-stream position of S base 0
             const uint32_t tile_base = t * TILE_WORDS * 32u;
-            // SCAN_UNROLL independent positions per lane and trip: the hash chains interleave (ILP) and the
-            // loop / ballot overhead is paid once per 64 * SCAN_UNROLL positions.  Branch-free: out-of-range
-            // lanes recompute the last valid position and are masked.
-#if defined(SCAN_ABLATE) && SCAN_ABLATE == 2
-            for (unsigned j0 = 0; j0 < 0; j0 += 64 * SCAN_UNROLL) {                              // ablation: no k-mer loop
-#else
-            for (unsigned j0 = 0; j0 < nk; j0 += 64 * SCAN_UNROLL) {
-#endif
-                bool sel[SCAN_UNROLL];
-                uint32_t val[SCAN_UNROLL], dir[SCAN_UNROLL];
-                unsigned long long bal[SCAN_UNROLL];
-                unsigned long long any = 0;
-#pragma unroll
-                for (int u = 0; u < SCAN_UNROLL; u++) {
-                    const unsigned j = j0 + 64u * u + lane;
-                    const unsigned jc = j < nk ? j : nk - 1u;
-                    uint32_t e = stream_extract(S, jc, kmask);
-                    uint32_t rev = e ^ comp_mask;
-                    uint32_t fwd = digit_reverse(e, K);
-                    dir[u] = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
-                    val[u] = dir[u] ? rev : fwd;
-                    // first k-mer of the read skipped (Kmer.hpp:1395)
-#if defined(SCAN_ABLATE) && SCAN_ABLATE == 1
-                    sel[u] = (val[u] == 0x12345u) && (j < nk);                                  // ablation: no hash
-#else
-                    sel[u] = (kmer_hash32(val[u]) < a.threshold) && (hp_base + j >= 1u) && (j < nk);
-#endif
-                    if (HAS_N) sel[u] = sel[u] && (istream_extract(SI, jc, kbits) == 0u);   // Kmer.hpp:574-580
-                }
-#pragma unroll
-                for (int u = 0; u < SCAN_UNROLL; u++) { bal[u] = __ballot(sel[u]); any |= bal[u]; }
-                if (any) {
-                    if (a.n_rep) {   // Kmer.hpp:1437
-#pragma unroll
-                        for (int u = 0; u < SCAN_UNROLL; u++) {
-                            if (sel[u]) sel[u] = !rep_contains(a.rep, a.n_rep, val[u]);
-                            bal[u] = __ballot(sel[u]);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < SCAN_UNROLL; u++) {
-                        const unsigned j = j0 + 64u * u + lane;
-                        const uint32_t p = hp_base + j;
-                        if (sel[u]) {
-                            uint32_t idx = nout + (uint32_t)__popcll(bal[u] & lanemask_lt());
-                            if (idx < cap) {
-                                a.out_min[cap0 + idx] = val[u];
-                                a.out_pos[cap0 + idx] = p;
-                                a.out_dir[cap0 + idx] = (uint8_t)dir[u];
-                                if (HAS_QUAL) {
-                                    uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
-                                    if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
-                                    else { os = p; oe = p + K; }
-                                    if (a.inline_minq) {
-                                        const uint8_t *qq = a.qual + a.qual_off[r];
-                                        uint8_t mq = 255;   // getMinQuality (ReadSelection.hpp:1302-1320)
-                                        for (uint32_t b = os; b < oe; b++) { uint8_t q = (uint8_t)(qq[b] - 33); if (q < mq) mq = q; }
-                                        a.out_mqual[cap0 + idx] = mq;
-                                    } else {
-                                        a.out_os[cap0 + idx] = os;
-                                        a.out_oe[cap0 + idx] = oe;
-                                    }
-                                }
-                            }
-                        }
-                        nout += (uint32_t)__popcll(bal[u]);
-                    }
+            // Each lane takes PP ADJACENT positions per trip: one LDS read and one digit reversal serve all of
+            // them (the forward k-mer of the next position is a shift-in of one base), and the PP hash chains
+            // interleave.  The last trip of a tile uses the smallest PP that covers what is left.
+            for (unsigned j0 = 0; j0 < nk; j0 += 64 * SCAN_PP) {
+                const unsigned left = nk - j0;
+                const unsigned pp = left >= 64u * SCAN_PP ? (unsigned)SCAN_PP : (left + 63u) / 64u;
+                KmerTrip<HPC, HAS_QUAL, HAS_N> trip{a, S, SI, Q, K, kmask, kbits, comp_mask, lane, nk, hp_base, cb, tile_base, cap0, cap, r};
+                switch (pp) {
+                    case 1: nout = trip.template run<1>(j0, nout); break;
+                    case 2: nout = trip.template run<2>(j0, nout); break;
+                    case 3: nout = trip.template run<3>(j0, nout); break;
+                    default: nout = trip.template run<4>(j0, nout); break;
                 }
             }
 
