@@ -159,6 +159,11 @@ int  mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_
                        uint64_t n, uint32_t *abundance);
 void mdbg_table_free(mdbg_table *t);
 
+/* Page-locked host memory for read batches handed to mdbg_reads_from_ascii / _from_packed: uploads from it
+ * run at PCIe rate instead of through the driver's staging copies.  Release with mdbg_host_free. */
+int  mdbg_host_alloc(mdbg_ctx *ctx, size_t bytes, void **out);
+void mdbg_host_free(mdbg_ctx *ctx, void *p);
+
 /* Stream-ordered device-to-device copy on the context stream followed by a synchronize; lets a
  * harness move library-owned rows into buffers it owns (e.g. torch tensors for RCCL). */
 int  mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t bytes);

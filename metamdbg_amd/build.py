@@ -63,11 +63,12 @@ def build_lib(force: bool = False, verbose: bool = False, tag: str = "", extra_f
 def build_tool() -> str:
     """The C++ host tool (drop-in readSelection / graph over the C ABI), in-tree at metamdbg_amd/bin/mdbg_tool."""
     src = os.path.join(HERE, "host", "mdbg_tool.cpp")
-    deps = [src, os.path.join(HERE, "host", "fastx.hpp"), os.path.join(HERE, "..", "include", "mdbg_hip.h"), LIB]
+    deps = [src, os.path.join(HERE, "host", "fastx.hpp"), os.path.join(HERE, "host", "hostfeed.hpp"),
+            os.path.join(HERE, "..", "include", "mdbg_hip.h"), LIB]
     out = os.path.join(HERE, "bin", "mdbg_tool")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if _stale(out, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", src, "-o", out, "-L" + HERE, "-lmdbg_hip", "-lz",
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", src, "-o", out, "-L" + HERE, "-lmdbg_hip", "-lz", "-lpthread",
                "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:

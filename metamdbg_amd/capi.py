@@ -51,6 +51,8 @@ SIGNATURES = {
     "mdbg_reads_get": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _u32p]),
     "mdbg_reads_export_ascii": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _u64p]),
     "mdbg_memcpy_device": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "mdbg_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "mdbg_host_free": (None, [_P, _P]),
     "mdbg_reads_free": (None, [_P]),
     "mdbg_scan": (C.c_int, [_P, _P, C.POINTER(ScanParams), C.POINTER(_P)]),
     "mdbg_minimizers_info": (C.c_int, [_P, _u32p, _u64p]),

@@ -123,3 +123,16 @@ extern "C" int mdbg_timing_get(mdbg_ctx *ctx, const char *kernel, double *ms_tot
     if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.second;
     return MDBG_OK;
 }
+
+extern "C" int mdbg_host_alloc(mdbg_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_host_alloc: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return set_error(ctx, MDBG_ENOMEM, "hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return MDBG_OK;
+}
+
+extern "C" void mdbg_host_free(mdbg_ctx *ctx, void *p) {
+    (void)ctx;
+    if (p) (void)hipHostFree(p);
+}

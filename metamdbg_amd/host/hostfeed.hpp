@@ -1,0 +1,351 @@
+// hostfeed.hpp -- parallel FASTA / FASTQ ingestion for the host tool.
+//
+// The reference parses with one kseq reader inside an `omp critical` (Commons.hpp:5868-5905), which
+// caps it near 0.5 Gbp/s whatever the thread count.  Here a plain (uncompressed) file is mmap'ed and
+// cut at record boundaries into chunks that worker threads parse independently into page-locked
+// batches (read order preserved by sequence numbers); gzip files fall back to a sequential reader
+// thread (one deflate stream cannot be split).  Batches come out in file order, ready for
+// mdbg_reads_from_ascii.
+#pragma once
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fastx.hpp"
+
+namespace mdbg_host {
+
+struct ReadBatch {
+    char *bases = nullptr;      // page-locked, `cap` bytes
+    char *quals = nullptr;      // page-locked, `cap` bytes
+    size_t cap = 0;
+    size_t nbases = 0;
+    std::vector<uint64_t> offsets{0};
+    bool hasQual = false;
+    int file = 0;
+    uint32_t n() const { return (uint32_t)(offsets.size() - 1); }
+    void clear() { nbases = 0; offsets.assign(1, 0); hasQual = false; }
+};
+
+class ReadFeeder {
+public:
+    using Alloc = std::function<void *(size_t)>;
+    using Free = std::function<void(void *)>;
+
+    ReadFeeder(std::vector<std::string> files, size_t chunkBytes, int threads, uint64_t maxReadsPerFile, Alloc alloc, Free free_)
+        : files_(std::move(files)), chunk_(chunkBytes), maxReads_(maxReadsPerFile), free_(std::move(free_)),
+          fileDone_(files_.size() ? files_.size() : 1) {
+        for (auto &f : fileDone_) f.store(false);
+        if (threads < 1) threads = 1;
+        const int nbuf = threads + 3;
+        for (int i = 0; i < nbuf; i++) {
+            ReadBatch *b = new ReadBatch();
+            b->cap = chunk_ + 64;
+            b->bases = (char *)alloc(b->cap);
+            b->quals = (char *)alloc(b->cap);
+            if (!b->bases || !b->quals) throw std::runtime_error("page-locked batch allocation failed");
+            all_.push_back(b);
+            freeList_.push_back(b);
+        }
+        splitter_ = std::thread([this] { split(); });
+        for (int i = 0; i < threads; i++) workers_.emplace_back([this] { work(); });
+    }
+
+    ~ReadFeeder() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cvWork_.notify_all(); cvFree_.notify_all(); cvDone_.notify_all();
+        if (splitter_.joinable()) splitter_.join();
+        for (auto &t : workers_) if (t.joinable()) t.join();
+        for (ReadBatch *b : all_) { free_(b->bases); free_(b->quals); delete b; }
+        for (auto &m : maps_) if (m.addr) munmap((void *)m.addr, m.len);
+    }
+
+    // Next batch in read order, nullptr at the end.  Give it back with recycle().
+    ReadBatch *next() {
+        for (;;) {
+            ReadBatch *b = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cvDone_.wait(g, [&] { return stop_ || !error_.empty() || done_.count(nextSeq_) || (splitDone_ && nextSeq_ >= totalSeq_); });
+                if (!error_.empty()) throw std::runtime_error(error_);
+                if (stop_) return nullptr;
+                auto it = done_.find(nextSeq_);
+                if (it == done_.end()) return nullptr;   // all chunks delivered
+                b = it->second;
+                done_.erase(it);
+                nextSeq_++;
+            }
+            // per-file read cap (the reference's `_maxReads`: readIndexPerDataset > maxReads stops the file)
+            if (maxReads_ > 0) {
+                if ((size_t)b->file >= perFile_.size()) perFile_.resize(b->file + 1, 0);
+                uint64_t &seen = perFile_[b->file];
+                const uint64_t allowed = maxReads_ + 1 > seen ? maxReads_ + 1 - seen : 0;
+                if (b->n() > allowed) { b->offsets.resize(allowed + 1); b->nbases = b->offsets.back(); }
+                seen += b->n();
+                if (seen >= maxReads_ + 1) fileDone_[b->file].store(true);   // later chunks of this file are skipped
+            }
+            if (b->n() == 0) { recycle(b); continue; }
+            return b;
+        }
+    }
+
+    void recycle(ReadBatch *b) {
+        b->clear();
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            freeList_.push_back(b);
+        }
+        cvFree_.notify_all();
+        cvWork_.notify_all();
+    }
+
+private:
+    struct Mapping { const char *addr = nullptr; size_t len = 0; };
+    struct Work { uint64_t seq; int file; const char *begin; const char *end; bool fastq; bool gz; std::string path; };
+
+    static bool is_gzip(const std::string &path) {
+        unsigned char m[2] = {0, 0};
+        int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("File not found: " + path);
+        ssize_t n = read(fd, m, 2);
+        close(fd);
+        return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+    }
+
+    static bool is_record_start(const char *c, const char *end, bool fastq) {
+        if (!fastq) return *c == '>';
+        if (*c != '@') return false;
+        // a header is followed two lines later by a '+' line (a quality line starting with '@' is not)
+        const char *l1 = (const char *)memchr(c, '\n', (size_t)(end - c));
+        const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', (size_t)(end - l1 - 1)) : nullptr;
+        return l2 && l2 + 1 < end && l2[1] == '+';
+    }
+
+    // last record start in (p, lim]; p if there is none
+    static const char *last_record_before(const char *p, const char *lim, const char *end, bool fastq) {
+        const char *r = lim;
+        while (r > p) {
+            const char *nl = (const char *)memrchr(p, '\n', (size_t)(r - p));
+            if (!nl) return p;
+            const char *cand = nl + 1;
+            if (cand < end && cand <= lim && is_record_start(cand, end, fastq)) return cand;
+            r = nl;
+        }
+        return p;
+    }
+
+    void push_work(Work w) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            work_.push_back(std::move(w));
+        }
+        cvWork_.notify_one();
+    }
+
+    void split() {
+        try {
+            uint64_t seq = 0;
+            for (size_t f = 0; f < files_.size(); f++) {
+                const std::string &path = files_[f];
+                if (is_gzip(path)) {
+                    // one deflate stream: a single sequential work item produces all its batches in order
+                    seq = read_gz(path, (int)f, seq);
+                    continue;
+                }
+                int fd = open(path.c_str(), O_RDONLY);
+                if (fd < 0) throw std::runtime_error("File not found: " + path);
+                struct stat st;
+                fstat(fd, &st);
+                if (st.st_size == 0) { close(fd); continue; }
+                const char *addr = (const char *)mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                close(fd);
+                if (addr == MAP_FAILED) throw std::runtime_error("mmap failed: " + path);
+                madvise((void *)addr, (size_t)st.st_size, MADV_SEQUENTIAL);
+                maps_.push_back({addr, (size_t)st.st_size});
+                const char *begin = addr, *end = addr + st.st_size;
+                while (begin < end && (*begin == '\n' || *begin == '\r')) begin++;
+                if (begin == end) continue;
+                const bool fastq = *begin == '@';
+                if (!fastq && *begin != '>') throw std::runtime_error("not FASTA/FASTQ: " + path);
+                const char *p = begin;
+                while (p < end && !fileDone_[f].load()) {
+                    const char *q = end;
+                    if ((size_t)(end - p) > chunk_) {
+                        q = last_record_before(p, p + chunk_, end, fastq);
+                        if (q == p) throw std::runtime_error("a single read is larger than the batch size; raise --batch-bases");
+                    }
+                    push_work({seq++, (int)f, p, q, fastq, false, ""});
+                    p = q;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                totalSeq_ = seq;
+                splitDone_ = true;
+            }
+            cvWork_.notify_all(); cvDone_.notify_all();
+        } catch (const std::exception &e) { fail(e.what()); }
+    }
+
+    // used by the sequential gzip reader only: earlier (lower sequence number) work items must already own
+    // their buffers, otherwise later batches could starve them
+    ReadBatch *take_free() {
+        std::unique_lock<std::mutex> g(mu_);
+        cvFree_.wait(g, [&] { return stop_ || (!freeList_.empty() && work_.empty()); });
+        if (stop_) return nullptr;
+        ReadBatch *b = freeList_.back();
+        freeList_.pop_back();
+        return b;
+    }
+
+    void deliver(uint64_t seq, ReadBatch *b) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            done_[seq] = b;
+        }
+        cvDone_.notify_all();
+    }
+
+    // gzip: sequential decode on the splitter thread itself
+    uint64_t read_gz(const std::string &path, int file, uint64_t seq) {
+        FastxReader rd(path);
+        if (!rd.ok()) throw std::runtime_error("File not found: " + path);
+        std::string s, q;
+        ReadBatch *b = take_free();
+        if (!b) return seq;
+        b->file = file;
+        for (;;) {
+            s.clear(); q.clear();
+            bool hq = false;
+            if (fileDone_[file].load()) break;
+            if (!rd.next(s, q, hq)) break;
+            if (s.size() > chunk_) throw std::runtime_error("a single read is larger than the batch size; raise --batch-bases");
+            if ((b->n() && hq != b->hasQual) || b->nbases + s.size() > chunk_) {
+                deliver(seq++, b);
+                b = take_free();
+                if (!b) return seq;
+                b->file = file;
+            }
+            b->hasQual = hq;
+            memcpy(b->bases + b->nbases, s.data(), s.size());
+            if (hq) memcpy(b->quals + b->nbases, q.data(), s.size());
+            b->nbases += s.size();
+            b->offsets.push_back(b->nbases);
+        }
+        deliver(seq++, b);
+        return seq;
+    }
+
+    void parse(const Work &w, ReadBatch *b) {
+        b->file = w.file;
+        b->hasQual = w.fastq;
+        const char *p = w.begin, *end = w.end;
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));   // header line
+            if (!nl) break;
+            p = nl + 1;
+            if (!w.fastq) {
+                // sequence lines until the next '>' at a line start
+                while (p < end && *p != '>') {
+                    nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    const char *le = nl ? nl : end;
+                    size_t n = (size_t)(le - p);
+                    if (n && p[n - 1] == '\r') n--;
+                    memcpy(b->bases + b->nbases, p, n);
+                    b->nbases += n;
+                    p = nl ? nl + 1 : end;
+                }
+            } else {
+                nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                const char *le = nl ? nl : end;
+                size_t n = (size_t)(le - p);
+                if (n && p[n - 1] == '\r') n--;
+                memcpy(b->bases + b->nbases, p, n);
+                p = nl ? nl + 1 : end;
+                if (p >= end || *p != '+') throw std::runtime_error("FASTQ records are not 4-line; unwrap or gzip the file");
+                nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                if (!nl) throw std::runtime_error("truncated FASTQ record");
+                p = nl + 1;
+                nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                le = nl ? nl : end;
+                size_t nq = (size_t)(le - p);
+                if (nq && p[nq - 1] == '\r') nq--;
+                if (nq != n) throw std::runtime_error("FASTQ quality length differs from sequence length");
+                memcpy(b->quals + b->nbases, p, n);
+                b->nbases += n;
+                p = nl ? nl + 1 : end;
+            }
+            b->offsets.push_back(b->nbases);
+        }
+    }
+
+    void work() {
+        try {
+            for (;;) {
+                Work w;
+                ReadBatch *b = nullptr;
+                {
+                    // a work item is taken only together with a buffer: items leave the queue in sequence
+                    // order, so the batch the consumer waits for always owns a buffer (no deadlock)
+                    std::unique_lock<std::mutex> g(mu_);
+                    cvWork_.wait(g, [&] { return stop_ || (!work_.empty() && !freeList_.empty()) || (splitDone_ && work_.empty()); });
+                    if (stop_) return;
+                    if (work_.empty()) return;
+                    w = std::move(work_.front());
+                    work_.pop_front();
+                    b = freeList_.back();
+                    freeList_.pop_back();
+                }
+                cvFree_.notify_all();   // the sequential gzip reader waits for an empty work queue
+                if (!fileDone_[w.file].load()) parse(w, b); else b->file = w.file;
+                deliver(w.seq, b);
+            }
+        } catch (const std::exception &e) { fail(e.what()); }
+    }
+
+    void fail(const std::string &msg) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (error_.empty()) error_ = msg;
+        }
+        cvDone_.notify_all(); cvWork_.notify_all(); cvFree_.notify_all();
+    }
+
+    std::vector<std::string> files_;
+    size_t chunk_;
+    uint64_t maxReads_;
+    Free free_;
+    std::vector<ReadBatch *> all_, freeList_;
+    std::deque<Work> work_;
+    std::map<uint64_t, ReadBatch *> done_;
+    std::vector<Mapping> maps_;
+    std::vector<uint64_t> perFile_;
+    std::vector<std::atomic<bool>> fileDone_;
+    std::mutex mu_;
+    std::condition_variable cvWork_, cvFree_, cvDone_;
+    std::thread splitter_;
+    std::vector<std::thread> workers_;
+    uint64_t nextSeq_ = 0, totalSeq_ = 0;
+    bool splitDone_ = false, stop_ = false;
+    std::string error_;
+};
+
+}  // namespace mdbg_host

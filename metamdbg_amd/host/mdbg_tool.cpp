@@ -31,6 +31,7 @@
 
 #include "../../include/mdbg_hip.h"
 #include "fastx.hpp"
+#include "hostfeed.hpp"
 
 namespace {
 
@@ -120,7 +121,7 @@ struct Args {
     float minReadQuality = 0;
     bool skipCorrection = false, outputQuality = false, firstPass = false;
     uint32_t minAbundance = 0;
-    size_t batchBases = (size_t)1 << 30;   // bases per device batch (not a reference flag)
+    size_t batchBases = (size_t)64 << 20;  // bytes of input per device batch (not a reference flag)
 };
 Args parse_args(int argc, char **argv, int first) {
     Args a;
@@ -140,47 +141,32 @@ Args parse_args(int argc, char **argv, int first) {
     return a;
 }
 
-// ---- a batch of parsed reads ------------------------------------------------------------------------------
-struct Batch {
-    std::string bases, quals;
-    std::vector<uint64_t> offsets{0};
-    bool anyQual = false;
-    uint32_t n() const { return (uint32_t)(offsets.size() - 1); }
-    void clear() { bases.clear(); quals.clear(); offsets.assign(1, 0); anyQual = false; }
-};
+// ---- batches of parsed reads ---------------------------------------------------------------------------------
+using mdbg_host::ReadBatch;
 
-// Feeds `fn` with batches of reads from the files listed in inputList; at most maxReadsPerFile + 1 reads of
-// each file when maxReadsPerFile > 0 (the reference's `_maxReads` check, Commons.hpp:5873).
-void for_each_batch(const std::string &inputList, size_t batchBases, uint64_t maxReadsPerFile, const std::function<void(Batch &)> &fn) {
+std::vector<std::string> read_input_list(const std::string &inputList) {
     std::ifstream lst(inputList);
     if (!lst) die("File not found: " + inputList);
+    std::vector<std::string> files;
     std::string path;
-    Batch b;
-    while (std::getline(lst, path)) {
-        if (path.empty()) continue;
-        mdbg_host::FastxReader rd(path);
-        if (!rd.ok()) die("File not found: " + path);
-        uint64_t perFile = 0;
-        for (;;) {
-            if (maxReadsPerFile > 0 && perFile > maxReadsPerFile) break;
-            bool hasQ = false;
-            const size_t q0 = b.quals.size();
-            if (!rd.next(b.bases, b.quals, hasQ)) break;
-            perFile++;
-            if (hasQ != b.anyQual && b.n() > 0) {
-                // FASTA and FASTQ records never share a batch: cut before this read
-                std::string seq = b.bases.substr(b.offsets.back()), ql = b.quals.substr(q0);
-                b.bases.resize(b.offsets.back()); b.quals.resize(q0);
-                fn(b);
-                b.clear();
-                b.bases = seq; b.quals = ql;
-            }
-            b.anyQual = hasQ;
-            b.offsets.push_back(b.bases.size());
-            if (b.bases.size() >= batchBases) { fn(b); b.clear(); }
+    while (std::getline(lst, path)) if (!path.empty()) files.push_back(path);
+    return files;
+}
+
+// Feeds `fn` with batches of reads, in read order, from the files of inputList; at most maxReadsPerFile + 1 reads
+// of each file when maxReadsPerFile > 0 (the reference's `_maxReads` check, Commons.hpp:5873).  Parsing runs on
+// `threads` workers into page-locked buffers (hostfeed.hpp) while fn -- upload, kernels, record writing -- runs here.
+void for_each_batch(const std::string &inputList, size_t batchBases, int threads, uint64_t maxReadsPerFile,
+                    const std::function<void(ReadBatch &)> &fn) {
+    auto alloc = [](size_t n) -> void * { void *p = nullptr; check(mdbg_host_alloc(g_ctx, n, &p), "mdbg_host_alloc"); return p; };
+    auto release = [](void *p) { mdbg_host_free(g_ctx, p); };
+    try {
+        mdbg_host::ReadFeeder feeder(read_input_list(inputList), batchBases, threads, maxReadsPerFile, alloc, release);
+        while (ReadBatch *b = feeder.next()) {
+            fn(*b);
+            feeder.recycle(b);
         }
-    }
-    if (b.n() > 0) fn(b);
+    } catch (const std::exception &e) { die(e.what()); }
 }
 
 mdbg_scan_params scan_params(const Parameters &P, float density, const std::vector<uint32_t> &rep, float minQ, bool filters) {
@@ -211,10 +197,10 @@ int run_read_selection(int argc, char **argv) {
         if (!P.hpc) {
             std::vector<uint32_t> all;
             std::vector<uint64_t> offs{0};
-            for_each_batch(inputList, a.batchBases, 1000000, [&](Batch &b) {
+            for_each_batch(inputList, a.batchBases, a.threads, 1000000, [&](ReadBatch &b) {
                 mdbg_reads *reads = nullptr;
                 mdbg_minimizers *mins = nullptr;
-                check(mdbg_reads_from_ascii(g_ctx, b.bases.data(), nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+                check(mdbg_reads_from_ascii(g_ctx, b.bases, nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
                 mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
                 check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
                 uint32_t n; uint64_t t;
@@ -253,10 +239,10 @@ int run_read_selection(int argc, char **argv) {
     long double qualitySum = 0, qualityN = 0;
     std::vector<mdbg_minimizers *> kept;   // device-resident minimizer reads, purged once N50 is known
     const bool needCorrected = P.hpc || a.skipCorrection;
-    for_each_batch(inputList, a.batchBases, 0, [&](Batch &b) {
+    for_each_batch(inputList, a.batchBases, a.threads, 0, [&](ReadBatch &b) {
         mdbg_reads *reads = nullptr;
         mdbg_minimizers *mins = nullptr;
-        check(mdbg_reads_from_ascii(g_ctx, b.bases.data(), b.anyQual ? b.quals.data() : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+        check(mdbg_reads_from_ascii(g_ctx, b.bases, b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
         mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
         check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
         mdbg_reads_free(reads);

