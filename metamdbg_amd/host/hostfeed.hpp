@@ -52,13 +52,16 @@ public:
           fileDone_(files_.size() ? files_.size() : 1) {
         for (auto &f : fileDone_) f.store(false);
         if (threads < 1) threads = 1;
-        const int nbuf = threads + 3;
+        // parsing is memcpy-bound (4 workers deliver ~7 GB/s) and page-locking memory costs ~1 ms per MB:
+        // more workers / buffers only add start-up time
+        if (threads > 6) threads = 6;
+        alloc_ = std::move(alloc);
+        const int nbuf = threads + 2;
         for (int i = 0; i < nbuf; i++) {
             ReadBatch *b = new ReadBatch();
             b->cap = chunk_ + 64;
-            b->bases = (char *)alloc(b->cap);
-            b->quals = (char *)alloc(b->cap);
-            if (!b->bases || !b->quals) throw std::runtime_error("page-locked batch allocation failed");
+            b->bases = (char *)alloc_(b->cap);      // quality buffers are allocated on first use (FASTQ only)
+            if (!b->bases) throw std::runtime_error("page-locked batch allocation failed");
             all_.push_back(b);
             freeList_.push_back(b);
         }
@@ -74,7 +77,7 @@ public:
         cvWork_.notify_all(); cvFree_.notify_all(); cvDone_.notify_all();
         if (splitter_.joinable()) splitter_.join();
         for (auto &t : workers_) if (t.joinable()) t.join();
-        for (ReadBatch *b : all_) { free_(b->bases); free_(b->quals); delete b; }
+        for (ReadBatch *b : all_) { free_(b->bases); if (b->quals) free_(b->quals); delete b; }
         for (auto &m : maps_) if (m.addr) munmap((void *)m.addr, m.len);
     }
 
@@ -246,6 +249,7 @@ private:
             }
             b->hasQual = hq;
             memcpy(b->bases + b->nbases, s.data(), s.size());
+            if (hq && !b->quals) { b->quals = (char *)alloc_(b->cap); if (!b->quals) throw std::runtime_error("page-locked batch allocation failed"); }
             if (hq) memcpy(b->quals + b->nbases, q.data(), s.size());
             b->nbases += s.size();
             b->offsets.push_back(b->nbases);
@@ -257,6 +261,7 @@ private:
     void parse(const Work &w, ReadBatch *b) {
         b->file = w.file;
         b->hasQual = w.fastq;
+        if (w.fastq && !b->quals) { b->quals = (char *)alloc_(b->cap); if (!b->quals) throw std::runtime_error("page-locked batch allocation failed"); }
         const char *p = w.begin, *end = w.end;
         while (p < end) {
             const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));   // header line
@@ -332,6 +337,7 @@ private:
     std::vector<std::string> files_;
     size_t chunk_;
     uint64_t maxReads_;
+    Alloc alloc_;
     Free free_;
     std::vector<ReadBatch *> all_, freeList_;
     std::deque<Work> work_;

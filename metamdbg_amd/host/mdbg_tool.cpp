@@ -41,6 +41,14 @@ namespace {
 }
 
 mdbg_ctx *g_ctx = nullptr;
+
+// phase timings on stderr when MDBG_TRACE is set
+struct Trace {
+    double t0;
+    static double now() { struct timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+    Trace() : t0(now()) {}
+    void mark(const char *what) { if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg_tool] %8.3f s  %s\n", now() - t0, what); }
+} g_trace;
 void check(int rc, const char *what) {
     if (rc != MDBG_OK) die(std::string(what) + ": " + mdbg_last_error(g_ctx));
 }
@@ -121,7 +129,7 @@ struct Args {
     float minReadQuality = 0;
     bool skipCorrection = false, outputQuality = false, firstPass = false;
     uint32_t minAbundance = 0;
-    size_t batchBases = (size_t)64 << 20;  // bytes of input per device batch (not a reference flag)
+    size_t batchBases = (size_t)32 << 20;  // bytes of input per device batch (not a reference flag)
 };
 Args parse_args(int argc, char **argv, int first) {
     Args a;
@@ -189,6 +197,7 @@ int run_read_selection(int argc, char **argv) {
     Parameters P;
     P.load(tmpDir + "/parameters.gz");
     check(mdbg_create(0, &g_ctx), "mdbg_create");
+    g_trace.mark("context created");
 
     // repetitive minimizers (ReadSelection.hpp:497-561): HiFi writes an empty file
     std::vector<uint32_t> rep;
@@ -276,6 +285,7 @@ int run_read_selection(int argc, char **argv) {
         if (needCorrected) kept.push_back(mins); else mdbg_minimizers_free(mins);
     });
     out.close();
+    g_trace.mark("main pass done (parse + scan + read_data_init.txt)");
 
     // read_stats.txt (ReadSelection.hpp:305-384)
     const uint64_t nbReads = allReadSizes.size();
@@ -315,8 +325,10 @@ int run_read_selection(int argc, char **argv) {
             mdbg_minimizers_free(mins);
         }
     }
+    g_trace.mark("read_data_corrected.txt written");
     write_perf(tmpDir);
     mdbg_destroy(g_ctx);
+    g_trace.mark("done");
     return 0;
 }
 
