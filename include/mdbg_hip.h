@@ -157,6 +157,13 @@ int  mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, 
  * graph/CreateMdbg.cpp:3990): abundance of each of n keys, 0 when absent. */
 int  mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
                        uint64_t n, uint32_t *abundance);
+/* SURVEY.md 8(f) N2 -- EdgeIndexer (graph/CreateMdbg.hpp:4010-4230, driven by indexEdges, graph/CreateMdbg.cpp:1178-1186):
+ * the distinct identities of the normalised (k-1)-prefix and (k-1)-suffix of every k-min-mer vector of `nodes`
+ * (a table with vectors, i.e. the rows of kminmerData_min.txt) = the content of edges.bin.  The result is a table
+ * without vectors whose abundance column is 0; *checksum = sum of the identities truncated to u64 as the reference
+ * logs it.  Fetch the 16-byte records with mdbg_table_keys_to_host (u128 little-endian: lo, hi). */
+int  mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum);
+int  mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_lo_hi);
 void mdbg_table_free(mdbg_table *t);
 
 /* Page-locked host memory for read batches handed to mdbg_reads_from_ascii / _from_packed: uploads from it

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mdbg_table_info": (C.c_int, [_P, _u32p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "mdbg_table_to_host": (C.c_int, [_P, _P, _P, _P]),
     "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
+    "mdbg_edge_index": (C.c_int, [_P, _P, C.POINTER(_P), _u64p]),
+    "mdbg_table_keys_to_host": (C.c_int, [_P, _P, _P]),
     "mdbg_table_free": (None, [_P]),
     "mdbg_row_words": (C.c_uint32, [C.c_uint32]),
     "mdbg_kminmer_partial_counts": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), _u64p]),
@@ -230,6 +232,13 @@ class Context:
     def memcpy_device(self, dst_ptr: int, src_ptr: int, nbytes: int) -> None:
         self.check(lib().mdbg_memcpy_device(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
 
+    def edge_index(self, nodes: "Table") -> tuple["Table", int]:
+        """EdgeIndexer: (table of distinct prefix/suffix identities, checksum as the reference logs it)."""
+        h = C.c_void_p()
+        ck = C.c_uint64()
+        self.check(lib().mdbg_edge_index(self.h, nodes.h, C.byref(h), C.byref(ck)))
+        return Table(self, h), ck.value
+
     # -- multi-GPU pieces --------------------------------------------------------------------------
     def partial_counts(self, m: "Minimizers", k: int, n_ranks: int) -> tuple[int, np.ndarray]:
         """(device pointer of the owner-grouped rows, rows per owner)."""
@@ -345,6 +354,13 @@ class Table:
         vec = np.zeros((i["n_records"], i["k"]), dtype=np.uint32) if i["has_vectors"] else None
         self.ctx.check(lib().mdbg_table_to_host(self.ctx.h, self.h, _ptr(rec), _ptr(vec)))
         return rec, vec
+
+    def keys_to_host(self) -> np.ndarray:
+        """(n, 2) u64 array of (lo, hi) -- the 16-byte little-endian u128 records of edges.bin."""
+        n = self.info()["n_records"]
+        out = np.zeros((n, 2), dtype=np.uint64)
+        self.ctx.check(lib().mdbg_table_keys_to_host(self.ctx.h, self.h, _ptr(out)))
+        return out
 
     def lookup(self, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
         lo = np.ascontiguousarray(lo, dtype=np.uint64)

@@ -333,6 +333,31 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView t, const uint64_t
     out[i] = table_lookup(t, lo[i], hi[i], v) ? v : 0u;
 }
 
+// EdgeIndexer::partitionNode (graph/CreateMdbg.hpp:4083-4100): prefix and suffix identities of one node
+__global__ __launch_bounds__(256) void edge_insert_kernel(const uint32_t *vecs, uint64_t n, uint32_t k, TableView t) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *v = vecs + i * k;
+    uint64_t hi, lo;
+    window_hash(v, k - 1, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, 0u);
+    window_hash(v + 1, k - 1, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void sum_u64_kernel(const uint64_t *v, uint64_t n, unsigned long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = i < n ? v[i] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    if ((threadIdx.x & 63u) == 0 && x) atomicAdd(out, (unsigned long long)x);
+}
+
+__global__ void interleave_keys_kernel(const uint64_t *lo, const uint64_t *hi, uint64_t n, uint64_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[2 * i] = lo[i]; out[2 * i + 1] = hi[i]; }
+}
+
 __global__ void unpack_records_kernel(const uint8_t *rec, uint64_t n, uint64_t *lo, uint64_t *hi, uint32_t *ab) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -736,6 +761,62 @@ extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint6
     hipLaunchKernelGGL(lookup_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, t->lookup->view(), dl.p, dh.p, n, dv.p);
     MDBG_HIP_CHECK(ctx, hipMemcpyAsync(abundance, dv.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum) {
+    if (!ctx || !nodes || !edges) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: null argument");
+    if (!nodes->has_vectors || nodes->k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: needs a table with vectors (k <= firstK+1)");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = nodes->n_records;
+    DeviceTable tab;
+    MDBG_TRY(build_table_adaptive(ctx, tab, n, 2 * n, [&](TableView v) {
+        if (n) {
+            LaunchTimer timer(ctx, "edge_index");
+            hipLaunchKernelGGL(edge_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, nodes->d_vec.p, n, nodes->k, v);
+        }
+        return MDBG_OK;
+    }));
+    TableView tv = tab.view();
+    const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
+    DevBuf<uint32_t> sflag;
+    DevBuf<uint64_t> spos;
+    MDBG_TRY(sflag.alloc(ctx, nslots));
+    MDBG_TRY(spos.alloc(ctx, nslots + 1));
+    hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 2, sflag.p);
+    MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
+    uint64_t n_rows = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    mdbg_table *t = new mdbg_table();
+    t->k = nodes->k - 1;
+    t->n_solid = n_rows;
+    int rc = alloc_rows(ctx, t, n_rows, false);
+    if (rc) { delete t; return rc; }
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, nullptr, t->k};
+    hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, sflag.p, spos.p, SeqView{}, SeqView{}, ro, (uint64_t)0);
+    if (checksum) {
+        DevBuf<unsigned long long> acc;
+        rc = acc.alloc(ctx, 1);
+        if (rc) { delete t; return rc; }
+        (void)hipMemsetAsync(acc.p, 0, 8, ctx->stream);
+        if (n_rows) hipLaunchKernelGGL(sum_u64_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, ctx->stream, t->d_lo.p, n_rows, acc.p);
+        hipError_t e = memcpy_sync(ctx, checksum, acc.p, 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "edge checksum copy failed: %s", hipGetErrorString(e)); }
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "mdbg_edge_index failed: %s", hipGetErrorString(e)); }
+    *edges = t;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_lo_hi) {
+    if (!ctx || !t || (t->n_records && !keys_lo_hi)) return set_error(ctx, MDBG_EINVAL, "mdbg_table_keys_to_host: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!t->n_records) return MDBG_OK;
+    DevBuf<uint64_t> tmp;
+    MDBG_TRY(tmp.alloc(ctx, t->n_records * 2));
+    hipLaunchKernelGGL(interleave_keys_kernel, dim3(grid_for(t->n_records, 256)), dim3(256), 0, ctx->stream, t->d_lo.p, t->d_hi.p, t->n_records, tmp.p);
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, keys_lo_hi, tmp.p, t->n_records * 16, hipMemcpyDeviceToHost));
     return MDBG_OK;
 }
 

@@ -721,3 +721,26 @@ void orc_kminmer_index(const uint32_t *mins, const uint64_t *off, uint64_t n_seq
     out->n_solid = out->n;
     free(tmp); free(ents);
 }
+
+uint64_t orc_edge_index(const uint32_t *vecs, uint64_t n, unsigned k, uint64_t *out_hi, uint64_t *out_lo, uint64_t *checksum)
+{
+    idx_ent *e = (idx_ent *)malloc((n ? 2 * n : 1) * sizeof(idx_ent));
+    uint32_t *tmp = (uint32_t *)malloc(k * sizeof(uint32_t));
+    for (uint64_t i = 0; i < n; i++) { /* partitionNode (graph/CreateMdbg.hpp:4083-4100): prefix = first k-1, suffix = last k-1 */
+        orc_kminmer_normalize(vecs + i * k, k - 1, tmp);
+        orc_kminmer_hash128(tmp, k - 1, &e[2 * i].hi, &e[2 * i].lo);
+        orc_kminmer_normalize(vecs + i * k + 1, k - 1, tmp);
+        orc_kminmer_hash128(tmp, k - 1, &e[2 * i + 1].hi, &e[2 * i + 1].lo);
+        e[2 * i].a = e[2 * i + 1].a = 0;
+    }
+    qsort(e, 2 * n, sizeof(idx_ent), cmp_idx_ent);
+    uint64_t m = 0, sum = 0;
+    for (uint64_t i = 0; i < 2 * n; i++) {
+        if (i && e[i].hi == e[i - 1].hi && e[i].lo == e[i - 1].lo) continue;   /* dereplicatePartition (:4147-4180) */
+        out_hi[m] = e[i].hi; out_lo[m] = e[i].lo; m++;
+        sum += e[i].lo;                                                        /* u64 += u128 keeps the low word */
+    }
+    *checksum = sum;
+    free(e); free(tmp);
+    return m;
+}

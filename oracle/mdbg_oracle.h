@@ -161,6 +161,12 @@ void orc_kminmer_count_refined(const uint32_t *minimizers, const uint64_t *offse
 void orc_kminmer_index(const uint32_t *minimizers, const uint64_t *offsets, uint64_t n_seqs,
                        unsigned k, const orc_abundance_map *prev, orc_kminmer_table *out);
 
+/* EdgeIndexer (graph/CreateMdbg.hpp:4010-4230): the distinct identities of the normalised
+ * (k-1)-prefix and (k-1)-suffix of every k-min-mer vector (the content of edges.bin, sorted by (hi,lo));
+ * *checksum = sum of the identities truncated to u64, as indexEdges logs it (graph/CreateMdbg.cpp:1184).
+ * out_hi / out_lo must hold 2 n entries; returns the number of distinct edges. */
+uint64_t orc_edge_index(const uint32_t *vecs, uint64_t n, unsigned k, uint64_t *out_hi, uint64_t *out_lo, uint64_t *checksum);
+
 #ifdef __cplusplus
 }
 #endif

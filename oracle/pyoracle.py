@@ -203,6 +203,19 @@ def kminmer_index(mins, offsets, k: int, prev: PrevAbundance) -> dict:
     return _table_to_numpy(t)
 
 
+def edge_index(vecs) -> tuple[np.ndarray, np.ndarray, int]:
+    """(hi, lo, checksum) of the distinct prefix/suffix identities of k-min-mer vectors (EdgeIndexer)."""
+    v = np.ascontiguousarray(vecs, dtype=np.uint32)
+    n, k = v.shape
+    hi = np.zeros(2 * n, np.uint64); lo = np.zeros(2 * n, np.uint64)
+    ck = C.c_uint64()
+    f = lib().orc_edge_index
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    m = f(v.ctypes.data, n, k, hi.ctypes.data, lo.ctypes.data, C.byref(ck))
+    return hi[:m].copy(), lo[:m].copy(), ck.value
+
+
 def table_abundance_records(t: dict) -> np.ndarray:
     """20-byte records (lo, hi, abundance) of an oracle table, as a structured array."""
     from metamdbg_amd.formats import ABUNDANCE_DTYPE

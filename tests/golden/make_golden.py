@@ -61,8 +61,29 @@ def sha256(path: str) -> str:
     return h.hexdigest()
 
 
+def log_known_answers(tmp: str) -> dict:
+    """Numbers the reference logs while running `graph` (metaMDBG.log next to tmp/): the EdgeIndexer's edge count and
+    checksum (graph/CreateMdbg.cpp:1184) and the abundance checksum sum(abundance * hash) (:3321, :3397)."""
+    import re
+    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+    out = {}
+    m = re.search(r"Dereplicating edges.*?\n\s*Done: (\d+) (\d+) ", log, flags=re.S)
+    if m:
+        out["n_edges"], out["edge_checksum"] = int(m.group(1)), int(m.group(2))
+    m = re.search(r"Checksum kminmer abundance: (\d+)", log)
+    if m:
+        out["abundance_checksum"] = int(m.group(1))
+    for key, pat in (("n_solid", r"Nb solid kminmers: (\d+)"), ("n_rescued", r"Nb rescued kminmers: (\d+)")):
+        m = re.search(pat, log)
+        if m:
+            out[key] = int(m.group(1))
+    return out
+
+
 def store_outputs(tmp: str, dst: str, k: int, manifest: dict) -> None:
     os.makedirs(dst, exist_ok=True)
+    if os.path.exists(os.path.join(tmp, "kminmerData_abundance.txt")):
+        manifest = dict(manifest, reference_log=log_known_answers(tmp))
     for name in ("read_data_init.txt", "read_stats.txt", "repetitiveMinimizers.bin", "parameters.gz"):
         shutil.copy(os.path.join(tmp, name), os.path.join(dst, name))
     p = os.path.join(tmp, "read_data_corrected.txt")

@@ -383,3 +383,21 @@ def test_ont_like_reads_vs_oracle(ctx, orc):
     exp = b"".join(orc.read_selection(asc[r].tobytes(), q[r].tobytes(), K=15, density=0.005, hpc=False, repetitive=rep)["record"]
                    for r in range(spec.n_reads))
     assert formats.build_read_data_init(h) == exp
+
+
+@pytest.mark.parametrize("name", ["hifi_200", "ont_100"])
+def test_edge_index_vs_reference_log(ctx, orc, name):
+    """EdgeIndexer on the device against the edge count and checksum the reference logs, and
+    against the oracle's edge set."""
+    m = H.load_manifest(name)
+    raw = H.golden_bytes(name, "read_data_corrected.txt")
+    mins, offs = formats.parse_minimizer_reads(raw)
+    table = ctx.kminmer_count_first(ctx.minimizers_from_host(mins, offs), m["k"], m["min_abundance"])
+    edges, ck = ctx.edge_index(table)
+    log = m["reference_log"]
+    assert edges.info()["n_records"] == log["n_edges"] and ck == log["edge_checksum"]
+    rec, vec = table.to_host()
+    ohi, olo, ock = orc.edge_index(vec)
+    keys = edges.keys_to_host()
+    order = np.lexsort((keys[:, 0], keys[:, 1]))
+    assert np.array_equal(keys[order, 0], olo) and np.array_equal(keys[order, 1], ohi) and ock == ck

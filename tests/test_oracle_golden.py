@@ -157,3 +157,19 @@ def test_ont_100_end_to_end():
     assert len(rep) == n_keep
     top = sorted(counts.values(), reverse=True)[n_keep - 1]
     assert all(counts[int(r)] >= top for r in rep)
+
+
+@pytest.mark.parametrize("name", ["hifi_200", "ont_100"])
+def test_reference_log_known_answers(name):
+    """Numbers the reference itself logs for the fixture runs: solid / rescued counts, the abundance checksum
+    sum(abundance * hash) (graph/CreateMdbg.cpp:3321) and the EdgeIndexer's edge count + checksum (:1184)."""
+    m = H.load_manifest(name)
+    log = m["reference_log"]
+    ab = np.fromfile(os.path.join(H.GOLDEN, name, "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert int((ab["abundance"] > 1).sum()) == log["n_solid"] and int((ab["abundance"] == 1).sum()) == log["n_rescued"]
+    with np.errstate(over="ignore"):
+        ck = int((ab["lo"] * ab["abundance"].astype(np.uint64)).sum(dtype=np.uint64))
+    assert ck == log["abundance_checksum"]
+    vecs = np.fromfile(os.path.join(H.GOLDEN, name, "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    hi, lo, eck = orc.edge_index(vecs)
+    assert len(hi) == log["n_edges"] and eck == log["edge_checksum"]
