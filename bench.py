@@ -116,9 +116,11 @@ def main() -> None:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_exchange = os.environ.get("MDBG_BENCH_FORCE_EXCHANGE") == "1"    # exercise the sharded path on one GPU
+    if world > 1 or force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ctx = capi.Context(local_rank)
@@ -135,23 +137,40 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("MDBG_BENCH_TRACE") == "1"
+    phases: dict = {}
+
     def step():
         mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
         corr = ctx.purge_palindromes(mins, 4, 100)
-        if world == 1:
+        if world == 1 and not force_exchange:
             table = ctx.kminmer_count_first(corr, KMINMER, 0)
         else:
             from metamdbg_amd import distributed as D
-            d_rows, counts = ctx.partial_counts(corr, KMINMER, world)
-            n_local = int(counts.sum())
-            send = torch.empty((n_local, rw), dtype=torch.int64, device="cuda")
-            ctx.memcpy_device(send.data_ptr(), d_rows, n_local * rw * 8)
-            mine = D.exchange_by_owner(send, [int(c) for c in counts])
+            tr = [time.perf_counter()] if trace else None
+            def mark(name):
+                if tr is not None:
+                    torch.cuda.synchronize()
+                    tr.append(time.perf_counter())
+                    phases[name] = phases.get(name, 0.0) + (tr[-1] - tr[-2]) * 1e3
+            sh = ctx.shard_begin(corr, KMINMER, world)
+            mark("begin")
+            sent = [int(c) for c in sh.counts]
+            send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
+                torch.empty((0, rw), dtype=torch.int64, device="cuda")
+            mine, got = D.exchange_by_owner(send, sent)
             torch.cuda.synchronize()
-            n_owned = ctx.reduce_rows(mine.data_ptr(), mine.shape[0], KMINMER)
-            glob = D.all_gather_rows(mine[:n_owned].contiguous())
+            mark("all_to_all_rows")
+            d_reply = sh.reduce(mine.data_ptr(), mine.shape[0])
+            reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
+                torch.empty((0,), dtype=torch.int64, device="cuda")
+            mark("reduce")
+            glob = D.reply_to_senders(reply, got, sent)
             torch.cuda.synchronize()
-            table = ctx.count_first_merged(corr, KMINMER, 0, glob.data_ptr(), glob.shape[0], rank, world)
+            mark("all_to_all_reply")
+            table = sh.finish(glob.data_ptr(), 0, rank)
+            sh.free()
+            mark("finish")
         n_min = mins.info()["n_minimizers"]
         ti = table.info()
         for o in (table, corr, mins):
@@ -175,6 +194,8 @@ def main() -> None:
     dt = float(tmax.item())
 
     names = ["scan", "scan_compact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit"]
+    if world > 1 or force_exchange:
+        names += ["shard_rows", "shard_reduce"]
     ktimes = {k: ctx.timing_get(k) for k in names}
     scan_ms, scan_n = ktimes["scan"]
     scan_avg_s = scan_ms / 1e3 / max(scan_n, 1)
@@ -206,6 +227,8 @@ def main() -> None:
         }
         if base and base.get("value"):
             out["speedup_vs_cpu_reference"] = out["value"] / base["value"]
+        if trace and phases:
+            out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + args.warmup) for k, v in phases.items()}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -175,26 +175,29 @@ void mdbg_host_free(mdbg_ctx *ctx, void *p);
  * harness move library-owned rows into buffers it owns (e.g. torch tensors for RCCL). */
 int  mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 
-/* ---- multi-GPU merge (one process per GPU; the caller moves the bytes, e.g. RCCL all-to-all) ---- */
-/* Rows are mdbg_row_words(k) u64 words each: [hash_lo, hash_hi, count, vec01, vec23, ...] -- the
- * canonical vector travels with the key because the owner of a key may hold no read containing it. */
+/* ---- sharded first pass (one process per GPU; the caller moves the bytes, e.g. RCCL all-to-all over xGMI) ----
+ * Reads shard across ranks; only the counts are global.  Keys are partitioned by owner rank (top bits of hash_hi
+ * scaled to [0, n_ranks), n_ranks <= 64).  Per rank and step:
+ *     mdbg_shard_begin   local counts -> rows [lo, hi, count, vector...] grouped by owner        (send: all-to-all)
+ *     mdbg_shard_reduce  owner sums the rows it received; reply[i] = GLOBAL count of received row i (send back:
+ *                        all-to-all with the transposed split sizes; replies arrive in the order the rows were sent)
+ *     mdbg_shard_finish  global counts -> solid rows of the keys this rank owns + rescue of its own reads
+ * The union over ranks of the finished tables equals mdbg_kminmer_count_first on the union of the reads.
+ * Nearest reference analogue: KminmerCounter's on-disk partitioning `vecHash % _nbPartitions`
+ * (graph/CreateMdbg.hpp:3714-3724).  Rows are mdbg_row_words(k) u64 words each. */
+typedef struct mdbg_shard mdbg_shard;
 uint32_t mdbg_row_words(uint32_t k);
-/* Partial counts of the local reads, grouped by owner rank (owner = top bits of hash_hi scaled to
- * [0, n_ranks), n_ranks <= 64): *d_rows points at device memory holding one row per distinct local
- * key, rows of owner 0 first, then owner 1, ...; counts[r] = rows destined to rank r.  The buffer is
- * owned by ctx and valid until the next call of this function or mdbg_destroy. */
-int  mdbg_kminmer_partial_counts(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
-                                 const uint64_t **d_rows, uint64_t *counts);
-/* Sum the counts of rows with equal keys, in place on the device (what the owner does with the rows
- * it received); *n_out = number of distinct keys, stored in the first *n_out rows. */
-int  mdbg_reduce_rows(mdbg_ctx *ctx, uint64_t *d_rows, uint64_t n_rows, uint32_t k, uint64_t *n_out);
-/* Finish the first pass from the globally reduced rows of ALL ranks (after an all-gather of the owners'
- * reduced rows; each key appears once): emits the solid records of the keys this rank owns followed by
- * the rescued records of the local reads, judged against the global abundances.  The union over ranks
- * equals the single-GPU table of mdbg_kminmer_count_first on the union of the reads. */
-int  mdbg_kminmer_count_first_merged(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance,
-                                     const uint64_t *d_global_rows, uint64_t n_global_rows,
-                                     uint32_t rank, uint32_t n_ranks, mdbg_table **out);
+/* *d_rows: device rows of every distinct local key, owner 0 first; counts[r] = rows for rank r.  `reads` must stay
+ * alive until mdbg_shard_free. */
+int  mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
+                      mdbg_shard **shard, const uint64_t **d_rows, uint64_t *counts);
+/* d_recv: device rows received from all ranks (any order); it must stay alive until mdbg_shard_finish (the vectors
+ * of the solid rows are read from it).  *d_reply: n_recv u64 global counts, aligned with d_recv. */
+int  mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply);
+/* d_global_counts: n_sent u64, the replies for the rows of mdbg_shard_begin in the order they were sent. */
+int  mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_global_counts, uint32_t min_abundance,
+                       uint32_t rank, mdbg_table **out);
+void mdbg_shard_free(mdbg_shard *shard);
 
 #ifdef __cplusplus
 }

@@ -74,10 +74,10 @@ SIGNATURES = {
     "mdbg_table_keys_to_host": (C.c_int, [_P, _P, _P]),
     "mdbg_table_free": (None, [_P]),
     "mdbg_row_words": (C.c_uint32, [C.c_uint32]),
-    "mdbg_kminmer_partial_counts": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), _u64p]),
-    "mdbg_reduce_rows": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _u64p]),
-    "mdbg_kminmer_count_first_merged": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_uint32,
-                                                  C.c_uint32, C.POINTER(_P)]),
+    "mdbg_shard_begin": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(_P), _u64p]),
+    "mdbg_shard_reduce": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(_P)]),
+    "mdbg_shard_finish": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_shard_free": (None, [_P]),
 }
 
 _lib = None
@@ -239,25 +239,48 @@ class Context:
         self.check(lib().mdbg_edge_index(self.h, nodes.h, C.byref(h), C.byref(ck)))
         return Table(self, h), ck.value
 
-    # -- multi-GPU pieces --------------------------------------------------------------------------
-    def partial_counts(self, m: "Minimizers", k: int, n_ranks: int) -> tuple[int, np.ndarray]:
-        """(device pointer of the owner-grouped rows, rows per owner)."""
-        d_rows = C.c_void_p()
+    # -- sharded first pass (one process per GPU) ---------------------------------------------------
+    def shard_begin(self, m: "Minimizers", k: int, n_ranks: int) -> "Shard":
+        h, d_rows = C.c_void_p(), C.c_void_p()
         counts = np.zeros(n_ranks, dtype=np.uint64)
-        self.check(lib().mdbg_kminmer_partial_counts(self.h, m.h, k, n_ranks, C.byref(d_rows), counts.ctypes.data_as(_u64p)))
-        return d_rows.value or 0, counts
+        self.check(lib().mdbg_shard_begin(self.h, m.h, k, n_ranks, C.byref(h), C.byref(d_rows), counts.ctypes.data_as(_u64p)))
+        return Shard(self, h, k, d_rows.value or 0, counts)
 
-    def reduce_rows(self, d_rows: int, n_rows: int, k: int) -> int:
-        n = C.c_uint64()
-        self.check(lib().mdbg_reduce_rows(self.h, C.c_void_p(d_rows), n_rows, k, C.byref(n)))
-        return n.value
 
-    def count_first_merged(self, m: "Minimizers", k: int, min_abundance: int, d_global_rows: int, n_global_rows: int,
-                           rank: int, n_ranks: int) -> "Table":
+class DeviceView:
+    """Zero-copy window on library-owned device memory for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, shape: tuple, typestr: str = "<i8"):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class Shard:
+    """State of one rank's sharded first pass: begin (rows to send) -> reduce (reply) -> finish (table)."""
+
+    def __init__(self, ctx: Context, h, k: int, d_rows: int, counts: np.ndarray):
+        self.ctx, self.h, self.k = ctx, h, k
+        self.d_rows, self.counts = d_rows, counts
+        self.row_words = lib().mdbg_row_words(k)
+
+    @property
+    def n_rows(self) -> int:
+        return int(self.counts.sum())
+
+    def reduce(self, d_recv: int, n_recv: int) -> int:
+        """Device pointer of n_recv u64 global counts aligned with the received rows."""
+        d_reply = C.c_void_p()
+        self.ctx.check(lib().mdbg_shard_reduce(self.ctx.h, self.h, C.c_void_p(d_recv), n_recv, C.byref(d_reply)))
+        return d_reply.value or 0
+
+    def finish(self, d_global_counts: int, min_abundance: int, rank: int) -> "Table":
         h = C.c_void_p()
-        self.check(lib().mdbg_kminmer_count_first_merged(self.h, m.h, k, min_abundance, C.c_void_p(d_global_rows),
-                                                         n_global_rows, rank, n_ranks, C.byref(h)))
-        return Table(self, h)
+        self.ctx.check(lib().mdbg_shard_finish(self.ctx.h, self.h, C.c_void_p(d_global_counts), min_abundance, rank, C.byref(h)))
+        return Table(self.ctx, h)
+
+    def free(self):
+        if self.h:
+            lib().mdbg_shard_free(self.h)
+            self.h = None
 
 
 class Reads:

@@ -425,35 +425,6 @@ static int alloc_rows(mdbg_ctx *ctx, mdbg_table *t, uint64_t n, bool vec) {
     return MDBG_OK;
 }
 
-// used by multigpu.hip: size `t` for n_solid + rescued rows and emit the rescued block
-int mg_rescue_rows(mdbg_ctx *ctx, const mdbg_minimizers *reads, const uint64_t *inst_off, uint64_t n_inst, uint32_t k,
-                   const uint32_t *ab, mdbg_table *t, uint64_t n_solid) {
-    uint64_t n_resc = 0;
-    DevBuf<uint32_t> rflag;
-    DevBuf<uint64_t> rpos;
-    if (n_inst) {
-        MDBG_TRY(rflag.alloc(ctx, n_inst));
-        MDBG_TRY(rpos.alloc(ctx, n_inst + 1));
-        unsigned blocks = grid_for((uint64_t)reads->n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
-        {
-            LaunchTimer timer(ctx, "kminmer_rescue");
-            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, inst_off, reads->n_reads, ab, rescue_m_star(), rflag.p);
-        }
-        MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, n_inst));
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + n_inst, 8, hipMemcpyDeviceToHost));
-    }
-    MDBG_TRY(alloc_rows(ctx, t, n_solid + n_resc, true));
-    if (n_resc) {
-        SeqView sv;
-        sv.mins = reads->d_min.p; sv.off = reads->d_off.p; sv.inst_off = inst_off; sv.n_reads = reads->n_reads; sv.n_inst = n_inst;
-        RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
-        LaunchTimer timer(ctx, "kminmer_emit");
-        hipLaunchKernelGGL(emit_rescued_kernel, dim3(grid_for(n_inst, 256)), dim3(256), 0, ctx->stream, sv, k, rflag.p, rpos.p, ro, n_solid);
-    }
-    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return MDBG_OK;
-}
-
 }  // namespace mdbg
 
 using namespace mdbg;
@@ -821,3 +792,268 @@ extern "C" int mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint6
 }
 
 extern "C" void mdbg_table_free(mdbg_table *t) { delete t; }
+
+
+// =====================================================================================================
+// Sharded first pass (reads split over several GPUs, one process each).  See include/mdbg_hip.h.
+// =====================================================================================================
+namespace mdbg {
+
+__host__ __device__ __forceinline__ uint32_t row_words_for(uint32_t k) { return 3u + (k + 1u) / 2u; }
+
+__device__ __forceinline__ uint32_t owner_of(uint64_t hi, uint32_t n_ranks) {
+    return (uint32_t)(((hi >> 32) * (uint64_t)n_ranks) >> 32);
+}
+
+__device__ __forceinline__ bool slot_read(const TableView &t, uint64_t cap, uint64_t s, uint64_t &lo, uint64_t &hi, uint32_t &v, uint32_t &rep) {
+    if (s < cap) {
+        const TableSlot &sl = t.slots[s];
+        lo = sl.lo;
+        if (lo == 0ull) return false;
+        hi = sl.hi; v = sl.val; rep = sl.rep;
+        return true;
+    }
+    uint32_t i = (uint32_t)(s - cap);
+    if (i >= *t.exc_n) return false;
+    lo = t.exc_lo[i]; hi = t.exc_hi[i]; v = t.exc_val[i]; rep = t.exc_rep[i];
+    return true;
+}
+
+// Rows are grouped by owner without a single global atomic (same-address device-scope atomics cost
+// ~0.2 us each on this part, serialised): pass 1 writes one LDS histogram per block of SHARD_SPB slots
+// to block_hist[owner][block]; an exclusive scan over that owner-major array gives every (owner, block)
+// its first row; pass 2 hands out the places inside the block's range through LDS.
+constexpr uint32_t SHARD_SPB = 2048;   // slots per block
+
+__global__ __launch_bounds__(256) void owner_hist_kernel(TableView t, uint64_t cap, uint32_t n_ranks, uint32_t *block_hist) {
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t s0 = (uint64_t)blockIdx.x * SHARD_SPB;
+    for (uint32_t j = threadIdx.x; j < SHARD_SPB; j += 256) {
+        uint64_t lo, hi; uint32_t v, rep;
+        if (s0 + j < cap + TABLE_EXC_CAP && slot_read(t, cap, s0 + j, lo, hi, v, rep)) atomicAdd(&h[owner_of(hi, n_ranks)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_ranks) block_hist[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// write every occupied slot as a row [lo, hi, count, vector] into its owner's range and remember its slot
+__global__ __launch_bounds__(256) void owner_scatter_kernel(TableView t, uint64_t cap, uint32_t n_ranks, const uint64_t *block_base,
+                                                            SeqView sv, uint32_t k, uint64_t *rows, uint32_t *row_slot) {
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t s0 = (uint64_t)blockIdx.x * SHARD_SPB;
+    const uint32_t rw = row_words_for(k);
+    for (uint32_t j = threadIdx.x; j < SHARD_SPB; j += 256) {
+        const uint64_t s = s0 + j;
+        uint64_t lo, hi; uint32_t v, rep;
+        if (!(s < cap + TABLE_EXC_CAP && slot_read(t, cap, s, lo, hi, v, rep))) continue;
+        const uint32_t own = owner_of(hi, n_ranks);
+        const uint64_t row = block_base[(uint64_t)own * gridDim.x + blockIdx.x] + atomicAdd(&h[own], 1u);
+        uint64_t *o = rows + row * rw;
+        o[0] = lo; o[1] = hi; o[2] = v;
+        row_slot[row] = s < cap ? (uint32_t)s : (0x80000000u | (uint32_t)(s - cap));
+        uint32_t r = find_read(sv.inst_off, sv.n_reads, rep);
+        const uint32_t *m = sv.mins + sv.off[r] + (rep - sv.inst_off[r]);
+        bool reversed = true;
+        for (uint32_t i = 0; i < k; i++) {
+            uint32_t a = m[i], b = m[k - 1 - i];
+            if (a == b) continue;
+            reversed = !(a < b);
+            break;
+        }
+        for (uint32_t w = 0; w < (k + 1) / 2; w++) {
+            uint32_t i0 = 2 * w, i1 = 2 * w + 1;
+            uint64_t a = reversed ? m[k - 1 - i0] : m[i0];
+            uint64_t b2 = i1 < k ? (reversed ? m[k - 1 - i1] : m[i1]) : 0u;
+            o[3 + w] = a | (b2 << 32);
+        }
+    }
+}
+
+// owner: sum the received rows by key; rep = index of one received row of the key (its vector)
+__global__ __launch_bounds__(256) void rows_add_kernel(const uint64_t *rows, uint64_t n, uint32_t rw, TableView t) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *r = rows + i * rw;
+    table_upsert_count(t, r[0], r[1], (uint32_t)r[2], (uint32_t)i);
+}
+
+__global__ __launch_bounds__(256) void rows_reply_kernel(const uint64_t *rows, uint64_t n, uint32_t rw, TableView t, uint64_t *reply) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *r = rows + i * rw;
+    uint32_t v = 0;
+    table_lookup(t, r[0], r[1], v);
+    reply[i] = v;
+}
+
+// global counts back into the local table (the slot of every sent row was remembered)
+__global__ __launch_bounds__(256) void apply_global_counts_kernel(const uint64_t *counts, const uint32_t *row_slot, uint64_t n, TableView t) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = row_slot[i], v = (uint32_t)counts[i];
+    if (s & 0x80000000u) t.exc_val[s & 0x7FFFFFFFu] = v; else t.slots[s].val = v;
+}
+
+__global__ __launch_bounds__(256) void emit_owner_solid_kernel(TableView t, uint64_t cap, const uint32_t *flag, const uint64_t *pos,
+                                                               const uint64_t *src_rows, uint32_t rw, RowOut o) {
+    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap + TABLE_EXC_CAP || !flag[s]) return;
+    uint64_t lo, hi; uint32_t v, rep;
+    slot_read(t, cap, s, lo, hi, v, rep);
+    const uint64_t row = pos[s];
+    o.lo[row] = lo; o.hi[row] = hi; o.ab[row] = v;
+    const uint64_t *src = src_rows + (uint64_t)rep * rw + 3;
+    for (uint32_t i = 0; i < o.k; i++) o.vec[row * o.k + i] = (uint32_t)(src[i / 2] >> (32 * (i & 1)));
+}
+
+}  // namespace mdbg
+
+struct mdbg_shard {
+    uint32_t k = 0, n_ranks = 1;
+    const mdbg_minimizers *reads = nullptr;
+    mdbg::InstIndex ix;
+    mdbg::DeviceTable local, owner;
+    mdbg::DevBuf<uint32_t> inst_slot, row_slot;
+    mdbg::DevBuf<uint64_t> rows, reply;
+    uint64_t n_rows = 0;
+    const uint64_t *d_recv = nullptr;
+    uint64_t n_recv = 0;
+};
+
+extern "C" uint32_t mdbg_row_words(uint32_t k) { return mdbg::row_words_for(k); }
+
+extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
+                                mdbg_shard **out, const uint64_t **d_rows, uint64_t *counts) {
+    if (!ctx || !reads || !out || !d_rows || !counts || k < 2 || n_ranks < 1 || n_ranks > 64)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_shard_begin: bad argument");
+    MDBG_TRY(check_seq(ctx, reads, "mdbg_shard_begin"));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<mdbg_shard> sh(new mdbg_shard());
+    sh->k = k; sh->n_ranks = n_ranks; sh->reads = reads;
+    MDBG_TRY(build_inst_index(ctx, reads, k, sh->ix));
+    const uint64_t I = sh->ix.total;
+    SeqView sv = make_view(reads, sh->ix);
+    MDBG_TRY(sh->inst_slot.alloc(ctx, I));
+    MDBG_TRY(build_table_adaptive(ctx, sh->local, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
+        if (I) {
+            LaunchTimer timer(ctx, "kminmer_insert");
+            hipLaunchKernelGGL(count_insert_kernel, dim3(instance_grid(ctx, sv.n_reads)), dim3(256), 0, ctx->stream, sv, k, v, sh->inst_slot.p, (uint64_t)0);
+        }
+        return MDBG_OK;
+    }));
+    if (I) ctx->key_ratio_hint = (double)sh->local.cap / 2.0 / (double)I;
+    TableView tv = sh->local.view();
+    const uint64_t nslots = sh->local.cap + TABLE_EXC_CAP;
+    const unsigned nb = grid_for(nslots, SHARD_SPB);
+    const uint64_t nh = (uint64_t)nb * n_ranks;
+    DevBuf<uint32_t> block_hist;
+    DevBuf<uint64_t> block_base;
+    MDBG_TRY(block_hist.alloc(ctx, nh));
+    MDBG_TRY(block_base.alloc(ctx, nh + 1));
+    {
+        LaunchTimer timer(ctx, "shard_rows");
+        hipLaunchKernelGGL(owner_hist_kernel, dim3(nb), dim3(256), 0, ctx->stream, tv, sh->local.cap, n_ranks, block_hist.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, block_hist.p, block_base.p, nh));
+    std::vector<uint64_t> base(nh + 1);
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, base.data(), block_base.p, (nh + 1) * 8, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_ranks; r++) counts[r] = base[(uint64_t)(r + 1) * nb] - base[(uint64_t)r * nb];
+    const uint64_t total = base[nh];
+    if (total >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 distinct local keys");
+    const uint32_t rw = row_words_for(k);
+    MDBG_TRY(sh->rows.alloc(ctx, total * rw));
+    MDBG_TRY(sh->row_slot.alloc(ctx, total));
+    sh->n_rows = total;
+    {
+        LaunchTimer timer(ctx, "shard_rows");
+        hipLaunchKernelGGL(owner_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, tv, sh->local.cap, n_ranks, block_base.p,
+                           sv, k, sh->rows.p, sh->row_slot.p);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *d_rows = sh->rows.p;
+    *out = sh.release();
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) {
+    if (!ctx || !sh || !d_reply || (n_recv && !d_recv)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_reduce: bad argument");
+    if (n_recv >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 received rows");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t rw = row_words_for(sh->k);
+    MDBG_TRY(sh->owner.init(ctx, n_recv * 2 + 1024));
+    TableView tv = sh->owner.view();
+    MDBG_TRY(sh->reply.alloc(ctx, n_recv));
+    if (n_recv) {
+        LaunchTimer timer(ctx, "shard_reduce");
+        hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, rw, tv);
+        hipLaunchKernelGGL(rows_reply_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, rw, tv, sh->reply.p);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MDBG_TRY(sh->owner.check_overflow(ctx));
+    sh->d_recv = d_recv;
+    sh->n_recv = n_recv;
+    *d_reply = sh->reply.p;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_global_counts, uint32_t min_abundance,
+                                 uint32_t rank, mdbg_table **out) {
+    if (!ctx || !sh || !out || rank >= sh->n_ranks || (sh->n_rows && !d_global_counts))
+        return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: bad argument");
+    if (!sh->owner.cap) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: mdbg_shard_reduce has not run");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t k = sh->k, rw = row_words_for(k);
+    const uint64_t I = sh->ix.total;
+    TableView lv = sh->local.view(), ov = sh->owner.view();
+    if (sh->n_rows)
+        hipLaunchKernelGGL(apply_global_counts_kernel, dim3(grid_for(sh->n_rows, 256)), dim3(256), 0, ctx->stream, d_global_counts,
+                           sh->row_slot.p, sh->n_rows, lv);
+    // solid rows: keys this rank owns
+    const uint64_t nslots = sh->owner.cap + TABLE_EXC_CAP;
+    DevBuf<uint32_t> sflag, ab, rflag;
+    DevBuf<uint64_t> spos, rpos;
+    MDBG_TRY(sflag.alloc(ctx, nslots));
+    MDBG_TRY(spos.alloc(ctx, nslots + 1));
+    hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, ov, sh->owner.cap, min_abundance, 0, sflag.p);
+    MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
+    uint64_t n_solid = 0, n_resc = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    // rescue over the local reads against the global counts now sitting in the local table
+    SeqView sv = make_view(sh->reads, sh->ix);
+    if (min_abundance <= 1 && I) {
+        MDBG_TRY(ab.alloc(ctx, I));
+        MDBG_TRY(rflag.alloc(ctx, I));
+        MDBG_TRY(rpos.alloc(ctx, I + 1));
+        {
+            LaunchTimer timer(ctx, "kminmer_rescue");
+            hipLaunchKernelGGL(inst_abundance_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, I, sh->inst_slot.p, lv, min_abundance, ab.p);
+            unsigned blocks = grid_for((uint64_t)sv.n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
+            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sh->ix.off.p, sv.n_reads, ab.p, rescue_m_star(), rflag.p);
+        }
+        MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, I));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
+    }
+    mdbg_table *t = new mdbg_table();
+    t->k = k;
+    t->n_solid = n_solid;
+    int rc = alloc_rows(ctx, t, n_solid + n_resc, true);
+    if (rc) { delete t; return rc; }
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(emit_owner_solid_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, ov, sh->owner.cap, sflag.p, spos.p,
+                           sh->d_recv, rw, ro);
+        if (n_resc)
+            hipLaunchKernelGGL(emit_rescued_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, sv, k, rflag.p, rpos.p, ro, n_solid);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "mdbg_shard_finish failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return MDBG_OK;
+}
+
+extern "C" void mdbg_shard_free(mdbg_shard *shard) { delete shard; }

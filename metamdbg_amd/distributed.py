@@ -1,11 +1,13 @@
-"""Exchange step of the multi-GPU first pass: one process per GPU, torch.distributed for the bytes
+"""Exchange steps of the sharded first pass: one process per GPU, torch.distributed for the bytes
 (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU tensors in the tests).
 
-Rows are int64 tensors of shape (n, row_words): [hash_lo, hash_hi, count, packed vector...]
-(include/mdbg_hip.h).  Keys are partitioned by owner rank, so the merge is a reduce-scatter by
-key (all-to-all + local reduce) followed by an all-gather of the owners' reduced slices -- together
-an all-reduce of the count tables by key.  A dense ncclAllReduce would need the ranks to agree on
-a common key order first and is bound by one xGMI link; the partitioned form keeps all 7 links busy.
+Reads are sharded over the ranks; only the k-min-mer counts are global.  Keys are partitioned by
+owner rank (include/mdbg_hip.h, mdbg_shard_*), so the merge is
+    all-to-all   rows [hash_lo, hash_hi, count, packed vector...] -> owner     (exchange_by_owner)
+    all-to-all   one u64 global count per row back to the sender             (reply_to_senders)
+i.e. a reduce-scatter by key and its transpose.  xGMI is point-to-point, so an all-to-all keeps all
+7 links of every GPU busy; a dense all-reduce would need a common key order first and nothing is
+replicated here: no rank ever holds the global table.
 """
 from __future__ import annotations
 
@@ -13,8 +15,9 @@ import torch
 import torch.distributed as dist
 
 
-def exchange_by_owner(rows: torch.Tensor, counts: list[int], group=None) -> torch.Tensor:
-    """rows: (sum(counts), rw) grouped by destination rank.  Returns the rows this rank owns."""
+def exchange_by_owner(rows: torch.Tensor, counts: list[int], group=None) -> tuple[torch.Tensor, list[int]]:
+    """rows: (sum(counts), rw) grouped by destination rank.  Returns (rows this rank owns, rows received
+    from each rank) -- the second list is the split of the reply."""
     world = dist.get_world_size(group)
     assert len(counts) == world and rows.shape[0] == sum(counts)
     send = torch.tensor(counts, dtype=torch.int64, device=rows.device)
@@ -23,19 +26,12 @@ def exchange_by_owner(rows: torch.Tensor, counts: list[int], group=None) -> torc
     recv_counts = [int(x) for x in recv.tolist()]
     out = torch.empty((sum(recv_counts), rows.shape[1]), dtype=rows.dtype, device=rows.device)
     dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
+    return out, recv_counts
+
+
+def reply_to_senders(reply: torch.Tensor, recv_counts: list[int], sent_counts: list[int], group=None) -> torch.Tensor:
+    """reply: one value per received row (same order).  Returns one value per SENT row, in the order sent."""
+    assert reply.shape[0] == sum(recv_counts)
+    out = torch.empty((sum(sent_counts),) + tuple(reply.shape[1:]), dtype=reply.dtype, device=reply.device)
+    dist.all_to_all_single(out, reply.contiguous(), output_split_sizes=list(sent_counts), input_split_sizes=list(recv_counts), group=group)
     return out
-
-
-def all_gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
-    """Concatenate every rank's (n_r, rw) rows, rank order."""
-    world = dist.get_world_size(group)
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
-    sizes = [torch.empty(1, dtype=torch.int64, device=rows.device) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes) if sizes else 0
-    pad = torch.zeros((mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    pad[: rows.shape[0]] = rows
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)

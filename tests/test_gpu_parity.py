@@ -193,10 +193,11 @@ def test_refined_and_index_vs_oracle(ctx, orc, k):
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
-def test_multi_gpu_pieces_on_one_gpu(ctx, orc, n_ranks):
-    """All kernels of the sharded first pass, with the exchange emulated on one device: shard the reads,
-    partial counts per shard, concatenate the rows per owner (the all-to-all), reduce per owner, gather,
-    finish per (rank, shard); the union of the per-rank tables must equal the single-GPU table."""
+def test_sharded_first_pass_on_one_gpu(ctx, orc, n_ranks):
+    """All kernels of the sharded first pass, with the two all-to-alls emulated on one device: shard the
+    reads, mdbg_shard_begin per shard, concatenate the rows per owner, mdbg_shard_reduce per owner, route the
+    replies back to the senders, mdbg_shard_finish per shard; the union of the per-rank tables must equal the
+    single-GPU table, and every row's global count the count over all reads."""
     import ctypes as C
     k = 4
     rng = np.random.default_rng(11 + n_ranks)
@@ -208,46 +209,57 @@ def test_multi_gpu_pieces_on_one_gpu(ctx, orc, n_ranks):
         so = offs[cuts[r]: cuts[r + 1] + 1] - offs[cuts[r]]
         sm = mins[int(offs[cuts[r]]): int(offs[cuts[r + 1]])]
         shards.append(ctx.minimizers_from_host(sm, so))
-    from metamdbg_amd import capi
-    rw = capi.lib().mdbg_row_words(k)
     hip = C.CDLL("libamdhip64.so.7")   # already loaded by libmdbg_hip.so (same SONAME)
-    # rows destined to each owner, copied to the host (stands in for the all-to-all)
+
+    def to_host(ptr, shape):
+        out = np.zeros(shape, dtype=np.uint64)
+        if out.nbytes:
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def to_device(a):
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), C.c_size_t(max(a.nbytes, 8))) == 0
+        if a.nbytes:
+            assert hip.hipMemcpy(buf, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+        return buf
+
+    # begin: rows destined to each owner (host copies stand in for the all-to-all)
+    sh = [ctx.shard_begin(shards[r], k, n_ranks) for r in range(n_ranks)]
+    rw = sh[0].row_words
+    sent = [to_host(s.d_rows, (s.n_rows, rw)) for s in sh]
     per_owner = [[] for _ in range(n_ranks)]
     for r in range(n_ranks):
-        d_rows, counts = ctx.partial_counts(shards[r], k, n_ranks)
-        total = int(counts.sum())
-        host = np.zeros((total, rw), dtype=np.uint64)
-        if total:
-            assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(d_rows), C.c_size_t(total * rw * 8), 2) == 0
         o = 0
         for dst in range(n_ranks):
-            per_owner[dst].append(host[o: o + int(counts[dst])]); o += int(counts[dst])
-    # each owner reduces what it received; then everyone gathers all reduced rows
-    reduced = []
+            c = int(sh[r].counts[dst])
+            per_owner[dst].append(sent[r][o: o + c]); o += c
+    # reduce on the owners; replies go back split by source rank
+    recv_bufs, replies = [], []
     for dst in range(n_ranks):
         rows = np.ascontiguousarray(np.concatenate(per_owner[dst]))
-        buf = C.c_void_p()
-        assert hip.hipMalloc(C.byref(buf), C.c_size_t(max(rows.nbytes, 8))) == 0
-        if rows.nbytes:
-            assert hip.hipMemcpy(buf, rows.ctypes.data_as(C.c_void_p), C.c_size_t(rows.nbytes), 1) == 0
-        n = ctx.reduce_rows(buf.value, len(rows), k)
-        out = np.zeros((n, rw), dtype=np.uint64)
-        if n:
-            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), buf, C.c_size_t(out.nbytes), 2) == 0
-        hip.hipFree(buf)
-        reduced.append(out)
-    glob = np.ascontiguousarray(np.concatenate(reduced))
-    gbuf = C.c_void_p()
-    assert hip.hipMalloc(C.byref(gbuf), C.c_size_t(max(glob.nbytes, 8))) == 0
-    if glob.nbytes:
-        assert hip.hipMemcpy(gbuf, glob.ctypes.data_as(C.c_void_p), C.c_size_t(glob.nbytes), 1) == 0
+        buf = to_device(rows)
+        recv_bufs.append(buf)
+        replies.append(to_host(sh[dst].reduce(buf.value, len(rows)), (len(rows),)))
+    # exact global counts, from the oracle over all the reads
+    exp = orc.kminmer_count_first(mins, offs, k, 0)
     recs, vecs, n_solid = [], [], 0
     for r in range(n_ranks):
-        t = ctx.count_first_merged(shards[r], k, 0, gbuf.value, len(glob), r, n_ranks)
+        glob = []
+        for dst in range(n_ranks):
+            o = sum(int(sh[src].counts[dst]) for src in range(r))
+            glob.append(replies[dst][o: o + int(sh[r].counts[dst])])
+        glob = np.ascontiguousarray(np.concatenate(glob))
+        assert len(glob) == sh[r].n_rows
+        gbuf = to_device(glob)
+        t = sh[r].finish(gbuf.value, 0, r)
+        hip.hipFree(gbuf)
         rec, vec = t.to_host()
         recs.append(rec); vecs.append(vec); n_solid += t.info()["n_solid"]
-    hip.hipFree(gbuf)
-    exp = orc.kminmer_count_first(mins, offs, k, 0)
+        t.free()
+    for s, buf in zip(sh, recv_bufs):
+        s.free()
+        hip.hipFree(buf)
     assert n_solid == exp["n_solid"]
     _assert_tables_equal(np.concatenate(recs), np.concatenate(vecs), exp, k)
 
