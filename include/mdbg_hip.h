@@ -91,6 +91,11 @@ typedef struct {
     uint32_t n_repetitive;
     int32_t  apply_read_filters;  /* 1: complexity + quality filters of ReadSelectionFunctor (ReadSelection.hpp:890-915);
                                      0: bare MinimizerParser::parse as CountMinimizerFunctor uses it (:599-611) */
+    int32_t  quality_window;      /* per-minimizer minimum quality over the ORIGINAL coordinates
+                                     0: [rle[pos], rle[pos+l])    ReadSelectionFunctor   (ReadSelection.hpp:1135, :1302-1320)
+                                     1: [rle[pos], rle[pos+l-1]]  the correction scan, ReadCorrection::ReadSelectionFunctor
+                                                                  (ReadCorrection.hpp:2340, :2467-2481); used with
+                                                                  density = _minimizerDensity_correction, apply_read_filters = 0 */
 } mdbg_scan_params;
 
 /* Replaces, for a whole batch, EncoderRLE::execute + MinimizerParser::parse + complexity /
@@ -113,6 +118,12 @@ int  mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimizers, const 
 /* Device pointers for zero-copy consumers (torch.from_dlpack-style wrapping in the harness). */
 int  mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers);
 void mdbg_minimizers_free(mdbg_minimizers *m);
+
+/* Replaces Utils::applyDensityThreshold over every read (Commons.hpp:2507-2550; callers ReadCorrection.hpp:6385, :6435,
+ * Commons.hpp:2563 getLowDensityMinimizerRead, :7252-7742 the minimizer-read parsers): keeps the minimizers whose
+ * selection hash is below `density` -- the down-sampling from the correction density to the assembly density.
+ * Positions / directions / qualities / per-read fields follow when `in` carries them. */
+int  mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out);
 
 /* Replaces Commons::purgePalindrome over every read (Commons.hpp:1617-1723, driven by
  * ReadSelection::purgePalindromes, ReadSelection.hpp:1374-1431). */

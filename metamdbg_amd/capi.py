@@ -26,7 +26,7 @@ class MdbgError(RuntimeError):
 class ScanParams(C.Structure):
     _fields_ = [("minimizer_size", C.c_uint32), ("density", C.c_float), ("hpc", C.c_int32),
                 ("min_read_quality", C.c_float), ("repetitive", C.POINTER(C.c_uint32)),
-                ("n_repetitive", C.c_uint32), ("apply_read_filters", C.c_int32)]
+                ("n_repetitive", C.c_uint32), ("apply_read_filters", C.c_int32), ("quality_window", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/mdbg_hip.h declares
@@ -60,6 +60,7 @@ SIGNATURES = {
     "mdbg_minimizers_from_host": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_minimizers_device_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "mdbg_minimizers_free": (None, [_P]),
+    "mdbg_apply_density_threshold": (C.c_int, [_P, _P, C.c_float, C.POINTER(_P)]),
     "mdbg_purge_palindromes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "mdbg_repetitive_minimizers": (C.c_int, [_P, _P, _P, _u32p]),
     "mdbg_kminmer_count_first": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
@@ -184,12 +185,18 @@ class Context:
         return Minimizers(self, h)
 
     def scan(self, reads: "Reads", K: int = 15, density: float = 0.005, hpc: bool = True,
-             min_read_quality: float = 0.0, repetitive=None, apply_read_filters: bool = True) -> "Minimizers":
+             min_read_quality: float = 0.0, repetitive=None, apply_read_filters: bool = True,
+             quality_window: int = 0) -> "Minimizers":
         rep = np.ascontiguousarray(repetitive if repetitive is not None else [], dtype=np.uint32)
         p = ScanParams(K, density, int(hpc), min_read_quality, rep.ctypes.data_as(C.POINTER(C.c_uint32)), len(rep),
-                       int(apply_read_filters))
+                       int(apply_read_filters), int(quality_window))
         h = C.c_void_p()
         self.check(lib().mdbg_scan(self.h, reads.h, C.byref(p), C.byref(h)))
+        return Minimizers(self, h)
+
+    def apply_density_threshold(self, m: "Minimizers", density: float) -> "Minimizers":
+        h = C.c_void_p()
+        self.check(lib().mdbg_apply_density_threshold(self.h, m.h, C.c_float(density), C.byref(h)))
         return Minimizers(self, h)
 
     def purge_palindromes(self, m: "Minimizers", first_k: int, last_k: int) -> "Minimizers":

@@ -235,4 +235,18 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // device-wide exclusive scan (prims.hip): out[i] = sum(in[0..i)), out[n] = total; out has n+1 entries.
 int exclusive_scan_u32(mdbg_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, uint64_t n);
 
+// density (f32) -> integer threshold: hash < T  <=>  (double)hash < (double)density * 2^64, the compare of
+// MinimizerParser (utils/kmer/Kmer.hpp:1421-1430) and Utils::applyDensityThreshold (Commons.hpp:2524-2533; its
+// float product density * 2^64 is exact).  See oracle/mdbg_oracle.c orc_density_threshold.
+inline uint64_t density_threshold(float density) {
+    const double bound = (double)density * 18446744073709551616.0;
+    if (!((double)UINT64_MAX >= bound)) return UINT64_MAX;
+    uint64_t lo = 0, hi = UINT64_MAX;
+    while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if ((double)mid >= bound) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 }  // namespace mdbg

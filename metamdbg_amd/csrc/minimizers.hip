@@ -3,6 +3,7 @@
 // (ReadSelection::determineRepetitiveMinimizers, readSelection/ReadSelection.hpp:497-625).
 #include "common.hpp"
 #include "objects.hpp"
+#include "murmur.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -85,6 +86,27 @@ __global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *src_
 }
 
 // ---- u32 value census (open addressing, value+1 as key so 0 marks empty) ----
+// ---- Utils::applyDensityThreshold (Commons.hpp:2507-2550) ----------------------------------------
+__global__ __launch_bounds__(256) void density_flag_kernel(const uint32_t *mins, uint64_t n, uint64_t threshold, uint32_t *flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = kmer_hash32(mins[i]) < threshold ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void density_offsets_kernel(const uint64_t *off, uint32_t n_reads, const uint64_t *pos, uint64_t *new_off) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_reads) new_off[r] = pos[off[r]];
+}
+
+__global__ __launch_bounds__(256) void density_compact_kernel(uint64_t n, const uint32_t *flag, const uint64_t *pos, const uint32_t *mins,
+                                                              const uint32_t *mpos, const uint8_t *dir, const uint8_t *qual,
+                                                              uint32_t *omin, uint32_t *opos, uint8_t *odir, uint8_t *oqual) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint64_t d = pos[i];
+    omin[d] = mins[i];
+    if (mpos) { opos[d] = mpos[i]; odir[d] = dir[i]; oqual[d] = qual[i]; }
+}
+
 __global__ __launch_bounds__(256) void census_insert_kernel(const uint32_t *vals, uint64_t n, unsigned long long *keys,
                                                             uint32_t *counts, uint64_t mask) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,6 +196,55 @@ extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint6
 }
 
 extern "C" void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
+
+extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out) {
+    if (!ctx || !in || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: null argument");
+    if (!(density > 0.0f)) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: density must be > 0");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = in->n_reads;
+    const uint64_t total = in->n_min;
+    std::unique_ptr<mdbg_minimizers> m(new mdbg_minimizers());
+    m->n_reads = n;
+    m->from_scan = in->from_scan;
+    m->h_mean_quality = in->h_mean_quality;
+    DevBuf<uint32_t> flag;
+    DevBuf<uint64_t> pos;
+    MDBG_TRY(flag.alloc(ctx, total));
+    MDBG_TRY(pos.alloc(ctx, total + 1));
+    MDBG_TRY(m->d_off.alloc(ctx, (size_t)n + 1));
+    if (total) {
+        LaunchTimer timer(ctx, "density_threshold");
+        hipLaunchKernelGGL(density_flag_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, in->d_min.p, total,
+                           density_threshold(density), flag.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, total));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &m->n_min, pos.p + total, 8, hipMemcpyDeviceToHost));
+    MDBG_TRY(m->d_min.alloc(ctx, m->n_min));
+    const bool side = in->from_scan && in->d_pos.p;
+    if (side) {
+        MDBG_TRY(m->d_pos.alloc(ctx, m->n_min));
+        MDBG_TRY(m->d_dir.alloc(ctx, m->n_min));
+        MDBG_TRY(m->d_mqual.alloc(ctx, m->n_min));
+    }
+    if (in->d_len.p) {
+        MDBG_TRY(m->d_len.alloc(ctx, n));
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_len.p, in->d_len.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (in->d_flags.p) {
+        MDBG_TRY(m->d_flags.alloc(ctx, n));
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_flags.p, in->d_flags.p, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    {
+        LaunchTimer timer(ctx, "density_threshold");
+        hipLaunchKernelGGL(density_offsets_kernel, dim3(grid_for((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, in->d_off.p, n, pos.p, m->d_off.p);
+        if (total)
+            hipLaunchKernelGGL(density_compact_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, total, flag.p, pos.p, in->d_min.p,
+                               side ? in->d_pos.p : nullptr, in->d_dir.p, in->d_mqual.p, m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = m.release();
+    return MDBG_OK;
+}
 
 extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t first_k, uint32_t last_k,
                                       mdbg_minimizers **out) {

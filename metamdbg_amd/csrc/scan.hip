@@ -50,6 +50,7 @@ struct ScanArgs {
     uint32_t n_reads;
     uint32_t K;
     uint64_t threshold;           // hash < threshold  <=>  (double)hash < density * 2^64
+    uint32_t q_last;              // 1: quality span ends ON the last base of the l-mer (correction scan), 0: at the next run
     const uint32_t *rep;          // sorted repetitive minimizers
     uint32_t n_rep;
     int apply_filters;
@@ -396,8 +397,8 @@ struct KmerTrip {
                         a.out_pos[cap0 + idx] = p;
                         a.out_dir[cap0 + idx] = (uint8_t)dir[u];
                         if (HAS_QUAL) {
-                            uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates
-                            if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K, cb, tile_base); }
+                            uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates, or [.., rle[pos + K - 1]]
+                            if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K - a.q_last, cb, tile_base) + a.q_last; }
                             else { os = p; oe = p + K; }
                             if (a.inline_minq) {
                                 const uint8_t *qq = a.qual + a.qual_off[r];
@@ -727,18 +728,6 @@ __global__ void apply_low_quality_kernel(const uint8_t *low, uint32_t n_reads, u
 
 using namespace mdbg;
 
-// host double threshold -> integer threshold (see oracle/mdbg_oracle.c orc_density_threshold)
-static uint64_t density_threshold(float density) {
-    const double bound = (double)density * 18446744073709551616.0;
-    if (!((double)UINT64_MAX >= bound)) return UINT64_MAX;
-    uint64_t lo = 0, hi = UINT64_MAX;
-    while (lo < hi) {
-        uint64_t mid = lo + (hi - lo) / 2;
-        if ((double)mid >= bound) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-
 // ReadSelection.hpp:870-879: float meanReadError = errorSum / n; meanReadQuality = -10.0f * log10(meanReadError).
 // Evaluated at run time (volatile) so that n == 0 yields the same NaN bits (0xFFC00000 on x86-64)
 // the reference writes into read_data_init.txt.
@@ -781,6 +770,7 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
 
 extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan_params *p, mdbg_minimizers **out) {
     if (!ctx || !reads || !p || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_scan: null argument");
+    if (p->quality_window != 0 && p->quality_window != 1) return set_error(ctx, MDBG_EINVAL, "mdbg_scan: quality_window must be 0 or 1");
     if (p->minimizer_size < 2 || p->minimizer_size > 16)
         return set_error(ctx, MDBG_EINVAL, "mdbg_scan: minimizer_size %u outside [2,16]", p->minimizer_size);
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -871,6 +861,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     a.qual_off = has_q ? reads->d_qual_off.p : nullptr;
     a.K = p->minimizer_size;
     a.threshold = density_threshold(p->density);
+    a.q_last = p->quality_window == 1 ? 1u : 0u;
     a.rep = d_rep.p; a.n_rep = p->n_repetitive;
     a.apply_filters = p->apply_read_filters;
     a.subset = nullptr;

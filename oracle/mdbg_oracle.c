@@ -293,6 +293,55 @@ void orc_read_selection(const char *seq, const char *qual, size_t len,
     free(rle_pos);
 }
 
+void orc_correction_scan(const char *seq, const char *qual, size_t len,
+                         const orc_scan_params *p, orc_read_record *rec)
+{
+    /* readSelection/ReadCorrection.hpp:2318-2372 */
+    char *rle = (char *)malloc(len + 2);
+    uint64_t *rle_pos = (uint64_t *)malloc((len + 2) * sizeof(uint64_t));
+    size_t hl = orc_hpc_encode(seq, len, p->hpc, rle, rle_pos);
+    size_t cap = hl ? hl : 1;
+    rec->minimizers = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    rec->pos = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    rec->dir = (uint8_t *)malloc(cap);
+    rec->qual = (uint8_t *)malloc(cap);
+    size_t n = orc_minimizer_parse(rle, hl, p->K, p->density, p->repetitive, p->n_rep,
+                                   rec->minimizers, rec->pos, rec->dir);
+    rec->hpc_length = (uint32_t)hl;
+    rec->read_length = (uint32_t)len;
+    rec->mean_quality = 0.0f;                                        /* :2370 */
+    rec->low_complexity = 0;
+    rec->low_quality = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!qual) { rec->qual[i] = 1; continue; }                   /* :2328-2332 */
+        uint64_t s = rle_pos[rec->pos[i]], e = rle_pos[rec->pos[i] + p->K - 1];   /* :2340 */
+        uint8_t mq = 255;
+        for (uint64_t j = s; j <= e; j++) {                          /* :2472, inclusive */
+            uint8_t q = (uint8_t)qual[j];
+            q = (uint8_t)(q - 33);
+            if (q < mq) mq = q;
+        }
+        rec->qual[i] = mq;
+    }
+    rec->n = (uint32_t)n;
+    free(rle);
+    free(rle_pos);
+}
+
+size_t orc_apply_density_threshold(const uint32_t *minimizers, size_t n, float density, uint8_t *keep)
+{
+    /* Commons.hpp:2524-2533: double bound = density(f32) * (u64)-1 -- a float product, exact (power of two);
+     * the key hashed is the stored minimizer widened to u64 */
+    uint64_t max_hash = (uint64_t)-1;
+    double bound = density * max_hash;
+    size_t kept = 0;
+    for (size_t i = 0; i < n; i++) {
+        keep[i] = (double)orc_kmer_hash((uint64_t)minimizers[i]) < bound;
+        kept += keep[i];
+    }
+    return kept;
+}
+
 void orc_read_record_free(orc_read_record *rec)
 {
     free(rec->minimizers); free(rec->pos); free(rec->dir); free(rec->qual);

@@ -95,6 +95,16 @@ void orc_read_selection(const char *seq, const char *qual, size_t len,
                         const orc_scan_params *p, orc_read_record *rec);
 void orc_read_record_free(orc_read_record *rec);
 
+/* ReadCorrection::ReadSelectionFunctor::operator() up to its record sink (readSelection/ReadCorrection.hpp:2318-2372):
+ * HPC + MinimizerParser at p->density (the correction density), NO complexity / quality filters, mean quality 0,
+ * per-minimizer min quality over the INCLUSIVE span [rle[pos], rle[pos+K-1]] (:2340, getMinQuality :2467-2481). */
+void orc_correction_scan(const char *seq, const char *qual, size_t len,
+                         const orc_scan_params *p, orc_read_record *rec);
+
+/* Utils::applyDensityThreshold (Commons.hpp:2507-2550): keep[i] = 1 iff Murmur(minimizer i) < density * 2^64.
+ * Returns the number kept. */
+size_t orc_apply_density_threshold(const uint32_t *minimizers, size_t n, float density, uint8_t *keep);
+
 /* Serialise a record exactly as ReadSelection::writeRead does (ReadSelection.hpp:415-467).
  * Returns bytes written (13 + 10 n). buf must hold that many. */
 size_t orc_write_read_record(const orc_read_record *rec, uint8_t *buf);

@@ -66,6 +66,9 @@ def lib():
         L.orc_read_selection.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(ScanParams), C.POINTER(ReadRecord)]
         L.orc_write_read_record.restype = C.c_size_t
         L.orc_compute_n50.restype = C.c_uint32
+        L.orc_correction_scan.argtypes = L.orc_read_selection.argtypes
+        L.orc_apply_density_threshold.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
+        L.orc_apply_density_threshold.restype = C.c_size_t
         L.orc_compute_n50.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_compute_mean_length.restype = C.c_uint32
         L.orc_compute_mean_length.argtypes = [C.c_void_p, C.c_size_t]
@@ -100,14 +103,28 @@ def murmur128(data: bytes, seed: int = 0) -> tuple[int, int]:
     return out[0], out[1]
 
 
+def correction_scan(seq: bytes, qual: bytes | None, K: int = 13, density: float = 0.025, hpc: bool = False,
+                    repetitive=None) -> dict:
+    """One read -> what ReadCorrection::ReadSelectionFunctor hands to its record sink."""
+    return read_selection(seq, qual, K, density, hpc, 0.0, repetitive, _fn="orc_correction_scan")
+
+
+def apply_density_threshold(mins, density: float) -> np.ndarray:
+    """Indices kept by Utils::applyDensityThreshold."""
+    m = np.ascontiguousarray(mins, dtype=np.uint32)
+    keep = np.zeros(len(m), dtype=np.uint8)
+    lib().orc_apply_density_threshold(m.ctypes.data, len(m), C.c_float(density), keep.ctypes.data)
+    return np.flatnonzero(keep)
+
+
 def read_selection(seq: bytes, qual: bytes | None, K: int = 15, density: float = 0.005, hpc: bool = True,
-                   min_read_quality: float = 0.0, repetitive=None) -> dict:
+                   min_read_quality: float = 0.0, repetitive=None, _fn: str = "orc_read_selection") -> dict:
     """One read -> the record the reference's readSelection would write for it."""
     rep = np.ascontiguousarray(repetitive if repetitive is not None else [], dtype=np.uint32)
     p = ScanParams(K, density, int(hpc), min_read_quality,
                    rep.ctypes.data_as(C.POINTER(C.c_uint32)), len(rep))
     rec = ReadRecord()
-    lib().orc_read_selection(seq, qual, len(seq), C.byref(p), C.byref(rec))
+    getattr(lib(), _fn)(seq, qual, len(seq), C.byref(p), C.byref(rec))
     n = rec.n
     out = dict(
         minimizers=np.ctypeslib.as_array(rec.minimizers, (n,)).copy() if n else np.zeros(0, np.uint32),

@@ -18,12 +18,16 @@
  *   refdrv fn_kminmer <k>                  : lines "m0 .. m(k-1)"       -> "rev hi lo c0 .. c(k-1)"
  *   refdrv fn_murmur                       : lines "<u64>"              -> Murmur3_x64_128(&v,8,42)
  *   refdrv fn_lastk <density> <n50> <firstK> <maxK>
+ *   refdrv fn_density <density>            : lines "m0 m1 ..."          -> indices kept by Utils::applyDensityThreshold
+ *   refdrv fn_corrscan <K> <density> <hpc> : lines "<seq> <qual>"       -> "n v:pos:dir:minq ..." as the correction scan
+ *                                            (ReadCorrection::ReadSelectionFunctor) computes them
  */
 #include "Commons.hpp"
 #include "readSelection/ReadSelection.hpp"
 #include "graph/CreateMdbg.hpp"
 #include "assembly/GenerateContigs.hpp"
 #include "toBasespace/ToMinspace.hpp"
+#include "readSelection/ReadCorrection.hpp"
 
 #include <iostream>
 #include <sstream>
@@ -95,6 +99,61 @@ static int fn_kminmer(int argc, char **argv)
     return 0;
 }
 
+static int fn_density(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    float density = std::stof(argv[2]);
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        vector<MinimizerType> m, mf;
+        for (uint64_t x : parse_u64s(line)) m.push_back((MinimizerType)x);
+        vector<u_int32_t> pos(m.size()), posf;
+        for (size_t i = 0; i < m.size(); i++) pos[i] = (u_int32_t)i;
+        vector<u_int8_t> dir(m.size(), 0), qual(m.size(), 0), dirf, qualf;
+        Utils::applyDensityThreshold(density, m, pos, dir, qual, mf, posf, dirf, qualf);
+        std::cout << mf.size();
+        for (size_t i = 0; i < mf.size(); i++) std::cout << " " << posf[i];
+        std::cout << "\n";
+    }
+    return 0;
+}
+
+/* The statements of ReadCorrection::ReadSelectionFunctor::operator() (ReadCorrection.hpp:2318-2343) up to the
+ * record sink, on the reference's own EncoderRLE / MinimizerParser / getMinQuality.  getMinQuality reads no
+ * member, so it is called on raw storage: building a ReadCorrection would pull the whole correction tool in. */
+static int fn_corrscan(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    size_t K = std::stoul(argv[2]);
+    float density = std::stof(argv[3]);
+    bool hpc = std::stoi(argv[4]) != 0;
+    unordered_set<MinimizerType> rep;
+    MinimizerParser parser(K, density, rep);
+    EncoderRLE enc;
+    alignas(16) static unsigned char storage[sizeof(ReadCorrection::ReadSelectionFunctor)];
+    auto *f = reinterpret_cast<ReadCorrection::ReadSelectionFunctor *>(storage);
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        std::istringstream is(line);
+        std::string seq, qual;
+        is >> seq >> qual;
+        std::string rle;
+        vector<u_int64_t> rlePos;
+        enc.execute(seq.c_str(), seq.size(), rle, rlePos, hpc);
+        vector<MinimizerType> m;
+        vector<u_int32_t> pos;
+        vector<u_int8_t> dir;
+        parser.parse(rle, m, pos, dir);
+        std::cout << m.size();
+        for (size_t i = 0; i < m.size(); i++) {
+            u_int8_t q = f->getMinQuality(0, seq, qual, rlePos[pos[i]], rlePos[pos[i] + K - 1]);
+            std::cout << " " << m[i] << ":" << pos[i] << ":" << (int)dir[i] << ":" << (int)q;
+        }
+        std::cout << "\n";
+    }
+    return 0;
+}
+
 static int fn_murmur()
 {
     std::string line;
@@ -111,6 +170,8 @@ int main(int argc, char **argv)
     std::string cmd = argv[1];
     if (cmd == "fn_scan") return fn_scan(argc, argv);
     if (cmd == "fn_purge") return fn_purge(argc, argv);
+    if (cmd == "fn_density") return fn_density(argc, argv);
+    if (cmd == "fn_corrscan") return fn_corrscan(argc, argv);
     if (cmd == "fn_kminmer") return fn_kminmer(argc, argv);
     if (cmd == "fn_murmur") return fn_murmur();
     if (cmd == "fn_lastk") {

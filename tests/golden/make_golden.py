@@ -254,6 +254,22 @@ def make_fn() -> None:
              (0.025, 9000, 4, 0), (0.005, 15431, 4, 0), (0.005, 100, 4, 0)]
     out["lastk"] = [dict(args=list(c), out=int(subprocess.run(
         [REFDRV, "fn_lastk"] + [str(x) for x in c], capture_output=True, text=True, check=True).stdout)) for c in cases]
+    # Utils::applyDensityThreshold: kept indices of random minimizer lists (own generator: the cases above stay as they were)
+    rng2 = np.random.default_rng(20260926)
+    dl = [" ".join(map(str, rng2.integers(0, 2**32, int(n)).tolist())) for n in (0, 1, 7, 400, 3000)]
+    out["density"] = {str(d): dict(inputs=dl, outputs=refdrv_lines(["fn_density", str(d)], dl)) for d in (0.005, 0.025, 0.2, 0.5)}
+    # the correction scan (ReadCorrection::ReadSelectionFunctor): minimizers + min quality over [rle[pos], rle[pos+l-1]]
+    def rnd_hp(n):   # homopolymer-rich
+        base = synth.CODE2ASCII[rng2.integers(0, 4, n)]
+        return bytes(np.repeat(base, rng2.choice([1, 1, 1, 2, 3, 6], n))).decode()
+    creads = [rnd_hp(n) for n in (40, 500, 2500, 2100, 5000)] + ["ACGT" * 300, "A" * 50 + rnd_hp(200) + "T" * 70]
+    cquals = ["".join(chr(33 + int(q)) for q in rng2.integers(0, 60, len(r))) for r in creads]
+    clines = [f"{r} {q}" for r, q in zip(creads, cquals)]
+    out["corrscan"] = {}
+    for hpc in (0, 1):
+        for K, dens in ((13, 0.025), (15, 0.025), (16, 0.05)):
+            out["corrscan"][f"K{K}_hpc{hpc}"] = dict(K=K, density=dens, hpc=hpc, reads=creads, quals=cquals,
+                                                     outputs=refdrv_lines(["fn_corrscan", str(K), str(dens), str(hpc)], clines))
     with open(os.path.join(dst, "fn_golden.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
 
@@ -264,6 +280,8 @@ def main() -> None:
     work = tempfile.mkdtemp(prefix="mdbg_golden_")
     try:
         make_fn()
+        if "--only-fn" in sys.argv:
+            return
         make_edge(work)
         make_hifi(work)
         make_ont(work)

@@ -351,6 +351,47 @@ def test_scan_reads_with_n(ctx, orc):
         _check_scan_against_oracle(ctx, orc, seqs, None, 15, 0.02, hpc)
 
 
+def test_correction_scan_and_density_threshold(ctx, orc):
+    """N1: the correction-density scan (ReadCorrection::ReadSelectionFunctor: no read filters, inclusive quality
+    span) and Utils::applyDensityThreshold, against the reference's own outputs (fn_golden.json) and the oracle."""
+    with open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")) as f:
+        g = json.load(f)
+    for key, gg in g["corrscan"].items():
+        reads = ctx.reads_from_ascii([r.encode() for r in gg["reads"]], [q.encode() for q in gg["quals"]])
+        m = ctx.scan(reads, K=gg["K"], density=gg["density"], hpc=bool(gg["hpc"]), apply_read_filters=False, quality_window=1)
+        h = m.to_host()
+        for i, out in enumerate(gg["outputs"]):
+            exp = [tuple(int(x) for x in t.split(":")) for t in out.split()[1:]]
+            a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
+            got = list(zip(h["minimizers"][a:b].tolist(), h["pos"][a:b].tolist(), h["dir"][a:b].tolist(), h["qual"][a:b].tolist()))
+            assert got == exp, (key, i)
+        # down-sample the same reads to the assembly density: every per-minimizer array follows
+        low = ctx.apply_density_threshold(m, 0.005).to_host()
+        for i in range(len(gg["reads"])):
+            a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
+            keep = orc.apply_density_threshold(h["minimizers"][a:b], 0.005) + a
+            c, d = int(low["offsets"][i]), int(low["offsets"][i + 1])
+            for f_ in ("minimizers", "pos", "dir", "qual"):
+                assert low[f_][c:d].tolist() == h[f_][keep].tolist(), (key, i, f_)
+        assert low["read_length"].tolist() == h["read_length"].tolist()
+    for dens, gg in g["density"].items():
+        lists = [np.array(line.split(), dtype=np.uint64).astype(np.uint32) for line in gg["inputs"]]
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+        m = ctx.minimizers_from_host(np.concatenate(lists), offs)
+        low = ctx.apply_density_threshold(m, float(dens)).to_host(full=False)
+        for i, out in enumerate(gg["outputs"]):
+            exp = lists[i][[int(x) for x in out.split()[1:]]]
+            assert low["minimizers"][int(low["offsets"][i]): int(low["offsets"][i + 1])].tolist() == exp.tolist(), (dens, i)
+    # large random case against the oracle
+    rng = np.random.default_rng(9)
+    mins = rng.integers(0, 2**32, 300000, dtype=np.uint64).astype(np.uint32)
+    offs = np.concatenate([[0], np.sort(rng.integers(0, len(mins), 999)), [len(mins)]]).astype(np.uint64)
+    low = ctx.apply_density_threshold(ctx.minimizers_from_host(mins, offs), 0.2).to_host(full=False)
+    keep = orc.apply_density_threshold(mins, 0.2)
+    assert low["minimizers"].tolist() == mins[keep].tolist()
+    assert low["offsets"].tolist() == np.searchsorted(keep, offs).tolist()
+
+
 def test_multi_k_loop_benchmark_mode(ctx, orc):
     """BASELINE.json configs[2] at test scale: k = 4 .. 11 over the same minimizer-space reads, reads only,
     previous table = own k-1 output (SURVEY.md 8(d) "benchmark mode"); every k must equal the oracle's loop."""

@@ -86,6 +86,32 @@ def test_scan_with_invalid_characters(fn_golden):
             assert hl == int(toks[1]) and got == exp, key
 
 
+def test_apply_density_threshold(fn_golden):
+    """Utils::applyDensityThreshold (Commons.hpp:2507-2550) via refdrv fn_density."""
+    for dens, g in fn_golden["density"].items():
+        for line, out in zip(g["inputs"], g["outputs"]):
+            mins = np.array(line.split(), dtype=np.uint64).astype(np.uint32)
+            exp = [int(x) for x in out.split()[1:]]
+            assert orc.apply_density_threshold(mins, float(dens)).tolist() == exp, dens
+
+
+def test_correction_scan(fn_golden):
+    """ReadCorrection::ReadSelectionFunctor up to its sink, via refdrv fn_corrscan; the inclusive quality span must
+    also be told apart from ReadSelection's on these reads (else the fixture pins nothing)."""
+    differs = False
+    for key, g in fn_golden["corrscan"].items():
+        for seq, qual, out in zip(g["reads"], g["quals"], g["outputs"]):
+            exp = [tuple(int(x) for x in t.split(":")) for t in out.split()[1:]]
+            r = orc.correction_scan(seq.encode(), qual.encode(), K=g["K"], density=g["density"], hpc=bool(g["hpc"]))
+            got = list(zip(r["minimizers"].tolist(), r["pos"].tolist(), r["dir"].tolist(), r["qual"].tolist()))
+            assert got == exp, key
+            assert r["mean_quality"] == 0.0 and not r["low_complexity"] and not r["low_quality"]
+            if g["hpc"]:
+                r0 = orc.read_selection(seq.encode(), qual.encode(), K=g["K"], density=g["density"], hpc=True)
+                differs |= (not r0["low_complexity"]) and r0["qual"].tolist() != r["qual"].tolist()
+    assert differs
+
+
 @pytest.mark.parametrize("tag,K,dens,hpc", [("hpc_k15", 15, 0.005, True), ("nohpc_k15", 15, 0.005, False),
                                             ("hpc_k16", 16, 0.005, True), ("nohpc_k13", 13, 0.02, False)])
 def test_edge_reads_fasta(tag, K, dens, hpc):
