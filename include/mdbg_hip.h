@@ -96,6 +96,9 @@ typedef struct {
                                      1: [rle[pos], rle[pos+l-1]]  the correction scan, ReadCorrection::ReadSelectionFunctor
                                                                   (ReadCorrection.hpp:2340, :2467-2481); used with
                                                                   density = _minimizerDensity_correction, apply_read_filters = 0 */
+    int32_t  no_end_trim;         /* 0: MinimizerParser's default _trimBps = 1, the first and last l-mer of a read are never
+                                     selected (utils/kmer/Kmer.hpp:1362, :1395); 1: _trimBps = 0 as GenerateGfa's
+                                     LoadUnitigsFunctor sets it for unitig sequences (graph/GenerateGfa.hpp:366) */
 } mdbg_scan_params;
 
 /* Replaces, for a whole batch, EncoderRLE::execute + MinimizerParser::parse + complexity /

@@ -50,6 +50,7 @@ struct ScanArgs {
     uint32_t n_reads;
     uint32_t K;
     uint64_t threshold;           // hash < threshold  <=>  (double)hash < density * 2^64
+    uint32_t trim;                // MinimizerParser::_trimBps: 1 (default) skips the first and last l-mer, 0 keeps them
     uint32_t q_last;              // 1: quality span ends ON the last base of the l-mer (correction scan), 0: at the next run
     const uint32_t *rep;          // sorted repetitive minimizers
     uint32_t n_rep;
@@ -366,7 +367,7 @@ struct KmerTrip {
             sel[u] = (val[u] == 0x12345u) && (j < nk);                                  // ablation: no hash
 #else
             // first k-mer of the read skipped (Kmer.hpp:1395)
-            sel[u] = (kmer_hash32(val[u]) < a.threshold) && (hp_base + j >= 1u) && (j < nk);
+            sel[u] = (kmer_hash32(val[u]) < a.threshold) && (hp_base + j >= a.trim) && (j < nk);
 #endif
             if (HAS_N) sel[u] = sel[u] && (istream_extract(SI, j < nk ? j : nk - 1u, kbits) == 0u);   // Kmer.hpp:574-580
         }
@@ -607,6 +608,40 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             hp_total += C;
             wave_lds_sync();   // all reads of S / Q done before the next tile rewrites them
             if (HAS_QUAL && HPC) { if (lane < cbn) Q->carry_orig[lane] = my_orig; }
+        }
+
+        // ---- _trimBps == 0 (GenerateGfa.hpp:366): the last l-mer, which the tiles never evaluate because
+        // no base follows it.  Its K bases are the carry; one lane does the work.
+        if (a.trim == 0u && hp_total >= K) {
+            if (HAS_QUAL && HPC) wave_lds_sync();   // carry_orig of the last tile
+            const uint32_t e = carry & kmask;
+            const uint32_t rev = e ^ comp_mask, fwd = digit_reverse(e, K);
+            const uint32_t d = fwd < rev ? 0u : 1u, v = d ? rev : fwd;
+            bool s1 = kmer_hash32(v) < a.threshold;
+            if (HAS_N) s1 = s1 && icarry == 0u;
+            if (s1 && a.n_rep) s1 = !rep_contains(a.rep, a.n_rep, v);
+            if (s1) {
+                if (lane == 0 && nout < cap) {
+                    const uint32_t p = hp_total - K;
+                    a.out_min[cap0 + nout] = v;
+                    a.out_pos[cap0 + nout] = p;
+                    a.out_dir[cap0 + nout] = (uint8_t)d;
+                    if (HAS_QUAL) {
+                        const uint32_t os = HPC ? Q->carry_orig[0] : p;
+                        const uint32_t oe = a.q_last ? (HPC ? Q->carry_orig[K - 1] : p + K - 1u) + 1u : L;
+                        if (a.inline_minq) {
+                            const uint8_t *qq = a.qual + a.qual_off[r];
+                            uint8_t mq = 255;
+                            for (uint32_t bq = os; bq < oe; bq++) { uint8_t q = (uint8_t)(qq[bq] - 33); if (q < mq) mq = q; }
+                            a.out_mqual[cap0 + nout] = mq;
+                        } else {
+                            a.out_os[cap0 + nout] = os;
+                            a.out_oe[cap0 + nout] = oe;
+                        }
+                    }
+                }
+                nout++;
+            }
         }
 
         // ---- per-read epilogue -----------------------------------------------------------------
@@ -862,6 +897,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     a.K = p->minimizer_size;
     a.threshold = density_threshold(p->density);
     a.q_last = p->quality_window == 1 ? 1u : 0u;
+    a.trim = p->no_end_trim ? 0u : 1u;
     a.rep = d_rep.p; a.n_rep = p->n_repetitive;
     a.apply_filters = p->apply_read_filters;
     a.subset = nullptr;

@@ -155,6 +155,13 @@ size_t orc_minimizer_parse(const char *seq, size_t len, unsigned K, float densit
                            const uint32_t *repetitive, size_t n_rep,
                            uint32_t *out_min, uint32_t *out_pos, uint8_t *out_dir)
 {
+    return orc_minimizer_parse_trim(seq, len, K, density, repetitive, n_rep, 1, out_min, out_pos, out_dir);
+}
+
+size_t orc_minimizer_parse_trim(const char *seq, size_t len, unsigned K, float density,
+                                const uint32_t *repetitive, size_t n_rep, size_t trim_bps,
+                                uint32_t *out_min, uint32_t *out_pos, uint8_t *out_dir)
+{
     if (len < K) return 0;
     size_t nk = len - K + 1;
     uint64_t *kmers = (uint64_t *)malloc(nk * sizeof(uint64_t));
@@ -169,7 +176,7 @@ size_t orc_minimizer_parse(const char *seq, size_t len, unsigned K, float densit
         qsort(rep_sorted, n_rep, sizeof(uint32_t), cmp_u32);
     }
     size_t n = 0;
-    for (size_t pos = 1; pos + 1 < nk; pos++) { /* :1395 with _trimBps = 1 */
+    for (size_t pos = trim_bps; pos + trim_bps < nk; pos++) { /* :1395; _trimBps = 1 by default (:1362) */
         uint64_t v = kmers[pos];
         uint64_t h = orc_kmer_hash(v);
         if ((double)h < bound) {

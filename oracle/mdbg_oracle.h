@@ -57,6 +57,11 @@ size_t orc_kmer_iterate(const char *seq, size_t len, unsigned K, uint64_t *kmers
 size_t orc_minimizer_parse(const char *seq, size_t len, unsigned K, float density,
                            const uint32_t *repetitive, size_t n_rep,
                            uint32_t *out_min, uint32_t *out_pos, uint8_t *out_dir);
+/* Same with MinimizerParser::_trimBps explicit: 1 is the constructor's default (Kmer.hpp:1362); GenerateGfa's
+ * LoadUnitigsFunctor sets 0 (graph/GenerateGfa.hpp:366) so the first and last l-mer of a unitig can be selected. */
+size_t orc_minimizer_parse_trim(const char *seq, size_t len, unsigned K, float density,
+                                const uint32_t *repetitive, size_t n_rep, size_t trim_bps,
+                                uint32_t *out_min, uint32_t *out_pos, uint8_t *out_dir);
 
 /* ReadSelectionFunctor::computeSequenceComplexity (readSelection/ReadSelection.hpp:1171-1228)
  * with w=64, step=32 on the ORIGINAL (not HPC) sequence.  NaN when there is no full window.

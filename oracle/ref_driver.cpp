@@ -14,6 +14,7 @@
  *   refdrv contig ... / refdrv toMinspace ...      (producers of the k>4 inputs)
  * Function-level probes (text on stdin -> text on stdout), used by tests/golden/make_golden.py:
  *   refdrv fn_scan <K> <density> <hpc>     : lines "<seq>"              -> "n v:pos:dir ..."
+ *   refdrv fn_scan_notrim <K> <density> <hpc> : same with MinimizerParser::_trimBps = 0 (GenerateGfa's unitig scan)
  *   refdrv fn_purge <firstK> <lastK>       : lines "m0 m1 ..."          -> purged list
  *   refdrv fn_kminmer <k>                  : lines "m0 .. m(k-1)"       -> "rev hi lo c0 .. c(k-1)"
  *   refdrv fn_murmur                       : lines "<u64>"              -> Murmur3_x64_128(&v,8,42)
@@ -41,7 +42,7 @@ static std::vector<uint64_t> parse_u64s(const std::string &line)
     return v;
 }
 
-static int fn_scan(int argc, char **argv)
+static int fn_scan(int argc, char **argv, size_t trim)
 {
     if (argc < 5) return 2;
     size_t K = std::stoul(argv[2]);
@@ -50,6 +51,7 @@ static int fn_scan(int argc, char **argv)
     unordered_set<MinimizerType> rep;
     for (int i = 5; i < argc; i++) rep.insert((MinimizerType)std::stoul(argv[i]));
     MinimizerParser parser(K, density, rep);
+    parser._trimBps = trim;                 /* 1 = the constructor's default; 0 as graph/GenerateGfa.hpp:366 sets it */
     EncoderRLE enc;
     std::string line;
     while (std::getline(std::cin, line)) {
@@ -168,7 +170,8 @@ int main(int argc, char **argv)
 {
     if (argc < 2) { std::cerr << "usage: refdrv <sub-command> ...\n"; return 2; }
     std::string cmd = argv[1];
-    if (cmd == "fn_scan") return fn_scan(argc, argv);
+    if (cmd == "fn_scan") return fn_scan(argc, argv, 1);
+    if (cmd == "fn_scan_notrim") return fn_scan(argc, argv, 0);
     if (cmd == "fn_purge") return fn_purge(argc, argv);
     if (cmd == "fn_density") return fn_density(argc, argv);
     if (cmd == "fn_corrscan") return fn_corrscan(argc, argv);

@@ -270,6 +270,13 @@ def make_fn() -> None:
         for K, dens in ((13, 0.025), (15, 0.025), (16, 0.05)):
             out["corrscan"][f"K{K}_hpc{hpc}"] = dict(K=K, density=dens, hpc=hpc, reads=creads, quals=cquals,
                                                      outputs=refdrv_lines(["fn_corrscan", str(K), str(dens), str(hpc)], clines))
+    # MinimizerParser with _trimBps = 0 (GenerateGfa's unitig scan): high density so the end l-mers do get selected
+    treads = [rnd_hp(n) for n in (15, 16, 17, 18, 40, 300, 2048 * 2 + 15, 2048 + 16, 5000)] + ["ACGTTGCA" * 40]
+    out["scan_notrim"] = {}
+    for hpc in (0, 1):
+        for K, dens in ((15, 0.5), (16, 0.3), (11, 0.9)):
+            out["scan_notrim"][f"K{K}_hpc{hpc}"] = dict(K=K, density=dens, hpc=hpc, inputs=treads,
+                                                        outputs=refdrv_lines(["fn_scan_notrim", str(K), str(dens), str(hpc)], treads))
     with open(os.path.join(dst, "fn_golden.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
 

@@ -351,6 +351,20 @@ def test_scan_reads_with_n(ctx, orc):
         _check_scan_against_oracle(ctx, orc, seqs, None, 15, 0.02, hpc)
 
 
+def test_scan_without_end_trim(ctx):
+    """N4: GenerateGfa's unitig scan sets MinimizerParser::_trimBps = 0 (GenerateGfa.hpp:366)."""
+    with open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")) as f:
+        g = json.load(f)["scan_notrim"]
+    for key, gg in g.items():
+        reads = ctx.reads_from_ascii([s.encode() for s in gg["inputs"]])
+        h = ctx.scan(reads, K=gg["K"], density=gg["density"], hpc=bool(gg["hpc"]), apply_read_filters=False, no_end_trim=True).to_host()
+        for i, out in enumerate(gg["outputs"]):
+            exp = [tuple(int(x) for x in t.split(":")) for t in out.split()[2:]]
+            a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
+            got = list(zip(h["minimizers"][a:b].tolist(), h["pos"][a:b].tolist(), h["dir"][a:b].tolist()))
+            assert got == exp, (key, i)
+
+
 def test_correction_scan_and_density_threshold(ctx, orc):
     """N1: the correction-density scan (ReadCorrection::ReadSelectionFunctor: no read filters, inclusive quality
     span) and Utils::applyDensityThreshold, against the reference's own outputs (fn_golden.json) and the oracle."""

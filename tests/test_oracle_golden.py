@@ -86,6 +86,28 @@ def test_scan_with_invalid_characters(fn_golden):
             assert hl == int(toks[1]) and got == exp, key
 
 
+def test_scan_without_end_trim(fn_golden):
+    """MinimizerParser with _trimBps = 0 (GenerateGfa's LoadUnitigsFunctor) via refdrv fn_scan_notrim."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_minimizer_parse_trim.restype = C.c_size_t
+    n_end = 0
+    for key, g in fn_golden["scan_notrim"].items():
+        for seq, out in zip(g["inputs"], g["outputs"]):
+            toks = out.split()
+            exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
+            s = seq.encode()
+            rle = C.create_string_buffer(len(s) + 2)
+            pos = (C.c_uint64 * (len(s) + 2))()
+            hl = L.orc_hpc_encode(s, C.c_size_t(len(s)), g["hpc"], rle, pos)
+            om = (C.c_uint32 * max(hl, 1))(); op = (C.c_uint32 * max(hl, 1))(); od = (C.c_uint8 * max(hl, 1))()
+            n = L.orc_minimizer_parse_trim(rle, C.c_size_t(hl), g["K"], C.c_float(g["density"]), None, C.c_size_t(0), C.c_size_t(0), om, op, od)
+            got = [(om[i], op[i], od[i]) for i in range(n)]
+            assert hl == int(toks[1]) and got == exp, key
+            n_end += sum(1 for e in exp if e[1] == 0 or e[1] == hl - g["K"])
+    assert n_end > 10      # the fixture does exercise the end positions
+
+
 def test_apply_density_threshold(fn_golden):
     """Utils::applyDensityThreshold (Commons.hpp:2507-2550) via refdrv fn_density."""
     for dens, g in fn_golden["density"].items():
