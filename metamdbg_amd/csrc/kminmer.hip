@@ -58,20 +58,22 @@ __device__ __forceinline__ bool window_hash(const uint32_t *m, uint32_t k, uint6
 
 __device__ __forceinline__ uint32_t table_upsert_count(const TableView &t, uint64_t lo, uint64_t hi, uint32_t add, uint32_t rep) {
     if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, add, 0, false, rep, true);
-    uint32_t s = table_find_or_insert(t, lo, hi, true);
+    bool created = false;
+    uint32_t s = table_find_or_insert(t, lo, hi, true, &created);
     if (s != SLOT_NONE) {
         if (add) atomicAdd(&t.slots[s].val, add);
-        t.slots[s].rep = rep;   // any instance of the key is a valid representative
+        if (created) t.slots[s].rep = rep;   // the instance that published the key represents it: one store per key, not per instance
     }
     return s;
 }
 
 __device__ __forceinline__ uint32_t table_upsert_set(const TableView &t, uint64_t lo, uint64_t hi, uint32_t v, uint32_t rep) {
     if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, 0, v, true, rep, true);
-    uint32_t s = table_find_or_insert(t, lo, hi, true);
+    bool created = false;
+    uint32_t s = table_find_or_insert(t, lo, hi, true, &created);
     if (s != SLOT_NONE) {
         __hip_atomic_store(&t.slots[s].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t.slots[s].rep = rep;
+        if (created) t.slots[s].rep = rep;
     }
     return s;
 }
@@ -82,7 +84,14 @@ struct SeqView {
     const uint64_t *inst_off;  // n_reads + 1
     uint32_t n_reads;
     uint64_t n_inst;
+    uint64_t n_min;            // minimizers in `mins`
 };
+
+// A table slot's `rep` names one instance of its key by the FLAT index of the window's first minimizer
+// (set a first, then set b): reading the window back needs no search over the offsets.
+__device__ __forceinline__ const uint32_t *rep_window(const SeqView &a, const SeqView &b, uint32_t rep) {
+    return rep < a.n_min ? a.mins + rep : b.mins + (rep - a.n_min);
+}
 
 // Visit every instance with 16 lanes per sequence (4 sequences per wave): sequences hold a few dozen
 // windows, the minimizers of neighbouring windows are loaded coalesced, and no per-instance binary search
@@ -110,30 +119,49 @@ __global__ __launch_bounds__(256) void count_insert_kernel(SeqView s, uint32_t k
     for_each_instance(s, [&](uint32_t, uint64_t g, const uint32_t *m) {
         uint64_t hi, lo;
         window_hash(m, k, hi, lo);
-        uint32_t slot = table_upsert_count(t, lo, hi, 1u, (uint32_t)(rep_base + g));
+#if defined(INSERT_ABLATE) && INSERT_ABLATE == 3
+        if (inst_slot) inst_slot[g] = (uint32_t)(lo ^ hi);                                          // ablation: hash only
+#elif defined(INSERT_ABLATE) && INSERT_ABLATE == 2
+        bool created = false;
+        uint32_t slot = table_find_or_insert(t, lo, hi, true, &created);                            // ablation: no count
         if (inst_slot) inst_slot[g] = slot;
+#else
+        uint32_t slot = table_upsert_count(t, lo, hi, 1u, (uint32_t)(rep_base + (uint64_t)(m - s.mins)));
+#if !defined(INSERT_ABLATE) || INSERT_ABLATE != 1
+        if (inst_slot) inst_slot[g] = slot;
+#else
+        if (inst_slot && slot == 0x7FFFFFFEu) inst_slot[g] = slot;                                  // ablation: no slot store
+#endif
+#endif
     });
 }
 
-// abundance seen by the rescue pass: solid count or 1 (graph/CreateMdbg.hpp:4590-4600)
-__global__ __launch_bounds__(256) void inst_abundance_kernel(uint64_t n_inst, const uint32_t *inst_slot, TableView t,
-                                                             uint32_t min_abundance, uint32_t *ab) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_inst) return;
-    uint32_t slot = inst_slot[g];
-    uint32_t c = slot == SLOT_NONE ? 1u : table_slot_val(t, slot);
-    bool solid = c > 1u && !(c < min_abundance);
-    ab[g] = solid ? c : 0u;   // 0 = not in the solid table
+// ---- rescue (graph/CreateMdbg.hpp:4514-4640) --------------------------------------------------------
+// The rescue pass needs the count of every instance's key.  Reading it from the 32-byte table slots is one
+// random 64-byte sector per instance (0.65 ms per 34 M instances); instead every slot's count is first
+// reduced to a 2-bit class -- all the decision below needs except in one rare tie case -- packed 4 slots per
+// byte: 1 MB for a 4 M-slot table, L2-resident, so the per-instance reads are cache hits.
+//   class 0: count <= 1   not solid, counts as 1 (CreateMdbg.hpp:4598)
+//   class 1: 2 .. m*      solid, <= m*
+//   class 2: > m*         solid
+// m* is the largest u32 whose float product m * 0.1f is not > 1 (computed on the host: 10).
+// class of instance g's key (failed inserts count as 1)
+__device__ __forceinline__ uint32_t count_class(const uint8_t *cls, uint64_t cap, uint32_t slot) {
+    if (slot == SLOT_NONE) return 0u;
+    const uint64_t idx = (slot & 0x80000000u) ? cap + (slot & 0x7FFFFFFFu) : (uint64_t)slot;
+    return (cls[idx >> 2] >> (2u * (uint32_t)(idx & 3u))) & 3u;
 }
 
-// Rescue decision per read (graph/CreateMdbg.hpp:4590-4640) without sorting.  With m* the largest u32
-// whose float product m * 0.1f is not > 1 (computed on the host: 10), "median * 0.1f > 1" is false
+// Rescue decision per read without sorting.  A k-min-mer is solid iff its count is > 1 (the rescue pass only
+// runs when min_abundance <= 1, graph/CreateMdbg.cpp:317-319).  "median * 0.1f > 1" (:4610) is false
 //   odd n : iff at least n/2+1 abundances are <= m*
 //   even n: iff at least n/2+1 are <= m*, or exactly n/2 are and (max{<= m*} + min{> m*}) / 2 passes the
-//           same float test (Utils::compute_median on u32, Commons.hpp:2972-2988)
-// 16 lanes per read (4 reads per wave): reads hold a few dozen k-min-mers.
-__global__ __launch_bounds__(256) void rescue_flag_kernel(const uint64_t *inst_off, uint32_t n_reads, const uint32_t *ab,
-                                                          uint32_t m_star, uint32_t *flag) {
+//           same float test (Utils::compute_median on u32, Commons.hpp:2972-2988) -- the one case that needs
+//           exact counts, which are then read from the table
+// 16 lanes per read (4 reads per wave): reads hold a few dozen k-min-mers.  Output: per read the number of
+// non-solid instances to append (0 when the read is not rescued).
+__global__ __launch_bounds__(256) void rescue_count_kernel(const uint64_t *inst_off, uint32_t n_reads, const uint32_t *inst_slot,
+                                                           const uint8_t *cls, TableView t, uint64_t cap, uint32_t m_star, uint32_t *resc_cnt) {
     const unsigned sub = threadIdx.x & 15u;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
@@ -142,49 +170,80 @@ __global__ __launch_bounds__(256) void rescue_flag_kernel(const uint64_t *inst_o
         const bool live = r < n_reads;
         const uint64_t f = live ? inst_off[r] : 0;
         const uint32_t n = live ? (uint32_t)(inst_off[r + 1] - f) : 0u;
-        uint32_t c_le = 0, mx_le = 0, mn_gt = 0xFFFFFFFFu, any_solid = 0;
+        uint32_t n_weak = 0, n_small = 0, n_big = 0;
         for (uint32_t i = sub; i < n; i += 16) {
-            uint32_t a = ab[f + i];
-            any_solid |= (a != 0u);
-            if (a == 0u) a = 1u;                               // non-solid counts as 1 (CreateMdbg.hpp:4598)
-            if (a <= m_star) { c_le++; mx_le = a > mx_le ? a : mx_le; }
-            else mn_gt = a < mn_gt ? a : mn_gt;
+            const uint32_t c = count_class(cls, cap, inst_slot[f + i]);
+            n_weak += c == 0u; n_small += c == 1u; n_big += c == 2u;
         }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) {                     // reduce within the 16-lane group
-            c_le += __shfl_xor(c_le, d, 64);
-            uint32_t t = __shfl_xor(mx_le, d, 64); mx_le = t > mx_le ? t : mx_le;
-            t = __shfl_xor(mn_gt, d, 64); mn_gt = t < mn_gt ? t : mn_gt;
-            any_solid |= __shfl_xor(any_solid, d, 64);
+            n_weak += __shfl_xor(n_weak, d, 64);
+            n_small += __shfl_xor(n_small, d, 64);
+            n_big += __shfl_xor(n_big, d, 64);
         }
-        bool rescue = false;
-        if (n && any_solid) {                                  // all-ones reads are skipped (:4612)
-            const uint32_t half = n / 2;
-            if (c_le >= half + 1) rescue = true;
-            else if ((n & 1u) == 0u && c_le == half) {
-                uint32_t median = (uint32_t)(mx_le + mn_gt) / 2u;
+        const uint32_t c_le = n_weak + n_small, half = n / 2;
+        const bool any_solid = (n_small + n_big) != 0u;        // all-ones reads are skipped (:4612)
+        bool rescue = n && any_solid && c_le >= half + 1;
+        const bool tie = n && any_solid && (n & 1u) == 0u && c_le == half;
+        // the branch below is per read, i.e. uniform over the 16 lanes that shuffle with each other
+        uint32_t mx_le = 1u, mn_gt = 0xFFFFFFFFu;
+        if (__any(tie)) {
+            if (tie) {
+                for (uint32_t i = sub; i < n; i += 16) {
+                    const uint32_t slot = inst_slot[f + i];
+                    uint32_t a = slot == SLOT_NONE ? 1u : table_slot_val(t, slot);
+                    if (a <= 1u) a = 1u;
+                    if (a <= m_star) mx_le = a > mx_le ? a : mx_le; else mn_gt = a < mn_gt ? a : mn_gt;
+                }
+            }
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) {                 // all lanes of the wave take part (tie or not)
+                uint32_t x = __shfl_xor(mx_le, d, 64); mx_le = x > mx_le ? x : mx_le;
+                x = __shfl_xor(mn_gt, d, 64); mn_gt = x < mn_gt ? x : mn_gt;
+            }
+            if (tie) {
+                const uint32_t median = (uint32_t)(mx_le + mn_gt) / 2u;
                 rescue = !((float)median * 0.1f > 1.0f);       // :4610
             }
         }
-        for (uint32_t i = sub; i < n; i += 16) flag[f + i] = (rescue && ab[f + i] == 0u) ? 1u : 0u;
+        if (live && sub == 0) resc_cnt[r] = rescue ? n_weak : 0u;
     }
 }
 
+// One pass over the table: which slots become output rows, and (optionally) the 2-bit count class of every slot
+// for the rescue pass.  A lane reads its 32-byte slot as two 16-byte loads; 4 neighbouring lanes pack their
+// classes into one byte.
 __global__ __launch_bounds__(256) void slot_flag_kernel(TableView t, uint64_t cap, uint32_t min_abundance, int mode,
-                                                        uint32_t *flag) {
+                                                        uint32_t *flag, uint8_t *cls = nullptr, uint32_t m_star = 0, uint32_t *occ_count = nullptr) {
     // mode 0: solid (count > 1 and >= min_abundance); mode 1: any occupied slot with val > 1; mode 2: occupied
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= cap + TABLE_EXC_CAP) return;
-    bool occ; uint32_t v;
-    if (s < cap) { occ = t.slots[s].lo != 0ull; v = t.slots[s].val; }
-    else { uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; v = occ ? t.exc_val[i] : 0u; }
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = s < cap + TABLE_EXC_CAP;   // cap is a multiple of 256: whole waves are in or out of the main table
+    bool occ = false; uint32_t v = 0;
+    if (s < cap) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(t.slots + s);
+        const uint4 key = q[0], rest = q[1];
+        occ = (key.x | key.y) != 0u;
+        v = rest.x;
+    } else if (in_range) {
+        uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; v = occ ? t.exc_val[i] : 0u;
+    }
     bool keep = false;
     if (occ) {
         if (mode == 0) keep = v > 1u && !(v < min_abundance);
         else if (mode == 1) keep = v > 1u;
         else keep = true;
     }
-    flag[s] = keep ? 1u : 0u;
+    if (in_range && flag) flag[s] = keep ? 1u : 0u;
+    if (cls) {
+        uint32_t c = (!occ || v <= 1u) ? 0u : (v <= m_star ? 1u : 2u);
+        c |= __shfl_down(c, 1, 64) << 2;             // lanes 4j..4j+3 -> lane 4j
+        c |= __shfl_down(c, 2, 64) << 4;
+        if (in_range && (threadIdx.x & 3u) == 0u) cls[s >> 2] = (uint8_t)c;
+    }
+    if (occ_count) {   // uniform branch: distinct keys, for sizing the next table of this kind
+        const int n = __syncthreads_count(occ);
+        if (threadIdx.x == 0 && n) atomicAdd(&occ_count[blockIdx.x % TABLE_OCC_WAYS], (uint32_t)n);
+    }
 }
 
 struct RowOut {
@@ -194,12 +253,9 @@ struct RowOut {
     uint32_t k;
 };
 
-// write the canonical vector of global instance id `g` (over one or two sequence sets)
-__device__ __forceinline__ void write_instance_vector(const SeqView &a, const SeqView &b, uint64_t g, uint32_t k, uint32_t *dst) {
-    const SeqView &s = g < a.n_inst ? a : b;
-    uint64_t gl = g < a.n_inst ? g : g - a.n_inst;
-    uint32_t r = find_read(s.inst_off, s.n_reads, gl);
-    const uint32_t *m = s.mins + s.off[r] + (gl - s.inst_off[r]);
+// write the canonical vector of the instance `rep` names (over one or two sequence sets)
+__device__ __forceinline__ void write_instance_vector(const SeqView &a, const SeqView &b, uint32_t rep, uint32_t k, uint32_t *dst) {
+    const uint32_t *m = rep_window(a, b, rep);
     bool reversed = true;
     for (uint32_t i = 0; i < k; i++) {
         uint32_t x = m[i], y = m[k - 1 - i];
@@ -221,18 +277,42 @@ __global__ __launch_bounds__(256) void emit_slots_kernel(TableView t, uint64_t c
     if (o.vec) write_instance_vector(a, b, rep, o.k, o.vec + row * o.k);
 }
 
-__global__ __launch_bounds__(256) void emit_rescued_kernel(SeqView s, uint32_t k, const uint32_t *flag, const uint64_t *pos,
-                                                           RowOut o, uint64_t row_base) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= s.n_inst || !flag[g]) return;
-    uint64_t row = row_base + pos[g];
-    uint32_t r = find_read(s.inst_off, s.n_reads, g);
-    const uint32_t *m = s.mins + s.off[r] + (g - s.inst_off[r]);
-    uint64_t hi, lo;
-    bool reversed = window_hash(m, k, hi, lo);
-    o.lo[row] = lo; o.hi[row] = hi; o.ab[row] = 1u;
-    for (uint32_t i = 0; i < k; i++) o.vec[row * k + i] = reversed ? m[k - 1 - i] : m[i];
+// rows of the rescued reads' non-solid instances, in read order then window order (abundance 1, :4630-4636)
+__global__ __launch_bounds__(256) void emit_rescued_kernel(SeqView s, uint32_t k, const uint32_t *inst_slot, const uint8_t *cls, uint64_t cap,
+                                                           const uint32_t *resc_cnt, const uint64_t *resc_pos, RowOut o, uint64_t row_base) {
+    const unsigned sub = threadIdx.x & 15u, gshift = (threadIdx.x & 63u) & ~15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (resc_cnt[r] == 0u) continue;
+        const uint64_t f = s.inst_off[r];
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - f);
+        const uint32_t *m0 = s.mins + s.off[r];
+        uint64_t row = row_base + resc_pos[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 16) {              // the 16 lanes of a group stay converged: ballot sees all of them
+            const uint32_t i = i0 + sub;
+            const bool weak = i < n && count_class(cls, cap, inst_slot[f + i]) == 0u;
+            const uint32_t bal = (uint32_t)(__ballot(weak) >> gshift) & 0xFFFFu;
+            if (weak) {
+                const uint64_t dst = row + (uint32_t)__popc(bal & ((1u << sub) - 1u));
+                const uint32_t *m = m0 + i;
+                uint64_t hi, lo;
+                bool reversed = window_hash(m, k, hi, lo);
+                o.lo[dst] = lo; o.hi[dst] = hi; o.ab[dst] = 1u;
+                for (uint32_t j = 0; j < k; j++) o.vec[dst * k + j] = reversed ? m[k - 1 - j] : m[j];
+            }
+            row += (uint32_t)__popc(bal);
+        }
+    }
 }
+
+// The rescue pass over one read set against the counts in `t`: per-read decision, row positions, total.
+struct RescuePlan {
+    DevBuf<uint8_t> cls;      // 2-bit count class per table slot
+    DevBuf<uint32_t> cnt;
+    DevBuf<uint64_t> pos;
+    uint64_t cap = 0, total = 0;
+};
 
 // ---- k > firstK --------------------------------------------------------------------------------------
 // distinct keys of all k-windows (k = firstK+1)
@@ -240,7 +320,7 @@ __global__ __launch_bounds__(256) void distinct_insert_kernel(SeqView s, uint32_
     for_each_instance(s, [&](uint32_t, uint64_t g, const uint32_t *m) {
         uint64_t hi, lo;
         window_hash(m, k, hi, lo);
-        table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + g));
+        table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + (uint64_t)(m - s.mins)));
     });
 }
 
@@ -254,10 +334,7 @@ __global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t
     if (s < cap) { occ = t.slots[s].lo != 0ull; rep = occ ? t.slots[s].rep : 0; }
     else { uint32_t i = (uint32_t)(s - cap); occ = i < *t.exc_n; rep = occ ? t.exc_rep[i] : 0; }
     if (!occ) return;
-    const SeqView &sv = rep < a.n_inst ? a : b;
-    uint64_t gl = rep < a.n_inst ? rep : rep - a.n_inst;
-    uint32_t r = find_read(sv.inst_off, sv.n_reads, gl);
-    const uint32_t *m = sv.mins + sv.off[r] + (gl - sv.inst_off[r]);
+    const uint32_t *m = rep_window(a, b, rep);
     // sub-windows of the CANONICAL vector; min over both is orientation independent, so use m directly
     uint32_t min_ab = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < 2; i++) {
@@ -389,6 +466,12 @@ static uint32_t rescue_m_star() {
     return m;
 }
 
+// Size the next table of this kind for the distinct keys just seen (+12.5 %): build_table_adaptive doubles that and
+// rounds up to a power of two, i.e. 25-45 % load.
+static void update_key_hint(mdbg_ctx *ctx, uint64_t distinct, uint64_t instances) {
+    if (instances) ctx->key_ratio_hint = 1.125 * (double)distinct / (double)instances;
+}
+
 struct InstIndex {
     DevBuf<uint64_t> off;   // n_reads + 1
     uint64_t total = 0;
@@ -405,6 +488,37 @@ static int build_inst_index(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t k,
     return MDBG_OK;
 }
 
+// dense counts + per-read rescue decision + row positions (only meaningful when min_abundance <= 1)
+static int plan_rescue(mdbg_ctx *ctx, const DeviceTable &tab, const InstIndex &ix, uint32_t n_reads, const uint32_t *inst_slot,
+                       RescuePlan &p) {
+    TableView tv = tab.view();
+    const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
+    const uint32_t m_star = rescue_m_star();
+    MDBG_TRY(p.cnt.alloc(ctx, n_reads));
+    MDBG_TRY(p.pos.alloc(ctx, (size_t)n_reads + 1));
+    {
+        LaunchTimer timer(ctx, "kminmer_rescue");
+        if (!p.cls.p) {   // classes not produced by the caller's own pass over the table
+            p.cap = tab.cap;
+            MDBG_TRY(p.cls.alloc(ctx, (nslots + 3) / 4));
+            hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 0, (uint32_t *)nullptr,
+                               p.cls.p, m_star);
+        }
+        unsigned blocks = grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
+        hipLaunchKernelGGL(rescue_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.off.p, n_reads, inst_slot, p.cls.p, tv, tab.cap,
+                           m_star, p.cnt.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, p.cnt.p, p.pos.p, n_reads));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &p.total, p.pos.p + n_reads, 8, hipMemcpyDeviceToHost));
+    return MDBG_OK;
+}
+
+static void launch_emit_rescued(mdbg_ctx *ctx, const SeqView &sv, uint32_t k, const uint32_t *inst_slot, const RescuePlan &p, const RowOut &ro,
+                                uint64_t row_base) {
+    unsigned blocks = grid_for((uint64_t)sv.n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
+    hipLaunchKernelGGL(emit_rescued_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sv, k, inst_slot, p.cls.p, p.cap, p.cnt.p, p.pos.p, ro, row_base);
+}
+
 static SeqView make_view(const mdbg_minimizers *m, const InstIndex &ix) {
     SeqView v;
     v.mins = m ? m->d_min.p : nullptr;
@@ -412,6 +526,7 @@ static SeqView make_view(const mdbg_minimizers *m, const InstIndex &ix) {
     v.inst_off = ix.off.p;
     v.n_reads = m ? m->n_reads : 0;
     v.n_inst = ix.total;
+    v.n_min = m ? m->n_min : 0;
     return v;
 }
 
@@ -445,7 +560,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     const uint64_t I = ix.total;
     SeqView sv = make_view(reads, ix), none{};
     DeviceTable tab;
-    DevBuf<uint32_t> inst_slot, ab, rflag, sflag;
+    DevBuf<uint32_t> inst_slot, sflag;
     MDBG_TRY(inst_slot.alloc(ctx, I));
     // distinct keys are usually a small fraction of the instances (coverage): start small so the table
     // stays cache-resident, grow and rebuild when a probe sequence gets long
@@ -456,36 +571,32 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
         }
         return MDBG_OK;
     }));
-    if (I) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)I;
     TableView tv = tab.view();
 
     // solid rows
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
-    DevBuf<uint64_t> spos, rpos;
+    DevBuf<uint64_t> spos;
     MDBG_TRY(sflag.alloc(ctx, nslots));
     MDBG_TRY(spos.alloc(ctx, nslots + 1));
+    // rescue (graph/CreateMdbg.cpp:317-319: only when min_abundance <= 1) wants the count class of every slot:
+    // produced by the same pass over the table that flags the solid slots
+    RescuePlan plan;
+    const bool do_rescue = min_abundance <= 1 && I;
+    if (do_rescue) { plan.cap = tab.cap; MDBG_TRY(plan.cls.alloc(ctx, (nslots + 3) / 4)); }
     {
         LaunchTimer timer(ctx, "kminmer_emit");
-        hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, min_abundance, 0, sflag.p);
+        hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, min_abundance, 0, sflag.p,
+                           plan.cls.p, rescue_m_star(), tv.occ);
     }
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
-    uint64_t n_solid = 0, n_resc = 0;
+    uint64_t n_solid = 0, n_resc = 0, n_keys = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    MDBG_TRY(tab.occupied(ctx, &n_keys));
+    update_key_hint(ctx, n_keys, I);
 
-    // rescue (graph/CreateMdbg.cpp:317-319: only when min_abundance <= 1)
-    const bool do_rescue = min_abundance <= 1;
-    if (do_rescue && I) {
-        MDBG_TRY(ab.alloc(ctx, I));
-        MDBG_TRY(rflag.alloc(ctx, I));
-        MDBG_TRY(rpos.alloc(ctx, I + 1));
-        {
-            LaunchTimer timer(ctx, "kminmer_rescue");
-            hipLaunchKernelGGL(inst_abundance_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, I, inst_slot.p, tv, min_abundance, ab.p);
-            unsigned blocks = grid_for((uint64_t)reads->n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
-            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.off.p, reads->n_reads, ab.p, rescue_m_star(), rflag.p);
-        }
-        MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, I));
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
+    if (do_rescue) {
+        MDBG_TRY(plan_rescue(ctx, tab, ix, reads->n_reads, inst_slot.p, plan));
+        n_resc = plan.total;
     }
 
     mdbg_table *t = new mdbg_table();
@@ -497,8 +608,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     {
         LaunchTimer timer(ctx, "kminmer_emit");
         hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, sflag.p, spos.p, sv, none, ro, (uint64_t)0);
-        if (n_resc)
-            hipLaunchKernelGGL(emit_rescued_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, sv, k, rflag.p, rpos.p, ro, n_solid);
+        if (n_resc) launch_emit_rescued(ctx, sv, k, inst_slot.p, plan, ro, n_solid);
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_count_first failed: %s", hipGetErrorString(e)); }
@@ -587,15 +697,15 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     if (unitigs) MDBG_TRY(build_inst_index(ctx, unitigs, k, ib));
     SeqView a = make_view(reads, ia), b = unitigs ? make_view(unitigs, ib) : SeqView{};
     const uint64_t I = ia.total + ib.total;
-    if (I >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 k-min-mer instances in one call");
+    if (I >= (1ull << 32) || a.n_min + b.n_min >= (1ull << 32))
+        return set_error(ctx, MDBG_ERANGE, "more than 2^32 minimizers / k-min-mer instances in one call");
     DeviceTable tab;
     MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
         LaunchTimer timer(ctx, "kminmer_insert");
         if (a.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, a.n_reads)), dim3(256), 0, ctx->stream, a, k, v, (uint64_t)0);
-        if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, b.n_reads)), dim3(256), 0, ctx->stream, b, k, v, a.n_inst);
+        if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, b.n_reads)), dim3(256), 0, ctx->stream, b, k, v, a.n_min);
         return MDBG_OK;
     }));
-    if (I) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)I;
     TableView tv = tab.view();
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
@@ -605,9 +715,15 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     {
         LaunchTimer timer(ctx, "kminmer_emit");
         hipLaunchKernelGGL(refine_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, a, b, k, pv);
-        hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 1, sflag.p);
+        hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 1, sflag.p,
+                           (uint8_t *)nullptr, 0u, tv.occ);
     }
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
+    {
+        uint64_t n_keys = 0;
+        MDBG_TRY(tab.occupied(ctx, &n_keys));
+        update_key_hint(ctx, n_keys, I);
+    }
     uint64_t n_rows = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     mdbg_table *t = new mdbg_table();
@@ -662,7 +778,6 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
         if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, v));
         return MDBG_OK;
     }));
-    if (bound) ctx->key_ratio_hint = (double)tab.cap / 2.0 / (double)bound;
     TableView tv = tab.view();
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
@@ -673,6 +788,7 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
     uint64_t n_rows = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
+    update_key_hint(ctx, n_rows, bound);   // every occupied slot is a row
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_rows;
@@ -855,8 +971,7 @@ __global__ __launch_bounds__(256) void owner_scatter_kernel(TableView t, uint64_
         uint64_t *o = rows + row * rw;
         o[0] = lo; o[1] = hi; o[2] = v;
         row_slot[row] = s < cap ? (uint32_t)s : (0x80000000u | (uint32_t)(s - cap));
-        uint32_t r = find_read(sv.inst_off, sv.n_reads, rep);
-        const uint32_t *m = sv.mins + sv.off[r] + (rep - sv.inst_off[r]);
+        const uint32_t *m = sv.mins + rep;
         bool reversed = true;
         for (uint32_t i = 0; i < k; i++) {
             uint32_t a = m[i], b = m[k - 1 - i];
@@ -945,7 +1060,6 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
         }
         return MDBG_OK;
     }));
-    if (I) ctx->key_ratio_hint = (double)sh->local.cap / 2.0 / (double)I;
     TableView tv = sh->local.view();
     const uint64_t nslots = sh->local.cap + TABLE_EXC_CAP;
     const unsigned nb = grid_for(nslots, SHARD_SPB);
@@ -964,6 +1078,7 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     for (uint32_t r = 0; r < n_ranks; r++) counts[r] = base[(uint64_t)(r + 1) * nb] - base[(uint64_t)r * nb];
     const uint64_t total = base[nh];
     if (total >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 distinct local keys");
+    update_key_hint(ctx, total, I);        // one row per distinct local key
     const uint32_t rw = row_words_for(k);
     MDBG_TRY(sh->rows.alloc(ctx, total * rw));
     MDBG_TRY(sh->row_slot.alloc(ctx, total));
@@ -1014,8 +1129,8 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
                            sh->row_slot.p, sh->n_rows, lv);
     // solid rows: keys this rank owns
     const uint64_t nslots = sh->owner.cap + TABLE_EXC_CAP;
-    DevBuf<uint32_t> sflag, ab, rflag;
-    DevBuf<uint64_t> spos, rpos;
+    DevBuf<uint32_t> sflag;
+    DevBuf<uint64_t> spos;
     MDBG_TRY(sflag.alloc(ctx, nslots));
     MDBG_TRY(spos.alloc(ctx, nslots + 1));
     hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, ov, sh->owner.cap, min_abundance, 0, sflag.p);
@@ -1024,18 +1139,10 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     // rescue over the local reads against the global counts now sitting in the local table
     SeqView sv = make_view(sh->reads, sh->ix);
+    RescuePlan plan;
     if (min_abundance <= 1 && I) {
-        MDBG_TRY(ab.alloc(ctx, I));
-        MDBG_TRY(rflag.alloc(ctx, I));
-        MDBG_TRY(rpos.alloc(ctx, I + 1));
-        {
-            LaunchTimer timer(ctx, "kminmer_rescue");
-            hipLaunchKernelGGL(inst_abundance_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, I, sh->inst_slot.p, lv, min_abundance, ab.p);
-            unsigned blocks = grid_for((uint64_t)sv.n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
-            hipLaunchKernelGGL(rescue_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sh->ix.off.p, sv.n_reads, ab.p, rescue_m_star(), rflag.p);
-        }
-        MDBG_TRY(exclusive_scan_u32(ctx, rflag.p, rpos.p, I));
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_resc, rpos.p + I, 8, hipMemcpyDeviceToHost));
+        MDBG_TRY(plan_rescue(ctx, sh->local, sh->ix, sv.n_reads, sh->inst_slot.p, plan));
+        n_resc = plan.total;
     }
     mdbg_table *t = new mdbg_table();
     t->k = k;
@@ -1047,8 +1154,7 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
         LaunchTimer timer(ctx, "kminmer_emit");
         hipLaunchKernelGGL(emit_owner_solid_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, ov, sh->owner.cap, sflag.p, spos.p,
                            sh->d_recv, rw, ro);
-        if (n_resc)
-            hipLaunchKernelGGL(emit_rescued_kernel, dim3(grid_for(I, 256)), dim3(256), 0, ctx->stream, sv, k, rflag.p, rpos.p, ro, n_solid);
+        if (n_resc) launch_emit_rescued(ctx, sv, k, sh->inst_slot.p, plan, ro, n_solid);
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "mdbg_shard_finish failed: %s", hipGetErrorString(e)); }

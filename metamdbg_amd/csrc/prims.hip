@@ -26,15 +26,37 @@ __device__ __forceinline__ uint64_t block_exclusive_sum(uint64_t v, uint64_t *to
     return base + inc - v;
 }
 
+// A block owns a tile of SCAN_TILE items and walks it in SCAN_SUB sub-tiles of 4 items per thread, so that every
+// load is one 16-byte (u32 input) access per lane and every store two 16-byte accesses per lane: fully coalesced.
+constexpr int SCAN_VEC = 4;
+constexpr int SCAN_SUB = SCAN_ITEMS / SCAN_VEC;
+
+template <typename Tin>
+__device__ __forceinline__ void load_vec(const Tin *in, uint64_t idx, uint64_t n, uint64_t v[SCAN_VEC]) {
+    if (idx + SCAN_VEC <= n && (reinterpret_cast<uintptr_t>(in + idx) & (sizeof(Tin) * SCAN_VEC - 1)) == 0) {
+        if (sizeof(Tin) == 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(in + idx);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            const ulonglong2 q0 = *reinterpret_cast<const ulonglong2 *>(in + idx), q1 = *reinterpret_cast<const ulonglong2 *>(in + idx + 2);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q1.x; v[3] = q1.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_VEC; i++) v[i] = idx + i < n ? (uint64_t)in[idx + i] : 0ull;
+    }
+}
+
 template <typename Tin>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const Tin *in, uint64_t n, uint64_t *block_sums) {
     __shared__ uint64_t lds[4];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     uint64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint64_t idx = base + (uint64_t)i * SCAN_THREADS + threadIdx.x;
-        if (idx < n) s += in[idx];
+    for (int t = 0; t < SCAN_SUB; t++) {
+        uint64_t v[SCAN_VEC];
+        load_vec(in, base + ((uint64_t)t * SCAN_THREADS + threadIdx.x) * SCAN_VEC, n, v);
+        s += v[0] + v[1] + v[2] + v[3];
     }
     uint64_t total;
     block_exclusive_sum(s, &total, lds);
@@ -60,24 +82,31 @@ template <typename Tin>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const Tin *in, uint64_t n, const uint64_t *block_offsets,
                                                                   uint64_t *out) {
     __shared__ uint64_t lds[4];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    Tin v[SCAN_ITEMS];
-    uint64_t s = 0;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    uint64_t carry = block_offsets[blockIdx.x];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint64_t idx = base + i;
-        v[i] = idx < n ? in[idx] : (Tin)0;
-        s += v[i];
-    }
-    uint64_t total;
-    uint64_t ex = block_exclusive_sum(s, &total, lds) + block_offsets[blockIdx.x];
+    for (int t = 0; t < SCAN_SUB; t++) {
+        const uint64_t idx = base + ((uint64_t)t * SCAN_THREADS + threadIdx.x) * SCAN_VEC;
+        uint64_t v[SCAN_VEC];
+        load_vec(in, idx, n, v);
+        uint64_t total;
+        uint64_t ex = block_exclusive_sum(v[0] + v[1] + v[2] + v[3], &total, lds) + carry;
+        if (idx + SCAN_VEC <= n) {                       // out is 8-byte aligned and idx a multiple of 4: 32-byte aligned stores
+            ulonglong2 o0, o1;
+            o0.x = ex; o0.y = ex + v[0]; o1.x = ex + v[0] + v[1]; o1.y = ex + v[0] + v[1] + v[2];
+            if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+                *reinterpret_cast<ulonglong2 *>(out + idx) = o0;
+                *reinterpret_cast<ulonglong2 *>(out + idx + 2) = o1;
+            } else { out[idx] = o0.x; out[idx + 1] = o0.y; out[idx + 2] = o1.x; out[idx + 3] = o1.y; }
+        } else {
+            uint64_t e = ex;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint64_t idx = base + i;
-        if (idx < n) out[idx] = ex;
-        ex += v[i];
+            for (int i = 0; i < SCAN_VEC; i++) { if (idx + i < n) out[idx + i] = e; e += v[i]; }
+        }
+        carry += total;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = ex;
+    // the total: written by the block that owns item n-1, once its last sub-tile is done
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = carry;
 }
 
 template <typename Tin>

@@ -17,6 +17,7 @@ namespace mdbg {
 
 constexpr uint32_t TABLE_EXC_CAP = 64;
 constexpr uint32_t SLOT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t TABLE_OCC_WAYS = 256;    // same-address atomics serialise at ~0.2 us each: spread the block sums
 
 // One slot = 32 bytes, half a 64-byte sector: key, value and representative arrive with ONE memory
 // transaction per probe (the SoA layout of round 1 touched four sectors per insert).
@@ -39,6 +40,7 @@ struct TableView {
     uint32_t *exc_n;          // entries used
     uint32_t *exc_lock;
     uint32_t *overflow;       // set when the table or the side list is full
+    uint32_t *occ;            // TABLE_OCC_WAYS partial counts of occupied slots, filled by a pass that asks for them
 };
 
 #ifdef __HIPCC__
@@ -91,7 +93,8 @@ __device__ inline uint32_t table_exc_upsert(const TableView &t, uint64_t lo, uin
 
 // Find or create the slot of (lo,hi).  Returns the slot index (bit 31 set = side list entry),
 // or SLOT_NONE when create == false and the key is absent / the table is full.
-__device__ __forceinline__ uint32_t table_find_or_insert(const TableView &t, uint64_t lo, uint64_t hi, bool create) {
+// *created (optional) is set when THIS call published the key: exactly one caller per key sees it.
+__device__ __forceinline__ uint32_t table_find_or_insert(const TableView &t, uint64_t lo, uint64_t hi, bool create, bool *created = nullptr) {
     uint64_t s = table_home(lo, hi, t.mask);
     const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
     for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
@@ -110,7 +113,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const TableView &t, uin
                 return SLOT_NONE;
             }
             h = atomicCAS(&t.slots[s].hi, 0ull, (unsigned long long)hi);
-            if (h == 0ull) h = hi;
+            if (h == 0ull) { h = hi; if (created) *created = true; }
         }
         if (h == hi) return (uint32_t)s;
     }
@@ -148,7 +151,7 @@ struct DeviceTable {
     uint64_t cap = 0;
     DevBuf<TableSlot> slots;
     DevBuf<unsigned long long> exc_lo, exc_hi;
-    DevBuf<uint32_t> exc_val, exc_rep, ctl;  // ctl: [0]=exc_n [1]=exc_lock [2]=overflow
+    DevBuf<uint32_t> exc_val, exc_rep, ctl;  // ctl: [0]=exc_n [1]=exc_lock [2]=overflow [4..4+TABLE_OCC_WAYS)=occupied counts
 
     int init(mdbg_ctx *ctx, uint64_t min_slots) {
         cap = 1024;
@@ -159,20 +162,20 @@ struct DeviceTable {
         MDBG_TRY(exc_hi.alloc(ctx, TABLE_EXC_CAP));
         MDBG_TRY(exc_val.alloc(ctx, TABLE_EXC_CAP));
         MDBG_TRY(exc_rep.alloc(ctx, TABLE_EXC_CAP));
-        MDBG_TRY(ctl.alloc(ctx, 4));
+        MDBG_TRY(ctl.alloc(ctx, 4 + TABLE_OCC_WAYS));
         return clear(ctx);
     }
     int clear(mdbg_ctx *ctx) {
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(slots.p, 0, cap * sizeof(TableSlot), ctx->stream));
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(exc_val.p, 0, TABLE_EXC_CAP * 4, ctx->stream));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(ctl.p, 0, 16, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(ctl.p, 0, (4 + TABLE_OCC_WAYS) * 4, ctx->stream));
         return MDBG_OK;
     }
     TableView view() const {
         TableView v;
         v.slots = slots.p; v.mask = cap - 1;
         v.exc_lo = exc_lo.p; v.exc_hi = exc_hi.p; v.exc_val = exc_val.p; v.exc_rep = exc_rep.p;
-        v.exc_n = ctl.p; v.exc_lock = ctl.p + 1; v.overflow = ctl.p + 2;
+        v.exc_n = ctl.p; v.exc_lock = ctl.p + 1; v.overflow = ctl.p + 2; v.occ = ctl.p + 4;
         return v;
     }
     // 0 = fine, 1 = too full (caller grows and rebuilds), negative = error
@@ -180,6 +183,15 @@ struct DeviceTable {
         uint32_t c[4];
         MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, c, ctl.p, 16, hipMemcpyDeviceToHost));
         return c[2] ? 1 : 0;
+    }
+    // distinct keys in the table, after a pass that filled view().occ (slot_flag_kernel)
+    int occupied(mdbg_ctx *ctx, uint64_t *n) {
+        uint32_t c[TABLE_OCC_WAYS];
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, c, ctl.p + 4, sizeof(c), hipMemcpyDeviceToHost));
+        uint64_t s = 0;
+        for (uint32_t i = 0; i < TABLE_OCC_WAYS; i++) s += c[i];
+        *n = s;
+        return MDBG_OK;
     }
     int check_overflow(mdbg_ctx *ctx) {
         int o = overflowed(ctx);
