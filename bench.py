@@ -4,8 +4,9 @@
 A step = one pass of the hot path over one batch of synthetic HiFi reads already resident in HBM
 (2-bit packed): reads -> minimizers (HPC, l=15, density 0.005) -> palindrome purge -> k-min-mer
 table at k=4 (count + rescue).  N=1 workload = BASELINE.json configs[1]: 1 M x 10 kb reads.
-N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); the
-per-rank count tables are merged by key with an all-to-all + all-gather over RCCL.
+N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); only the
+k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
+all-to-alls over RCCL (metamdbg_amd/distributed.py, include/mdbg_hip.h mdbg_shard_*).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library's
 stream) and `cpu_baseline` (the reference's own code, oracle/_ref/refdrv, timed on this box's cores
@@ -202,6 +203,10 @@ def main() -> None:
     # algorithmic bytes of one scan launch: 0.25 B per base read + 10 B per emitted minimizer
     alg_bytes = 0.25 * n_bases + 10.0 * n_min
     achieved = alg_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+    # compute floor of the reference's algorithm on this part: one Murmur3 per homopolymer-compressed position
+    hpc_positions = int(0.75 * n_bases)            # HPC keeps 3/4 of uniform random bases
+    clock_hz = 2.4e9
+    hash_floor_ms = hpc_positions / 64 * 186 / (info["n_cu"] * 4) / clock_hz * 1e3
 
     if rank == 0:
         base = cpu_baseline(ctx, reads, min(args.cpu_sample, args.reads)) if world == 1 else None
@@ -220,8 +225,12 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
-                         "note": "integer-hash kernel: 3 x 64-bit Murmur3 multiplies chains per position put the ceiling at the "
-                                 "VALU integer-multiply rate, far below HBM (DESIGN.md)"},
+                         "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies, half-rate VALU) "
+                                 "puts the ceiling at the VALU, far below HBM (DESIGN.md 4.1)",
+                         # the hash alone, measured in isolation at full occupancy (tools/ubench/hash_rates.hip,
+                         # profiles/r01_hash_rates_gfx950.txt): 186 cycles per 64 hashes per SIMD
+                         "valu_floor": {"hash_cycles_per_64": 186, "hpc_positions_per_launch": hpc_positions,
+                                        "floor_ms": hash_floor_ms, "frac": hash_floor_ms / (scan_avg_s * 1e3) if scan_avg_s > 0 else None}},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()},
             "cpu_baseline": base,
         }

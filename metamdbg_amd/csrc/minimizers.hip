@@ -73,15 +73,16 @@ __global__ __launch_bounds__(64) void purge_fix_kernel(const uint64_t *off, cons
     new_count[r] = n;
 }
 
+// 16 lanes per read: a chain of dependent loads per read, so reads in flight are what it runs on
 __global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *src_off, const uint64_t *dst_off, uint32_t n_reads,
                                                             const uint32_t *src, uint32_t *dst) {
-    const unsigned lane = threadIdx.x & 63u;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+    const unsigned lane = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r = group; r < n_reads; r += ngroups) {
         uint64_t s = src_off[r], d = dst_off[r];
         uint32_t n = (uint32_t)(dst_off[r + 1] - d);
-        for (uint32_t i = lane; i < n; i += 64) dst[d + i] = src[s + i];
+        for (uint32_t i = lane; i < n; i += 16) dst[d + i] = src[s + i];
     }
 }
 
@@ -290,12 +291,19 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
         if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
         e = memcpy_sync(ctx, &m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
-        if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
-        unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 16u);
-        LaunchTimer timer(ctx, "purge_palindromes");
-        hipLaunchKernelGGL(gather_prefix_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, m->d_off.p, n, work.p, m->d_min.p);
-        e = hipStreamSynchronize(ctx->stream);   // `work` goes back to the pool on return
-        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
+        if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg] purge: %u suspect reads of %u, %llu minimizers dropped\n", n_suspect, n,
+                                          (unsigned long long)(in->n_min - m->n_min));
+        if (m->n_min == in->n_min) {
+            // suspects, but nothing was palindromic: the working copy is the output
+            m->d_min = std::move(work);
+        } else {
+            if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
+            unsigned blocks = grid_for((uint64_t)n * 16, 256, (unsigned)ctx->n_cu * 32u);
+            LaunchTimer timer(ctx, "purge_palindromes");
+            hipLaunchKernelGGL(gather_prefix_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, m->d_off.p, n, work.p, m->d_min.p);
+            e = hipStreamSynchronize(ctx->stream);   // `work` goes back to the pool on return
+            if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
+        }
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));

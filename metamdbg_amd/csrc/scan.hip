@@ -661,22 +661,23 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
 }
 
 // ---- padded -> dense CSR (+ per-minimizer minimum quality) -------------------------------------
-template <bool HAS_QUAL>
+// G lanes per read: 16 when reads hold a few dozen minimizers (4 reads in flight per wave: the kernel is a chain of
+// dependent loads per read, so reads in flight are what it runs on), 64 for long reads / high densities.
+template <bool HAS_QUAL, int G>
 __global__ __launch_bounds__(256) void compact_minimizers_kernel(
     const uint64_t *cap_off, const uint64_t *off, uint32_t n_reads,
     const uint32_t *pmin, const uint32_t *ppos, const uint8_t *pdir, const uint32_t *pos_s, const uint32_t *pos_e,
     const uint8_t *qual, const uint64_t *qual_off,
     uint32_t *omin, uint32_t *opos, uint8_t *odir, uint8_t *oqual) {
-    // one wave per read (reads hold a few dozen to a few thousand minimizers)
-    const unsigned lane = threadIdx.x & 63u;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const unsigned lane = threadIdx.x & (unsigned)(G - 1);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / G;
     for (uint64_t r = wave; r < n_reads; r += nwaves) {
         uint64_t src = cap_off[r], dst = off[r];
         uint32_t n = (uint32_t)(off[r + 1] - dst);
         uint32_t ncopy = (uint32_t)(cap_off[r + 1] - src);   // padded capacity (overflowed reads are re-run)
         if (ncopy > n) ncopy = n;
-        for (uint32_t i = lane; i < n; i += 64) {
+        for (uint32_t i = lane; i < n; i += G) {
             uint8_t mq = 1;   // no qualities: ReadSelection.hpp:1047-1051
             if (i < ncopy) {
                 omin[dst + i] = pmin[src + i];
@@ -944,16 +945,22 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         return fail(rc);
 
     if (n) {
-        unsigned blocks = (unsigned)ctx->n_cu * 8u;
+        const bool few = total / (n ? n : 1) < 96;   // minimizers per read
+        unsigned blocks = grid_for((uint64_t)n * (few ? 16 : 64), 256, (unsigned)ctx->n_cu * (few ? 32u : 8u));
         LaunchTimer timer(ctx, "scan_compact");
-        if (has_q)
-            hipLaunchKernelGGL(compact_minimizers_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, p_os.p, p_oe.p, reads->d_qual.p, reads->d_qual_off.p,
-                               m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
-        else
-            hipLaunchKernelGGL(compact_minimizers_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream,
-                               d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, nullptr, nullptr, nullptr, nullptr,
-                               m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+#define MDBG_COMPACT(Q, G, ...) hipLaunchKernelGGL((compact_minimizers_kernel<Q, G>), dim3(blocks), dim3(256), 0, ctx->stream, __VA_ARGS__)
+        if (has_q) {
+            if (few) MDBG_COMPACT(true, 16, d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, p_os.p, p_oe.p, reads->d_qual.p, reads->d_qual_off.p,
+                                  m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+            else MDBG_COMPACT(true, 64, d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, p_os.p, p_oe.p, reads->d_qual.p, reads->d_qual_off.p,
+                              m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+        } else {
+            if (few) MDBG_COMPACT(false, 16, d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, nullptr, nullptr, nullptr, nullptr,
+                                  m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+            else MDBG_COMPACT(false, 64, d_cap_off.p, m->d_off.p, n, p_min.p, p_pos.p, p_dir.p, nullptr, nullptr, nullptr, nullptr,
+                              m->d_min.p, m->d_pos.p, m->d_dir.p, m->d_mqual.p);
+        }
+#undef MDBG_COMPACT
     }
     if (n_over) {
         // reads that overflowed their padded slots are re-run straight into their dense slots
