@@ -169,7 +169,7 @@ def main() -> None:
             glob = D.reply_to_senders(reply, got, sent)
             torch.cuda.synchronize()
             mark("all_to_all_reply")
-            table = sh.finish(glob.data_ptr(), 0, rank)
+            table = sh.finish(glob.data_ptr(), 0)
             sh.free()
             mark("finish")
         n_min = mins.info()["n_minimizers"]

@@ -192,25 +192,26 @@ int  mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t byte
 /* ---- sharded first pass (one process per GPU; the caller moves the bytes, e.g. RCCL all-to-all over xGMI) ----
  * Reads shard across ranks; only the counts are global.  Keys are partitioned by owner rank (top bits of hash_hi
  * scaled to [0, n_ranks), n_ranks <= 64).  Per rank and step:
- *     mdbg_shard_begin   local counts -> rows [lo, hi, count, vector...] grouped by owner        (send: all-to-all)
- *     mdbg_shard_reduce  owner sums the rows it received; reply[i] = GLOBAL count of received row i (send back:
- *                        all-to-all with the transposed split sizes; replies arrive in the order the rows were sent)
- *     mdbg_shard_finish  global counts -> solid rows of the keys this rank owns + rescue of its own reads
+ *     mdbg_shard_begin   local counts -> rows [hash_lo, hash_hi, count] grouped by owner                (send: all-to-all)
+ *     mdbg_shard_reduce  owner sums the rows it received; reply[i] answers received row i                 (send back: all-to-all
+ *                        with the transposed split sizes; replies arrive in the order the rows were sent)
+ *     mdbg_shard_finish  global counts -> this rank's share of the solid rows + rescue of its own reads
+ * A reply is the GLOBAL count of the row's key (low 32 bits) plus bit 63 on exactly one of the rows of each key: the
+ * rank that sent that row lists the key in its table, with the vector from its own reads -- vectors never travel.
  * The union over ranks of the finished tables equals mdbg_kminmer_count_first on the union of the reads.
  * Nearest reference analogue: KminmerCounter's on-disk partitioning `vecHash % _nbPartitions`
- * (graph/CreateMdbg.hpp:3714-3724).  Rows are mdbg_row_words(k) u64 words each. */
+ * (graph/CreateMdbg.hpp:3714-3724).  Rows are mdbg_row_words(k) = 3 u64 words each. */
 typedef struct mdbg_shard mdbg_shard;
 uint32_t mdbg_row_words(uint32_t k);
 /* *d_rows: device rows of every distinct local key, owner 0 first; counts[r] = rows for rank r.  `reads` must stay
  * alive until mdbg_shard_free. */
 int  mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
                       mdbg_shard **shard, const uint64_t **d_rows, uint64_t *counts);
-/* d_recv: device rows received from all ranks (any order); it must stay alive until mdbg_shard_finish (the vectors
- * of the solid rows are read from it).  *d_reply: n_recv u64 global counts, aligned with d_recv. */
+/* d_recv: device rows received from all ranks (any order; free to reuse once the call returns).
+ * *d_reply: n_recv u64, aligned with d_recv, valid until mdbg_shard_free. */
 int  mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply);
-/* d_global_counts: n_sent u64, the replies for the rows of mdbg_shard_begin in the order they were sent. */
-int  mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_global_counts, uint32_t min_abundance,
-                       uint32_t rank, mdbg_table **out);
+/* d_replies: n_sent u64, the replies for the rows of mdbg_shard_begin in the order they were sent. */
+int  mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out);
 void mdbg_shard_free(mdbg_shard *shard);
 
 #ifdef __cplusplus

@@ -77,7 +77,7 @@ SIGNATURES = {
     "mdbg_row_words": (C.c_uint32, [C.c_uint32]),
     "mdbg_shard_begin": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(_P), _u64p]),
     "mdbg_shard_reduce": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(_P)]),
-    "mdbg_shard_finish": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_shard_finish": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_shard_free": (None, [_P]),
 }
 
@@ -274,14 +274,14 @@ class Shard:
         return int(self.counts.sum())
 
     def reduce(self, d_recv: int, n_recv: int) -> int:
-        """Device pointer of n_recv u64 global counts aligned with the received rows."""
+        """Device pointer of n_recv u64 replies (global count | bit 63 = lister) aligned with the received rows."""
         d_reply = C.c_void_p()
         self.ctx.check(lib().mdbg_shard_reduce(self.ctx.h, self.h, C.c_void_p(d_recv), n_recv, C.byref(d_reply)))
         return d_reply.value or 0
 
-    def finish(self, d_global_counts: int, min_abundance: int, rank: int) -> "Table":
+    def finish(self, d_replies: int, min_abundance: int) -> "Table":
         h = C.c_void_p()
-        self.ctx.check(lib().mdbg_shard_finish(self.ctx.h, self.h, C.c_void_p(d_global_counts), min_abundance, rank, C.byref(h)))
+        self.ctx.check(lib().mdbg_shard_finish(self.ctx.h, self.h, C.c_void_p(d_replies), min_abundance, C.byref(h)))
         return Table(self.ctx, h)
 
     def free(self):

@@ -915,23 +915,26 @@ extern "C" void mdbg_table_free(mdbg_table *t) { delete t; }
 // =====================================================================================================
 namespace mdbg {
 
-__host__ __device__ __forceinline__ uint32_t row_words_for(uint32_t k) { return 3u + (k + 1u) / 2u; }
+constexpr uint32_t SHARD_ROW_WORDS = 3;                 // [hash_lo, hash_hi, count]
+constexpr uint64_t SHARD_EMIT_BIT = 1ull << 63;         // in a reply: "you list this key in your table"
 
 __device__ __forceinline__ uint32_t owner_of(uint64_t hi, uint32_t n_ranks) {
     return (uint32_t)(((hi >> 32) * (uint64_t)n_ranks) >> 32);
 }
 
-__device__ __forceinline__ bool slot_read(const TableView &t, uint64_t cap, uint64_t s, uint64_t &lo, uint64_t &hi, uint32_t &v, uint32_t &rep) {
+__device__ __forceinline__ bool slot_read(const TableView &t, uint64_t cap, uint64_t s, uint64_t &lo, uint64_t &hi, uint32_t &v) {
     if (s < cap) {
-        const TableSlot &sl = t.slots[s];
-        lo = sl.lo;
+        const uint4 *q = reinterpret_cast<const uint4 *>(t.slots + s);
+        const uint4 key = q[0];
+        lo = (uint64_t)key.x | ((uint64_t)key.y << 32);
         if (lo == 0ull) return false;
-        hi = sl.hi; v = sl.val; rep = sl.rep;
+        hi = (uint64_t)key.z | ((uint64_t)key.w << 32);
+        v = q[1].x;
         return true;
     }
     uint32_t i = (uint32_t)(s - cap);
     if (i >= *t.exc_n) return false;
-    lo = t.exc_lo[i]; hi = t.exc_hi[i]; v = t.exc_val[i]; rep = t.exc_rep[i];
+    lo = t.exc_lo[i]; hi = t.exc_hi[i]; v = t.exc_val[i];
     return true;
 }
 
@@ -947,82 +950,61 @@ __global__ __launch_bounds__(256) void owner_hist_kernel(TableView t, uint64_t c
     __syncthreads();
     const uint64_t s0 = (uint64_t)blockIdx.x * SHARD_SPB;
     for (uint32_t j = threadIdx.x; j < SHARD_SPB; j += 256) {
-        uint64_t lo, hi; uint32_t v, rep;
-        if (s0 + j < cap + TABLE_EXC_CAP && slot_read(t, cap, s0 + j, lo, hi, v, rep)) atomicAdd(&h[owner_of(hi, n_ranks)], 1u);
+        uint64_t lo, hi; uint32_t v;
+        if (s0 + j < cap + TABLE_EXC_CAP && slot_read(t, cap, s0 + j, lo, hi, v)) atomicAdd(&h[owner_of(hi, n_ranks)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < n_ranks) block_hist[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
-// write every occupied slot as a row [lo, hi, count, vector] into its owner's range and remember its slot
+// write every occupied slot as a row [lo, hi, count] into its owner's range and remember its slot
 __global__ __launch_bounds__(256) void owner_scatter_kernel(TableView t, uint64_t cap, uint32_t n_ranks, const uint64_t *block_base,
-                                                            SeqView sv, uint32_t k, uint64_t *rows, uint32_t *row_slot) {
+                                                            uint64_t *rows, uint32_t *row_slot) {
     __shared__ uint32_t h[64];
     if (threadIdx.x < 64) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t s0 = (uint64_t)blockIdx.x * SHARD_SPB;
-    const uint32_t rw = row_words_for(k);
     for (uint32_t j = threadIdx.x; j < SHARD_SPB; j += 256) {
         const uint64_t s = s0 + j;
-        uint64_t lo, hi; uint32_t v, rep;
-        if (!(s < cap + TABLE_EXC_CAP && slot_read(t, cap, s, lo, hi, v, rep))) continue;
+        uint64_t lo, hi; uint32_t v;
+        if (!(s < cap + TABLE_EXC_CAP && slot_read(t, cap, s, lo, hi, v))) continue;
         const uint32_t own = owner_of(hi, n_ranks);
         const uint64_t row = block_base[(uint64_t)own * gridDim.x + blockIdx.x] + atomicAdd(&h[own], 1u);
-        uint64_t *o = rows + row * rw;
+        uint64_t *o = rows + row * SHARD_ROW_WORDS;
         o[0] = lo; o[1] = hi; o[2] = v;
         row_slot[row] = s < cap ? (uint32_t)s : (0x80000000u | (uint32_t)(s - cap));
-        const uint32_t *m = sv.mins + rep;
-        bool reversed = true;
-        for (uint32_t i = 0; i < k; i++) {
-            uint32_t a = m[i], b = m[k - 1 - i];
-            if (a == b) continue;
-            reversed = !(a < b);
-            break;
-        }
-        for (uint32_t w = 0; w < (k + 1) / 2; w++) {
-            uint32_t i0 = 2 * w, i1 = 2 * w + 1;
-            uint64_t a = reversed ? m[k - 1 - i0] : m[i0];
-            uint64_t b2 = i1 < k ? (reversed ? m[k - 1 - i1] : m[i1]) : 0u;
-            o[3 + w] = a | (b2 << 32);
-        }
     }
 }
 
-// owner: sum the received rows by key; rep = index of one received row of the key (its vector)
-__global__ __launch_bounds__(256) void rows_add_kernel(const uint64_t *rows, uint64_t n, uint32_t rw, TableView t) {
+// owner: sum the received rows by key; rep = index of the received row that created the key -- its sender is the
+// one rank that will list the key
+__global__ __launch_bounds__(256) void rows_add_kernel(const uint64_t *rows, uint64_t n, TableView t) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t *r = rows + i * rw;
+    const uint64_t *r = rows + i * SHARD_ROW_WORDS;
     table_upsert_count(t, r[0], r[1], (uint32_t)r[2], (uint32_t)i);
 }
 
-__global__ __launch_bounds__(256) void rows_reply_kernel(const uint64_t *rows, uint64_t n, uint32_t rw, TableView t, uint64_t *reply) {
+__global__ __launch_bounds__(256) void rows_reply_kernel(const uint64_t *rows, uint64_t n, TableView t, uint64_t *reply) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t *r = rows + i * rw;
-    uint32_t v = 0;
-    table_lookup(t, r[0], r[1], v);
-    reply[i] = v;
+    const uint64_t *r = rows + i * SHARD_ROW_WORDS;
+    const uint32_t slot = table_lookup_slot(t, r[0], r[1]);
+    uint64_t out = 0;
+    if (slot != SLOT_NONE) out = (uint64_t)table_slot_val(t, slot) | (table_slot_rep(t, slot) == (uint32_t)i ? SHARD_EMIT_BIT : 0ull);
+    reply[i] = out;
 }
 
-// global counts back into the local table (the slot of every sent row was remembered)
-__global__ __launch_bounds__(256) void apply_global_counts_kernel(const uint64_t *counts, const uint32_t *row_slot, uint64_t n, TableView t) {
+// global counts back into the local table (the slot of every sent row was remembered); the rows this rank
+// was told to list and that are solid get their flag
+__global__ __launch_bounds__(256) void apply_global_counts_kernel(const uint64_t *reply, const uint32_t *row_slot, uint64_t n, TableView t,
+                                                                  uint64_t cap, uint32_t min_abundance, uint32_t *flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t s = row_slot[i], v = (uint32_t)counts[i];
-    if (s & 0x80000000u) t.exc_val[s & 0x7FFFFFFFu] = v; else t.slots[s].val = v;
-}
-
-__global__ __launch_bounds__(256) void emit_owner_solid_kernel(TableView t, uint64_t cap, const uint32_t *flag, const uint64_t *pos,
-                                                               const uint64_t *src_rows, uint32_t rw, RowOut o) {
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= cap + TABLE_EXC_CAP || !flag[s]) return;
-    uint64_t lo, hi; uint32_t v, rep;
-    slot_read(t, cap, s, lo, hi, v, rep);
-    const uint64_t row = pos[s];
-    o.lo[row] = lo; o.hi[row] = hi; o.ab[row] = v;
-    const uint64_t *src = src_rows + (uint64_t)rep * rw + 3;
-    for (uint32_t i = 0; i < o.k; i++) o.vec[row * o.k + i] = (uint32_t)(src[i / 2] >> (32 * (i & 1)));
+    const uint32_t s = row_slot[i], v = (uint32_t)reply[i];
+    const bool emit = (reply[i] & SHARD_EMIT_BIT) != 0ull && v > 1u && !(v < min_abundance);
+    if (s & 0x80000000u) { t.exc_val[s & 0x7FFFFFFFu] = v; flag[cap + (s & 0x7FFFFFFFu)] = emit ? 1u : 0u; }
+    else { t.slots[s].val = v; flag[s] = emit ? 1u : 0u; }
 }
 
 }  // namespace mdbg
@@ -1035,11 +1017,10 @@ struct mdbg_shard {
     mdbg::DevBuf<uint32_t> inst_slot, row_slot;
     mdbg::DevBuf<uint64_t> rows, reply;
     uint64_t n_rows = 0;
-    const uint64_t *d_recv = nullptr;
-    uint64_t n_recv = 0;
+    bool reduced = false;
 };
 
-extern "C" uint32_t mdbg_row_words(uint32_t k) { return mdbg::row_words_for(k); }
+extern "C" uint32_t mdbg_row_words(uint32_t) { return mdbg::SHARD_ROW_WORDS; }
 
 extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
                                 mdbg_shard **out, const uint64_t **d_rows, uint64_t *counts) {
@@ -1079,14 +1060,13 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     const uint64_t total = base[nh];
     if (total >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 distinct local keys");
     update_key_hint(ctx, total, I);        // one row per distinct local key
-    const uint32_t rw = row_words_for(k);
-    MDBG_TRY(sh->rows.alloc(ctx, total * rw));
+    MDBG_TRY(sh->rows.alloc(ctx, total * SHARD_ROW_WORDS));
     MDBG_TRY(sh->row_slot.alloc(ctx, total));
     sh->n_rows = total;
     {
         LaunchTimer timer(ctx, "shard_rows");
         hipLaunchKernelGGL(owner_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, tv, sh->local.cap, n_ranks, block_base.p,
-                           sv, k, sh->rows.p, sh->row_slot.p);
+                           sh->rows.p, sh->row_slot.p);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *d_rows = sh->rows.p;
@@ -1098,47 +1078,43 @@ extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     if (!ctx || !sh || !d_reply || (n_recv && !d_recv)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_reduce: bad argument");
     if (n_recv >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 received rows");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t rw = row_words_for(sh->k);
     MDBG_TRY(sh->owner.init(ctx, n_recv * 2 + 1024));
     TableView tv = sh->owner.view();
     MDBG_TRY(sh->reply.alloc(ctx, n_recv));
     if (n_recv) {
         LaunchTimer timer(ctx, "shard_reduce");
-        hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, rw, tv);
-        hipLaunchKernelGGL(rows_reply_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, rw, tv, sh->reply.p);
+        hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, tv);
+        hipLaunchKernelGGL(rows_reply_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, tv, sh->reply.p);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     MDBG_TRY(sh->owner.check_overflow(ctx));
-    sh->d_recv = d_recv;
-    sh->n_recv = n_recv;
+    sh->owner = DeviceTable();      // only the replies are needed from here on
+    sh->reduced = true;
     *d_reply = sh->reply.p;
     return MDBG_OK;
 }
 
-extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_global_counts, uint32_t min_abundance,
-                                 uint32_t rank, mdbg_table **out) {
-    if (!ctx || !sh || !out || rank >= sh->n_ranks || (sh->n_rows && !d_global_counts))
-        return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: bad argument");
-    if (!sh->owner.cap) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: mdbg_shard_reduce has not run");
+extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out) {
+    if (!ctx || !sh || !out || (sh->n_rows && !d_replies)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: bad argument");
+    if (!sh->reduced) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: mdbg_shard_reduce has not run");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t k = sh->k, rw = row_words_for(k);
+    const uint32_t k = sh->k;
     const uint64_t I = sh->ix.total;
-    TableView lv = sh->local.view(), ov = sh->owner.view();
-    if (sh->n_rows)
-        hipLaunchKernelGGL(apply_global_counts_kernel, dim3(grid_for(sh->n_rows, 256)), dim3(256), 0, ctx->stream, d_global_counts,
-                           sh->row_slot.p, sh->n_rows, lv);
-    // solid rows: keys this rank owns
-    const uint64_t nslots = sh->owner.cap + TABLE_EXC_CAP;
+    TableView lv = sh->local.view();
+    const uint64_t nslots = sh->local.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
     DevBuf<uint64_t> spos;
     MDBG_TRY(sflag.alloc(ctx, nslots));
     MDBG_TRY(spos.alloc(ctx, nslots + 1));
-    hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, ov, sh->owner.cap, min_abundance, 0, sflag.p);
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(sflag.p, 0, nslots * 4, ctx->stream));
+    if (sh->n_rows)
+        hipLaunchKernelGGL(apply_global_counts_kernel, dim3(grid_for(sh->n_rows, 256)), dim3(256), 0, ctx->stream, d_replies, sh->row_slot.p,
+                           sh->n_rows, lv, sh->local.cap, min_abundance, sflag.p);
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
     uint64_t n_solid = 0, n_resc = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     // rescue over the local reads against the global counts now sitting in the local table
-    SeqView sv = make_view(sh->reads, sh->ix);
+    SeqView sv = make_view(sh->reads, sh->ix), none{};
     RescuePlan plan;
     if (min_abundance <= 1 && I) {
         MDBG_TRY(plan_rescue(ctx, sh->local, sh->ix, sv.n_reads, sh->inst_slot.p, plan));
@@ -1152,8 +1128,7 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
     {
         LaunchTimer timer(ctx, "kminmer_emit");
-        hipLaunchKernelGGL(emit_owner_solid_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, ov, sh->owner.cap, sflag.p, spos.p,
-                           sh->d_recv, rw, ro);
+        hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, lv, sh->local.cap, sflag.p, spos.p, sv, none, ro, (uint64_t)0);
         if (n_resc) launch_emit_rescued(ctx, sv, k, sh->inst_slot.p, plan, ro, n_solid);
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);

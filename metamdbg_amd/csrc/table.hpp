@@ -140,8 +140,31 @@ __device__ __forceinline__ bool table_lookup(const TableView &t, uint64_t lo, ui
     return false;   // inserts never place a key beyond the probe limit
 }
 
+// Same, returning the slot (bit 31 set = side-list entry) or SLOT_NONE.
+__device__ __forceinline__ uint32_t table_lookup_slot(const TableView &t, uint64_t lo, uint64_t hi) {
+    if (lo == 0ull || hi == 0ull) {
+        uint32_t n = *t.exc_n;
+        for (uint32_t i = 0; i < n; i++)
+            if (t.exc_lo[i] == lo && t.exc_hi[i] == hi) return 0x80000000u | i;
+        return SLOT_NONE;
+    }
+    uint64_t s = table_home(lo, hi, t.mask);
+    const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
+    for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
+        const TableSlot &sl = t.slots[s];
+        unsigned long long cur = sl.lo;
+        if (cur == 0ull) return SLOT_NONE;
+        if (cur == lo && sl.hi == hi) return (uint32_t)s;
+    }
+    return SLOT_NONE;
+}
+
 __device__ __forceinline__ uint32_t table_slot_val(const TableView &t, uint32_t slot) {
     return (slot & 0x80000000u) ? t.exc_val[slot & 0x7FFFFFFFu] : t.slots[slot].val;
+}
+
+__device__ __forceinline__ uint32_t table_slot_rep(const TableView &t, uint32_t slot) {
+    return (slot & 0x80000000u) ? t.exc_rep[slot & 0x7FFFFFFFu] : t.slots[slot].rep;
 }
 
 #endif  // __HIPCC__

@@ -22,8 +22,8 @@ def owner_of(hi: np.ndarray, n_ranks: int) -> np.ndarray:
 
 
 def partial_rows(orc, mins, offs, k, n_ranks):
-    """(rows int64[n, 3 + ceil(k/2)] grouped by owner, counts per owner) of one shard."""
-    rw = 3 + (k + 1) // 2
+    """(rows int64[n, 3] = [hash_lo, hash_hi, count] grouped by owner, counts per owner) of one shard."""
+    rw = 3
     keys = {}
     for r in range(len(offs) - 1):
         m = mins[int(offs[r]): int(offs[r + 1])]
@@ -34,23 +34,26 @@ def partial_rows(orc, mins, offs, k, n_ranks):
     rows = np.zeros((len(keys), rw), dtype=np.uint64)
     for j, ((hi, lo), (c, vec)) in enumerate(keys.items()):
         rows[j, 0], rows[j, 1], rows[j, 2] = lo, hi, c
-        v = np.zeros(2 * ((k + 1) // 2), dtype=np.uint64)
-        v[:k] = vec
-        rows[j, 3:] = v[0::2] | (v[1::2] << np.uint64(32))
     own = owner_of(rows[:, 1], n_ranks) if len(rows) else np.zeros(0, np.int64)
     order = np.argsort(own, kind="stable")
     counts = [int((own == r).sum()) for r in range(n_ranks)]
     return rows[order].view(np.int64), counts
 
 
+EMIT_BIT = 1 << 63
+
+
 def owner_reply(rows: np.ndarray) -> np.ndarray:
-    """What mdbg_shard_reduce answers: for every received row the sum of the counts of its key."""
+    """What mdbg_shard_reduce answers: for every received row the sum of the counts of its key, with bit 63 set on
+    exactly one row per key (the sender of that row lists the key)."""
     u = rows.view(np.uint64)
-    tot = {}
-    for row in u:
+    tot, first = {}, {}
+    for i, row in enumerate(u):
         key = (int(row[1]), int(row[0]))
         tot[key] = tot.get(key, 0) + int(row[2])
-    return np.array([tot[(int(r[1]), int(r[0]))] for r in u], dtype=np.int64)
+        first.setdefault(key, i)
+    out = [tot[(int(r[1]), int(r[0]))] | (EMIT_BIT if first[(int(r[1]), int(r[0]))] == i else 0) for i, r in enumerate(u)]
+    return np.array(out, dtype=np.uint64).view(np.int64)
 
 
 def _worker(rank, world, port, k, q):
@@ -77,11 +80,13 @@ def _worker(rank, world, port, k, q):
     exp_rows, _ = partial_rows(orc, mins, offs, k, 1)
     exp = {(int(r[1]), int(r[0])): int(r[2]) for r in exp_rows.view(np.uint64)}
     sent = rows.view(np.uint64)
-    ok = len(glob) == len(sent) and all(exp[(int(r[1]), int(r[0]))] == int(g) for r, g in zip(sent, glob))
+    glob = glob.view(np.uint64)
+    ok = len(glob) == len(sent) and all(exp[(int(r[1]), int(r[0]))] == int(g) & 0xFFFFFFFF for r, g in zip(sent, glob))
+    n_listed = int(sum(1 for g in glob if int(g) & EMIT_BIT))
     # the owners' key sets partition the global key set
     owned = {(int(r[1]), int(r[0])) for r in mine_np.view(np.uint64)}
     ok = ok and owned == {key for key in exp if owner_of(np.array([key[0]], dtype=np.uint64), world)[0] == rank}
-    q.put((rank, bool(ok), len(owned)))
+    q.put((rank, bool(ok), len(owned), n_listed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,5 +105,6 @@ def test_exchange_reduce_reply_world2(k):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _ in res), res
+    assert all(r[1] for r in res), res
     assert res[0][2] > 0 and res[1][2] > 0
+    assert res[0][3] + res[1][3] == res[0][2] + res[1][2]        # every key is listed by exactly one rank

@@ -252,7 +252,7 @@ def test_sharded_first_pass_on_one_gpu(ctx, orc, n_ranks):
         glob = np.ascontiguousarray(np.concatenate(glob))
         assert len(glob) == sh[r].n_rows
         gbuf = to_device(glob)
-        t = sh[r].finish(gbuf.value, 0, r)
+        t = sh[r].finish(gbuf.value, 0)
         hip.hipFree(gbuf)
         rec, vec = t.to_host()
         recs.append(rec); vecs.append(vec); n_solid += t.info()["n_solid"]
