@@ -468,3 +468,100 @@ def test_edge_index_vs_reference_log(ctx, orc, name):
     keys = edges.keys_to_host()
     order = np.lexsort((keys[:, 0], keys[:, 1]))
     assert np.array_equal(keys[order, 0], olo) and np.array_equal(keys[order, 1], ohi) and ock == ck
+
+
+def test_full_size_properties(ctx, orc):
+    """BASELINE.json configs[1] at FULL size (1 M x 10 kb HiFi reads, the bench workload), checked through
+    properties that do not need the oracle to run over 10 Gbp:
+      * the oracle on a sample of the batch (first / last reads) equals the corresponding slice of the full scan;
+      * shard invariance: scanning the two halves separately gives the two halves of the full scan;
+      * purge is idempotent;
+      * linearity of the counts: the sharded first pass over the two halves (both exchanges emulated on this
+        device) yields, as a multiset, exactly the table of the single call over the whole batch;
+      * conservation: the abundances of the solid rows account for every instance of a solid k-min-mer."""
+    import ctypes as C
+    n, L, k = 1_000_000, 10_000, 4
+    spec = synth.hifi_spec(n, seed=42, read_len=L, coverage=50.0)
+    reads = ctx.reads_synthetic(spec)
+    full = ctx.scan(reads, K=15, density=0.005, hpc=True)
+    h = full.to_host()
+    assert int(h["offsets"][-1]) == len(h["minimizers"]) and (np.diff(h["offsets"].astype(np.int64)) >= 0).all()
+    # oracle on a sample
+    for first in (0, n - 300):
+        bases, offs = reads.export_ascii(first, 300)
+        for r in range(0, 300, 7):
+            seq = bases[int(offs[r]): int(offs[r + 1])].tobytes()
+            o = orc.read_selection(seq, None, K=15, density=0.005, hpc=True)
+            a, b = int(h["offsets"][first + r]), int(h["offsets"][first + r + 1])
+            assert h["minimizers"][a:b].tolist() == o["minimizers"].tolist()
+            assert h["pos"][a:b].tolist() == o["pos"].tolist() and h["dir"][a:b].tolist() == o["dir"].tolist()
+    reads.free()
+    # shard invariance of the scan (the halves are regenerated: same generator, other read range)
+    halves = []
+    cut = int(h["offsets"][n // 2])
+    for i, (f, lo, hi) in enumerate(((0, 0, cut), (n // 2, cut, len(h["minimizers"])))):
+        part = ctx.reads_synthetic(spec, first_read=f, n_reads=n // 2)
+        m = ctx.scan(part, K=15, density=0.005, hpc=True)
+        part.free()
+        hp = m.to_host(full=False)
+        assert np.array_equal(hp["minimizers"], h["minimizers"][lo:hi])
+        assert np.array_equal(hp["offsets"], h["offsets"][f: f + n // 2 + 1] - h["offsets"][f])
+        halves.append(m)
+    # purge: idempotent
+    corr = ctx.purge_palindromes(full, 4, 100)
+    corr2 = ctx.purge_palindromes(corr, 4, 100)
+    hc, hc2 = corr.to_host(full=False), corr2.to_host(full=False)
+    assert np.array_equal(hc["minimizers"], hc2["minimizers"]) and np.array_equal(hc["offsets"], hc2["offsets"])
+    corr2.free()
+    # single call over the whole batch
+    t = ctx.kminmer_count_first(corr, k, 0)
+    rec, vec = t.to_host()
+    info = t.info()
+    n_inst = int(np.maximum(np.diff(hc["offsets"].astype(np.int64)) - (k - 1), 0).sum())
+    solid = rec[: info["n_solid"]]
+    assert (solid["abundance"] > 1).all() and (rec[info["n_solid"]:]["abundance"] == 1).all()
+    assert int(solid["abundance"].sum()) <= n_inst
+    # sharded over the halves, exchanges emulated
+    hip = C.CDLL("libamdhip64.so.7")
+
+    def to_host(ptr, shape):
+        out = np.zeros(shape, dtype=np.uint64)
+        if out.nbytes:
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def to_device(a):
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), C.c_size_t(max(a.nbytes, 8))) == 0
+        if a.nbytes:
+            assert hip.hipMemcpy(buf, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+        return buf
+
+    shards = [ctx.purge_palindromes(m, 4, 100) for m in halves]
+    sh = [ctx.shard_begin(s, k, 2) for s in shards]
+    rw = sh[0].row_words
+    sent = [to_host(s.d_rows, (s.n_rows, rw)) for s in sh]
+    replies = []
+    for dst in range(2):
+        parts = []
+        for src in range(2):
+            o = int(sh[src].counts[:dst].sum())
+            parts.append(sent[src][o: o + int(sh[src].counts[dst])])
+        rows = np.ascontiguousarray(np.concatenate(parts))
+        buf = to_device(rows)
+        replies.append(to_host(sh[dst].reduce(buf.value, len(rows)), (len(rows),)))
+        hip.hipFree(buf)
+    recs, vecs, n_solid = [], [], 0
+    for r in range(2):
+        glob = np.ascontiguousarray(np.concatenate([
+            replies[dst][sum(int(sh[src].counts[dst]) for src in range(r)):][: int(sh[r].counts[dst])] for dst in range(2)]))
+        gbuf = to_device(glob)
+        ts = sh[r].finish(gbuf.value, 0)
+        hip.hipFree(gbuf)
+        rs, vs = ts.to_host()
+        recs.append(rs); vecs.append(vs); n_solid += ts.info()["n_solid"]
+        ts.free(); sh[r].free()
+    assert n_solid == info["n_solid"]
+    assert np.array_equal(formats.sorted_abundance_records(np.concatenate(recs)), formats.sorted_abundance_records(rec))
+    assert np.array_equal(formats.sorted_vector_records(np.concatenate(vecs).astype("<u4").tobytes(), k),
+                          formats.sorted_vector_records(vec.astype("<u4").tobytes(), k))
