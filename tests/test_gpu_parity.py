@@ -565,3 +565,54 @@ def test_full_size_properties(ctx, orc):
     assert np.array_equal(formats.sorted_abundance_records(np.concatenate(recs)), formats.sorted_abundance_records(rec))
     assert np.array_equal(formats.sorted_vector_records(np.concatenate(vecs).astype("<u4").tobytes(), k),
                           formats.sorted_vector_records(vec.astype("<u4").tobytes(), k))
+
+
+# ---- empty, ragged and extreme inputs ---------------------------------------------------------------
+def test_empty_and_degenerate_batches(ctx, orc):
+    """No reads, empty reads, reads shorter than l, reads of exactly l / l+1 / l+2 bases (0 / 0 / 1 eligible l-mers
+    with the end trim), one-base homopolymers -- alone and mixed with normal reads."""
+    rng = np.random.default_rng(77)
+    rnd = lambda n: bytes(synth.CODE2ASCII[rng.integers(0, 4, n)])
+    # empty batch through the whole chain
+    reads = ctx.reads_from_ascii([])
+    m = ctx.scan(reads, K=15, density=0.005, hpc=True)
+    assert m.info() == dict(n_reads=0, n_minimizers=0)
+    c = ctx.purge_palindromes(m, 4, 100)
+    t = ctx.kminmer_count_first(c, 4, 0)
+    assert t.info()["n_records"] == 0
+    low = ctx.apply_density_threshold(m, 0.001)
+    assert low.info()["n_minimizers"] == 0
+    sh = ctx.shard_begin(c, 4, 3)
+    assert sh.n_rows == 0
+    sh.reduce(0, 0)
+    assert sh.finish(0, 0).info()["n_records"] == 0
+    sh.free()
+    # degenerate reads
+    seqs = [b"", b"A", b"ACGT", rnd(14), rnd(15), rnd(16), rnd(17), b"A" * 5000, b"AC" * 3000, rnd(3000), b"", rnd(40), b"T" * 15, rnd(2048),
+            rnd(2047), rnd(2049), rnd(2048 + 15), rnd(4096), b"G"]
+    for hpc in (True, False):
+        for K, dens in ((15, 0.3), (16, 0.9), (11, 0.05)):
+            _check_scan_against_oracle(ctx, orc, seqs, None, K, dens, hpc)
+    # reads with fewer than k minimizers contribute no instance; k larger than any read
+    mins = ctx.scan(ctx.reads_from_ascii(seqs), K=15, density=0.3, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    hc = corr.to_host(full=False)
+    for k in (2, 4, 50, 5000):
+        t = ctx.kminmer_count_first(corr, k, 0)
+        exp = orc.kminmer_count_first(hc["minimizers"], hc["offsets"], k, 0)
+        rec, vec = t.to_host()
+        assert t.info()["n_solid"] == exp["n_solid"] and len(rec) == exp["n"]
+        if len(rec):
+            _assert_tables_equal(rec, vec, exp, k)
+
+
+def test_extreme_reads(ctx, orc):
+    """One 3 Mbp read next to short ones (1500 tiles in one wave), a density that overflows every padded output slot
+    (the re-run path), and the largest minimizer size (l = 16: full 32-bit minimizers)."""
+    rng = np.random.default_rng(78)
+    rnd = lambda n: bytes(synth.CODE2ASCII[rng.integers(0, 4, n)])
+    seqs = [rnd(200), rnd(3_000_000), rnd(50), rnd(100_000)]
+    for hpc in (True, False):
+        _check_scan_against_oracle(ctx, orc, seqs, None, 16, 0.005, hpc)
+    _check_scan_against_oracle(ctx, orc, [rnd(20000), rnd(64), rnd(9000)], None, 15, 0.99, True)    # nearly every position selected
+    _check_scan_against_oracle(ctx, orc, [rnd(20000), rnd(64), rnd(9000)], None, 8, 1.0, False)     # density 1: threshold saturates
