@@ -23,37 +23,38 @@ __host__ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
     return k;
 }
 
-// 64 x 64 -> low 64 product by a constant, as three v_mad_u64_u32 (the adds ride along): on gfx950
-// this sequence issues ~5 % faster at 5 waves/SIMD than the mul_lo / mad / add3 mix the compiler
-// picks for a plain u64 multiply (tools/ubench/hash_rates.hip).
-__host__ __device__ __forceinline__ uint64_t mul64_const(uint64_t a, uint32_t clo, uint32_t chi) {
-    const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
-    const uint64_t p = (uint64_t)alo * clo;
-    const uint64_t t = (uint64_t)alo * chi + (uint32_t)(p >> 32);
-    const uint64_t u = (uint64_t)ahi * clo + (uint32_t)t;
-    return (uint64_t)(uint32_t)p | ((uint64_t)(uint32_t)u << 32);
+// 64 x 64 -> low 64 product by a constant on explicit halves: one 32 x 32 -> 64 product and two low products
+// (v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32): 3 multiplier operations, the minimum, and no register-pair shuffling
+// (chaining three v_mad_u64_u32 needs the 32-bit carry in an aligned 64-bit pair: 8 v_mov per hash).  Either form
+// issues at the same rate on gfx950 -- every VOP3 integer op costs 4.2 cycles (tools/ubench/valu_rates.hip).
+__host__ __device__ __forceinline__ void mul64_halves(uint32_t &l, uint32_t &h, uint32_t clo, uint32_t chi) {
+    const uint64_t p = (uint64_t)l * clo;
+    const uint32_t nh = (uint32_t)(p >> 32) + l * chi + h * clo;
+    l = (uint32_t)p; h = nh;
 }
 
-__host__ __device__ __forceinline__ uint64_t fmix64_const(uint64_t k) {
-    k ^= k >> 33;
-    k = mul64_const(k, 0xed558ccdu, 0xff51afd7u);
-    k ^= k >> 33;
-    k = mul64_const(k, 0x1a85ec53u, 0xc4ceb9feu);
-    k ^= k >> 33;
-    return k;
+__host__ __device__ __forceinline__ void fmix64_halves(uint32_t &l, uint32_t &h) {
+    l ^= h >> 1;                                   // k ^= k >> 33
+    mul64_halves(l, h, 0xed558ccdu, 0xff51afd7u);
+    l ^= h >> 1;
+    mul64_halves(l, h, 0x1a85ec53u, 0xc4ceb9feu);
+    l ^= h >> 1;
 }
 
 // MurmurHash3_x64_128(&v, 8, 42) -> h1 for v < 2^32.  len = 8, seed = 42: no body block; tail k1 = key;
 // h1 = 42 ^ mix(k1); h2 = 42; both ^= 8  =>  h1 = (k1 ^ 34) + 34, h2 = h1 + 34 before the finalisers.
+// 17 multiplier operations per hash (2 + 3 + 4 x 3).
 __host__ __device__ __forceinline__ uint64_t kmer_hash32(uint32_t v) {
     const uint64_t p = (uint64_t)v * 0x114253d5u;                        // v * c1, 32 x 64
-    const uint64_t t = (uint64_t)v * 0x87c37b91u + (uint32_t)(p >> 32);
-    uint64_t k1 = (uint64_t)(uint32_t)p | ((uint64_t)(uint32_t)t << 32);
-    k1 = rotl64(k1, 31);
-    k1 = mul64_const(k1, 0x2745937fu, 0x4cf5ad43u);                      // * c2
-    const uint64_t h1 = (k1 ^ 34ull) + 34ull;
-    const uint64_t h2 = h1 + 34ull;
-    return fmix64_const(h1) + fmix64_const(h2);
+    uint32_t l = (uint32_t)p, h = (uint32_t)(p >> 32) + v * 0x87c37b91u;
+    const uint32_t rl = (l << 31) | (h >> 1), rh = (h << 31) | (l >> 1);   // rotl64(k1, 31)
+    l = rl; h = rh;
+    mul64_halves(l, h, 0x2745937fu, 0x4cf5ad43u);                        // * c2
+    const uint64_t h1 = ((((uint64_t)h << 32) | l) ^ 34ull) + 34ull, h2 = h1 + 34ull;
+    uint32_t al = (uint32_t)h1, ah = (uint32_t)(h1 >> 32), bl = (uint32_t)h2, bh = (uint32_t)(h2 >> 32);
+    fmix64_halves(al, ah);
+    fmix64_halves(bl, bh);
+    return (((uint64_t)ah << 32) | al) + (((uint64_t)bh << 32) | bl);
 }
 
 // Streaming Murmur3 x64-128 over a sequence of u32 words (little-endian), seed 0.
