@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 
 namespace mdbg {
 
@@ -299,27 +300,14 @@ __global__ __launch_bounds__(256) void complexity_exact_kernel(const uint64_t *w
     }
 }
 
-// per-wave LDS used by the HAS_QUAL variant to map a stream position back to original coordinates
+// per-wave LDS used by the HAS_QUAL && HPC variant: the original coordinate (rlePositions[hpc index], i.e. the
+// start of the run) of every position of the compressed stream -- [carry (cb)] [new bases (C)] like the stream
+// itself.  Filled by the lanes while they compact their words (one 4-byte LDS store per kept base), read twice
+// per selected minimizer.
+constexpr int ORIG_WORDS = 16 + 64 * 32;
 struct QualMap {
-    uint32_t lane_off[64];     // stream position of the first new base of each lane (cb + prefix)
-    uint64_t lane_flags[64];   // run-start flags of each lane's word (spread form)
-    uint32_t carry_orig[16];   // original coordinate of each carried base
+    uint32_t orig[ORIG_WORDS];
 };
-
-// original coordinate of stream position s (HPC: start of its run == rlePositions[hpc index])
-__device__ __forceinline__ uint32_t orig_of(const QualMap *q, unsigned s, unsigned cb, uint32_t tile_base) {
-    if (s < cb) return q->carry_orig[s];
-    unsigned lo = 0, hi = 64;  // largest lane with lane_off <= s
-    while (hi - lo > 1) {
-        unsigned mid = (lo + hi) >> 1;
-        if (q->lane_off[mid] <= s) lo = mid; else hi = mid;
-    }
-    unsigned idx = s - q->lane_off[lo];
-    uint64_t d = q->lane_flags[lo];
-    for (unsigned t = 0; t < idx; t++) d &= d - 1;   // drop idx lowest set bits
-    unsigned bit = (unsigned)__ffsll((long long)d) - 1u;
-    return tile_base + lo * 32u + (bit >> 1);
-}
 
 #ifndef SCAN_PP
 #define SCAN_PP 4          // adjacent k-mer positions per lane per trip of the hash loop (1..4)
@@ -399,7 +387,7 @@ struct KmerTrip {
                         a.out_dir[cap0 + idx] = (uint8_t)dir[u];
                         if (HAS_QUAL) {
                             uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates, or [.., rle[pos + K - 1]]
-                            if (HPC) { os = orig_of(Q, j, cb, tile_base); oe = orig_of(Q, j + K - a.q_last, cb, tile_base) + a.q_last; }
+                            if (HPC) { os = Q->orig[j]; oe = Q->orig[j + K - a.q_last] + a.q_last; }
                             else { os = p; oe = p + K; }
                             if (a.inline_minq) {
                                 const uint8_t *qq = a.qual + a.qual_off[r];
@@ -506,6 +494,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             }
 
             // ---- 1. run starts / compaction ---------------------------------------------------
+            const uint32_t tile_base_now = t * TILE_WORDS * 32u;
             uint64_t y, d;
             unsigned c;
             if (HPC) {
@@ -554,7 +543,17 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             S[lane + 64] = 0;
             if (lane < STREAM_WORDS - 128) S[lane + 128] = 0;
             if (HAS_N) { SI[lane] = 0; if (lane < ISTREAM_WORDS - 64) SI[lane + 64] = 0; }
-            if (HAS_QUAL && HPC) { Q->lane_off[lane] = cb + o; Q->lane_flags[lane] = d; }
+            if (HAS_QUAL && HPC) {
+                // d: bit 2i set iff base i of this lane's word starts a run; the r-th set bit is stream position cb + o + r
+                uint64_t dd = d;
+                uint32_t *dst = Q->orig + cb + o;
+                const uint32_t w0 = tile_base_now + lane * 32u;
+                while (dd) {
+                    const unsigned bit = (unsigned)__ffsll((long long)dd) - 1u;
+                    *dst++ = w0 + (bit >> 1);
+                    dd &= dd - 1;
+                }
+            }
             wave_lds_sync();
             if (lane == 0 && cb) { atomicOr(&S[0], carry); if (HAS_N && icarry) atomicOr(&SI[0], icarry); }
             if (c) {
@@ -603,11 +602,11 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             carry = cbn ? stream_extract(S, tot - cbn, cmask) : 0u;
             if (HAS_N) icarry = cbn ? istream_extract(SI, tot - cbn, (1u << cbn) - 1u) : 0u;
             uint32_t my_orig = 0;
-            if (HAS_QUAL && HPC) { if (lane < cbn) my_orig = orig_of(Q, tot - cbn + lane, cb, tile_base); }
+            if (HAS_QUAL && HPC) { if (lane < cbn) my_orig = Q->orig[tot - cbn + lane]; }
             cb = cbn;
             hp_total += C;
             wave_lds_sync();   // all reads of S / Q done before the next tile rewrites them
-            if (HAS_QUAL && HPC) { if (lane < cbn) Q->carry_orig[lane] = my_orig; }
+            if (HAS_QUAL && HPC) { if (lane < cbn) Q->orig[lane] = my_orig; }
         }
 
         // ---- _trimBps == 0 (GenerateGfa.hpp:366): the last l-mer, which the tiles never evaluate because
@@ -627,8 +626,8 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
                     a.out_pos[cap0 + nout] = p;
                     a.out_dir[cap0 + nout] = (uint8_t)d;
                     if (HAS_QUAL) {
-                        const uint32_t os = HPC ? Q->carry_orig[0] : p;
-                        const uint32_t oe = a.q_last ? (HPC ? Q->carry_orig[K - 1] : p + K - 1u) + 1u : L;
+                        const uint32_t os = HPC ? Q->orig[0] : p;
+                        const uint32_t oe = a.q_last ? (HPC ? Q->orig[K - 1] : p + K - 1u) + 1u : L;
                         if (a.inline_minq) {
                             const uint8_t *qq = a.qual + a.qual_off[r];
                             uint8_t mq = 255;
@@ -697,43 +696,53 @@ __global__ __launch_bounds__(256) void compact_minimizers_kernel(
     }
 }
 
-// Exact sum of per-base error probabilities as a 128-bit fixed-point integer (units of 2^-64):
-// one wave per read, conflict-free per-lane LDS histogram of the quality bytes, then
-// sum_q count[q] * T[q] with T[q] = float table entry * 2^64 (exact).  The host turns it into the
-// reference's long double error sum (ReadSelection.hpp:870-879).
+// Exact sum of per-base error probabilities as a 128-bit fixed-point integer (units of 2^-64): sum_q T[q] with
+// T[q] = float table entry * 2^64 (exact).  The host turns it into the reference's long double error sum
+// (ReadSelection.hpp:870-879).  Every T[q] is a multiple of 2^QSHIFT (24-bit mantissas, smallest entry 10^-9.4;
+// checked on the host), so T >> QSHIFT fits 56 bits: a lane adds 16 table entries per 16-byte load into a u64 and
+// carries into a u32 above it.  One wave per read, 1 KB per wave per load; the 96-entry table sits in LDS.
 constexpr int QBINS = 96;   // bins 0..94 = chars 33..127, bin 95 = everything else (contributes 0)
-__global__ __launch_bounds__(64) void quality_sum_kernel(const uint8_t *qual, const uint64_t *qual_off, const uint32_t *len,
-                                                         uint32_t n_reads, const uint64_t *tab_lo, const uint64_t *tab_hi,
-                                                         uint64_t *sum_lo, uint64_t *sum_hi) {
-    __shared__ uint32_t hist[QBINS][64];   // hist[bin][lane]: lanes never collide
-    const unsigned lane = threadIdx.x;
-    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-        for (int b = 0; b < QBINS; b++) hist[b][lane] = 0;
-        const uint8_t *q = qual + qual_off[r];
-        const uint32_t L = len[r];
-        for (uint32_t i = lane; i < L; i += 64) {
-            unsigned c = q[i];
-            unsigned bin = (c >= 33u && c <= 127u) ? c - 33u : (unsigned)(QBINS - 1);
-            hist[bin][lane] += 1;
+constexpr int QSHIFT = 9;
+__global__ __launch_bounds__(256) void quality_sum_kernel(const uint8_t *qual, const uint64_t *qual_off, const uint32_t *len,
+                                                          uint32_t n_reads, const uint64_t *tab_shifted,
+                                                          uint64_t *sum_lo, uint64_t *sum_hi) {
+    __shared__ uint64_t T[QBINS];
+    if (threadIdx.x < QBINS) T[threadIdx.x] = tab_shifted[threadIdx.x];
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint64_t begin = qual_off[r], end = begin + len[r];
+        uint64_t acc_lo = 0;
+        uint32_t acc_hi = 0;
+        for (uint64_t chunk = (begin & ~15ull) + 16ull * lane; chunk < end; chunk += 16ull * 64ull) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(qual + chunk);   // the buffer is 16-byte padded at both ends
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const bool full = chunk >= begin && chunk + 16 <= end;
+            uint64_t part = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                uint32_t idx = ((w[b >> 2] >> (8 * (b & 3))) & 0xFFu) - 33u;      // < 33 wraps around
+                idx = idx < (uint32_t)(QBINS - 1) ? idx : (uint32_t)(QBINS - 1);
+                if (!full && (chunk + b < begin || chunk + b >= end)) idx = QBINS - 1;
+                part += T[idx];
+            }
+            const uint64_t nlo = acc_lo + part;
+            acc_hi += nlo < acc_lo ? 1u : 0u;
+            acc_lo = nlo;
         }
-        __syncthreads();
-        unsigned __int128 acc = 0;
-        for (int b = lane; b < QBINS - 1; b += 64) {
-            uint64_t cnt = 0;
-            for (int l = 0; l < 64; l++) cnt += hist[b][l];
-            unsigned __int128 t = ((unsigned __int128)tab_hi[b] << 64) | tab_lo[b];
-            acc += t * cnt;
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {     // 96-bit wave reduction
+            const uint64_t olo = __shfl_xor(acc_lo, dlt, 64);
+            const uint32_t ohi = __shfl_xor(acc_hi, dlt, 64);
+            const uint64_t nlo = acc_lo + olo;
+            acc_hi += ohi + (nlo < acc_lo ? 1u : 0u);
+            acc_lo = nlo;
         }
-        uint64_t lo = (uint64_t)acc, hi = (uint64_t)(acc >> 64);
-        // 128-bit wave reduction
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-            uint64_t olo = __shfl_xor(lo, dlt, 64), ohi = __shfl_xor(hi, dlt, 64);
-            uint64_t nlo = lo + olo;
-            hi = hi + ohi + (nlo < lo ? 1ull : 0ull);
-            lo = nlo;
+        if (lane == 0) {
+            sum_lo[r] = acc_lo << QSHIFT;
+            sum_hi[r] = ((uint64_t)acc_hi << QSHIFT) | (acc_lo >> (64 - QSHIFT));
         }
-        if (lane == 0) { sum_lo[r] = lo; sum_hi[r] = hi; }
-        __syncthreads();
     }
 }
 
@@ -839,25 +848,24 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     bool any_low_quality = false;
     if (has_q && n) {
         // table exactly as the reference builds it (ReadSelection.hpp:101-104, Commons.hpp:2338-2341)
-        std::vector<uint64_t> tlo(QBINS, 0), thi(QBINS, 0);
+        std::vector<uint64_t> tsh(QBINS, 0);
         for (int q = 33; q <= 127; q++) {
             float qq = (float)(uint8_t)(q - 33);
             float t = powf(10.0f, -qq / 10.0f);
             long double scaled = (long double)t * 18446744073709551616.0L;   // * 2^64, exact (24-bit mantissa)
             unsigned __int128 v = (unsigned __int128)scaled;
-            tlo[q - 33] = (uint64_t)v; thi[q - 33] = (uint64_t)(v >> 64);
+            if ((uint64_t)v & ((1ull << QSHIFT) - 1ull)) return fail(set_error(ctx, MDBG_EINVAL, "quality table entry %d is not a multiple of 2^%d", q, QSHIFT));
+            tsh[q - 33] = (uint64_t)(v >> QSHIFT);
         }
-        DevBuf<uint64_t> d_tlo, d_thi, d_slo, d_shi;
-        if ((rc = d_tlo.alloc(ctx, QBINS)) || (rc = d_thi.alloc(ctx, QBINS)) || (rc = d_slo.alloc(ctx, n)) || (rc = d_shi.alloc(ctx, n)))
-            return fail(rc);
-        if ((e = memcpy_sync(ctx, d_tlo.p, tlo.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = memcpy_sync(ctx, d_thi.p, thi.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess)
+        DevBuf<uint64_t> d_tab, d_slo, d_shi;
+        if ((rc = d_tab.alloc(ctx, QBINS)) || (rc = d_slo.alloc(ctx, n)) || (rc = d_shi.alloc(ctx, n))) return fail(rc);
+        if ((e = memcpy_sync(ctx, d_tab.p, tsh.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess)
             return fail(set_error(ctx, MDBG_EHIP, "quality table upload failed: %s", hipGetErrorString(e)));
         {
             LaunchTimer timer(ctx, "quality_sum");
-            unsigned blocks = n < (unsigned)ctx->n_cu * 16u ? n : (unsigned)ctx->n_cu * 16u;
-            hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(64), 0, ctx->stream, reads->d_qual.p, reads->d_qual_off.p,
-                               reads->d_len.p, n, d_tlo.p, d_thi.p, d_slo.p, d_shi.p);
+            unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 8u);
+            hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_qual.p, reads->d_qual_off.p,
+                               reads->d_len.p, n, d_tab.p, d_slo.p, d_shi.p);
         }
         std::vector<uint64_t> slo(n), shi(n);
         std::vector<uint32_t> lens(n);
@@ -867,12 +875,27 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
             return fail(set_error(ctx, MDBG_EHIP, "quality sums download failed: %s", hipGetErrorString(e)));
         m->h_mean_quality.resize(n);
         low_quality.assign(n, 0);
-        for (uint32_t r = 0; r < n; r++) {
-            long double s = ((long double)shi[r] * 18446744073709551616.0L + (long double)slo[r]) / 18446744073709551616.0L;
-            float mq = mean_quality_from_sum(s, lens[r]);
-            m->h_mean_quality[r] = mq;
-            if (p->apply_read_filters && mq < p->min_read_quality) { low_quality[r] = 1; any_low_quality = true; }   // ReadSelection.hpp:901-909
+        // the reference's long double division and log10 per read, on a few host threads
+        const bool filter = p->apply_read_filters != 0;
+        const float min_q = p->min_read_quality;
+        const unsigned n_thr = n < 65536 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<char> any(n_thr, 0);
+        auto work = [&](unsigned t) {
+            const uint32_t r0 = (uint32_t)((uint64_t)n * t / n_thr), r1 = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
+            for (uint32_t r = r0; r < r1; r++) {
+                long double sq = ((long double)shi[r] * 18446744073709551616.0L + (long double)slo[r]) / 18446744073709551616.0L;
+                float mq = mean_quality_from_sum(sq, lens[r]);
+                m->h_mean_quality[r] = mq;
+                if (filter && mq < min_q) { low_quality[r] = 1; any[t] = 1; }   // ReadSelection.hpp:901-909
+            }
+        };
+        if (n_thr == 1) work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_thr; t++) pool.emplace_back(work, t);
+            for (auto &th : pool) th.join();
         }
+        for (char c : any) any_low_quality |= c != 0;
     } else {
         m->h_mean_quality.assign(n, mean_quality_from_sum(0, 0));
     }
