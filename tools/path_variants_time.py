@@ -15,7 +15,7 @@ from metamdbg_amd import capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ctx = capi.Context(0)
 NAMES = ["scan", "scan_compact", "quality_sum", "complexity_exact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit",
-         "density_threshold"]
+         "density_threshold", "kminmer_prev_lookup", "edge_index", "minimizer_census"]
 
 
 def report(tag, t0):
@@ -45,15 +45,15 @@ for rep in range(2):
     ctx.timing_reset(); t0 = time.perf_counter()
     t = ctx.kminmer_count_first(corr, 4, 0)
     if rep: report(f"k=4 first pass records={t.info()['n_records']}", t0)
+ctx.timing_reset(); t0 = time.perf_counter()
+e, ck = ctx.edge_index(t)
+report(f"edge index of the k=4 nodes: {e.info()['n_records']} edges", t0)
+e.free()
 for k in range(5, 12):
     ctx.timing_reset(); t0 = time.perf_counter()
     t2 = ctx.kminmer_count_refined(corr, None, k, t) if k == 5 else ctx.kminmer_index(corr, None, k, t)
     report(f"k={k} {'refined' if k == 5 else 'index'} records={t2.info()['n_records']}", t0)
     t.free(); t = t2
-ctx.timing_reset(); t0 = time.perf_counter()
-e, ck = ctx.edge_index(t)
-report(f"edge index of the k=11 nodes: {e.info()['n_records']} edges", t0)
-
 # ONT-like: 20 kb reads, 2 % errors, qualities, no HPC, correction density + down-sampling
 n_ont = max(n // 4, 1000)
 ont = synth.SynthSpec(n_reads=n_ont, read_len=20000, seed=7, sub_rate=0.02, species_len=[int(n_ont * 20000 / 30)], species_weight=[1.0],
