@@ -545,13 +545,16 @@ __global__ __launch_bounds__(SCAN_BLOCK, SCAN_MIN_WAVES) void scan_kernel(ScanAr
             if (HAS_N) { SI[lane] = 0; if (lane < ISTREAM_WORDS - 64) SI[lane + 64] = 0; }
             if (HAS_QUAL && HPC) {
                 // d: bit 2i set iff base i of this lane's word starts a run; the r-th set bit is stream position cb + o + r
-                uint64_t dd = d;
                 uint32_t *dst = Q->orig + cb + o;
                 const uint32_t w0 = tile_base_now + lane * 32u;
-                while (dd) {
-                    const unsigned bit = (unsigned)__ffsll((long long)dd) - 1u;
-                    *dst++ = w0 + (bit >> 1);
-                    dd &= dd - 1;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {          // 32-bit halves: cheaper bit scans than on the u64
+                    uint32_t m = half ? (uint32_t)(d >> 32) : (uint32_t)d;
+                    const uint32_t wb = w0 + 16u * half;
+                    while (m) {
+                        *dst++ = wb + (((uint32_t)__ffs((int)m) - 1u) >> 1);
+                        m &= m - 1u;
+                    }
                 }
             }
             wave_lds_sync();
