@@ -27,6 +27,11 @@
 #include <fstream>
 #include <functional>
 #include <string>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/mdbg_hip.h"
@@ -248,42 +253,90 @@ int run_read_selection(int argc, char **argv) {
     long double qualitySum = 0, qualityN = 0;
     std::vector<mdbg_minimizers *> kept;   // device-resident minimizer reads, purged once N50 is known
     const bool needCorrected = P.hpc || a.skipCorrection;
+    // The thread that owns the GPU context turns a batch into host arrays; a writer thread behind a short FIFO
+    // builds the records and writes them, in batch order, while the next batch is on the device.
+    struct HostBatch {
+        uint32_t n = 0; uint64_t t = 0;
+        std::vector<uint64_t> off; std::vector<uint32_t> m, pos, len; std::vector<uint8_t> dir, qual, flags; std::vector<float> meanQ;
+    };
+    std::deque<std::unique_ptr<HostBatch>> fifo;
+    std::mutex fifoMu;
+    std::condition_variable fifoCv;
+    bool fifoDone = false;
+    std::thread writer([&] {
+        std::string rec;
+        for (;;) {
+            std::unique_ptr<HostBatch> hb;
+            {
+                std::unique_lock<std::mutex> lk(fifoMu);
+                fifoCv.wait(lk, [&] { return fifoDone || !fifo.empty(); });
+                if (fifo.empty()) return;
+                hb = std::move(fifo.front());
+                fifo.pop_front();
+            }
+            fifoCv.notify_all();
+            rec.clear();
+            rec.reserve(hb->t * 10 + (size_t)hb->n * 13);
+            for (uint32_t r = 0; r < hb->n; r++) {
+                const uint64_t s0 = hb->off[r];
+                const uint32_t k = (uint32_t)(hb->off[r + 1] - s0);
+                const uint8_t circ = 0;
+                rec.append((const char *)&k, 4); rec.append((const char *)&circ, 1);
+                rec.append((const char *)(hb->m.data() + s0), (size_t)k * 4);
+                rec.append((const char *)(hb->pos.data() + s0), (size_t)k * 4);
+                rec.append((const char *)(hb->dir.data() + s0), k);
+                rec.append((const char *)(hb->qual.data() + s0), k);
+                rec.append((const char *)&hb->meanQ[r], 4);
+                rec.append((const char *)&hb->len[r], 4);
+                allReadSizes.push_back(hb->len[r]);
+                nbSelected += k;
+                nbKmers += (uint64_t)((size_t)hb->len[r] - P.minimizerSize + 1);   // size_t arithmetic as in :480
+                nbBases += hb->len[r];
+                if (!(hb->flags[r] & MDBG_READ_LOW_QUALITY)) { qualitySum += hb->meanQ[r]; qualityN += 1; }   // :911-914
+            }
+            out.write(rec.data(), (std::streamsize)rec.size());
+        }
+    });
+    double tUpload = 0, tScan = 0, tDownload = 0, tQueue = 0, tLast = g_trace.now(), tWait = 0;
+    uint64_t nBatches = 0;
     for_each_batch(inputList, a.batchBases, a.threads, 0, [&](ReadBatch &b) {
+        double t0 = g_trace.now();
+        tWait += t0 - tLast;                      // time this thread waited for the feeder
         mdbg_reads *reads = nullptr;
         mdbg_minimizers *mins = nullptr;
         check(mdbg_reads_from_ascii(g_ctx, b.bases, b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+        double t1 = g_trace.now();
         mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
         check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
         mdbg_reads_free(reads);
-        uint32_t n; uint64_t t;
-        mdbg_minimizers_info(mins, &n, &t);
-        std::vector<uint64_t> off((size_t)n + 1);
-        std::vector<uint32_t> m(t), pos(t), len(n);
-        std::vector<uint8_t> dir(t), qual(t), flags(n);
-        std::vector<float> meanQ(n);
-        check(mdbg_minimizers_to_host(g_ctx, mins, off.data(), m.data(), pos.data(), dir.data(), qual.data(), len.data(), meanQ.data(), flags.data()), "to_host");
-        std::string rec;
-        rec.reserve(t * 10 + (size_t)n * 13);
-        for (uint32_t r = 0; r < n; r++) {
-            const uint64_t s = off[r];
-            const uint32_t k = (uint32_t)(off[r + 1] - s);
-            const uint8_t circ = 0;
-            rec.append((const char *)&k, 4); rec.append((const char *)&circ, 1);
-            rec.append((const char *)(m.data() + s), (size_t)k * 4);
-            rec.append((const char *)(pos.data() + s), (size_t)k * 4);
-            rec.append((const char *)(dir.data() + s), k);
-            rec.append((const char *)(qual.data() + s), k);
-            rec.append((const char *)&meanQ[r], 4);
-            rec.append((const char *)&len[r], 4);
-            allReadSizes.push_back(len[r]);
-            nbSelected += k;
-            nbKmers += (uint64_t)((size_t)len[r] - P.minimizerSize + 1);   // size_t arithmetic as in :480
-            nbBases += len[r];
-            if (!(flags[r] & MDBG_READ_LOW_QUALITY)) { qualitySum += meanQ[r]; qualityN += 1; }   // :911-914
-        }
-        out.write(rec.data(), (std::streamsize)rec.size());
+        double t2 = g_trace.now();
+        std::unique_ptr<HostBatch> hb(new HostBatch());
+        mdbg_minimizers_info(mins, &hb->n, &hb->t);
+        hb->off.resize((size_t)hb->n + 1);
+        hb->m.resize(hb->t); hb->pos.resize(hb->t); hb->len.resize(hb->n);
+        hb->dir.resize(hb->t); hb->qual.resize(hb->t); hb->flags.resize(hb->n); hb->meanQ.resize(hb->n);
+        check(mdbg_minimizers_to_host(g_ctx, mins, hb->off.data(), hb->m.data(), hb->pos.data(), hb->dir.data(), hb->qual.data(), hb->len.data(),
+                                      hb->meanQ.data(), hb->flags.data()), "to_host");
         if (needCorrected) kept.push_back(mins); else mdbg_minimizers_free(mins);
+        double t3 = g_trace.now();
+        {
+            std::unique_lock<std::mutex> lk(fifoMu);
+            fifoCv.wait(lk, [&] { return fifo.size() < 4; });
+            fifo.push_back(std::move(hb));
+        }
+        fifoCv.notify_all();
+        tLast = g_trace.now();
+        tUpload += t1 - t0; tScan += t2 - t1; tDownload += t3 - t2; tQueue += tLast - t3; nBatches++;
     });
+    if (getenv("MDBG_TRACE"))
+        fprintf(stderr, "[mdbg_tool] %llu batches: waiting for the feeder %.3f s, upload+pack %.3f s, scan %.3f s, download %.3f s, writer queue %.3f s\n",
+                (unsigned long long)nBatches, tWait, tUpload, tScan, tDownload, tQueue);
+    {
+        std::lock_guard<std::mutex> lk(fifoMu);
+        fifoDone = true;
+    }
+    fifoCv.notify_all();
+    writer.join();
     out.close();
     g_trace.mark("main pass done (parse + scan + read_data_init.txt)");
 
