@@ -131,7 +131,8 @@ static int exclusive_scan_impl(mdbg_ctx *ctx, const Tin *d_in, uint64_t *d_out, 
     }
     hipLaunchKernelGGL(scan_apply_kernel<Tin>, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in, n, sums.p, d_out);
     MDBG_HIP_CHECK(ctx, hipGetLastError());
-    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // sums freed on return
+    // no synchronisation: `sums` returns to the context's pool, whose blocks are only ever handed to later work on
+    // the same stream, i.e. after the kernels above
     return MDBG_OK;
 }
 
