@@ -4,6 +4,9 @@
 A step = one pass of the hot path over one batch of synthetic HiFi reads already resident in HBM
 (2-bit packed): reads -> minimizers (HPC, l=15, density 0.005) -> palindrome purge -> k-min-mer
 table at k=4 (count + rescue).  N=1 workload = BASELINE.json configs[1]: 1 M x 10 kb reads.
+Two batches are in flight per GPU (--in-flight): consecutive steps run on two library contexts
+(own HIP stream, memory pool and host thread each), so the atomic-bound table kernels of one batch
+overlap the ALU-bound scan of the next; every step is still a complete pass over its batch.
 N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); only the
 k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
 all-to-alls over RCCL (metamdbg_amd/distributed.py, include/mdbg_hip.h mdbg_shard_*).
@@ -21,6 +24,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -37,6 +41,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (10 kb each)")
     ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--in-flight", type=int, default=2, help="batches processed concurrently per GPU (own context, stream and host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads in the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -124,13 +129,21 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    ctx = capi.Context(local_rank)
+    # IN_FLIGHT batches are processed concurrently, each by its own host thread on its own library context (own HIP
+    # stream and memory pool) over its own copy of the reads: the k-min-mer kernels of one batch (bound by the atomic
+    # rate) and the gaps between launches overlap with the scan of the other (bound by the vector ALU).  Step i runs
+    # on slot i % IN_FLIGHT; every step is still the complete pass over one batch.
+    n_slots = max(1, args.in_flight)
+    slots = []
+    spec = synth.hifi_spec(args.reads * world, seed=42, read_len=args.read_len, coverage=50.0)   # one metagenome for the job
+    for _ in range(n_slots):
+        c = capi.Context(local_rank)
+        slots.append((c, c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)))   # rank r owns reads [r*n, (r+1)*n)
+    ctx, reads = slots[0]
     info = ctx.device_info()
-    # one metagenome for the whole job; rank r owns reads [r*n, (r+1)*n)
-    spec = synth.hifi_spec(args.reads * world, seed=42, read_len=args.read_len, coverage=50.0)
-    reads = ctx.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)
     n_bases = reads.info()["n_bases"]
     rw = capi.lib().mdbg_row_words(KMINMER)
+    exchange = world > 1 or force_exchange
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,35 +153,47 @@ def main() -> None:
 
     trace = os.environ.get("MDBG_BENCH_TRACE") == "1"
     phases: dict = {}
+    # the exchanges of the sharded pass use ONE communicator: they run in global step order on every rank, one at a
+    # time (a step's scan is several times longer than its exchange, so the turn-taking costs nothing)
+    turn = threading.Condition()
+    next_exchange = [0]
 
-    def step():
+    def step(slot: int, index: int):
+        ctx, reads = slots[slot]
         mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
         corr = ctx.purge_palindromes(mins, 4, 100)
-        if world == 1 and not force_exchange:
+        if not exchange:
             table = ctx.kminmer_count_first(corr, KMINMER, 0)
         else:
             from metamdbg_amd import distributed as D
             tr = [time.perf_counter()] if trace else None
             def mark(name):
                 if tr is not None:
-                    torch.cuda.synchronize()
+                    ctx.synchronize()
                     tr.append(time.perf_counter())
                     phases[name] = phases.get(name, 0.0) + (tr[-1] - tr[-2]) * 1e3
             sh = ctx.shard_begin(corr, KMINMER, world)
             mark("begin")
             sent = [int(c) for c in sh.counts]
-            send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
-                torch.empty((0, rw), dtype=torch.int64, device="cuda")
-            mine, got = D.exchange_by_owner(send, sent)
-            torch.cuda.synchronize()
-            mark("all_to_all_rows")
-            d_reply = sh.reduce(mine.data_ptr(), mine.shape[0])
-            reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
-                torch.empty((0,), dtype=torch.int64, device="cuda")
-            mark("reduce")
-            glob = D.reply_to_senders(reply, got, sent)
-            torch.cuda.synchronize()
-            mark("all_to_all_reply")
+            with turn:
+                turn.wait_for(lambda: next_exchange[0] >= index)
+            try:
+                send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
+                    torch.empty((0, rw), dtype=torch.int64, device="cuda")
+                mine, got = D.exchange_by_owner(send, sent)
+                torch.cuda.current_stream().synchronize()      # not the device: the other slot keeps running
+                mark("all_to_all_rows")
+                d_reply = sh.reduce(mine.data_ptr(), mine.shape[0])
+                reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
+                    torch.empty((0,), dtype=torch.int64, device="cuda")
+                mark("reduce")
+                glob = D.reply_to_senders(reply, got, sent)
+                torch.cuda.current_stream().synchronize()
+                mark("all_to_all_reply")
+            finally:
+                with turn:
+                    next_exchange[0] = index + 1
+                    turn.notify_all()
             table = sh.finish(glob.data_ptr(), 0)
             sh.free()
             mark("finish")
@@ -178,26 +203,61 @@ def main() -> None:
             o.free()
         return n_min, ti
 
-    for _ in range(args.warmup):
-        step()
-    ctx.timing(True)
-    ctx.timing_reset()
+    results: dict = {}
+    errors: list = []
+
+    def run_steps(slot: int, indices: list):
+        try:
+            torch.cuda.set_device(local_rank)                  # the current device is per thread
+            for i in indices:
+                results[i] = step(slot, i)
+            slots[slot][0].synchronize()
+        except BaseException as exc:                           # surface it in the main thread
+            errors.append(exc)
+            with turn:
+                next_exchange[0] = 1 << 60                     # never block the other slot on a dead one
+                turn.notify_all()
+
+    def run_phase(first: int, count: int):
+        """Steps first .. first+count-1, step i on slot i % n_slots, the slots concurrently."""
+        work = [[i for i in range(first, first + count) if i % n_slots == sl] for sl in range(n_slots)]
+        threads = [threading.Thread(target=run_steps, args=(sl, w)) for sl, w in enumerate(work) if w]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    # warm-up: at least one step per slot (pools, table sizing, RCCL set-up), in whole rounds so that the timed steps
+    # start on slot 0
+    n_warm = max(args.warmup, n_slots)
+    n_warm += (-n_warm) % n_slots
+    run_phase(0, n_warm)
+    for c, _ in slots:
+        c.timing(True)
+        c.timing_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_min, ti = step()
+    run_phase(n_warm, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    ctx.timing(False)
+    for c, _ in slots:
+        c.timing(False)
+    n_min, ti = results[n_warm + args.steps - 1]
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    def timing_get(name):
+        tot = [c.timing_get(name) for c, _ in slots]
+        return sum(t[0] for t in tot), sum(t[1] for t in tot)
+
     names = ["scan", "scan_compact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit"]
-    if world > 1 or force_exchange:
+    if exchange:
         names += ["shard_rows", "shard_reduce"]
-    ktimes = {k: ctx.timing_get(k) for k in names}
+    ktimes = {k: timing_get(k) for k in names}
     scan_ms, scan_n = ktimes["scan"]
     scan_avg_s = scan_ms / 1e3 / max(scan_n, 1)
     # algorithmic bytes of one scan launch (SURVEY.md 8(d)): 0.25 B per base read + 10 B per emitted minimizer
@@ -221,10 +281,15 @@ def main() -> None:
                                    "(count + rescue); inputs 2-bit packed and resident in HBM",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(ti["n_records"]), "solid": int(ti["n_solid"]),
-                       "device": info["arch"], "cus": info["n_cu"]},
+                       "batches_in_flight": n_slots, "device": info["arch"], "cus": info["n_cu"]},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
+                         "concurrent_launches": n_slots,
+                         "concurrency_note": (f"{n_slots} batches are in flight: a scan launch shares the device with the other batch's "
+                                              "table kernels and lasts longer than alone (15.4 ms with --in-flight 1: 186 GB/s, 2.3 % of "
+                                              "peak, 57 % of the hash floor); scans of different batches never overlap each other")
+                                             if n_slots > 1 else None,
                          "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies, half-rate VALU) "
                                  "puts the ceiling at the VALU, far below HBM (DESIGN.md 4.1)",
                          # the hash alone, measured in isolation at full occupancy (tools/ubench/hash_rates.hip,
@@ -237,12 +302,14 @@ def main() -> None:
         if base and base.get("value"):
             out["speedup_vs_cpu_reference"] = out["value"] / base["value"]
         if trace and phases:
-            out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + args.warmup) for k, v in phases.items()}
+            out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + n_warm) for k, v in phases.items()}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c, r in slots:
+        r.free()
+        c.close()
 
 
 if __name__ == "__main__":

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 
 namespace mdbg {
@@ -786,17 +787,23 @@ static float mean_quality_from_sum(long double error_sum_in, size_t n_in) {
     return -10.0f * log10f(mean_err);
 }
 
+static std::mutex &device_scan_mutex(int device) {
+    static std::mutex m[64];
+    return m[(unsigned)device % 64u];
+}
+
 template <bool HPC, bool Q, bool N>
 static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks, uint32_t n_items) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_kernel<HPC, Q, N>, SCAN_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    // exactly one resident generation of waves: reads are dealt grid-stride, so a partial second
-    // generation would leave SIMDs under-filled for the tail
-    unsigned blocks = (unsigned)ctx->n_cu * (unsigned)per_cu;
-    if (blocks > max_blocks) blocks = max_blocks;
-    uint64_t need = ((uint64_t)n_items + SCAN_WAVES - 1) / SCAN_WAVES;
-    if (need < blocks) blocks = (unsigned)(need ? need : 1);
-    hipLaunchKernelGGL((scan_kernel<HPC, Q, N>), dim3(blocks), dim3(SCAN_BLOCK), 0, ctx->stream, a);
+    // SCAN_READS_PER_WAVE reads per wave, then the wave retires: short-lived workgroups let the dispatcher interleave
+    // the kernels of another stream (a second batch in flight, RCCL) instead of queueing them behind one resident
+    // generation of persistent waves; the per-block set-up (1024-entry LUT) is noise next to a 10 kb read.
+    (void)max_blocks;
+    const char *env = getenv("MDBG_SCAN_READS_PER_WAVE");
+    const uint64_t per_wave = env && atoi(env) > 0 ? (uint64_t)atoi(env) : 1;
+    uint64_t blocks = ((uint64_t)n_items + SCAN_WAVES * per_wave - 1) / (SCAN_WAVES * per_wave);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
+    hipLaunchKernelGGL((scan_kernel<HPC, Q, N>), dim3((unsigned)blocks), dim3(SCAN_BLOCK), 0, ctx->stream, a);
 }
 
 static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool has_n, uint32_t n_items) {
@@ -932,6 +939,11 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     a.out_min = p_min.p; a.out_pos = p_pos.p; a.out_dir = p_dir.p;
     a.out_os = p_os.p; a.out_oe = p_oe.p; a.out_mqual = nullptr; a.inline_minq = 0;
     a.out_count = d_count.p; a.out_flags = m->d_flags.p;
+    // One scan kernel at a time per device, whatever the number of contexts: two of them interleaved workgroup by
+    // workgroup each run at half speed and worse (measured: 2 x 15.5 ms alone, 2 x 30 ms interleaved), while everything
+    // else a second context does -- table building, purge, RCCL -- overlaps a running scan nicely.  The lock covers the
+    // launch and is released when the kernel has finished (the counter download below waits for it).
+    std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));
     if (n && (rc = launch_scan(ctx, a, hpc, has_q, has_n, n))) return fail(rc);
 
     // overflow handling (reads that selected more than their padded capacity are re-run with exact room)
@@ -943,6 +955,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
                               d_count.p, d_cap.p, m->d_flags.p, n, d_list.p, d_suspects.p, d_nlist.p);
     uint32_t h_counters[2] = {0, 0};
     e = memcpy_sync(ctx, h_counters, d_nlist.p, 8, hipMemcpyDeviceToHost);
+    scan_turn.unlock();
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "overflow count copy failed: %s", hipGetErrorString(e)));
     const uint32_t n_over = h_counters[0], n_suspect = h_counters[1];
     if (n_suspect) {
