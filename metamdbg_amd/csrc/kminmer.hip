@@ -110,7 +110,7 @@ __device__ __forceinline__ void for_each_instance(const SeqView &s, F f) {
 }
 
 static unsigned instance_grid(const mdbg_ctx *ctx, uint32_t n_reads) {
-    return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 32u);
+    return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 1024u);
 }
 
 // ---- first pass -----------------------------------------------------------------------------------
