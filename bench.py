@@ -37,8 +37,8 @@ K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (10 kb each)")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--in-flight", type=int, default=2, help="batches processed concurrently per GPU (own context, stream and host thread each)")

@@ -794,12 +794,15 @@ static std::mutex &device_scan_mutex(int device) {
 
 template <bool HPC, bool Q, bool N>
 static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks, uint32_t n_items) {
-    // SCAN_READS_PER_WAVE reads per wave, then the wave retires: short-lived workgroups let the dispatcher interleave
-    // the kernels of another stream (a second batch in flight, RCCL) instead of queueing them behind one resident
-    // generation of persistent waves; the per-block set-up (1024-entry LUT) is noise next to a 10 kb read.
+    // A few reads per wave, then the wave retires.  One resident generation of persistent waves (the first design)
+    // took 17.9 ms for 1 M x 10 kb reads although every wave had the same work: CUs do not all run at the same
+    // speed, and the kernel ended with the slowest.  Dealt out by the dispatcher as slots free up, the same reads take
+    // 15.4 ms; short-lived workgroups also let the kernels of another stream (a second batch in flight, RCCL) in
+    // instead of queueing them behind the resident generation.  The per-block set-up (1024-entry LUT) is noise next
+    // to a 10 kb read.  4 reads per wave measured best with two batches in flight (MDBG_SCAN_READS_PER_WAVE to tune).
     (void)max_blocks;
     const char *env = getenv("MDBG_SCAN_READS_PER_WAVE");
-    const uint64_t per_wave = env && atoi(env) > 0 ? (uint64_t)atoi(env) : 1;
+    const uint64_t per_wave = env && atoi(env) > 0 ? (uint64_t)atoi(env) : 4;
     uint64_t blocks = ((uint64_t)n_items + SCAN_WAVES * per_wave - 1) / (SCAN_WAVES * per_wave);
     if (blocks < 1) blocks = 1;
     if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
