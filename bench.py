@@ -120,6 +120,8 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("MDBG_BENCH_SHARE_GPU") == "1":      # test hook: every rank on device 0 (multi-rank logic on a 1-GPU box)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     force_exchange = os.environ.get("MDBG_BENCH_FORCE_EXCHANGE") == "1"    # exercise the sharded path on one GPU
@@ -127,7 +129,11 @@ def main() -> None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MDBG_BENCH_BACKEND", "nccl")   # "gloo": exchanges staged through the host (test hook)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # IN_FLIGHT batches are processed concurrently, each by its own host thread on its own library context (own HIP
     # stream and memory pool) over its own copy of the reads: the k-min-mer kernels of one batch (bound by the atomic
@@ -246,8 +252,10 @@ def main() -> None:
         c.timing(False)
     n_min, ti = results[n_warm + args.steps - 1]
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    totals = torch.tensor([ti["n_records"], ti["n_solid"]], dtype=torch.int64, device="cuda")   # last step, summed over ranks
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
 
     def timing_get(name):
@@ -280,7 +288,7 @@ def main() -> None:
                                    f"4 species, 50x), HPC on, l={K_MINIMIZER}, density {DENSITY}, single k iteration k={KMINMER} "
                                    "(count + rescue); inputs 2-bit packed and resident in HBM",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
-                       "kminmer_records": int(ti["n_records"]), "solid": int(ti["n_solid"]),
+                       "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
                        "batches_in_flight": n_slots, "device": info["arch"], "cus": info["n_cu"]},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),

@@ -15,6 +15,20 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(group) -> bool:
+    """gloo has no all-to-all on device tensors: stage through the host (tests of the multi-rank logic on one GPU)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group) -> None:
+    if inp.is_cuda and _staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
 def exchange_by_owner(rows: torch.Tensor, counts: list[int], group=None) -> tuple[torch.Tensor, list[int]]:
     """rows: (sum(counts), rw) grouped by destination rank.  Returns (rows this rank owns, rows received
     from each rank) -- the second list is the split of the reply."""
@@ -22,10 +36,10 @@ def exchange_by_owner(rows: torch.Tensor, counts: list[int], group=None) -> tupl
     assert len(counts) == world and rows.shape[0] == sum(counts)
     send = torch.tensor(counts, dtype=torch.int64, device=rows.device)
     recv = torch.empty(world, dtype=torch.int64, device=rows.device)
-    dist.all_to_all_single(recv, send, group=group)
+    _all_to_all(recv, send, None, None, group)
     recv_counts = [int(x) for x in recv.tolist()]
     out = torch.empty((sum(recv_counts), rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
+    _all_to_all(out, rows, recv_counts, list(counts), group)
     return out, recv_counts
 
 
@@ -33,5 +47,5 @@ def reply_to_senders(reply: torch.Tensor, recv_counts: list[int], sent_counts: l
     """reply: one value per received row (same order).  Returns one value per SENT row, in the order sent."""
     assert reply.shape[0] == sum(recv_counts)
     out = torch.empty((sum(sent_counts),) + tuple(reply.shape[1:]), dtype=reply.dtype, device=reply.device)
-    dist.all_to_all_single(out, reply.contiguous(), output_split_sizes=list(sent_counts), input_split_sizes=list(recv_counts), group=group)
+    _all_to_all(out, reply, list(sent_counts), list(recv_counts), group)
     return out

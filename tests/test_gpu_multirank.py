@@ -1,0 +1,42 @@
+"""Two real ranks of bench.py's sharded step on ONE GPU (every rank on device 0, exchanges staged through the host with
+gloo -- RCCL refuses two ranks per device): the whole multi-rank orchestration (shard begin / reduce / finish, the two
+all-to-alls, two batches in flight taking turns on the communicator) must give, summed over the ranks, exactly the
+table of one rank over the same reads."""
+from __future__ import annotations
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env: dict, args: list[str], nproc: int | None) -> dict:
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable]
+    if nproc:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_two_ranks_equal_one(in_flight):
+    n = 40_000
+    common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--in-flight", str(in_flight)]
+    one = _bench({}, ["--gpus", "1", "--reads", str(2 * n)] + common, None)
+    two = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}, ["--gpus", "2", "--reads", str(n)] + common, 2)
+    assert two["n_gpus"] == 2
+    assert two["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
+    assert two["config"]["solid"] == one["config"]["solid"] > 0
