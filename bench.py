@@ -29,6 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP multiplexes streams onto a few hardware queues (4 by default); two contexts whose streams land on the same queue
+# run their kernels one after the other and the two batches in flight no longer overlap.  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4

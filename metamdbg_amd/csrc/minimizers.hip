@@ -49,13 +49,8 @@ __global__ __launch_bounds__(256) void purge_detect_kernel(const uint64_t *off, 
 // Serial replay of the reference for the listed reads: smallest k, then smallest i whose window of k
 // surviving minimizers is a palindrome -> drop its first element -> restart, until none is left.
 // Dropping from a compacted copy is equivalent to the reference's banned-position bookkeeping.
-__global__ __launch_bounds__(64) void purge_fix_kernel(const uint64_t *off, const uint32_t *list, uint32_t n_list, uint32_t *work,
-                                                       uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
-    uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_list) return;
-    const uint32_t r = list[li];
-    uint32_t *a = work + off[r];
-    uint32_t n = (uint32_t)(off[r + 1] - off[r]);
+template <typename Ptr>
+__device__ __forceinline__ uint32_t purge_replay(Ptr a, uint32_t n, uint32_t first_k, uint32_t last_k) {
     for (;;) {
         bool hit = false;
         for (uint32_t k = first_k; k < last_k && k <= n && !hit; k++) {
@@ -69,6 +64,29 @@ __global__ __launch_bounds__(64) void purge_fix_kernel(const uint64_t *off, cons
             }
         }
         if (!hit) break;
+    }
+    return n;
+}
+
+// One thread per suspect read.  The replay is a long chain of dependent reads of the same few dozen minimizers, so
+// reads of up to PURGE_LDS_MAX minimizers are staged in LDS (a padded row per thread) and written back once.
+constexpr uint32_t PURGE_LDS_MAX = 96;
+__global__ __launch_bounds__(64) void purge_fix_kernel(const uint64_t *off, const uint32_t *list, uint32_t n_list, uint32_t *work,
+                                                       uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
+    __shared__ uint32_t stage[64][PURGE_LDS_MAX + 1];
+    uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    const uint32_t r = list[li];
+    uint32_t *a = work + off[r];
+    uint32_t n = (uint32_t)(off[r + 1] - off[r]);
+    if (n <= PURGE_LDS_MAX) {
+        uint32_t *row = stage[threadIdx.x];
+        for (uint32_t i = 0; i < n; i++) row[i] = a[i];
+        const uint32_t m = purge_replay(row, n, first_k, last_k);
+        if (m != n) for (uint32_t i = 0; i < m; i++) a[i] = row[i];
+        n = m;
+    } else {
+        n = purge_replay(a, n, first_k, last_k);
     }
     new_count[r] = n;
 }
