@@ -329,7 +329,9 @@ struct KmerTrip {
     uint64_t cap0;
     uint32_t cap, r;
 
-    template <int PP>
+    // INTERIOR: every position of the trip is a real k-mer followed by a known base and none is the read's trimmed
+    // first position -- the per-position range tests fall away (all full trips but the very first of a read).
+    template <int PP, bool INTERIOR>
     __device__ __forceinline__ uint32_t run(unsigned j0, uint32_t nout) const {
         const unsigned jb = j0 + (unsigned)PP * lane;
         // 64 stream bits from position jb (enough for K + PP - 1 <= 19 bases)
@@ -341,7 +343,7 @@ struct KmerTrip {
             a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
         } else { a0 = 0; a1 = 0; }   // lanes far beyond nk in a short last trip
         bool sel[PP];
-        uint32_t val[PP], dir[PP];
+        uint32_t val[PP];
         uint32_t fwd = 0;
 #pragma unroll
         for (int u = 0; u < PP; u++) {
@@ -350,13 +352,13 @@ struct KmerTrip {
             const uint32_t rev = e ^ comp_mask;
             // forward k-mer: full digit reversal once, then shift in the newest base (top digit of e)
             fwd = u == 0 ? digit_reverse(e, K) : (((fwd << 2) | (e >> (2u * K - 2u))) & kmask);
-            dir[u] = fwd < rev ? 0u : 1u;               // tie -> 1 (Kmer.hpp:427)
-            val[u] = dir[u] ? rev : fwd;
+            val[u] = fwd < rev ? fwd : rev;             // canonical; the direction is worked out for the selected few
 #if defined(SCAN_ABLATE) && SCAN_ABLATE == 1
             sel[u] = (val[u] == 0x12345u) && (j < nk);                                  // ablation: no hash
 #else
             // first k-mer of the read skipped (Kmer.hpp:1395)
-            sel[u] = (kmer_hash32(val[u]) < a.threshold) && (hp_base + j >= a.trim) && (j < nk);
+            sel[u] = kmer_hash32(val[u]) < a.threshold;
+            if (!INTERIOR) sel[u] = sel[u] && (hp_base + j >= a.trim) && (j < nk);
 #endif
             if (HAS_N) sel[u] = sel[u] && (istream_extract(SI, j < nk ? j : nk - 1u, kbits) == 0u);   // Kmer.hpp:574-580
         }
@@ -383,9 +385,11 @@ struct KmerTrip {
                     const unsigned j = jb + u;
                     const uint32_t p = hp_base + j;
                     if (idx < cap) {
+                        // direction 1 iff the reverse complement is the canonical form, ties included (Kmer.hpp:427)
+                        const uint32_t e = (u == 0 ? a0 : __builtin_amdgcn_alignbit(a1, a0, 2 * u)) & kmask;
                         a.out_min[cap0 + idx] = val[u];
                         a.out_pos[cap0 + idx] = p;
-                        a.out_dir[cap0 + idx] = (uint8_t)dir[u];
+                        a.out_dir[cap0 + idx] = (uint8_t)(val[u] == (e ^ comp_mask) ? 1u : 0u);
                         if (HAS_QUAL) {
                             uint32_t os, oe;   // [rle[pos], rle[pos + K]) in original coordinates, or [.., rle[pos + K - 1]]
                             if (HPC) { os = Q->orig[j]; oe = Q->orig[j + K - a.q_last] + a.q_last; }
@@ -409,11 +413,11 @@ struct KmerTrip {
         return nout;
     }
 };
-// Waves per SIMD the register allocator must allow.  The plain variant (no qualities, no N) fits 80 VGPRs with a
-// 12-byte spill, i.e. 6 waves per SIMD instead of 5: no faster alone, but it leaves room for a second batch's
-// table kernels beside it (+1.5 % with two batches in flight).  The other variants need > 100 VGPRs and are left alone.
+// Waves per SIMD the register allocator must allow for the plain variant (no qualities, no N): it needs 85 VGPRs,
+// i.e. 5 waves.  Forcing 6 (80 VGPRs) costs an 80-byte spill and is slower; the other variants need > 100 VGPRs and
+// are left to the compiler.
 #ifndef SCAN_MIN_WAVES
-#define SCAN_MIN_WAVES 6
+#define SCAN_MIN_WAVES 5
 #endif
 
 template <bool HPC, bool HAS_QUAL, bool HAS_N>
@@ -595,11 +599,16 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
                 const unsigned left = nk - j0;
                 const unsigned pp = left >= 64u * SCAN_PP ? (unsigned)SCAN_PP : (left + 63u) / 64u;
                 KmerTrip<HPC, HAS_QUAL, HAS_N> trip{a, S, SI, Q, K, kmask, kbits, comp_mask, lane, nk, hp_base, cb, tile_base, cap0, cap, r};
-                switch (pp) {
-                    case 1: nout = trip.template run<1>(j0, nout); break;
-                    case 2: nout = trip.template run<2>(j0, nout); break;
-                    case 3: nout = trip.template run<3>(j0, nout); break;
-                    default: nout = trip.template run<4>(j0, nout); break;
+                // full trips are interior unless this is the trimmed start of the read
+                if (pp == (unsigned)SCAN_PP && left >= 64u * SCAN_PP && hp_base + j0 >= a.trim) {
+                    nout = trip.template run<SCAN_PP, true>(j0, nout);
+                } else {
+                    switch (pp) {
+                        case 1: nout = trip.template run<1, false>(j0, nout); break;
+                        case 2: nout = trip.template run<2, false>(j0, nout); break;
+                        case 3: nout = trip.template run<3, false>(j0, nout); break;
+                        default: nout = trip.template run<4, false>(j0, nout); break;
+                    }
                 }
             }
 
