@@ -15,13 +15,14 @@ timeout 600 python bench.py > $OUT/bench_stdout.json 2> $OUT/bench_stderr.log
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/kt -o kt -- python $ROOT/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $ROOT/$OUT/kt_bench.json 2> $ROOT/$OUT/kt.err )
 python tools/rocpd_summary.py $OUT/kt/kt_results.db > $OUT/bench_kernel_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$OUT/pmc_$c -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $ROOT/$OUT/pmc_$c.err )
+  # one batch in flight: the counters are device-wide while the kernel runs, a second batch's kernels would be counted too
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$OUT/pmc_$c -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 --in-flight 1 > /dev/null 2> $ROOT/$OUT/pmc_$c.err )
   python tools/rocpd_summary.py $OUT/pmc_$c/p_results.db > $OUT/pmc_$c.txt 2>&1
 done
 : > $OUT/pmc_sq.txt
 for c in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   n=$(echo $c | tr " " "_")
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$OUT/sq_$n -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $ROOT/$OUT/sq_$n.err )
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$OUT/sq_$n -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 --in-flight 1 > /dev/null 2> $ROOT/$OUT/sq_$n.err )
   python tools/rocpd_summary.py $OUT/sq_$n/p_results.db 2>&1 | grep "n=" | grep scan_kernel >> $OUT/pmc_sq.txt
 done
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/sq_*/   # keep the text, not the 64 MiB of databases
