@@ -5,11 +5,13 @@
 //   1. every lane holds one u64 word (32 bases); run-start flags for homopolymer compression come
 //      from a bit trick on the packed word (x ^ (x<<2 | prev base)), a wave prefix sum of their
 //      popcounts gives each lane its offset in the compressed stream        [EncoderRLE, Commons.hpp:4163-4203]
-//   2. lanes squeeze their kept bases to contiguous 2-bit fields and OR them into a per-wave LDS
-//      bit stream (carry of the last K bases from the previous tile in front)
-//   3. lanes take k-mers j = lane, lane+64, ...: one ds_read2 + v_alignbit extracts the K bases
-//      LSB-first (E); revcomp = E ^ 0xAAAA.., forward = digit-reverse(E); canonical = min;
-//      closed-form 8-byte Murmur3 (seed 42) and an integer threshold replace the double compare
+//   2. lanes squeeze their kept bases to contiguous 2-bit fields (a 1024-entry LDS table: 5 bases per
+//      look-up) and OR them into a per-wave LDS bit stream (carry of the last K bases from the
+//      previous tile in front)
+//   3. lanes take 4 adjacent k-mers per trip: one 3-word LDS read + v_alignbit extracts the bases
+//      LSB-first (E); revcomp = E ^ 0xAAAA.., forward = digit-reverse(E) once, then one shift-in per
+//      position; canonical = min; closed-form 8-byte Murmur3 (seed 42) on explicit 32-bit halves and
+//      an integer threshold replace the u64-vs-double compare
 //                                                           [KmerModel::iterate + MinimizerParser::parse,
 //                                                            utils/kmer/Kmer.hpp:531-611, :1373-1456]
 //   4. selected lanes are compacted in position order with ballot + popcount.
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
     const uint32_t kbits = (1u << K) - 1u;
     const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
 
-    // reads are dealt round-robin to the resident waves (grid-stride)
+    // a wave takes a few reads and retires (launch_variant sizes the grid); written as a grid-stride loop
     const uint32_t wave_global = (blockIdx.x * SCAN_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SCAN_BLOCK) >> 6;
     for (uint32_t slot = wave_global; slot < a.n_reads; slot += n_waves) {
