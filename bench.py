@@ -144,7 +144,9 @@ def main() -> None:
     # on slot i % IN_FLIGHT; every step is still the complete pass over one batch.
     n_slots = max(1, args.in_flight)
     slots = []
-    spec = synth.hifi_spec(args.reads * world, seed=42, read_len=args.read_len, coverage=50.0)   # one metagenome for the job
+    # one metagenome for the job (MDBG_BENCH_SPEC_RANKS: test hook, the per-rank workload of an N-rank job on one GPU)
+    spec_ranks = int(os.environ.get("MDBG_BENCH_SPEC_RANKS", world))
+    spec = synth.hifi_spec(args.reads * spec_ranks, seed=42, read_len=args.read_len, coverage=50.0)
     for _ in range(n_slots):
         c = capi.Context(local_rank)
         slots.append((c, c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)))   # rank r owns reads [r*n, (r+1)*n)
