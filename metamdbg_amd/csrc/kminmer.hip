@@ -1078,12 +1078,20 @@ extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     if (!ctx || !sh || !d_reply || (n_recv && !d_recv)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_reduce: bad argument");
     if (n_recv >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 received rows");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    MDBG_TRY(sh->owner.init(ctx, n_recv * 2 + 1024));
+    // every key this rank owns arrives once from each rank that saw it: about n_recv / n_ranks distinct keys.  Sized for
+    // that (+50 %), the table is n_ranks times smaller than one sized for the rows; it grows and refills if that was short.
+    const uint64_t expected = n_recv / sh->n_ranks + n_recv / (2 * sh->n_ranks) + 1024;
+    MDBG_TRY(build_table_adaptive(ctx, sh->owner, expected < n_recv ? expected : n_recv, n_recv, [&](TableView v) {
+        if (n_recv) {
+            LaunchTimer timer(ctx, "shard_reduce");
+            hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, v);
+        }
+        return MDBG_OK;
+    }));
     TableView tv = sh->owner.view();
     MDBG_TRY(sh->reply.alloc(ctx, n_recv));
     if (n_recv) {
         LaunchTimer timer(ctx, "shard_reduce");
-        hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, tv);
         hipLaunchKernelGGL(rows_reply_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, tv, sh->reply.p);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
