@@ -65,6 +65,9 @@ int  mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, 
  * read r occupies words[word_offsets[r] .. word_offsets[r+1]) and starts on an even word. */
 int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
                             const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out);
+/* Phred+33 qualities (Read::_qual) for reads made by mdbg_reads_from_packed: read r = quals[offsets[r] .. offsets[r+1]),
+ * offsets[r+1] - offsets[r] must equal its length.  Once per reads object. */
+int  mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *reads, const char *quals, const uint64_t *offsets);
 /* Seeded synthetic read set generated directly in HBM (bench/test harness; same generator as
  * metamdbg_amd/synth.py).  thresholds[s] = cumulative species weight as u64. */
 int  mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,

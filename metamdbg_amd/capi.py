@@ -45,6 +45,7 @@ SIGNATURES = {
     "mdbg_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), _u64p]),
     "mdbg_reads_from_ascii": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_from_packed": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_reads_attach_qualities": (C.c_int, [_P, _P, C.c_char_p, _u64p]),
     "mdbg_reads_synthetic": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, C.c_uint32,
                                        C.c_uint64, C.c_int, C.POINTER(_P)]),
     "mdbg_reads_info": (C.c_int, [_P, _u32p, _u64p, _u64p]),
@@ -158,12 +159,16 @@ class Context:
         self.check(lib().mdbg_reads_from_ascii(self.h, bases, q, _ptr(offs), len(seqs), C.byref(h)))
         return Reads(self, h)
 
-    def reads_from_packed(self, words: np.ndarray, word_off: np.ndarray, lens: np.ndarray) -> "Reads":
+    def reads_from_packed(self, words: np.ndarray, word_off: np.ndarray, lens: np.ndarray, quals: list[bytes] | None = None) -> "Reads":
         words = np.ascontiguousarray(words, dtype=np.uint64)
         word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         h = C.c_void_p()
         self.check(lib().mdbg_reads_from_packed(self.h, _ptr(words), _ptr(word_off), _ptr(lens), len(lens), C.byref(h)))
+        if quals is not None:
+            offs = np.zeros(len(quals) + 1, dtype=np.uint64)
+            np.cumsum([len(q) for q in quals], out=offs[1:])
+            self.check(lib().mdbg_reads_attach_qualities(self.h, h, b"".join(quals), _ptr(offs)))
         return Reads(self, h)
 
     def reads_synthetic(self, spec, first_read: int = 0, n_reads: int | None = None) -> "Reads":

@@ -205,6 +205,29 @@ extern "C" int mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, cons
     return MDBG_OK;
 }
 
+extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets) {
+    if (!ctx || !r || (r->n_reads && (!quals || !offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities: null argument");
+    if (r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities: the reads already carry qualities");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = r->n_reads;
+    if (!n) return MDBG_OK;
+    std::vector<uint32_t> lens(n);
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, lens.data(), r->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; i++) rel[i] = offsets[i] - offsets[0];
+    for (uint32_t i = 0; i < n; i++)
+        if (rel[i + 1] - rel[i] != lens[i]) return set_error(ctx, MDBG_EINVAL, "read %u: %llu qualities for %u bases", i,
+                                                            (unsigned long long)(rel[i + 1] - rel[i]), lens[i]);
+    const uint64_t nb = rel[n];
+    MDBG_TRY(r->d_qual.alloc(ctx, nb));
+    MDBG_TRY(r->d_qual_off.alloc(ctx, (size_t)n + 1));
+    if (nb) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(r->d_qual.p, quals + offsets[0], nb, hipMemcpyHostToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(r->d_qual_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    r->has_qual = true;
+    return MDBG_OK;
+}
+
 extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,
                                     uint64_t first_read, const uint64_t *species_len,
                                     const uint64_t *species_threshold, uint32_t n_species,

@@ -31,15 +31,84 @@
 namespace mdbg_host {
 
 struct ReadBatch {
-    char *bases = nullptr;      // page-locked, `cap` bytes
+    char *bases = nullptr;      // page-locked, `cap` bytes: ASCII bases, or (packed) the 2-bit words of the device layout
     char *quals = nullptr;      // page-locked, `cap` bytes
     size_t cap = 0;
     size_t nbases = 0;
-    std::vector<uint64_t> offsets{0};
+    std::vector<uint64_t> offsets{0};     // base offsets of the reads (also the offsets of the qualities)
     bool hasQual = false;
+    // packed == true: `bases` holds u64 words, 32 bases each (base i at bits [2i, 2i+2), code (c >> 1) & 3), read r in
+    // words [wordOff[r], wordOff[r+1]) starting on an even word -- what mdbg_reads_from_packed takes.  Workers pack
+    // while they parse (a quarter of the PCIe bytes); a chunk holding a character with bit 3 set (N, n, ...) or too
+    // many tiny reads for the buffer is delivered as ASCII instead.
+    bool packed = false;
+    std::vector<uint64_t> wordOff{0};
+    std::vector<uint32_t> lens;
     int file = 0;
     uint32_t n() const { return (uint32_t)(offsets.size() - 1); }
-    void clear() { nbases = 0; offsets.assign(1, 0); hasQual = false; }
+    const uint64_t *words() const { return reinterpret_cast<const uint64_t *>(bases); }
+    void clear() { nbases = 0; offsets.assign(1, 0); hasQual = false; packed = false; wordOff.assign(1, 0); lens.clear(); }
+};
+
+// ---- 2-bit packing of ASCII bases on the host -------------------------------------------------------------------
+// 8 characters -> 16 bits.  code = (c >> 1) & 3 (utils/kmer/Kmer.hpp:462); bit 3 of a character marks it invalid.
+inline uint64_t pack8_swar(uint64_t x) {
+    uint64_t y = (x >> 1) & 0x0303030303030303ull;
+    y = (y | (y >> 6)) & 0x000F000F000F000Full;
+    y = (y | (y >> 12)) & 0x000000FF000000FFull;
+    return (y | (y >> 24)) & 0xFFFFull;
+}
+#if defined(__x86_64__)
+__attribute__((target("bmi2"))) inline uint64_t pack8_pext(uint64_t x) { return __builtin_ia32_pext_di(x >> 1, 0x0303030303030303ull); }
+inline bool have_bmi2() { static const bool v = __builtin_cpu_supports("bmi2"); return v; }
+#else
+inline uint64_t pack8_pext(uint64_t x) { return pack8_swar(x); }
+inline bool have_bmi2() { return false; }
+#endif
+
+// Appends bases to a stream of u64 words.  `invalid` collects bit 3 of every character seen.
+struct PackCursor {
+    uint64_t *words;      // destination
+    size_t capWords;
+    size_t w = 0;         // current word
+    unsigned fill = 0;    // bases already in words[w] (0..31)
+    uint64_t cur = 0;
+    uint64_t invalid = 0;
+    bool overflow = false;
+
+    template <bool PEXT>
+    void append_impl(const char *p, size_t n) {
+        // head: byte-wise until the word boundary
+        while (n && fill) { push1((unsigned char)*p++); n--; }
+        if (overflow) return;
+        // body: 32 characters -> one word
+        while (n >= 32) {
+            if (w >= capWords) { overflow = true; return; }
+            uint64_t x0, x1, x2, x3;
+            memcpy(&x0, p, 8); memcpy(&x1, p + 8, 8); memcpy(&x2, p + 16, 8); memcpy(&x3, p + 24, 8);
+            invalid |= (x0 | x1 | x2 | x3);
+            const uint64_t a = PEXT ? pack8_pext(x0) : pack8_swar(x0), b = PEXT ? pack8_pext(x1) : pack8_swar(x1);
+            const uint64_t c = PEXT ? pack8_pext(x2) : pack8_swar(x2), d = PEXT ? pack8_pext(x3) : pack8_swar(x3);
+            words[w++] = a | (b << 16) | (c << 32) | (d << 48);
+            p += 32; n -= 32;
+        }
+        while (n) { push1((unsigned char)*p++); n--; }
+    }
+    void append(const char *p, size_t n) { if (have_bmi2()) append_impl<true>(p, n); else append_impl<false>(p, n); }
+    void push1(unsigned char c) {
+        invalid |= c;
+        cur |= (uint64_t)((c >> 1) & 3u) << (2 * fill);
+        if (++fill == 32) {
+            if (w >= capWords) { overflow = true; fill = 0; cur = 0; return; }
+            words[w++] = cur; cur = 0; fill = 0;
+        }
+    }
+    // end of a read: flush the partial word and pad with zero words to a 64-base unit (two words)
+    void end_read() {
+        if (fill) { if (w >= capWords) { overflow = true; } else words[w++] = cur; cur = 0; fill = 0; }
+        if (w & 1) { if (w >= capWords) overflow = true; else words[w++] = 0; }
+    }
+    bool bad() const { return overflow || (invalid & 0x0808080808080808ull) != 0; }
 };
 
 class ReadFeeder {
@@ -52,14 +121,15 @@ public:
           fileDone_(files_.size() ? files_.size() : 1) {
         for (auto &f : fileDone_) f.store(false);
         if (threads < 1) threads = 1;
-        // parsing is memcpy-bound (4 workers deliver ~7 GB/s) and page-locking memory costs ~1 ms per MB:
-        // more workers / buffers only add start-up time
-        if (threads > 6) threads = 6;
+        // Page-locking memory costs ~1 ms per MB, so buffers are kept few and small: a worker that packs to 2 bits needs a
+        // quarter of the chunk (+ padding of every read to a 64-base unit), which pays for 12 packing workers where 6
+        // copying ones were the limit; a buffer grows to the full chunk only if its chunk has to be delivered as ASCII.
+        if (threads > (pack_ ? 12 : 6)) threads = pack_ ? 12 : 6;
         alloc_ = std::move(alloc);
         const int nbuf = threads + 2;
         for (int i = 0; i < nbuf; i++) {
             ReadBatch *b = new ReadBatch();
-            b->cap = chunk_ + 64;
+            b->cap = pack_ ? chunk_ / 4 + chunk_ / 32 + 4096 : chunk_ + 64;
             b->bases = (char *)alloc_(b->cap);      // quality buffers are allocated on first use (FASTQ only)
             if (!b->bases) throw std::runtime_error("page-locked batch allocation failed");
             all_.push_back(b);
@@ -101,7 +171,10 @@ public:
                 if ((size_t)b->file >= perFile_.size()) perFile_.resize(b->file + 1, 0);
                 uint64_t &seen = perFile_[b->file];
                 const uint64_t allowed = maxReads_ + 1 > seen ? maxReads_ + 1 - seen : 0;
-                if (b->n() > allowed) { b->offsets.resize(allowed + 1); b->nbases = b->offsets.back(); }
+                if (b->n() > allowed) {
+                    b->offsets.resize(allowed + 1); b->nbases = b->offsets.back();
+                    if (b->packed) { b->wordOff.resize(allowed + 1); b->lens.resize(allowed); }
+                }
                 seen += b->n();
                 if (seen >= maxReads_ + 1) fileDone_[b->file].store(true);   // later chunks of this file are skipped
             }
@@ -248,9 +321,9 @@ private:
                 b->file = file;
             }
             b->hasQual = hq;
+            need_ascii_capacity(b);
             memcpy(b->bases + b->nbases, s.data(), s.size());
-            if (hq && !b->quals) { b->quals = (char *)alloc_(b->cap); if (!b->quals) throw std::runtime_error("page-locked batch allocation failed"); }
-            if (hq) memcpy(b->quals + b->nbases, q.data(), s.size());
+            if (hq) { need_quals(b); memcpy(b->quals + b->nbases, q.data(), s.size()); }
             b->nbases += s.size();
             b->offsets.push_back(b->nbases);
         }
@@ -258,10 +331,75 @@ private:
         return seq;
     }
 
+    void need_quals(ReadBatch *b) {
+        if (!b->quals) { b->quals = (char *)alloc_(chunk_ + 64); if (!b->quals) throw std::runtime_error("page-locked batch allocation failed"); }
+    }
+    void need_ascii_capacity(ReadBatch *b) {
+        if (b->cap >= chunk_ + 64) return;
+        free_(b->bases);
+        b->cap = chunk_ + 64;
+        b->bases = (char *)alloc_(b->cap);
+        if (!b->bases) throw std::runtime_error("page-locked batch allocation failed");
+    }
+
+    // Same walk over the records as parse(), bases packed to 2 bits on the way.  false = deliver this chunk as ASCII.
+    bool parse_packed(const Work &w, ReadBatch *b) {
+        b->file = w.file;
+        b->hasQual = w.fastq;
+        if (w.fastq) need_quals(b);
+        PackCursor pc{reinterpret_cast<uint64_t *>(b->bases), b->cap / 8};
+        const char *p = w.begin, *end = w.end;
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));   // header line
+            if (!nl) break;
+            p = nl + 1;
+            size_t len = 0;
+            if (!w.fastq) {
+                while (p < end && *p != '>') {
+                    nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    const char *le = nl ? nl : end;
+                    size_t n = (size_t)(le - p);
+                    if (n && p[n - 1] == '\r') n--;
+                    pc.append(p, n);
+                    len += n;
+                    p = nl ? nl + 1 : end;
+                }
+            } else {
+                nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                const char *le = nl ? nl : end;
+                size_t n = (size_t)(le - p);
+                if (n && p[n - 1] == '\r') n--;
+                pc.append(p, n);
+                len = n;
+                p = nl ? nl + 1 : end;
+                if (p >= end || *p != '+') throw std::runtime_error("FASTQ records are not 4-line; unwrap or gzip the file");
+                nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                if (!nl) throw std::runtime_error("truncated FASTQ record");
+                p = nl + 1;
+                nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                le = nl ? nl : end;
+                size_t nq = (size_t)(le - p);
+                if (nq && p[nq - 1] == '\r') nq--;
+                if (nq != n) throw std::runtime_error("FASTQ quality length differs from sequence length");
+                memcpy(b->quals + b->nbases, p, n);
+                p = nl ? nl + 1 : end;
+            }
+            pc.end_read();
+            if (pc.bad() || len > 0xFFFFFFF0ull) return false;
+            b->nbases += len;
+            b->offsets.push_back(b->nbases);
+            b->wordOff.push_back(pc.w);
+            b->lens.push_back((uint32_t)len);
+        }
+        b->packed = true;
+        return true;
+    }
+
     void parse(const Work &w, ReadBatch *b) {
         b->file = w.file;
         b->hasQual = w.fastq;
-        if (w.fastq && !b->quals) { b->quals = (char *)alloc_(b->cap); if (!b->quals) throw std::runtime_error("page-locked batch allocation failed"); }
+        if (w.fastq) need_quals(b);
+        need_ascii_capacity(b);
         const char *p = w.begin, *end = w.end;
         while (p < end) {
             const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));   // header line
@@ -320,7 +458,9 @@ private:
                     freeList_.pop_back();
                 }
                 cvFree_.notify_all();   // the sequential gzip reader waits for an empty work queue
-                if (!fileDone_[w.file].load()) parse(w, b); else b->file = w.file;
+                if (!fileDone_[w.file].load()) {
+                    if (!pack_ || !parse_packed(w, b)) { b->clear(); parse(w, b); }
+                } else b->file = w.file;
                 deliver(w.seq, b);
             }
         } catch (const std::exception &e) { fail(e.what()); }
@@ -351,6 +491,7 @@ private:
     std::vector<std::thread> workers_;
     uint64_t nextSeq_ = 0, totalSeq_ = 0;
     bool splitDone_ = false, stop_ = false;
+    bool pack_ = getenv("MDBG_HOST_NO_PACK") == nullptr;   // pack to 2 bits on the host unless asked not to
     std::string error_;
 };
 

@@ -182,6 +182,18 @@ void for_each_batch(const std::string &inputList, size_t batchBases, int threads
     } catch (const std::exception &e) { die(e.what()); }
 }
 
+// a parsed batch -> reads in HBM: 2-bit words when the feeder packed the chunk, ASCII (packed on the device) otherwise
+mdbg_reads *upload_batch(ReadBatch &b, bool withQual) {
+    mdbg_reads *reads = nullptr;
+    if (b.packed) {
+        check(mdbg_reads_from_packed(g_ctx, b.words(), b.wordOff.data(), b.lens.data(), b.n(), &reads), "mdbg_reads_from_packed");
+        if (withQual && b.hasQual) check(mdbg_reads_attach_qualities(g_ctx, reads, b.quals, b.offsets.data()), "mdbg_reads_attach_qualities");
+    } else {
+        check(mdbg_reads_from_ascii(g_ctx, b.bases, withQual && b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+    }
+    return reads;
+}
+
 mdbg_scan_params scan_params(const Parameters &P, float density, const std::vector<uint32_t> &rep, float minQ, bool filters) {
     mdbg_scan_params p{};
     p.minimizer_size = (uint32_t)P.minimizerSize;
@@ -214,7 +226,7 @@ int run_read_selection(int argc, char **argv) {
             for_each_batch(inputList, a.batchBases, a.threads, 1000000, [&](ReadBatch &b) {
                 mdbg_reads *reads = nullptr;
                 mdbg_minimizers *mins = nullptr;
-                check(mdbg_reads_from_ascii(g_ctx, b.bases, nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+                reads = upload_batch(b, false);
                 mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
                 check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
                 uint32_t n; uint64_t t;
@@ -304,7 +316,7 @@ int run_read_selection(int argc, char **argv) {
         tWait += t0 - tLast;                      // time this thread waited for the feeder
         mdbg_reads *reads = nullptr;
         mdbg_minimizers *mins = nullptr;
-        check(mdbg_reads_from_ascii(g_ctx, b.bases, b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+        reads = upload_batch(b, true);
         double t1 = g_trace.now();
         mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
         check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");

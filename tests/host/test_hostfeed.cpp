@@ -1,5 +1,7 @@
 // CPU check of metamdbg_amd/host/hostfeed.hpp: the parallel chunked reader must deliver exactly the
-// reads (bases, qualities, order) the sequential kseq-style reader (fastx.hpp) delivers.
+// reads (bases, qualities, order) the sequential kseq-style reader (fastx.hpp) delivers.  Batches the workers packed
+// to 2 bits are compared through the base codes ((c >> 1) & 3), must follow the device layout (reads on even words,
+// zero padding) and must never contain a character with bit 3 set -- those chunks have to arrive as ASCII.
 //   test_hostfeed <chunkBytes> <threads> <maxReadsPerFile> file...
 #include <cstdio>
 #include <cstdlib>
@@ -29,15 +31,33 @@ int main(int argc, char **argv) {
             expQual.push_back(hq ? q : std::string());
         }
     }
-    size_t i = 0, nbatches = 0;
+    size_t i = 0, nbatches = 0, npacked = 0;
     try {
         mdbg_host::ReadFeeder feeder(files, chunk, threads, maxReads, [](size_t n) { return malloc(n); }, [](void *p) { free(p); });
         while (mdbg_host::ReadBatch *b = feeder.next()) {
             nbatches++;
+            if (b->packed) {
+                npacked++;
+                if (b->wordOff.size() != (size_t)b->n() + 1 || b->lens.size() != b->n()) { fprintf(stderr, "packed batch: bad index sizes\n"); return 1; }
+            }
             for (uint32_t r = 0; r < b->n(); r++, i++) {
                 if (i >= expSeq.size()) { fprintf(stderr, "too many reads\n"); return 1; }
-                std::string s(b->bases + b->offsets[r], b->bases + b->offsets[r + 1]);
-                if (s != expSeq[i]) { fprintf(stderr, "read %zu differs (len %zu vs %zu)\n", i, s.size(), expSeq[i].size()); return 1; }
+                if (b->packed) {
+                    const std::string &e = expSeq[i];
+                    const uint64_t w0 = b->wordOff[r], w1 = b->wordOff[r + 1];
+                    if (b->lens[r] != e.size() || (w0 & 1) || w1 - w0 != ((e.size() + 63) / 64) * 2 || b->offsets[r + 1] - b->offsets[r] != e.size()) {
+                        fprintf(stderr, "packed read %zu: bad layout\n", i); return 1;
+                    }
+                    for (size_t k = 0; k < (w1 - w0) * 32; k++) {
+                        const unsigned got = (unsigned)((b->words()[w0 + k / 32] >> (2 * (k % 32))) & 3u);
+                        const unsigned want = k < e.size() ? (((unsigned char)e[k] >> 1) & 3u) : 0u;
+                        if (k < e.size() && ((unsigned char)e[k] & 8u)) { fprintf(stderr, "packed read %zu holds an invalid character\n", i); return 1; }
+                        if (got != want) { fprintf(stderr, "packed read %zu differs at base %zu\n", i, k); return 1; }
+                    }
+                } else {
+                    std::string s(b->bases + b->offsets[r], b->bases + b->offsets[r + 1]);
+                    if (s != expSeq[i]) { fprintf(stderr, "read %zu differs (len %zu vs %zu)\n", i, s.size(), expSeq[i].size()); return 1; }
+                }
                 if (b->hasQual) {
                     std::string q(b->quals + b->offsets[r], b->quals + b->offsets[r + 1]);
                     if (q != expQual[i]) { fprintf(stderr, "qual %zu differs\n", i); return 1; }
@@ -47,6 +67,6 @@ int main(int argc, char **argv) {
         }
     } catch (const std::exception &e) { fprintf(stderr, "exception: %s\n", e.what()); return 3; }
     if (i != expSeq.size()) { fprintf(stderr, "got %zu reads, expected %zu\n", i, expSeq.size()); return 1; }
-    printf("ok %zu reads %zu batches\n", i, nbatches);
+    printf("ok %zu reads %zu batches %zu packed\n", i, nbatches, npacked);
     return 0;
 }

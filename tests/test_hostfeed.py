@@ -54,6 +54,15 @@ def files(tmp_path_factory):
             q[-1] = ord("+") if i % 5 == 0 else q[-1]
             f.write(b"@q%d\n" % i + _rand_seq(rng, n) + b"\n+\n" + bytes(q) + b"\n")
     out["fastq"] = p
+    # FASTA with N / lower-case n in a few reads: those chunks must come through as ASCII, the others packed
+    p = str(d / "with_n.fasta")
+    with open(p, "wb") as f:
+        for i in range(600):
+            sq = bytearray(_rand_seq(rng, int(rng.integers(200, 3000))))
+            if i in (17, 400, 401):
+                sq[len(sq) // 2] = ord("N") if i != 401 else ord("n")
+            f.write(b">n%d\n" % i + bytes(sq) + b"\n")
+    out["with_n"] = p
     # gzipped FASTA
     p = str(d / "z.fasta.gz")
     with gzip.open(p, "wb") as f:
@@ -78,3 +87,17 @@ def test_per_file_read_cap(exe, files):
     r = subprocess.run([exe, "20000", "3", "100", files["single"], files["fastq"], files["gz"]], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("ok 303 reads")      # 101 reads of each file (readIndexPerDataset > maxReads stops a file)
+
+
+def test_packed_and_ascii_batches(exe, files):
+    """Workers pack chunks to 2 bits unless a character with bit 3 set shows up (then the chunk is delivered as ASCII)."""
+    r = subprocess.run([exe, "20000", "3", "0", files["with_n"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    toks = r.stdout.split()          # ok <reads> reads <batches> batches <packed> packed
+    n_batches, n_packed = int(toks[3]), int(toks[5])
+    assert toks[1] == "600" and 0 < n_packed < n_batches and n_batches - n_packed <= 3
+    r = subprocess.run([exe, "20000", "3", "0", files["single"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.split()[3] == r.stdout.split()[5]          # all packed
+    r = subprocess.run([exe, "20000", "3", "0", files["single"]], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, MDBG_HOST_NO_PACK="1"))
+    assert r.returncode == 0 and r.stdout.split()[5] == "0"
