@@ -616,3 +616,20 @@ def test_extreme_reads(ctx, orc):
         _check_scan_against_oracle(ctx, orc, seqs, None, 16, 0.005, hpc)
     _check_scan_against_oracle(ctx, orc, [rnd(20000), rnd(64), rnd(9000)], None, 15, 0.99, True)    # nearly every position selected
     _check_scan_against_oracle(ctx, orc, [rnd(20000), rnd(64), rnd(9000)], None, 8, 1.0, False)     # density 1: threshold saturates
+
+
+def test_packed_upload_with_qualities_equals_ascii(ctx):
+    """mdbg_reads_from_packed + mdbg_reads_attach_qualities (what the host feed sends) == mdbg_reads_from_ascii."""
+    rng = np.random.default_rng(21)
+    codes = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in (1, 63, 64, 65, 700, 5000, 31, 2048)]
+    seqs = [bytes(synth.CODE2ASCII[c]) for c in codes]
+    quals = [bytes((rng.integers(0, 50, len(s)) + 33).astype(np.uint8)) for s in seqs]
+    words, woff, lens = synth.pack_reads(codes)
+    a = ctx.scan(ctx.reads_from_ascii(seqs, quals), K=13, density=0.05, hpc=True).to_host()
+    b = ctx.scan(ctx.reads_from_packed(words, woff, lens, quals), K=13, density=0.05, hpc=True).to_host()
+    for key in a:
+        assert np.array_equal(a[key], b[key]) or (key == "mean_quality" and _nan_eq(a[key], b[key])), key
+    assert formats.build_read_data_init(a) == formats.build_read_data_init(b)
+    from metamdbg_amd import capi
+    with pytest.raises(capi.MdbgError):      # one quality per base
+        ctx.reads_from_packed(words, woff, lens, [q[:-1] if len(q) > 5 else q for q in quals])
