@@ -12,7 +12,13 @@
  * owned by the library and released with the matching *_free; a context is bound to one HIP
  * device and one stream and is not thread-safe (use one context per host thread / stream,
  * as the reference uses one functor copy per OpenMP thread: Commons.hpp:5846-5914).
+ * Several contexts on one device may be driven concurrently from several threads; that is the intended way to keep
+ * two batches in flight (the table kernels of one batch overlap the scan of the next -- bench.py).
+ * mdbg_scan calls on the same device take turns: one scan kernel runs at a time.
  * There is no CPU fallback: without a usable GPU every call fails with MDBG_ENODEV.
+ *
+ * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE (default 4) -- reads a scan wave processes before it
+ * retires; MDBG_TRACE -- one line per purge with the number of suspect reads.
  */
 #ifndef MDBG_HIP_H
 #define MDBG_HIP_H
