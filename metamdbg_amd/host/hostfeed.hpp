@@ -60,7 +60,7 @@ inline uint64_t pack8_swar(uint64_t x) {
 }
 #if defined(__x86_64__)
 __attribute__((target("bmi2"))) inline uint64_t pack8_pext(uint64_t x) { return __builtin_ia32_pext_di(x >> 1, 0x0303030303030303ull); }
-inline bool have_bmi2() { static const bool v = __builtin_cpu_supports("bmi2"); return v; }
+inline bool have_bmi2() { static const bool v = __builtin_cpu_supports("bmi2") && !getenv("MDBG_HOST_NO_BMI2"); return v; }
 #else
 inline uint64_t pack8_pext(uint64_t x) { return pack8_swar(x); }
 inline bool have_bmi2() { return false; }

@@ -101,3 +101,8 @@ def test_packed_and_ascii_batches(exe, files):
     r = subprocess.run([exe, "20000", "3", "0", files["single"]], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, MDBG_HOST_NO_PACK="1"))
     assert r.returncode == 0 and r.stdout.split()[5] == "0"
+    # the portable (no BMI2 pext) packing path
+    for key in ("single", "wrapped", "fastq", "with_n"):
+        r = subprocess.run([exe, "10000", "2", "0", files[key]], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, MDBG_HOST_NO_BMI2="1"))
+        assert r.returncode == 0 and int(r.stdout.split()[5]) > 0, (key, r.stderr)
