@@ -605,12 +605,18 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
                 if (pp == (unsigned)SCAN_PP && left >= 64u * SCAN_PP && hp_base + j0 >= a.trim) {
                     nout = trip.template run<SCAN_PP, true>(j0, nout);
                 } else {
+#if SCAN_PP <= 4
                     switch (pp) {
                         case 1: nout = trip.template run<1, false>(j0, nout); break;
                         case 2: nout = trip.template run<2, false>(j0, nout); break;
                         case 3: nout = trip.template run<3, false>(j0, nout); break;
                         default: nout = trip.template run<4, false>(j0, nout); break;
                     }
+#else
+                    if (pp <= 2) nout = trip.template run<2, false>(j0, nout);
+                    else if (pp <= 4) nout = trip.template run<4, false>(j0, nout);
+                    else nout = trip.template run<SCAN_PP, false>(j0, nout);
+#endif
                 }
             }
 
