@@ -187,6 +187,10 @@ int  mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_
  * logs it.  Fetch the 16-byte records with mdbg_table_keys_to_host (u128 little-endian: lo, hi). */
 int  mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum);
 int  mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_lo_hi);
+/* Replaces UnitigEdgeIndexer::partitionEdges + dereplicatePartitions (graph/CreateMdbg.hpp:4234-4512): the distinct
+ * (k-1)-prefix/suffix identities of the FIRST and LAST k-min-mer of every unitig of unitigGraph.nodes.bin (uploaded as
+ * minimizer-space sequences; sequences shorter than k contribute nothing).  *checksum as in mdbg_edge_index (may be NULL). */
+int  mdbg_unitig_edge_index(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, mdbg_table **edges, uint64_t *checksum);
 void mdbg_table_free(mdbg_table *t);
 
 /* Page-locked host memory for read batches handed to mdbg_reads_from_ascii / _from_packed: uploads from it

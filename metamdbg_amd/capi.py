@@ -73,6 +73,7 @@ SIGNATURES = {
     "mdbg_table_to_host": (C.c_int, [_P, _P, _P, _P]),
     "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
     "mdbg_edge_index": (C.c_int, [_P, _P, C.POINTER(_P), _u64p]),
+    "mdbg_unitig_edge_index": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P), _u64p]),
     "mdbg_table_keys_to_host": (C.c_int, [_P, _P, _P]),
     "mdbg_table_free": (None, [_P]),
     "mdbg_row_words": (C.c_uint32, [C.c_uint32]),
@@ -249,6 +250,13 @@ class Context:
         h = C.c_void_p()
         ck = C.c_uint64()
         self.check(lib().mdbg_edge_index(self.h, nodes.h, C.byref(h), C.byref(ck)))
+        return Table(self, h), ck.value
+
+    def unitig_edge_index(self, unitigs: "Minimizers", k: int) -> tuple["Table", int]:
+        """UnitigEdgeIndexer: distinct prefix/suffix identities of the first and last k-min-mer of every unitig."""
+        h = C.c_void_p()
+        ck = C.c_uint64()
+        self.check(lib().mdbg_unitig_edge_index(self.h, unitigs.h, k, C.byref(h), C.byref(ck)))
         return Table(self, h), ck.value
 
     # -- sharded first pass (one process per GPU) ---------------------------------------------------

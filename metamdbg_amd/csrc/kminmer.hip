@@ -422,6 +422,29 @@ __global__ __launch_bounds__(256) void edge_insert_kernel(const uint32_t *vecs, 
     table_upsert_count(t, lo, hi, 0u, 0u);
 }
 
+// UnitigEdgeIndexer::partitionUnitig (graph/CreateMdbg.hpp:4352-4389): the same two identities for the first and
+// the last k-min-mer of every unitig (the last one skipped when it is the first).  The reference normalises the node
+// before taking prefix and suffix; the pair {prefix, suffix} of a vector and of its reverse are each other's reverses,
+// and every identity is taken on the normalised (k-1)-vector, so the orientation of the node does not matter.
+__global__ __launch_bounds__(256) void unitig_edge_insert_kernel(const uint64_t *off, uint32_t n_unitigs, const uint32_t *mins, uint32_t k, TableView t) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_unitigs) return;
+    const uint64_t f = off[i], n = off[i + 1] - f;
+    if (n < k) return;
+    uint64_t hi, lo;
+    const uint32_t *v = mins + f;
+    window_hash(v, k - 1, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, 0u);
+    window_hash(v + 1, k - 1, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, 0u);
+    if (n == k) return;
+    v = mins + f + (n - k);
+    window_hash(v, k - 1, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, 0u);
+    window_hash(v + 1, k - 1, hi, lo);
+    table_upsert_count(t, lo, hi, 0u, 0u);
+}
+
 __global__ __launch_bounds__(256) void sum_u64_kernel(const uint64_t *v, uint64_t n, unsigned long long *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t x = i < n ? v[i] : 0;
@@ -851,19 +874,8 @@ extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint6
     return MDBG_OK;
 }
 
-extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum) {
-    if (!ctx || !nodes || !edges) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: null argument");
-    if (!nodes->has_vectors || nodes->k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: needs a table with vectors (k <= firstK+1)");
-    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint64_t n = nodes->n_records;
-    DeviceTable tab;
-    MDBG_TRY(build_table_adaptive(ctx, tab, n, 2 * n, [&](TableView v) {
-        if (n) {
-            LaunchTimer timer(ctx, "edge_index");
-            hipLaunchKernelGGL(edge_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, nodes->d_vec.p, n, nodes->k, v);
-        }
-        return MDBG_OK;
-    }));
+// every occupied slot of `tab` becomes a key-only row of a new table of (k-1)-identities
+static int edges_from_table(mdbg_ctx *ctx, DeviceTable &tab, uint32_t k_edge, mdbg_table **edges, uint64_t *checksum, const char *who) {
     TableView tv = tab.view();
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
@@ -875,7 +887,7 @@ extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_tabl
     uint64_t n_rows = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     mdbg_table *t = new mdbg_table();
-    t->k = nodes->k - 1;
+    t->k = k_edge;
     t->n_solid = n_rows;
     int rc = alloc_rows(ctx, t, n_rows, false);
     if (rc) { delete t; return rc; }
@@ -891,9 +903,42 @@ extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_tabl
         if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "edge checksum copy failed: %s", hipGetErrorString(e)); }
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "mdbg_edge_index failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "%s failed: %s", who, hipGetErrorString(e)); }
     *edges = t;
     return MDBG_OK;
+}
+
+extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum) {
+    if (!ctx || !nodes || !edges) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: null argument");
+    if (!nodes->has_vectors || nodes->k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: needs a table with vectors (k <= firstK+1)");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = nodes->n_records;
+    DeviceTable tab;
+    MDBG_TRY(build_table_adaptive(ctx, tab, n, 2 * n, [&](TableView v) {
+        if (n) {
+            LaunchTimer timer(ctx, "edge_index");
+            hipLaunchKernelGGL(edge_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, nodes->d_vec.p, n, nodes->k, v);
+        }
+        return MDBG_OK;
+    }));
+    return edges_from_table(ctx, tab, nodes->k - 1, edges, checksum, "mdbg_edge_index");
+}
+
+extern "C" int mdbg_unitig_edge_index(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, mdbg_table **edges, uint64_t *checksum) {
+    if (!ctx || !edges || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_unitig_edge_index: bad argument");
+    MDBG_TRY(check_seq(ctx, unitigs, "mdbg_unitig_edge_index"));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = unitigs->n_reads;
+    DeviceTable tab;
+    MDBG_TRY(build_table_adaptive(ctx, tab, 2 * n, 4 * n, [&](TableView v) {
+        if (n) {
+            LaunchTimer timer(ctx, "edge_index");
+            hipLaunchKernelGGL(unitig_edge_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, unitigs->d_off.p, (uint32_t)n,
+                               unitigs->d_min.p, k, v);
+        }
+        return MDBG_OK;
+    }));
+    return edges_from_table(ctx, tab, k - 1, edges, checksum, "mdbg_unitig_edge_index");
 }
 
 extern "C" int mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_lo_hi) {

@@ -110,6 +110,22 @@ def write_minimizer_reads(mins: np.ndarray, offs: np.ndarray) -> bytes:
 ABUNDANCE_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<u8"), ("abundance", "<u4")])  # 20 B packed
 
 
+def parse_unitig_nodes(raw: bytes) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """unitigGraph.nodes.bin (graph/CreateMdbg.hpp:4335-4343): records `u32 n; u32 minimizers[n]; u32 unitigIndex`.
+    Returns (minimizers u32[], offsets u64[n_unitigs+1], unitigIndex u32[])."""
+    a = np.frombuffer(raw, dtype="<u4")
+    mins, offs, idx = [], [0], []
+    i = 0
+    while i < len(a):
+        n = int(a[i])
+        mins.append(a[i + 1: i + 1 + n])
+        idx.append(int(a[i + 1 + n]))
+        offs.append(offs[-1] + n)
+        i += n + 2
+    return (np.concatenate(mins).astype(np.uint32) if mins else np.zeros(0, np.uint32),
+            np.asarray(offs, dtype=np.uint64), np.asarray(idx, dtype=np.uint32))
+
+
 def parse_abundance_table(raw: bytes) -> np.ndarray:
     return np.frombuffer(raw, ABUNDANCE_DTYPE)
 

@@ -800,3 +800,36 @@ uint64_t orc_edge_index(const uint32_t *vecs, uint64_t n, unsigned k, uint64_t *
     free(e); free(tmp);
     return m;
 }
+
+uint64_t orc_unitig_edge_index(const uint32_t *minimizers, const uint64_t *offsets, uint64_t n_seqs, unsigned k,
+                               uint64_t *out_hi, uint64_t *out_lo, uint64_t *checksum)
+{
+    idx_ent *e = (idx_ent *)malloc((n_seqs ? 4 * n_seqs : 1) * sizeof(idx_ent));
+    uint32_t *node = (uint32_t *)malloc(k * sizeof(uint32_t));
+    uint32_t *tmp = (uint32_t *)malloc(k * sizeof(uint32_t));
+    uint64_t m = 0;
+    for (uint64_t s = 0; s < n_seqs; s++) {
+        const uint32_t *u = minimizers + offsets[s];
+        const uint64_t n = offsets[s + 1] - offsets[s];
+        if (n < k) continue;                                   /* minimizersToKminmers yields nothing */
+        const uint64_t last = n - k;
+        for (int which = 0; which < 2; which++) {
+            if (which == 1 && last == 0) break;                /* startNode == endNode (:4378) */
+            orc_kminmer_normalize(u + (which ? last : 0), k, node);          /* :4366 / :4380 */
+            orc_kminmer_normalize(node + 1, k - 1, tmp);                     /* suffix (:4395) */
+            orc_kminmer_hash128(tmp, k - 1, &e[m].hi, &e[m].lo); e[m].a = 0; m++;
+            orc_kminmer_normalize(node, k - 1, tmp);                         /* prefix (:4394) */
+            orc_kminmer_hash128(tmp, k - 1, &e[m].hi, &e[m].lo); e[m].a = 0; m++;
+        }
+    }
+    qsort(e, m, sizeof(idx_ent), cmp_idx_ent);
+    uint64_t d = 0, sum = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        if (i && e[i].hi == e[i - 1].hi && e[i].lo == e[i - 1].lo) continue;
+        out_hi[d] = e[i].hi; out_lo[d] = e[i].lo; d++;
+        sum += e[i].lo;
+    }
+    *checksum = sum;
+    free(e); free(node); free(tmp);
+    return d;
+}

@@ -182,6 +182,13 @@ void orc_kminmer_index(const uint32_t *minimizers, const uint64_t *offsets, uint
  * out_hi / out_lo must hold 2 n entries; returns the number of distinct edges. */
 uint64_t orc_edge_index(const uint32_t *vecs, uint64_t n, unsigned k, uint64_t *out_hi, uint64_t *out_lo, uint64_t *checksum);
 
+/* UnitigEdgeIndexer (graph/CreateMdbg.hpp:4234-4512): per unitig (minimizer sequence), the first and the last k-min-mer
+ * (only one when they are the same vector, :4378), each normalised (:4366, :4380), then the identities of its
+ * normalised (k-1)-prefix and -suffix (:4391-4402); de-duplicated, sorted by (hi,lo).  Sequences shorter than k have no
+ * k-min-mer.  out_hi / out_lo must hold 4 n_seqs entries; returns the number of distinct edges. */
+uint64_t orc_unitig_edge_index(const uint32_t *minimizers, const uint64_t *offsets, uint64_t n_seqs, unsigned k,
+                               uint64_t *out_hi, uint64_t *out_lo, uint64_t *checksum);
+
 #ifdef __cplusplus
 }
 #endif

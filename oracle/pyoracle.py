@@ -233,6 +233,21 @@ def edge_index(vecs) -> tuple[np.ndarray, np.ndarray, int]:
     return hi[:m].copy(), lo[:m].copy(), ck.value
 
 
+def unitig_edge_index(mins, offsets, k: int) -> tuple[np.ndarray, np.ndarray, int]:
+    """(hi, lo, checksum) of the distinct unitig-edge identities, sorted by (hi, lo)."""
+    m = np.ascontiguousarray(mins, dtype=np.uint32)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(o) - 1
+    hi = np.zeros(max(4 * n, 1), dtype=np.uint64)
+    lo = np.zeros(max(4 * n, 1), dtype=np.uint64)
+    ck = C.c_uint64()
+    f = lib().orc_unitig_edge_index
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    d = f(m.ctypes.data, o.ctypes.data, n, k, hi.ctypes.data, lo.ctypes.data, C.byref(ck))
+    return hi[:d].copy(), lo[:d].copy(), ck.value
+
+
 def table_abundance_records(t: dict) -> np.ndarray:
     """20-byte records (lo, hi, abundance) of an oracle table, as a structured array."""
     from metamdbg_amd.formats import ABUNDANCE_DTYPE

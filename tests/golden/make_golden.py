@@ -70,6 +70,9 @@ def log_known_answers(tmp: str) -> dict:
     m = re.search(r"Dereplicating edges.*?\n\s*Done: (\d+) (\d+) ", log, flags=re.S)
     if m:
         out["n_edges"], out["edge_checksum"] = int(m.group(1)), int(m.group(2))
+    m = re.search(r"Dereplicating unitig edges.*?\n\s*Done: (\d+) ", log, flags=re.S)   # UnitigEdgeIndexer (CreateMdbg.hpp:4234-4512)
+    if m:
+        out["n_unitig_edges"] = int(m.group(1))
     m = re.search(r"Checksum kminmer abundance: (\d+)", log)
     if m:
         out["abundance_checksum"] = int(m.group(1))
@@ -89,6 +92,9 @@ def store_outputs(tmp: str, dst: str, k: int, manifest: dict) -> None:
     p = os.path.join(tmp, "read_data_corrected.txt")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "read_data_corrected.txt"))  # threads=1 -> read order
+    p = os.path.join(tmp, "unitigGraph.nodes.bin")          # the reference's unitigs (data): input of the unitig-edge index
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, "unitigGraph.nodes.bin"))
     ab = os.path.join(tmp, "kminmerData_abundance.txt")
     if os.path.exists(ab):
         raw = open(ab, "rb").read()
@@ -288,6 +294,10 @@ def main() -> None:
     try:
         make_fn()
         if "--only-fn" in sys.argv:
+            return
+        if "--only-pipelines" in sys.argv:
+            make_hifi(work)
+            make_ont(work)
             return
         make_edge(work)
         make_hifi(work)

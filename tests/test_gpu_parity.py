@@ -633,3 +633,28 @@ def test_packed_upload_with_qualities_equals_ascii(ctx):
     from metamdbg_amd import capi
     with pytest.raises(capi.MdbgError):      # one quality per base
         ctx.reads_from_packed(words, woff, lens, [q[:-1] if len(q) > 5 else q for q in quals])
+
+
+@pytest.mark.parametrize("name", ["hifi_200", "ont_100"])
+def test_unitig_edge_index_vs_oracle_and_reference_log(ctx, orc, name):
+    """N2, second half: UnitigEdgeIndexer on the reference's own unitigs; plus random sequences incl. ones shorter
+    than k, exactly k long (first == last k-min-mer) and palindromic ones."""
+    m = H.load_manifest(name)
+    k = m["k"]
+    mins, offs, _ = formats.parse_unitig_nodes(H.golden_bytes(name, "unitigGraph.nodes.bin"))
+    t, ck = ctx.unitig_edge_index(ctx.minimizers_from_host(mins, offs), k)
+    assert t.info()["n_records"] == m["reference_log"]["n_unitig_edges"]
+    hi, lo, ock = orc.unitig_edge_index(mins, offs, k)
+    keys = t.keys_to_host()
+    got = keys[np.lexsort((keys[:, 0], keys[:, 1]))]
+    assert np.array_equal(got[:, 1], hi) and np.array_equal(got[:, 0], lo) and ck == ock
+    rng = np.random.default_rng(5)
+    for kk in (3, 4, 7):
+        lens = np.concatenate([rng.integers(0, kk + 3, 300), rng.integers(kk, 60, 300)])
+        o = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        mm = rng.integers(0, 6, int(o[-1])).astype(np.uint32)            # tiny alphabet: ties and palindromes
+        t, ck = ctx.unitig_edge_index(ctx.minimizers_from_host(mm, o), kk)
+        hi, lo, ock = orc.unitig_edge_index(mm, o, kk)
+        keys = t.keys_to_host()
+        got = keys[np.lexsort((keys[:, 0], keys[:, 1]))] if len(keys) else keys
+        assert len(got) == len(hi) and np.array_equal(got[:, 1], hi) and np.array_equal(got[:, 0], lo) and ck == ock

@@ -221,3 +221,16 @@ def test_reference_log_known_answers(name):
     vecs = np.fromfile(os.path.join(H.GOLDEN, name, "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
     hi, lo, eck = orc.edge_index(vecs)
     assert len(hi) == log["n_edges"] and eck == log["edge_checksum"]
+
+
+@pytest.mark.parametrize("name", ["hifi_200", "ont_100"])
+def test_unitig_edge_index_reference_count(name):
+    """UnitigEdgeIndexer (CreateMdbg.hpp:4234-4512) on the reference's own unitigGraph.nodes.bin: the number of
+    distinct unitig edges the reference logs ("Dereplicating unitig edges ... Done: N")."""
+    m = H.load_manifest(name)
+    mins, offs, idx = formats.parse_unitig_nodes(H.golden_bytes(name, "unitigGraph.nodes.bin"))
+    assert len(idx) > 10 and (np.diff(offs.astype(np.int64)) >= m["k"]).all()
+    hi, lo, ck = orc.unitig_edge_index(mins, offs, m["k"])
+    assert len(hi) == m["reference_log"]["n_unitig_edges"]
+    keys = np.stack([hi, lo], axis=1)
+    assert len(np.unique(keys, axis=0)) == len(keys)
