@@ -143,6 +143,8 @@ def main() -> None:
     # rate) and the gaps between launches overlap with the scan of the other (bound by the vector ALU).  Step i runs
     # on slot i % IN_FLIGHT; every step is still the complete pass over one batch.
     n_slots = max(1, args.in_flight)
+    if n_slots > 1:
+        os.environ.setdefault("MDBG_TABLE_BLOCKS_PER_CU", "3")   # keep the table kernels' footprint small beside the other batch's scan
     slots = []
     # one metagenome for the job (MDBG_BENCH_SPEC_RANKS: test hook, the per-rank workload of an N-rank job on one GPU)
     spec_ranks = int(os.environ.get("MDBG_BENCH_SPEC_RANKS", world))
