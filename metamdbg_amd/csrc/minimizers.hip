@@ -49,21 +49,41 @@ __global__ __launch_bounds__(256) void purge_detect_kernel(const uint64_t *off, 
 // Serial replay of the reference for the listed reads: smallest k, then smallest i whose window of k
 // surviving minimizers is a palindrome -> drop its first element -> restart, until none is left.
 // Dropping from a compacted copy is equivalent to the reference's banned-position bookkeeping.
+// Replay of Commons::purgePalindrome on one read: the reference looks, for k = first_k .. last_k-1 and then for
+// i = 0 .. n-k, for the first palindromic window, drops its first element and starts over (Commons.hpp:1617-1723).
+// A window is a palindrome iff it is centred on a palindromic centre whose radius covers it, and with a centre of
+// radius R every shorter window of the same parity about it is one too.  So the first hit is, over all centres
+// (between two equal neighbours, or on an element whose two neighbours are equal), the lexicographically smallest
+// (k0, start) with k0 the smallest length >= first_k of the centre's parity that its radius allows: one linear pass
+// with a short expansion per centre instead of O(n * k) window tests per drop.
 template <typename Ptr>
 __device__ __forceinline__ uint32_t purge_replay(Ptr a, uint32_t n, uint32_t first_k, uint32_t last_k) {
+    const uint32_t k_even = first_k + (first_k & 1u), k_odd = first_k | 1u;     // smallest allowed length of each parity
     for (;;) {
-        bool hit = false;
-        for (uint32_t k = first_k; k < last_k && k <= n && !hit; k++) {
-            for (uint32_t i = 0; i + k <= n; i++) {
-                if (window_is_palindrome(a + i, k)) {
-                    for (uint32_t j = i; j + 1 < n; j++) a[j] = a[j + 1];
-                    n--;
-                    hit = true;
-                    break;
+        uint32_t best_k = 0xFFFFFFFFu, best_i = 0;
+        for (uint32_t c = 0; c + 1 < n; c++) {
+            // even centre between c and c+1: window of length k_even starts at c + 1 - k_even / 2
+            if (a[c] == a[c + 1] && k_even < last_k && k_even <= n && k_even < best_k) {
+                const uint32_t half = k_even / 2;
+                if (c + 1 >= half && c + half < n) {
+                    uint32_t r = 1;
+                    while (r < half && a[c - r] == a[c + 1 + r]) r++;
+                    if (r == half) { best_k = k_even; best_i = c + 1 - half; }
+                }
+            }
+            // odd centre on c+1 (neighbours c and c+2): window of length k_odd starts at c + 1 - k_odd / 2
+            if (c + 2 < n && a[c] == a[c + 2] && k_odd < last_k && k_odd <= n && k_odd < best_k) {
+                const uint32_t half = k_odd / 2;              // pairs to match around the centre
+                if (c + 1 >= half && c + 1 + half < n) {
+                    uint32_t r = 1;
+                    while (r < half && a[c - r] == a[c + 2 + r]) r++;
+                    if (r == half) { best_k = k_odd; best_i = c + 1 - half; }
                 }
             }
         }
-        if (!hit) break;
+        if (best_k == 0xFFFFFFFFu) break;
+        for (uint32_t j = best_i; j + 1 < n; j++) a[j] = a[j + 1];
+        n--;
     }
     return n;
 }
