@@ -17,7 +17,7 @@
  * mdbg_scan calls on the same device take turns: one scan kernel runs at a time.
  * There is no CPU fallback: without a usable GPU every call fails with MDBG_ENODEV.
  *
- * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE (default 4) -- reads a scan wave processes before it
+ * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE (default 2) -- reads a scan wave processes before it
  * retires; MDBG_TABLE_BLOCKS_PER_CU (default: unlimited) -- resident blocks per CU of the k-min-mer insert kernels, to be
  * set to a few (3) when two contexts share a device; MDBG_TRACE -- one line per purge with the number of suspect reads.
  */

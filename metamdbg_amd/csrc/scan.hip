@@ -819,10 +819,11 @@ static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks
     // speed, and the kernel ended with the slowest.  Dealt out by the dispatcher as slots free up, the same reads take
     // 15.4 ms; short-lived workgroups also let the kernels of another stream (a second batch in flight, RCCL) in
     // instead of queueing them behind the resident generation.  The per-block set-up (1024-entry LUT) is noise next
-    // to a 10 kb read.  4 reads per wave measured best with two batches in flight (MDBG_SCAN_READS_PER_WAVE to tune).
+    // to a 10 kb read.  2 reads per wave measured best with two batches in flight: a waiting kernel of the other batch gets
+    // a slot within ~0.2 ms (MDBG_SCAN_READS_PER_WAVE to tune).
     (void)max_blocks;
     const char *env = getenv("MDBG_SCAN_READS_PER_WAVE");
-    const uint64_t per_wave = env && atoi(env) > 0 ? (uint64_t)atoi(env) : 4;
+    const uint64_t per_wave = env && atoi(env) > 0 ? (uint64_t)atoi(env) : 2;
     uint64_t blocks = ((uint64_t)n_items + SCAN_WAVES * per_wave - 1) / (SCAN_WAVES * per_wave);
     if (blocks < 1) blocks = 1;
     if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
