@@ -29,8 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP multiplexes streams onto a few hardware queues (4 by default); two contexts whose streams land on the same queue
-# run their kernels one after the other and the two batches in flight no longer overlap.  Must be set before HIP starts.
+# HIP multiplexes streams onto a few hardware queues (4 by default).  With 4, the streams of the two library contexts
+# ended up on one queue in every run under torch.distributed + RCCL (no overlap of the batches in flight); with 8 they
+# rarely do, and main() checks and repairs the rest.  Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -247,6 +248,46 @@ def main() -> None:
     n_warm = max(args.warmup, n_slots)
     n_warm += (-n_warm) % n_slots
     run_phase(0, n_warm)
+
+    # HIP multiplexes streams onto a few hardware queues; when the streams of two contexts land on the same queue their
+    # kernels run one after the other and the batches in flight do not overlap at all (GPU_MAX_HW_QUEUES=1 reproduces
+    # it: 520 instead of 615 Gbp/s).  Probe it with purely local steps (no collective, every rank decides alone): two
+    # concurrent steps must take clearly less than twice one step; if not, give slot 1 a new context -- a new stream --
+    # and look again.
+    def local_step(slot: int):
+        c, r = slots[slot]
+        mins = c.scan(r, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = c.purge_palindromes(mins, 4, 100)
+        t = c.kminmer_count_first(corr, KMINMER, 0)
+        for o in (t, corr, mins):
+            o.free()
+        c.synchronize()
+
+    probe = None
+    if n_slots > 1 and args.steps > 1:
+        def timed(fn):
+            t = time.perf_counter()
+            fn()
+            return time.perf_counter() - t
+
+        def both():
+            th = [threading.Thread(target=lambda sl=sl: (torch.cuda.set_device(local_rank), local_step(sl), local_step(sl))) for sl in (0, 1)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+        for attempt in range(4):
+            local_step(0); local_step(1)                       # pools of the local path
+            one = min(timed(lambda: local_step(0)) for _ in range(2))
+            two = timed(both) / 2.0                            # per concurrent pair of steps
+            probe = {"one_step_ms": one * 1e3, "two_concurrent_steps_ms": two * 1e3, "ratio": two / one, "contexts_replaced": attempt}
+            if two < 1.85 * one:
+                break
+            c, r = slots[1]
+            r.free(); c.close()
+            c = capi.Context(local_rank)
+            slots[1] = (c, c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads))
     for c, _ in slots:
         c.timing(True)
         c.timing_reset()
@@ -296,7 +337,7 @@ def main() -> None:
                                    "(count + rescue); inputs 2-bit packed and resident in HBM",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
-                       "batches_in_flight": n_slots, "device": info["arch"], "cus": info["n_cu"]},
+                       "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"]},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
