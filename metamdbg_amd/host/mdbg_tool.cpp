@@ -29,6 +29,7 @@
 #include <string>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -183,13 +184,17 @@ void for_each_batch(const std::string &inputList, size_t batchBases, int threads
 }
 
 // a parsed batch -> reads in HBM: 2-bit words when the feeder packed the chunk, ASCII (packed on the device) otherwise
-mdbg_reads *upload_batch(ReadBatch &b, bool withQual) {
+void check_on(mdbg_ctx *ctx, int rc, const char *what) {
+    if (rc) die(std::string(what) + ": " + mdbg_last_error(ctx));
+}
+
+mdbg_reads *upload_batch(mdbg_ctx *ctx, ReadBatch &b, bool withQual) {
     mdbg_reads *reads = nullptr;
     if (b.packed) {
-        check(mdbg_reads_from_packed(g_ctx, b.words(), b.wordOff.data(), b.lens.data(), b.n(), &reads), "mdbg_reads_from_packed");
-        if (withQual && b.hasQual) check(mdbg_reads_attach_qualities(g_ctx, reads, b.quals, b.offsets.data()), "mdbg_reads_attach_qualities");
+        check_on(ctx, mdbg_reads_from_packed(ctx, b.words(), b.wordOff.data(), b.lens.data(), b.n(), &reads), "mdbg_reads_from_packed");
+        if (withQual && b.hasQual) check_on(ctx, mdbg_reads_attach_qualities(ctx, reads, b.quals, b.offsets.data()), "mdbg_reads_attach_qualities");
     } else {
-        check(mdbg_reads_from_ascii(g_ctx, b.bases, withQual && b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
+        check_on(ctx, mdbg_reads_from_ascii(ctx, b.bases, withQual && b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
     }
     return reads;
 }
@@ -226,7 +231,7 @@ int run_read_selection(int argc, char **argv) {
             for_each_batch(inputList, a.batchBases, a.threads, 1000000, [&](ReadBatch &b) {
                 mdbg_reads *reads = nullptr;
                 mdbg_minimizers *mins = nullptr;
-                reads = upload_batch(b, false);
+                reads = upload_batch(g_ctx, b, false);
                 mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
                 check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
                 uint32_t n; uint64_t t;
@@ -263,15 +268,26 @@ int run_read_selection(int argc, char **argv) {
     std::vector<uint32_t> allReadSizes;
     uint64_t nbKmers = 0, nbBases = 0, nbSelected = 0;
     long double qualitySum = 0, qualityN = 0;
-    std::vector<mdbg_minimizers *> kept;   // device-resident minimizer reads, purged once N50 is known
     const bool needCorrected = P.hpc || a.skipCorrection;
-    // The thread that owns the GPU context turns a batch into host arrays; a writer thread behind a short FIFO
-    // builds the records and writes them, in batch order, while the next batch is on the device.
+    // Batches are turned into host arrays by consumer threads, each with its own library context (stream, pool), so the
+    // upload of one batch can overlap the scan and the download of another; a writer thread builds the records and
+    // writes them in batch order while later batches are on the device.  One consumer is the default: at 28 GB/s of
+    // FASTA the pass is bound by the parser workers and the page-locked buffers, and a second consumer measured no
+    // faster (profiles/r01f_tool_consumers.json); MDBG_TOOL_CONSUMERS=2..4 is there for slower-to-scan inputs.
     struct HostBatch {
+        uint64_t seq = 0;
         uint32_t n = 0; uint64_t t = 0;
         std::vector<uint64_t> off; std::vector<uint32_t> m, pos, len; std::vector<uint8_t> dir, qual, flags; std::vector<float> meanQ;
     };
-    std::deque<std::unique_ptr<HostBatch>> fifo;
+    struct Kept { uint64_t seq; mdbg_ctx *ctx; mdbg_minimizers *mins; };
+    std::vector<Kept> kept;                 // device-resident minimizer reads, purged once N50 is known
+    int nConsumers = 1;
+    if (const char *e = getenv("MDBG_TOOL_CONSUMERS")) nConsumers = std::max(1, std::min(4, atoi(e)));
+    std::vector<mdbg_ctx *> ctxs{g_ctx};
+    for (int i = 1; i < nConsumers; i++) { mdbg_ctx *c = nullptr; check(mdbg_create(0, &c), "mdbg_create"); ctxs.push_back(c); }
+
+    std::map<uint64_t, std::unique_ptr<HostBatch>> pending;     // finished batches waiting for their turn at the writer
+    uint64_t nextWrite = 0;
     std::mutex fifoMu;
     std::condition_variable fifoCv;
     bool fifoDone = false;
@@ -281,10 +297,12 @@ int run_read_selection(int argc, char **argv) {
             std::unique_ptr<HostBatch> hb;
             {
                 std::unique_lock<std::mutex> lk(fifoMu);
-                fifoCv.wait(lk, [&] { return fifoDone || !fifo.empty(); });
-                if (fifo.empty()) return;
-                hb = std::move(fifo.front());
-                fifo.pop_front();
+                fifoCv.wait(lk, [&] { return pending.count(nextWrite) || (fifoDone && pending.empty()); });
+                auto it = pending.find(nextWrite);
+                if (it == pending.end()) return;
+                hb = std::move(it->second);
+                pending.erase(it);
+                nextWrite++;
             }
             fifoCv.notify_all();
             rec.clear();
@@ -309,40 +327,72 @@ int run_read_selection(int argc, char **argv) {
             out.write(rec.data(), (std::streamsize)rec.size());
         }
     });
-    double tUpload = 0, tScan = 0, tDownload = 0, tQueue = 0, tLast = g_trace.now(), tWait = 0;
+
+    double tUpload = 0, tScan = 0, tDownload = 0, tQueue = 0, tWait = 0;
     uint64_t nBatches = 0;
-    for_each_batch(inputList, a.batchBases, a.threads, 0, [&](ReadBatch &b) {
-        double t0 = g_trace.now();
-        tWait += t0 - tLast;                      // time this thread waited for the feeder
-        mdbg_reads *reads = nullptr;
-        mdbg_minimizers *mins = nullptr;
-        reads = upload_batch(b, true);
-        double t1 = g_trace.now();
-        mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
-        check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
-        mdbg_reads_free(reads);
-        double t2 = g_trace.now();
-        std::unique_ptr<HostBatch> hb(new HostBatch());
-        mdbg_minimizers_info(mins, &hb->n, &hb->t);
-        hb->off.resize((size_t)hb->n + 1);
-        hb->m.resize(hb->t); hb->pos.resize(hb->t); hb->len.resize(hb->n);
-        hb->dir.resize(hb->t); hb->qual.resize(hb->t); hb->flags.resize(hb->n); hb->meanQ.resize(hb->n);
-        check(mdbg_minimizers_to_host(g_ctx, mins, hb->off.data(), hb->m.data(), hb->pos.data(), hb->dir.data(), hb->qual.data(), hb->len.data(),
-                                      hb->meanQ.data(), hb->flags.data()), "to_host");
-        if (needCorrected) kept.push_back(mins); else mdbg_minimizers_free(mins);
-        double t3 = g_trace.now();
-        {
-            std::unique_lock<std::mutex> lk(fifoMu);
-            fifoCv.wait(lk, [&] { return fifo.size() < 4; });
-            fifo.push_back(std::move(hb));
-        }
-        fifoCv.notify_all();
-        tLast = g_trace.now();
-        tUpload += t1 - t0; tScan += t2 - t1; tDownload += t3 - t2; tQueue += tLast - t3; nBatches++;
-    });
+    {
+        auto alloc = [](size_t n) -> void * { void *p = nullptr; check(mdbg_host_alloc(g_ctx, n, &p), "mdbg_host_alloc"); return p; };
+        auto release = [](void *p) { mdbg_host_free(g_ctx, p); };
+        std::unique_ptr<mdbg_host::ReadFeeder> feeder;
+        try { feeder.reset(new mdbg_host::ReadFeeder(read_input_list(inputList), a.batchBases, a.threads, 0, alloc, release)); }
+        catch (const std::exception &e) { die(e.what()); }
+        std::mutex feedMu, statMu;
+        uint64_t nextSeq = 0;
+        auto consume = [&](int ci) {
+            mdbg_ctx *ctx = ctxs[(size_t)ci];
+            double up = 0, sc = 0, dn = 0, qu = 0, wt = 0;
+            uint64_t nb = 0;
+            for (;;) {
+                ReadBatch *b = nullptr;
+                uint64_t seq = 0;
+                const double tw = g_trace.now();
+                try {
+                    std::lock_guard<std::mutex> g(feedMu);       // batches leave the feeder in read order
+                    b = feeder->next();
+                    seq = nextSeq++;
+                } catch (const std::exception &e) { die(e.what()); }
+                if (!b) break;
+                const double t0 = g_trace.now();
+                mdbg_reads *reads = upload_batch(ctx, *b, true);
+                feeder->recycle(b);                              // the page-locked buffer is free again once the upload is done
+                const double t1 = g_trace.now();
+                mdbg_minimizers *mins = nullptr;
+                mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
+                check_on(ctx, mdbg_scan(ctx, reads, &p, &mins), "mdbg_scan");
+                mdbg_reads_free(reads);
+                const double t2 = g_trace.now();
+                std::unique_ptr<HostBatch> hb(new HostBatch());
+                hb->seq = seq;
+                mdbg_minimizers_info(mins, &hb->n, &hb->t);
+                hb->off.resize((size_t)hb->n + 1);
+                hb->m.resize(hb->t); hb->pos.resize(hb->t); hb->len.resize(hb->n);
+                hb->dir.resize(hb->t); hb->qual.resize(hb->t); hb->flags.resize(hb->n); hb->meanQ.resize(hb->n);
+                check_on(ctx, mdbg_minimizers_to_host(ctx, mins, hb->off.data(), hb->m.data(), hb->pos.data(), hb->dir.data(), hb->qual.data(),
+                                                      hb->len.data(), hb->meanQ.data(), hb->flags.data()), "to_host");
+                const double t3 = g_trace.now();
+                {
+                    std::unique_lock<std::mutex> lk(fifoMu);
+                    if (needCorrected) kept.push_back(Kept{seq, ctx, mins});
+                    // bounded, but the batch the writer is waiting for always gets in
+                    fifoCv.wait(lk, [&] { return pending.size() < 6 || seq == nextWrite; });
+                    pending.emplace(seq, std::move(hb));
+                }
+                if (!needCorrected) mdbg_minimizers_free(mins);
+                fifoCv.notify_all();
+                const double t4 = g_trace.now();
+                wt += t0 - tw; up += t1 - t0; sc += t2 - t1; dn += t3 - t2; qu += t4 - t3; nb++;
+            }
+            std::lock_guard<std::mutex> g(statMu);
+            tWait += wt; tUpload += up; tScan += sc; tDownload += dn; tQueue += qu; nBatches += nb;
+        };
+        std::vector<std::thread> consumers;
+        for (int i = 1; i < nConsumers; i++) consumers.emplace_back(consume, i);
+        consume(0);
+        for (auto &t : consumers) t.join();
+    }
     if (getenv("MDBG_TRACE"))
-        fprintf(stderr, "[mdbg_tool] %llu batches: waiting for the feeder %.3f s, upload+pack %.3f s, scan %.3f s, download %.3f s, writer queue %.3f s\n",
-                (unsigned long long)nBatches, tWait, tUpload, tScan, tDownload, tQueue);
+        fprintf(stderr, "[mdbg_tool] %llu batches on %d consumer(s), summed over them: waiting for the feeder %.3f s, upload %.3f s, scan %.3f s, "
+                        "download %.3f s, writer queue %.3f s\n", (unsigned long long)nBatches, nConsumers, tWait, tUpload, tScan, tDownload, tQueue);
     {
         std::lock_guard<std::mutex> lk(fifoMu);
         fifoDone = true;
@@ -369,14 +419,16 @@ int run_read_selection(int argc, char **argv) {
     if (needCorrected) {
         const int lastK = compute_last_k(P.densityAssembly, n50, P.firstK, 0);
         std::ofstream corr(tmpDir + "/read_data_corrected.txt", std::ios::binary);
-        for (mdbg_minimizers *mins : kept) {
+        std::sort(kept.begin(), kept.end(), [](const Kept &x, const Kept &y) { return x.seq < y.seq; });
+        for (const Kept &kp : kept) {
+            mdbg_minimizers *mins = kp.mins;
             mdbg_minimizers *pur = nullptr;
-            check(mdbg_purge_palindromes(g_ctx, mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+            check_on(kp.ctx, mdbg_purge_palindromes(kp.ctx, mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
             uint32_t n; uint64_t t;
             mdbg_minimizers_info(pur, &n, &t);
             std::vector<uint64_t> off((size_t)n + 1);
             std::vector<uint32_t> m(t);
-            check(mdbg_minimizers_to_host(g_ctx, pur, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
+            check_on(kp.ctx, mdbg_minimizers_to_host(kp.ctx, pur, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
             std::string rec;
             rec.reserve(t * 4 + (size_t)n * 5);
             for (uint32_t r = 0; r < n; r++) {
@@ -392,6 +444,7 @@ int run_read_selection(int argc, char **argv) {
     }
     g_trace.mark("read_data_corrected.txt written");
     write_perf(tmpDir);
+    for (size_t i = 1; i < ctxs.size(); i++) mdbg_destroy(ctxs[i]);
     mdbg_destroy(g_ctx);
     g_trace.mark("done");
     return 0;
@@ -511,6 +564,7 @@ int run_graph(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     if (argc < 2) die("usage: mdbg_tool <readSelection|graph> ...");
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // two contexts must not share a hardware queue; before HIP starts
     const std::string cmd = argv[1];
     if (cmd == "readSelection") return run_read_selection(argc, argv);
     if (cmd == "graph") return run_graph(argc, argv);
