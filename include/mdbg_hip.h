@@ -170,6 +170,15 @@ int  mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *reads, con
 int  mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
                         uint32_t k, const mdbg_table *prev, mdbg_table **out);
 
+/* Replaces the small-contig branch of IndexKminmerFunctor (graph/CreateMdbg.hpp:1330-1352), taken in the unitig pass of
+ * `graph` when k > 8: a unitig with no k-min-mer whose getAbundance(0, prevAbundances) (:988-1010, prevAbundances over
+ * its k_prev-min-mers, missing => 1, :1240-1265) exceeds 1 is appended to smallContigs/smallContigs_k<k>.bin
+ * (`u32 n; u8 circular; u32 m[n]`) instead of being indexed.  flags (host, one per unitig) is set to 1 for those
+ * unitigs; the caller applies the k > 8 condition and writes the records.  Unitigs shorter than k_prev, for which the
+ * reference reads an empty vector (undefined), are never flagged. */
+int  mdbg_small_contigs(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, uint32_t k_prev, const mdbg_table *prev,
+                        uint8_t *flags);
+
 /* n_records = rows of kminmerData_abundance.txt; n_solid of them are solid (the rest rescued,
  * abundance 1); has_vectors = whether kminmerData_min.txt rows exist (k <= firstK+1). */
 int  mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_records, uint64_t *n_solid, int *has_vectors);

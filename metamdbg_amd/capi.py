@@ -74,6 +74,7 @@ SIGNATURES = {
     "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
     "mdbg_edge_index": (C.c_int, [_P, _P, C.POINTER(_P), _u64p]),
     "mdbg_unitig_edge_index": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P), _u64p]),
+    "mdbg_small_contigs": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "mdbg_table_keys_to_host": (C.c_int, [_P, _P, _P]),
     "mdbg_table_free": (None, [_P]),
     "mdbg_row_words": (C.c_uint32, [C.c_uint32]),
@@ -258,6 +259,13 @@ class Context:
         ck = C.c_uint64()
         self.check(lib().mdbg_unitig_edge_index(self.h, unitigs.h, k, C.byref(h), C.byref(ck)))
         return Table(self, h), ck.value
+
+    def small_contigs(self, unitigs: "Minimizers", k: int, k_prev: int, prev: "Table") -> np.ndarray:
+        """1 per unitig that IndexKminmerFunctor writes to smallContigs_k<k>.bin instead of indexing (k > 8 is the caller's test)."""
+        n = unitigs.info()["n_reads"]
+        flags = np.zeros(n, dtype=np.uint8)
+        self.check(lib().mdbg_small_contigs(self.h, unitigs.h, k, k_prev, prev.h, flags.ctypes.data))
+        return flags
 
     # -- sharded first pass (one process per GPU) ---------------------------------------------------
     def shard_begin(self, m: "Minimizers", k: int, n_ranks: int) -> "Shard":

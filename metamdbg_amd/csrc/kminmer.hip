@@ -415,6 +415,28 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView t, const uint64_t
     out[i] = table_lookup(t, lo[i], hi[i], v) ? v : 0u;
 }
 
+// small-contig test of IndexKminmerFunctor (graph/CreateMdbg.hpp:1330; getAbundance(0, .) :988-1010): one thread per unitig
+__global__ __launch_bounds__(256) void small_contig_kernel(const uint64_t *off, uint32_t n_unitigs, const uint32_t *mins, uint32_t k,
+                                                           uint32_t k_prev, TableView prev, uint8_t *flags) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_unitigs) return;
+    const uint64_t b = off[u], n = off[u + 1] - b;
+    uint8_t f = 0;
+    if (n < k && n >= k_prev) {
+        const uint32_t windows = (n - k_prev + 1) < 2 ? 1u : 2u;     // prev[0], or min(prev[0], prev[1])
+        uint32_t a = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < windows; i++) {
+            uint64_t hi, lo;
+            window_hash(mins + b + i, k_prev, hi, lo);
+            uint32_t v;
+            if (!table_lookup(prev, lo, hi, v)) v = 1u;               // getPrevAbundances: missing => 1 (:1240-1265)
+            a = v < a ? v : a;
+        }
+        f = a > 1u;
+    }
+    flags[u] = f;
+}
+
 // EdgeIndexer::partitionNode (graph/CreateMdbg.hpp:4083-4100): prefix and suffix identities of one node
 __global__ __launch_bounds__(256) void edge_insert_kernel(const uint32_t *vecs, uint64_t n, uint32_t k, TableView t) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -875,6 +897,24 @@ extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint6
     MDBG_HIP_CHECK(ctx, hipMemcpyAsync(dh.p, hash_hi, n * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(lookup_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, t->lookup->view(), dl.p, dh.p, n, dv.p);
     MDBG_HIP_CHECK(ctx, hipMemcpyAsync(abundance, dv.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_small_contigs(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, uint32_t k_prev, const mdbg_table *prev,
+                                  uint8_t *flags) {
+    if (!ctx || !unitigs || k_prev < 1 || k <= k_prev) return set_error(ctx, MDBG_EINVAL, "mdbg_small_contigs: bad argument");
+    MDBG_TRY(check_seq(ctx, unitigs, "mdbg_small_contigs"));
+    if (unitigs->n_reads && !flags) return set_error(ctx, MDBG_EINVAL, "mdbg_small_contigs: flags is null");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TableView pv;
+    MDBG_TRY(prev_view(ctx, prev, pv));
+    if (!unitigs->n_reads) return MDBG_OK;
+    DevBuf<uint8_t> d_flags;
+    MDBG_TRY(d_flags.alloc(ctx, unitigs->n_reads));
+    hipLaunchKernelGGL(small_contig_kernel, dim3(grid_for(unitigs->n_reads, 256)), dim3(256), 0, ctx->stream, unitigs->d_off.p,
+                       unitigs->n_reads, unitigs->d_min.p, k, k_prev, pv, d_flags.p);
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags.p, unitigs->n_reads, hipMemcpyDeviceToHost, ctx->stream));
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;
 }

@@ -452,12 +452,14 @@ int run_read_selection(int argc, char **argv) {
 
 // ---- graph ---------------------------------------------------------------------------------------------------------
 // "u32 n; u8 circ; u32 m[n]" records (read_data_corrected.txt, unitig_data.txt) -> CSR
-void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs) {
+void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs,
+                           std::vector<uint8_t> *circular = nullptr) {
     offs.assign(1, 0);
     size_t o = 0;
     while (o + 5 <= raw.size()) {
         uint32_t n;
         memcpy(&n, raw.data() + o, 4);
+        if (circular) circular->push_back(raw[o + 4]);
         o += 5;
         if (o + (size_t)n * 4 > raw.size()) die("truncated minimizer read file");
         const size_t base = mins.size();
@@ -488,6 +490,8 @@ int run_graph(int argc, char **argv) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     mdbg_minimizers *reads = upload_reads(dir + "/read_data_corrected.txt", true);
     mdbg_table *table = nullptr;
+    // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
+    std::ofstream small(dir + "/smallContigs/smallContigs_k" + std::to_string(k) + ".bin", std::ios::binary);
     if (a.firstPass) {
         check(mdbg_kminmer_count_first(g_ctx, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first");
     } else {
@@ -526,9 +530,32 @@ int run_graph(int argc, char **argv) {
             mdbg_minimizers_free(un);
         }
         mdbg_minimizers *unitigs = nullptr;
+        std::vector<uint32_t> unitigMins;
+        std::vector<uint64_t> unitigOffs;
+        std::vector<uint8_t> unitigCirc;
         {
             std::ifstream probe(dir + "/unitig_data.txt", std::ios::binary);
-            if (probe) unitigs = upload_reads(dir + "/unitig_data.txt", true);
+            if (probe) {
+                parse_minimizer_reads(read_file(dir + "/unitig_data.txt", true), unitigMins, unitigOffs, &unitigCirc);
+                check(mdbg_minimizers_from_host(g_ctx, unitigMins.data(), unitigOffs.data(), (uint32_t)(unitigOffs.size() - 1), &unitigs),
+                      "mdbg_minimizers_from_host");
+            }
+        }
+        // smallContigs_k<k>.bin is filled by the unitig pass of IndexKminmerFunctor when k > 8 (graph/CreateMdbg.hpp:1330-1352);
+        // those unitigs have no k-min-mer, so they add nothing to the table below.
+        {
+            if (unitigs && k > 8 && k != P.firstK + 1) {
+                const uint32_t nUnitigs = (uint32_t)(unitigOffs.size() - 1);
+                std::vector<uint8_t> isSmall(nUnitigs);
+                check(mdbg_small_contigs(g_ctx, unitigs, k, (uint32_t)P.prevK, prev, isSmall.data()), "mdbg_small_contigs");
+                for (uint32_t u = 0; u < nUnitigs; u++) {
+                    if (!isSmall[u]) continue;
+                    const uint32_t n = (uint32_t)(unitigOffs[u + 1] - unitigOffs[u]);
+                    const uint8_t circ = unitigCirc[u];   // the record's own flag byte (Commons.hpp:7413, :7485)
+                    small.write((const char *)&n, 4); small.write((const char *)&circ, 1);
+                    small.write((const char *)(unitigMins.data() + unitigOffs[u]), (std::streamsize)n * 4);
+                }
+            }
         }
         if (k == P.firstK + 1) check(mdbg_kminmer_count_refined(g_ctx, reads, unitigs, k, prev, &table), "mdbg_kminmer_count_refined");
         else check(mdbg_kminmer_index(g_ctx, reads, unitigs, k, prev, &table), "mdbg_kminmer_index");

@@ -778,6 +778,29 @@ void orc_kminmer_index(const uint32_t *mins, const uint64_t *off, uint64_t n_seq
     free(tmp); free(ents);
 }
 
+void orc_small_contigs(const uint32_t *mins, const uint64_t *off, uint64_t n_seqs, unsigned k, unsigned kprev,
+                       const orc_abundance_map *prev, uint8_t *flags)
+{
+    uint32_t *tmp = (uint32_t *)malloc((kprev ? kprev : 1) * sizeof(uint32_t));
+    for (uint64_t r = 0; r < n_seqs; r++) {
+        const uint32_t *m = mins + off[r];
+        uint64_t n = off[r + 1] - off[r];
+        flags[r] = 0;
+        if (n >= k || n < kprev) continue;       /* has k-min-mers (:1330) / empty prevAbundances (undefined in the reference) */
+        uint32_t a = 0xFFFFFFFFu;
+        uint64_t np = n - kprev + 1, use = np < 2 ? np : 2;   /* getAbundance(0, .): prev[0], or min(prev[0], prev[1]) (:990-1006) */
+        for (uint64_t i = 0; i < use; i++) {
+            uint64_t hi, lo; uint32_t v;
+            orc_kminmer_normalize(m + i, kprev, tmp);
+            orc_kminmer_hash128(tmp, kprev, &hi, &lo);
+            if (!orc_abundance_map_get(prev, hi, lo, &v)) v = 1;
+            if (v < a) a = v;
+        }
+        flags[r] = a > 1;
+    }
+    free(tmp);
+}
+
 uint64_t orc_edge_index(const uint32_t *vecs, uint64_t n, unsigned k, uint64_t *out_hi, uint64_t *out_lo, uint64_t *checksum)
 {
     idx_ent *e = (idx_ent *)malloc((n ? 2 * n : 1) * sizeof(idx_ent));

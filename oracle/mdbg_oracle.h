@@ -176,6 +176,15 @@ void orc_kminmer_count_refined(const uint32_t *minimizers, const uint64_t *offse
 void orc_kminmer_index(const uint32_t *minimizers, const uint64_t *offsets, uint64_t n_seqs,
                        unsigned k, const orc_abundance_map *prev, orc_kminmer_table *out);
 
+/* The small-contig branch of IndexKminmerFunctor (graph/CreateMdbg.hpp:1330-1352), taken in the unitig pass when
+ * k > 8: a unitig with no k-min-mer whose getAbundance(0, prevAbundances) (:988-1010) exceeds 1 is written to
+ * smallContigs_k<k>.bin as `u32 n; u8 circular; u32 m[n]` instead of being indexed.  prevAbundances holds one entry per
+ * kprev-min-mer of the unitig (missing => 1, :1240-1265): with one entry the value is that entry, with more it is
+ * min(prev[0], prev[1]); with none (n < kprev) the reference reads prev[0] of an empty vector (undefined), restated here
+ * as "not a small contig".  flags[u] = 1 where the unitig is written.  The caller applies the k > 8 condition. */
+void orc_small_contigs(const uint32_t *minimizers, const uint64_t *offsets, uint64_t n_seqs, unsigned k, unsigned kprev,
+                       const orc_abundance_map *prev, uint8_t *flags);
+
 /* EdgeIndexer (graph/CreateMdbg.hpp:4010-4230): the distinct identities of the normalised
  * (k-1)-prefix and (k-1)-suffix of every k-min-mer vector (the content of edges.bin, sorted by (hi,lo));
  * *checksum = sum of the identities truncated to u64, as indexEdges logs it (graph/CreateMdbg.cpp:1184).

@@ -82,6 +82,8 @@ def lib():
         L.orc_kminmer_count_first.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_uint32, C.POINTER(KminmerTable)]
         L.orc_kminmer_count_refined.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(AbundanceMap), C.POINTER(KminmerTable)]
         L.orc_kminmer_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(AbundanceMap), C.POINTER(KminmerTable)]
+        L.orc_small_contigs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_uint, C.POINTER(AbundanceMap), C.c_void_p]
+        L.orc_small_contigs.restype = None
         L.orc_abundance_map_from_records.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(AbundanceMap)]
         L.orc_abundance_map_overlay.argtypes = [C.POINTER(AbundanceMap), C.c_void_p, C.c_uint32, C.c_uint, C.c_uint32]
         L.orc_murmur3_x64_128.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
@@ -218,6 +220,15 @@ def kminmer_index(mins, offsets, k: int, prev: PrevAbundance) -> dict:
     t = KminmerTable()
     lib().orc_kminmer_index(m.ctypes.data, o.ctypes.data, len(o) - 1, k, C.byref(prev.m), C.byref(t))
     return _table_to_numpy(t)
+
+
+def small_contigs(mins, offsets, k: int, kprev: int, prev: PrevAbundance) -> np.ndarray:
+    """1 per sequence that IndexKminmerFunctor writes to smallContigs_k<k>.bin (graph/CreateMdbg.hpp:1330-1352)."""
+    m = np.ascontiguousarray(mins, dtype=np.uint32)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    flags = np.zeros(len(o) - 1, np.uint8)
+    lib().orc_small_contigs(m.ctypes.data, o.ctypes.data, len(o) - 1, k, kprev, C.byref(prev.m), flags.ctypes.data)
+    return flags
 
 
 def edge_index(vecs) -> tuple[np.ndarray, np.ndarray, int]:

@@ -132,6 +132,73 @@ def make_ont(work: str) -> None:
         fasta_sha256=sha256(fastq), K=15, density=0.005, hpc=False, k=4, min_abundance=0, skip_correction=True))
 
 
+MULTIK_INPUTS = ("parameters.gz", "kminmerData_abundance_prev.txt", "unitigGraph_prev.nodes.bin",
+                 "unitigGraph.nodes.refined_abundances.bin", "unitig_data.txt")
+
+
+def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, manifest: dict) -> None:
+    """The reference's own multi-k loop after readSelection (pipeline/AssemblyPipeline.hpp:609-671, executePass :1076-1145):
+    per k write parameters.gz (k, prevK), run `graph`, then `contig` and `toMinspace`, which produce the next iteration's
+    unitig_data.txt / *_prev files.  For every k > firstK the fixture keeps the INPUTS `graph` read (data files) and its
+    hot-path OUTPUTS (sorted kminmerData_abundance.txt, kminmerData_min.txt at firstK+1, smallContigs_k<k>.bin)."""
+    import dataclasses
+    first_k = params.first_k
+    prev_k = params.prev_k
+    per_k = {}
+    for k in range(first_k, last_k + 1):
+        dataclasses.replace(params, kminmer_size=k, prev_k=prev_k, last_k=last_k).save(os.path.join(tmp, "parameters.gz"))
+        cmd = [REFDRV, "graph", tmp, "--threads", "1"] + (["--min-abundance", "0", "--firstpass"] if k == first_k else [])
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if k > first_k:
+            d = os.path.join(dst, f"k{k}")
+            os.makedirs(d, exist_ok=True)
+            for name in MULTIK_INPUTS:
+                shutil.copy(os.path.join(tmp, name), os.path.join(d, name))
+            raw = open(os.path.join(tmp, "kminmerData_abundance.txt"), "rb").read()
+            formats.sorted_abundance_records(raw).tofile(os.path.join(d, "kminmerData_abundance.sorted.bin"))
+            if k == first_k + 1:
+                raw = open(os.path.join(tmp, "kminmerData_min.txt"), "rb").read()
+                formats.sorted_vector_records(raw, k).astype("<u4").tofile(os.path.join(d, "kminmerData_min.sorted.bin"))
+            shutil.copy(os.path.join(tmp, "smallContigs", f"smallContigs_k{k}.bin"), os.path.join(d, "smallContigs.bin"))
+            per_k[str(k)] = dict(n_records=len(raw) // 20 if k > first_k + 1 else os.path.getsize(os.path.join(tmp, "kminmerData_abundance.txt")) // 20,
+                                 small_contigs_bytes=os.path.getsize(os.path.join(d, "smallContigs.bin")))
+        if k == last_k:
+            break
+        subprocess.run([REFDRV, "contig", tmp, "--threads", "1", "--max-bubble-length", "50000", "--max-tip-length", "50000"],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([REFDRV, "toMinspace", tmp, os.path.join(tmp, "contigs.nodepath"), os.path.join(tmp, "unitig_data.txt"),
+                        os.path.join(tmp, "unitigGraph.nodes.bin"), "--threads", "1"],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        prev_k = k
+    shutil.copy(os.path.join(tmp, "read_data_corrected.txt"), os.path.join(dst, "read_data_corrected.txt"))
+    with open(os.path.join(dst, "manifest.json"), "w") as f:
+        json.dump(dict(manifest, first_k=first_k, last_k=last_k, per_k=per_k), f, indent=1, sort_keys=True)
+
+
+def make_multik(work: str) -> None:
+    """hifi (HPC, 300 reads, three species) and ont (no HPC, 2 % errors, --skip-correction) through k = 4..11."""
+    spec = synth.hifi_spec(300, seed=19, coverage=30.0)
+    fasta = os.path.join(work, "hifi_multik.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                last_k=0, hpc=True, data_type=0)
+    tmp = run_ref_pipeline(os.path.join(work, "hifi_multik"), fasta, params, graph=False)
+    run_ref_multik(tmp, params, 11, os.path.join(HERE, "hifi_multik"), dict(
+        kind="hifi", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+        species_len=spec.species_len, species_weight=spec.species_weight, fasta_sha256=sha256(fasta), K=15, density=0.005, hpc=True))
+    spec = synth.SynthSpec(n_reads=150, read_len=20_000, seed=23, sub_rate=0.02,
+                           species_len=[50_000, 40_000], species_weight=[0.7, 0.3], with_quality=True, name="ont")
+    fastq = os.path.join(work, "ont_multik.fastq")
+    synth.write_fasta(fastq, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                last_k=0, hpc=False, data_type=1, correction_density=0.025)
+    tmp = run_ref_pipeline(os.path.join(work, "ont_multik"), fastq, params, extra_rs=["--skip-correction"], graph=False)
+    run_ref_multik(tmp, params, 11, os.path.join(HERE, "ont_multik"), dict(
+        kind="ont", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+        species_len=spec.species_len, species_weight=spec.species_weight, with_quality=True, fasta_sha256=sha256(fastq),
+        K=15, density=0.005, hpc=False, skip_correction=True))
+
+
 def edge_reads() -> list[bytes]:
     rng = np.random.default_rng(1234)
 
@@ -295,6 +362,9 @@ def main() -> None:
         make_fn()
         if "--only-fn" in sys.argv:
             return
+        if "--only-multik" in sys.argv:
+            make_multik(work)
+            return
         if "--only-pipelines" in sys.argv:
             make_hifi(work)
             make_ont(work)
@@ -302,6 +372,7 @@ def main() -> None:
         make_edge(work)
         make_hifi(work)
         make_ont(work)
+        make_multik(work)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     print("golden fixtures written under", HERE)

@@ -658,3 +658,35 @@ def test_unitig_edge_index_vs_oracle_and_reference_log(ctx, orc, name):
         keys = t.keys_to_host()
         got = keys[np.lexsort((keys[:, 0], keys[:, 1]))] if len(keys) else keys
         assert len(got) == len(hi) and np.array_equal(got[:, 1], hi) and np.array_equal(got[:, 0], lo) and ck == ock
+
+
+def _multik_cases():
+    from tests import multik_fixture as mk
+    return [(s, k) for s in mk.SETS for k in mk.steps(s)]
+
+
+@pytest.mark.parametrize("name,k", _multik_cases())
+def test_next_k_tables_equal_reference_multik(ctx, name, k):
+    """Rows A13 / A14 against the REFERENCE: previous table + unitig overlay, refined count (k = firstK+1), index
+    (k >= firstK+2) and the small-contig branch, on the inputs the reference's `graph` read in its own multi-k loop and
+    the tables it wrote (tests/golden/*_multik)."""
+    from tests import multik_fixture as mk
+    fx = mk.load(name, k)
+    P = fx["params"]
+    (rm, ro), (um, uo) = fx["reads"], fx["unitigs"]
+    d_reads = ctx.minimizers_from_host(rm, ro)
+    d_unitigs = ctx.minimizers_from_host(um, uo)
+    dprev = ctx.prev_from_records(fx["prev_records"])
+    if fx["prev_unitigs"]:
+        pm = np.concatenate([u for u, _ in fx["prev_unitigs"]]).astype(np.uint32)
+        po = np.concatenate([[0], np.cumsum([len(u) for u, _ in fx["prev_unitigs"]])]).astype(np.uint64)
+        pa = np.array([a for _, a in fx["prev_unitigs"]], dtype=np.uint32)
+        ctx.prev_overlay_unitigs(dprev, ctx.minimizers_from_host(pm, po), pa, P.prev_k)
+    t = (ctx.kminmer_count_refined if k == P.first_k + 1 else ctx.kminmer_index)(d_reads, d_unitigs, k, dprev)
+    rec, vec = t.to_host()
+    assert np.array_equal(formats.sorted_abundance_records(rec.tobytes()), fx["abundance_sorted"])
+    if fx["min_sorted"] is not None:
+        assert np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), k), fx["min_sorted"])
+    flags = ctx.small_contigs(d_unitigs, k, P.prev_k, dprev) if k > 8 else np.zeros(len(uo) - 1, np.uint8)
+    mine = sorted((0, tuple(int(x) for x in um[int(uo[i]): int(uo[i + 1])])) for i in np.nonzero(flags)[0])
+    assert mine == mk.small_contig_records(fx["small_contigs"])

@@ -199,3 +199,30 @@ def test_tool_graph_next_k_vs_oracle(tmp_path):
             assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k),
                                   formats.sorted_vector_records(exp["vecs"].astype("<u4").tobytes(), k))
             assert fbytes(tmp, "kminmerData_abundance_init_k5.txt") == fbytes(tmp, "kminmerData_abundance.txt")
+
+
+def _multik_cases():
+    from tests import multik_fixture as mk
+    return [(s, k) for s in mk.SETS for k in mk.steps(s)]
+
+
+@pytest.mark.parametrize("name,k", _multik_cases())
+def test_tool_graph_next_k_equals_reference(tmp_path, name, k):
+    """`mdbg_tool graph` at k = 5..11 on the files the reference's own `graph` read in its multi-k loop (unitig_data.txt,
+    *_prev, refined abundances -- products of the reference's contig / toMinspace stages, kept as data under
+    tests/golden/*_multik) against the files it wrote: abundance table, vectors at firstK+1, smallContigs_k<k>.bin."""
+    import shutil
+    from tests import multik_fixture as mk
+    fx = mk.load(name, k)
+    tmp = make_tmp(tmp_path, fx["params"], ["unused"])
+    for f in ("parameters.gz", "kminmerData_abundance_prev.txt", "unitigGraph_prev.nodes.bin",
+              "unitigGraph.nodes.refined_abundances.bin", "unitig_data.txt"):
+        shutil.copy(os.path.join(fx["dir"], f), os.path.join(tmp, f))
+    shutil.copy(os.path.join(mk.GOLDEN, name, "read_data_corrected.txt"), os.path.join(tmp, "read_data_corrected.txt"))
+    open(os.path.join(tmp, "smallContigs", f"smallContigs_k{k}.bin"), "wb").write(b"stale")
+    run(TOOL, "graph", tmp, "--threads", "1")
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), fx["abundance_sorted"])
+    if fx["min_sorted"] is not None:
+        assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k), fx["min_sorted"])
+    got = fbytes(tmp, os.path.join("smallContigs", f"smallContigs_k{k}.bin"))
+    assert mk.small_contig_records(got) == mk.small_contig_records(fx["small_contigs"])
