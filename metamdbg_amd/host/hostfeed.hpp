@@ -3,9 +3,10 @@
 // The reference parses with one kseq reader inside an `omp critical` (Commons.hpp:5868-5905), which
 // caps it near 0.5 Gbp/s whatever the thread count.  Here a plain (uncompressed) file is mmap'ed and
 // cut at record boundaries into chunks that worker threads parse independently into page-locked
-// batches (read order preserved by sequence numbers); gzip files fall back to a sequential reader
-// thread (one deflate stream cannot be split).  Batches come out in file order, ready for
-// mdbg_reads_from_ascii.
+// batches (read order preserved by sequence numbers).  A gzip file is one deflate stream and cannot be
+// split: one thread inflates it into slabs cut at record starts and the same workers parse and pack the
+// slabs (multi-line FASTQ inside gzip falls back to a sequential kseq-style reader).  Batches come out in
+// file order, ready for mdbg_reads_from_packed / mdbg_reads_from_ascii.
 #pragma once
 
 #include <fcntl.h>
@@ -13,6 +14,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -20,6 +22,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -111,6 +114,150 @@ struct PackCursor {
     bool bad() const { return overflow || (invalid & 0x0808080808080808ull) != 0; }
 };
 
+// BGZF (the blocked gzip that htslib writes: samtools fastq, bam2fastq, bgzip): every block of at most 64 KB is its
+// own gzip member whose header carries the compressed block size, so the blocks of a memory-mapped file can be inflated
+// by several threads at once.  read() hands the text out in file order.
+class BgzfReader {
+public:
+    struct Block { size_t payload; uint32_t csize; uint32_t isize; uint32_t crc; };
+
+    // true iff [addr, addr+len) is a sequence of BGZF blocks and nothing else
+    static bool index(const unsigned char *addr, size_t len, std::vector<Block> &out) {
+        size_t o = 0;
+        out.clear();
+        while (o < len) {
+            if (len - o < 18 + 8) return false;
+            const unsigned char *h = addr + o;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+            const size_t xlen = h[10] | ((size_t)h[11] << 8);
+            if (len - o < 12 + xlen + 8) return false;
+            size_t bsize = 0;
+            for (size_t x = 0; x + 4 <= xlen;) {               // extra subfields: SI1 SI2 SLEN(2) data
+                const unsigned char *sf = h + 12 + x;
+                const size_t slen = sf[2] | ((size_t)sf[3] << 8);
+                if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (sf[4] | ((size_t)sf[5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if ((h[3] & ~4u) || bsize < 12 + xlen + 8 || bsize > len - o) return false;   // other header fields are never set by BGZF writers
+            const unsigned char *t = addr + o + bsize - 8;
+            Block b;
+            b.payload = o + 12 + xlen;
+            b.csize = (uint32_t)(bsize - 12 - xlen - 8);
+            b.crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            b.isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            if (b.isize > (1u << 16)) return false;
+            out.push_back(b);
+            o += bsize;
+        }
+        return !out.empty();
+    }
+
+    BgzfReader(const unsigned char *addr, std::vector<Block> blocks, int threads, std::string path)
+        : addr_(addr), blocks_(std::move(blocks)), path_(std::move(path)) {
+        // groups of consecutive blocks holding about 4 MB of text
+        size_t text = 0;
+        groups_.push_back(0);
+        for (size_t i = 0; i < blocks_.size(); i++) {
+            if (text && text + blocks_[i].isize > ((size_t)4 << 20)) { groups_.push_back(i); text = 0; }
+            text += blocks_[i].isize;
+        }
+        groups_.push_back(blocks_.size());
+        window_ = (size_t)threads * 2 + 2;
+        for (int i = 0; i < threads; i++) pool_.emplace_back([this] { inflate_loop(); });
+    }
+    ~BgzfReader() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : pool_) if (t.joinable()) t.join();
+    }
+
+    // up to `want` bytes of text; 0 at the end of the file
+    size_t read(char *dst, size_t want) {
+        size_t got = 0;
+        while (got < want) {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return !error_.empty() || cur_ + 1 >= groups_.size() || ready_.count(cur_); });
+            if (!error_.empty()) throw std::runtime_error(error_);
+            if (cur_ + 1 >= groups_.size()) break;
+            std::vector<char> &t = ready_[cur_];
+            const size_t n = std::min(want - got, t.size() - pos_);
+            g.unlock();                                   // the entry of the current group is only touched by this thread
+            memcpy(dst + got, t.data() + pos_, n);
+            got += n; pos_ += n;
+            if (pos_ == t.size()) {
+                g.lock();
+                ready_.erase(cur_);
+                cur_++; pos_ = 0;
+                g.unlock();
+                cv_.notify_all();
+            }
+        }
+        return got;
+    }
+
+private:
+    void inflate_loop() {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) { fail("zlib initialisation failed"); return; }
+        for (;;) {
+            size_t gi;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || !error_.empty() || next_ + 1 >= groups_.size() || next_ < cur_ + window_; });
+                if (stop_ || !error_.empty() || next_ + 1 >= groups_.size()) break;
+                gi = next_++;
+            }
+            size_t total = 0;
+            for (size_t b = groups_[gi]; b < groups_[gi + 1]; b++) total += blocks_[b].isize;
+            std::vector<char> text(total);
+            size_t o = 0;
+            bool ok = true;
+            for (size_t b = groups_[gi]; b < groups_[gi + 1] && ok; b++) {
+                const Block &blk = blocks_[b];
+                inflateReset(&zs);
+                zs.next_in = const_cast<Bytef *>(addr_ + blk.payload);
+                zs.avail_in = blk.csize;
+                zs.next_out = (Bytef *)text.data() + o;
+                zs.avail_out = blk.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                ok = rc == Z_STREAM_END && zs.avail_out == 0 &&
+                     (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)text.data() + o, blk.isize) == blk.crc;
+                o += blk.isize;
+            }
+            if (!ok) { fail("corrupt BGZF block in " + path_); break; }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                ready_[gi] = std::move(text);
+            }
+            cv_.notify_all();
+        }
+        inflateEnd(&zs);
+    }
+    void fail(const std::string &msg) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (error_.empty()) error_ = msg;
+        }
+        cv_.notify_all();
+    }
+
+    const unsigned char *addr_;
+    std::vector<Block> blocks_;
+    std::vector<size_t> groups_;           // first block of every group, then the block count
+    std::string path_;
+    std::map<size_t, std::vector<char>> ready_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> pool_;
+    size_t next_ = 0, cur_ = 0, pos_ = 0, window_ = 4;
+    bool stop_ = false;
+    std::string error_;
+};
+
 class ReadFeeder {
 public:
     using Alloc = std::function<void *(size_t)>;
@@ -126,6 +273,7 @@ public:
         // copying ones were the limit; a buffer grows to the full chunk only if its chunk has to be delivered as ASCII.
         if (threads > (pack_ ? 12 : 6)) threads = pack_ ? 12 : 6;
         alloc_ = std::move(alloc);
+        nThreads_ = threads;
         const int nbuf = threads + 2;
         for (int i = 0; i < nbuf; i++) {
             ReadBatch *b = new ReadBatch();
@@ -195,7 +343,8 @@ public:
 
 private:
     struct Mapping { const char *addr = nullptr; size_t len = 0; };
-    struct Work { uint64_t seq; int file; const char *begin; const char *end; bool fastq; bool gz; std::string path; };
+    // [begin, end) lies in a memory-mapped file, or in `slab` (inflated text of a gzip file, released with the item)
+    struct Work { uint64_t seq; int file; const char *begin; const char *end; bool fastq; std::shared_ptr<char> slab; };
 
     static bool is_gzip(const std::string &path) {
         unsigned char m[2] = {0, 0};
@@ -242,7 +391,7 @@ private:
             for (size_t f = 0; f < files_.size(); f++) {
                 const std::string &path = files_[f];
                 if (is_gzip(path)) {
-                    // one deflate stream: a single sequential work item produces all its batches in order
+                    // one deflate stream: this thread inflates, the workers parse and pack the inflated slabs
                     seq = read_gz(path, (int)f, seq);
                     continue;
                 }
@@ -268,7 +417,7 @@ private:
                         q = last_record_before(p, p + chunk_, end, fastq);
                         if (q == p) throw std::runtime_error("a single read is larger than the batch size; raise --batch-bases");
                     }
-                    push_work({seq++, (int)f, p, q, fastq, false, ""});
+                    push_work({seq++, (int)f, p, q, fastq, nullptr});
                     p = q;
                 }
             }
@@ -300,8 +449,110 @@ private:
         cvDone_.notify_all();
     }
 
-    // gzip: sequential decode on the splitter thread itself
+    // First records of an inflated FASTQ slab: 4 lines each?  (Multi-line FASTQ goes to the sequential reader.)
+    static bool looks_four_line(const char *p, const char *end) {
+        for (int rec = 0; rec < 256 && p < end; rec++) {
+            const char *l[4];
+            const char *c = p;
+            for (int i = 0; i < 4; i++) {
+                l[i] = (const char *)memchr(c, '\n', (size_t)(end - c));
+                if (!l[i]) return true;              // slab ends inside this record: nothing seen against 4 lines
+                c = l[i] + 1;
+            }
+            if (*p != '@' || l[1][1] != '+') return false;
+            size_t ns = (size_t)(l[1] - l[0] - 1), nq = (size_t)(l[3] - l[2] - 1);
+            if (ns && l[1][-1] == '\r') ns--;
+            if (nq && l[3][-1] == '\r') nq--;
+            if (ns != nq) return false;
+            p = c;
+        }
+        return true;
+    }
+
+    // gzip: this thread only inflates.  The text is cut at record starts into slabs of at most one chunk, which the
+    // workers parse and pack like slices of a memory-mapped file; at most threads + 2 slabs exist at a time.
     uint64_t read_gz(const std::string &path, int file, uint64_t seq) {
+        // BGZF: the blocks are inflated by a pool of threads, this thread only stitches the text into slabs
+        std::unique_ptr<BgzfReader> bgzf;
+        Mapping map;
+        struct Unmap { Mapping *m; ~Unmap() { if (m->addr) munmap((void *)m->addr, m->len); } } unmap{&map};
+        if (!getenv("MDBG_HOST_NO_BGZF")) {
+            int fd = open(path.c_str(), O_RDONLY);
+            if (fd < 0) throw std::runtime_error("File not found: " + path);
+            struct stat st;
+            fstat(fd, &st);
+            void *addr = st.st_size ? mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+            close(fd);
+            if (addr != MAP_FAILED) {
+                map = {(const char *)addr, (size_t)st.st_size};
+                std::vector<BgzfReader::Block> blocks;
+                if (BgzfReader::index((const unsigned char *)addr, map.len, blocks))
+                    bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), nThreads_, path));
+            }
+        }
+        gzFile fp = nullptr;
+        if (!bgzf) {
+            fp = gzopen(path.c_str(), "r");
+            if (!fp) throw std::runtime_error("File not found: " + path);
+            gzbuffer(fp, 1 << 20);
+        }
+        struct Closer { gzFile f; ~Closer() { if (f) gzclose(f); } } closer{fp};
+        std::vector<char> carry;          // text behind the last cut: an incomplete record and the look-ahead
+        bool first = true, fastq = false, eof = false;
+        const size_t maxSlabs = (size_t)nThreads_ + 2;
+        // a record start is recognised from the two lines that follow it, so text is inflated some way past the
+        // chunk before the cut is chosen (enough for reads of a few Mbp; longer ones need a larger --batch-bases)
+        const size_t cap = chunk_ + std::min<size_t>(chunk_, (size_t)4 << 20);
+        while ((!eof || !carry.empty()) && !fileDone_[file].load()) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cvFree_.wait(g, [&] { return stop_ || slabsOut_ < maxSlabs; });
+                if (stop_) return seq;
+            }
+            std::shared_ptr<char> slab(new char[cap + 1], std::default_delete<char[]>());
+            char *buf = slab.get();
+            size_t len = carry.size();
+            if (len) memcpy(buf, carry.data(), len);
+            carry.clear();
+            while (!eof && len < cap) {
+                long n;
+                if (bgzf) n = (long)bgzf->read(buf + len, cap - len);
+                else n = gzread(fp, buf + len, (unsigned)std::min<size_t>(cap - len, (size_t)1 << 30));
+                if (n < 0) throw std::runtime_error("gzip read error: " + path);
+                if (n == 0) { eof = true; break; }
+                len += (size_t)n;
+            }
+            const char *begin = buf, *end = buf + len;
+            if (first) {
+                while (begin < end && (*begin == '\n' || *begin == '\r')) begin++;
+                if (begin == end) { if (eof) break; continue; }
+                fastq = *begin == '@';
+                if (!fastq && *begin != '>') throw std::runtime_error("not FASTA/FASTQ: " + path);
+                if (fastq && !looks_four_line(begin, end)) {
+                    if (fp) gzclose(fp);
+                    closer.f = nullptr;
+                    bgzf.reset();
+                    return read_gz_sequential(path, file, seq);
+                }
+                first = false;
+            }
+            const char *q = end;
+            if ((size_t)(end - begin) > chunk_) {
+                q = last_record_before(begin, begin + chunk_, end, fastq);
+                if (q == begin) throw std::runtime_error("a single read is larger than the batch size; raise --batch-bases");
+            }
+            carry.assign(q, end);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                slabsOut_++;
+            }
+            push_work({seq++, file, begin, q, fastq, slab});
+        }
+        return seq;
+    }
+
+    // gzip, multi-line FASTQ: sequential decode and parse on the splitter thread itself
+    uint64_t read_gz_sequential(const std::string &path, int file, uint64_t seq) {
         FastxReader rd(path);
         if (!rd.ok()) throw std::runtime_error("File not found: " + path);
         std::string s, q;
@@ -461,6 +712,14 @@ private:
                 if (!fileDone_[w.file].load()) {
                     if (!pack_ || !parse_packed(w, b)) { b->clear(); parse(w, b); }
                 } else b->file = w.file;
+                if (w.slab) {
+                    w.slab.reset();
+                    {
+                        std::lock_guard<std::mutex> g(mu_);
+                        slabsOut_--;
+                    }
+                    cvFree_.notify_all();
+                }
                 deliver(w.seq, b);
             }
         } catch (const std::exception &e) { fail(e.what()); }
@@ -490,6 +749,8 @@ private:
     std::thread splitter_;
     std::vector<std::thread> workers_;
     uint64_t nextSeq_ = 0, totalSeq_ = 0;
+    size_t slabsOut_ = 0;   // inflated gzip slabs queued or being parsed
+    int nThreads_ = 1;
     bool splitDone_ = false, stop_ = false;
     bool pack_ = getenv("MDBG_HOST_NO_PACK") == nullptr;   // pack to 2 bits on the host unless asked not to
     std::string error_;

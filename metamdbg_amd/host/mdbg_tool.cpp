@@ -59,6 +59,20 @@ void check(int rc, const char *what) {
     if (rc != MDBG_OK) die(std::string(what) + ": " + mdbg_last_error(g_ctx));
 }
 
+// Appends to <parent of tmpDir>/metaMDBG.log, the file Tool::openLogFile points the reference's logger at (Commons.hpp:8070-8086).
+struct LogFile {
+    std::ofstream f;
+    void open(const std::string &tmpDir) {
+        std::string d = tmpDir;
+        while (d.size() > 1 && d.back() == '/') d.pop_back();
+        const size_t cut = d.find_last_of('/');
+        std::string parent = cut == std::string::npos ? std::string() : d.substr(0, cut == 0 ? 1 : cut);
+        if (parent.empty()) parent = tmpDir;
+        f.open(parent + "/metaMDBG.log", std::ios::app);
+    }
+    void line(const std::string &s) { if (f) { f << s << "\n"; f.flush(); } }
+} g_log;
+
 // ---- parameters.gz (pipeline/AssemblyPipeline.hpp:1479-1517 / Commons.hpp:1475-1497) -----------------
 struct Parameters {
     size_t minimizerSize = 0, kminmerSize = 0;
@@ -218,6 +232,8 @@ int run_read_selection(int argc, char **argv) {
     const std::string tmpDir = a.pos[0], outFile = a.pos[1], inputList = a.pos[2];
     Parameters P;
     P.load(tmpDir + "/parameters.gz");
+    g_log.open(tmpDir);
+    g_log.line("mdbg_tool readSelection (MI355X) " + inputList);
     check(mdbg_create(0, &g_ctx), "mdbg_create");
     g_trace.mark("context created");
 
@@ -415,6 +431,8 @@ int run_read_selection(int argc, char **argv) {
         st.write((const char *)&nbSelected, 8);
     }
 
+    g_log.line("\tNb reads: " + std::to_string(nbReads) + "  bases: " + std::to_string(nbBases) + "  minimizers: " + std::to_string(nbSelected) +
+               "  N50: " + std::to_string(n50));
     // purgePalindromes (ReadSelection.hpp:1374-1431): lastK from the N50, --max-k ignored
     if (needCorrected) {
         const int lastK = compute_last_k(P.densityAssembly, n50, P.firstK, 0);
@@ -486,8 +504,10 @@ int run_graph(int argc, char **argv) {
     const std::string dir = a.pos[0];
     Parameters P;
     P.load(dir + "/parameters.gz");
+    g_log.open(dir);
     check(mdbg_create(0, &g_ctx), "mdbg_create");
     const uint32_t k = (uint32_t)P.kminmerSize;
+    g_log.line("mdbg_tool graph (MI355X) k = " + std::to_string(k) + (a.firstPass ? " --firstpass" : ""));
     mdbg_minimizers *reads = upload_reads(dir + "/read_data_corrected.txt", true);
     mdbg_table *table = nullptr;
     // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
@@ -562,9 +582,15 @@ int run_graph(int argc, char **argv) {
         if (unitigs) mdbg_minimizers_free(unitigs);
         mdbg_table_free(prev);
     }
-    uint64_t n = 0;
+    uint64_t n = 0, nSolid = 0;
     int hasVec = 0;
-    mdbg_table_info(table, nullptr, &n, nullptr, &hasVec);
+    mdbg_table_info(table, nullptr, &n, &nSolid, &hasVec);
+    if (a.firstPass) {   // the two counts the reference logs after its first pass (graph/CreateMdbg.cpp:300-328)
+        g_log.line("\tNb solid kminmers: " + std::to_string(nSolid));
+        g_log.line("\tNb rescued kminmers: " + std::to_string(n - nSolid));
+    } else {
+        g_log.line("\tNb kminmers: " + std::to_string(n));
+    }
     std::vector<uint8_t> rec(n * 20);
     std::vector<uint32_t> vec(hasVec ? n * k : 0);
     check(mdbg_table_to_host(g_ctx, table, rec.data(), hasVec ? vec.data() : nullptr), "mdbg_table_to_host");

@@ -69,6 +69,11 @@ def test_tool_hifi_200_golden(tmp_path):
     assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
     assert fbytes(tmp, "kminmerData_abundance_init.txt") == fbytes(tmp, "kminmerData_abundance.txt")
     assert len(fbytes(tmp, "perf.bin")) == 16
+    assert fbytes(tmp, "smallContigs/smallContigs_k4.bin") == b""
+    # <out>/metaMDBG.log is appended to like the reference's logger, with the two first-pass counts in the reference's words
+    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+    assert f"Nb solid kminmers: {m['reference_log']['n_solid']}\n" in log
+    assert f"Nb rescued kminmers: {m['reference_log']['n_rescued']}\n" in log
 
 
 def test_tool_ont_100_golden(tmp_path):
@@ -144,11 +149,17 @@ def test_tool_vs_reference_live_fastq_hpc(tmp_path):
             s = synth.CODE2ASCII[rng.integers(0, 4, L)]
             q = (rng.integers(2, 94, L) + 33).astype(np.uint8)
             f.write(b"@r%d\n" % i + bytes(s) + b"\n+\n" + bytes(q) + b"\n")
+    # the same records once more as BGZF (htslib's blocked gzip: inflated by several threads) and as ordinary gzip
+    from tests.test_hostfeed import _bgzf
+    raw = open(fq, "rb").read()
+    fq_bgzf, fq_gz = str(tmp_path / "r.bgzf.fastq.gz"), str(tmp_path / "r.plain.fastq.gz")
+    open(fq_bgzf, "wb").write(_bgzf(raw, block=20000))
+    open(fq_gz, "wb").write(gzip.compress(raw, 1))
     P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
-    t_ref = make_tmp(tmp_path / "ref", P, [fq])
-    t_gpu = make_tmp(tmp_path / "gpu", P, [fq])
+    t_ref = make_tmp(tmp_path / "ref", P, [fq, fq_bgzf, fq_gz])
+    t_gpu = make_tmp(tmp_path / "gpu", P, [fq, fq_bgzf, fq_gz])
     read_selection(REFDRV, t_ref)
-    read_selection(TOOL, t_gpu, extra=["--batch-bases", "300000"])
+    read_selection(TOOL, t_gpu, extra=["--batch-bases", "300000", "--threads", "4"])
     for name in ("read_data_init.txt", "read_data_corrected.txt"):
         assert fbytes(t_gpu, name) == fbytes(t_ref, name), name
     assert fbytes(t_gpu, "read_stats.txt") == fbytes(t_ref, "read_stats.txt")

@@ -19,6 +19,21 @@ def exe(tmp_path_factory):
     return out
 
 
+def _bgzf(data: bytes, block: int = 0xff00, level: int = 6, eof_marker: bool = True) -> bytes:
+    """BGZF as htslib writes it (SAM spec 4.1): gzip members of <= 64 KB with the 'BC' extra subfield = block size - 1."""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[o:o + block] for o in range(0, len(data), block)] + ([b""] if eof_marker else [])
+    for c in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = co.compress(c) + co.flush()
+        bsize = 12 + 6 + len(payload) + 8
+        out += struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += payload + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c))
+    return bytes(out)
+
+
 def _rand_seq(rng, n):
     return bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)])
 
@@ -69,16 +84,72 @@ def files(tmp_path_factory):
         for i in range(200):
             f.write(b">z%d\n" % i + _rand_seq(rng, int(rng.integers(1, 4000))) + b"\n")
     out["gz"] = p
+    # gzipped 4-line FASTQ (inflated slabs go to the parallel workers), '@' / '+' at the ends of quality strings
+    p = str(d / "z.fastq.gz")
+    with gzip.open(p, "wb") as f:
+        for i in range(300):
+            n = int(rng.integers(1, 4000))
+            q = (rng.integers(0, 61, n) + 33).astype(np.uint8)
+            q[0] = ord("@") if i % 3 == 0 else q[0]
+            q[-1] = ord("+") if i % 4 == 0 else q[-1]
+            f.write(b"@g%d\n" % i + _rand_seq(rng, n) + b"\n+g%d\n" % i + bytes(q) + b"\n")
+    out["gz_fastq"] = p
+    # gzipped wrapped FASTA, two gzip members, no trailing newline
+    p = str(d / "zw.fasta.gz")
+    with open(p, "wb") as raw:
+        for member in range(2):
+            with gzip.GzipFile(fileobj=raw, mode="wb") as f:
+                for i in range(150):
+                    s = _rand_seq(rng, int(rng.integers(0, 3000)))
+                    f.write(b">m%d_%d\n" % (member, i))
+                    for o in range(0, len(s), 80):
+                        f.write(s[o:o + 80] + b"\n")
+                if member == 1:
+                    f.write(b">last\nACGTTGCA")
+    out["gz_wrapped"] = p
+    # gzipped multi-line FASTQ: the sequential reader's job
+    p = str(d / "zm.fastq.gz")
+    with gzip.open(p, "wb") as f:
+        for i in range(120):
+            n = int(rng.integers(100, 1500))
+            s_, q_ = _rand_seq(rng, n), bytes((rng.integers(0, 40, n) + 33).astype(np.uint8))
+            f.write(b"@ml%d\n" % i)
+            for o in range(0, n, 70):
+                f.write(s_[o:o + 70] + b"\n")
+            f.write(b"+\n")
+            for o in range(0, n, 70):
+                f.write(q_[o:o + 70] + b"\n")
+    out["gz_multiline_fastq"] = p
+    # BGZF (samtools fastq / bam2fastq / bgzip output): FASTQ, small blocks so that records straddle many of them
+    recs = bytearray()
+    for i in range(500):
+        n = int(rng.integers(1, 4000))
+        q = (rng.integers(0, 61, n) + 33).astype(np.uint8)
+        q[0] = ord("@") if i % 3 == 0 else q[0]
+        recs += b"@b%d\n" % i + _rand_seq(rng, n) + b"\n+\n" + bytes(q) + b"\n"
+    p = str(d / "b.fastq.gz")
+    open(p, "wb").write(_bgzf(bytes(recs), block=3000))
+    out["bgzf_fastq"] = p
+    p = str(d / "b64k.fastq.gz")
+    open(p, "wb").write(_bgzf(bytes(recs), eof_marker=False))
+    out["bgzf_fastq_64k"] = p
+    # BGZF FASTA followed by an ordinary gzip member: not pure BGZF, must take the gzread path
+    p = str(d / "mixed.fasta.gz")
+    fa = b"".join(b">x%d\n" % i + _rand_seq(rng, int(rng.integers(1, 3000))) + b"\n" for i in range(100))
+    open(p, "wb").write(_bgzf(fa[: len(fa) // 2], eof_marker=False) + gzip.compress(fa[len(fa) // 2:]))
+    out["bgzf_then_gzip"] = p
     return out
 
 
 @pytest.mark.parametrize("chunk", [10000, 50000, 1 << 22])
 @pytest.mark.parametrize("threads", [1, 4])
 def test_parallel_reader_matches_sequential(exe, files, chunk, threads):
-    for key in ("single", "wrapped", "fastq", "gz"):
+    for key in ("single", "wrapped", "fastq", "gz", "gz_fastq", "gz_wrapped", "gz_multiline_fastq", "bgzf_fastq", "bgzf_fastq_64k",
+                "bgzf_then_gzip"):
         r = subprocess.run([exe, str(chunk), str(threads), "0", files[key]], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (key, r.stderr)
-    r = subprocess.run([exe, str(chunk), str(threads), "0", files["single"], files["gz"], files["fastq"], files["wrapped"]],
+    r = subprocess.run([exe, str(chunk), str(threads), "0", files["single"], files["gz"], files["fastq"], files["gz_fastq"],
+                        files["wrapped"], files["gz_multiline_fastq"], files["bgzf_fastq"], files["gz_wrapped"]],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
 
@@ -106,3 +177,13 @@ def test_packed_and_ascii_batches(exe, files):
         r = subprocess.run([exe, "10000", "2", "0", files[key]], capture_output=True, text=True, timeout=120,
                            env=dict(os.environ, MDBG_HOST_NO_BMI2="1"))
         assert r.returncode == 0 and int(r.stdout.split()[5]) > 0, (key, r.stderr)
+
+
+def test_bgzf_corruption_is_reported(exe, files, tmp_path):
+    """A flipped byte inside a BGZF block fails the block's CRC (or the inflate) and surfaces as an error, not as wrong reads."""
+    raw = bytearray(open(files["bgzf_fastq_64k"], "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    r = subprocess.run([exe, str(1 << 20), "3", "0", bad], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
