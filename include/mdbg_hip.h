@@ -46,7 +46,7 @@ typedef struct mdbg_table mdbg_table;             /* k-min-mer table resident in
 /* ---- context ------------------------------------------------------------------------- */
 int  mdbg_create(int device, mdbg_ctx **ctx);
 void mdbg_destroy(mdbg_ctx *ctx);
-const char *mdbg_last_error(const mdbg_ctx *ctx);      /* ctx may be NULL: last creation error */
+const char *mdbg_last_error(const mdbg_ctx *ctx);      /* ctx may be NULL: last creation error of the calling thread */
 int  mdbg_synchronize(mdbg_ctx *ctx);
 void *mdbg_stream(mdbg_ctx *ctx);                       /* the hipStream_t every launch goes to */
 int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes);

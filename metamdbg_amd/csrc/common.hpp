@@ -11,6 +11,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -112,8 +114,6 @@ struct mdbg_ctx {
     bool timing = false;
     std::vector<mdbg::TimedLaunch> launches;               // pending (not yet folded) timed launches
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
-    // scratch kept between calls (partial-count rows handed out to the caller)
-    void *partial_rows = nullptr;
     double key_ratio_hint = 0.0625;                        // distinct keys per k-min-mer instance seen last time (table sizing)
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out
 };
@@ -121,7 +121,7 @@ struct mdbg_ctx {
 namespace mdbg {
 
 int set_error(mdbg_ctx *ctx, int code, const char *fmt, ...);
-extern std::string g_last_error;  // for failures before a context exists
+extern thread_local std::string g_last_error;  // for failures before a context exists (per calling thread)
 
 #define MDBG_HIP_CHECK(ctx, expr)                                                              \
     do {                                                                                       \
@@ -130,6 +130,11 @@ extern std::string g_last_error;  // for failures before a context exists
             return mdbg::set_error((ctx), e_ == hipErrorOutOfMemory ? MDBG_ENOMEM : MDBG_EHIP, \
                                    "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// No C++ exception may cross the C ABI: every entry point that can allocate on the host is a function-try-block ending in this.
+#define MDBG_API_CATCH(ctx)                                                                                     \
+    catch (const std::bad_alloc &) { return mdbg::set_error((ctx), MDBG_ENOMEM, "host memory allocation failed"); } \
+    catch (const std::exception &e_) { return mdbg::set_error((ctx), MDBG_EHIP, "internal error: %s", e_.what()); }
 
 #define MDBG_TRY(expr)            \
     do {                          \

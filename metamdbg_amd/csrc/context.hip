@@ -3,7 +3,7 @@
 
 namespace mdbg {
 
-std::string g_last_error;
+thread_local std::string g_last_error;
 
 int set_error(mdbg_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
@@ -35,7 +35,7 @@ static void fold_timers(mdbg_ctx *ctx) {
 
 using namespace mdbg;
 
-extern "C" int mdbg_create(int device, mdbg_ctx **out) {
+extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     if (!out) return set_error(nullptr, MDBG_EINVAL, "mdbg_create: null out pointer");
     *out = nullptr;
     int count = 0;
@@ -66,13 +66,12 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) {
     ctx->pool->device = device;
     *out = ctx;
     return MDBG_OK;
-}
+} MDBG_API_CATCH((mdbg_ctx *)nullptr)
 
 extern "C" void mdbg_destroy(mdbg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     fold_timers(ctx);
-    if (ctx->partial_rows) (void)hipFree(ctx->partial_rows);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pool) ctx->pool->close();      // cached blocks are freed now; blocks still handed out free themselves
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -83,15 +82,15 @@ extern "C" const char *mdbg_last_error(const mdbg_ctx *ctx) {
     return ctx ? ctx->err.c_str() : g_last_error.c_str();
 }
 
-extern "C" int mdbg_synchronize(mdbg_ctx *ctx) {
+extern "C" int mdbg_synchronize(mdbg_ctx *ctx) try {
     if (!ctx) return MDBG_EINVAL;
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" void *mdbg_stream(mdbg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-extern "C" int mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes) {
+extern "C" int mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes) try {
     if (!ctx) return MDBG_EINVAL;
     if (arch && arch_len) {
         strncpy(arch, ctx->arch.c_str(), arch_len - 1);
@@ -100,37 +99,37 @@ extern "C" int mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int 
     if (n_cu) *n_cu = ctx->n_cu;
     if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_timing_enable(mdbg_ctx *ctx, int on) {
+extern "C" int mdbg_timing_enable(mdbg_ctx *ctx, int on) try {
     if (!ctx) return MDBG_EINVAL;
     ctx->timing = on != 0;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_timing_reset(mdbg_ctx *ctx) {
+extern "C" int mdbg_timing_reset(mdbg_ctx *ctx) try {
     if (!ctx) return MDBG_EINVAL;
     fold_timers(ctx);
     ctx->timers.clear();
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_timing_get(mdbg_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches) {
+extern "C" int mdbg_timing_get(mdbg_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches) try {
     if (!ctx || !kernel) return MDBG_EINVAL;
     fold_timers(ctx);
     auto it = ctx->timers.find(kernel);
     if (ms_total) *ms_total = it == ctx->timers.end() ? 0.0 : it->second.first;
     if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.second;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_host_alloc(mdbg_ctx *ctx, size_t bytes, void **out) {
+extern "C" int mdbg_host_alloc(mdbg_ctx *ctx, size_t bytes, void **out) try {
     if (!ctx || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_host_alloc: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
     if (e != hipSuccess) return set_error(ctx, MDBG_ENOMEM, "hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" void mdbg_host_free(mdbg_ctx *ctx, void *p) {
     (void)ctx;

@@ -601,7 +601,7 @@ static int check_seq(mdbg_ctx *ctx, const mdbg_minimizers *m, const char *who) {
 }
 
 extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance,
-                                        mdbg_table **out) {
+                                        mdbg_table **out) try {
     if (!ctx || !out || k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_first: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_count_first"));
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -664,7 +664,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_count_first failed: %s", hipGetErrorString(e)); }
     *out = t;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 // build a lookup DeviceTable from the rows of `t` (abundance == 1 skipped as loadRefinedAbundances does)
 static int ensure_lookup(mdbg_ctx *ctx, mdbg_table *t, bool skip_one) {
@@ -680,7 +680,7 @@ static int ensure_lookup(mdbg_ctx *ctx, mdbg_table *t, bool skip_one) {
     return MDBG_OK;
 }
 
-extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, uint64_t n_records, mdbg_table **out) {
+extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, uint64_t n_records, mdbg_table **out) try {
     if (!ctx || !out || (n_records && !records20)) return set_error(ctx, MDBG_EINVAL, "mdbg_prev_from_records: bad argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mdbg_table *t = new mdbg_table();
@@ -706,10 +706,10 @@ extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, u
     t->lookup = std::move(tab);
     *out = t;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_prev_overlay_unitigs(mdbg_ctx *ctx, mdbg_table *prev, const mdbg_minimizers *unitigs,
-                                         const uint32_t *abundance, uint32_t k_prev) {
+                                         const uint32_t *abundance, uint32_t k_prev) try {
     if (!ctx || !prev || !prev->lookup || !abundance || k_prev < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_prev_overlay_unitigs: bad argument");
     MDBG_TRY(check_seq(ctx, unitigs, "mdbg_prev_overlay_unitigs"));
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -725,7 +725,7 @@ extern "C" int mdbg_prev_overlay_unitigs(mdbg_ctx *ctx, mdbg_table *prev, const 
         hipLaunchKernelGGL(overlay_kernel, dim3(grid_for(ix.total, 256)), dim3(256), 0, ctx->stream, sv, k_prev, d_ab.p, prev->lookup->view());
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return prev->lookup->check_overflow(ctx);
-}
+} MDBG_API_CATCH(ctx)
 
 static int prev_view(mdbg_ctx *ctx, const mdbg_table *prev, TableView &pv) {
     if (!prev) return set_error(ctx, MDBG_EINVAL, "previous table is null");
@@ -735,7 +735,7 @@ static int prev_view(mdbg_ctx *ctx, const mdbg_table *prev, TableView &pv) {
 }
 
 extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
-                                          uint32_t k, const mdbg_table *prev, mdbg_table **out) {
+                                          uint32_t k, const mdbg_table *prev, mdbg_table **out) try {
     if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_refined: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_count_refined"));
     if (unitigs) MDBG_TRY(check_seq(ctx, unitigs, "mdbg_kminmer_count_refined"));
@@ -790,7 +790,7 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_count_refined failed: %s", hipGetErrorString(e)); }
     *out = t;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, const TableView &pv, const TableView &tv) {
     InstIndex ik, ikm1;
@@ -813,7 +813,7 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
 }
 
 extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
-                                  uint32_t k, const mdbg_table *prev, mdbg_table **out) {
+                                  uint32_t k, const mdbg_table *prev, mdbg_table **out) try {
     if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_index: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_index"));
     if (unitigs) MDBG_TRY(check_seq(ctx, unitigs, "mdbg_kminmer_index"));
@@ -853,7 +853,7 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_index failed: %s", hipGetErrorString(e)); }
     *out = t;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_records, uint64_t *n_solid, int *has_vectors) {
     if (!t) return MDBG_EINVAL;
@@ -864,7 +864,7 @@ extern "C" int mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_rec
     return MDBG_OK;
 }
 
-extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors) {
+extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors) try {
     if (!ctx || !t) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (records20 && t->n_records) {
@@ -880,10 +880,10 @@ extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *r
         if (t->n_records) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, vectors, t->d_vec.p, t->n_records * t->k * 4, hipMemcpyDeviceToHost));
     }
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
-                                 uint64_t n, uint32_t *abundance) {
+                                 uint64_t n, uint32_t *abundance) try {
     if (!ctx || !t || (n && (!hash_lo || !hash_hi || !abundance))) return set_error(ctx, MDBG_EINVAL, "mdbg_table_lookup: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     MDBG_TRY(ensure_lookup(ctx, const_cast<mdbg_table *>(t), false));
@@ -899,10 +899,10 @@ extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint6
     MDBG_HIP_CHECK(ctx, hipMemcpyAsync(abundance, dv.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_small_contigs(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, uint32_t k_prev, const mdbg_table *prev,
-                                  uint8_t *flags) {
+                                  uint8_t *flags) try {
     if (!ctx || !unitigs || k_prev < 1 || k <= k_prev) return set_error(ctx, MDBG_EINVAL, "mdbg_small_contigs: bad argument");
     MDBG_TRY(check_seq(ctx, unitigs, "mdbg_small_contigs"));
     if (unitigs->n_reads && !flags) return set_error(ctx, MDBG_EINVAL, "mdbg_small_contigs: flags is null");
@@ -917,7 +917,7 @@ extern "C" int mdbg_small_contigs(mdbg_ctx *ctx, const mdbg_minimizers *unitigs,
     MDBG_HIP_CHECK(ctx, hipMemcpyAsync(flags, d_flags.p, unitigs->n_reads, hipMemcpyDeviceToHost, ctx->stream));
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 // every occupied slot of `tab` becomes a key-only row of a new table of (k-1)-identities
 static int edges_from_table(mdbg_ctx *ctx, DeviceTable &tab, uint32_t k_edge, mdbg_table **edges, uint64_t *checksum, const char *who) {
@@ -953,7 +953,7 @@ static int edges_from_table(mdbg_ctx *ctx, DeviceTable &tab, uint32_t k_edge, md
     return MDBG_OK;
 }
 
-extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum) {
+extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_table **edges, uint64_t *checksum) try {
     if (!ctx || !nodes || !edges) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: null argument");
     if (!nodes->has_vectors || nodes->k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_edge_index: needs a table with vectors (k <= firstK+1)");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -967,9 +967,9 @@ extern "C" int mdbg_edge_index(mdbg_ctx *ctx, const mdbg_table *nodes, mdbg_tabl
         return MDBG_OK;
     }));
     return edges_from_table(ctx, tab, nodes->k - 1, edges, checksum, "mdbg_edge_index");
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_unitig_edge_index(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, mdbg_table **edges, uint64_t *checksum) {
+extern "C" int mdbg_unitig_edge_index(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, mdbg_table **edges, uint64_t *checksum) try {
     if (!ctx || !edges || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_unitig_edge_index: bad argument");
     MDBG_TRY(check_seq(ctx, unitigs, "mdbg_unitig_edge_index"));
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -984,9 +984,9 @@ extern "C" int mdbg_unitig_edge_index(mdbg_ctx *ctx, const mdbg_minimizers *unit
         return MDBG_OK;
     }));
     return edges_from_table(ctx, tab, k - 1, edges, checksum, "mdbg_unitig_edge_index");
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_lo_hi) {
+extern "C" int mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_lo_hi) try {
     if (!ctx || !t || (t->n_records && !keys_lo_hi)) return set_error(ctx, MDBG_EINVAL, "mdbg_table_keys_to_host: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (!t->n_records) return MDBG_OK;
@@ -995,7 +995,7 @@ extern "C" int mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint6
     hipLaunchKernelGGL(interleave_keys_kernel, dim3(grid_for(t->n_records, 256)), dim3(256), 0, ctx->stream, t->d_lo.p, t->d_hi.p, t->n_records, tmp.p);
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, keys_lo_hi, tmp.p, t->n_records * 16, hipMemcpyDeviceToHost));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" void mdbg_table_free(mdbg_table *t) { delete t; }
 
@@ -1113,7 +1113,7 @@ struct mdbg_shard {
 extern "C" uint32_t mdbg_row_words(uint32_t) { return mdbg::SHARD_ROW_WORDS; }
 
 extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t n_ranks,
-                                mdbg_shard **out, const uint64_t **d_rows, uint64_t *counts) {
+                                mdbg_shard **out, const uint64_t **d_rows, uint64_t *counts) try {
     if (!ctx || !reads || !out || !d_rows || !counts || k < 2 || n_ranks < 1 || n_ranks > 64)
         return set_error(ctx, MDBG_EINVAL, "mdbg_shard_begin: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_shard_begin"));
@@ -1162,9 +1162,9 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     *d_rows = sh->rows.p;
     *out = sh.release();
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) {
+extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) try {
     if (!ctx || !sh || !d_reply || (n_recv && !d_recv)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_reduce: bad argument");
     if (n_recv >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 received rows");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1190,9 +1190,9 @@ extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     sh->reduced = true;
     *d_reply = sh->reply.p;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out) {
+extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out) try {
     if (!ctx || !sh || !out || (sh->n_rows && !d_replies)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: bad argument");
     if (!sh->reduced) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: mdbg_shard_reduce has not run");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1233,6 +1233,6 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "mdbg_shard_finish failed: %s", hipGetErrorString(e)); }
     *out = t;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" void mdbg_shard_free(mdbg_shard *shard) { delete shard; }

@@ -187,7 +187,7 @@ extern "C" int mdbg_minimizers_info(const mdbg_minimizers *m, uint32_t *n_reads,
 
 extern "C" int mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, uint64_t *offsets,
                                        uint32_t *minimizers, uint32_t *positions, uint8_t *directions, uint8_t *qualities,
-                                       uint32_t *read_lengths, float *mean_quality, uint8_t *read_flags) {
+                                       uint32_t *read_lengths, float *mean_quality, uint8_t *read_flags) try {
     if (!ctx || !m) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_to_host: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = m->n_reads, t = m->n_min;
@@ -202,10 +202,10 @@ extern "C" int mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, 
     if (read_flags && n) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, read_flags, m->d_flags.p, n, hipMemcpyDeviceToHost));
     if (mean_quality && n) memcpy(mean_quality, m->h_mean_quality.data(), n * sizeof(float));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimizers, const uint64_t *offsets,
-                                         uint32_t n_reads, mdbg_minimizers **out) {
+                                         uint32_t n_reads, mdbg_minimizers **out) try {
     if (!ctx || !out || !offsets) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_host: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mdbg_minimizers *m = new mdbg_minimizers();
@@ -225,7 +225,7 @@ extern "C" int mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimize
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "upload failed: %s", hipGetErrorString(e)));
     *out = m;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers) {
     if (!m) return MDBG_EINVAL;
@@ -236,7 +236,7 @@ extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint6
 
 extern "C" void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
 
-extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out) {
+extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out) try {
     if (!ctx || !in || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: null argument");
     if (!(density > 0.0f)) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: density must be > 0");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -283,10 +283,10 @@ extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = m.release();
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t first_k, uint32_t last_k,
-                                      mdbg_minimizers **out) {
+                                      mdbg_minimizers **out) try {
     if (!ctx || !in || !out || first_k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_purge_palindromes: bad argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = in->n_reads;
@@ -347,9 +347,9 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
     *out = m;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out) {
+extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out) try {
     if (!ctx || !m || !out || !n_out) return set_error(ctx, MDBG_EINVAL, "mdbg_repetitive_minimizers: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint64_t n = m->n_min;
@@ -396,4 +396,4 @@ extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *
     for (int i = 0; i < keep; i++) out[i] = hv[order[i]];
     *n_out = (uint32_t)keep;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)

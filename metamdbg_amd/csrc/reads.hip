@@ -113,7 +113,7 @@ using namespace mdbg;
 static inline uint64_t words_for(uint64_t len) { return ((len + 63) / 64) * 2; }  // reads start on 16-byte units
 
 extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, const uint64_t *offsets,
-                                     uint32_t n_reads, mdbg_reads **out) {
+                                     uint32_t n_reads, mdbg_reads **out) try {
     if (!ctx || !out || (n_reads && (!bases || !offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_from_ascii: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mdbg_reads *r = new mdbg_reads();
@@ -168,10 +168,10 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
     if (!r->has_invalid) r->d_invalid.release();
     *out = r;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
-                                      const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out) {
+                                      const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out) try {
     if (!ctx || !out || (n_reads && (!words || !word_offsets || !lengths)))
         return set_error(ctx, MDBG_EINVAL, "mdbg_reads_from_packed: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -203,9 +203,9 @@ extern "C" int mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, cons
 #undef CK
     *out = r;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets) {
+extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets) try {
     if (!ctx || !r || (r->n_reads && (!quals || !offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities: null argument");
     if (r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities: the reads already carry qualities");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -226,12 +226,12 @@ extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const c
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     r->has_qual = true;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,
                                     uint64_t first_read, const uint64_t *species_len,
                                     const uint64_t *species_threshold, uint32_t n_species,
-                                    uint64_t sub_threshold, int with_quality, mdbg_reads **out) {
+                                    uint64_t sub_threshold, int with_quality, mdbg_reads **out) try {
     if (!ctx || !out || !species_len || !species_threshold || !n_species || !read_len)
         return set_error(ctx, MDBG_EINVAL, "mdbg_reads_synthetic: bad argument");
     for (uint32_t s = 0; s < n_species; s++)
@@ -278,7 +278,7 @@ extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_rea
 #undef CK
     *out = r;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t *n_bases, uint64_t *n_words) {
     if (!r) return MDBG_EINVAL;
@@ -288,7 +288,7 @@ extern "C" int mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t 
     return MDBG_OK;
 }
 
-extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length) {
+extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length) try {
     if (!ctx || !r || index >= r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_get: bad argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     uint64_t off[2];
@@ -317,10 +317,10 @@ extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index
         if (L) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, quals, r->d_qual.p + qo[0], L, hipMemcpyDeviceToHost));
     }
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t first, uint32_t count,
-                                       char *bases, uint64_t *offsets, uint64_t *n_bytes) {
+                                       char *bases, uint64_t *offsets, uint64_t *n_bytes) try {
     if (!ctx || !r || (uint64_t)first + count > r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_ascii: bad range");
     if (r->has_invalid) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_ascii: batch holds N bases; use mdbg_reads_get");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -344,13 +344,13 @@ extern "C" int mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint3
     }
     if (offsets) offsets[count] = o;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+extern "C" int mdbg_memcpy_device(mdbg_ctx *ctx, void *dst, const void *src, uint64_t bytes) try {
     if (!ctx || (bytes && (!dst || !src))) return set_error(ctx, MDBG_EINVAL, "mdbg_memcpy_device: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (bytes) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, dst, src, bytes, hipMemcpyDeviceToDevice));
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
 
 extern "C" void mdbg_reads_free(mdbg_reads *r) { delete r; }

@@ -847,7 +847,7 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
     return MDBG_OK;
 }
 
-extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan_params *p, mdbg_minimizers **out) {
+extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan_params *p, mdbg_minimizers **out) try {
     if (!ctx || !reads || !p || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_scan: null argument");
     if (p->quality_window != 0 && p->quality_window != 1) return set_error(ctx, MDBG_EINVAL, "mdbg_scan: quality_window must be 0 or 1");
     if (p->minimizer_size < 2 || p->minimizer_size > 16)
@@ -1044,4 +1044,4 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan failed: %s", hipGetErrorString(e)));
     *out = m;
     return MDBG_OK;
-}
+} MDBG_API_CATCH(ctx)
