@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "fastx.hpp"
+#include "inflate.hpp"
 
 namespace mdbg_host {
 
@@ -114,6 +115,178 @@ struct PackCursor {
     bool bad() const { return overflow || (invalid & 0x0808080808080808ull) != 0; }
 };
 
+inline bool zlib_inflate_requested() { static const bool v = getenv("MDBG_HOST_ZLIB_INFLATE") != nullptr; return v; }
+
+// An ordinary gzip file (one or more members), memory-mapped and decoded by inflate.hpp in pieces of 4 MB on a thread of
+// its own; a second thread checks every member's CRC-32 and length behind the decoder.  read() hands the text out in
+// order and throws on damaged data.  Trailing bytes that are not a gzip member are ignored, as gzread does.
+class GzipMemReader {
+public:
+    GzipMemReader(const uint8_t *addr, size_t len, std::string path) : addr_(addr), len_(len), path_(std::move(path)) {
+        decoder_ = std::thread([this] { decode_loop(); });
+        checker_ = std::thread([this] { check_loop(); });
+    }
+    ~GzipMemReader() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (decoder_.joinable()) decoder_.join();
+        if (checker_.joinable()) checker_.join();
+    }
+
+    size_t read(char *dst, size_t want) {
+        size_t got = 0;
+        while (got < want) {
+            if (!cur_ || cpos_ == cur_->len) {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || !ready_.empty() || decoded_all_; });
+                if (ready_.empty()) {
+                    // everything decoded and handed out: the verdict of the checker is part of the end of the file
+                    cv_.wait(g, [&] { return stop_ || checked_all_ || !error_.empty(); });
+                    if (!error_.empty()) throw std::runtime_error(error_);
+                    break;
+                }
+                cur_ = ready_.front();
+                ready_.pop_front();
+                cpos_ = 0;
+                g.unlock();
+                cv_.notify_all();
+                continue;
+            }
+            const size_t n = std::min(want - got, cur_->len - cpos_);
+            memcpy(dst + got, cur_->text() + cpos_, n);
+            got += n; cpos_ += n;
+        }
+        return got;
+    }
+
+private:
+    static constexpr size_t HIST = 32768, ROOM = (size_t)4 << 20;
+    struct Piece {
+        GzipMemReader *owner;
+        std::unique_ptr<uint8_t[]> buf;    // HIST bytes of earlier text, then the text of this piece; recycled through the owner
+        explicit Piece(GzipMemReader *o) : owner(o), buf(o->take_buffer()) {}
+        ~Piece() { owner->give_buffer(std::move(buf)); }
+        size_t len = 0;
+        bool member_end = false;
+        uint32_t crc = 0, isize = 0;       // the member's trailer (with member_end)
+        const uint8_t *text() const { return buf.get() + HIST; }
+    };
+
+    // touched pages are worth keeping: a fresh 4 MB buffer per piece costs a thousand page faults
+    std::unique_ptr<uint8_t[]> take_buffer() {
+        {
+            std::lock_guard<std::mutex> g(pool_mu_);
+            if (!pool_.empty()) { std::unique_ptr<uint8_t[]> b = std::move(pool_.back()); pool_.pop_back(); return b; }
+        }
+        return std::unique_ptr<uint8_t[]>(new uint8_t[HIST + ROOM]);
+    }
+    void give_buffer(std::unique_ptr<uint8_t[]> b) {
+        std::lock_guard<std::mutex> g(pool_mu_);
+        pool_.push_back(std::move(b));
+    }
+
+    void fail(const std::string &msg) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (error_.empty()) error_ = msg;
+            decoded_all_ = true;
+        }
+        cv_.notify_all();
+    }
+
+    void decode_loop() {
+        Inflater inf;
+        size_t pos = 0, hist = 0, members = 0;
+        bool in_member = false;
+        std::shared_ptr<Piece> prev;
+        for (;;) {
+            if (!in_member) {
+                const size_t h = pos < len_ ? gzip_header_size(addr_ + pos, len_ - pos) : 0;
+                if (!h) {
+                    if (members == 0) { fail("not a gzip file: " + path_); return; }
+                    break;                                  // end of file, or trailing bytes that are no gzip member
+                }
+                inf.reset(addr_ + pos + h, addr_ + len_);
+                in_member = true;
+                members++;
+                hist = 0;
+            }
+            std::shared_ptr<Piece> p = std::make_shared<Piece>(this);
+            if (hist) memcpy(p->buf.get() + HIST - hist, prev->text() + prev->len - hist, hist);
+            size_t produced = 0;
+            const Inflater::Status st = inf.run(p->buf.get() + HIST, p->buf.get() + HIST + ROOM, hist, &produced);
+            if (st == Inflater::CORRUPT) { fail("corrupt gzip data in " + path_ + " (MDBG_HOST_ZLIB_INFLATE=1 decodes with zlib)"); return; }
+            p->len = produced;
+            if (st == Inflater::STREAM_END) {
+                const uint8_t *t = inf.in_pos();
+                if ((size_t)(addr_ + len_ - t) < 8) { fail("truncated gzip file: " + path_); return; }
+                p->member_end = true;
+                p->crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                p->isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                pos = (size_t)(t - addr_) + 8;
+                in_member = false;
+            }
+            hist = std::min(HIST, hist + produced);         // contiguous in p->buf: its own history, then its text
+            prev = p;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || (ready_.size() < 6 && check_.size() < 6); });
+                if (stop_) return;
+                ready_.push_back(p);
+                check_.push_back(p);
+            }
+            cv_.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            decoded_all_ = true;
+        }
+        cv_.notify_all();
+    }
+
+    void check_loop() {
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        uint64_t n = 0;
+        for (;;) {
+            std::shared_ptr<Piece> p;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || !check_.empty() || decoded_all_; });
+                if (stop_) return;
+                if (check_.empty()) { checked_all_ = true; g.unlock(); cv_.notify_all(); return; }
+                p = check_.front();
+                check_.pop_front();
+            }
+            cv_.notify_all();
+            crc = (uint32_t)crc32(crc, p->text(), (uInt)p->len);
+            n += p->len;
+            if (p->member_end) {
+                if (crc != p->crc || (uint32_t)n != p->isize)
+                    fail("gzip CRC / length mismatch in " + path_ + " (MDBG_HOST_ZLIB_INFLATE=1 decodes with zlib)");
+                crc = (uint32_t)crc32(0L, Z_NULL, 0);
+                n = 0;
+            }
+        }
+    }
+
+    const uint8_t *addr_;
+    size_t len_;
+    std::string path_;
+    std::mutex pool_mu_;                                   // the buffer pool outlives every piece (declared before them)
+    std::vector<std::unique_ptr<uint8_t[]>> pool_;
+    size_t cpos_ = 0;
+    std::shared_ptr<Piece> cur_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Piece>> ready_, check_;
+    std::thread decoder_, checker_;
+    bool stop_ = false, decoded_all_ = false, checked_all_ = false;
+    std::string error_;
+};
+
 // BGZF (the blocked gzip that htslib writes: samtools fastq, bam2fastq, bgzip): every block of at most 64 KB is its
 // own gzip member whose header carries the compressed block size, so the blocks of a memory-mapped file can be inflated
 // by several threads at once.  read() hands the text out in file order.
@@ -182,12 +355,12 @@ public:
             cv_.wait(g, [&] { return !error_.empty() || cur_ + 1 >= groups_.size() || ready_.count(cur_); });
             if (!error_.empty()) throw std::runtime_error(error_);
             if (cur_ + 1 >= groups_.size()) break;
-            std::vector<char> &t = ready_[cur_];
-            const size_t n = std::min(want - got, t.size() - pos_);
+            Text &t = ready_[cur_];
+            const size_t n = std::min(want - got, t.len - pos_);
             g.unlock();                                   // the entry of the current group is only touched by this thread
-            memcpy(dst + got, t.data() + pos_, n);
+            memcpy(dst + got, t.buf.data() + pos_, n);
             got += n; pos_ += n;
-            if (pos_ == t.size()) {
+            if (pos_ == t.len) {
                 g.lock();
                 ready_.erase(cur_);
                 cur_++; pos_ = 0;
@@ -199,10 +372,14 @@ public:
     }
 
 private:
+    struct Text { std::vector<char> buf; size_t len = 0; };
+
     void inflate_loop() {
+        const bool use_zlib = zlib_inflate_requested();
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) { fail("zlib initialisation failed"); return; }
+        if (use_zlib && inflateInit2(&zs, -15) != Z_OK) { fail("zlib initialisation failed"); return; }
+        std::unique_ptr<Inflater> inf(use_zlib ? nullptr : new Inflater());
         for (;;) {
             size_t gi;
             {
@@ -213,19 +390,28 @@ private:
             }
             size_t total = 0;
             for (size_t b = groups_[gi]; b < groups_[gi + 1]; b++) total += blocks_[b].isize;
-            std::vector<char> text(total);
+            Text text;
+            text.len = total;
+            text.buf.resize(total + 512);                  // the decoder wants 258 + 16 bytes of room in front of every symbol
             size_t o = 0;
             bool ok = true;
             for (size_t b = groups_[gi]; b < groups_[gi + 1] && ok; b++) {
                 const Block &blk = blocks_[b];
-                inflateReset(&zs);
-                zs.next_in = const_cast<Bytef *>(addr_ + blk.payload);
-                zs.avail_in = blk.csize;
-                zs.next_out = (Bytef *)text.data() + o;
-                zs.avail_out = blk.isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                ok = rc == Z_STREAM_END && zs.avail_out == 0 &&
-                     (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)text.data() + o, blk.isize) == blk.crc;
+                if (use_zlib) {
+                    inflateReset(&zs);
+                    zs.next_in = const_cast<Bytef *>(addr_ + blk.payload);
+                    zs.avail_in = blk.csize;
+                    zs.next_out = (Bytef *)text.buf.data() + o;
+                    zs.avail_out = blk.isize;
+                    ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+                } else {
+                    // blocks are independent deflate streams: no history in front of them
+                    inf->reset(addr_ + blk.payload, addr_ + blk.payload + blk.csize);
+                    size_t produced = 0;
+                    uint8_t *out = (uint8_t *)text.buf.data() + o;
+                    ok = inf->run(out, (uint8_t *)text.buf.data() + text.buf.size(), 0, &produced) == Inflater::STREAM_END && produced == blk.isize;
+                }
+                ok = ok && (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)text.buf.data() + o, blk.isize) == blk.crc;
                 o += blk.isize;
             }
             if (!ok) { fail("corrupt BGZF block in " + path_); break; }
@@ -235,7 +421,7 @@ private:
             }
             cv_.notify_all();
         }
-        inflateEnd(&zs);
+        if (use_zlib) inflateEnd(&zs);
     }
     void fail(const std::string &msg) {
         {
@@ -249,7 +435,7 @@ private:
     std::vector<Block> blocks_;
     std::vector<size_t> groups_;           // first block of every group, then the block count
     std::string path_;
-    std::map<size_t, std::vector<char>> ready_;
+    std::map<size_t, Text> ready_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<std::thread> pool_;
@@ -473,10 +659,11 @@ private:
     // workers parse and pack like slices of a memory-mapped file; at most threads + 2 slabs exist at a time.
     uint64_t read_gz(const std::string &path, int file, uint64_t seq) {
         // BGZF: the blocks are inflated by a pool of threads, this thread only stitches the text into slabs
-        std::unique_ptr<BgzfReader> bgzf;
-        Mapping map;
+        Mapping map;                       // declared first: unmapped after the readers (and their threads) are gone
         struct Unmap { Mapping *m; ~Unmap() { if (m->addr) munmap((void *)m->addr, m->len); } } unmap{&map};
-        if (!getenv("MDBG_HOST_NO_BGZF")) {
+        std::unique_ptr<BgzfReader> bgzf;
+        std::unique_ptr<GzipMemReader> gzmem;
+        {
             int fd = open(path.c_str(), O_RDONLY);
             if (fd < 0) throw std::runtime_error("File not found: " + path);
             struct stat st;
@@ -485,13 +672,16 @@ private:
             close(fd);
             if (addr != MAP_FAILED) {
                 map = {(const char *)addr, (size_t)st.st_size};
+                madvise(addr, map.len, MADV_SEQUENTIAL);
                 std::vector<BgzfReader::Block> blocks;
-                if (BgzfReader::index((const unsigned char *)addr, map.len, blocks))
+                if (!getenv("MDBG_HOST_NO_BGZF") && BgzfReader::index((const unsigned char *)addr, map.len, blocks))
                     bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), nThreads_, path));
+                else if (!zlib_inflate_requested())
+                    gzmem.reset(new GzipMemReader((const uint8_t *)addr, map.len, path));
             }
         }
         gzFile fp = nullptr;
-        if (!bgzf) {
+        if (!bgzf && !gzmem) {
             fp = gzopen(path.c_str(), "r");
             if (!fp) throw std::runtime_error("File not found: " + path);
             gzbuffer(fp, 1 << 20);
@@ -517,6 +707,7 @@ private:
             while (!eof && len < cap) {
                 long n;
                 if (bgzf) n = (long)bgzf->read(buf + len, cap - len);
+                else if (gzmem) n = (long)gzmem->read(buf + len, cap - len);
                 else n = gzread(fp, buf + len, (unsigned)std::min<size_t>(cap - len, (size_t)1 << 30));
                 if (n < 0) throw std::runtime_error("gzip read error: " + path);
                 if (n == 0) { eof = true; break; }
@@ -532,6 +723,7 @@ private:
                     if (fp) gzclose(fp);
                     closer.f = nullptr;
                     bgzf.reset();
+                    gzmem.reset();
                     return read_gz_sequential(path, file, seq);
                 }
                 first = false;

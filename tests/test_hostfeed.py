@@ -187,3 +187,39 @@ def test_bgzf_corruption_is_reported(exe, files, tmp_path):
     open(bad, "wb").write(bytes(raw))
     r = subprocess.run([exe, str(1 << 20), "3", "0", bad], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_gzip_damage_and_zlib_switch(exe, files, tmp_path):
+    """Ordinary gzip: a flipped byte or a truncated file is an error (CRC-32 / length of every member are checked behind
+    the decoder), trailing garbage behind the last member is ignored as gzread does, and MDBG_HOST_ZLIB_INFLATE=1 decodes
+    the same reads with zlib."""
+    raw = open(files["gz_fastq"], "rb").read()
+    bad = bytearray(raw)
+    bad[len(bad) // 2] ^= 0x10
+    p = str(tmp_path / "flipped.fastq.gz")
+    open(p, "wb").write(bytes(bad))
+    r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    p = str(tmp_path / "truncated.fastq.gz")
+    open(p, "wb").write(raw[: len(raw) * 2 // 3])
+    r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    p = str(tmp_path / "garbage_tail.fastq.gz")
+    open(p, "wb").write(raw + b"\x00" * 37 + b"not gzip")
+    r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for key in ("gz", "gz_fastq", "gz_wrapped", "bgzf_fastq"):
+        r = subprocess.run([exe, "50000", "3", "0", files[key]], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, MDBG_HOST_ZLIB_INFLATE="1"))
+        assert r.returncode == 0, (key, r.stderr)
+
+
+def test_inflate_against_zlib(tmp_path):
+    """metamdbg_amd/host/inflate.hpp vs zlib: every block type, level and strategy, output room cut at random places, and
+    damaged streams -- built with the address and undefined-behaviour sanitizers."""
+    out = str(tmp_path / "test_inflate")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    os.path.join(ROOT, "tests", "host", "test_inflate.cpp"), "-o", out, "-lz"], check=True)
+    r = subprocess.run([out, "11", "30"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert r.stdout.startswith("ok 30 streams")
