@@ -4,7 +4,8 @@
 // stream.  This is an own implementation shaped for what the feed needs and zlib's stream API cannot assume: the WHOLE
 // compressed file is in memory (memory-mapped), so the hot loop refills a 64-bit bit buffer with unaligned 8-byte
 // loads, decodes through wide single-level-mostly tables (11 bits for literals/lengths, 8 for distances), emits up to
-// three literals per refill and copies matches 8 bytes at a time.  Output is produced in caller-sized pieces: run()
+// four literals per table look-up (a second table holds, for every 11-bit index, the run of literals it decodes to on
+// its own) and copies matches 8 bytes at a time.  Output is produced in caller-sized pieces: run()
 // stops in front of a symbol when fewer than 258+16 bytes of room are left, so a match is never split and the only
 // state carried between calls is the bit buffer, the current block's tables and the remainder of a stored block.
 // Back-references reach into the text already produced, which the caller keeps directly in front of the output
@@ -201,6 +202,25 @@ private:
         for (unsigned i = 0; i < 32; i++) lens[288 + i] = 5;
         build_table(lens, 288, LIT_BITS, lit_, LIT_CAP, false, litlen_entry);
         build_table(lens + 288, 32, DIST_BITS, dist_, DIST_CAP, false, dist_entry);
+        build_literal_runs();
+    }
+
+    // run_info_[i] / run_lits_[i]: the literals that the index bits i decode to on their own -- up to four, as long as
+    // each next code is a literal that lies wholly inside the 11 bits.  info = bits consumed | count << 4; 0 = none.
+    void build_literal_runs() {
+        for (unsigned i = 0; i < (1u << LIT_BITS); i++) {
+            unsigned pos = 0, count = 0;
+            uint32_t lits = 0;
+            while (count < 4) {
+                const uint32_t e = lit_[i >> pos];            // the unknown high bits read as zero: fine while the code fits
+                if (!(e & F_LITERAL) || (e & 0xFF) > LIT_BITS - pos) break;
+                lits |= (e >> 16) << (8 * count);
+                pos += e & 0xFF;
+                count++;
+            }
+            run_info_[i] = (uint8_t)(count ? (pos | (count << 4)) : 0);
+            run_lits_[i] = lits;
+        }
     }
 
     bool read_dynamic() {
@@ -246,6 +266,7 @@ private:
         if (lens[256] == 0) return false;                     // no end-of-block code
         if (!build_table(lens, hlit, LIT_BITS, lit_, LIT_CAP, false, litlen_entry)) return false;
         if (!build_table(lens + hlit, hdist, DIST_BITS, dist_, DIST_CAP, true, dist_entry)) return false;
+        build_literal_runs();
         return true;
     }
 
@@ -264,28 +285,26 @@ private:
             bitbuf |= load64(in) << bitcnt;
             in += (63 - bitcnt) >> 3;
             bitcnt |= 56;
-            uint32_t e = lit[bitbuf & ((1u << LIT_BITS) - 1)];
-            if (e & F_LITERAL) {
-                // up to three literals from one refill (3 x 15 bits <= 56)
-                *out++ = (uint8_t)(e >> 16);
-                bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
-                e = lit[bitbuf & ((1u << LIT_BITS) - 1)];
-                if (e & F_LITERAL) {
-                    *out++ = (uint8_t)(e >> 16);
-                    bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
-                    e = lit[bitbuf & ((1u << LIT_BITS) - 1)];
-                    if (e & F_LITERAL) {
-                        *out++ = (uint8_t)(e >> 16);
-                        bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
-                        continue;
-                    }
+            // literal runs: one look-up yields up to four literals whose codes fit the 11 index bits together (DNA text has
+            // 2- to 3-bit codes, quality strings 4 to 7); four look-ups per refill (4 x 11 <= 56 bits)
+            {
+                unsigned info = run_info_[bitbuf & ((1u << LIT_BITS) - 1)];
+                if (info) {
+                    int k = 0;
+                    do {
+                        memcpy(out, &run_lits_[bitbuf & ((1u << LIT_BITS) - 1)], 4);
+                        out += info >> 4;
+                        bitbuf >>= (info & 15); bitcnt -= (int)(info & 15);
+                        info = run_info_[bitbuf & ((1u << LIT_BITS) - 1)];
+                    } while (info && ++k < 4);
+                    if (info) continue;                       // still literals: refill and go on
+                    // a non-literal follows and up to 44 bits are gone: refill for length + distance (48 bits)
+                    bitbuf |= load64(in) << bitcnt;
+                    in += (63 - bitcnt) >> 3;
+                    bitcnt |= 56;
                 }
-                // a non-literal follows; at least 56 - 30 = 26 bits are left: enough for a length code + extra (20),
-                // not for the distance too -> refill
-                bitbuf |= load64(in) << bitcnt;
-                in += (63 - bitcnt) >> 3;
-                bitcnt |= 56;
             }
+            uint32_t e = lit[bitbuf & ((1u << LIT_BITS) - 1)];
             if (e & F_SUB) {
                 e = lit[(e >> 16) + ((bitbuf >> LIT_BITS) & ((1u << ((e >> 8) & 15)) - 1))];
                 if (e & F_LITERAL) {
@@ -389,6 +408,8 @@ private:
     uint32_t stored_left_ = 0;
     uint32_t lit_[LIT_CAP];
     uint32_t dist_[DIST_CAP];
+    uint32_t run_lits_[1u << LIT_BITS];    // up to four literals per index, little-endian
+    uint8_t run_info_[1u << LIT_BITS];
 };
 
 // gzip member header (RFC 1952) at p: returns the offset of the deflate data, 0 if this is not a gzip member

@@ -29,6 +29,8 @@ def main() -> None:
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--repeat", type=int, default=1, help="run the tool this many times per setting, report the fastest")
+    ap.add_argument("--compress", default="none", choices=["none", "gzip", "bgzf"],
+                    help="write the reads as plain FASTA, gzip -1, or BGZF (htslib's blocked gzip)")
     ap.add_argument("--consumers", default="", help="comma list of MDBG_TOOL_CONSUMERS settings to compare (tool only)")
     args = ap.parse_args()
     import numpy as np
@@ -49,6 +51,20 @@ def main() -> None:
                 for r in range(n):
                     f.write(b">r%d\n" % (r0 + r)); f.write(bases[int(offs[r]): int(offs[r + 1])].tobytes()); f.write(b"\n")
         reads.free(); ctx.close()
+        if args.compress != "none":
+            import zlib
+            raw = open(fasta, "rb").read()
+            os.remove(fasta)
+            fasta += ".gz"
+            if args.compress == "gzip":
+                import gzip
+                with gzip.open(fasta, "wb", compresslevel=1) as f:
+                    f.write(raw)
+            else:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from test_hostfeed import _bgzf
+                open(fasta, "wb").write(_bgzf(raw, level=1))
+            del raw
         nbases = args.reads * 10_000
         P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
         res = {}
@@ -98,7 +114,7 @@ def main() -> None:
             identical = identical and len(oa) == len(ob) and int(oa[-1]) == int(ob[-1])
         for v in res.values():
             v.pop("tmp")
-        print(json.dumps({"reads": args.reads, "gbp": nbases / 1e9, "threads": args.threads, "input": "uncompressed FASTA in " + (args.dir or "tmp"),
+        print(json.dumps({"reads": args.reads, "gbp": nbases / 1e9, "threads": args.threads, "input": {"none": "uncompressed", "gzip": "gzip -1", "bgzf": "BGZF"}[args.compress] + " FASTA in " + (args.dir or "tmp"),
                           "results": res, "products_identical": identical,
                           "speedup_end_to_end": (res[runs[0][0]]["gbps"] / res["reference"]["gbps"]) if "reference" in res else None}))
     finally:
