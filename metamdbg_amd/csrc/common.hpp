@@ -242,7 +242,7 @@ int exclusive_scan_u32(mdbg_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, uin
 
 // density (f32) -> integer threshold: hash < T  <=>  (double)hash < (double)density * 2^64, the compare of
 // MinimizerParser (utils/kmer/Kmer.hpp:1421-1430) and Utils::applyDensityThreshold (Commons.hpp:2524-2533; its
-// float product density * 2^64 is exact).  See oracle/mdbg_oracle.c orc_density_threshold.
+// float product density * 2^64 is exact).
 inline uint64_t density_threshold(float density) {
     const double bound = (double)density * 18446744073709551616.0;
     if (!((double)UINT64_MAX >= bound)) return UINT64_MAX;

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """End-to-end (from FASTA on disk) timing of the C++ drop-in tool against the reference's own code.
 
-    python tools/e2e_bench.py --reads 200000 [--threads 32] [--dir /dev/shm]
+    python tests/perf/e2e_bench.py --reads 200000 [--threads 32] [--dir /dev/shm]
 
 Writes the synthetic reads of bench.py's workload as FASTA, runs `mdbg_tool readSelection` + `graph --firstpass`
 and `oracle/_ref/refdrv` with the same argv on the same file, checks the products are identical
 (read_data_init.txt / read_data_corrected.txt byte-equal, k-min-mer tables equal as multisets) and prints one
-JSON line.  This is the PCIe- and parser-inclusive rate DESIGN.md quotes next to the HBM-resident `value` of bench.py."""
+JSON line.  It lives under tests/ because it runs the reference build (oracle/_ref), which only tests and the
+baseline leg of bench.py may do.  This is the PCIe- and parser-inclusive rate DESIGN.md quotes next to the HBM-resident `value` of bench.py."""
 from __future__ import annotations
 
 import argparse
@@ -18,7 +19,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
