@@ -343,8 +343,8 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "concurrent_launches": n_slots,
                          "concurrency_note": (f"{n_slots} batches are in flight: a scan launch shares the device with the other batch's "
-                                              "table kernels and lasts longer than alone (14.6 ms with --in-flight 1: 196 GB/s, 2.5 % of "
-                                              "peak, 61 % of the hash floor); scans of different batches never overlap each other")
+                                              "table kernels and lasts longer than alone (13.8 ms with --in-flight 1: 209 GB/s, 2.6 % of "
+                                              "peak, 64 % of the hash floor); scans of different batches never overlap each other")
                                              if n_slots > 1 else None,
                          "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies, half-rate VALU) "
                                  "puts the ceiling at the VALU, far below HBM (DESIGN.md 4.1)",

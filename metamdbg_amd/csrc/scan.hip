@@ -339,7 +339,7 @@ struct KmerTrip {
         // 64 stream bits from position jb (enough for K + PP - 1 <= 19 bases)
         const unsigned b = 2u * jb, w = b >> 5, sh = b & 31u;
         uint32_t a0, a1;
-        if (w + 2 < STREAM_WORDS) {
+        if (INTERIOR || w + 2 < STREAM_WORDS) {   // interior trips end K + 4 bases before the end of the stream: always in range
             const uint32_t w0 = S[w], w1 = S[w + 1], w2 = S[w + 2];
             a0 = __builtin_amdgcn_alignbit(w1, w0, sh);
             a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
@@ -433,7 +433,9 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
         __syncthreads();
     }
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned wv = threadIdx.x >> 6;
+    // everything that depends only on the wave (its read, the read's length, tile counts, stream lengths) is told to the
+    // compiler as wave-uniform, so it lives in scalar registers and the loops around the tiles and trips are scalar branches
+    const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *S = lds_stream[wv];
     uint32_t *SI = lds_istream[HAS_N ? wv : 0];
     QualMap *Q = &lds_qmap[(HAS_QUAL && HPC) ? wv : 0];
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
     const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
 
     // a wave takes a few reads and retires (launch_variant sizes the grid); written as a grid-stride loop
-    const uint32_t wave_global = (blockIdx.x * SCAN_BLOCK + threadIdx.x) >> 6;
+    const uint32_t wave_global = blockIdx.x * (SCAN_BLOCK / 64) + wv;
     const uint32_t n_waves = (gridDim.x * SCAN_BLOCK) >> 6;
     for (uint32_t slot = wave_global; slot < a.n_reads; slot += n_waves) {
         const uint32_t r = a.subset ? a.subset[slot] : slot;
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
                     c = (unsigned)__popcll(d);
                     y = compress_pairs(x, d);
                 }
-                prev_last = (uint32_t)__shfl((uint32_t)(x >> 62), 63, 64);
+                prev_last = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 62), 63);
             } else {
                 d = vspread;
                 c = nvalid;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
             }
             const unsigned inc = wave_inclusive_sum(c);
             const unsigned o = inc - c;
-            const unsigned C = __shfl(inc, 63, 64);
+            const unsigned C = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
 
             // ---- 2. LDS bit stream: [carry (cb bases)] [new C bases] ---------------------------
             S[lane] = 0;
