@@ -415,9 +415,9 @@ struct KmerTrip {
         return nout;
     }
 };
-// Waves per SIMD the register allocator must allow for the plain variant (no qualities, no N): it needs 85 VGPRs,
-// i.e. 5 waves.  Forcing 6 (80 VGPRs) costs an 80-byte spill and is slower; the other variants need > 100 VGPRs and
-// are left to the compiler.
+// Waves per SIMD the register allocator must allow for the plain variant (no qualities, no N).  With the wave-uniform
+// values in scalar registers it needs 76 VGPRs (6 waves fit); asking for 7 (72 VGPRs, no spill) makes the kernel no
+// faster alone (14.0 vs 13.8 ms) and starves the other batch's table kernels when two batches are in flight; 8 spills.
 #ifndef SCAN_MIN_WAVES
 #define SCAN_MIN_WAVES 5
 #endif
