@@ -4,9 +4,9 @@
 A step = one pass of the hot path over one batch of synthetic HiFi reads already resident in HBM
 (2-bit packed): reads -> minimizers (HPC, l=15, density 0.005) -> palindrome purge -> k-min-mer
 table at k=4 (count + rescue).  N=1 workload = BASELINE.json configs[1]: 1 M x 10 kb reads.
-Two batches are in flight per GPU (--in-flight): consecutive steps run on two library contexts
-(own HIP stream, memory pool and host thread each), so the atomic-bound table kernels of one batch
-overlap the ALU-bound scan of the next; every step is still a complete pass over its batch.
+Three batches are in flight per GPU (--in-flight): consecutive steps run on their own library contexts
+(own HIP stream, memory pool and host thread each), so the atomic-bound table kernels and the exchanges of
+one batch overlap the ALU-bound scan of another; every step is still a complete pass over its batch.
 N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); only the
 k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
 all-to-alls over RCCL (metamdbg_amd/distributed.py, include/mdbg_hip.h mdbg_shard_*).
@@ -41,11 +41,11 @@ K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (10 kb each)")
     ap.add_argument("--read-len", type=int, default=10_000)
-    ap.add_argument("--in-flight", type=int, default=2, help="batches processed concurrently per GPU (own context, stream and host thread each)")
+    ap.add_argument("--in-flight", type=int, default=3, help="batches processed concurrently per GPU (own context, stream and host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads in the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -114,6 +114,11 @@ def measured_traffic(reads: int, read_len: int):
 
 def main() -> None:
     args = parse_args()
+    # The one JSON line must be the only thing on stdout: RCCL prints a version banner through C stdio, which a redirected
+    # stdout delivers at exit -- after the line.  Everything else that goes to file descriptor 1 is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     from metamdbg_amd import capi, synth
@@ -145,7 +150,10 @@ def main() -> None:
     # on slot i % IN_FLIGHT; every step is still the complete pass over one batch.
     n_slots = max(1, args.in_flight)
     if n_slots > 1:
-        os.environ.setdefault("MDBG_TABLE_BLOCKS_PER_CU", "3")   # keep the table kernels' footprint small beside the other batch's scan
+        # keep the table kernels' footprint small beside the other batches' scans: 1 / 2 / 3 / 4 resident blocks per CU give
+        # 676 / 672 / 657 / 643 Gbp/s on one GPU and 489 / 479 / 463 on the per-rank workload of an 8-GPU job run through
+        # the sharded path (profiles/r01g_table_footprint_sweep.txt)
+        os.environ.setdefault("MDBG_TABLE_BLOCKS_PER_CU", "1")
     slots = []
     # one metagenome for the job (MDBG_BENCH_SPEC_RANKS: test hook, the per-rank workload of an N-rank job on one GPU)
     spec_ranks = int(os.environ.get("MDBG_BENCH_SPEC_RANKS", world))
@@ -342,7 +350,7 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "concurrent_launches": n_slots,
-                         "concurrency_note": (f"{n_slots} batches are in flight: a scan launch shares the device with the other batch's "
+                         "concurrency_note": (f"{n_slots} batches are in flight: a scan launch shares the device with the other batches' "
                                               "table kernels and lasts longer than alone (13.8 ms with --in-flight 1: 209 GB/s, 2.6 % of "
                                               "peak, 64 % of the hash floor); scans of different batches never overlap each other")
                                              if n_slots > 1 else None,
@@ -359,7 +367,7 @@ def main() -> None:
             out["speedup_vs_cpu_reference"] = out["value"] / base["value"]
         if trace and phases:
             out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + n_warm) for k, v in phases.items()}
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
