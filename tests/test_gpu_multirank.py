@@ -31,7 +31,7 @@ def _bench(extra_env: dict, args: list[str], nproc: int | None) -> dict:
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("in_flight", [1, 2])
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
 def test_two_ranks_equal_one(in_flight):
     n = 40_000
     common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--in-flight", str(in_flight)]
