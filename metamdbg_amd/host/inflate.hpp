@@ -332,8 +332,13 @@ private:
             if ((size_t)(out - lowest) < off) { result = -1; break; }
             const uint8_t *src = out - off;
             uint8_t *const end = out + len;
-            if (off >= 8) {
-                do { memcpy(out, src, 8); out += 8; src += 8; } while (out < end);
+            if (__builtin_expect(off >= 8, 1)) {
+                // read text has short matches (3 to 8 bytes): the first 8 bytes without a loop
+                memcpy(out, src, 8);
+                if (__builtin_expect(len > 8, 0)) {
+                    out += 8; src += 8;
+                    do { memcpy(out, src, 8); out += 8; src += 8; } while (out < end);
+                }
             } else if (off == 1) {
                 memset(out, *src, len);
             } else {
