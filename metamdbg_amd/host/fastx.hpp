@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -15,7 +16,7 @@ namespace mdbg_host {
 
 class FastxReader {
 public:
-    explicit FastxReader(const std::string &path) : buf_(1 << 22) {
+    explicit FastxReader(const std::string &path) : buf_(1 << 22), path_(path) {
         fp_ = gzopen(path.c_str(), "r");
         if (fp_) gzbuffer(fp_, 1 << 20);
     }
@@ -65,13 +66,21 @@ private:
         if (pos_ == len_) {
             if (eof_) return -1;
             int n = gzread(fp_, buf_.data(), (unsigned)buf_.size());
-            if (n <= 0) { eof_ = true; return -1; }
+            if (n <= 0) {
+                // damaged or truncated gzip data is an error, not the end of the reads
+                int err = Z_OK;
+                const char *msg = gzerror(fp_, &err);
+                if (n < 0 || (err != Z_OK && err != Z_STREAM_END)) throw std::runtime_error("gzip read error in " + path_ + ": " + (msg ? msg : "?"));
+                eof_ = true;
+                return -1;
+            }
             len_ = (size_t)n; pos_ = 0;
         }
         return (unsigned char)buf_[pos_++];
     }
     gzFile fp_ = nullptr;
     std::vector<char> buf_;
+    std::string path_;
     size_t pos_ = 0, len_ = 0;
     bool eof_ = false;
     int last_ = 0;   // header character already consumed

@@ -1,0 +1,368 @@
+// gzip_parallel.hpp -- one ordinary gzip stream decoded by several threads.
+//
+// A deflate stream has no index and every block may refer to the 32 KB before it, so it is normally decoded by one
+// thread (0.4 GB/s of text with inflate.hpp).  The two-pass scheme used here (known from pugz / rapidgzip) removes
+// that dependency:
+//   1. the compressed bytes of a member are cut into chunks; for every chunk but the first a thread looks for the first
+//      deflate block header behind the cut -- a position where a non-final dynamic block parses with complete Huffman
+//      codes, decodes to plain text and is followed by more valid data;
+//   2. a chunk is decoded from its header to the next chunk's header WITHOUT its window, into 16-bit symbols: bytes, or
+//      "position p of the unknown window" (32768 + p), which matches copy around like bytes.  It must end exactly on the
+//      header the next chunk found -- a wrongly guessed header makes the decoder run past it, which is an error;
+//   3. windows are resolved in chunk order (32 KB per chunk) and every chunk's symbols are translated to bytes by the
+//      pool; the CRC-32s of the chunks are combined and checked against the member's trailer, like its length.
+// read() hands the text out in order.  Any inconsistency ends the run with an error naming the switch back to one
+// decoding thread; nothing is guessed silently.  Jobs never wait for each other: a chunk is decoded only once its stop
+// position is known, translated only once its window is.
+#pragma once
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "inflate.hpp"
+
+namespace mdbg_host {
+
+class ParallelGzipReader {
+public:
+    static constexpr size_t WINDOW = 32768;
+    static constexpr uint64_t NONE = ~0ull;
+
+    ParallelGzipReader(const uint8_t *addr, size_t len, int threads, std::string path, size_t chunk_bytes)
+        : addr_(addr), len_(len), path_(std::move(path)), chunk_(chunk_bytes < 65536 ? 65536 : chunk_bytes), nthreads_(threads < 1 ? 1 : threads) {
+        start_member(0);
+        for (int i = 0; i < nthreads_; i++) pool_.emplace_back([this] { work(); });
+    }
+    ~ParallelGzipReader() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : pool_) if (t.joinable()) t.join();
+    }
+
+    // up to `want` bytes of text; 0 at the end of the file; throws on damaged data
+    size_t read(char *dst, size_t want) {
+        size_t got = 0;
+        while (got < want) {
+            std::unique_lock<std::mutex> g(mu_);
+            if (!fatal_.empty()) throw std::runtime_error(fatal_);
+            if (!gen_) break;                                                  // end of file
+            std::shared_ptr<Gen> gen = gen_;
+            if (gen->consumed >= gen->chunks.size()) throw std::runtime_error("gzip stream without an end in " + path_ + hint());
+            Chunk &c = gen->chunks[gen->consumed];
+            cv_.wait(g, [&] { return c.translated; });
+            if (!c.error.empty()) throw std::runtime_error(c.error + hint());
+            g.unlock();
+            const size_t n = std::min(want - got, c.ntext - rpos_);
+            if (n) memcpy(dst + got, c.text.get() + rpos_, n);
+            got += n; rpos_ += n;
+            if (rpos_ == c.ntext) {
+                g.lock();
+                crc_ = (uint32_t)crc32_combine(crc_, c.crc, (z_off_t)c.ntext);
+                total_ += c.ntext;
+                const uint64_t end_pos = c.member_end;
+                c.text.reset();
+                rpos_ = 0;
+                gen->consumed++;
+                if (end_pos != NONE) {
+                    const uint8_t *t = addr_ + end_pos;                        // trailer: CRC-32, ISIZE
+                    const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                    const uint32_t want_len = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                    if (want_crc != crc_ || want_len != (uint32_t)total_) throw std::runtime_error("gzip CRC / length mismatch in " + path_ + hint());
+                    total_ = 0;
+                    crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
+                    start_member((size_t)end_pos + 8);                         // next member, or the end (trailing bytes ignored)
+                }
+                g.unlock();
+                cv_.notify_all();
+            }
+        }
+        return got;
+    }
+
+private:
+    struct Chunk {
+        uint64_t start_bit = NONE;          // first block header behind the cut, in bits from the member's deflate data; NONE: none here
+        bool find_taken = false, start_known = false, decode_taken = false, decoded = false, window_known = false, translate_taken = false,
+             translated = false;
+        std::unique_ptr<uint16_t[]> sym;    // WINDOW place-holders, then the symbols
+        size_t nsym = 0;
+        std::unique_ptr<uint8_t[]> window;  // the WINDOW bytes in front of this chunk, right-aligned when fewer exist
+        size_t window_valid = 0;
+        std::unique_ptr<uint8_t[]> text;
+        size_t ntext = 0;
+        uint32_t crc = 0;
+        uint64_t member_end = NONE;         // file offset of the member's trailer if the stream ended in this chunk
+        std::string error;
+    };
+    struct Gen {                            // one gzip member
+        size_t data = 0;                    // file offset of the deflate data
+        std::vector<Chunk> chunks;
+        size_t consumed = 0, chain_next = 0;
+        size_t end_chunk = (size_t)-1;      // chunk in which the final block ended: later ones are never delivered
+    };
+
+    std::string hint() const { return " (MDBG_HOST_GZIP_THREADS=1 decodes the stream on one thread)"; }
+
+    void start_member(size_t pos) {         // mu_ held, or during construction
+        gen_.reset();
+        const size_t h = pos < len_ ? gzip_header_size(addr_ + pos, len_ - pos) : 0;
+        if (!h) {
+            if (pos == 0) fatal_ = "not a gzip file: " + path_;
+            return;
+        }
+        auto gen = std::make_shared<Gen>();
+        gen->data = pos + h;
+        gen->chunks.resize((len_ - gen->data) / chunk_ + 1);
+        Chunk &c0 = gen->chunks[0];
+        c0.start_bit = 0;
+        c0.find_taken = c0.start_known = c0.window_known = true;               // starts with the stream; nothing precedes it
+        gen_ = gen;
+    }
+
+    // ---- finding a block header ------------------------------------------------------------------------------------
+    static bool plausible_text(const uint16_t *s, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            const uint16_t v = s[i];
+            if (v < 256 && !((v >= 32 && v < 127) || v == '\n' || v == '\r' || v == '\t')) return false;
+        }
+        return true;
+    }
+
+    // first bit in [from, to) of `data` where a non-final dynamic block starts that decodes to text and is followed by
+    // more valid data; NONE if there is none
+    static uint64_t find_block(const uint8_t *data, const uint8_t *end, uint64_t from, uint64_t to, InflaterT<uint16_t> &probe, std::vector<uint16_t> &scratch) {
+        if (scratch.size() < WINDOW + PROBE_ROOM) {
+            scratch.resize(WINDOW + PROBE_ROOM);
+            for (size_t i = 0; i < WINDOW; i++) scratch[i] = (uint16_t)(0x8000u + i);
+        }
+        const uint64_t last = (uint64_t)(end - data) * 8;
+        for (uint64_t bit = from; bit < to && bit + 128 < last; bit++) {
+            uint64_t w;
+            memcpy(&w, data + (bit >> 3), 8);
+            w >>= (bit & 7);
+            if ((w & 7) != 4) continue;                                        // BFINAL = 0, BTYPE = 2 (dynamic Huffman)
+            if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;        // HLIT, HDIST
+            // the code-length code must be complete: sum over its codes of 2^(7 - length) == 2^7
+            const unsigned hclen = (unsigned)((w >> 13) & 15) + 4;
+            uint64_t cl;
+            memcpy(&cl, data + ((bit + 17) >> 3), 8);
+            cl >>= ((bit + 17) & 7);                                           // 57 bits left: 19 lengths of 3 bits
+            unsigned kraft = 0;
+            for (unsigned i = 0; i < hclen; i++) {
+                const unsigned l = (unsigned)((cl >> (3 * i)) & 7);
+                if (l) kraft += 128u >> l;
+            }
+            if (kraft != 128) continue;
+            probe.reset_at_bit(data, bit, end);
+            size_t produced = 0;
+            const auto st = probe.run(scratch.data() + WINDOW, scratch.data() + scratch.size(), WINDOW, &produced);
+            if (st == InflaterT<uint16_t>::CORRUPT) continue;                  // NEED_ROOM: 256 K symbols decoded cleanly
+            if (st == InflaterT<uint16_t>::STREAM_END && probe.blocks_done() < 2) continue;
+            if (!plausible_text(scratch.data() + WINDOW, produced)) continue;
+            return bit;
+        }
+        return NONE;
+    }
+
+    // ---- the pool ------------------------------------------------------------------------------------------------------
+    enum Job { NOTHING, FIND, DECODE, TRANSLATE };
+
+    // stop position of chunk k: the header found by the next chunk that has one.  false = not decided yet
+    static bool stop_of(const Gen &gen, size_t k, uint64_t *stop) {
+        size_t j = k + 1;
+        while (j < gen.chunks.size() && gen.chunks[j].start_known && gen.chunks[j].start_bit == NONE) j++;
+        if (j == gen.chunks.size()) { *stop = NONE; return true; }             // runs to the end of the stream
+        if (!gen.chunks[j].start_known) return false;
+        *stop = gen.chunks[j].start_bit;
+        return true;
+    }
+
+    Job next_job(Gen &gen, size_t *k, uint64_t *stop) {                        // mu_ held
+        const size_t ahead = (size_t)nthreads_ + 2;
+        const size_t hi = std::min(gen.chunks.size(), gen.consumed + ahead);
+        // translation first: it feeds the reader and frees the symbols
+        for (size_t i = gen.consumed; i < hi; i++) {
+            Chunk &c = gen.chunks[i];
+            if (i > gen.end_chunk) break;
+            if (c.decoded && c.window_known && !c.translate_taken) { c.translate_taken = true; *k = i; return TRANSLATE; }
+        }
+        for (size_t i = gen.consumed; i < hi; i++) {
+            Chunk &c = gen.chunks[i];
+            if (i > gen.end_chunk) break;
+            if (c.start_known && c.start_bit != NONE && !c.decode_taken && stop_of(gen, i, stop)) { c.decode_taken = true; *k = i; return DECODE; }
+        }
+        // headers are looked for one chunk further than chunks are decoded -- and as far beyond that as it takes to find the
+        // stop position of the last chunk in the window (a deflate block may be longer than a chunk)
+        for (size_t i = gen.consumed; i < gen.chunks.size(); i++) {
+            Chunk &c = gen.chunks[i];
+            if (i > gen.end_chunk) break;
+            if (!c.find_taken) { c.find_taken = true; *k = i; return FIND; }
+            if (i >= hi && (!c.start_known || c.start_bit != NONE)) break;      // being looked for, or found: nothing further is needed yet
+        }
+        return NOTHING;
+    }
+
+    void work() {
+        InflaterT<uint16_t> inf, probe;
+        std::vector<uint16_t> scratch;
+        for (;;) {
+            std::shared_ptr<Gen> gen;
+            size_t k = 0;
+            uint64_t stop = NONE;
+            Job job = NOTHING;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                for (;;) {
+                    if (stop_) return;
+                    gen = gen_;
+                    if (gen && fatal_.empty()) job = next_job(*gen, &k, &stop);
+                    if (job != NOTHING) break;
+                    cv_.wait(g);
+                }
+            }
+            Chunk &c = gen->chunks[k];
+            try {
+                if (job == FIND) {
+                    const uint8_t *data = addr_ + gen->data;
+                    const uint64_t b = find_block(data, addr_ + len_, (uint64_t)k * chunk_ * 8, (uint64_t)(k + 1) * chunk_ * 8, probe, scratch);
+                    std::lock_guard<std::mutex> g(mu_);
+                    c.start_bit = b;
+                    c.start_known = true;
+                    if (b == NONE) { c.decode_taken = true; finish_decode(*gen, k, 0); }   // nothing starts here: the previous chunk runs through
+                } else if (job == DECODE) {
+                    decode_chunk(*gen, k, stop, inf);
+                } else {
+                    translate_chunk(*gen, k);
+                }
+            } catch (const std::exception &e) {
+                // the reader meets the error when it gets to this chunk (chunks behind the end of the member never are)
+                std::lock_guard<std::mutex> g(mu_);
+                c.error = e.what();
+                c.decoded = c.translated = true;
+            }
+            cv_.notify_all();
+        }
+    }
+
+    void decode_chunk(Gen &gen, size_t k, uint64_t stop, InflaterT<uint16_t> &inf) {
+        const uint8_t *data = addr_ + gen.data, *end = addr_ + len_;
+        Chunk &c = gen.chunks[k];
+        inf.reset_at_bit(data, c.start_bit, end);
+        if (stop != NONE) inf.set_stop_bit(stop);
+        size_t cap = WINDOW + chunk_ * 5 + 65536;                              // symbols: [WINDOW place-holders][output]; grows as needed
+        std::unique_ptr<uint16_t[]> sym(new uint16_t[cap]);
+        if (k > 0) for (size_t i = 0; i < WINDOW; i++) sym[i] = (uint16_t)(0x8000u + i);
+        size_t n = 0;
+        uint64_t member_end = NONE;
+        for (;;) {
+            if (cap - (WINDOW + n) < 4096) {
+                const size_t ncap = cap + cap / 2;
+                std::unique_ptr<uint16_t[]> bigger(new uint16_t[ncap]);
+                memcpy(bigger.get(), sym.get(), (WINDOW + n) * sizeof(uint16_t));
+                sym = std::move(bigger);
+                cap = ncap;
+            }
+            size_t produced = 0;
+            const auto st = inf.run(sym.get() + WINDOW + n, sym.get() + cap, k > 0 ? WINDOW + n : n, &produced);
+            n += produced;
+            if (st == InflaterT<uint16_t>::CORRUPT) throw std::runtime_error("corrupt gzip data or a misjudged block boundary in " + path_);
+            if (st == InflaterT<uint16_t>::AT_STOP) break;
+            if (st == InflaterT<uint16_t>::STREAM_END) {
+                const uint8_t *t = inf.in_pos();
+                if ((size_t)(end - t) < 8) throw std::runtime_error("truncated gzip file: " + path_);
+                member_end = (uint64_t)(t - addr_);
+                break;
+            }
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        c.sym = std::move(sym);
+        if (member_end != NONE) { c.member_end = member_end; if (k < gen.end_chunk) gen.end_chunk = k; }
+        finish_decode(gen, k, n);
+    }
+
+    // mu_ held.  Marks chunk k decoded and resolves windows in chunk order: the window of chunk i + 1 is the last WINDOW bytes
+    // of the text up to the end of chunk i.  (Under the same lock as `decoded`, so that no translation frees symbols the
+    // chain still needs.)
+    void finish_decode(Gen &gen, size_t k, size_t nsym) {
+        gen.chunks[k].nsym = nsym;
+        gen.chunks[k].decoded = true;
+        while (gen.chain_next < gen.chunks.size()) {
+            Chunk &c = gen.chunks[gen.chain_next];
+            if (!c.decoded || !c.window_known) break;
+            const size_t i = gen.chain_next++;
+            if (!c.error.empty() || i + 1 >= gen.chunks.size() || i >= gen.end_chunk) continue;
+            Chunk &nx = gen.chunks[i + 1];
+            nx.window.reset(new uint8_t[WINDOW]);
+            const size_t from_text = std::min(c.nsym, WINDOW), from_win = WINDOW - from_text;
+            if (from_win) {
+                if (c.window) memcpy(nx.window.get(), c.window.get() + from_text, from_win);
+                else memset(nx.window.get(), 0, from_win);
+            }
+            nx.window_valid = std::min(WINDOW, from_text + std::min(c.window_valid, from_win));
+            for (size_t j = 0; j < from_text; j++) {
+                const uint16_t v = c.sym[WINDOW + c.nsym - from_text + j];
+                if (v < 256) { nx.window[from_win + j] = (uint8_t)v; continue; }
+                const size_t p = v - 0x8000u;
+                if (!c.window || p < WINDOW - c.window_valid) { nx.error = "gzip data refers to text before the start of the stream in " + path_; break; }
+                nx.window[from_win + j] = c.window[p];
+            }
+            nx.window_known = true;
+        }
+    }
+
+    void translate_chunk(Gen &gen, size_t k) {
+        Chunk &c = gen.chunks[k];
+        if (!c.error.empty()) { std::lock_guard<std::mutex> g(mu_); c.translated = true; return; }
+        std::unique_ptr<uint8_t[]> text(new uint8_t[c.nsym ? c.nsym : 1]);
+        const uint16_t *s = c.sym ? c.sym.get() + WINDOW : nullptr;
+        const uint8_t *win = c.window.get();
+        const size_t min_p = WINDOW - c.window_valid;
+        for (size_t i = 0; i < c.nsym; i++) {
+            const uint16_t v = s[i];
+            if (v < 256) { text[i] = (uint8_t)v; continue; }
+            const size_t p = v - 0x8000u;
+            if (!win || p < min_p) throw std::runtime_error("gzip data refers to text before the start of the stream in " + path_);
+            text[i] = win[p];
+        }
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t o = 0; o < c.nsym; o += (size_t)1 << 30) crc = (uint32_t)crc32(crc, text.get() + o, (uInt)std::min<size_t>(c.nsym - o, (size_t)1 << 30));
+        std::lock_guard<std::mutex> g(mu_);
+        c.text = std::move(text);
+        c.ntext = c.nsym;
+        c.crc = crc;
+        c.sym.reset();
+        c.translated = true;
+    }
+
+    static constexpr size_t PROBE_ROOM = 1u << 18;
+
+    const uint8_t *addr_;
+    size_t len_;
+    std::string path_;
+    size_t chunk_;
+    int nthreads_;
+    std::shared_ptr<Gen> gen_;
+    size_t rpos_ = 0;
+    uint32_t crc_ = 0;
+    uint64_t total_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> pool_;
+    bool stop_ = false;
+    std::string fatal_;
+};
+
+}  // namespace mdbg_host

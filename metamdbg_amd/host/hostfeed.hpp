@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "fastx.hpp"
+#include "gzip_parallel.hpp"
 #include "inflate.hpp"
 
 namespace mdbg_host {
@@ -663,6 +664,7 @@ private:
         struct Unmap { Mapping *m; ~Unmap() { if (m->addr) munmap((void *)m->addr, m->len); } } unmap{&map};
         std::unique_ptr<BgzfReader> bgzf;
         std::unique_ptr<GzipMemReader> gzmem;
+        std::unique_ptr<ParallelGzipReader> gzpar;
         {
             int fd = open(path.c_str(), O_RDONLY);
             if (fd < 0) throw std::runtime_error("File not found: " + path);
@@ -676,12 +678,22 @@ private:
                 std::vector<BgzfReader::Block> blocks;
                 if (!getenv("MDBG_HOST_NO_BGZF") && BgzfReader::index((const unsigned char *)addr, map.len, blocks))
                     bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), nThreads_, path));
-                else if (!zlib_inflate_requested())
-                    gzmem.reset(new GzipMemReader((const uint8_t *)addr, map.len, path));
+                else if (!zlib_inflate_requested()) {
+                    // an ordinary gzip stream: several decoding threads when the file is worth it (gzip_parallel.hpp), else one
+                    // (decoding without the window costs about twice the work: below six threads one thread is as fast)
+                    int gthreads = nThreads_ >= 6 ? nThreads_ : 1;
+                    if (const char *e = getenv("MDBG_HOST_GZIP_THREADS")) gthreads = atoi(e);
+                    size_t gchunk = (size_t)4 << 20;
+                    if (const char *e = getenv("MDBG_HOST_GZIP_CHUNK")) gchunk = (size_t)atoll(e);
+                    if (gthreads >= 2 && map.len >= 4 * gchunk)
+                        gzpar.reset(new ParallelGzipReader((const uint8_t *)addr, map.len, gthreads, path, gchunk));
+                    else
+                        gzmem.reset(new GzipMemReader((const uint8_t *)addr, map.len, path));
+                }
             }
         }
         gzFile fp = nullptr;
-        if (!bgzf && !gzmem) {
+        if (!bgzf && !gzmem && !gzpar) {
             fp = gzopen(path.c_str(), "r");
             if (!fp) throw std::runtime_error("File not found: " + path);
             gzbuffer(fp, 1 << 20);
@@ -708,9 +720,18 @@ private:
                 long n;
                 if (bgzf) n = (long)bgzf->read(buf + len, cap - len);
                 else if (gzmem) n = (long)gzmem->read(buf + len, cap - len);
+                else if (gzpar) n = (long)gzpar->read(buf + len, cap - len);
                 else n = gzread(fp, buf + len, (unsigned)std::min<size_t>(cap - len, (size_t)1 << 30));
                 if (n < 0) throw std::runtime_error("gzip read error: " + path);
-                if (n == 0) { eof = true; break; }
+                if (n == 0) {
+                    if (fp) {   // zlib: a truncated file ends with 0 bytes read and an error state
+                        int err = Z_OK;
+                        gzerror(fp, &err);
+                        if (err != Z_OK && err != Z_STREAM_END) throw std::runtime_error("gzip read error (truncated file?): " + path);
+                    }
+                    eof = true;
+                    break;
+                }
                 len += (size_t)n;
             }
             const char *begin = buf, *end = buf + len;
@@ -724,6 +745,7 @@ private:
                     closer.f = nullptr;
                     bgzf.reset();
                     gzmem.reset();
+                    gzpar.reset();
                     return read_gz_sequential(path, file, seq);
                 }
                 first = false;

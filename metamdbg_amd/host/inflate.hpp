@@ -23,28 +23,49 @@
 
 namespace mdbg_host {
 
-class Inflater {
+// OutT = uint8_t: the text.  OutT = uint16_t: symbols for decoding WITHOUT the preceding 32 KB (gzip_parallel.hpp): values
+// < 256 are bytes, larger ones stand for a position of the unknown window and are copied around like bytes.
+template <typename OutT>
+class InflaterT {
 public:
-    enum Status { NEED_ROOM = 0, STREAM_END = 1, CORRUPT = -1 };
+    enum Status { NEED_ROOM = 0, STREAM_END = 1, AT_STOP = 2, CORRUPT = -1 };
 
     // start decoding a raw deflate stream at `in`; [in, in_end) must stay readable
     void reset(const uint8_t *in, const uint8_t *in_end) {
-        in_ = in; in_end_ = in_end;
+        base_ = in; in_ = in; in_end_ = in_end;
         bitbuf_ = 0; bitcnt_ = 0;
         state_ = BLOCK_HEADER; final_ = false; stored_left_ = 0;
+        stop_bit_ = ~0ull; blocks_done_ = 0;
     }
+    // start at a block header that lies `bit` bits behind `base` (gzip_parallel.hpp: decoding from the middle of a stream)
+    void reset_at_bit(const uint8_t *base, uint64_t bit, const uint8_t *in_end) {
+        reset(base, in_end);
+        in_ = base + (bit >> 3);
+        if (bit & 7) { bitbuf_ = (uint64_t)(*in_++ >> (bit & 7)); bitcnt_ = 8 - (int)(bit & 7); }
+    }
+    // bits consumed since `base`; exact at block boundaries
+    uint64_t bit_position() const { return (uint64_t)(in_ - base_) * 8 - (uint64_t)bitcnt_; }
+    // run() returns AT_STOP in front of the block header at this bit position (CORRUPT if the stream's block boundaries skip it)
+    void set_stop_bit(uint64_t bit) { stop_bit_ = bit; }
+    unsigned blocks_done() const { return blocks_done_; }
+    bool in_final_block() const { return final_; }
 
     // Decodes into [out, out_end).  `hist` is the number of bytes of earlier output that lie directly in front of `out`
     // (at least min(32768, everything produced so far)).  *produced = bytes written.  Returns STREAM_END after the
     // final block (in_pos() is then the first byte behind the stream), NEED_ROOM when the room is used up (call again
     // with fresh room; up to 258+16 bytes of the old room may stay unused), CORRUPT on invalid data.
-    Status run(uint8_t *out, uint8_t *out_end, size_t hist, size_t *produced) {
-        uint8_t *const out0 = out;
-        const uint8_t *const lowest = out - hist;
+    Status run(OutT *out, OutT *out_end, size_t hist, size_t *produced) {
+        OutT *const out0 = out;
+        const OutT *const lowest = out - hist;
         Status st = NEED_ROOM;
         for (;;) {
             if (state_ == BLOCK_HEADER) {
                 if (final_) { st = STREAM_END; break; }
+                if (stop_bit_ != ~0ull) {
+                    const uint64_t at = bit_position();
+                    if (at == stop_bit_) { st = AT_STOP; break; }
+                    if (at > stop_bit_) { st = CORRUPT; break; }
+                }
                 if (!need(3)) { st = CORRUPT; break; }
                 final_ = take(1);
                 const unsigned type = take(2);
@@ -70,10 +91,12 @@ public:
                 if ((size_t)(in_end_ - in_) < n) { st = CORRUPT; break; }
                 const size_t room = (size_t)(out_end - out);
                 if (n > room) n = room;
-                memcpy(out, in_, n);
+                if (sizeof(OutT) == 1) memcpy(out, in_, n);
+                else for (size_t i = 0; i < n; i++) out[i] = (OutT)in_[i];
                 out += n; in_ += n; stored_left_ -= (uint32_t)n;
                 if (stored_left_) break;                      // room used up
                 state_ = BLOCK_HEADER;
+                blocks_done_++;
                 continue;
             }
             // HUFFMAN
@@ -81,6 +104,7 @@ public:
             if (r < 0) { st = CORRUPT; break; }
             if (r == 0) break;                                // room used up
             state_ = BLOCK_HEADER;                            // end-of-block symbol
+            blocks_done_++;
         }
         *produced = (size_t)(out - out0);
         return st;
@@ -272,8 +296,8 @@ private:
 
     // ---- the block loop ----------------------------------------------------------------------------------------
     // 1 = end of block, 0 = out of room, -1 = corrupt
-    int decode_block(uint8_t *&out_ref, uint8_t *out_end, const uint8_t *lowest) {
-        uint8_t *out = out_ref;
+    int decode_block(OutT *&out_ref, OutT *out_end, const OutT *lowest) {
+        OutT *out = out_ref;
         const uint8_t *in = in_;
         uint64_t bitbuf = bitbuf_;
         int bitcnt = bitcnt_;
@@ -292,7 +316,7 @@ private:
                 if (info) {
                     int k = 0;
                     do {
-                        memcpy(out, &run_lits_[bitbuf & ((1u << LIT_BITS) - 1)], 4);
+                        store_run(out, run_lits_[bitbuf & ((1u << LIT_BITS) - 1)]);
                         out += info >> 4;
                         bitbuf >>= (info & 15); bitcnt -= (int)(info & 15);
                         info = run_info_[bitbuf & ((1u << LIT_BITS) - 1)];
@@ -308,7 +332,7 @@ private:
             if (e & F_SUB) {
                 e = lit[(e >> 16) + ((bitbuf >> LIT_BITS) & ((1u << ((e >> 8) & 15)) - 1))];
                 if (e & F_LITERAL) {
-                    *out++ = (uint8_t)(e >> 16);
+                    *out++ = (OutT)(uint8_t)(e >> 16);
                     bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
                     continue;
                 }
@@ -330,17 +354,19 @@ private:
             const unsigned off = (d >> 16) + (unsigned)(bitbuf & ((1u << ((d >> 8) & 15)) - 1));
             bitbuf >>= ((d >> 8) & 15); bitcnt -= (int)((d >> 8) & 15);
             if ((size_t)(out - lowest) < off) { result = -1; break; }
-            const uint8_t *src = out - off;
-            uint8_t *const end = out + len;
-            if (__builtin_expect(off >= 8, 1)) {
+            const OutT *src = out - off;
+            OutT *const end = out + len;
+            constexpr unsigned STEP = 8 / sizeof(OutT);        // elements per 8-byte copy
+            if (__builtin_expect(off >= STEP, 1)) {
                 // read text has short matches (3 to 8 bytes): the first 8 bytes without a loop
                 memcpy(out, src, 8);
-                if (__builtin_expect(len > 8, 0)) {
-                    out += 8; src += 8;
-                    do { memcpy(out, src, 8); out += 8; src += 8; } while (out < end);
+                if (__builtin_expect(len > STEP, 0)) {
+                    out += STEP; src += STEP;
+                    do { memcpy(out, src, 8); out += STEP; src += STEP; } while (out < end);
                 }
             } else if (off == 1) {
-                memset(out, *src, len);
+                if (sizeof(OutT) == 1) memset(out, (int)*src, len);
+                else { const OutT v = *src; for (unsigned i = 0; i < len; i++) out[i] = v; }
             } else {
                 do { *out++ = *src++; } while (out < end);
             }
@@ -358,6 +384,15 @@ private:
         return result;
     }
 
+    // up to four literals at once (the unused ones are overwritten by what follows)
+    static void store_run(uint8_t *out, uint32_t lits) { memcpy(out, &lits, 4); }
+    static void store_run(uint16_t *out, uint32_t lits) {
+        uint64_t w = lits;
+        w = (w | (w << 16)) & 0x0000FFFF0000FFFFull;
+        w = (w | (w << 8)) & 0x00FF00FF00FF00FFull;
+        memcpy(out, &w, 8);
+    }
+
     // fetch bytes while available (up to 56 bits); decoding then checks that the bits it consumes exist
     void soft_refill() {
         while (bitcnt_ < 56 && in_ < in_end_) { bitbuf_ |= (uint64_t)*in_++ << bitcnt_; bitcnt_ += 8; }
@@ -368,7 +403,7 @@ private:
         return true;
     }
 
-    int decode_block_careful(uint8_t *&out, uint8_t *out_end, const uint8_t *lowest) {
+    int decode_block_careful(OutT *&out, OutT *out_end, const OutT *lowest) {
         for (;;) {
             if (out_end - out < 258 + 16) {
                 // out of room -- unless the input still allows the fast loop next time, which the caller decides
@@ -383,7 +418,7 @@ private:
             if (e & F_SUB) e = lit_[(e >> 16) + ((bitbuf_ >> LIT_BITS) & ((1u << ((e >> 8) & 15)) - 1))];
             if (e & F_INVALID) return -1;
             if (!drop(e & 0xFF)) return -1;
-            if (e & F_LITERAL) { *out++ = (uint8_t)(e >> 16); continue; }
+            if (e & F_LITERAL) { *out++ = (OutT)(uint8_t)(e >> 16); continue; }
             if (e & F_EOB) return 1;
             const unsigned lx = (e >> 8) & 15;
             soft_refill();
@@ -399,13 +434,15 @@ private:
             const unsigned off = (d >> 16) + (unsigned)(bitbuf_ & ((1u << dx) - 1));
             if (!drop(dx)) return -1;
             if ((size_t)(out - lowest) < off) return -1;
-            const uint8_t *src = out - off;
+            const OutT *src = out - off;
             while (len--) *out++ = *src++;
         }
     }
 
     static constexpr unsigned LIT_CAP = (1u << LIT_BITS) + 288 * 16, DIST_CAP = (1u << DIST_BITS) + 32 * 128;
-    const uint8_t *in_ = nullptr, *in_end_ = nullptr;
+    const uint8_t *base_ = nullptr, *in_ = nullptr, *in_end_ = nullptr;
+    uint64_t stop_bit_ = ~0ull;
+    unsigned blocks_done_ = 0;
     uint64_t bitbuf_ = 0;
     int bitcnt_ = 0;
     State state_ = BLOCK_HEADER;
@@ -416,6 +453,8 @@ private:
     uint32_t run_lits_[1u << LIT_BITS];    // up to four literals per index, little-endian
     uint8_t run_info_[1u << LIT_BITS];
 };
+
+using Inflater = InflaterT<uint8_t>;
 
 // gzip member header (RFC 1952) at p: returns the offset of the deflate data, 0 if this is not a gzip member
 inline size_t gzip_header_size(const uint8_t *p, size_t n) {

@@ -185,8 +185,9 @@ def test_bgzf_corruption_is_reported(exe, files, tmp_path):
     raw[len(raw) // 2] ^= 0x55
     bad = str(tmp_path / "bad.fastq.gz")
     open(bad, "wb").write(bytes(raw))
-    r = subprocess.run([exe, str(1 << 20), "3", "0", bad], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0
+    r = subprocess.run([exe, str(1 << 20), "3", "0", bad], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, MDBG_TEST_DRAIN_ONLY="1"))
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
 
 
 def test_gzip_damage_and_zlib_switch(exe, files, tmp_path):
@@ -198,12 +199,25 @@ def test_gzip_damage_and_zlib_switch(exe, files, tmp_path):
     bad[len(bad) // 2] ^= 0x10
     p = str(tmp_path / "flipped.fastq.gz")
     open(p, "wb").write(bytes(bad))
-    r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0
+    drain = dict(os.environ, MDBG_TEST_DRAIN_ONLY="1")     # exit code 3 = the feeder ended with an error, 0 = it delivered "all" reads
+    modes = ({}, {"MDBG_HOST_ZLIB_INFLATE": "1"}, {"MDBG_HOST_GZIP_THREADS": "4", "MDBG_HOST_GZIP_CHUNK": "65536"})
+    for mode in modes:
+        r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120, env=dict(drain, **mode))
+        assert r.returncode == 3, (mode, r.returncode, r.stdout, r.stderr)
     p = str(tmp_path / "truncated.fastq.gz")
     open(p, "wb").write(raw[: len(raw) * 2 // 3])
-    r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0
+    for mode in modes:
+        r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120, env=dict(drain, **mode))
+        assert r.returncode == 3, (mode, r.returncode, r.stdout, r.stderr)
+    # damage inside the first slab sends the file to the sequential reader (no 4-line records to be seen): still an error,
+    # not a silently shortened read set
+    bad = bytearray(raw)
+    bad[len(bad) // 50] ^= 0x04
+    p = str(tmp_path / "early.fastq.gz")
+    open(p, "wb").write(bytes(bad))
+    for mode in modes:
+        r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120, env=dict(drain, **mode))
+        assert r.returncode == 3, (mode, r.returncode, r.stdout, r.stderr)
     p = str(tmp_path / "garbage_tail.fastq.gz")
     open(p, "wb").write(raw + b"\x00" * 37 + b"not gzip")
     r = subprocess.run([exe, str(1 << 20), "3", "0", p], capture_output=True, text=True, timeout=120)
@@ -223,3 +237,58 @@ def test_inflate_against_zlib(tmp_path):
     r = subprocess.run([out, "11", "30"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr + r.stdout
     assert r.stdout.startswith("ok 30 streams")
+
+
+@pytest.fixture(scope="module")
+def big_gz(tmp_path_factory):
+    """A few MB of gzip so that the several-threads decoder has chunks to cut: FASTQ at three levels, three members with
+    trailing zeros, FASTA."""
+    d = tmp_path_factory.mktemp("biggz")
+    rng = np.random.default_rng(9)
+    recs = bytearray()
+    for i in range(2500):
+        n = int(rng.integers(1, 3000))
+        q = (rng.integers(0, 40, n) + 33).astype(np.uint8)
+        recs += b"@p%d\n" % i + _rand_seq(rng, n) + b"\n+\n" + bytes(q) + b"\n"
+    recs = bytes(recs)
+    out = {}
+    for lvl in (1, 6, 9):
+        out[f"l{lvl}"] = str(d / f"l{lvl}.fastq.gz")
+        open(out[f"l{lvl}"], "wb").write(gzip.compress(recs, lvl))
+    c1 = recs.rfind(b"\n@p", 0, len(recs) // 3) + 1
+    c2 = recs.rfind(b"\n@p", 0, 2 * len(recs) // 3) + 1
+    out["members"] = str(d / "m3.fastq.gz")
+    open(out["members"], "wb").write(gzip.compress(recs[:c1], 6) + gzip.compress(recs[c1:c2], 1) + gzip.compress(recs[c2:], 9) + b"\0" * 64)
+    fa = b"".join(b">f%d\n" % i + _rand_seq(rng, int(rng.integers(1, 20000))) + b"\n" for i in range(800))
+    out["fasta"] = str(d / "f.fasta.gz")
+    open(out["fasta"], "wb").write(gzip.compress(fa, 6))
+    return out
+
+
+@pytest.mark.parametrize("gzchunk", [65536, 150000, 700000])
+def test_one_gzip_stream_on_several_threads(exe, big_gz, gzchunk):
+    """gzip_parallel.hpp: chunks decoded without their window and resolved afterwards must give exactly the reads of the
+    sequential reader -- blocks longer than a chunk, members ending inside chunks, trailing bytes."""
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK=str(gzchunk))
+    for key, path in big_gz.items():
+        r = subprocess.run([exe, "300000", "3", "0", path], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (key, r.stderr)
+    r = subprocess.run([exe, "300000", "2", "0", big_gz["members"], big_gz["fasta"], big_gz["l1"]], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+
+
+def test_damaged_gzip_on_several_threads(exe, big_gz, tmp_path):
+    raw = open(big_gz["l6"], "rb").read()
+    rng = np.random.default_rng(4)
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK="150000", MDBG_TEST_DRAIN_ONLY="1")
+    for t in range(12):
+        bad = bytearray(raw)
+        if t % 4 == 3:
+            bad = bad[: int(rng.integers(len(bad) // 4, len(bad) - 1))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(100, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        p = str(tmp_path / "bad.fastq.gz")
+        open(p, "wb").write(bytes(bad))
+        r = subprocess.run([exe, "300000", "3", "0", p], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 3, (t, r.returncode, r.stdout, r.stderr)
