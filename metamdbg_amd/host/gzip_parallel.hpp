@@ -41,8 +41,18 @@ public:
     ParallelGzipReader(const uint8_t *addr, size_t len, int threads, std::string path, size_t chunk_bytes)
         : addr_(addr), len_(len), path_(std::move(path)), chunk_(chunk_bytes < 65536 ? 65536 : chunk_bytes), nthreads_(threads < 1 ? 1 : threads) {
         start_member(0);
-        for (int i = 0; i < nthreads_; i++) pool_.emplace_back([this] { work(); });
+        // A stream without dynamic-Huffman block headers to start from (stored blocks: gzip -0, incompressible data) cannot be
+        // cut: ask before the first read() and use one thread then.  Looked for in the second and third chunk.
+        if (gen_) {
+            InflaterT<uint16_t> probe;
+            std::vector<uint16_t> scratch;
+            const uint8_t *data = addr_ + gen_->data;
+            for (size_t k = 1; k < std::min<size_t>(3, gen_->chunks.size()) && !usable_; k++)
+                usable_ = find_block(data, addr_ + len_, (uint64_t)k * chunk_ * 8, (uint64_t)(k + 1) * chunk_ * 8, probe, scratch) != NONE;
+        }
+        if (usable_) for (int i = 0; i < nthreads_; i++) pool_.emplace_back([this] { work(); });
     }
+    bool usable() const { return usable_; }
     ~ParallelGzipReader() {
         {
             std::lock_guard<std::mutex> g(mu_);
@@ -269,6 +279,9 @@ private:
         uint64_t member_end = NONE;
         for (;;) {
             if (cap - (WINDOW + n) < 4096) {
+                // a chunk that never reaches the next header (a long stretch of stored or fixed-code blocks) would grow without
+                // bound: 64 chunks' worth of text is where this gives up
+                if (n > chunk_ * 64 * 4) throw std::runtime_error("no block header to cut at for " + std::to_string(n) + " bytes of text in " + path_);
                 const size_t ncap = cap + cap / 2;
                 std::unique_ptr<uint16_t[]> bigger(new uint16_t[ncap]);
                 memcpy(bigger.get(), sym.get(), (WINDOW + n) * sizeof(uint16_t));
@@ -361,7 +374,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<std::thread> pool_;
-    bool stop_ = false;
+    bool stop_ = false, usable_ = false;
     std::string fatal_;
 };
 

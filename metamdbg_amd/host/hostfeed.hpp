@@ -685,10 +685,11 @@ private:
                     if (const char *e = getenv("MDBG_HOST_GZIP_THREADS")) gthreads = atoi(e);
                     size_t gchunk = (size_t)4 << 20;
                     if (const char *e = getenv("MDBG_HOST_GZIP_CHUNK")) gchunk = (size_t)atoll(e);
-                    if (gthreads >= 2 && map.len >= 4 * gchunk)
+                    if (gthreads >= 2 && map.len >= 4 * gchunk) {
                         gzpar.reset(new ParallelGzipReader((const uint8_t *)addr, map.len, gthreads, path, gchunk));
-                    else
-                        gzmem.reset(new GzipMemReader((const uint8_t *)addr, map.len, path));
+                        if (!gzpar->usable()) gzpar.reset();                  // no block header to cut at: one thread
+                    }
+                    if (!gzpar) gzmem.reset(new GzipMemReader((const uint8_t *)addr, map.len, path));
                 }
             }
         }

@@ -262,6 +262,11 @@ def big_gz(tmp_path_factory):
     fa = b"".join(b">f%d\n" % i + _rand_seq(rng, int(rng.integers(1, 20000))) + b"\n" for i in range(800))
     out["fasta"] = str(d / "f.fasta.gz")
     open(out["fasta"], "wb").write(gzip.compress(fa, 6))
+    # stored blocks only (gzip -0): nothing to cut at, one thread must take it; and a stored member between compressed ones
+    out["stored"] = str(d / "s0.fastq.gz")
+    open(out["stored"], "wb").write(gzip.compress(recs, 0))
+    out["stored_between"] = str(d / "s1.fastq.gz")
+    open(out["stored_between"], "wb").write(gzip.compress(recs[:c1], 6) + gzip.compress(recs[c1:c2], 0) + gzip.compress(recs[c2:], 6))
     return out
 
 
