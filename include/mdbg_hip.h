@@ -13,13 +13,13 @@
  * device and one stream and is not thread-safe (use one context per host thread / stream,
  * as the reference uses one functor copy per OpenMP thread: Commons.hpp:5846-5914).
  * Several contexts on one device may be driven concurrently from several threads; that is the intended way to keep
- * two batches in flight (the table kernels of one batch overlap the scan of the next -- bench.py).
+ * two or three batches in flight (the table kernels of one batch overlap the scan of the next -- bench.py).
  * mdbg_scan calls on the same device take turns: one scan kernel runs at a time.
  * There is no CPU fallback: without a usable GPU every call fails with MDBG_ENODEV.
  *
  * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE (default 2) -- reads a scan wave processes before it
  * retires; MDBG_TABLE_BLOCKS_PER_CU (default: unlimited) -- resident blocks per CU of the k-min-mer insert kernels, to be
- * set to a few (3) when two contexts share a device; MDBG_TRACE -- one line per purge with the number of suspect reads.
+ * set to 1..3 when several contexts share a device (bench.py: 1); MDBG_TRACE -- one line per purge with the number of suspect reads.
  */
 #ifndef MDBG_HIP_H
 #define MDBG_HIP_H
