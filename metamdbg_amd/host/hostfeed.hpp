@@ -450,8 +450,8 @@ public:
     using Alloc = std::function<void *(size_t)>;
     using Free = std::function<void(void *)>;
 
-    ReadFeeder(std::vector<std::string> files, size_t chunkBytes, int threads, uint64_t maxReadsPerFile, Alloc alloc, Free free_)
-        : files_(std::move(files)), chunk_(chunkBytes), maxReads_(maxReadsPerFile), free_(std::move(free_)),
+    ReadFeeder(std::vector<std::string> files, size_t chunkBytes, int threads, uint64_t maxReadsPerFile, Alloc alloc, Free freeFn)
+        : files_(std::move(files)), chunk_(chunkBytes), maxReads_(maxReadsPerFile), free_(std::move(freeFn)),
           fileDone_(files_.size() ? files_.size() : 1) {
         for (auto &f : fileDone_) f.store(false);
         if (threads < 1) threads = 1;
