@@ -19,6 +19,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -60,6 +64,9 @@ public:
         }
         cv_.notify_all();
         for (auto &t : pool_) if (t.joinable()) t.join();
+        if (getenv("MDBG_HOST_GZIP_TRACE"))
+            fprintf(stderr, "[gzip on %d threads] thread-seconds: looking for headers %.3f, decoding %.3f, translating + CRC %.3f\n", nthreads_,
+                    t_find_.load() * 1e-9, t_decode_.load() * 1e-9, t_translate_.load() * 1e-9);
     }
 
     // up to `want` bytes of text; 0 at the end of the file; throws on damaged data
@@ -244,6 +251,7 @@ private:
                 }
             }
             Chunk &c = gen->chunks[k];
+            const auto t0 = std::chrono::steady_clock::now();
             try {
                 if (job == FIND) {
                     const uint8_t *data = addr_ + gen->data;
@@ -263,6 +271,8 @@ private:
                 c.error = e.what();
                 c.decoded = c.translated = true;
             }
+            const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            (job == FIND ? t_find_ : job == DECODE ? t_decode_ : t_translate_) += ns;
             cv_.notify_all();
         }
     }
@@ -374,6 +384,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<std::thread> pool_;
+    std::atomic<long long> t_find_{0}, t_decode_{0}, t_translate_{0};
     bool stop_ = false, usable_ = false;
     std::string fatal_;
 };

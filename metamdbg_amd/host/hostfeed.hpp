@@ -458,6 +458,7 @@ public:
         // Page-locking memory costs ~1 ms per MB, so buffers are kept few and small: a worker that packs to 2 bits needs a
         // quarter of the chunk (+ padding of every read to a 64-base unit), which pays for 12 packing workers where 6
         // copying ones were the limit; a buffer grows to the full chunk only if its chunk has to be delivered as ASCII.
+        gzThreads_ = threads > 24 ? 24 : threads;      // decompression is plain CPU work: it may use more threads than there are buffers
         if (threads > (pack_ ? 12 : 6)) threads = pack_ ? 12 : 6;
         alloc_ = std::move(alloc);
         nThreads_ = threads;
@@ -677,11 +678,11 @@ private:
                 madvise(addr, map.len, MADV_SEQUENTIAL);
                 std::vector<BgzfReader::Block> blocks;
                 if (!getenv("MDBG_HOST_NO_BGZF") && BgzfReader::index((const unsigned char *)addr, map.len, blocks))
-                    bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), nThreads_, path));
+                    bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), gzThreads_, path));
                 else if (!zlib_inflate_requested()) {
                     // an ordinary gzip stream: several decoding threads when the file is worth it (gzip_parallel.hpp), else one
                     // (decoding without the window costs about twice the work: below six threads one thread is as fast)
-                    int gthreads = nThreads_ >= 6 ? nThreads_ : 1;
+                    int gthreads = gzThreads_ >= 6 ? gzThreads_ : 1;
                     if (const char *e = getenv("MDBG_HOST_GZIP_THREADS")) gthreads = atoi(e);
                     size_t gchunk = (size_t)4 << 20;
                     if (const char *e = getenv("MDBG_HOST_GZIP_CHUNK")) gchunk = (size_t)atoll(e);
@@ -965,7 +966,7 @@ private:
     std::vector<std::thread> workers_;
     uint64_t nextSeq_ = 0, totalSeq_ = 0;
     size_t slabsOut_ = 0;   // inflated gzip slabs queued or being parsed
-    int nThreads_ = 1;
+    int nThreads_ = 1, gzThreads_ = 1;
     bool splitDone_ = false, stop_ = false;
     bool pack_ = getenv("MDBG_HOST_NO_PACK") == nullptr;   // pack to 2 bits on the host unless asked not to
     std::string error_;
