@@ -61,11 +61,11 @@ def sha256(path: str) -> str:
     return h.hexdigest()
 
 
-def log_known_answers(tmp: str) -> dict:
-    """Numbers the reference logs while running `graph` (metaMDBG.log next to tmp/): the EdgeIndexer's edge count and
-    checksum (graph/CreateMdbg.cpp:1184) and the abundance checksum sum(abundance * hash) (:3321, :3397)."""
+def log_known_answers(tmp: str, start: int = 0) -> dict:
+    """Numbers the reference logs while running `graph` (metaMDBG.log next to tmp/, from byte `start` on): the EdgeIndexer's
+    edge count and checksum (graph/CreateMdbg.cpp:1184) and the abundance checksum sum(abundance * hash) (:3321, :3397)."""
     import re
-    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()[start:]
     out = {}
     m = re.search(r"Dereplicating edges.*?\n\s*Done: (\d+) (\d+) ", log, flags=re.S)
     if m:
@@ -148,6 +148,8 @@ def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, 
     for k in range(first_k, last_k + 1):
         dataclasses.replace(params, kminmer_size=k, prev_k=prev_k, last_k=last_k).save(os.path.join(tmp, "parameters.gz"))
         cmd = [REFDRV, "graph", tmp, "--threads", "1"] + (["--min-abundance", "0", "--firstpass"] if k == first_k else [])
+        log_path = os.path.join(os.path.dirname(tmp), "metaMDBG.log")
+        log_start = os.path.getsize(log_path) if os.path.exists(log_path) else 0
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         if k > first_k:
             d = os.path.join(dst, f"k{k}")
@@ -160,7 +162,10 @@ def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, 
                 raw = open(os.path.join(tmp, "kminmerData_min.txt"), "rb").read()
                 formats.sorted_vector_records(raw, k).astype("<u4").tofile(os.path.join(d, "kminmerData_min.sorted.bin"))
             shutil.copy(os.path.join(tmp, "smallContigs", f"smallContigs_k{k}.bin"), os.path.join(d, "smallContigs.bin"))
-            per_k[str(k)] = dict(n_records=len(raw) // 20 if k > first_k + 1 else os.path.getsize(os.path.join(tmp, "kminmerData_abundance.txt")) // 20,
+            known = log_known_answers(tmp, log_start)       # EdgeIndexer / UnitigEdgeIndexer run while vectors exist (k <= firstK+1)
+            if "n_unitig_edges" in known:
+                shutil.copy(os.path.join(tmp, "unitigGraph.nodes.bin"), os.path.join(d, "unitigGraph.nodes.bin"))
+            per_k[str(k)] = dict(reference_log=known, n_records=len(raw) // 20 if k > first_k + 1 else os.path.getsize(os.path.join(tmp, "kminmerData_abundance.txt")) // 20,
                                  small_contigs_bytes=os.path.getsize(os.path.join(d, "smallContigs.bin")))
         if k == last_k:
             break

@@ -690,3 +690,27 @@ def test_next_k_tables_equal_reference_multik(ctx, name, k):
     flags = ctx.small_contigs(d_unitigs, k, P.prev_k, dprev) if k > 8 else np.zeros(len(uo) - 1, np.uint8)
     mine = sorted((0, tuple(int(x) for x in um[int(uo[i]): int(uo[i + 1])])) for i in np.nonzero(flags)[0])
     assert mine == mk.small_contig_records(fx["small_contigs"])
+
+
+@pytest.mark.parametrize("name", ["hifi_multik", "ont_multik"])
+def test_edge_indexes_at_first_k_plus_one_vs_reference_log(ctx, name):
+    """N2 once more at k = firstK+1, where the reference still has vectors: EdgeIndexer over the refined table and
+    UnitigEdgeIndexer over the reference's own unitigGraph.nodes.bin against the counts and the checksum it logs."""
+    from tests import multik_fixture as mk
+    m = mk.manifest(name)
+    k = m["first_k"] + 1
+    log = m["per_k"][str(k)]["reference_log"]
+    fx = mk.load(name, k)
+    P = fx["params"]
+    (rm, ro), (um, uo) = fx["reads"], fx["unitigs"]
+    dprev = ctx.prev_from_records(fx["prev_records"])
+    if fx["prev_unitigs"]:
+        pm = np.concatenate([u for u, _ in fx["prev_unitigs"]]).astype(np.uint32)
+        po = np.concatenate([[0], np.cumsum([len(u) for u, _ in fx["prev_unitigs"]])]).astype(np.uint64)
+        ctx.prev_overlay_unitigs(dprev, ctx.minimizers_from_host(pm, po), np.array([a for _, a in fx["prev_unitigs"]], dtype=np.uint32), P.prev_k)
+    table = ctx.kminmer_count_refined(ctx.minimizers_from_host(rm, ro), ctx.minimizers_from_host(um, uo), k, dprev)
+    edges, ck = ctx.edge_index(table)
+    assert edges.info()["n_records"] == log["n_edges"] and ck == log["edge_checksum"]
+    nm, no, _ = formats.parse_unitig_nodes(open(os.path.join(fx["dir"], "unitigGraph.nodes.bin"), "rb").read())
+    uedges, _ = ctx.unitig_edge_index(ctx.minimizers_from_host(nm, no), k)
+    assert uedges.info()["n_records"] == log["n_unitig_edges"]
