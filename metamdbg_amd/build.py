@@ -64,7 +64,7 @@ def build_tool() -> str:
     """The C++ host tool (drop-in readSelection / graph over the C ABI), in-tree at metamdbg_amd/bin/mdbg_tool."""
     src = os.path.join(HERE, "host", "mdbg_tool.cpp")
     deps = [src, os.path.join(HERE, "host", "fastx.hpp"), os.path.join(HERE, "host", "hostfeed.hpp"),
-            os.path.join(HERE, "host", "inflate.hpp"), os.path.join(HERE, "host", "gzip_parallel.hpp"), os.path.join(HERE, "..", "include", "mdbg_hip.h"), LIB]
+            os.path.join(HERE, "host", "inflate.hpp"), os.path.join(HERE, "host", "gzip_parallel.hpp"), os.path.join(HERE, "host", "crc32_fast.hpp"), os.path.join(HERE, "..", "include", "mdbg_hip.h"), LIB]
     out = os.path.join(HERE, "bin", "mdbg_tool")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if _stale(out, deps):

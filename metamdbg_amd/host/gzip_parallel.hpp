@@ -33,6 +33,7 @@
 #include <thread>
 #include <vector>
 
+#include "crc32_fast.hpp"
 #include "inflate.hpp"
 
 namespace mdbg_host {
@@ -360,8 +361,7 @@ private:
             if (!win || p < min_p) throw std::runtime_error("gzip data refers to text before the start of the stream in " + path_);
             text[i] = win[p];
         }
-        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-        for (size_t o = 0; o < c.nsym; o += (size_t)1 << 30) crc = (uint32_t)crc32(crc, text.get() + o, (uInt)std::min<size_t>(c.nsym - o, (size_t)1 << 30));
+        const uint32_t crc = crc32_fast(0, text.get(), c.nsym);
         std::lock_guard<std::mutex> g(mu_);
         c.text = std::move(text);
         c.ntext = c.nsym;

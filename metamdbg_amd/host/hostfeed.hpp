@@ -29,6 +29,7 @@
 #include <thread>
 #include <vector>
 
+#include "crc32_fast.hpp"
 #include "fastx.hpp"
 #include "gzip_parallel.hpp"
 #include "inflate.hpp"
@@ -262,7 +263,7 @@ private:
                 check_.pop_front();
             }
             cv_.notify_all();
-            crc = (uint32_t)crc32(crc, p->text(), (uInt)p->len);
+            crc = crc32_fast(crc, p->text(), p->len);
             n += p->len;
             if (p->member_end) {
                 if (crc != p->crc || (uint32_t)n != p->isize)
@@ -412,7 +413,7 @@ private:
                     uint8_t *out = (uint8_t *)text.buf.data() + o;
                     ok = inf->run(out, (uint8_t *)text.buf.data() + text.buf.size(), 0, &produced) == Inflater::STREAM_END && produced == blk.isize;
                 }
-                ok = ok && (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)text.buf.data() + o, blk.isize) == blk.crc;
+                ok = ok && crc32_fast(0, (const unsigned char *)text.buf.data() + o, blk.isize) == blk.crc;
                 o += blk.isize;
             }
             if (!ok) { fail("corrupt BGZF block in " + path_); break; }

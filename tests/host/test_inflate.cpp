@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "../../metamdbg_amd/host/crc32_fast.hpp"
 #include "../../metamdbg_amd/host/inflate.hpp"
 
 using mdbg_host::Inflater;
@@ -130,6 +131,26 @@ int main(int argc, char **argv) {
             damaged++;
             if (rc2 != 0 || o2 != text) detected++;
         }
+    }
+    // crc32_fast (carry-less multiplication) against zlib: lengths around the 64-byte folds, odd alignments, a running CRC
+    {
+        std::vector<uint8_t> buf(1 << 20);
+        for (auto &c : buf) c = (uint8_t)rng();
+        for (int t = 0; t < 3000; t++) {
+            const size_t off = rng() % 64, len = t < 1200 ? (size_t)t : rng() % 200000;
+            const uint32_t seed = t % 3 ? (uint32_t)rng() : 0;
+            if ((uint32_t)crc32(seed, buf.data() + off, (uInt)len) != mdbg_host::crc32_fast(seed, buf.data() + off, len)) {
+                fprintf(stderr, "crc32_fast differs from zlib: length %zu offset %zu\n", len, off);
+                return 1;
+            }
+        }
+        uint32_t a = 0, b = 0;
+        for (size_t o = 0; o < buf.size();) {
+            const size_t l = std::min<size_t>(buf.size() - o, rng() % 50000);
+            a = (uint32_t)crc32(a, buf.data() + o, (uInt)l); b = mdbg_host::crc32_fast(b, buf.data() + o, l);
+            o += l;
+        }
+        if (a != b) { fprintf(stderr, "running crc32_fast differs from zlib\n"); return 1; }
     }
     printf("ok %zu streams, %zu damaged copies (%zu changed the result or were rejected)\n", streams, damaged, detected);
     return 0;
