@@ -1,0 +1,123 @@
+"""The oracle against the reference's own code run NOW (oracle/_ref/refdrv, built from /root/reference by oracle/Makefile)
+on inputs drawn fresh for this run -- beyond the committed vectors of tests/golden/fn_golden.json.  Skipped where the
+reference build is absent.  The seed is printed on failure through the assertion message."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDRV = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+pytestmark = pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
+SEED = int(os.environ.get("MDBG_TEST_SEED", str(int(time.time()) % 1_000_000)))
+
+
+def refdrv(args, lines):
+    r = subprocess.run([REFDRV] + [str(a) for a in args], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    return r.stdout.splitlines()
+
+
+def rand_read(rng, n, kind):
+    if kind == 0:
+        codes = rng.integers(0, 4, n)
+    elif kind == 1:                                   # homopolymer-rich
+        codes = np.repeat(rng.integers(0, 4, n), rng.integers(1, 9, n))[:n]
+    else:                                             # short tandem repeats
+        unit = rng.integers(0, 4, int(rng.integers(1, 7)))
+        codes = np.tile(unit, n // len(unit) + 1)[:n]
+        flip = rng.random(n) < 0.02
+        codes = np.where(flip, rng.integers(0, 4, n), codes)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+    if kind == 0 and n > 10:
+        for _ in range(int(rng.integers(0, 4))):      # N, n and lower case (Kmer.hpp:462: purely bitwise character handling)
+            p = int(rng.integers(0, n))
+            s[p] = rng.choice(np.frombuffer(b"NnacgtR", dtype=np.uint8))
+    return bytes(s)
+
+
+@pytest.mark.parametrize("K,density,hpc", [(15, 0.005, 1), (15, 0.05, 0), (13, 0.025, 0), (16, 0.2, 1), (7, 0.5, 1)])
+def test_minimizer_parser_live(K, density, hpc):
+    rng = np.random.default_rng(SEED + K)
+    reads = [rand_read(rng, int(rng.integers(0, 4000)), int(rng.integers(0, 3))) for _ in range(60)]
+    reads = [r for r in reads if r]                   # the driver reads one sequence per line
+    L = orc.lib()
+    L.orc_minimizer_parse.restype = C.c_size_t
+    for trim, cmd in ((1, "fn_scan"), (0, "fn_scan_notrim")):
+        out = refdrv([cmd, K, density, hpc], [r.decode() for r in reads])
+        assert len(out) == len(reads)
+        for seq, line in zip(reads, out):
+            toks = line.split()
+            exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
+            rle = C.create_string_buffer(len(seq) + 2)
+            pos = (C.c_uint64 * (len(seq) + 2))()
+            hl = L.orc_hpc_encode(seq, C.c_size_t(len(seq)), hpc, rle, pos)
+            cap = max(hl, 1)
+            om = (C.c_uint32 * cap)(); op = (C.c_uint32 * cap)(); od = (C.c_uint8 * cap)()
+            if trim:
+                n = L.orc_minimizer_parse(rle, C.c_size_t(hl), K, C.c_float(density), None, C.c_size_t(0), om, op, od)
+            else:
+                L.orc_minimizer_parse_trim.restype = C.c_size_t
+                n = L.orc_minimizer_parse_trim(rle, C.c_size_t(hl), K, C.c_float(density), None, C.c_size_t(0), C.c_size_t(0), om, op, od)
+            got = [(om[i], op[i], od[i]) for i in range(n)]
+            assert hl == int(toks[1]) and got == exp, (SEED, cmd, K, density, hpc, seq[:60])
+
+
+@pytest.mark.parametrize("k", [3, 4, 5, 8, 11, 21])
+def test_kminmer_normalize_hash_live(k):
+    rng = np.random.default_rng(SEED + 100 + k)
+    vecs = []
+    for _ in range(200):
+        v = rng.integers(0, 2 ** 32, k, dtype=np.uint64).astype(np.uint32)
+        t = int(rng.integers(0, 4))
+        if t == 0:
+            v = np.concatenate([v[: k // 2], v[: k - k // 2][::-1]])[:k]     # palindromes and near-palindromes
+        elif t == 1:
+            v[:] = v[0]
+        vecs.append(v)
+    out = refdrv(["fn_kminmer", k], [" ".join(str(int(x)) for x in v) for v in vecs])
+    for v, line in zip(vecs, out):
+        o = [int(x) for x in line.split()]
+        rev, cvec, hi, lo = orc.kminmer_normalize_hash(v)
+        assert [rev, hi, lo] + cvec.tolist() == o, (SEED, k, v.tolist())
+
+
+@pytest.mark.parametrize("first_k,last_k", [(4, 6), (4, 11), (3, 9), (5, 21)])
+def test_purge_palindrome_live(first_k, last_k):
+    rng = np.random.default_rng(SEED + 200 + last_k)
+    lines = []
+    for _ in range(150):
+        n = int(rng.integers(0, 60))
+        alphabet = int(rng.integers(2, 8))            # few distinct minimizers: palindromic windows everywhere
+        v = rng.integers(0, alphabet, n)
+        if n > 8 and rng.integers(0, 2):
+            h = int(rng.integers(2, n // 2))
+            a = int(rng.integers(0, n - 2 * h + 1))
+            v[a + h: a + 2 * h] = v[a: a + h][::-1]
+        lines.append(" ".join(str(int(x)) for x in v))
+    lines = [ln for ln in lines if ln]
+    out = refdrv(["fn_purge", first_k, last_k], lines)
+    for line, o in zip(lines, out):
+        got = orc.purge_palindrome([int(x) for x in line.split()], first_k, last_k).tolist()
+        assert got == [int(x) for x in o.split()], (SEED, first_k, last_k, line)
+
+
+def test_murmur_and_density_live():
+    rng = np.random.default_rng(SEED + 300)
+    vals = [int(x) for x in rng.integers(0, 2 ** 63, 300, dtype=np.uint64)] + [0, 1, 2 ** 30 - 1, 2 ** 32 - 1, 2 ** 64 - 1]
+    out = refdrv(["fn_murmur"], [str(v) for v in vals])
+    assert [int(x) for x in out] == [orc.kmer_hash(v) for v in vals], SEED
+    for d in (0.005, 0.025, 0.3):
+        lines = [" ".join(str(int(x)) for x in rng.integers(0, 2 ** 32, int(rng.integers(1, 400)), dtype=np.uint64)) for _ in range(20)]
+        out = refdrv(["fn_density", d], lines)
+        for line, o in zip(lines, out):
+            m = np.array([int(x) for x in line.split()], dtype=np.uint32)
+            keep = orc.apply_density_threshold(m, d).tolist()          # indices kept; the driver prints their number first
+            assert keep == [int(x) for x in o.split()[1:]], (SEED, d)
