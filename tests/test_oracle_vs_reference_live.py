@@ -121,3 +121,59 @@ def test_murmur_and_density_live():
             m = np.array([int(x) for x in line.split()], dtype=np.uint32)
             keep = orc.apply_density_threshold(m, d).tolist()          # indices kept; the driver prints their number first
             assert keep == [int(x) for x in o.split()[1:]], (SEED, d)
+
+
+@pytest.mark.parametrize("kind", ["hifi_fasta", "hifi_fastq", "ont_fastq"])
+def test_pipeline_live(kind, tmp_path):
+    """readSelection + graph --firstpass of the reference on a read set drawn now (repeats, low-complexity reads, short
+    reads, skewed base composition) against the oracle: read_data_init.txt byte for byte, read_data_corrected.txt, the table."""
+    from metamdbg_amd import formats
+    rng = np.random.default_rng(SEED + 400 + len(kind))
+    hpc = kind != "ont_fastq"
+    with_q = kind != "hifi_fasta"
+    p = np.array([0.3, 0.2, 0.2, 0.3]) if kind == "hifi_fastq" else np.full(4, 0.25)
+    genome = rng.choice(4, size=40_000, p=p)
+    genome[5000:5400] = np.tile([0, 1], 200)                              # a low-complexity stretch
+    genome[9000:9300] = 2                                                  # a long homopolymer
+    seqs, quals = [], []
+    for i in range(150):
+        L = int(rng.integers(20, 9000)) if i % 10 else int(rng.integers(0, 70))
+        a = int(rng.integers(0, len(genome) - L))
+        c = genome[a:a + L].copy()
+        err = rng.random(L) < (0.002 if hpc else 0.03)
+        c = np.where(err, rng.integers(0, 4, L), c)
+        if rng.integers(0, 2):
+            c = (c[::-1] ^ 2)                                              # reverse complement in the A0 C1 T2 G3 code
+        seqs.append(bytes(np.frombuffer(b"ACTG", dtype=np.uint8)[c]))
+        quals.append(bytes((rng.integers(1, 60, L) + 33).astype(np.uint8)))
+    path = str(tmp_path / ("r.fastq" if with_q else "r.fasta"))
+    with open(path, "wb") as f:
+        for i, s in enumerate(seqs):
+            if not s:
+                s, quals[i] = b"A", b"I"                                   # kseq skips nothing, but an empty record has no line to parse
+                seqs[i] = s
+            f.write((b"@r%d\n" % i + s + b"\n+\n" + quals[i] + b"\n") if with_q else (b">r%d\n" % i + s + b"\n"))
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=hpc, data_type=0 if hpc else 1,
+                           correction_density=0.025)
+    tmp = str(tmp_path / "out" / "tmp")
+    for d in ("", "filter", "smallContigs", "checkpoints"):
+        os.makedirs(os.path.join(tmp, d), exist_ok=True)
+    P.save(os.path.join(tmp, "parameters.gz"))
+    open(os.path.join(tmp, "input.txt"), "w").write(path + "\n")
+    rs = [REFDRV, "readSelection", tmp, tmp + "/read_data_init.txt", tmp + "/input.txt", "--threads", "1", "--min-read-quality", "0.000000"]
+    subprocess.run(rs + ([] if hpc else ["--skip-correction"]), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    subprocess.run([REFDRV, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass"], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL, timeout=300)
+    rd = lambda n: open(os.path.join(tmp, n), "rb").read()
+    rep = np.frombuffer(rd("repetitiveMinimizers.bin"), "<u4")
+    recs = [orc.read_selection(s, quals[i] if with_q else None, K=15, density=0.005, hpc=hpc, repetitive=rep) for i, s in enumerate(seqs)]
+    assert b"".join(r["record"] for r in recs) == rd("read_data_init.txt"), (SEED, kind)
+    st = formats.parse_read_stats(rd("read_stats.txt"))
+    last_k = orc.lib().orc_compute_last_k(0.005, st["n50"], 4, 0)
+    purged = [orc.purge_palindrome(r["minimizers"], 4, last_k) for r in recs]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in purged])]).astype(np.uint64)
+    mins = np.concatenate(purged).astype(np.uint32) if purged else np.zeros(0, np.uint32)
+    assert formats.write_minimizer_reads(mins, offs) == rd("read_data_corrected.txt"), (SEED, kind)
+    t = orc.kminmer_count_first(mins, offs, 4, 0)
+    assert np.array_equal(formats.sorted_abundance_records(orc.table_abundance_records(t)), formats.sorted_abundance_records(rd("kminmerData_abundance.txt"))), (SEED, kind)
+    assert np.array_equal(formats.sorted_vector_records(t["vecs"].astype("<u4").tobytes(), 4), formats.sorted_vector_records(rd("kminmerData_min.txt"), 4)), (SEED, kind)
