@@ -177,3 +177,36 @@ def test_pipeline_live(kind, tmp_path):
     t = orc.kminmer_count_first(mins, offs, 4, 0)
     assert np.array_equal(formats.sorted_abundance_records(orc.table_abundance_records(t)), formats.sorted_abundance_records(rd("kminmerData_abundance.txt"))), (SEED, kind)
     assert np.array_equal(formats.sorted_vector_records(t["vecs"].astype("<u4").tobytes(), 4), formats.sorted_vector_records(rd("kminmerData_min.txt"), 4)), (SEED, kind)
+
+
+def test_multik_loop_live(tmp_path):
+    """The reference's multi-k loop (graph -> contig -> toMinspace per k, as tests/golden/make_golden.py drives it) on reads
+    drawn now; every k > firstK: previous table + unitig overlay, refined count / index and the small-contig branch of the
+    oracle against what the reference wrote."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from metamdbg_amd import formats, synth
+    from tests import multik_fixture as mk
+    spec = synth.hifi_spec(160, seed=SEED % 100000 + 7, coverage=25.0)
+    fasta = str(tmp_path / "reads.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=True, data_type=0)
+    tmp = mg.run_ref_pipeline(str(tmp_path / "ref"), fasta, params, graph=False)
+    root = str(tmp_path / "fx")
+    mg.run_ref_multik(tmp, params, 10, os.path.join(root, "live"), dict(kind="hifi", seed=spec.seed))
+    for k in range(5, 11):
+        fx = mk.load("live", k, root=root)
+        P = fx["params"]
+        prev = orc.PrevAbundance(fx["prev_records"])
+        prev.overlay_unitigs(fx["prev_unitigs"], P.prev_k)
+        (rm, ro), (um, uo) = fx["reads"], fx["unitigs"]
+        allm = np.concatenate([rm, um]); alloff = np.concatenate([ro, ro[-1] + uo[1:]])
+        t = (orc.kminmer_count_refined if k == P.first_k + 1 else orc.kminmer_index)(allm, alloff, k, prev)
+        got = formats.sorted_abundance_records(orc.table_abundance_records(t))
+        assert np.array_equal(got, fx["abundance_sorted"]), (SEED, k)
+        if fx["min_sorted"] is not None:
+            assert np.array_equal(formats.sorted_vector_records(t["vecs"].astype("<u4").tobytes(), k), fx["min_sorted"]), (SEED, k)
+        flags = orc.small_contigs(um, uo, k, P.prev_k, prev) if k > 8 else np.zeros(len(uo) - 1, np.uint8)
+        mine = sorted((0, tuple(int(x) for x in um[int(uo[i]): int(uo[i + 1])])) for i in np.nonzero(flags)[0])
+        assert mine == mk.small_contig_records(fx["small_contigs"]), (SEED, k)
