@@ -1,6 +1,7 @@
 """The oracle against the reference's own code run NOW (oracle/_ref/refdrv, built from /root/reference by oracle/Makefile)
-on inputs drawn fresh for this run -- beyond the committed vectors of tests/golden/fn_golden.json.  Skipped where the
-reference build is absent.  The seed is printed on failure through the assertion message."""
+on generated inputs -- beyond the committed vectors of tests/golden/fn_golden.json.  Skipped where the reference build is
+absent.  MDBG_TEST_SEED=<n> draws different inputs (MDBG_TEST_SEED=time: from the clock); the seed is part of every
+assertion message.  Round 1 ran about a hundred seeds of every test here without a difference."""
 from __future__ import annotations
 
 import ctypes as C
@@ -16,7 +17,8 @@ from oracle import pyoracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDRV = os.path.join(ROOT, "oracle", "_ref", "refdrv")
 pytestmark = pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
-SEED = int(os.environ.get("MDBG_TEST_SEED", str(int(time.time()) % 1_000_000)))
+_seed = os.environ.get("MDBG_TEST_SEED", "20260927")
+SEED = int(time.time()) % 1_000_000 if _seed == "time" else int(_seed)
 
 
 def refdrv(args, lines):
