@@ -132,6 +132,23 @@ int main(int argc, char **argv) {
             if (rc2 != 0 || o2 != text) detected++;
         }
     }
+    // arbitrary bytes as a deflate stream / gzip header: any verdict, no crash, no read outside the buffer (address sanitizer)
+    {
+        size_t verdicts[3] = {0, 0, 0};
+        for (int t = 0; t < 4000; t++) {
+            std::vector<uint8_t> junk(rng() % 600);
+            for (auto &c : junk) c = (uint8_t)rng();
+            if (t % 3 == 0 && junk.size() > 4) { junk[0] = (uint8_t)(4 | (rng() & 1)); }          // a dynamic-block header more often
+            std::vector<uint8_t> o2;
+            size_t u2 = 0;
+            const int rc = inflate_pieces(junk, o2, rng, &u2);
+            verdicts[rc == 0 ? 0 : rc == -1 ? 1 : 2]++;
+            if (!junk.empty()) { junk[0] = 0x1f; if (junk.size() > 3) { junk[1] = 0x8b; junk[2] = 8; junk[3] &= 0x1f; } }
+            const size_t h = mdbg_host::gzip_header_size(junk.data(), junk.size());
+            if (h > junk.size()) { fprintf(stderr, "gzip_header_size beyond the buffer\n"); return 1; }
+        }
+        fprintf(stderr, "random bytes: %zu decoded, %zu rejected, %zu gave up\n", verdicts[0], verdicts[1], verdicts[2]);
+    }
     // crc32_fast (carry-less multiplication) against zlib: lengths around the 64-byte folds, odd alignments, a running CRC
     {
         std::vector<uint8_t> buf(1 << 20);
