@@ -73,3 +73,18 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "liboracle" not in text and "mdbg_oracle.h" not in text, f
+
+
+def test_c_example_compiles_links_and_fails_loudly_without_gpu(lib_path, tmp_path):
+    """examples/first_pass.c is strict C99: the header is a C header, the library links from C, and on a box without a
+    gfx950 device the program stops at mdbg_create with the library's message instead of computing anything."""
+    exe = str(tmp_path / "first_pass")
+    libdir = os.path.dirname(lib_path)
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "first_pass.c"), "-o", exe, "-L" + libdir, "-lmdbg_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU tests run the path")
+    r = subprocess.run([exe], input="ACGTACGTACGTACGTACGT\n", capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no CPU path" in r.stderr
