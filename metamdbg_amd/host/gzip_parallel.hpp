@@ -154,7 +154,9 @@ private:
     static bool plausible_text(const uint16_t *s, size_t n) {
         for (size_t i = 0; i < n; i++) {
             const uint16_t v = s[i];
-            if (v < 256 && !((v >= 32 && v < 127) || v == '\n' || v == '\r' || v == '\t')) return false;
+            // read files are text: no control characters (bytes >= 128 may be UTF-8 in a header line).  Bytes decoded from a
+            // wrong position are uniformly random: a few hundred of them already contain one.
+            if (v < 32 ? !(v == '\n' || v == '\r' || v == '\t') : v == 127) return false;
         }
         return true;
     }
