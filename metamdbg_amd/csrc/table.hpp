@@ -238,9 +238,10 @@ int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uin
         int o = tab.overflowed(ctx);
         if (o < 0) return o;
         if (!o) return MDBG_OK;
-        if (tab.cap >= most) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow at %llu slots", (unsigned long long)tab.cap);
-        want = tab.cap * 4;
-        if (want > most) want = most;
+        // At load 2/3 a linear-probing run can still exceed TABLE_MAX_PROBES (nearly all keys distinct: ONT, the edge index),
+        // so `most` is not an error yet: grow twice more (load <= 1/3, then <= 1/6) before giving up.
+        if (tab.cap >= 4 * most) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow at %llu slots", (unsigned long long)tab.cap);
+        want = tab.cap >= most ? tab.cap * 2 : (tab.cap * 4 > most ? most : tab.cap * 4);
     }
 }
 

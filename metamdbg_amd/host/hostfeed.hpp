@@ -394,7 +394,7 @@ private:
             for (size_t b = groups_[gi]; b < groups_[gi + 1]; b++) total += blocks_[b].isize;
             Text text;
             text.len = total;
-            text.buf.resize(total + 512);                  // the decoder wants 258 + 16 bytes of room in front of every symbol
+            text.buf.resize(total + 512);                  // the decoder wants Inflater::MIN_ROOM bytes of room in front of every symbol
             size_t o = 0;
             bool ok = true;
             for (size_t b = groups_[gi]; b < groups_[gi + 1] && ok; b++) {
@@ -599,6 +599,11 @@ private:
                 if (begin == end) continue;
                 const bool fastq = *begin == '@';
                 if (!fastq && *begin != '>') throw std::runtime_error("not FASTA/FASTQ: " + path);
+                if (fastq && !looks_four_line(begin, end)) {
+                    // multi-line FASTQ, which kseq accepts (Commons.hpp:82): the sequential kseq-style reader, as for gzip
+                    seq = read_gz_sequential(path, (int)f, seq);
+                    continue;
+                }
                 const char *p = begin;
                 while (p < end && !fileDone_[f].load()) {
                     const char *q = end;

@@ -6,7 +6,7 @@
 // loads, decodes through wide single-level-mostly tables (11 bits for literals/lengths, 8 for distances), emits up to
 // four literals per table look-up (a second table holds, for every 11-bit index, the run of literals it decodes to on
 // its own) and copies matches 8 bytes at a time.  Output is produced in caller-sized pieces: run()
-// stops in front of a symbol when fewer than 258+16 bytes of room are left, so a match is never split and the only
+// stops in front of a symbol when fewer than MIN_ROOM (288) elements of room are left, so a match is never split and the only
 // state carried between calls is the bit buffer, the current block's tables and the remainder of a stored block.
 // Back-references reach into the text already produced, which the caller keeps directly in front of the output
 // pointer (the last 32 KB suffice).
@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <initializer_list>
 
 namespace mdbg_host {
 
@@ -29,6 +30,11 @@ template <typename OutT>
 class InflaterT {
 public:
     enum Status { NEED_ROOM = 0, STREAM_END = 1, AT_STOP = 2, CORRUPT = -1 };
+    // Room (in elements) one trip of the fast loop may write: four literal runs of up to four literals each (16; every run is
+    // stored as four elements, the unused ones overwritten by what follows), then one maximal match (258) copied in 8-byte
+    // steps that may overshoot its end by 7 bytes: 16 + 258 + 7 = 281, rounded up.  Callers pass the exact end of their
+    // allocation as out_end, so this bound is what keeps the decoder inside it.
+    static constexpr ptrdiff_t MIN_ROOM = 288;
 
     // start decoding a raw deflate stream at `in`; [in, in_end) must stay readable
     void reset(const uint8_t *in, const uint8_t *in_end) {
@@ -53,7 +59,7 @@ public:
     // Decodes into [out, out_end).  `hist` is the number of bytes of earlier output that lie directly in front of `out`
     // (at least min(32768, everything produced so far)).  *produced = bytes written.  Returns STREAM_END after the
     // final block (in_pos() is then the first byte behind the stream), NEED_ROOM when the room is used up (call again
-    // with fresh room; up to 258+16 bytes of the old room may stay unused), CORRUPT on invalid data.
+    // with fresh room; up to MIN_ROOM elements of the old room may stay unused), CORRUPT on invalid data.
     Status run(OutT *out, OutT *out_end, size_t hist, size_t *produced) {
         OutT *const out0 = out;
         const OutT *const lowest = out - hist;
@@ -288,7 +294,8 @@ private:
             while (rep--) lens[n++] = (uint8_t)val;
         }
         if (lens[256] == 0) return false;                     // no end-of-block code
-        if (!build_table(lens, hlit, LIT_BITS, lit_, LIT_CAP, false, litlen_entry)) return false;
+        // incomplete only in the one shape zlib accepts too: a single 1-bit code (a block holding nothing but its end-of-block)
+        if (!build_table(lens, hlit, LIT_BITS, lit_, LIT_CAP, true, litlen_entry)) return false;
         if (!build_table(lens + hlit, hdist, DIST_BITS, dist_, DIST_CAP, true, dist_entry)) return false;
         build_literal_runs();
         return true;
@@ -303,8 +310,8 @@ private:
         int bitcnt = bitcnt_;
         int result = 0;
         const uint32_t *const lit = lit_, *const dist = dist_;
-        // fast loop: at least 16 readable input bytes and room for one maximal match plus the 8-byte copy overshoot
-        while (in_end_ - in >= 16 && out_end - out >= 258 + 16) {
+        // fast loop: at least 16 readable input bytes and MIN_ROOM elements of room (16 literals + one maximal match + copy overshoot)
+        while (in_end_ - in >= 16 && out_end - out >= MIN_ROOM) {
             // refill to >= 56 bits
             bitbuf |= load64(in) << bitcnt;
             in += (63 - bitcnt) >> 3;
@@ -405,7 +412,7 @@ private:
 
     int decode_block_careful(OutT *&out, OutT *out_end, const OutT *lowest) {
         for (;;) {
-            if (out_end - out < 258 + 16) {
+            if (out_end - out < MIN_ROOM) {
                 // out of room -- unless the input still allows the fast loop next time, which the caller decides
                 return 0;
             }

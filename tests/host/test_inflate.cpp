@@ -94,7 +94,153 @@ static int inflate_pieces(const std::vector<uint8_t> &comp, std::vector<uint8_t>
     return -3;
 }
 
+// ---- hand-built streams --------------------------------------------------------------------------------------------
+struct BitWriter {
+    std::vector<uint8_t> bytes;
+    uint64_t acc = 0;
+    int n = 0;
+    void bits(uint32_t v, int count) {                        // LSB first (header fields, extra bits)
+        acc |= (uint64_t)v << n; n += count;
+        while (n >= 8) { bytes.push_back((uint8_t)acc); acc >>= 8; n -= 8; }
+    }
+    void code(uint32_t c, int len) {                          // Huffman codes travel most significant bit first
+        for (int i = len - 1; i >= 0; i--) bits((c >> i) & 1u, 1);
+    }
+    void finish() { if (n) bits(0, 8 - n); }
+};
+
+// One dynamic block: literals A, C, G with 2-bit codes (00, 01, 10), end-of-block 110, length-258 code 111; a single
+// 1-bit distance code (symbol 5: distances 7-8, one extra bit).  Four such literals fit one 11-bit look-up four times
+// over, so one trip of the fast loop emits 16 literals AND a 258-byte match copied in 8-byte steps: the most a trip
+// can write.  An earlier room test (258 + 16) was 6 bytes short of that.
+static std::vector<uint8_t> literal_run_match_stream(std::vector<uint8_t> &text, int groups) {
+    BitWriter w;
+    w.bits(1, 1); w.bits(2, 2);                               // final block, dynamic
+    w.bits(286 - 257, 5); w.bits(30 - 1, 5); w.bits(18 - 4, 4);
+    // code-length alphabet: symbols 0..3 get 2-bit codes (00 01 10 11), sent in the order 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1
+    static const int order[18] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1};
+    for (int s : order) w.bits(s <= 3 ? 2 : 0, 3);
+    uint8_t lens[286 + 30] = {0};
+    lens['A'] = 2; lens['C'] = 2; lens['G'] = 2; lens[256] = 3; lens[285] = 3;
+    lens[286 + 5] = 1;
+    for (uint8_t l : lens) w.code(l, 2);
+    text.clear();
+    auto lit = [&](char c) { w.code(c == 'A' ? 0 : c == 'C' ? 1 : 2, 2); text.push_back((uint8_t)c); };
+    static const char acg[] = "ACG";
+    unsigned x = 7;
+    for (int i = 0; i < 320; i++) { x = x * 1103515245u + 12345u; lit(acg[(x >> 16) % 3]); }
+    for (int g = 0; g < groups; g++) {
+        for (int i = 0; i < 16; i++) { x = x * 1103515245u + 12345u; lit(acg[(x >> 16) % 3]); }
+        w.code(7, 3);                                         // length 258 (symbol 285, no extra bits)
+        w.code(0, 1); w.bits(1, 1);                           // distance symbol 5, extra bit 1: distance 8
+        for (int i = 0; i < 258; i++) text.push_back(text[text.size() - 8]);
+    }
+    w.code(6, 3);                                             // end of block
+    w.finish();
+    for (int i = 0; i < 32; i++) w.bytes.push_back(0);        // readable input behind the stream (a gzip trailer in real life)
+    return w.bytes;
+}
+
+// every room size against a buffer whose end is guarded: the decoder must stay inside [out, out_end)
+static bool test_room_is_respected() {
+    std::vector<uint8_t> text;
+    const std::vector<uint8_t> comp = literal_run_match_stream(text, 12);
+    {   // the stream is valid deflate: zlib agrees
+        std::vector<uint8_t> ref(text.size() + 16);
+        z_stream zs{};
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(comp.data()); zs.avail_in = (uInt)comp.size();
+        zs.next_out = ref.data(); zs.avail_out = (uInt)ref.size();
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool ok = rc == Z_STREAM_END && zs.total_out == text.size() && memcmp(ref.data(), text.data(), text.size()) == 0;
+        inflateEnd(&zs);
+        if (!ok) { fprintf(stderr, "hand-built stream: zlib disagrees (rc %d)\n", rc); return false; }
+    }
+    const size_t GUARD = 64;
+    for (size_t room = (size_t)Inflater::MIN_ROOM; room < 1400; room++) {
+        Inflater inf;
+        inf.reset(comp.data(), comp.data() + comp.size());
+        std::vector<uint8_t> out;
+        for (int piece = 0; piece < 100000; piece++) {
+            const size_t hist = std::min<size_t>(out.size(), 32768);
+            // exact-size allocation + guard bytes behind out_end
+            uint8_t *buf = (uint8_t *)malloc(hist + room + GUARD);
+            if (hist) memcpy(buf, out.data() + out.size() - hist, hist);
+            memset(buf + hist + room, 0xA5, GUARD);
+            size_t produced = 0;
+            const Inflater::Status st = inf.run(buf + hist, buf + hist + room, hist, &produced);
+            bool guard_ok = true;
+            for (size_t i = 0; i < GUARD; i++) guard_ok &= buf[hist + room + i] == 0xA5;
+            if (!guard_ok || produced > room) {
+                fprintf(stderr, "room %zu: the decoder wrote behind out_end (produced %zu)\n", room, produced);
+                free(buf);
+                return false;
+            }
+            out.insert(out.end(), buf + hist, buf + hist + produced);
+            free(buf);
+            if (st == Inflater::CORRUPT) { fprintf(stderr, "room %zu: hand-built stream rejected\n", room); return false; }
+            if (st == Inflater::STREAM_END) break;
+        }
+        if (out != text) { fprintf(stderr, "room %zu: wrong text (%zu bytes, want %zu)\n", room, out.size(), text.size()); return false; }
+    }
+    // the same trip in the 16-bit symbol decoder (gzip_parallel.hpp): elements, not bytes
+    for (size_t room = (size_t)mdbg_host::InflaterT<uint16_t>::MIN_ROOM; room < 700; room++) {
+        mdbg_host::InflaterT<uint16_t> inf;
+        inf.reset(comp.data(), comp.data() + comp.size());
+        std::vector<uint16_t> out;
+        for (int piece = 0; piece < 100000; piece++) {
+            const size_t hist = std::min<size_t>(out.size(), 32768);
+            uint16_t *buf = (uint16_t *)malloc((hist + room + GUARD) * 2);
+            if (hist) memcpy(buf, out.data() + out.size() - hist, hist * 2);
+            for (size_t i = 0; i < GUARD; i++) buf[hist + room + i] = 0xA5A5;
+            size_t produced = 0;
+            const auto st = inf.run(buf + hist, buf + hist + room, hist, &produced);
+            bool guard_ok = true;
+            for (size_t i = 0; i < GUARD; i++) guard_ok &= buf[hist + room + i] == 0xA5A5;
+            if (!guard_ok || produced > room) { fprintf(stderr, "room %zu (u16): the decoder wrote behind out_end\n", room); free(buf); return false; }
+            out.insert(out.end(), buf + hist, buf + hist + produced);
+            free(buf);
+            if (st == mdbg_host::InflaterT<uint16_t>::CORRUPT) { fprintf(stderr, "room %zu (u16): rejected\n", room); return false; }
+            if (st == mdbg_host::InflaterT<uint16_t>::STREAM_END) break;
+        }
+        if (out.size() != text.size()) { fprintf(stderr, "room %zu (u16): wrong length\n", room); return false; }
+        for (size_t i = 0; i < out.size(); i++) if (out[i] != text[i]) { fprintf(stderr, "room %zu (u16): wrong symbol\n", room); return false; }
+    }
+    // a dynamic block whose literal/length set is the single 1-bit end-of-block code (zlib accepts it): empty output
+    {
+        BitWriter w;
+        w.bits(1, 1); w.bits(2, 2);
+        w.bits(0, 5); w.bits(0, 5); w.bits(18 - 4, 4);         // 257 literal/length codes, 1 distance code
+        static const int order[18] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1};
+        for (int s : order) w.bits((s == 0 || s == 1 || s == 18) ? (s == 18 ? 1 : 2) : 0, 3);   // 18: code 0, 0: code 10, 1: code 11
+        w.code(0, 1); w.bits(127, 7);                          // 138 zeros
+        w.code(0, 1); w.bits(118 - 11, 7);                     // 118 zeros: symbols 0..255
+        w.code(3, 2);                                          // symbol 256: length 1
+        w.code(2, 2);                                          // the distance code: unused
+        w.code(0, 1);                                          // end of block
+        w.finish();
+        for (int i = 0; i < 32; i++) w.bytes.push_back(0);
+        std::vector<uint8_t> ref(16);
+        z_stream zs{};
+        inflateInit2(&zs, -15);
+        zs.next_in = w.bytes.data(); zs.avail_in = (uInt)w.bytes.size();
+        zs.next_out = ref.data(); zs.avail_out = (uInt)ref.size();
+        const int rc = inflate(&zs, Z_FINISH);
+        const size_t zout = zs.total_out;
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zout != 0) { fprintf(stderr, "end-of-block-only stream: zlib says %d\n", rc); return false; }
+        Inflater inf;
+        inf.reset(w.bytes.data(), w.bytes.data() + w.bytes.size());
+        std::vector<uint8_t> buf(4096);
+        size_t produced = 1;
+        const Inflater::Status st = inf.run(buf.data(), buf.data() + buf.size(), 0, &produced);
+        if (st != Inflater::STREAM_END || produced != 0) { fprintf(stderr, "end-of-block-only block: status %d\n", (int)st); return false; }
+    }
+    return true;
+}
+
 int main(int argc, char **argv) {
+    if (!test_room_is_respected()) return 1;
     const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const int rounds = argc > 2 ? atoi(argv[2]) : 40;
     std::mt19937_64 rng(seed);

@@ -120,6 +120,11 @@ def files(tmp_path_factory):
             for o in range(0, n, 70):
                 f.write(q_[o:o + 70] + b"\n")
     out["gz_multiline_fastq"] = p
+    # the same records uncompressed: kseq accepts multi-line FASTQ (Commons.hpp:82), so must the memory-mapped path
+    p = str(d / "m.fastq")
+    with gzip.open(out["gz_multiline_fastq"], "rb") as f, open(p, "wb") as g:
+        g.write(f.read())
+    out["multiline_fastq"] = p
     # BGZF (samtools fastq / bam2fastq / bgzip output): FASTQ, small blocks so that records straddle many of them
     recs = bytearray()
     for i in range(500):
@@ -144,12 +149,12 @@ def files(tmp_path_factory):
 @pytest.mark.parametrize("chunk", [10000, 50000, 1 << 22])
 @pytest.mark.parametrize("threads", [1, 4])
 def test_parallel_reader_matches_sequential(exe, files, chunk, threads):
-    for key in ("single", "wrapped", "fastq", "gz", "gz_fastq", "gz_wrapped", "gz_multiline_fastq", "bgzf_fastq", "bgzf_fastq_64k",
-                "bgzf_then_gzip"):
+    for key in ("single", "wrapped", "fastq", "gz", "gz_fastq", "gz_wrapped", "gz_multiline_fastq", "multiline_fastq", "bgzf_fastq",
+                "bgzf_fastq_64k", "bgzf_then_gzip"):
         r = subprocess.run([exe, str(chunk), str(threads), "0", files[key]], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (key, r.stderr)
     r = subprocess.run([exe, str(chunk), str(threads), "0", files["single"], files["gz"], files["fastq"], files["gz_fastq"],
-                        files["wrapped"], files["gz_multiline_fastq"], files["bgzf_fastq"], files["gz_wrapped"]],
+                        files["wrapped"], files["gz_multiline_fastq"], files["bgzf_fastq"], files["multiline_fastq"], files["gz_wrapped"]],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
 
