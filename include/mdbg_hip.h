@@ -63,24 +63,30 @@ int  mdbg_timing_get(mdbg_ctx *ctx, const char *kernel, double *ms_total, uint64
  * hands a batch of parsed reads (ASCII, concatenated; read r = bases[offsets[r] .. offsets[r+1]))
  * and optional phred+33 qualities with the same offsets (NULL for FASTA).  The batch is packed
  * to 2 bits/base (code (c>>1)&3, utils/kmer/Kmer.hpp:462) on the device.  Characters with
- * bit 3 set (N, n) are kept in a side bitmask.  HPC in the reference compares raw characters
- * (Commons.hpp:4177-4178); here it compares (code, invalid) so e.g. "aA" IS one run -- inputs
- * are expected to be upper-case ACGTN (stated in DESIGN.md). */
+ * bit 3 set (N, n) are kept in a side bitmask, and so is every place where two neighbouring characters
+ * differ although their codes agree ("aA", IUPAC letters): the reference's homopolymer compression compares
+ * raw characters (Commons.hpp:4177-4178), and so does this path -- any byte string gives the reference's
+ * minimizers.  Batches of plain upper-case ACGT carry neither mask and take the fast kernel variant. */
 int  mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, const uint64_t *offsets,
                            uint32_t n_reads, mdbg_reads **out);
 /* Already packed on the host: words[] holds 32 bases per u64 (base i of a word at bits [2i,2i+2)),
- * read r occupies words[word_offsets[r] .. word_offsets[r+1]) and starts on an even word. */
+ * read r occupies words[word_offsets[r] .. word_offsets[r+1]) and starts on an even word.  The packed form
+ * cannot say more than the code: use it for reads made of A, C, G, T only (the host feed does). */
 int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
                             const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out);
 /* Phred+33 qualities (Read::_qual) for reads made by mdbg_reads_from_packed: read r = quals[offsets[r] .. offsets[r+1]),
  * offsets[r+1] - offsets[r] must equal its length.  Once per reads object. */
 int  mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *reads, const char *quals, const uint64_t *offsets);
 /* Seeded synthetic read set generated directly in HBM (bench/test harness; same generator as
- * metamdbg_amd/synth.py).  thresholds[s] = cumulative species weight as u64. */
+ * metamdbg_amd/synth.py).  thresholds[s] = cumulative species weight as u64.  Per read position one u64 draw e decides:
+ * e < ins_threshold an inserted base, then del_threshold a skipped genome base, then sub_threshold a substitution
+ * (HiFi 0.1 % substitutions; ONT R10 1 % + 0.5 % + 0.5 %).  window = genome bases set aside per read
+ * (>= read_len; ignored without indels). */
 int  mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,
                           uint64_t first_read, const uint64_t *species_len,
                           const uint64_t *species_threshold, uint32_t n_species,
-                          uint64_t sub_threshold, int with_quality, mdbg_reads **out);
+                          uint64_t sub_threshold, uint64_t ins_threshold, uint64_t del_threshold, uint32_t window,
+                          int with_quality, mdbg_reads **out);
 int  mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t *n_bases, uint64_t *n_words);
 /* Copy read `index` back as ASCII (buffer of at least its length; quals may be NULL). */
 int  mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length);

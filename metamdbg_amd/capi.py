@@ -47,7 +47,7 @@ SIGNATURES = {
     "mdbg_reads_from_packed": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_attach_qualities": (C.c_int, [_P, _P, C.c_char_p, _P]),
     "mdbg_reads_synthetic": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, C.c_uint32,
-                                       C.c_uint64, C.c_int, C.POINTER(_P)]),
+                                       C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_P)]),
     "mdbg_reads_info": (C.c_int, [_P, _u32p, _u64p, _u64p]),
     "mdbg_reads_get": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _u32p]),
     "mdbg_reads_export_ascii": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _u64p]),
@@ -180,7 +180,8 @@ class Context:
         thr = np.ascontiguousarray(spec.weight_thresholds(), dtype=np.uint64)
         h = C.c_void_p()
         self.check(lib().mdbg_reads_synthetic(self.h, spec.seed, n, spec.read_len, first_read, _ptr(slen), _ptr(thr),
-                                              len(slen), spec.sub_threshold(), int(spec.with_quality), C.byref(h)))
+                                              len(slen), spec.sub_threshold(), spec.ins_threshold(), spec.del_threshold(), spec.window(),
+                                              int(spec.with_quality), C.byref(h)))
         return Reads(self, h)
 
     # -- minimizer space ----------------------------------------------------------------------

@@ -10,6 +10,9 @@
 //   d_word_off   u64[n+1]       read r occupies words [off[r], off[r+1]); off[r] is even (16-byte aligned reads)
 //   d_len        u32[n]         original length in bases
 //   d_invalid    u32[n_words]   optional, bit i = base i of the word had bit 3 set (N/n); NULL when no read has any
+//   d_break      u32[n_words]   optional, bit i = base i differs as a CHARACTER from the base before it although (code, invalid)
+//                               are equal ("aA", "CR", ...): the reference's homopolymer compression compares raw characters
+//                               (Commons.hpp:4177-4178), so such a base starts a run; NULL when no read has any
 //   d_qual       u8[..]         optional phred+33 bytes, read r at [qual_off[r], qual_off[r+1])
 struct mdbg_reads {
     uint32_t n_reads = 0;
@@ -20,9 +23,11 @@ struct mdbg_reads {
     mdbg::DevBuf<uint64_t> d_word_off;
     mdbg::DevBuf<uint32_t> d_len;
     mdbg::DevBuf<uint32_t> d_invalid;
+    mdbg::DevBuf<uint32_t> d_break;
     mdbg::DevBuf<uint8_t> d_qual;
     mdbg::DevBuf<uint64_t> d_qual_off;
-    bool has_invalid = false;
+    bool has_invalid = false;   // d_invalid is present (some base is invalid, or d_break is present)
+    bool has_break = false;
     bool has_qual = false;
 };
 

@@ -15,22 +15,26 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 
     return z ^ (z >> 31);
 }
 
-// one wave per read, lanes stride over its words; each lane packs 32 ASCII bases into a u64
+// one wave per read, lanes stride over its words; each lane packs 32 ASCII bases into a u64.  Besides the 2-bit code and the
+// invalid bit of every character (utils/kmer/Kmer.hpp:462) a third bit records where two neighbouring characters differ
+// although code and invalid bit agree (mixed case, IUPAC letters): EncoderRLE compares characters (Commons.hpp:4177-4178).
 __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, const uint64_t *base_off,
                                                          const uint64_t *word_off, uint32_t n_reads,
-                                                         uint64_t *words, uint32_t *invalid, uint32_t *any_invalid) {
+                                                         uint64_t *words, uint32_t *invalid, uint32_t *brk, uint32_t *any_flags) {
     const unsigned lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    uint32_t seen = 0;
+    uint32_t seen = 0, seen_brk = 0;
     for (uint64_t r = wave; r < n_reads; r += nwaves) {
         const uint8_t *src = bases + base_off[r];
         const uint64_t L = base_off[r + 1] - base_off[r];
         const uint64_t w0 = word_off[r], nw = word_off[r + 1] - w0;
         for (uint64_t w = lane; w < nw; w += 64) {
             uint64_t x = 0;
-            uint32_t inv = 0;
+            uint32_t inv = 0, bk = 0;
             uint64_t b0 = w * 32;
+            uint8_t prev = (b0 > 0 && b0 <= L) ? src[b0 - 1] : 0;
+            bool have_prev = b0 > 0 && b0 <= L;
 #pragma unroll 8
             for (int i = 0; i < 32; i++) {
                 uint64_t bi = b0 + i;
@@ -38,14 +42,19 @@ __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, c
                     uint8_t c = src[bi];
                     x |= (uint64_t)((c >> 1) & 3u) << (2 * i);    // utils/kmer/Kmer.hpp:462
                     inv |= (uint32_t)((c >> 3) & 1u) << i;
+                    if (have_prev && c != prev && ((c ^ prev) & 0x0Eu) == 0) bk |= 1u << i;   // same code and invalid bit, other character
+                    prev = c; have_prev = true;
                 }
             }
             words[w0 + w] = x;
             invalid[w0 + w] = inv;
+            brk[w0 + w] = bk;
             seen |= inv;
+            seen_brk |= bk;
         }
     }
-    if (seen) atomicOr(any_invalid, 1u);
+    if (seen) atomicOr(any_flags, 1u);
+    if (seen_brk) atomicOr(any_flags, 2u);
 }
 
 struct SynthArgs {
@@ -57,6 +66,8 @@ struct SynthArgs {
     const uint64_t *species_thr;      // n_species
     uint32_t n_species;
     uint64_t sub_thr;
+    uint64_t ins_thr, del_thr;        // indel model (synth.read_codes): both 0 for substitution-only reads
+    uint32_t window;                  // genome bases set aside per read (= read_len without indels)
     uint32_t words_per_read;
     uint64_t *words;
     uint8_t *qual;                    // nullptr or n_reads * read_len
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
     const uint64_t u_species = mix64(base + 4 * r), u_start = mix64(base + 4 * r + 1), u_strand = mix64(base + 4 * r + 2);
     uint32_t sp = 0;
     while (sp + 1 < a.n_species && !(u_species < a.species_thr[sp])) sp++;
-    const uint64_t span = a.species_len[sp] - L + 1;
+    const uint64_t span = a.species_len[sp] - a.window + 1;
     const uint64_t start = a.species_off[sp] + (u_start % span);
     const unsigned strand = (unsigned)(u_strand & 1ull);
     const uint64_t gkey = mix64(a.seed);
@@ -94,6 +105,87 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
         if (a.qual) a.qual[(uint64_t)rl * L + bi] = (uint8_t)(mix64(qkey + bi) % 30ull + 43ull);
     }
     a.words[gid] = x;
+}
+
+// Reads with insertions and deletions (synth.read_codes): read position i shows genome base k(i) = i - #insertions before i
+// + #deletions up to i of the read's window, so a word needs the event counts of everything before it.  One wave per
+// read: pass 1 counts (deletions - insertions) per 32-position word into LDS, a wave scan turns them into the offset at
+// the start of every word, pass 2 generates the words.
+constexpr int SYNTH_MAX_WORDS = 2048;            // read_len <= 65536 for reads with indels
+__global__ __launch_bounds__(256) void synth_indel_kernel(SynthArgs a) {
+    __shared__ int32_t lds_delta[4][SYNTH_MAX_WORDS];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    int32_t *delta = lds_delta[wv];
+    const uint32_t L = a.read_len, W = a.window;
+    const uint32_t nw = (L + 31u) / 32u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t base = mix64(a.seed ^ 0xA5A5A5A5A5A5A5A5ull);
+    const uint64_t gkey = mix64(a.seed);
+    const uint64_t t_id = a.ins_thr + a.del_thr;
+    const uint64_t t_all = (t_id + a.sub_thr < t_id) ? ~0ull : t_id + a.sub_thr;
+    for (uint64_t rl = wave; rl < a.n_reads; rl += nwaves) {
+        const uint64_t r = a.first_read + rl;
+        const uint64_t u_species = mix64(base + 4 * r), u_start = mix64(base + 4 * r + 1), u_strand = mix64(base + 4 * r + 2);
+        uint32_t sp = 0;
+        while (sp + 1 < a.n_species && !(u_species < a.species_thr[sp])) sp++;
+        const uint64_t span = a.species_len[sp] - W + 1;
+        const uint64_t start = a.species_off[sp] + (u_start % span);
+        const unsigned strand = (unsigned)(u_strand & 1ull);
+        const uint64_t ekey = mix64(mix64(a.seed ^ 0x5EED5EED5EED5EEDull) + r);
+        const uint64_t qkey = mix64(mix64(a.seed ^ 0x0123456789ABCDEFull) + r);
+        // pass 1: net offset change inside every word
+        for (uint32_t w = lane; w < nw; w += 64) {
+            int32_t d = 0;
+            for (uint32_t i = 0; i < 32; i++) {
+                const uint32_t bi = w * 32 + i;
+                if (bi >= L) break;
+                const uint64_t e = mix64(ekey + bi);
+                if (e < a.ins_thr) d--; else if (e < t_id) d++;
+            }
+            delta[w] = d;
+        }
+        wave_lds_sync();
+        // exclusive scan over the words (nw <= 2048: each lane sums a contiguous run, then a wave scan of the run totals)
+        const uint32_t per = (nw + 63u) / 64u;
+        int32_t run = 0;
+        for (uint32_t j = 0; j < per; j++) { const uint32_t w = lane * per + j; if (w < nw) run += delta[w]; }
+        int32_t incl = run;
+        for (int dlt = 1; dlt < 64; dlt <<= 1) { int32_t t = __shfl_up(incl, dlt, 64); if (lane >= (unsigned)dlt) incl += t; }
+        int32_t acc = incl - run;
+        wave_lds_sync();
+        for (uint32_t j = 0; j < per; j++) { const uint32_t w = lane * per + j; if (w < nw) { int32_t d = delta[w]; delta[w] = acc; acc += d; } }
+        wave_lds_sync();
+        // pass 2
+        for (uint32_t w = lane; w < a.words_per_read; w += 64) {
+            uint64_t x = 0;
+            if (w < nw) {
+                int64_t off = delta[w];           // (#deletions - #insertions) before position 32 w
+                for (uint32_t i = 0; i < 32; i++) {
+                    const uint32_t bi = w * 32 + i;
+                    if (bi >= L) break;
+                    const uint64_t e = mix64(ekey + bi);
+                    unsigned code;
+                    if (e < a.ins_thr) {
+                        code = (unsigned)(mix64(e ^ 0x1B5E47EDull) >> 62);
+                        off--;                    // this position consumed no genome base
+                    } else {
+                        if (e < t_id) off++;
+                        int64_t k = (int64_t)bi + off;
+                        if (k > (int64_t)W - 1) k = (int64_t)W - 1;
+                        const uint64_t gpos = strand ? (start + (W - 1) - (uint64_t)k) : (start + (uint64_t)k);
+                        code = (unsigned)(mix64(gkey + gpos) >> 62);
+                        if (strand) code ^= 2u;
+                        if (e >= t_id && e < t_all) code = (code + 1u + (unsigned)(mix64(e) % 3ull)) & 3u;
+                    }
+                    x |= (uint64_t)code << (2 * i);
+                    if (a.qual) a.qual[rl * L + bi] = (uint8_t)(mix64(qkey + bi) % 30ull + 43ull);
+                }
+            }
+            a.words[rl * a.words_per_read + w] = x;
+        }
+        wave_lds_sync();
+    }
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
@@ -135,7 +227,7 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
     DevBuf<uint8_t> d_ascii;
     DevBuf<uint64_t> d_boff;
     DevBuf<uint32_t> d_any;
-    if ((rc = r->d_words.alloc(ctx, r->n_words)) || (rc = r->d_invalid.alloc(ctx, r->n_words)) ||
+    if ((rc = r->d_words.alloc(ctx, r->n_words)) || (rc = r->d_invalid.alloc(ctx, r->n_words)) || (rc = r->d_break.alloc(ctx, r->n_words)) ||
         (rc = r->d_word_off.alloc(ctx, (size_t)n_reads + 1)) || (rc = r->d_len.alloc(ctx, n_reads)) ||
         (rc = d_ascii.alloc(ctx, nb)) || (rc = d_boff.alloc(ctx, (size_t)n_reads + 1)) || (rc = d_any.alloc(ctx, 1)))
         return fail(rc);
@@ -152,7 +244,7 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
         unsigned blocks = grid_for((uint64_t)n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
         LaunchTimer timer(ctx, "pack_ascii");
         hipLaunchKernelGGL(pack_ascii_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_ascii.p, d_boff.p,
-                           r->d_word_off.p, n_reads, r->d_words.p, r->d_invalid.p, d_any.p);
+                           r->d_word_off.p, n_reads, r->d_words.p, r->d_invalid.p, r->d_break.p, d_any.p);
     }
     uint32_t any = 0;
     CK(hipMemcpyAsync(&any, d_any.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -164,8 +256,10 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
     }
     CK(hipStreamSynchronize(ctx->stream));
 #undef CK
-    r->has_invalid = any != 0;
+    r->has_break = (any & 2u) != 0;
+    r->has_invalid = any != 0;            // the scan's side-mask variant reads d_invalid whenever either mask matters
     if (!r->has_invalid) r->d_invalid.release();
+    if (!r->has_break) r->d_break.release();
     *out = r;
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
@@ -231,11 +325,18 @@ extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const c
 extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_reads, uint32_t read_len,
                                     uint64_t first_read, const uint64_t *species_len,
                                     const uint64_t *species_threshold, uint32_t n_species,
-                                    uint64_t sub_threshold, int with_quality, mdbg_reads **out) try {
+                                    uint64_t sub_threshold, uint64_t ins_threshold, uint64_t del_threshold, uint32_t window,
+                                    int with_quality, mdbg_reads **out) try {
     if (!ctx || !out || !species_len || !species_threshold || !n_species || !read_len)
         return set_error(ctx, MDBG_EINVAL, "mdbg_reads_synthetic: bad argument");
+    const bool indels = ins_threshold != 0 || del_threshold != 0;
+    if (!indels) window = read_len;
+    if (window < read_len) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_synthetic: window %u shorter than a read", window);
+    if (indels && (read_len + 31u) / 32u > (uint32_t)SYNTH_MAX_WORDS)
+        return set_error(ctx, MDBG_ERANGE, "mdbg_reads_synthetic: reads with indels are limited to %d bases", SYNTH_MAX_WORDS * 32);
+    if (ins_threshold > (1ull << 62) || del_threshold > (1ull << 62)) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_synthetic: indel rate above 1/4");
     for (uint32_t s = 0; s < n_species; s++)
-        if (species_len[s] < read_len) return set_error(ctx, MDBG_EINVAL, "species %u shorter than a read", s);
+        if (species_len[s] < window) return set_error(ctx, MDBG_EINVAL, "species %u shorter than a read's window", s);
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mdbg_reads *r = new mdbg_reads();
     auto fail = [&](int rc) { delete r; return rc; };
@@ -261,11 +362,12 @@ extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_rea
     CK(hipMemcpyAsync(d_slen.p, species_len, (size_t)n_species * 8, hipMemcpyHostToDevice, ctx->stream));
     CK(hipMemcpyAsync(d_soff.p, soff.data(), soff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     CK(hipMemcpyAsync(d_sthr.p, species_threshold, (size_t)n_species * 8, hipMemcpyHostToDevice, ctx->stream));
-    SynthArgs a{seed, n_reads, read_len, first_read, d_slen.p, d_soff.p, d_sthr.p, n_species, sub_threshold, wpr,
-                r->d_words.p, with_quality ? r->d_qual.p : nullptr};
+    SynthArgs a{seed, n_reads, read_len, first_read, d_slen.p, d_soff.p, d_sthr.p, n_species, sub_threshold, ins_threshold,
+                del_threshold, window, wpr, r->d_words.p, with_quality ? r->d_qual.p : nullptr};
     uint64_t total = (uint64_t)n_reads * wpr;
     if (total) {
-        hipLaunchKernelGGL(synth_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, a);
+        if (indels) hipLaunchKernelGGL(synth_indel_kernel, dim3(grid_for((uint64_t)n_reads * 64, 256, (unsigned)ctx->n_cu * 16u)), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(synth_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, r->d_len.p, (uint64_t)n_reads, read_len);
     }
     hipLaunchKernelGGL(iota_scaled_u64_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream,

@@ -49,6 +49,7 @@ struct ScanArgs {
     const uint64_t *word_off;
     const uint32_t *len;
     const uint32_t *invalid;      // per word mask (HAS_N)
+    const uint32_t *brk;          // per word mask of character changes the 2-bit codes do not show (HAS_N; may be null)
     const uint8_t *qual;          // phred+33 bytes (inline min-quality in the overflow re-run)
     const uint64_t *qual_off;
     uint32_t n_reads;
@@ -534,6 +535,9 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
                     uint32_t pi = (uint32_t)__shfl_up(iv >> 31, 1, 64);
                     if (lane == 0) pi = prev_inv;
                     d |= spread_bits(iv ^ ((iv << 1) | pi));
+                    // ... and so does any other change of character ("aA", IUPAC letters sharing a code): HPC compares
+                    // characters (Commons.hpp:4177-4178)
+                    if (a.brk) d |= spread_bits((wi < nwords) ? a.brk[w_base + wi] : 0u);
                     prev_inv = (uint32_t)__shfl(iv >> 31, 63, 64);
                     if (wi == 0) d |= 1ull;
                     d &= vspread;
@@ -952,6 +956,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     ScanArgs a{};
     a.words = reads->d_words.p; a.word_off = reads->d_word_off.p; a.len = reads->d_len.p;
     a.invalid = has_n ? reads->d_invalid.p : nullptr;
+    a.brk = reads->has_break ? reads->d_break.p : nullptr;
     a.qual = has_q ? reads->d_qual.p : nullptr;
     a.qual_off = has_q ? reads->d_qual_off.p : nullptr;
     a.K = p->minimizer_size;

@@ -45,8 +45,9 @@ struct ReadBatch {
     bool hasQual = false;
     // packed == true: `bases` holds u64 words, 32 bases each (base i at bits [2i, 2i+2), code (c >> 1) & 3), read r in
     // words [wordOff[r], wordOff[r+1]) starting on an even word -- what mdbg_reads_from_packed takes.  Workers pack
-    // while they parse (a quarter of the PCIe bytes); a chunk holding a character with bit 3 set (N, n, ...) or too
-    // many tiny reads for the buffer is delivered as ASCII instead.
+    // while they parse (a quarter of the PCIe bytes); a chunk holding any character other than A, C, G, T (N, lower case,
+    // IUPAC letters: the device packer keeps their invalid bits and character changes) or too many tiny reads for the
+    // buffer is delivered as ASCII instead.
     bool packed = false;
     std::vector<uint64_t> wordOff{0};
     std::vector<uint32_t> lens;
@@ -72,7 +73,17 @@ inline uint64_t pack8_pext(uint64_t x) { return pack8_swar(x); }
 inline bool have_bmi2() { return false; }
 #endif
 
-// Appends bases to a stream of u64 words.  `invalid` collects bit 3 of every character seen.
+// Bytes of x that are not one of 'A' (0x41), 'C' (0x43), 'G' (0x47), 'T' (0x54) leave a non-zero byte: with b1, b2 the
+// code bits of a byte, the only valid spelling of that code is 0x40 | code << 1 | (T ? 0x10 : 0x01), T <=> b2 & ~b1.
+inline uint64_t not_acgt8(uint64_t x) {
+    const uint64_t t = (x >> 2) & ~(x >> 1) & 0x0101010101010101ull;
+    const uint64_t expect = 0x4040404040404040ull | (x & 0x0606060606060606ull) | (t << 4) | (t ^ 0x0101010101010101ull);
+    return x ^ expect;
+}
+
+// Appends bases to a stream of u64 words.  `invalid` becomes non-zero when a character other than A, C, G, T was seen:
+// the packed form alone would lose what the reference still sees (bit 3 = invalid k-mers, utils/kmer/Kmer.hpp:462; any
+// change of character = a new homopolymer run, Commons.hpp:4177-4178).
 struct PackCursor {
     uint64_t *words;      // destination
     size_t capWords;
@@ -92,7 +103,7 @@ struct PackCursor {
             if (w >= capWords) { overflow = true; return; }
             uint64_t x0, x1, x2, x3;
             memcpy(&x0, p, 8); memcpy(&x1, p + 8, 8); memcpy(&x2, p + 16, 8); memcpy(&x3, p + 24, 8);
-            invalid |= (x0 | x1 | x2 | x3);
+            invalid |= not_acgt8(x0) | not_acgt8(x1) | not_acgt8(x2) | not_acgt8(x3);
             const uint64_t a = PEXT ? pack8_pext(x0) : pack8_swar(x0), b = PEXT ? pack8_pext(x1) : pack8_swar(x1);
             const uint64_t c = PEXT ? pack8_pext(x2) : pack8_swar(x2), d = PEXT ? pack8_pext(x3) : pack8_swar(x3);
             words[w++] = a | (b << 16) | (c << 32) | (d << 48);
@@ -102,7 +113,7 @@ struct PackCursor {
     }
     void append(const char *p, size_t n) { if (have_bmi2()) append_impl<true>(p, n); else append_impl<false>(p, n); }
     void push1(unsigned char c) {
-        invalid |= c;
+        invalid |= (uint64_t)(c != 'A' && c != 'C' && c != 'G' && c != 'T');
         cur |= (uint64_t)((c >> 1) & 3u) << (2 * fill);
         if (++fill == 32) {
             if (w >= capWords) { overflow = true; fill = 0; cur = 0; return; }
@@ -114,7 +125,7 @@ struct PackCursor {
         if (fill) { if (w >= capWords) { overflow = true; } else words[w++] = cur; cur = 0; fill = 0; }
         if (w & 1) { if (w >= capWords) overflow = true; else words[w++] = 0; }
     }
-    bool bad() const { return overflow || (invalid & 0x0808080808080808ull) != 0; }
+    bool bad() const { return overflow || invalid != 0; }
 };
 
 inline bool zlib_inflate_requested() { static const bool v = getenv("MDBG_HOST_ZLIB_INFLATE") != nullptr; return v; }

@@ -37,6 +37,8 @@ class SynthSpec:
     read_len: int = 10_000
     seed: int = 42
     sub_rate: float = 0.001            # HiFi: substitution-only 0.1 %
+    ins_rate: float = 0.0              # ONT R10: 1 % substitutions + 0.5 % insertions + 0.5 % deletions
+    del_rate: float = 0.0
     species_len: list[int] = field(default_factory=lambda: [2_000_000])
     species_weight: list[float] = field(default_factory=lambda: [1.0])
     with_quality: bool = False         # FASTQ with phred uniform 10..39
@@ -56,6 +58,19 @@ class SynthSpec:
     def sub_threshold(self) -> int:
         return min(int(self.sub_rate * 2.0**64), 2**64 - 1)
 
+    def ins_threshold(self) -> int:
+        return min(int(self.ins_rate * 2.0**64), 2**62)
+
+    def del_threshold(self) -> int:
+        return min(int(self.del_rate * 2.0**64), 2**62)
+
+    def window(self) -> int:
+        """Genome bases set aside for one read: its length, plus room for what deletions consume (reads with
+        indels; several standard deviations above the expected number)."""
+        if not (self.ins_rate or self.del_rate):
+            return self.read_len
+        return self.read_len + int(3.0 * self.del_rate * self.read_len) + 64
+
 
 def hifi_spec(n_reads: int, seed: int = 42, read_len: int = 10_000, coverage: float = 50.0) -> SynthSpec:
     """~`coverage`x total, several species with spread abundances."""
@@ -65,6 +80,16 @@ def hifi_spec(n_reads: int, seed: int = 42, read_len: int = 10_000, coverage: fl
     lens = np.maximum((fr * total).astype(np.int64), 2 * read_len)
     return SynthSpec(n_reads=n_reads, read_len=read_len, seed=seed, sub_rate=0.001,
                      species_len=[int(x) for x in lens], species_weight=[float(x) for x in wt], name="hifi")
+
+
+def ont_spec(n_reads: int, seed: int = 42, read_len: int = 20_000, coverage: float = 50.0) -> SynthSpec:
+    """SURVEY 8(d) ONT R10: 20 kb reads, 2 % errors (1 % substitutions, 0.5 % insertions, 0.5 % deletions), FASTQ with
+    phred uniform 10..39, the same species structure as hifi_spec."""
+    h = hifi_spec(n_reads, seed=seed, read_len=read_len, coverage=coverage)
+    spec = SynthSpec(n_reads=n_reads, read_len=read_len, seed=seed, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
+                     species_len=h.species_len, species_weight=h.species_weight, with_quality=True, name="ont")
+    spec.species_len = [max(int(x), 2 * spec.window()) for x in spec.species_len]
+    return spec
 
 
 def genome_codes(spec: SynthSpec, start: int = 0, stop: int | None = None) -> np.ndarray:
@@ -89,32 +114,43 @@ def read_layout(spec: SynthSpec, r0: int, r1: int):
     sp = np.searchsorted(thr, u_species, side="right")  # first s with u < thr[s]
     sp = np.minimum(sp, len(thr) - 1)
     offs = spec.genome_offsets()
-    span = (np.asarray(spec.species_len, dtype=np.uint64)[sp] - np.uint64(spec.read_len) + np.uint64(1))
+    span = (np.asarray(spec.species_len, dtype=np.uint64)[sp] - np.uint64(spec.window()) + np.uint64(1))
     start = offs[sp] + (u_start % span)
     strand = (u_strand & np.uint64(1)).astype(np.uint8)
     return start, strand
 
 
 def read_codes(spec: SynthSpec, r0: int, r1: int, genome: np.ndarray | None = None) -> np.ndarray:
-    """2-bit codes, shape (r1-r0, read_len), of reads [r0, r1) including substitution errors."""
+    """2-bit codes, shape (r1-r0, read_len), of reads [r0, r1) including sequencing errors.
+
+    One draw e = mix(mix(seed3 + r) + i) per READ position i decides what happens there, in this order of the u64 range:
+    e < T_ins: an inserted base (consumes no genome); then T_del: one genome base is skipped before this one; then T_sub:
+    the genome base is replaced by one of the other three.  Position i of a read therefore shows genome base
+    k(i) = i - #insertions before i + #deletions up to and including i of its window (counted from the window's end and
+    complemented on the reverse strand).  Without indels k(i) = i and the window is the read."""
     if genome is None:
         genome = genome_codes(spec)
-    L = spec.read_len
+    L, W = spec.read_len, spec.window()
     start, strand = read_layout(spec, r0, r1)
-    i = np.arange(L, dtype=np.int64)[None, :]
-    s = start.astype(np.int64)[:, None]
-    fwd = genome[s + i]
-    rev = genome[s + (L - 1) - i] ^ np.uint8(2)
-    codes = np.where(strand[:, None] == 0, fwd, rev).astype(np.uint8)
-    # substitutions: e = mix(mix(seed3 + r) + i); substitute iff e < thr, by (1 + mix(e) % 3)
     r = np.arange(r0, r1, dtype=np.uint64)[:, None]
     with np.errstate(over="ignore"):
         rk = mix64(np.uint64(spec.seed) ^ np.uint64(0x5EED5EED5EED5EED)) + r
         e = mix64(mix64(rk) + np.arange(L, dtype=np.uint64)[None, :])
-    hit = e < np.uint64(spec.sub_threshold())
+    t_ins, t_del, t_sub = spec.ins_threshold(), spec.del_threshold(), spec.sub_threshold()
+    ins = e < np.uint64(t_ins)
+    dele = ~ins & (e < np.uint64(t_ins + t_del))
+    hit = ~ins & ~dele & (e < np.uint64(min(t_ins + t_del + t_sub, 2**64 - 1)))
+    k = np.arange(L, dtype=np.int64)[None, :] - (np.cumsum(ins, axis=1) - ins) + np.cumsum(dele, axis=1)
+    k = np.minimum(k, W - 1)                       # never reached: the window has room for > 3x the expected deletions
+    s = start.astype(np.int64)[:, None]
+    fwd = genome[s + k]
+    rev = genome[s + (W - 1) - k] ^ np.uint8(2)
+    codes = np.where(strand[:, None] == 0, fwd, rev).astype(np.uint8)
     if hit.any():
         delta = (mix64(e[hit]) % np.uint64(3)).astype(np.uint8) + np.uint8(1)
         codes[hit] = (codes[hit] + delta) & np.uint8(3)
+    if ins.any():
+        codes[ins] = (mix64(e[ins] ^ np.uint64(0x1B5E47ED)) >> np.uint64(62)).astype(np.uint8)
     return codes
 
 

@@ -119,7 +119,8 @@ def make_hifi(work: str) -> None:
 
 
 def make_ont(work: str) -> None:
-    spec = synth.SynthSpec(n_reads=100, read_len=20_000, seed=11, sub_rate=0.02,
+    # SURVEY 8(d) ONT R10 error model: 1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred 10..39
+    spec = synth.SynthSpec(n_reads=100, read_len=20_000, seed=11, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
                            species_len=[60_000, 50_000], species_weight=[0.7, 0.3], with_quality=True, name="ont")
     fastq = os.path.join(work, "ont_100.fastq")
     synth.write_fasta(fastq, spec)
@@ -128,8 +129,65 @@ def make_ont(work: str) -> None:
     tmp = run_ref_pipeline(os.path.join(work, "ont"), fastq, params, extra_rs=["--skip-correction"])
     store_outputs(tmp, os.path.join(HERE, "ont_100"), 4, dict(
         kind="ont", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+        ins_rate=spec.ins_rate, del_rate=spec.del_rate,
         species_len=spec.species_len, species_weight=spec.species_weight, with_quality=True,
         fasta_sha256=sha256(fastq), K=15, density=0.005, hpc=False, k=4, min_abundance=0, skip_correction=True))
+
+
+def make_rep(work: str) -> None:
+    """SURVEY 8(a) A8, determineRepetitiveMinimizers (readSelection/ReadSelection.hpp:497-625) where its answer is
+    unambiguous: enough distinct minimizers at the correction density for a cut of several (max(1, 1e-5 x distinct)), a small
+    high-coverage species that supplies the top counts, and a seed for which no count ties across the cut -- std::sort's
+    order among equal counts is the one thing the reference leaves open.  Only the manifest and the few u32 the reference
+    chose are kept; the reads are regenerated from the seed."""
+    from oracle import pyoracle as orc
+    import ctypes as C
+    L = orc.lib()
+    L.orc_minimizer_parse.restype = C.c_size_t
+
+    def census(spec):
+        # with the oracle's parser (pinned above against the reference's MinimizerParser)
+        genome = synth.genome_codes(spec)
+        allm = []
+        for r0 in range(0, spec.n_reads, 200):
+            asc = synth.codes_to_ascii(synth.read_codes(spec, r0, min(r0 + 200, spec.n_reads), genome))
+            for row in asc:
+                sq = row.tobytes()
+                n = len(sq)
+                om = (C.c_uint32 * n)(); op = (C.c_uint32 * n)(); od = (C.c_uint8 * n)()
+                k = L.orc_minimizer_parse(sq, C.c_size_t(n), 15, C.c_float(0.025), None, C.c_size_t(0), om, op, od)
+                allm.append(np.frombuffer(om, np.uint32, k).copy())
+        return np.unique(np.concatenate(allm), return_counts=True)
+
+    for seed in range(5, 40):          # the first seed whose counts do not tie across the cut
+        spec = synth.SynthSpec(n_reads=1600, read_len=20_000, seed=seed, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
+                               species_len=[12_000_000, 30_000], species_weight=[0.85, 0.15], with_quality=True, name="ont")
+        vals, counts = census(spec)
+        n_keep = max(int(np.float32(0.00001) * np.float32(len(vals))), 1)
+        order = np.sort(counts)[::-1]
+        if n_keep >= 3 and order[n_keep - 1] > order[n_keep]:
+            break
+    else:
+        raise RuntimeError("no seed without a tie across the cut")
+    fastq = os.path.join(work, "ont_rep.fastq")
+    synth.write_fasta(fastq, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                last_k=0, hpc=False, data_type=1, correction_density=0.025)
+    tmp = run_ref_pipeline(os.path.join(work, "ont_rep"), fastq, params, threads=8, extra_rs=["--skip-correction"], graph=False)
+    rep = np.fromfile(os.path.join(tmp, "repetitiveMinimizers.bin"), "<u4")
+    assert len(rep) == n_keep, (len(rep), n_keep)
+    assert set(rep.tolist()) == set(vals[counts >= order[n_keep - 1]].tolist())
+    dst = os.path.join(HERE, "ont_rep")
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(tmp, "repetitiveMinimizers.bin"), os.path.join(dst, "repetitiveMinimizers.bin"))
+    with open(os.path.join(dst, "manifest.json"), "w") as f:
+        json.dump(dict(kind="ont", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+                       ins_rate=spec.ins_rate, del_rate=spec.del_rate, species_len=spec.species_len,
+                       species_weight=spec.species_weight, with_quality=True, fasta_sha256=sha256(fastq), K=15,
+                       density=0.005, correction_density=0.025, hpc=False, skip_correction=True,
+                       n_distinct=int(len(vals)), n_keep=int(n_keep), cut_count=int(order[n_keep - 1]),
+                       next_count=int(order[n_keep]), read_data_init_sha256=sha256(os.path.join(tmp, "read_data_init.txt"))),
+                  f, indent=1, sort_keys=True)
 
 
 MULTIK_INPUTS = ("parameters.gz", "kminmerData_abundance_prev.txt", "unitigGraph_prev.nodes.bin",
@@ -180,8 +238,14 @@ def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, 
         json.dump(dict(manifest, first_k=first_k, last_k=last_k, per_k=per_k), f, indent=1, sort_keys=True)
 
 
-def make_multik(work: str) -> None:
+def make_multik(work: str, only_ont: bool = False) -> None:
     """hifi (HPC, 300 reads, three species) and ont (no HPC, 2 % errors, --skip-correction) through k = 4..11."""
+    if not only_ont:
+        _make_multik_hifi(work)
+    _make_multik_ont(work)
+
+
+def _make_multik_hifi(work: str) -> None:
     spec = synth.hifi_spec(300, seed=19, coverage=30.0)
     fasta = os.path.join(work, "hifi_multik.fasta")
     synth.write_fasta(fasta, spec)
@@ -191,7 +255,10 @@ def make_multik(work: str) -> None:
     run_ref_multik(tmp, params, 11, os.path.join(HERE, "hifi_multik"), dict(
         kind="hifi", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
         species_len=spec.species_len, species_weight=spec.species_weight, fasta_sha256=sha256(fasta), K=15, density=0.005, hpc=True))
-    spec = synth.SynthSpec(n_reads=150, read_len=20_000, seed=23, sub_rate=0.02,
+
+
+def _make_multik_ont(work: str) -> None:
+    spec = synth.SynthSpec(n_reads=150, read_len=20_000, seed=23, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
                            species_len=[50_000, 40_000], species_weight=[0.7, 0.3], with_quality=True, name="ont")
     fastq = os.path.join(work, "ont_multik.fastq")
     synth.write_fasta(fastq, spec)
@@ -200,6 +267,7 @@ def make_multik(work: str) -> None:
     tmp = run_ref_pipeline(os.path.join(work, "ont_multik"), fastq, params, extra_rs=["--skip-correction"], graph=False)
     run_ref_multik(tmp, params, 11, os.path.join(HERE, "ont_multik"), dict(
         kind="ont", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate,
+        ins_rate=spec.ins_rate, del_rate=spec.del_rate,
         species_len=spec.species_len, species_weight=spec.species_weight, with_quality=True, fasta_sha256=sha256(fastq),
         K=15, density=0.005, hpc=False, skip_correction=True))
 
@@ -355,6 +423,44 @@ def make_fn() -> None:
         for K, dens in ((15, 0.5), (16, 0.3), (11, 0.9)):
             out["scan_notrim"][f"K{K}_hpc{hpc}"] = dict(K=K, density=dens, hpc=hpc, inputs=treads,
                                                         outputs=refdrv_lines(["fn_scan_notrim", str(K), str(dens), str(hpc)], treads))
+    # EncoderRLE compares CHARACTERS (Commons.hpp:4177-4178) while k-mers see 2-bit codes (utils/kmer/Kmer.hpp:462): mixed
+    # case ("aA" is two runs), soft-masked blocks, IUPAC letters that share a code with a neighbour ("CR", "GK"), case flips
+    # inside homopolymers across the 32-base word and 2048-base tile borders of the device layout
+    rng3 = np.random.default_rng(20260927)
+
+    def rnd3(n):
+        return bytes(synth.CODE2ASCII[rng3.integers(0, 4, n)]).decode()
+
+    def soft_masked(n):
+        s = bytearray(rnd_hp3(n).encode())
+        for _ in range(max(1, n // 400)):
+            a = int(rng3.integers(0, len(s))); b = min(len(s), a + int(rng3.integers(1, 200)))
+            s[a:b] = bytes(s[a:b]).lower()
+        return s.decode()
+
+    def rnd_hp3(n):
+        base = synth.CODE2ASCII[rng3.integers(0, 4, n)]
+        return bytes(np.repeat(base, rng3.choice([1, 1, 1, 2, 3, 6], n))).decode()
+
+    def flip_each(n):        # every base upper or lower at random: many "aA" pairs
+        s = bytearray(rnd_hp3(n).encode())
+        m = rng3.integers(0, 2, len(s)).astype(bool)
+        return bytes(c | 0x20 if f else c for c, f in zip(s, m)).decode()
+
+    def iupac(n):            # letters without bit 3 that share a 2-bit code with a base: R,S (C), U,T (T), W,V (G), B,Q (C/A)
+        s = bytearray(rnd_hp3(n).encode())
+        for _ in range(max(2, n // 100)):
+            s[int(rng3.integers(0, len(s)))] = ord(rng3.choice(list("RSUWVBQacgt")))
+        return s.decode()
+
+    borders = "A" * 31 + "a" * 3 + rnd3(2048 - 34 - 5) + "G" * 5 + "g" * 4 + rnd3(300) + "TtTtTTtt" + rnd3(100)
+    cases = [soft_masked(3000), soft_masked(700), flip_each(2500), flip_each(40), iupac(2600), iupac(300), borders,
+             "aAaAaAaA" * 10 + rnd3(200), rnd3(500).lower(), "cCGg" + rnd3(30)]
+    out["scan_case"] = {}
+    for hpc in (0, 1):
+        for K, dens in ((15, 0.05), (16, 0.05), (11, 0.1)):
+            out["scan_case"][f"K{K}_hpc{hpc}"] = dict(K=K, density=dens, hpc=hpc, inputs=cases,
+                                                      outputs=refdrv_lines(["fn_scan", str(K), str(dens), str(hpc)], cases))
     with open(os.path.join(dst, "fn_golden.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
 
@@ -370,6 +476,14 @@ def main() -> None:
         if "--only-multik" in sys.argv:
             make_multik(work)
             return
+        if "--only-rep" in sys.argv:
+            make_rep(work)
+            return
+        if "--only-ont" in sys.argv:
+            make_ont(work)
+            make_multik(work, only_ont=True)
+            make_rep(work)
+            return
         if "--only-pipelines" in sys.argv:
             make_hifi(work)
             make_ont(work)
@@ -378,6 +492,7 @@ def main() -> None:
         make_hifi(work)
         make_ont(work)
         make_multik(work)
+        make_rep(work)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     print("golden fixtures written under", HERE)

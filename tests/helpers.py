@@ -19,6 +19,7 @@ def load_manifest(name: str) -> dict:
 
 def spec_from_manifest(m: dict) -> synth.SynthSpec:
     return synth.SynthSpec(n_reads=m["n_reads"], read_len=m["read_len"], seed=m["seed"], sub_rate=m["sub_rate"],
+                           ins_rate=m.get("ins_rate", 0.0), del_rate=m.get("del_rate", 0.0),
                            species_len=m["species_len"], species_weight=m["species_weight"],
                            with_quality=m.get("with_quality", False), name=m["kind"])
 

@@ -64,6 +64,78 @@ def _check_scan_against_oracle(ctx, orc, seqs, quals, K, density, hpc, repetitiv
     return m, h
 
 
+@pytest.mark.parametrize("read_len", [20_000, 777, 65_536])
+def test_synthetic_generator_with_indels_matches_numpy(ctx, read_len):
+    """ONT R10 error model (1 % substitutions + 0.5 % insertions + 0.5 % deletions): the device generator's
+    per-word event counts and scan must land every read position on the genome base the numpy twin picks."""
+    spec = synth.SynthSpec(n_reads=70, read_len=read_len, seed=29, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
+                           species_len=[3 * read_len + 5000, 2 * read_len + 900], species_weight=[0.6, 0.4], with_quality=True, name="ont")
+    reads = ctx.reads_synthetic(spec, first_read=3, n_reads=60)
+    asc = synth.codes_to_ascii(synth.read_codes(spec, 3, 63))
+    q = synth.read_qualities(spec, 3, 63)
+    for r in (0, 1, 2, 31, 59):
+        b, qq = reads.get(r, with_quality=True)
+        assert b == asc[r].tobytes() and qq == q[r].tobytes(), r
+    # the model really shifts the reads against the genome
+    clean = synth.SynthSpec(**{**spec.__dict__, "sub_rate": 0.0, "ins_rate": 0.0, "del_rate": 0.0})
+    assert spec.window() > read_len and clean.window() == read_len
+    if read_len == 20_000:      # error rates: about 1 % + 0.5 % + 0.5 % of the positions draw an event
+        g = synth.genome_codes(spec)
+        e_ins = e_del = 0
+        codes = synth.read_codes(spec, 0, 20, g)
+        import numpy as _np
+        r = _np.arange(0, 20, dtype=_np.uint64)[:, None]
+        with _np.errstate(over="ignore"):
+            rk = synth.mix64(_np.uint64(spec.seed) ^ _np.uint64(0x5EED5EED5EED5EED)) + r
+            e = synth.mix64(synth.mix64(rk) + _np.arange(read_len, dtype=_np.uint64)[None, :])
+        f_ins = float((e < _np.uint64(spec.ins_threshold())).mean())
+        f_del = float(((e >= _np.uint64(spec.ins_threshold())) & (e < _np.uint64(spec.ins_threshold() + spec.del_threshold()))).mean())
+        assert 0.004 < f_ins < 0.006 and 0.004 < f_del < 0.006 and codes.shape == (20, read_len)
+
+
+def test_repetitive_minimizers_content(ctx, orc):
+    """SURVEY 8(a) A8, determineRepetitiveMinimizers (readSelection/ReadSelection.hpp:497-625): the device census' CONTENT.
+    (1) ont_rep: a read set for which the reference's answer is unambiguous (several minimizers to pick, no count tied
+    across the cut): the device must return exactly the reference's set.  (2) ont_100: the census recomputed with the oracle;
+    every value returned must have a count at or above the cut-off count, everything above it must be returned, and the set
+    has max(1, floor(1e-5 f x distinct)) members (ties AT the cut are the reference's std::sort order, unspecified)."""
+    import ctypes as C
+    m = H.load_manifest("ont_rep")
+    spec = H.spec_from_manifest(m)
+    reads = ctx.reads_synthetic(spec)
+    pre = ctx.scan(reads, K=m["K"], density=m["correction_density"], hpc=False, apply_read_filters=False)
+    rep_gpu = ctx.repetitive_minimizers(pre)
+    rep_ref = np.frombuffer(H.golden_bytes("ont_rep", "repetitiveMinimizers.bin"), "<u4")
+    assert len(rep_gpu) == m["n_keep"] >= 3 and len(set(rep_gpu.tolist())) == len(rep_gpu)
+    assert set(rep_gpu.tolist()) == set(rep_ref.tolist())
+    # the counts behind it, from the scan's own minimizer list (which other tests pin against the oracle)
+    vals, counts = np.unique(pre.to_host(full=False)["minimizers"], return_counts=True)
+    assert len(vals) == m["n_distinct"]
+    got = dict(zip(vals.tolist(), counts.tolist()))
+    assert min(got[int(v)] for v in rep_gpu) == m["cut_count"] and m["cut_count"] > m["next_count"]
+    pre.free(); reads.free()
+    # (2) oracle census, ties allowed
+    m = H.load_manifest("ont_100")
+    seqs, _ = H.regenerate_reads(m)
+    L = orc.lib()
+    L.orc_minimizer_parse.restype = C.c_size_t
+    allm = []
+    for sq in seqs:
+        n = len(sq)
+        om = (C.c_uint32 * n)(); op = (C.c_uint32 * n)(); od = (C.c_uint8 * n)()
+        k = L.orc_minimizer_parse(sq, C.c_size_t(n), 15, C.c_float(0.025), None, C.c_size_t(0), om, op, od)
+        allm.append(np.frombuffer(om, np.uint32, k).copy())
+    vals, counts = np.unique(np.concatenate(allm), return_counts=True)
+    n_keep = max(int(np.float32(0.00001) * np.float32(len(vals))), 1)
+    cut = np.sort(counts)[::-1][n_keep - 1]
+    reads = ctx.reads_from_ascii(seqs)
+    rep_gpu = ctx.repetitive_minimizers(ctx.scan(reads, K=15, density=0.025, hpc=False, apply_read_filters=False))
+    cnt = dict(zip(vals.tolist(), counts.tolist()))
+    assert len(rep_gpu) == n_keep and len(set(rep_gpu.tolist())) == n_keep
+    assert all(cnt[int(v)] >= cut for v in rep_gpu)
+    assert set(vals[counts > cut].tolist()) <= set(rep_gpu.tolist())
+
+
 @pytest.mark.parametrize("hpc", [True, False])
 @pytest.mark.parametrize("K,density", [(15, 0.005), (16, 0.02), (13, 0.05), (11, 0.01)])
 def test_scan_random_reads_vs_oracle(ctx, orc, hpc, K, density):
@@ -325,20 +397,37 @@ def test_scan_with_qualities_vs_oracle(ctx, orc, hpc):
 
 
 def test_scan_reads_with_n(ctx, orc):
+    """Reference outputs (refdrv fn_scan) for reads holding N / n, mixed case, soft-masked blocks and IUPAC letters: the
+    characters go to the device as they are (EncoderRLE compares characters, Commons.hpp:4177-4178)."""
     with open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")) as f:
-        g = json.load(f)["scan_n"]
-    for key, gg in g.items():
-        seqs = [s.upper().encode() for s in gg["inputs"]]
-        reads = ctx.reads_from_ascii(seqs)
-        h = ctx.scan(reads, K=gg["K"], density=gg["density"], hpc=bool(gg["hpc"]), apply_read_filters=False).to_host()
-        for i, out in enumerate(gg["outputs"]):
-            toks = out.split()
-            exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
-            a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
-            got = list(zip(h["minimizers"][a:b].tolist(), h["pos"][a:b].tolist(), h["dir"][a:b].tolist()))
-            if gg["inputs"][i] != gg["inputs"][i].upper():
-                continue        # lower-case input: HPC on raw characters differs from the packed form
-            assert got == exp, (key, i)
+        gold = json.load(f)
+    n_mixed = 0
+    for section in ("scan_n", "scan_case"):
+        for key, gg in gold[section].items():
+            seqs = [s.encode() for s in gg["inputs"]]
+            reads = ctx.reads_from_ascii(seqs)
+            h = ctx.scan(reads, K=gg["K"], density=gg["density"], hpc=bool(gg["hpc"]), apply_read_filters=False).to_host()
+            for i, out in enumerate(gg["outputs"]):
+                toks = out.split()
+                exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
+                a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
+                got = list(zip(h["minimizers"][a:b].tolist(), h["pos"][a:b].tolist(), h["dir"][a:b].tolist()))
+                assert got == exp, (section, key, i)
+                n_mixed += gg["inputs"][i] not in (gg["inputs"][i].upper(), gg["inputs"][i].lower())
+    assert n_mixed >= 40
+    # mixed case with the read filters on, against the oracle (qualities too: the coordinate map follows the runs)
+    rng0 = np.random.default_rng(11)
+    seqs, quals = [], []
+    for n in list(rng0.integers(20, 400, 12)) + list(rng0.integers(400, 9000, 12)):
+        s = bytearray(np.repeat(synth.CODE2ASCII[rng0.integers(0, 4, int(n))], rng0.choice([1, 1, 2, 5], int(n))).tobytes())
+        for _ in range(int(rng0.integers(1, 8))):
+            a = int(rng0.integers(0, len(s))); b = min(len(s), a + int(rng0.integers(1, 120)))
+            s[a:b] = bytes(s[a:b]).lower()
+        seqs.append(bytes(s))
+        quals.append(bytes((rng0.integers(0, 60, len(s)) + 33).astype(np.uint8)))
+    for hpc in (True, False):
+        _check_scan_against_oracle(ctx, orc, seqs, None, 15, 0.02, hpc)
+        _check_scan_against_oracle(ctx, orc, seqs, quals, 15, 0.02, hpc)
     # random reads with N against the oracle, filters on (N counts with its 2-bit code in the complexity score)
     rng = np.random.default_rng(5)
     seqs = []

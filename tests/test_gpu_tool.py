@@ -165,6 +165,34 @@ def test_tool_vs_reference_live_fastq_hpc(tmp_path):
     assert fbytes(t_gpu, "read_stats.txt") == fbytes(t_ref, "read_stats.txt")
 
 
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
+def test_tool_vs_reference_live_soft_masked(tmp_path):
+    """Soft-masked (mixed-case) FASTA, HPC on: the reference compresses runs of equal CHARACTERS (Commons.hpp:4177-4178),
+    so "aA" stays two bases; chunks holding anything but ACGT travel as text and are packed on the device with their
+    character changes.  Every product byte-equal to the reference's."""
+    rng = np.random.default_rng(44)
+    genome = np.repeat(synth.CODE2ASCII[rng.integers(0, 4, 40000)], rng.choice([1, 1, 2, 4], 40000))
+    mask = np.zeros(len(genome), bool)
+    for _ in range(300):
+        a = int(rng.integers(0, len(genome))); mask[a:a + int(rng.integers(1, 300))] = True
+    genome = np.where(mask, genome | 0x20, genome).astype(np.uint8)
+    fa = str(tmp_path / "masked.fasta")
+    with open(fa, "wb") as f:
+        for i in range(260):
+            a = int(rng.integers(0, len(genome) - 9000)); L = int(rng.integers(300, 9000))
+            f.write(b">m%d\n" % i + bytes(genome[a:a + L]) + b"\n")
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+    t_ref = make_tmp(tmp_path / "ref", P, [fa])
+    t_gpu = make_tmp(tmp_path / "gpu", P, [fa])
+    read_selection(REFDRV, t_ref)
+    read_selection(TOOL, t_gpu, extra=["--batch-bases", "150000", "--threads", "3"])
+    for name in ("read_data_init.txt", "read_stats.txt", "read_data_corrected.txt"):
+        assert fbytes(t_gpu, name) == fbytes(t_ref, name), name
+    run(REFDRV, "graph", t_ref, "--threads", "1", "--min-abundance", "0", "--firstpass")
+    run(TOOL, "graph", t_gpu, "--threads", "1", "--min-abundance", "0", "--firstpass")
+    assert_tables_equal(t_gpu, t_ref, 4)
+
+
 def test_tool_graph_next_k_vs_oracle(tmp_path):
     """k = firstK+1 and firstK+2 through the tool's file interface, inputs synthesised (the stages that
     produce them in the reference -- contig, toMinspace -- are out of scope), expected tables from the oracle."""

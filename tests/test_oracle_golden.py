@@ -67,8 +67,11 @@ def test_last_k(fn_golden):
         assert orc.lib().orc_compute_last_k(d, n50, fk, mk) == c["out"]
 
 
-def test_scan_with_invalid_characters(fn_golden):
-    for key, g in fn_golden["scan_n"].items():
+@pytest.mark.parametrize("section", ["scan_n", "scan_case"])
+def test_scan_with_invalid_characters(fn_golden, section):
+    """scan_n: N / n inside reads.  scan_case: mixed case, soft-masked blocks and IUPAC letters -- EncoderRLE compares
+    characters (Commons.hpp:4177-4178), the k-mer model sees 2-bit codes (utils/kmer/Kmer.hpp:462)."""
+    for key, g in fn_golden[section].items():
         for seq, out in zip(g["inputs"], g["outputs"]):
             toks = out.split()
             exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
@@ -205,6 +208,34 @@ def test_ont_100_end_to_end():
     assert len(rep) == n_keep
     top = sorted(counts.values(), reverse=True)[n_keep - 1]
     assert all(counts[int(r)] >= top for r in rep)
+
+
+def test_ont_rep_census():
+    """determineRepetitiveMinimizers where the reference's pick is unambiguous (tests/golden/ont_rep: four minimizers,
+    no count tied across the cut): the oracle's census must select exactly the reference's set."""
+    import ctypes as C
+    from metamdbg_amd import synth
+    m = H.load_manifest("ont_rep")
+    spec = H.spec_from_manifest(m)
+    L = orc.lib()
+    L.orc_minimizer_parse.restype = C.c_size_t
+    genome = synth.genome_codes(spec)
+    allm = []
+    for r0 in range(0, spec.n_reads, 200):
+        asc = synth.codes_to_ascii(synth.read_codes(spec, r0, min(r0 + 200, spec.n_reads), genome))
+        for row in asc:
+            sq = row.tobytes()
+            n = len(sq)
+            om = (C.c_uint32 * n)(); op = (C.c_uint32 * n)(); od = (C.c_uint8 * n)()
+            k = L.orc_minimizer_parse(sq, C.c_size_t(n), 15, C.c_float(m["correction_density"]), None, C.c_size_t(0), om, op, od)
+            allm.append(np.frombuffer(om, np.uint32, k).copy())
+    vals, counts = np.unique(np.concatenate(allm), return_counts=True)
+    n_keep = max(int(np.float32(0.00001) * np.float32(len(vals))), 1)
+    order = np.sort(counts)[::-1]
+    rep = np.frombuffer(H.golden_bytes("ont_rep", "repetitiveMinimizers.bin"), "<u4")
+    assert len(vals) == m["n_distinct"] and n_keep == m["n_keep"] == len(rep)
+    assert order[n_keep - 1] == m["cut_count"] > order[n_keep] == m["next_count"]
+    assert set(rep.tolist()) == set(vals[counts >= order[n_keep - 1]].tolist())
 
 
 @pytest.mark.parametrize("name", ["hifi_200", "ont_100"])
