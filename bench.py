@@ -3,17 +3,23 @@
 
 A step = one pass of the hot path over one batch of synthetic HiFi reads already resident in HBM
 (2-bit packed): reads -> minimizers (HPC, l=15, density 0.005) -> palindrome purge -> k-min-mer
-table at k=4 (count + rescue).  N=1 workload = BASELINE.json configs[1]: 1 M x 10 kb reads.
+table at k=4 (count + rescue).  N=1 workload = the headline of BASELINE.json's north_star: 10 M x 10 kb
+reads (100 Gbp, 25 GB packed) in one batch; N>1: 5 M reads per rank (configs[4]: 40 M reads over 8 ranks).
 Three batches are in flight per GPU (--in-flight): consecutive steps run on their own library contexts
-(own HIP stream, memory pool and host thread each), so the atomic-bound table kernels and the exchanges of
-one batch overlap the ALU-bound scan of another; every step is still a complete pass over its batch.
+(own HIP stream, memory pool and host thread each) over the one resident read set, so the atomic-bound table
+kernels and the exchanges of one batch overlap the ALU-bound scan of another; every step is still a complete
+pass over its batch.
 N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); only the
 k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
 all-to-alls over RCCL (metamdbg_amd/distributed.py, include/mdbg_hip.h mdbg_shard_*).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library's
-stream) and `cpu_baseline` (the reference's own code, oracle/_ref/refdrv, timed on this box's cores
-on a bounded sample of the same reads).
+stream), `cpu_baseline` (the reference's own code, oracle/_ref/refdrv, timed on this box's cores
+on a bounded sample of the same reads; `path_only` = up to the moment its tables are on disk) and, at N=1,
+`parity` (the HIP path's read_data_init bytes and k-min-mer table against the reference's files for that sample;
+a mismatch fails the run) and `legs`: `end_to_end` (the C++ tool against the reference from one FASTA file),
+`multik` (configs[2]: k = 4..11 over the resident batch, benchmark mode) and `ont` (configs[3] preset: 20 kb
+reads with qualities, no HPC, repetitive-minimizer filter from the 0.025 census).
 """
 from __future__ import annotations
 
@@ -41,60 +47,297 @@ K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (10 kb each)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (10 kb each); default 10 M at N=1, 5 M per rank at N>1")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--in-flight", type=int, default=3, help="batches processed concurrently per GPU (own context, stream and host thread each)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads in the CPU-baseline sample (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads in the CPU-baseline / parity sample (0 = skip)")
+    ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,ont ('all', 'none')")
+    ap.add_argument("--ont-reads", type=int, default=5_000_000, help="reads (20 kb, with qualities) of the ont leg")
+    a = ap.parse_args()
+    if a.reads <= 0:
+        a.reads = 10_000_000 if a.gpus <= 1 else 5_000_000
+    return a
 
 
-def cpu_baseline(ctx, reads, n_sample: int) -> dict | None:
-    """Time the REFERENCE's readSelection + graph --firstpass (oracle/_ref/refdrv) on the first
-    n_sample reads of the batch, all host cores."""
+REFDRV = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+TOOL = os.path.join(ROOT, "metamdbg_amd", "bin", "mdbg_tool")
+
+
+def _make_tmp(work: str, name: str, params, inputs: list) -> str:
+    """<work>/<name>/tmp laid out as AssemblyPipeline leaves it for the two child processes."""
+    tmp = os.path.join(work, name, "tmp")
+    for d in ("", "filter", "smallContigs", "checkpoints"):
+        os.makedirs(os.path.join(tmp, d), exist_ok=True)
+    params.save(os.path.join(tmp, "parameters.gz"))
+    with open(os.path.join(tmp, "input.txt"), "w") as f:
+        f.write("\n".join(inputs) + "\n")
+    return tmp
+
+
+def _run_two_commands(exe: str, tmp: str, threads: int, extra_rs=(), timeout: int = 600) -> dict:
+    """`readSelection` then `graph --firstpass` with the reference's argv (AssemblyPipeline.hpp:733-737, :770-783), timed.
+    `tables_s` = seconds into `graph` at which kminmerData_abundance_init.txt appears: the reference copies it right after
+    the tables are complete and before it goes on to build the graph (graph/CreateMdbg.cpp:515-553), so
+    read_selection_s + tables_s is the time of the path alone, measured on the reference's own code from outside."""
+    t0 = time.perf_counter()
+    subprocess.run([exe, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
+                    "--threads", str(threads), "--min-read-quality", "0.000000", *extra_rs], check=True, timeout=timeout,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t1 = time.perf_counter()
+    marker = os.path.join(tmp, "kminmerData_abundance_init.txt")
+    seen = [None]
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            if os.path.exists(marker):
+                seen[0] = time.perf_counter()
+                return
+            time.sleep(0.002)
+
+    th = threading.Thread(target=watch)
+    th.start()
+    try:
+        subprocess.run([exe, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], check=True,
+                       timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    finally:
+        t2 = time.perf_counter()
+        stop.set()
+        th.join()
+    return {"read_selection_s": t1 - t0, "graph_s": t2 - t1, "tables_s": (seen[0] - t1) if seen[0] else None}
+
+
+def _fbytes(tmp: str, name: str) -> bytes:
+    with open(os.path.join(tmp, name), "rb") as f:
+        return f.read()
+
+
+def _tables_equal(tmp_a: str, tmp_b: str, k: int) -> bool:
+    import numpy as np
     from metamdbg_amd import formats
-    refdrv = os.path.join(ROOT, "oracle", "_ref", "refdrv")
-    if n_sample <= 0 or not os.path.exists(refdrv):
-        return None
+    return bool(np.array_equal(formats.sorted_abundance_records(_fbytes(tmp_a, "kminmerData_abundance.txt")),
+                               formats.sorted_abundance_records(_fbytes(tmp_b, "kminmerData_abundance.txt"))) and
+                np.array_equal(formats.sorted_vector_records(_fbytes(tmp_a, "kminmerData_min.txt"), k),
+                               formats.sorted_vector_records(_fbytes(tmp_b, "kminmerData_min.txt"), k)))
+
+
+def sample_legs(ctx, reads, spec, first_read: int, n_sample: int, with_tool: bool) -> dict:
+    """cpu_baseline + parity (+ end_to_end) on the first n_sample reads of the resident batch.
+
+    The reads are written as FASTA; the REFERENCE's own code (oracle/_ref/refdrv) runs its two commands on the file with
+    the threads its README uses.  Its files are the expected values: the HIP path, run through the library on exactly those
+    reads as they sit in HBM, must give read_data_init.txt byte for byte and the k-min-mer table as a multiset of records and
+    vectors (the reference's own record order depends on its thread timing).  A mismatch raises."""
+    import numpy as np
+    from metamdbg_amd import formats
+    out: dict = {}
+    if n_sample <= 0 or not os.path.exists(REFDRV):
+        return out
     # the reference's thread scaling collapses past a few dozen threads (its graph command did not finish
     # in 60 s with 256 threads on a 0.2 Gbp sample, 0.8 s with 8): use what its README / test scripts use
     cores = min(os.cpu_count() or 1, 32)
     work = tempfile.mkdtemp(prefix="mdbg_cpu_")
     try:
         bases, offs = reads.export_ascii(0, n_sample)
+        nbases = int(offs[n_sample])
         fasta = os.path.join(work, "sample.fasta")
         with open(fasta, "wb") as f:
             for r in range(n_sample):
                 f.write(b">r%d\n" % r)
                 f.write(bases[int(offs[r]): int(offs[r + 1])].tobytes())
                 f.write(b"\n")
-        tmp = os.path.join(work, "tmp")
-        for d in ("", "filter", "smallContigs", "checkpoints"):
-            os.makedirs(os.path.join(tmp, d), exist_ok=True)
-        formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
-                           hpc=True, data_type=0).save(os.path.join(tmp, "parameters.gz"))
-        with open(os.path.join(tmp, "input.txt"), "w") as f:
-            f.write(fasta + "\n")
-        t0 = time.perf_counter()
-        subprocess.run([refdrv, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
-                        "--threads", str(cores), "--min-read-quality", "0.000000"], check=True, timeout=300,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        t1 = time.perf_counter()
-        subprocess.run([refdrv, "graph", tmp, "--threads", str(cores), "--min-abundance", "0", "--firstpass"], check=True, timeout=300,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        t2 = time.perf_counter()
-        nbases = int(offs[n_sample])
-        return {"value": nbases / 1e9 / (t2 - t0), "unit": "Gbp/s", "cores": cores, "kind": "reference",
-                "sample": f"first {n_sample} reads ({nbases / 1e9:.2f} Gbp) of the batch as FASTA on local disk: "
-                          f"readSelection {t1 - t0:.2f} s + graph --firstpass {t2 - t1:.2f} s "
-                          f"(the reference's graph command also builds the graph after the table), --threads {cores} "
-                          f"of {os.cpu_count()} hardware threads",
-                "read_selection_gbps": nbases / 1e9 / (t1 - t0)}
-    except Exception as exc:  # the baseline is reported, never required
-        return {"value": None, "unit": "Gbp/s", "cores": cores, "kind": "reference", "sample": f"failed: {exc}"}
+        del bases
+        P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
+                               hpc=True, data_type=0)
+        t_ref = _make_tmp(work, "ref", P, [fasta])
+        try:
+            tr = _run_two_commands(REFDRV, t_ref, cores)
+        except Exception as exc:  # the baseline is reported, never required
+            out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": cores, "kind": "reference", "sample": f"failed: {exc}"}
+            return out
+        whole = tr["read_selection_s"] + tr["graph_s"]
+        path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
+        out["cpu_baseline"] = {
+            "value": nbases / 1e9 / path, "unit": "Gbp/s", "cores": cores, "kind": "reference",
+            "sample": f"first {n_sample} reads ({nbases / 1e9:.2f} Gbp) of the batch as FASTA on local disk, --threads {cores} of "
+                      f"{os.cpu_count()} hardware threads; value = path only: readSelection {tr['read_selection_s']:.2f} s + "
+                      f"graph --firstpass until its tables are written "
+                      f"{(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.2f} s (the whole graph command, "
+                      f"which goes on to build the graph, takes {tr['graph_s']:.2f} s)",
+            "path_only": {"read_selection_s": tr["read_selection_s"], "tables_s": tr["tables_s"], "gbps": nbases / 1e9 / path},
+            "whole_commands": {"seconds": whole, "gbps": nbases / 1e9 / whole},
+            "read_selection_gbps": nbases / 1e9 / tr["read_selection_s"]}
+        # ---- parity: the library on the same reads as they sit in HBM
+        sub = ctx.reads_synthetic(spec, first_read=first_read, n_reads=n_sample)
+        mins = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        init_equal = formats.build_read_data_init(mins.to_host()) == _fbytes(t_ref, "read_data_init.txt")
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        hc = corr.to_host(full=False)
+        ref_m, ref_o = formats.parse_minimizer_reads(_fbytes(t_ref, "read_data_corrected.txt"))
+        # read_data_corrected.txt: the reference writes its records in thread order -> compare as multisets of reads
+        def read_multiset(m, o):
+            return sorted(m[int(o[i]): int(o[i + 1])].tobytes() for i in range(len(o) - 1))
+        corrected_equal = read_multiset(hc["minimizers"], hc["offsets"]) == read_multiset(ref_m, ref_o)
+        table = ctx.kminmer_count_first(corr, KMINMER, 0)
+        rec, vec = table.to_host()
+        table_equal = bool(
+            np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(_fbytes(t_ref, "kminmerData_abundance.txt"))) and
+            np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), KMINMER),
+                           formats.sorted_vector_records(_fbytes(t_ref, "kminmerData_min.txt"), KMINMER)))
+        out["parity"] = {"reads": n_sample, "bases": nbases, "minimizers": int(mins.info()["n_minimizers"]),
+                         "kminmer_records": int(len(rec)), "init_bytes_equal": bool(init_equal),
+                         "corrected_multiset_equal": bool(corrected_equal), "table_multiset_equal": table_equal,
+                         "against": "oracle/_ref/refdrv (the reference's own code) on the same reads, this run"}
+        for o in (table, corr, mins, sub):
+            o.free()
+        if not (init_equal and corrected_equal and table_equal):
+            raise SystemExit(f"bench.py: PARITY FAILURE against the reference: {out['parity']}")
+        # ---- end to end from the file: the C++ drop-in for the two child processes against the reference
+        if with_tool and os.path.exists(TOOL):
+            t_gpu = _make_tmp(work, "gpu", P, [fasta])
+            tg = _run_two_commands(TOOL, t_gpu, min(os.cpu_count() or 1, 16))
+            tool_s = tg["read_selection_s"] + tg["graph_s"]
+            e2e_init = _fbytes(t_gpu, "read_data_init.txt") == _fbytes(t_ref, "read_data_init.txt")
+            e2e_stats = _fbytes(t_gpu, "read_stats.txt") == _fbytes(t_ref, "read_stats.txt")
+            e2e_table = _tables_equal(t_gpu, t_ref, KMINMER)
+            out["end_to_end"] = {
+                "workload": f"{n_sample} reads ({nbases / 1e9:.2f} Gbp) from one FASTA file on local disk: readSelection + graph --firstpass, "
+                            "same argv, same files written",
+                "mdbg_tool_s": tool_s, "mdbg_tool_gbps": nbases / 1e9 / tool_s, "mdbg_tool_read_selection_s": tg["read_selection_s"],
+                "reference_path_only_s": path, "reference_whole_commands_s": whole,
+                "speedup_vs_reference_path_only": path / tool_s,
+                "init_bytes_equal": bool(e2e_init), "read_stats_equal": bool(e2e_stats), "table_multiset_equal": bool(e2e_table)}
+            if not (e2e_init and e2e_stats and e2e_table):
+                raise SystemExit(f"bench.py: PARITY FAILURE of mdbg_tool against the reference: {out['end_to_end']}")
+        return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def multik_leg(ctx, reads, n_bases: int, last_k: int = 11) -> dict:
+    """BASELINE.json configs[2]: the full multi-k loop k = 4 .. 11 over the resident batch, benchmark mode (SURVEY.md
+    8(d): reads only, previous table = the own k-1 output; the reference's loop pipeline/AssemblyPipeline.hpp:603-671
+    interleaves out-of-scope graph stages).  Timed once after one untimed pass."""
+    def one_pass():
+        ms = {}
+        t0 = time.perf_counter()
+        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        ms["scan_purge"] = (t1 - t0) * 1e3
+        n_min = mins.info()["n_minimizers"]
+        mins.free()
+        prev = ctx.kminmer_count_first(corr, 4, 0)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        ms["k4"] = (t2 - t1) * 1e3
+        records = {"4": prev.info()["n_records"]}
+        for k in range(5, last_k + 1):
+            tk = time.perf_counter()
+            nxt = ctx.kminmer_count_refined(corr, None, k, prev) if k == 5 else ctx.kminmer_index(corr, None, k, prev)
+            ctx.synchronize()
+            ms[f"k{k}"] = (time.perf_counter() - tk) * 1e3
+            records[str(k)] = nxt.info()["n_records"]
+            prev.free()
+            prev = nxt
+        prev.free(); corr.free()
+        total = time.perf_counter() - t0
+        return {"seconds": total, "gbps": n_bases / 1e9 / total, "ms": ms, "records": records, "minimizers": int(n_min)}
+    one_pass()
+    r = one_pass()
+    r["workload"] = (f"scan + purge + k-min-mer tables k = 4..{last_k} over the resident batch ({n_bases / 1e9:.0f} Gbp), one context, "
+                     "benchmark mode (reads only, previous table = own k-1 output)")
+    return r
+
+
+def ont_leg(ctx, n_reads: int, sample: int) -> dict:
+    """BASELINE.json configs[3] preset: 20 kb reads with qualities (1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred
+    10..39), no HPC, l = 15, density 0.005, repetitive-minimizer filter from the census of the first 1,000,000 reads at
+    density 0.025 (nanoMDBG parameters: pipeline/AssemblyPipeline.hpp:309-325, ReadSelection.hpp:497-561), --skip-correction
+    path: purge + k = 4 table.  configs[3] names 10 M reads; with qualities they take 250 GB, so the leg runs on the largest
+    power-of-ten-ish resident set that leaves room for the outputs."""
+    import numpy as np
+    from metamdbg_amd import formats, synth
+    spec = synth.ont_spec(n_reads, seed=43, read_len=20_000, coverage=50.0)
+    t0 = time.perf_counter()
+    reads = ctx.reads_synthetic(spec)
+    ctx.synchronize()
+    gen_s = time.perf_counter() - t0
+    n_bases = reads.info()["n_bases"]
+    n_census = min(n_reads, 1_000_001)
+    head = reads if n_census == n_reads else ctx.reads_synthetic(spec, first_read=0, n_reads=n_census)
+
+    def one_pass():
+        t0 = time.perf_counter()
+        pre = ctx.scan(head, K=K_MINIMIZER, density=0.025, hpc=False, apply_read_filters=False)
+        rep = ctx.repetitive_minimizers(pre)
+        pre.free()
+        t1 = time.perf_counter()
+        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        table = ctx.kminmer_count_first(corr, KMINMER, 0)
+        ctx.synchronize()
+        t3 = time.perf_counter()
+        r = {"seconds": t3 - t0, "gbps": n_bases / 1e9 / (t3 - t0), "census_ms": (t1 - t0) * 1e3, "scan_ms": (t2 - t1) * 1e3,
+             "purge_table_ms": (t3 - t2) * 1e3, "repetitive": int(len(rep)), "minimizers": int(mins.info()["n_minimizers"]),
+             "kminmer_records": int(table.info()["n_records"]), "solid": int(table.info()["n_solid"])}
+        for o in (table, corr, mins):
+            o.free()
+        return r
+    one_pass()
+    ctx.timing(True); ctx.timing_reset()
+    r = one_pass()
+    ctx.timing(False)
+    r["kernel_ms"] = {k: ctx.timing_get(k)[0] for k in ("scan", "quality_sum", "scan_compact", "purge_palindromes", "kminmer_insert",
+                                                      "kminmer_rescue", "kminmer_emit")}
+    r["workload"] = (f"{n_reads} synthetic ONT R10 reads x 20 kb with qualities ({n_bases / 1e9:.0f} Gbp; 1 % sub + 0.5 % ins + 0.5 % del), "
+                     "resident in HBM (2-bit bases + 1 byte per quality), no HPC, l=15, density 0.005, repetitive filter from the "
+                     f"0.025 census of the first {n_census} reads, purge + k=4 table (--skip-correction path)")
+    r["generate_s"] = gen_s
+    if head is not reads:
+        head.free()
+    reads.free()
+    # parity on a small sample against the reference's own run (qualities, mean read quality, repetitive filter pinned to
+    # the reference's pick: which of several equally frequent minimizers std::sort leaves first is not defined)
+    if sample > 0 and os.path.exists(REFDRV):
+        work = tempfile.mkdtemp(prefix="mdbg_ont_")
+        try:
+            sspec = synth.SynthSpec(**{**spec.__dict__, "n_reads": sample})
+            fq = os.path.join(work, "ont.fastq")
+            synth.write_fasta(fq, sspec)
+            P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
+                                   hpc=False, data_type=1, correction_density=0.025)
+            t_ref = _make_tmp(work, "ref", P, [fq])
+            cores = min(os.cpu_count() or 1, 32)
+            tr = _run_two_commands(REFDRV, t_ref, cores, extra_rs=["--skip-correction"])
+            rep_ref = np.frombuffer(_fbytes(t_ref, "repetitiveMinimizers.bin"), "<u4")
+            sub = ctx.reads_synthetic(sspec)
+            mins = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep_ref)
+            init_equal = formats.build_read_data_init(mins.to_host()) == _fbytes(t_ref, "read_data_init.txt")
+            st = formats.parse_read_stats(_fbytes(t_ref, "read_stats.txt"))
+            last_k = max(int(np.float32(st["n50"]) * np.float32(DENSITY) * np.float32(2)), 6)      # Commons::computeLastK (Commons.hpp:1726-1741)
+            corr = ctx.purge_palindromes(mins, 4, last_k)
+            rec, vec = ctx.kminmer_count_first(corr, KMINMER, 0).to_host()
+            table_equal = bool(
+                np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(_fbytes(t_ref, "kminmerData_abundance.txt"))) and
+                np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), KMINMER),
+                               formats.sorted_vector_records(_fbytes(t_ref, "kminmerData_min.txt"), KMINMER)))
+            nb = sample * 20_000
+            path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
+            r["parity"] = {"reads": sample, "init_bytes_equal": bool(init_equal), "table_multiset_equal": table_equal,
+                           "against": "oracle/_ref/refdrv on the same reads as FASTQ, --skip-correction, this run"}
+            r["cpu_reference"] = {"gbps_path_only": nb / 1e9 / path, "cores": cores, "read_selection_s": tr["read_selection_s"],
+                                  "tables_s": tr["tables_s"], "sample_gbp": nb / 1e9}
+            if not (init_equal and table_equal):
+                raise SystemExit(f"bench.py: PARITY FAILURE (ONT preset) against the reference: {r['parity']}")
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return r
 
 
 def measured_traffic(reads: int, read_len: int):
@@ -149,18 +392,22 @@ def main() -> None:
     # rate) and the gaps between launches overlap with the scan of the other (bound by the vector ALU).  Step i runs
     # on slot i % IN_FLIGHT; every step is still the complete pass over one batch.
     n_slots = max(1, args.in_flight)
-    if n_slots > 1:
-        # keep the table kernels' footprint small beside the other batches' scans: 1 / 2 / 3 / 4 resident blocks per CU give
-        # 676 / 672 / 657 / 643 Gbp/s on one GPU and 489 / 479 / 463 on the per-rank workload of an 8-GPU job run through
-        # the sharded path (profiles/r01g_table_footprint_sweep.txt)
-        os.environ.setdefault("MDBG_TABLE_BLOCKS_PER_CU", "1")
+    # beside the other batches' scans the table kernels keep to a small footprint: 1 / 2 / 3 / 4 resident blocks per CU gave
+    # 676 / 672 / 657 / 643 Gbp/s on one GPU and 489 / 479 / 463 on the per-rank workload of an 8-GPU job run through
+    # the sharded path (profiles/r01g_table_footprint_sweep.txt)
+    table_blocks = int(os.environ.get("MDBG_TABLE_BLOCKS_PER_CU", "1")) if n_slots > 1 else 0
     slots = []
     # one metagenome for the job (MDBG_BENCH_SPEC_RANKS: test hook, the per-rank workload of an N-rank job on one GPU)
     spec_ranks = int(os.environ.get("MDBG_BENCH_SPEC_RANKS", world))
     spec = synth.hifi_spec(args.reads * spec_ranks, seed=42, read_len=args.read_len, coverage=50.0)
+    # one resident read set per GPU (rank r owns reads [r*n, (r+1)*n)), read by every context in flight
+    shared_reads = None
     for _ in range(n_slots):
         c = capi.Context(local_rank)
-        slots.append((c, c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)))   # rank r owns reads [r*n, (r+1)*n)
+        c.set_option("table_blocks_per_cu", table_blocks)
+        if shared_reads is None:
+            shared_reads = c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)
+        slots.append((c, shared_reads))
     ctx, reads = slots[0]
     info = ctx.device_info()
     n_bases = reads.info()["n_bases"]
@@ -293,9 +540,9 @@ def main() -> None:
             if two < 1.85 * one:
                 break
             c, r = slots[1]
-            r.free(); c.close()
-            c = capi.Context(local_rank)
-            slots[1] = (c, c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads))
+            c.close()
+            slots[1] = (capi.Context(local_rank), r)
+            slots[1][0].set_option("table_blocks_per_cu", table_blocks)
     for c, _ in slots:
         c.timing(True)
         c.timing_reset()
@@ -333,7 +580,25 @@ def main() -> None:
     hash_floor_ms = hpc_positions / 64 * 186 / (info["n_cu"] * 4) / clock_hz * 1e3
 
     if rank == 0:
-        base = cpu_baseline(ctx, reads, min(args.cpu_sample, args.reads)) if world == 1 else None
+        legs_on = set() if (world > 1 or args.legs == "none") else \
+            ({"end_to_end", "multik", "ont"} if args.legs == "all" else set(args.legs.split(",")))
+        side = sample_legs(ctx, reads, spec, rank * args.reads, min(args.cpu_sample, args.reads), "end_to_end" in legs_on) if world == 1 else {}
+        base = side.get("cpu_baseline")
+        legs = {}
+        if "end_to_end" in side:
+            legs["end_to_end"] = side["end_to_end"]
+        if "multik" in legs_on:
+            ctx.set_option("table_blocks_per_cu", 0)       # this context runs alone now
+            legs["multik"] = multik_leg(ctx, reads, n_bases)
+        if "ont" in legs_on:
+            # the HiFi batch and the other contexts' pools make room first
+            for c, _ in slots[1:]:
+                c.close()
+            reads.free()
+            ctx.close()
+            octx = capi.Context(local_rank)
+            legs["ont"] = ont_leg(octx, args.ont_reads, sample=min(10_000, args.cpu_sample))
+            octx.close()
         total_bases = n_bases * world * args.steps
         out = {
             "metric": "Gbp/s through minimizer+k-min-mer step; bit-exact k-min-mer table vs ref",
@@ -341,8 +606,9 @@ def main() -> None:
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.reads} synthetic HiFi reads x {args.read_len} bp per GPU (seed 42, 0.1% substitutions, "
-                                   f"4 species, 50x), HPC on, l={K_MINIMIZER}, density {DENSITY}, single k iteration k={KMINMER} "
-                                   "(count + rescue); inputs 2-bit packed and resident in HBM",
+                                   f"4 species, 50x; {n_bases * world / 1e9:.0f} Gbp per step over all GPUs), HPC on, l={K_MINIMIZER}, density {DENSITY}, "
+                                   f"single k iteration k={KMINMER} (count + rescue); inputs 2-bit packed and resident in HBM, one read set per GPU "
+                                   "shared by the batches in flight",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
                        "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"]},
@@ -351,8 +617,8 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "concurrent_launches": n_slots,
                          "concurrency_note": (f"{n_slots} batches are in flight: a scan launch shares the device with the other batches' "
-                                              "table kernels and lasts longer than alone (13.8 ms with --in-flight 1: 209 GB/s, 2.6 % of "
-                                              "peak, 64 % of the hash floor); scans of different batches never overlap each other")
+                                              "table kernels and lasts longer than alone (--in-flight 1 shows it alone); scans of different batches "
+                                              "never overlap each other")
                                              if n_slots > 1 else None,
                          "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies, half-rate VALU) "
                                  "puts the ceiling at the VALU, far below HBM (DESIGN.md 4.1)",
@@ -363,16 +629,21 @@ def main() -> None:
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()},
             "cpu_baseline": base,
         }
+        if "parity" in side:
+            out["parity"] = side["parity"]
+        if legs:
+            out["legs"] = legs
         if base and base.get("value"):
-            out["speedup_vs_cpu_reference"] = out["value"] / base["value"]
+            out["speedup_vs_cpu_reference_path_only"] = out["value"] / base["value"]
         if trace and phases:
             out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + n_warm) for k, v in phases.items()}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for c, r in slots:
-        r.free()
+    if shared_reads.h:
+        shared_reads.free()
+    for c, _ in slots:
         c.close()
 
 

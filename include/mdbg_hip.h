@@ -17,9 +17,8 @@
  * mdbg_scan calls on the same device take turns: one scan kernel runs at a time.
  * There is no CPU fallback: without a usable GPU every call fails with MDBG_ENODEV.
  *
- * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE (default 2) -- reads a scan wave processes before it
- * retires; MDBG_TABLE_BLOCKS_PER_CU (default: unlimited) -- resident blocks per CU of the k-min-mer insert kernels, to be
- * set to 1..3 when several contexts share a device (bench.py: 1); MDBG_TRACE -- one line per purge with the number of suspect reads.
+ * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE, MDBG_TABLE_BLOCKS_PER_CU -- defaults of the options of
+ * mdbg_set_option; MDBG_TRACE -- one line per purge with the number of suspect reads.
  */
 #ifndef MDBG_HIP_H
 #define MDBG_HIP_H
@@ -50,6 +49,12 @@ const char *mdbg_last_error(const mdbg_ctx *ctx);      /* ctx may be NULL: last 
 int  mdbg_synchronize(mdbg_ctx *ctx);
 void *mdbg_stream(mdbg_ctx *ctx);                       /* the hipStream_t every launch goes to */
 int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes);
+/* Per-context tuning, value <= 0 restores the default:
+ *   "table_blocks_per_cu"   resident blocks per CU of the kernels that walk every k-min-mer instance (default: unlimited;
+ *                           1..3 when several contexts share a device, so that they do not displace another context's scan)
+ *   "scan_reads_per_wave"   reads a scan wave processes before it retires (default 2)
+ * The environment variables MDBG_TABLE_BLOCKS_PER_CU / MDBG_SCAN_READS_PER_WAVE set the defaults at mdbg_create. */
+int  mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value);
 
 /* Profiling aid: accumulated HIP-event time (ms) and launch count of the kernel named
  * `kernel` ("scan", "kminmer_insert", ...) since the last reset; events are recorded on

@@ -40,6 +40,7 @@ SIGNATURES = {
     "mdbg_synchronize": (C.c_int, [_P]),
     "mdbg_stream": (_P, [_P]),
     "mdbg_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), _u64p]),
+    "mdbg_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "mdbg_timing_enable": (C.c_int, [_P, C.c_int]),
     "mdbg_timing_reset": (C.c_int, [_P]),
     "mdbg_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), _u64p]),
@@ -138,6 +139,9 @@ class Context:
         ncu, hbm = C.c_int(), C.c_uint64()
         self.check(lib().mdbg_device_info(self.h, arch, 64, C.byref(ncu), C.byref(hbm)))
         return dict(arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+    def set_option(self, name: str, value: int) -> None:
+        self.check(lib().mdbg_set_option(self.h, name.encode(), value))
 
     # -- timing ---------------------------------------------------------------------------
     def timing(self, on: bool) -> None:

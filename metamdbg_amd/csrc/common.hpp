@@ -114,6 +114,8 @@ struct mdbg_ctx {
     bool timing = false;
     std::vector<mdbg::TimedLaunch> launches;               // pending (not yet folded) timed launches
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
+    unsigned table_blocks_per_cu = 1024;                   // resident blocks per CU of the kernels that walk every k-min-mer instance (mdbg_set_option)
+    unsigned scan_reads_per_wave = 2;                      // reads a scan wave processes before it retires (mdbg_set_option)
     double key_ratio_hint = 0.0625;                        // distinct keys per k-min-mer instance seen last time (table sizing)
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out
 };

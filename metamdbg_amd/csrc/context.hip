@@ -1,6 +1,9 @@
 // context.hip -- context lifetime, error reporting, timing of libmdbg_hip.so.
 #include "common.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace mdbg {
 
 thread_local std::string g_last_error;
@@ -57,6 +60,9 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     ctx->device = device;
     ctx->arch = prop.gcnArchName;
     ctx->n_cu = prop.multiProcessorCount;
+    // defaults of the per-context options from the environment (mdbg_set_option changes them later)
+    if (const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU")) if (atoi(e) > 0) ctx->table_blocks_per_cu = (unsigned)atoi(e);
+    if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
     ctx->hbm_bytes = prop.totalGlobalMem;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete ctx;
@@ -89,6 +95,14 @@ extern "C" int mdbg_synchronize(mdbg_ctx *ctx) try {
 } MDBG_API_CATCH(ctx)
 
 extern "C" void *mdbg_stream(mdbg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: null argument");
+    const std::string n(name);
+    if (n == "table_blocks_per_cu") { ctx->table_blocks_per_cu = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 1024u; return MDBG_OK; }
+    if (n == "scan_reads_per_wave") { ctx->scan_reads_per_wave = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 2u; return MDBG_OK; }
+    return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: unknown option '%s'", name);
+}
 
 extern "C" int mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes) try {
     if (!ctx) return MDBG_EINVAL;

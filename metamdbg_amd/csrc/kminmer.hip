@@ -110,12 +110,11 @@ __device__ __forceinline__ void for_each_instance(const SeqView &s, F f) {
 }
 
 // Grid of the kernels that walk every k-min-mer instance.  Alone they want every wave slot they can get (the insert is
-// bound by memory-side atomics); beside another context's scan a few resident blocks per CU (MDBG_TABLE_BLOCKS_PER_CU,
+// bound by memory-side atomics); beside another context's scan a few resident blocks per CU (mdbg_set_option "table_blocks_per_cu" / MDBG_TABLE_BLOCKS_PER_CU,
 // grid-stride over the reads) keep them from displacing the scan's waves: 3 per CU costs the insert 2.9 -> 3.6 ms and
 // gives the scan back 0.5 ms, which is what the step then runs at.
 static unsigned instance_grid(const mdbg_ctx *ctx, uint32_t n_reads) {
-    static const unsigned per_cu = [] { const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1024u; }();
-    return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * per_cu);
+    return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * ctx->table_blocks_per_cu);
 }
 
 // ---- first pass -----------------------------------------------------------------------------------

@@ -828,8 +828,7 @@ static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks
     // to a 10 kb read.  2 reads per wave measured best with two batches in flight: a waiting kernel of the other batch gets
     // a slot within ~0.2 ms (MDBG_SCAN_READS_PER_WAVE to tune).
     (void)max_blocks;
-    const char *env = getenv("MDBG_SCAN_READS_PER_WAVE");
-    const uint64_t per_wave = env && atoi(env) > 0 ? (uint64_t)atoi(env) : 2;
+    const uint64_t per_wave = ctx->scan_reads_per_wave;
     uint64_t blocks = ((uint64_t)n_items + SCAN_WAVES * per_wave - 1) / (SCAN_WAVES * per_wave);
     if (blocks < 1) blocks = 1;
     if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;

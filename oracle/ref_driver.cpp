@@ -12,6 +12,13 @@
  *   refdrv readSelection <tmpDir> <out> <input.txt> --threads N --min-read-quality Q [...]
  *   refdrv graph <tmpDir> --threads N [--min-abundance M] [--firstpass]
  *   refdrv contig ... / refdrv toMinspace ...      (producers of the k>4 inputs)
+ *   refdrv graph_from_tables <tmpDir> --threads N [--firstpass]
+ *        the REST of the reference's `graph` command after its tables exist: CreateMdbg::createGfa() (k <= firstK+1,
+ *        graph/CreateMdbg.cpp:527-553, :658-) or computeNextUnitigGraph() (k >= firstK+2, :525) run on tables some
+ *        other producer wrote into <tmpDir> -- the hand-over test: mdbg_tool's tables in, the reference's own graph
+ *        stage on top, products compared with a pure reference run.  At k >= firstK+2 the table the graph stage
+ *        queries in memory (_mdbgNodesLight: isEdgeSupported :3990, removeUnsupportedUnitigs :4156, createEdgeNode
+ *        :5013) is filled from the 20-byte records of kminmerData_abundance.txt.
  * Function-level probes (text on stdin -> text on stdout), used by tests/golden/make_golden.py:
  *   refdrv fn_scan <K> <density> <hpc>     : lines "<seq>"              -> "n v:pos:dir ..."
  *   refdrv fn_scan_notrim <K> <density> <hpc> : same with MinimizerParser::_trimBps = 0 (GenerateGfa's unitig scan)
@@ -156,6 +163,49 @@ static int fn_corrscan(int argc, char **argv)
     return 0;
 }
 
+/* What CreateMdbg::execute() + createMDBG() do around the table production (graph/CreateMdbg.cpp:168-196, :199-232,
+ * :515-553), with the tables taken from the files in <tmpDir> instead of being computed. */
+static int graph_from_tables(int argc, char **argv)
+{
+    CreateMdbg g;
+    g.parseArgs(argc, argv);
+    g._checksum_unitigNodes = 0;
+    g._checksum_unitigEdges = 0;
+    g._checksum_unitigAbundances = 0;
+    g._nbUnitigEdges = 0;
+    g._nbUnitigNodes = 0;
+    g._mutexes.resize(1000);
+    for (size_t i = 0; i < g._mutexes.size(); i++) omp_init_lock(&g._mutexes[i]);
+    g._readStats.load(g._outputDir + "/read_stats.txt");
+    g._nbPartitions = g._readStats._nbBases / 20000000000ull;
+    g._nbPartitions = max(g._nbPartitions, g._nbCores);
+    g._nbPartitions = max(g._nbPartitions, 1);
+    g._nbPartitions = min(g._nbPartitions, 5000);
+    if (g._kminmerSize > g._kminmerSizeFirst + 1) {
+        ifstream f(g._outputDir + "/kminmerData_abundance.txt", std::ios::binary);
+        u_int64_t n = 0;
+        while (true) {
+            u_int128_t hash;
+            u_int32_t abundance;
+            f.read((char *)&hash, sizeof(hash));
+            if (f.eof()) break;
+            f.read((char *)&abundance, sizeof(abundance));
+            g._mdbgNodesLight[hash] = abundance;
+            n++;
+        }
+        Logger::get().debug() << "graph_from_tables: " << n << " records into _mdbgNodesLight";
+        g.computeNextUnitigGraph();
+    } else {
+        g.createGfa();
+        Logger::get().debug() << "Checksum unitig nodes:   " << g._checksum_unitigNodes;        /* as CreateMdbg.cpp:574-576 */
+        Logger::get().debug() << "Checksum unitig edges:   " << g._checksum_unitigEdges;
+        Logger::get().debug() << "Checksum unitig abundance:   " << g._checksum_unitigAbundances;
+    }
+    for (size_t i = 0; i < g._mutexes.size(); i++) omp_destroy_lock(&g._mutexes[i]);
+    g.end();
+    return 0;
+}
+
 static int fn_murmur()
 {
     std::string line;
@@ -190,6 +240,7 @@ int main(int argc, char **argv)
     else if (cmd == "graph") CreateMdbg().run(n, args.data());
     else if (cmd == "contig") GenerateContigs().run(n, args.data());
     else if (cmd == "toMinspace") ToMinspace().run(n, args.data());
+    else if (cmd == "graph_from_tables") return graph_from_tables(n, args.data());
     else { std::cerr << "unknown sub-command " << cmd << "\n"; return 2; }
     return 0;
 }

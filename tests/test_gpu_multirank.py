@@ -34,7 +34,7 @@ def _bench(extra_env: dict, args: list[str], nproc: int | None) -> dict:
 @pytest.mark.parametrize("in_flight", [1, 2, 3])
 def test_two_ranks_equal_one(in_flight):
     n = 40_000
-    common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--in-flight", str(in_flight)]
+    common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
     one = _bench({}, ["--gpus", "1", "--reads", str(2 * n)] + common, None)
     two = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}, ["--gpus", "2", "--reads", str(n)] + common, 2)
     assert two["n_gpus"] == 2

@@ -98,6 +98,24 @@ def test_tool_ont_100_golden(tmp_path):
     assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
 
 
+def test_tool_ont_rep_golden(tmp_path):
+    """A read set on which the reference's repetitive-minimizer pick is unambiguous (tests/golden/ont_rep: a cut of four,
+    no count tied across it): the tool's own census must choose the reference's four, and read_data_init.txt -- filtered by
+    them -- must be the reference's file, without pinning anything."""
+    import hashlib
+    m = H.load_manifest("ont_rep")
+    spec = H.spec_from_manifest(m)
+    fastq = str(tmp_path / "ont_rep.fastq")
+    synth.write_fasta(fastq, spec)
+    tmp = make_tmp(tmp_path, formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                                hpc=False, data_type=1, correction_density=0.025), [fastq])
+    read_selection(TOOL, tmp, extra=["--skip-correction", "--threads", "4"])
+    got = np.frombuffer(fbytes(tmp, "repetitiveMinimizers.bin"), "<u4")
+    exp = np.frombuffer(H.golden_bytes("ont_rep", "repetitiveMinimizers.bin"), "<u4")
+    assert len(got) == m["n_keep"] and set(got.tolist()) == set(exp.tolist())
+    assert hashlib.sha256(fbytes(tmp, "read_data_init.txt")).hexdigest() == m["read_data_init_sha256"]
+
+
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
 def test_tool_vs_reference_live_multifile(tmp_path):
     """Two input files (one gzipped with wrapped lines, one plain), small batches so reads span several device
@@ -265,3 +283,50 @@ def test_tool_graph_next_k_equals_reference(tmp_path, name, k):
         assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k), fx["min_sorted"])
     got = fbytes(tmp, os.path.join("smallContigs", f"smallContigs_k{k}.bin"))
     assert mk.small_contig_records(got) == mk.small_contig_records(fx["small_contigs"])
+
+
+@pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
+@pytest.mark.parametrize("kind", ["hifi", "ont"])
+def test_handover_into_reference_graph_stage(tmp_path, kind):
+    """Closing the loop ("in-process consumer"): the reference's `graph` command builds the unitig graph in
+    the same process that made the tables -- createGfa() at k <= firstK+1, computeNextUnitigGraph() querying the in-memory
+    table _mdbgNodesLight at k >= firstK+2 (graph/CreateMdbg.cpp:527-553, :3990, :4156, :5013).  Here the reference's whole
+    multi-k loop (graph -> contig -> toMinspace, k = 4 .. 11) runs twice: as it is, and with every table written by
+    `mdbg_tool graph` (the HIP path) and handed to the reference's own graph stage (`refdrv graph_from_tables`, which fills
+    _mdbgNodesLight from the tool's 20-byte records).  Unitig graph files, the inputs of every next k and the tables must be
+    the same at every k: the GPU-made tables are a drop-in for the stage that consumes them."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from tests import handover as ho
+    if kind == "hifi":
+        spec = synth.hifi_spec(260, seed=91, coverage=30.0)
+        params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=True, data_type=0)
+        extra = []
+    else:
+        spec = synth.SynthSpec(n_reads=140, read_len=20_000, seed=92, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
+                               species_len=[50_000, 40_000], species_weight=[0.7, 0.3], with_quality=True, name="ont")
+        params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=False,
+                                    data_type=1, correction_density=0.025)
+        extra = ["--skip-correction"]
+    reads = str(tmp_path / "reads.fx")
+    synth.write_fasta(reads, spec)
+    t_ref = mg.run_ref_pipeline(str(tmp_path / "ref"), reads, params, graph=False, extra_rs=extra)
+    t_hyb = mg.run_ref_pipeline(str(tmp_path / "hyb"), reads, params, graph=False, extra_rs=extra)
+    last_k = 11
+
+    def tool_tables(tmp, k, first_k):
+        for name in ("kminmerData_abundance.txt", "kminmerData_min.txt"):      # nothing stale may be picked up
+            if os.path.exists(os.path.join(tmp, name)):
+                os.remove(os.path.join(tmp, name))
+        run(TOOL, "graph", *ho.graph_args(tmp, k, first_k))
+
+    ho.run_loop(t_ref, params, last_k, ho.reference_graph, str(tmp_path / "snap_ref"))
+    ho.run_loop(t_hyb, params, last_k, ho.tables_then_reference_graph_stage(tool_tables), str(tmp_path / "snap_hyb"))
+    seen = ho.compare_dirs(str(tmp_path / "snap_ref"), str(tmp_path / "snap_hyb"), 4, last_k)
+    assert seen["graph_files"] >= 4 * 7 and seen["next_inputs"] == 3 * 7 and seen["tables"] == 8, seen
+    # the checksums the reference logs at the end of a createGfa() pass (graph/CreateMdbg.cpp:574-576) agree as well
+    def checksums(tmp):
+        log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+        return [ln.split("Checksum", 1)[1] for ln in log.splitlines() if "Checksum unitig" in ln]
+    assert checksums(t_ref) == checksums(t_hyb) and len(checksums(t_ref)) >= 6

@@ -212,3 +212,28 @@ def test_multik_loop_live(tmp_path):
         flags = orc.small_contigs(um, uo, k, P.prev_k, prev) if k > 8 else np.zeros(len(uo) - 1, np.uint8)
         mine = sorted((0, tuple(int(x) for x in um[int(uo[i]): int(uo[i + 1])])) for i in np.nonzero(flags)[0])
         assert mine == mk.small_contig_records(fx["small_contigs"]), (SEED, k)
+
+
+def test_graph_stage_on_foreign_tables_live(tmp_path):
+    """The harness of the hand-over test (tests/handover.py) checked on the CPU: the reference's multi-k loop run twice,
+    once as it is and once with every `graph` split into (tables written by someone else: here the reference's own records
+    in shuffled order) + `refdrv graph_from_tables` (the reference's graph stage alone; at k >= firstK+2 its in-memory
+    table filled from the 20-byte records).  Everything the next stage reads must come out the same.  The GPU test
+    (tests/test_gpu_tool.py::test_handover_into_reference_graph_stage) swaps the stand-in producer for mdbg_tool."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from metamdbg_amd import formats, synth
+    from tests import handover as ho
+    spec = synth.hifi_spec(160, seed=SEED % 100000 + 13, coverage=25.0)
+    fasta = str(tmp_path / "reads.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=True, data_type=0)
+    t_ref = mg.run_ref_pipeline(str(tmp_path / "ref"), fasta, params, graph=False)
+    t_hyb = mg.run_ref_pipeline(str(tmp_path / "hyb"), fasta, params, graph=False)
+    last_k = 9
+    ho.run_loop(t_ref, params, last_k, ho.reference_graph, str(tmp_path / "snap_ref"))
+    producer = ho.shuffled_reference_tables(str(tmp_path / "scratch"), seed=SEED)
+    ho.run_loop(t_hyb, params, last_k, ho.tables_then_reference_graph_stage(producer), str(tmp_path / "snap_hyb"))
+    seen = ho.compare_dirs(str(tmp_path / "snap_ref"), str(tmp_path / "snap_hyb"), 4, last_k)
+    assert seen["graph_files"] >= 4 * (last_k - 3) - 4 and seen["next_inputs"] == 3 * (last_k - 4), seen
