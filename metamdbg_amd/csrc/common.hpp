@@ -234,6 +234,24 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
     return v;
 }
 
+// The same on the data-parallel-primitive path of the VALU (no LDS crossbar: __shfl_up is a ds_bpermute, 24 cycles per wave
+// instruction on gfx950 against 4.4 for a DPP move -- tools/ubench/op_rates.hip): shifts inside the rows of 16 lanes, then the
+// last lane of a row broadcast to the following rows.
+__device__ __forceinline__ unsigned wave_inclusive_sum_dpp(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// value of the lane below (lane 0 receives `first`): wave_shr:1
+__device__ __forceinline__ unsigned lane_below(unsigned v, unsigned first) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << lane_id()) - 1ull;
 }

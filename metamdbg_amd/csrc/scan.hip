@@ -251,6 +251,36 @@ __device__ __forceinline__ uint32_t word_pair_sq_sum(uint64_t x, uint32_t nb) {
     return sum;
 }
 
+// The same sum on 32-bit bit planes.  The two halves of the word are interleaved so that every mask is one register:
+// base i < 16 sits at bit 2i, base 16 + i at bit 2i + 1 ("slot" order); L / H = low / high bit of the 2-bit code.  The
+// successor of a slot is the slot two bits up, except slot 30 (base 15 -> base 16 = slot 1) and slot 31 (base 31 -> the first
+// base of the next word).  Built from the instructions that issue at the fast rate on gfx950 (and / or / xor / add / right
+// shift / v_bitop3, tools/ubench/op_rates.hip) plus two rotates; then 16 x (and, popcount, multiply-add).
+__device__ __forceinline__ uint32_t word_pair_sq_sum32(uint64_t x, uint32_t next_lo32) {
+    const uint32_t M = 0x55555555u;
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    const uint32_t th = xh & M;
+    const uint32_t L = (xl & M) | (th + th);                       // low code bits in slot order
+    const uint32_t H = ((xl >> 1) & M) | (xh & ~M);                // high code bits in slot order
+    // successor planes: slot s <- slot s + 2; slot 30 <- slot 1; slot 31 <- base 0 of the next word
+    const uint32_t nl = __builtin_amdgcn_alignbit(next_lo32, next_lo32, 1);      // bit 31 = low code bit of the next word's base 0
+    const uint32_t nh = __builtin_amdgcn_alignbit(next_lo32, next_lo32, 2);      // bit 31 = its high code bit
+    const uint32_t NL = (L >> 2) | (__builtin_amdgcn_alignbit(L, L, 3) & 0x40000000u) | (nl & 0x80000000u);
+    const uint32_t NH = (H >> 2) | (__builtin_amdgcn_alignbit(H, H, 3) & 0x40000000u) | (nh & 0x80000000u);
+    const uint32_t e[4] = {~(L | H), L & ~H, H & ~L, L & H};       // base == A, C, T, G (codes 0..3)
+    const uint32_t n[4] = {~(NL | NH), NL & ~NH, NH & ~NL, NL & NH};
+    uint32_t sum = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < 4; c0++) {
+#pragma unroll
+        for (int c1 = 0; c1 < 4; c1++) {
+            const uint32_t c = (uint32_t)__popc(e[c0] & n[c1]);
+            sum = __umul24(c, c) + sum;
+        }
+    }
+    return sum;
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -689,6 +719,307 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
     }
 }
 
+// ================================================================================================================
+// scan_fast_kernel<HPC> -- the variant every upper-case ACGT FASTA batch takes (no qualities, no side masks).
+//
+// Same arithmetic as scan_kernel, reorganised around what the instructions cost on gfx950 (tools/ubench/op_rates.hip,
+// profiles/r02a_op_rates_gfx950.txt: and/or/xor/add/sub/right shifts/v_bitop3 issue in 2.6 cycles per wave64, everything
+// else -- left shifts, min, compares, v_alignbit, DPP, every multiply -- in 4.4 to 4.8, a scalar instruction in 2.1, an
+// LDS read in 9, an LDS write or atomic in 17):
+//   * the compressed bases go to a per-wave LDS RING (8192 bases); whenever 2048 positions are complete (each followed
+//     by a known base) the wave hashes them as one BLOCK: lane l owns the 32 CONTIGUOUS positions 32 l .. 32 l + 31, reads
+//     its three stream words once and walks them in registers with compile-time shifts -- one v_alignbit per position,
+//     the forward k-mer rolled by one base, no address arithmetic, no scalar bookkeeping, no branches;
+//   * "selected" is recorded with two instructions per position (v_cmp + v_addc: a per-lane bit vector); the few selected
+//     positions of a block (about 10 of 2048) are materialised ONCE PER BLOCK, the lanes that own one recomputing its
+//     value from the ring -- instead of ballots, prefix counts and exec-masked stores after every 256 positions;
+//   * the minimizers of a read are staged in LDS and leave in coalesced rows;
+//   * the tail of a read (fewer than 2048 positions) runs the same code on spans of 4 G <= 32 positions per lane, the
+//     stream words fetched from the ring for every group of four.
+// ================================================================================================================
+constexpr int FAST_BLOCK = 256;                       // threads per workgroup (4 independent waves)
+constexpr int FAST_WAVES = FAST_BLOCK / 64;
+constexpr unsigned RING_BASES = 8192;                 // per wave: live bases never exceed 2 * 2048 + 16 + 1
+constexpr unsigned RING_WORDS = RING_BASES / 16;      // u32
+constexpr unsigned RING_WMASK = RING_WORDS - 1;
+constexpr unsigned SPAN = 32;                         // positions per lane in a full block
+constexpr unsigned BLOCK_POS = 64 * SPAN;             // 2048
+constexpr int STAGE_CAP = 384;                        // minimizers of one read staged per wave before a flush
+
+// One position of a lane's span: canonical k-mer from the 32 stream bits T that start at the position, Murmur3, compare,
+// and the verdict shifted into `bits` (the oldest position ends up in the highest of the bits used).
+struct SpanState {
+    uint32_t fwd;         // forward k-mer of the previous position
+    uint32_t bits;
+};
+
+__device__ __forceinline__ void span_step(SpanState &st, uint32_t T, bool first, uint32_t kmask, uint32_t comp_mask, unsigned top_shift,
+                                          unsigned K, uint64_t threshold) {
+    const uint32_t rev = (T ^ comp_mask) & kmask;                      // complement of every digit, already in reversed order
+    // forward k-mer: digits in reading order; rolled: drop the oldest digit, append the newest (the top digit of T's k-mer)
+    st.fwd = first ? digit_reverse(T & kmask, K) : (((st.fwd << 2) | ((T >> top_shift) & 3u)) & kmask);
+    const uint32_t val = st.fwd < rev ? st.fwd : rev;
+    const uint64_t h = kmer_hash32(val);
+    // bits = 2 * bits + (h < threshold): one compare into vcc, one add-with-carry
+    asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(st.bits) : "v"(h), "s"(threshold) : "vcc");
+}
+
+// the 32 stream bits that start at ring position p (any p), from LDS
+__device__ __forceinline__ uint32_t ring_window(const uint32_t *S, unsigned p) {
+    const unsigned b = 2u * p, w = (b >> 5) & RING_WMASK, sh = b & 31u;
+    return __builtin_amdgcn_alignbit(S[(w + 1) & RING_WMASK], S[w], sh);
+}
+
+template <bool HPC>
+__global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
+    __shared__ uint32_t lds_ring[FAST_WAVES][RING_WORDS];
+    __shared__ uint2 lds_stage[FAST_WAVES][STAGE_CAP];
+    __shared__ uint16_t lds_lut[HPC ? HPC_LUT_SIZE : 1];
+    if (HPC) {
+        for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += FAST_BLOCK) lds_lut[i] = hpc_lut_entry(i);
+    }
+    for (unsigned i = threadIdx.x; i < FAST_WAVES * RING_WORDS; i += FAST_BLOCK) (&lds_ring[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *S = lds_ring[wv];
+    uint2 *stage = lds_stage[wv];
+    const unsigned K = a.K;
+    const uint32_t kmask = (K >= 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+    const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
+    const unsigned top_shift = 2u * K - 2u;
+    const uint64_t threshold = a.threshold;
+
+    const uint32_t wave_global = blockIdx.x * FAST_WAVES + wv;
+    const uint32_t n_waves = gridDim.x * FAST_WAVES;
+    for (uint32_t r = wave_global; r < a.n_reads; r += n_waves) {
+        const uint32_t L = a.len[r];
+        const uint64_t w_base = a.word_off[r];
+        const uint64_t *rw = a.words + w_base;
+        const uint32_t nwords = (L + 31u) / 32u;
+        const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
+        const uint64_t cap0 = a.cap_off[r];
+        const uint32_t cap = (uint32_t)(a.cap_off[r + 1] - cap0);
+
+        uint32_t fill = 0;         // compressed bases written to the ring so far (= stream length)
+        uint32_t done = 0;         // positions already evaluated (= ring position of the next block, a multiple of 2048)
+        uint32_t nout = 0;         // minimizers of this read so far
+        uint32_t flushed = 0;      // ... of which already written to the output slot
+        uint32_t prev_last = 0;
+        uint64_t cx_acc = 0;       // per lane: sum of weight x Q over its words
+        uint64_t prev_word = 0;
+        const uint32_t cx_nW = L >= 66u ? (L - 66u) / 32u + 1u : 0u;      // number of complexity windows (ReadSelection.hpp:1171-1228)
+
+        // ---- emission: materialise the positions recorded in `bits` (span length P per lane, oldest position in bit P-1) ----
+        auto emit = [&](uint32_t bits, unsigned P, uint32_t npos_limit) {
+            // positions at or beyond npos_limit (tail lanes past the end) and the trimmed first position of the read
+            if (P < 32u) bits &= (1u << P) - 1u;
+            {
+                const uint32_t first_j = lane * P;                 // span-relative index of this lane's first position
+                if (first_j >= npos_limit) bits = 0;
+                else if (first_j + P > npos_limit) bits &= ~((1u << (first_j + P - npos_limit)) - 1u);
+                if (done == 0u && lane == 0u && a.trim) bits &= ~(1u << (P - 1u));      // Kmer.hpp:1395
+            }
+            if (__ballot(bits != 0u) == 0ull) return;
+            if (a.n_rep) {          // Kmer.hpp:1437: repetitive minimizers are not selected
+                uint32_t b2 = bits;
+                while (b2) {
+                    const unsigned bit = 31u - (unsigned)__clz((int)b2);
+                    b2 &= ~(1u << bit);
+                    const unsigned u = P - 1u - bit;
+                    const uint32_t e = ring_window(S, done + lane * P + u) & kmask;
+                    const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
+                    if (rep_contains(a.rep, a.n_rep, fw < rev ? fw : rev)) bits &= ~(1u << bit);
+                }
+            }
+            const unsigned cnt = (unsigned)__popc(bits);
+            const unsigned incl = wave_inclusive_sum_dpp(cnt);
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total == 0u) return;
+            if (nout - flushed + total > (unsigned)STAGE_CAP) {       // make room: the staged rows leave for the output slot
+                const uint32_t ns = nout - flushed;
+                for (uint32_t i = lane; i < ns; i += 64) {
+                    const uint32_t idx = flushed + i;
+                    if (idx < cap) {
+                        const uint2 e = stage[i];
+                        a.out_min[cap0 + idx] = e.x; a.out_pos[cap0 + idx] = e.y >> 1; a.out_dir[cap0 + idx] = (uint8_t)(e.y & 1u);
+                    }
+                }
+                flushed = nout;
+                wave_lds_sync();
+            }
+            if (total <= (unsigned)STAGE_CAP) {
+                uint32_t at = nout - flushed + incl - cnt;
+                while (bits) {
+                    const unsigned bit = 31u - (unsigned)__clz((int)bits);
+                    bits &= ~(1u << bit);
+                    const unsigned u = P - 1u - bit;
+                    const uint32_t j = done + lane * P + u;                    // position in the compressed read
+                    const uint32_t e = ring_window(S, j) & kmask;
+                    const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
+                    // direction 1 iff the reverse complement is the canonical form, ties included (Kmer.hpp:427)
+                    const uint32_t d = fw < rev ? 0u : 1u;
+                    stage[at++] = make_uint2(d ? rev : fw, (j << 1) | d);
+                }
+            } else {
+                // more selected positions in one block than the stage holds (densities near 1): straight to the slot
+                uint32_t at = nout + incl - cnt;
+                while (bits) {
+                    const unsigned bit = 31u - (unsigned)__clz((int)bits);
+                    bits &= ~(1u << bit);
+                    const unsigned u = P - 1u - bit;
+                    const uint32_t j = done + lane * P + u;
+                    const uint32_t e = ring_window(S, j) & kmask;
+                    const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
+                    const uint32_t d = fw < rev ? 0u : 1u;
+                    if (at < cap) { a.out_min[cap0 + at] = d ? rev : fw; a.out_pos[cap0 + at] = j; a.out_dir[cap0 + at] = (uint8_t)d; }
+                    at++;
+                }
+                flushed = nout + total;
+            }
+            nout += total;
+        };
+
+        uint64_t x_next = (lane < nwords) ? rw[lane] : 0;
+        for (uint32_t t = 0; t < ntiles; t++) {
+            const uint64_t x = x_next;
+            const uint32_t wi = t * TILE_WORDS + lane;
+            {
+                const uint32_t nwi = wi + TILE_WORDS;
+                x_next = (nwi < nwords) ? rw[nwi] : 0;
+            }
+            const int rem = (int)L - (int)(wi * 32u);
+            const unsigned nvalid = rem <= 0 ? 0u : (rem >= 32 ? 32u : (unsigned)rem);
+
+            // ---- complexity: upper bound from per-word 2-mer counts (as in scan_kernel; the word below comes over DPP) ----
+            if (a.apply_filters) {
+                const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+                const uint32_t pl32 = lane_below(xl, (uint32_t)prev_word), ph32 = lane_below(xh, (uint32_t)(prev_word >> 32));
+                prev_word = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)xh, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)xl, 63);
+                // word wq = wi - 1 enters window wq (if wq < nW) and window wq - 1 (if 1 <= wq <= nW): weight 1 at wq = 0 and nW, 2 between
+                const uint32_t q = word_pair_sq_sum32(((uint64_t)ph32 << 32) | pl32, xl);
+                const uint32_t wq = wi - 1u;                      // lane 0 of tile 0: wraps around, weight 0
+                const uint32_t w2 = wq < cx_nW ? q : 0u, w1 = (wq - 1u) < cx_nW ? q : 0u;
+                cx_acc += w2 + w1;
+            }
+
+            // ---- run starts / compaction of this lane's word ----
+            uint64_t y;
+            unsigned c;
+            if (HPC) {
+                uint32_t pl = lane_below((uint32_t)(x >> 62), prev_last);
+                if (wi == 0) pl = ((uint32_t)x & 3u) ^ 1u;      // the first base of the read starts a run whatever precedes it
+                unsigned nbits;
+                y = compress_pairs_lut(lds_lut, x, pl, &nbits);
+                c = nbits >> 1;
+                if (nvalid < 32) {
+                    const uint64_t vspread = ((1ull << (2 * nvalid)) - 1ull) & M5;
+                    const uint64_t diff = x ^ ((x << 2) | (uint64_t)pl);
+                    const uint64_t d = (diff | (diff >> 1)) & vspread;
+                    c = (unsigned)__popcll(d);
+                    y &= c >= 32 ? ~0ull : ((1ull << (2 * c)) - 1ull);
+                }
+                prev_last = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 62), 63);
+            } else {
+                c = nvalid;
+                y = nvalid == 32 ? x : (x & ((1ull << (2 * nvalid)) - 1ull));
+            }
+            const unsigned inc = wave_inclusive_sum_dpp(c);
+            const unsigned o = inc - c;
+            const unsigned C = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+
+            // ---- append to the ring (the region ahead of `fill` is zero) ----
+            if (c) {
+                const unsigned dst = 2u * ((fill + o) & (RING_BASES - 1u)), w = dst >> 5, sh = dst & 31u;
+                const uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+                const uint32_t p0 = yl << sh;
+                const uint32_t p1 = sh ? ((yl >> (32u - sh)) | (yh << sh)) : yh;
+                const uint32_t p2 = sh ? (yh >> (32u - sh)) : 0u;
+                atomicOr(&S[w], p0);
+                if (p1) atomicOr(&S[(w + 1) & RING_WMASK], p1);
+                if (p2) atomicOr(&S[(w + 2) & RING_WMASK], p2);
+            }
+            fill += C;
+            wave_lds_sync();
+
+            // ---- full blocks: 2048 positions, every one followed by a known base ----
+            while (fill - done >= BLOCK_POS + K + 1u) {
+                const unsigned wb = ((done >> 4) + 2u * lane) & RING_WMASK;
+                const uint32_t W0 = S[wb], W1 = S[(wb + 1) & RING_WMASK], W2 = S[(wb + 2) & RING_WMASK];
+                SpanState st{0u, 0u};
+#pragma unroll
+                for (int u = 0; u < (int)SPAN; u++) {
+                    const uint32_t T = u == 0 ? W0 : (u < 16 ? __builtin_amdgcn_alignbit(W1, W0, 2 * u)
+                                                             : (u == 16 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * (u - 16))));
+                    span_step(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold);
+                }
+                emit(st.bits, SPAN, BLOCK_POS);
+                wave_lds_sync();
+                // the block's bases are not needed any more: back to zero for the next lap of the ring
+                {
+                    const unsigned zb = (done >> 4);
+                    S[(zb + lane) & RING_WMASK] = 0;
+                    S[(zb + 64u + lane) & RING_WMASK] = 0;
+                }
+                done += BLOCK_POS;
+                wave_lds_sync();
+            }
+        }
+
+        // ---- tail: the positions left (each followed by a known base; with _trimBps == 0 also the last l-mer) ----
+        {
+            const uint32_t live = fill - done;
+            uint32_t npos = live > K ? live - K : 0u;
+            if (a.trim == 0u && live >= K) npos = live - K + 1u;
+            if (npos) {
+                const unsigned G = (npos + 255u) / 256u;            // groups of four positions per lane (<= 8)
+                const unsigned P = 4u * G;
+                SpanState st{0u, 0u};
+                for (unsigned g = 0; g < G; g++) {
+                    const unsigned p = done + lane * P + 4u * g;     // ring position of the group's first position
+                    const unsigned b = 2u * p, w = (b >> 5) & RING_WMASK, sh = b & 31u;
+                    const uint32_t w0 = S[w], w1 = S[(w + 1) & RING_WMASK], w2 = S[(w + 2) & RING_WMASK];
+                    const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t T = u == 0 ? a0 : __builtin_amdgcn_alignbit(a1, a0, 2 * u);
+                        span_step(st, T, g == 0 && u == 0, kmask, comp_mask, top_shift, K, threshold);
+                    }
+                }
+                emit(st.bits, P, npos);
+            }
+            wave_lds_sync();
+            // leave the ring zero for the next read: everything from `done` to `fill`
+            {
+                const unsigned zb = done >> 4, nz = ((fill + 15u) >> 4) - zb + 1u;
+                for (unsigned i = lane; i < nz; i += 64) S[(zb + i) & RING_WMASK] = 0;
+            }
+        }
+
+        // ---- the staged minimizers leave in rows ----
+        {
+            const uint32_t ns = nout - flushed;
+            for (uint32_t i = lane; i < ns; i += 64) {
+                const uint32_t idx = flushed + i;
+                if (idx < cap) {
+                    const uint2 e = stage[i];
+                    a.out_min[cap0 + idx] = e.x; a.out_pos[cap0 + idx] = e.y >> 1; a.out_dir[cap0 + idx] = (uint8_t)(e.y & 1u);
+                }
+            }
+        }
+        uint8_t flags = 0;
+        if (a.apply_filters && L >= 66) {
+            const uint64_t bound = wave_sum_u64(cx_acc);
+            if (bound > (300ull + 32ull) * cx_nW) flags |= READ_SUSPECT;
+        }
+        if (lane == 0) {
+            a.out_count[r] = nout;
+            a.out_flags[r] = flags;
+        }
+        wave_lds_sync();       // ring zeroed, stage drained: the next read starts clean
+    }
+}
+
 // ---- padded -> dense CSR (+ per-minimizer minimum quality) -------------------------------------
 // G lanes per read: 16 when reads hold a few dozen minimizers (4 reads in flight per wave: the kernel is a chain of
 // dependent loads per read, so reads in flight are what it runs on), 64 for long reads / high densities.
@@ -840,7 +1171,16 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
     const unsigned max_blocks = (unsigned)ctx->n_cu * 8u;
     {
         LaunchTimer timer(ctx, "scan");
-        if (hpc) {
+        static const bool no_fast = getenv("MDBG_SCAN_NO_FAST") != nullptr;      // A/B: the general kernel for everything
+        if (!has_q && !has_n && !a.subset && !no_fast) {
+            // plain ACGT without qualities: the block-structured kernel; a few reads per wave, then the wave retires
+            const uint64_t per_wave = ctx->scan_reads_per_wave;
+            uint64_t blocks = ((uint64_t)n_items + FAST_WAVES * per_wave - 1) / (FAST_WAVES * per_wave);
+            if (blocks < 1) blocks = 1;
+            if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
+            if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((scan_fast_kernel<false>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
+        } else if (hpc) {
             if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }
             else { if (has_q) launch_variant<true, true, false>(ctx, a, max_blocks, n_items); else launch_variant<true, false, false>(ctx, a, max_blocks, n_items); }
         } else {
