@@ -596,7 +596,7 @@ using namespace mdbg;
 static int check_seq(mdbg_ctx *ctx, const mdbg_minimizers *m, const char *who) {
     if (!m) return set_error(ctx, MDBG_EINVAL, "%s: null sequence set", who);
     if (m->n_min >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "%s: more than 2^32 minimizers in one batch", who);
-    return MDBG_OK;
+    return ensure_canonical(ctx, m);      // a scan output handed over without the purge in between
 }
 
 extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance,

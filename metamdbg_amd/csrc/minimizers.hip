@@ -21,7 +21,16 @@ __device__ __forceinline__ bool window_is_palindrome(const uint32_t *a, uint32_t
 // A palindromic window of length k >= 2 needs m[c]==m[c+1] (even k) or m[c-1]==m[c+1] (odd k) at its
 // centre, so reads without such a pair are untouched (the common case).  16 lanes per read look for
 // one; suspects are listed for the serial pass.
-__global__ __launch_bounds__(256) void purge_detect_kernel(const uint64_t *off, uint32_t n_reads, const uint32_t *mins,
+// Where the minimizers of read r are: CSR (end = begin + 1 of the same array, cnt null) or the scattered form of a fresh scan
+// output (begin[r], cnt[r]).
+struct ReadSpans {
+    const uint64_t *begin;
+    const uint64_t *end;
+    const uint32_t *cnt;
+    __device__ __forceinline__ uint32_t n(uint64_t r) const { return cnt ? cnt[r] : (uint32_t)(end[r] - begin[r]); }
+};
+
+__global__ __launch_bounds__(256) void purge_detect_kernel(ReadSpans sp, uint32_t n_reads, const uint32_t *mins,
                                                            uint32_t *new_count, uint32_t *list, uint32_t *n_list) {
     const unsigned sub = threadIdx.x & 15u;
     const unsigned gshift = (threadIdx.x & 63u) & ~15u;           // first lane of this 16-lane group in the wave
@@ -30,8 +39,8 @@ __global__ __launch_bounds__(256) void purge_detect_kernel(const uint64_t *off, 
     for (uint64_t r0 = 0; r0 < n_reads; r0 += ngroups) {
         const uint64_t r = r0 + group;
         const bool live = r < n_reads;
-        const uint64_t f = live ? off[r] : 0;
-        const uint32_t n = live ? (uint32_t)(off[r + 1] - f) : 0u;
+        const uint64_t f = live ? sp.begin[r] : 0;
+        const uint32_t n = live ? sp.n(r) : 0u;
         bool suspect = false;
         for (uint32_t i = sub; i + 1 < n; i += 16) {
             uint32_t x = mins[f + i];
@@ -91,14 +100,14 @@ __device__ __forceinline__ uint32_t purge_replay(Ptr a, uint32_t n, uint32_t fir
 // One thread per suspect read.  The replay is a long chain of dependent reads of the same few dozen minimizers, so
 // reads of up to PURGE_LDS_MAX minimizers are staged in LDS (a padded row per thread) and written back once.
 constexpr uint32_t PURGE_LDS_MAX = 96;
-__global__ __launch_bounds__(64) void purge_fix_kernel(const uint64_t *off, const uint32_t *list, uint32_t n_list, uint32_t *work,
+__global__ __launch_bounds__(64) void purge_fix_kernel(ReadSpans sp, const uint32_t *list, uint32_t n_list, uint32_t *work,
                                                        uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
     __shared__ uint32_t stage[64][PURGE_LDS_MAX + 1];
     uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n_list) return;
     const uint32_t r = list[li];
-    uint32_t *a = work + off[r];
-    uint32_t n = (uint32_t)(off[r + 1] - off[r]);
+    uint32_t *a = work + sp.begin[r];
+    uint32_t n = sp.n(r);
     if (n <= PURGE_LDS_MAX) {
         uint32_t *row = stage[threadIdx.x];
         for (uint32_t i = 0; i < n; i++) row[i] = a[i];
@@ -122,6 +131,49 @@ __global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *src_
         uint32_t n = (uint32_t)(dst_off[r + 1] - d);
         for (uint32_t i = lane; i < n; i += 16) dst[d + i] = src[s + i];
     }
+}
+
+// scattered scan output -> CSR order: values, positions, directions of every read (16 lanes per read)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint64_t *src_begin, const uint64_t *dst_off, uint32_t n_reads,
+                                                          const uint32_t *smin, const uint32_t *spos, const uint8_t *sdir,
+                                                          uint32_t *dmin, uint32_t *dpos, uint8_t *ddir) {
+    const unsigned lane = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r = group; r < n_reads; r += ngroups) {
+        const uint64_t s = src_begin[r], d = dst_off[r];
+        const uint32_t n = (uint32_t)(dst_off[r + 1] - d);
+        for (uint32_t i = lane; i < n; i += 16) { dmin[d + i] = smin[s + i]; dpos[d + i] = spos[s + i]; ddir[d + i] = sdir[s + i]; }
+    }
+}
+
+int ensure_canonical(mdbg_ctx *ctx, const mdbg_minimizers *cm) {
+    if (!cm || !cm->scattered) return MDBG_OK;
+    mdbg_minimizers *m = const_cast<mdbg_minimizers *>(cm);
+    mdbg_ctx *c = m->owner ? m->owner : ctx;            // on the stream that produced the rows
+    MDBG_HIP_CHECK(ctx, hipSetDevice(c->device));
+    const uint32_t n = m->n_reads;
+    MDBG_TRY(m->d_off.alloc(c, (size_t)n + 1));
+    MDBG_TRY(exclusive_scan_u32(c, m->d_cnt.p, m->d_off.p, n));
+    DevBuf<uint32_t> nmin, npos;
+    DevBuf<uint8_t> ndir;
+    MDBG_TRY(nmin.alloc(c, m->n_min));
+    MDBG_TRY(npos.alloc(c, m->n_min));
+    MDBG_TRY(ndir.alloc(c, m->n_min));
+    if (n) {
+        LaunchTimer timer(c, "scan_compact");
+        unsigned blocks = grid_for((uint64_t)n * 16, 256, (unsigned)c->n_cu * 32u);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, m->d_begin.p, m->d_off.p, n, m->d_min.p, m->d_pos.p,
+                           m->d_dir.p, nmin.p, npos.p, ndir.p);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));   // the old rows go back to the pool; other contexts may read the object next
+    m->d_min = std::move(nmin);
+    m->d_pos = std::move(npos);
+    m->d_dir = std::move(ndir);
+    m->d_begin.release();
+    m->d_cnt.release();
+    m->scattered = false;
+    return MDBG_OK;
 }
 
 // ---- u32 value census (open addressing, value+1 as key so 0 marks empty) ----
@@ -190,6 +242,7 @@ extern "C" int mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, 
                                        uint32_t *read_lengths, float *mean_quality, uint8_t *read_flags) try {
     if (!ctx || !m) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_to_host: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_TRY(ensure_canonical(ctx, m));
     const size_t n = m->n_reads, t = m->n_min;
     if (offsets) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, offsets, m->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
     if (minimizers && t) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, minimizers, m->d_min.p, t * 4, hipMemcpyDeviceToHost));
@@ -229,6 +282,7 @@ extern "C" int mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimize
 
 extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers) {
     if (!m) return MDBG_EINVAL;
+    if (m->scattered) { int rc = ensure_canonical(m->owner, m); if (rc) return rc; }
     if (d_offsets) *d_offsets = m->d_off.p;
     if (d_minimizers) *d_minimizers = m->d_min.p;
     return MDBG_OK;
@@ -238,6 +292,7 @@ extern "C" void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
 
 extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out) try {
     if (!ctx || !in || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: null argument");
+    MDBG_TRY(ensure_canonical(ctx, in));
     if (!(density > 0.0f)) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: density must be > 0");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = in->n_reads;
@@ -300,30 +355,42 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
     m->n_reads = n;
     int rc;
     if ((rc = m->d_off.alloc(ctx, (size_t)n + 1))) return fail(rc);
+    // the input as it is: CSR, or the scattered rows of a fresh scan output (which this step then puts in CSR order: the copy it
+    // makes anyway is a gather)
+    const ReadSpans sp = in->scattered ? ReadSpans{in->d_begin.p, nullptr, in->d_cnt.p} : ReadSpans{in->d_off.p, in->d_off.p + 1, nullptr};
     if (n) {
         LaunchTimer timer(ctx, "purge_palindromes");
         unsigned blocks = grid_for((uint64_t)n * 16, 256, (unsigned)ctx->n_cu * 16u);
-        hipLaunchKernelGGL(purge_detect_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, n, in->d_min.p, cnt.p, list.p, n_list.p);
+        hipLaunchKernelGGL(purge_detect_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sp, n, in->d_min.p, cnt.p, list.p, n_list.p);
     }
     uint32_t n_suspect = 0;
     hipError_t e = memcpy_sync(ctx, &n_suspect, n_list.p, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge suspect count copy failed: %s", hipGetErrorString(e)));
+    const unsigned gblocks = grid_for((uint64_t)n * 16, 256, (unsigned)ctx->n_cu * 32u);
     if (n_suspect == 0) {
         // nothing to purge: the output is a copy of the input
         m->n_min = in->n_min;
         if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
-        LaunchTimer timer(ctx, "purge_palindromes");
-        e = hipMemcpyAsync(m->d_off.p, in->d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess && m->n_min) e = hipMemcpyAsync(m->d_min.p, in->d_min.p, m->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
+        if (in->scattered) {
+            if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
+            LaunchTimer timer(ctx, "purge_palindromes");
+            if (n) hipLaunchKernelGGL(gather_prefix_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, in->d_begin.p, m->d_off.p, n, in->d_min.p, m->d_min.p);
+        } else {
+            LaunchTimer timer(ctx, "purge_palindromes");
+            e = hipMemcpyAsync(m->d_off.p, in->d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess && m->n_min) e = hipMemcpyAsync(m->d_min.p, in->d_min.p, m->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
+        }
     } else {
+        // working copy in the input's own layout (a scattered input occupies n_rows entries, rows of dropped reads included)
+        const size_t work_n = in->scattered ? (size_t)in->n_rows : (size_t)in->n_min;
         DevBuf<uint32_t> work;
-        if ((rc = work.alloc(ctx, in->n_min))) return fail(rc);
+        if ((rc = work.alloc(ctx, work_n))) return fail(rc);
         {
             LaunchTimer timer(ctx, "purge_palindromes");
-            e = hipMemcpyAsync(work.p, in->d_min.p, in->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            e = hipMemcpyAsync(work.p, in->d_min.p, work_n * 4, hipMemcpyDeviceToDevice, ctx->stream);
             if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
-            hipLaunchKernelGGL(purge_fix_kernel, dim3(grid_for(n_suspect, 64)), dim3(64), 0, ctx->stream, in->d_off.p, list.p, n_suspect,
+            hipLaunchKernelGGL(purge_fix_kernel, dim3(grid_for(n_suspect, 64)), dim3(64), 0, ctx->stream, sp, list.p, n_suspect,
                                work.p, first_k, last_k, cnt.p);
         }
         if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
@@ -331,14 +398,13 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
         if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
         if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg] purge: %u suspect reads of %u, %llu minimizers dropped\n", n_suspect, n,
                                           (unsigned long long)(in->n_min - m->n_min));
-        if (m->n_min == in->n_min) {
+        if (m->n_min == in->n_min && !in->scattered) {
             // suspects, but nothing was palindromic: the working copy is the output
             m->d_min = std::move(work);
         } else {
             if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
-            unsigned blocks = grid_for((uint64_t)n * 16, 256, (unsigned)ctx->n_cu * 32u);
             LaunchTimer timer(ctx, "purge_palindromes");
-            hipLaunchKernelGGL(gather_prefix_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in->d_off.p, m->d_off.p, n, work.p, m->d_min.p);
+            hipLaunchKernelGGL(gather_prefix_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, sp.begin, m->d_off.p, n, work.p, m->d_min.p);
             e = hipStreamSynchronize(ctx->stream);   // `work` goes back to the pool on return
             if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
         }
@@ -352,6 +418,7 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
 extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out) try {
     if (!ctx || !m || !out || !n_out) return set_error(ctx, MDBG_EINVAL, "mdbg_repetitive_minimizers: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_TRY(ensure_canonical(ctx, m));
     const uint64_t n = m->n_min;
     uint64_t cap = 1024;
     while (cap < n * 2) cap <<= 1;

@@ -44,7 +44,23 @@ struct mdbg_minimizers {
     mdbg::DevBuf<uint8_t> d_flags;    // n_reads: MDBG_READ_* (scan output only)
     std::vector<float> h_mean_quality;  // n_reads, finished on the host from per-read quality histograms
     bool from_scan = false;
+    // Fresh output of the block-structured scan kernel: the rows of read r sit at [d_begin[r], d_begin[r] + d_cnt[r]) of
+    // d_min / d_pos / d_dir in the order the waves finished their reads (each wave takes room with one atomic add when its
+    // read is done, and writes coalesced rows once).  mdbg_purge_palindromes -- the next step of the path -- reads this
+    // form directly and writes canonical CSR; every other consumer has it brought into CSR order first (ensure_canonical),
+    // which is the copy the padded-slot design of round 1 always paid.
+    bool scattered = false;
+    mdbg::DevBuf<uint64_t> d_begin;   // n_reads (scattered only)
+    mdbg::DevBuf<uint32_t> d_cnt;     // n_reads (scattered only)
+    uint64_t n_rows = 0;              // scattered only: extent of the row arrays (>= n_min: the regions the waves fill are not full,
+                                      // and rows of reads the complexity filter emptied stay behind)
+    mdbg_ctx *owner = nullptr;        // the context whose stream produced the object
 };
+
+namespace mdbg {
+// brings a scattered scan output into CSR order in place (no-op otherwise); the object is logically unchanged
+int ensure_canonical(mdbg_ctx *ctx, const mdbg_minimizers *m);
+}
 
 // k-min-mer table: output rows (file order) + an open-addressing lookup over the same keys.
 struct mdbg_table {

@@ -72,6 +72,15 @@ struct ScanArgs {
     int inline_minq;
     uint32_t *out_count;          // per read: number selected (may exceed capacity -> overflow)
     uint8_t *out_flags;           // per read: MDBG_READ_* | READ_SUSPECT
+    // scan_fast_kernel, bump mode (cursor != null; cap_off unused): a wave takes room for a finished read with one atomic
+    // add and writes its rows there; reads that outgrow the LDS stage and suspects of the complexity bound are listed
+    unsigned long long *cursor;   // [g]: rows handed out so far in region g of the output arrays (one address takes about 80 M
+                                  // returning atomics per second on this part; a million 10 kb reads finish in 11 ms)
+    uint32_t n_regions;           // power of two
+    uint64_t out_capacity;        // rows one region holds
+    uint64_t *out_begin;          // per read: first row
+    uint32_t *over_list, *suspect_list;
+    uint32_t *list_counters;      // [0] = reads in over_list, [1] = reads in suspect_list
 };
 
 // squeeze the 2-bit fields of x whose flag bit (bit 2i of d) is set down to the low end
@@ -321,7 +330,8 @@ __device__ int exact_low_complexity(const uint64_t *rw, uint32_t L, unsigned lan
 // one wave per suspect read: exact decision; low-complexity reads lose their minimizers but keep
 // their (empty) record (ReadSelection.hpp:890-899)
 __global__ __launch_bounds__(256) void complexity_exact_kernel(const uint64_t *words, const uint64_t *word_off, const uint32_t *len,
-                                                               const uint32_t *list, uint32_t n_list, uint32_t *count, uint8_t *flags) {
+                                                               const uint32_t *list, uint32_t n_list, uint32_t *count, uint8_t *flags,
+                                                               unsigned long long *dropped /* may be null: sum of the counts cleared */) {
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
     for (uint32_t i = wave; i < n_list; i += n_waves) {
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256) void complexity_exact_kernel(const uint64_t *w
         int low = exact_low_complexity(words + word_off[r], len[r], lane);
         if (lane == 0) {
             flags[r] = low ? (uint8_t)MDBG_READ_LOW_COMPLEXITY : (uint8_t)0;
-            if (low) count[r] = 0;
+            if (low) { if (dropped && count[r]) atomicAdd(dropped, (unsigned long long)count[r]); count[r] = 0; }
         }
     }
 }
@@ -798,8 +808,10 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
         const uint64_t *rw = a.words + w_base;
         const uint32_t nwords = (L + 31u) / 32u;
         const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
-        const uint64_t cap0 = a.cap_off[r];
-        const uint32_t cap = (uint32_t)(a.cap_off[r + 1] - cap0);
+        const bool bump = a.cursor != nullptr;
+        const uint64_t cap0 = bump ? 0ull : a.cap_off[r];
+        const uint32_t cap = bump ? 0u : (uint32_t)(a.cap_off[r + 1] - cap0);
+        bool outgrown = false;     // bump mode: the read selected more than the stage holds -> listed, re-run by the host
 
         uint32_t fill = 0;         // compressed bases written to the ring so far (= stream length)
         uint32_t done = 0;         // positions already evaluated (= ring position of the next block, a multiple of 2048)
@@ -836,7 +848,9 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             const unsigned incl = wave_inclusive_sum_dpp(cnt);
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             if (total == 0u) return;
-            if (nout - flushed + total > (unsigned)STAGE_CAP) {       // make room: the staged rows leave for the output slot
+            if (bump) {
+                if (outgrown || nout + total > (unsigned)STAGE_CAP) { outgrown = true; nout += total; return; }
+            } else if (nout - flushed + total > (unsigned)STAGE_CAP) {       // make room: the staged rows leave for the output slot
                 const uint32_t ns = nout - flushed;
                 for (uint32_t i = lane; i < ns; i += 64) {
                     const uint32_t idx = flushed + i;
@@ -996,8 +1010,36 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             }
         }
 
+        uint8_t flags = 0;
+        if (a.apply_filters && L >= 66) {
+            const uint64_t bound = wave_sum_u64(cx_acc);
+            if (bound > (300ull + 32ull) * cx_nW) flags |= READ_SUSPECT;
+        }
         // ---- the staged minimizers leave in rows ----
-        {
+        if (bump) {
+            uint64_t start = 0;
+            if (!outgrown && nout) {
+                uint32_t lo = 0, hi = 0;
+                const uint32_t region = wave_global & (a.n_regions - 1u);
+                if (lane == 0) { const unsigned long long s0 = atomicAdd(a.cursor + region, (unsigned long long)nout); lo = (uint32_t)s0; hi = (uint32_t)(s0 >> 32); }
+                start = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+                const bool fits = start + nout <= a.out_capacity;
+                start += (uint64_t)region * a.out_capacity;
+                if (fits) {
+                    for (uint32_t i = lane; i < nout; i += 64) {
+                        const uint2 e = stage[i];
+                        a.out_min[start + i] = e.x; a.out_pos[start + i] = e.y >> 1; a.out_dir[start + i] = (uint8_t)(e.y & 1u);
+                    }
+                }
+            }
+            if (lane == 0) {
+                a.out_begin[r] = start;
+                a.out_count[r] = outgrown ? 0u : nout;
+                a.out_flags[r] = flags;
+                if (outgrown) a.over_list[atomicAdd(&a.list_counters[0], 1u)] = r;
+                if (flags & READ_SUSPECT) a.suspect_list[atomicAdd(&a.list_counters[1], 1u)] = r;
+            }
+        } else {
             const uint32_t ns = nout - flushed;
             for (uint32_t i = lane; i < ns; i += 64) {
                 const uint32_t idx = flushed + i;
@@ -1006,15 +1048,10 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     a.out_min[cap0 + idx] = e.x; a.out_pos[cap0 + idx] = e.y >> 1; a.out_dir[cap0 + idx] = (uint8_t)(e.y & 1u);
                 }
             }
-        }
-        uint8_t flags = 0;
-        if (a.apply_filters && L >= 66) {
-            const uint64_t bound = wave_sum_u64(cx_acc);
-            if (bound > (300ull + 32ull) * cx_nW) flags |= READ_SUSPECT;
-        }
-        if (lane == 0) {
-            a.out_count[r] = nout;
-            a.out_flags[r] = flags;
+            if (lane == 0) {
+                a.out_count[r] = nout;
+                a.out_flags[r] = flags;
+            }
         }
         wave_lds_sync();       // ring zeroed, stage drained: the next read starts clean
     }
@@ -1279,6 +1316,70 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         m->h_mean_quality.assign(n, mean_quality_from_sum(0, 0));
     }
 
+    // ---- plain ACGT without qualities: the block-structured kernel writes every read's rows once, where a wave found room
+    // (mdbg_minimizers::scattered); one read-back instead of four.  Batches it cannot take -- a read selecting more than the
+    // LDS stage holds, more rows than the estimate allowed for -- go through the general path below.
+    static const bool no_bump = getenv("MDBG_SCAN_NO_BUMP") != nullptr || getenv("MDBG_SCAN_NO_FAST") != nullptr;
+    if (n && !has_q && !has_n && !no_bump && p->density < 0.2f) {
+        // the output arrays are cut into regions, each with its own cursor (reads are dealt to the waves round-robin, so the regions
+        // fill evenly); small batches use one
+        uint32_t n_regions = 1;
+        while (n_regions < 64u && (uint64_t)n_regions * 8192ull <= n) n_regions <<= 1;
+        const uint64_t region_cap = ((uint64_t)((double)reads->n_bases * (double)p->density * 1.3) + 64ull * n) / n_regions + 4096ull;
+        const uint64_t capacity = region_cap * n_regions;
+        constexpr uint32_t CTL_OVER = 64, CTL_DROPPED = 65, CTL_WORDS = 66;     // u64 words: cursors, {n_over, n_suspect}, rows dropped
+        DevBuf<uint32_t> d_over, d_susp;
+        DevBuf<unsigned long long> d_ctl;
+        if ((rc = m->d_begin.alloc(ctx, n)) || (rc = m->d_cnt.alloc(ctx, n)) || (rc = d_over.alloc(ctx, n)) || (rc = d_susp.alloc(ctx, n)) ||
+            (rc = d_ctl.alloc(ctx, CTL_WORDS)) || (rc = m->d_min.alloc(ctx, capacity)) || (rc = m->d_pos.alloc(ctx, capacity)) ||
+            (rc = m->d_dir.alloc(ctx, capacity)) || (rc = m->d_mqual.alloc(ctx, capacity)))
+            return fail(rc);
+        (void)hipMemsetAsync(d_ctl.p, 0, CTL_WORDS * 8, ctx->stream);
+        ScanArgs a{};
+        a.words = reads->d_words.p; a.word_off = reads->d_word_off.p; a.len = reads->d_len.p;
+        a.K = p->minimizer_size;
+        a.threshold = density_threshold(p->density);
+        a.trim = p->no_end_trim ? 0u : 1u;
+        a.rep = d_rep.p; a.n_rep = p->n_repetitive;
+        a.apply_filters = p->apply_read_filters;
+        a.out_min = m->d_min.p; a.out_pos = m->d_pos.p; a.out_dir = m->d_dir.p;
+        a.out_count = m->d_cnt.p; a.out_flags = m->d_flags.p;
+        a.cursor = d_ctl.p; a.n_regions = n_regions; a.out_capacity = region_cap; a.out_begin = m->d_begin.p;
+        a.over_list = d_over.p; a.suspect_list = d_susp.p; a.list_counters = (uint32_t *)(d_ctl.p + CTL_OVER);
+        unsigned long long h_ctl[CTL_WORDS];
+        {
+            std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));      // one scan kernel at a time per device (see below)
+            if ((rc = launch_scan(ctx, a, hpc, false, false, n))) return fail(rc);
+            e = memcpy_sync(ctx, h_ctl, d_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan counters copy failed: %s", hipGetErrorString(e)));
+        uint64_t rows = 0;
+        bool fits = true;
+        for (uint32_t g = 0; g < n_regions; g++) { rows += h_ctl[g]; fits = fits && h_ctl[g] <= region_cap; }
+        const uint32_t n_over = (uint32_t)h_ctl[CTL_OVER], n_suspect = (uint32_t)(h_ctl[CTL_OVER] >> 32);
+        if (n_over == 0 && fits) {
+            uint64_t dropped = 0;
+            if (n_suspect) {
+                LaunchTimer timer(ctx, "complexity_exact");
+                hipLaunchKernelGGL(complexity_exact_kernel, dim3(grid_for((uint64_t)n_suspect * 64, 256, (unsigned)ctx->n_cu * 8u)), dim3(256), 0,
+                                   ctx->stream, reads->d_words.p, reads->d_word_off.p, reads->d_len.p, d_susp.p, n_suspect,
+                                   m->d_cnt.p, m->d_flags.p, d_ctl.p + CTL_DROPPED);
+                if ((e = memcpy_sync(ctx, &dropped, d_ctl.p + CTL_DROPPED, 8, hipMemcpyDeviceToHost)) != hipSuccess)
+                    return fail(set_error(ctx, MDBG_EHIP, "complexity pass failed: %s", hipGetErrorString(e)));
+            }
+            (void)hipMemsetAsync(m->d_mqual.p, 1, capacity, ctx->stream);     // no qualities: ReadSelection.hpp:1047-1051
+            m->scattered = true;
+            m->owner = ctx;
+            m->n_rows = capacity;        // extent of the row arrays (regions are not filled to the brim)
+            m->n_min = rows - dropped;
+            if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan failed: %s", hipGetErrorString(e)));
+            *out = m;
+            return MDBG_OK;
+        }
+        // not this batch: give the buffers back and take the general path
+        m->d_begin.release(); m->d_cnt.release(); m->d_min.release(); m->d_pos.release(); m->d_dir.release(); m->d_mqual.release();
+    }
+
     if (n) hipLaunchKernelGGL(capacity_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
                               reads->d_len.p, n, p->density, d_cap.p);
     if ((rc = exclusive_scan_u32(ctx, d_cap.p, d_cap_off.p, n))) return fail(rc);
@@ -1332,7 +1433,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         LaunchTimer timer(ctx, "complexity_exact");
         hipLaunchKernelGGL(complexity_exact_kernel, dim3(grid_for((uint64_t)n_suspect * 64, 256, (unsigned)ctx->n_cu * 8u)), dim3(256), 0,
                            ctx->stream, reads->d_words.p, reads->d_word_off.p, reads->d_len.p, d_suspects.p, n_suspect,
-                           d_count.p, m->d_flags.p);
+                           d_count.p, m->d_flags.p, (unsigned long long *)nullptr);
     }
     if (any_low_quality) {
         DevBuf<uint8_t> d_low;
