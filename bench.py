@@ -408,6 +408,18 @@ def main() -> None:
         if shared_reads is None:
             shared_reads = c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)
         slots.append((c, shared_reads))
+    # N > 1: the exchange runs inside the library (RCCL send / receive groups on each context's own stream and communicator:
+    # mdbg_comm_create, mdbg_shard_exchange); MDBG_BENCH_EXCHANGE=torch moves the bytes with torch.distributed instead (and the
+    # gloo test hook always does)
+    comms = None
+    if (world > 1 or force_exchange) and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("MDBG_BENCH_EXCHANGE", "library") == "library":
+        comms = []
+        for c, _ in slots:
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, 0)
+            comms.append(c.comm_create(bytes(t.cpu().numpy().tobytes()), rank, world))
     ctx, reads = slots[0]
     info = ctx.device_info()
     n_bases = reads.info()["n_bases"]
@@ -446,6 +458,22 @@ def main() -> None:
             sent = [int(c) for c in sh.counts]
             with turn:
                 turn.wait_for(lambda: next_exchange[0] >= index)
+            if comms is not None:
+                try:
+                    d_glob = sh.exchange(comms[slot])
+                    mark("exchange")
+                finally:
+                    with turn:
+                        next_exchange[0] = index + 1
+                        turn.notify_all()
+                table = sh.finish(d_glob, 0)
+                sh.free()
+                mark("finish")
+                n_min = mins.info()["n_minimizers"]
+                ti = table.info()
+                for o in (table, corr, mins):
+                    o.free()
+                return n_min, ti
             try:
                 send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
                     torch.empty((0, rw), dtype=torch.int64, device="cuda")
@@ -543,6 +571,7 @@ def main() -> None:
             c.close()
             slots[1] = (capi.Context(local_rank), r)
             slots[1][0].set_option("table_blocks_per_cu", table_blocks)
+            # (the communicator of a slot belongs to the rank, not to the context: comms[1] stays)
     for c, _ in slots:
         c.timing(True)
         c.timing_reset()
@@ -567,7 +596,7 @@ def main() -> None:
 
     names = ["scan", "scan_compact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit"]
     if exchange:
-        names += ["shard_rows", "shard_reduce"]
+        names += ["shard_rows", "shard_reduce", "shard_exchange"]
     ktimes = {k: timing_get(k) for k in names}
     scan_ms, scan_n = ktimes["scan"]
     scan_avg_s = scan_ms / 1e3 / max(scan_n, 1)
@@ -611,7 +640,9 @@ def main() -> None:
                                    "shared by the batches in flight",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
-                       "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"]},
+                       "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
+                       "exchange": (None if not exchange else "library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
+                                    else "torch.distributed all_to_all_single")},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
@@ -638,6 +669,9 @@ def main() -> None:
         if trace and phases:
             out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + n_warm) for k, v in phases.items()}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if comms is not None:
+        for cm in comms:
+            cm.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -248,6 +248,34 @@ int  mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_recv,
 int  mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out);
 void mdbg_shard_free(mdbg_shard *shard);
 
+/* ---- the exchange inside the library: RCCL point-to-point over xGMI -----------------------------------------------
+ * For callers that do not want to move the bytes themselves (the C++ pipeline: src/pipeline has no communication layer).
+ * One communicator per context that takes part; rank 0 makes the id (128 bytes) and hands it to the other ranks by whatever
+ * means it has (a file in the shared tmp dir, a socket, MPI, torch.distributed -- bench.py broadcasts it).  Ranks may be
+ * processes (one per GPU) or threads of one process driving one context each.  RCCL is loaded on first use.
+ *     mdbg_comm_unique_id   ncclGetUniqueId
+ *     mdbg_comm_create      ncclCommInitRank: collective, every rank calls it with the same id
+ *     mdbg_comm_adopt       wraps a communicator the caller already has (an ncclComm_t); mdbg_comm_destroy leaves it alive
+ * mdbg_kminmer_count_first_sharded = mdbg_shard_begin -> rows to their owner ranks -> mdbg_shard_reduce -> replies back ->
+ * mdbg_shard_finish, all on the context's stream; every transfer is an ncclSend / ncclRecv pair inside one group, i.e. an
+ * all-to-all that keeps every xGMI link of the GPU busy.  Collective: every rank of the communicator calls it, in the same
+ * order if a rank drives several communicators.  The union over ranks of the tables equals mdbg_kminmer_count_first over the
+ * union of the reads.  Replaces, across GPUs, KminmerCounter's partition-to-disk + per-partition dereplication
+ * (graph/CreateMdbg.hpp:3714-3724, :3744-3851). */
+typedef struct mdbg_comm mdbg_comm;
+#define MDBG_COMM_ID_BYTES 128
+int  mdbg_comm_unique_id(uint8_t *id128);
+int  mdbg_comm_create(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, mdbg_comm **out);
+int  mdbg_comm_adopt(mdbg_ctx *ctx, void *nccl_comm, int rank, int n_ranks, mdbg_comm **out);
+void mdbg_comm_destroy(mdbg_comm *comm);
+int  mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, const mdbg_minimizers *reads, uint32_t k,
+                                      uint32_t min_abundance, mdbg_table **out);
+/* The collective middle part alone, between mdbg_shard_begin and mdbg_shard_finish (a caller with several batches in flight
+ * overlaps the local halves and takes turns on the wire): d_rows / counts as mdbg_shard_begin returned them; *d_replies (one
+ * u64 per sent row, in the order sent) is what mdbg_shard_finish takes and stays valid until the next exchange on `comm`. */
+int  mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts,
+                         const uint64_t **d_replies);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmdbg_hip.so")
-SOURCES = ["context", "prims", "reads", "scan", "minimizers", "kminmer"]
+SOURCES = ["context", "prims", "reads", "scan", "minimizers", "kminmer", "multigpu"]
 HEADERS = ["common.hpp", "murmur.hpp", "objects.hpp", "table.hpp", os.path.join("..", "..", "include", "mdbg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -50,7 +50,7 @@ def build_lib(force: bool = False, verbose: bool = False, tag: str = "", extra_f
                     raise RuntimeError("hipcc failed for " + cmd[-3])
     objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
     if force or jobs or _stale(lib_path, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             print(r.stdout, r.stderr)

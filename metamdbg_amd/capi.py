@@ -83,6 +83,12 @@ SIGNATURES = {
     "mdbg_shard_reduce": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(_P)]),
     "mdbg_shard_finish": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_shard_free": (None, [_P]),
+    "mdbg_comm_unique_id": (C.c_int, [_P]),
+    "mdbg_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mdbg_comm_adopt": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mdbg_comm_destroy": (None, [_P]),
+    "mdbg_kminmer_count_first_sharded": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_shard_exchange": (C.c_int, [_P, _P, _P, _P, _u64p, C.POINTER(_P)]),
 }
 
 _lib = None
@@ -272,12 +278,43 @@ class Context:
         self.check(lib().mdbg_small_contigs(self.h, unitigs.h, k, k_prev, prev.h, flags.ctypes.data))
         return flags
 
+    # -- the exchange inside the library (RCCL) -----------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = lib().mdbg_comm_unique_id(buf)
+        if rc:
+            raise MdbgError(rc, (lib().mdbg_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_create(self, unique_id: bytes, rank: int, n_ranks: int) -> "Comm":
+        h = C.c_void_p()
+        self.check(lib().mdbg_comm_create(self.h, unique_id, rank, n_ranks, C.byref(h)))
+        return Comm(h)
+
+    def kminmer_count_first_sharded(self, comm: "Comm", m: "Minimizers", k: int = 4, min_abundance: int = 0) -> "Table":
+        h = C.c_void_p()
+        self.check(lib().mdbg_kminmer_count_first_sharded(self.h, comm.h, m.h, k, min_abundance, C.byref(h)))
+        return Table(self, h)
+
     # -- sharded first pass (one process per GPU) ---------------------------------------------------
     def shard_begin(self, m: "Minimizers", k: int, n_ranks: int) -> "Shard":
         h, d_rows = C.c_void_p(), C.c_void_p()
         counts = np.zeros(n_ranks, dtype=np.uint64)
         self.check(lib().mdbg_shard_begin(self.h, m.h, k, n_ranks, C.byref(h), C.byref(d_rows), counts.ctypes.data_as(_u64p)))
         return Shard(self, h, k, d_rows.value or 0, counts)
+
+
+class Comm:
+    """An RCCL communicator owned by the library (mdbg_comm_create)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def destroy(self) -> None:
+        if self.h:
+            lib().mdbg_comm_destroy(self.h)
+            self.h = None
 
 
 class DeviceView:
@@ -304,6 +341,12 @@ class Shard:
         d_reply = C.c_void_p()
         self.ctx.check(lib().mdbg_shard_reduce(self.ctx.h, self.h, C.c_void_p(d_recv), n_recv, C.byref(d_reply)))
         return d_reply.value or 0
+
+    def exchange(self, comm: "Comm") -> int:
+        """Rows to their owners, reduce, replies back (RCCL inside the library): device pointer of the replies for finish()."""
+        d = C.c_void_p()
+        self.ctx.check(lib().mdbg_shard_exchange(self.ctx.h, comm.h, self.h, C.c_void_p(self.d_rows), self.counts.ctypes.data_as(_u64p), C.byref(d)))
+        return d.value or 0
 
     def finish(self, d_replies: int, min_abundance: int) -> "Table":
         h = C.c_void_p()

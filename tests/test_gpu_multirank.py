@@ -40,3 +40,25 @@ def test_two_ranks_equal_one(in_flight):
     assert two["n_gpus"] == 2
     assert two["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
     assert two["config"]["solid"] == one["config"]["solid"] > 0
+
+
+def test_library_rccl_exchange_two_gpus(tmp_path):
+    """Two ranks, two GPUs, RCCL over xGMI inside the library (mdbg_comm_create + mdbg_kminmer_count_first_sharded): the union of
+    the two tables equals the single-GPU table of all reads.  Skipped on a box with one GPU (one rank: tests/test_gpu_parity.py::
+    test_library_exchange_one_rank; RCCL refuses two ranks on one device)."""
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from metamdbg_amd import capi, formats, synth
+    n_total = 4000
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank.py"), str(r), "2", str(tmp_path / "id"),
+                               str(tmp_path / f"rec{r}.npy"), str(n_total)], cwd=ROOT) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    rec = np.concatenate([np.load(tmp_path / f"rec{r}.npy") for r in range(2)])
+    ctx = capi.Context(0)
+    spec = synth.hifi_spec(n_total, seed=23, read_len=6000, coverage=25.0)
+    corr = ctx.purge_palindromes(ctx.scan(ctx.reads_synthetic(spec), K=15, density=0.005, hpc=True), 4, 100)
+    one, _ = ctx.kminmer_count_first(corr, 4, 0).to_host()
+    assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(one))

@@ -803,3 +803,31 @@ def test_edge_indexes_at_first_k_plus_one_vs_reference_log(ctx, name):
     nm, no, _ = formats.parse_unitig_nodes(open(os.path.join(fx["dir"], "unitigGraph.nodes.bin"), "rb").read())
     uedges, _ = ctx.unitig_edge_index(ctx.minimizers_from_host(nm, no), k)
     assert uedges.info()["n_records"] == log["n_unitig_edges"]
+
+
+def test_library_exchange_one_rank(ctx, orc):
+    """The exchange inside the library (mdbg_comm_*, mdbg_shard_exchange, mdbg_kminmer_count_first_sharded: RCCL send / receive
+    groups on the context's stream) with a communicator of one rank: every row is sent to and received from the rank itself
+    through RCCL, and the table must be the single-GPU table.  (Two ranks on two GPUs: tests/test_gpu_multirank.py.)"""
+    from metamdbg_amd import capi
+    spec = synth.hifi_spec(3000, seed=17, read_len=6000, coverage=25.0)
+    reads = ctx.reads_synthetic(spec)
+    corr = ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=True), 4, 100)
+    rec0, vec0 = ctx.kminmer_count_first(corr, 4, 0).to_host()
+    comm = ctx.comm_create(capi.Context.comm_unique_id(), 0, 1)
+    try:
+        for min_ab in (0, 2):
+            exp_rec, exp_vec = (rec0, vec0) if min_ab == 0 else ctx.kminmer_count_first(corr, 4, min_ab).to_host()
+            rec, vec = ctx.kminmer_count_first_sharded(comm, corr, 4, min_ab).to_host()
+            assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(exp_rec))
+            assert np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), 4), formats.sorted_vector_records(exp_vec.astype("<u4").tobytes(), 4))
+        # the same in three calls, as a caller with several batches in flight drives it
+        sh = ctx.shard_begin(corr, 4, 1)
+        rec, vec = sh.finish(sh.exchange(comm), 0).to_host()
+        sh.free()
+        assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(rec0))
+        hc = corr.to_host(full=False)
+        t = orc.kminmer_count_first(hc["minimizers"], hc["offsets"], 4, 0)
+        assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(orc.table_abundance_records(t)))
+    finally:
+        comm.destroy()
