@@ -70,6 +70,10 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     }
     ctx->pool = std::make_shared<DevPool>();
     ctx->pool->device = device;
+    // freed blocks are kept up to a little over half of the HBM (an allocation that fails drops the cache and retries): a
+    // batch of 100 Gbp with qualities turns over tens of GB of scratch per call, and hipFree / hipMalloc of such blocks
+    // cost hundreds of milliseconds
+    if (ctx->hbm_bytes) ctx->pool->cache_limit = std::max<size_t>(ctx->pool->cache_limit, (size_t)((double)ctx->hbm_bytes * 0.55));
     *out = ctx;
     return MDBG_OK;
 } MDBG_API_CATCH((mdbg_ctx *)nullptr)

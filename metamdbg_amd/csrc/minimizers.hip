@@ -135,15 +135,15 @@ __global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *src_
 
 // scattered scan output -> CSR order: values, positions, directions of every read (16 lanes per read)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint64_t *src_begin, const uint64_t *dst_off, uint32_t n_reads,
-                                                          const uint32_t *smin, const uint32_t *spos, const uint8_t *sdir,
-                                                          uint32_t *dmin, uint32_t *dpos, uint8_t *ddir) {
+                                                          const uint32_t *smin, const uint32_t *spos, const uint8_t *sdir, const uint8_t *sq,
+                                                          uint32_t *dmin, uint32_t *dpos, uint8_t *ddir, uint8_t *dq) {
     const unsigned lane = threadIdx.x & 15u;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
     for (uint64_t r = group; r < n_reads; r += ngroups) {
         const uint64_t s = src_begin[r], d = dst_off[r];
         const uint32_t n = (uint32_t)(dst_off[r + 1] - d);
-        for (uint32_t i = lane; i < n; i += 16) { dmin[d + i] = smin[s + i]; dpos[d + i] = spos[s + i]; ddir[d + i] = sdir[s + i]; }
+        for (uint32_t i = lane; i < n; i += 16) { dmin[d + i] = smin[s + i]; dpos[d + i] = spos[s + i]; ddir[d + i] = sdir[s + i]; dq[d + i] = sq[s + i]; }
     }
 }
 
@@ -156,20 +156,22 @@ int ensure_canonical(mdbg_ctx *ctx, const mdbg_minimizers *cm) {
     MDBG_TRY(m->d_off.alloc(c, (size_t)n + 1));
     MDBG_TRY(exclusive_scan_u32(c, m->d_cnt.p, m->d_off.p, n));
     DevBuf<uint32_t> nmin, npos;
-    DevBuf<uint8_t> ndir;
+    DevBuf<uint8_t> ndir, nq;
     MDBG_TRY(nmin.alloc(c, m->n_min));
     MDBG_TRY(npos.alloc(c, m->n_min));
     MDBG_TRY(ndir.alloc(c, m->n_min));
+    MDBG_TRY(nq.alloc(c, m->n_min));
     if (n) {
         LaunchTimer timer(c, "scan_compact");
         unsigned blocks = grid_for((uint64_t)n * 16, 256, (unsigned)c->n_cu * 32u);
         hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, m->d_begin.p, m->d_off.p, n, m->d_min.p, m->d_pos.p,
-                           m->d_dir.p, nmin.p, npos.p, ndir.p);
+                           m->d_dir.p, m->d_mqual.p, nmin.p, npos.p, ndir.p, nq.p);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));   // the old rows go back to the pool; other contexts may read the object next
     m->d_min = std::move(nmin);
     m->d_pos = std::move(npos);
     m->d_dir = std::move(ndir);
+    m->d_mqual = std::move(nq);
     m->d_begin.release();
     m->d_cnt.release();
     m->scattered = false;

@@ -249,7 +249,7 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
     uint32_t any = 0;
     CK(hipMemcpyAsync(&any, d_any.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (quals && nb) {
-        if ((rc = r->d_qual.alloc(ctx, nb)) || (rc = r->d_qual_off.alloc(ctx, (size_t)n_reads + 1))) return fail(rc);
+        if ((rc = r->d_qual.alloc(ctx, nb + 32)) || (rc = r->d_qual_off.alloc(ctx, (size_t)n_reads + 1))) return fail(rc);   // + 32: kernels read whole 16-byte pieces
         CK(hipMemcpyAsync(r->d_qual.p, quals + offsets[0], nb, hipMemcpyHostToDevice, ctx->stream));
         CK(hipMemcpyAsync(r->d_qual_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         r->has_qual = true;
@@ -313,7 +313,7 @@ extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const c
         if (rel[i + 1] - rel[i] != lens[i]) return set_error(ctx, MDBG_EINVAL, "read %u: %llu qualities for %u bases", i,
                                                             (unsigned long long)(rel[i + 1] - rel[i]), lens[i]);
     const uint64_t nb = rel[n];
-    MDBG_TRY(r->d_qual.alloc(ctx, nb));
+    MDBG_TRY(r->d_qual.alloc(ctx, nb + 32));
     MDBG_TRY(r->d_qual_off.alloc(ctx, (size_t)n + 1));
     if (nb) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(r->d_qual.p, quals + offsets[0], nb, hipMemcpyHostToDevice, ctx->stream));
     MDBG_HIP_CHECK(ctx, hipMemcpyAsync(r->d_qual_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -354,7 +354,7 @@ extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_rea
         (rc = d_soff.alloc(ctx, (size_t)n_species + 1)) || (rc = d_sthr.alloc(ctx, n_species)))
         return fail(rc);
     if (with_quality) {
-        if ((rc = r->d_qual.alloc(ctx, r->n_bases)) || (rc = r->d_qual_off.alloc(ctx, (size_t)n_reads + 1))) return fail(rc);
+        if ((rc = r->d_qual.alloc(ctx, r->n_bases + 32)) || (rc = r->d_qual_off.alloc(ctx, (size_t)n_reads + 1))) return fail(rc);
         r->has_qual = true;
     }
     hipError_t e;

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 
 namespace mdbg {
 
@@ -780,8 +781,13 @@ __device__ __forceinline__ uint32_t ring_window(const uint32_t *S, unsigned p) {
     return __builtin_amdgcn_alignbit(S[(w + 1) & RING_WMASK], S[w], sh);
 }
 
-template <bool HPC>
+// QUAL (reads with qualities; without homopolymer compression only, where original and compressed coordinates coincide): the
+// minimum quality over every minimizer's bases (getMinQuality, ReadSelection.hpp:1302-1320; ReadCorrection.hpp:2467-2481) is
+// taken when the minimizer is materialised and travels with its row.
+template <bool HPC, bool QUAL>
 __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
+    static_assert(!(HPC && QUAL), "qualities under homopolymer compression take the general kernel");
+    __shared__ uint8_t lds_stage_q[QUAL ? FAST_WAVES : 1][QUAL ? STAGE_CAP : 1];
     __shared__ uint32_t lds_ring[FAST_WAVES][RING_WORDS];
     __shared__ uint2 lds_stage[FAST_WAVES][STAGE_CAP];
     __shared__ uint16_t lds_lut[HPC ? HPC_LUT_SIZE : 1];
@@ -794,6 +800,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *S = lds_ring[wv];
     uint2 *stage = lds_stage[wv];
+    uint8_t *stage_q = lds_stage_q[QUAL ? wv : 0];
     const unsigned K = a.K;
     const uint32_t kmask = (K >= 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
     const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
@@ -812,6 +819,21 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
         const uint64_t cap0 = bump ? 0ull : a.cap_off[r];
         const uint32_t cap = bump ? 0u : (uint32_t)(a.cap_off[r + 1] - cap0);
         bool outgrown = false;     // bump mode: the read selected more than the stage holds -> listed, re-run by the host
+
+        const uint8_t *qq = QUAL ? a.qual + a.qual_off[r] : nullptr;
+        auto min_quality = [&](uint32_t j) {       // the l bases of the l-mer at j (no HPC: [rle[pos], rle[pos + l]) = [j, j + l))
+            // l <= 16 bytes in two unaligned 8-byte loads (the quality buffer is padded by 16 bytes at both ends) instead of a
+            // chain of l dependent byte loads: a selected lane would otherwise wait longer than its whole block took to hash
+            uint64_t w[2];
+            __builtin_memcpy(w, qq + j, 16);
+            uint8_t mq = 255;
+#pragma unroll
+            for (unsigned b = 0; b < 16; b++) {
+                const uint8_t q = (uint8_t)((uint8_t)(w[b >> 3] >> (8 * (b & 7))) - 33);
+                if (b < K && q < mq) mq = q;
+            }
+            return mq;
+        };
 
         uint32_t fill = 0;         // compressed bases written to the ring so far (= stream length)
         uint32_t done = 0;         // positions already evaluated (= ring position of the next block, a multiple of 2048)
@@ -857,6 +879,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     if (idx < cap) {
                         const uint2 e = stage[i];
                         a.out_min[cap0 + idx] = e.x; a.out_pos[cap0 + idx] = e.y >> 1; a.out_dir[cap0 + idx] = (uint8_t)(e.y & 1u);
+                        if (QUAL) a.out_mqual[cap0 + idx] = stage_q[i];
                     }
                 }
                 flushed = nout;
@@ -873,6 +896,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
                     // direction 1 iff the reverse complement is the canonical form, ties included (Kmer.hpp:427)
                     const uint32_t d = fw < rev ? 0u : 1u;
+                    if (QUAL) stage_q[at] = min_quality(j);
                     stage[at++] = make_uint2(d ? rev : fw, (j << 1) | d);
                 }
             } else {
@@ -886,12 +910,41 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     const uint32_t e = ring_window(S, j) & kmask;
                     const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
                     const uint32_t d = fw < rev ? 0u : 1u;
-                    if (at < cap) { a.out_min[cap0 + at] = d ? rev : fw; a.out_pos[cap0 + at] = j; a.out_dir[cap0 + at] = (uint8_t)d; }
+                    if (at < cap) {
+                        a.out_min[cap0 + at] = d ? rev : fw; a.out_pos[cap0 + at] = j; a.out_dir[cap0 + at] = (uint8_t)d;
+                        if (QUAL) a.out_mqual[cap0 + at] = min_quality(j);
+                    }
                     at++;
                 }
                 flushed = nout + total;
             }
             nout += total;
+        };
+
+        // ---- 64 * SP positions from `done` on, each followed by a known base: lane l owns positions SP l .. SP l + SP - 1, i.e.
+        // 2 SP stream bits that start on a word boundary of the ring; walked in registers with compile-time shifts ----
+        auto aligned_block = [&](auto sp_tag) {
+            constexpr int SP = decltype(sp_tag)::value;              // 32 or 16
+            constexpr unsigned WPL = (unsigned)SP / 16u;               // stream words per lane
+            const unsigned wb = ((done >> 4) + WPL * lane) & RING_WMASK;
+            const uint32_t W0 = S[wb], W1 = S[(wb + 1) & RING_WMASK], W2 = SP > 16 ? S[(wb + 2) & RING_WMASK] : 0u;
+            SpanState st{0u, 0u};
+#pragma unroll
+            for (int u = 0; u < SP; u++) {
+                const uint32_t T = u == 0 ? W0 : (u < 16 ? __builtin_amdgcn_alignbit(W1, W0, 2 * u)
+                                                         : (u == 16 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * (u - 16))));
+                span_step(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold);
+            }
+            emit(st.bits, (unsigned)SP, 64u * (unsigned)SP);
+            wave_lds_sync();
+            // the block's bases are not needed any more: back to zero for the next lap of the ring
+            {
+                const unsigned zb = (done >> 4);
+                S[(zb + lane) & RING_WMASK] = 0;
+                if (SP > 16) S[(zb + 64u + lane) & RING_WMASK] = 0;
+            }
+            done += 64u * (unsigned)SP;
+            wave_lds_sync();
         };
 
         uint64_t x_next = (lane < nwords) ? rw[lane] : 0;
@@ -957,28 +1010,10 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             wave_lds_sync();
 
             // ---- full blocks: 2048 positions, every one followed by a known base ----
-            while (fill - done >= BLOCK_POS + K + 1u) {
-                const unsigned wb = ((done >> 4) + 2u * lane) & RING_WMASK;
-                const uint32_t W0 = S[wb], W1 = S[(wb + 1) & RING_WMASK], W2 = S[(wb + 2) & RING_WMASK];
-                SpanState st{0u, 0u};
-#pragma unroll
-                for (int u = 0; u < (int)SPAN; u++) {
-                    const uint32_t T = u == 0 ? W0 : (u < 16 ? __builtin_amdgcn_alignbit(W1, W0, 2 * u)
-                                                             : (u == 16 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * (u - 16))));
-                    span_step(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold);
-                }
-                emit(st.bits, SPAN, BLOCK_POS);
-                wave_lds_sync();
-                // the block's bases are not needed any more: back to zero for the next lap of the ring
-                {
-                    const unsigned zb = (done >> 4);
-                    S[(zb + lane) & RING_WMASK] = 0;
-                    S[(zb + 64u + lane) & RING_WMASK] = 0;
-                }
-                done += BLOCK_POS;
-                wave_lds_sync();
-            }
+            while (fill - done >= BLOCK_POS + K + 1u) aligned_block(std::integral_constant<int, (int)SPAN>());
         }
+        // (a last half block of 1024 positions, 16 per lane, before the tail was measured: 11.73 against 11.76 ms -- the tail's
+        // positions cost about what a block's do; not kept)
 
         // ---- tail: the positions left (each followed by a known base; with _trimBps == 0 also the last l-mer) ----
         {
@@ -1029,6 +1064,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     for (uint32_t i = lane; i < nout; i += 64) {
                         const uint2 e = stage[i];
                         a.out_min[start + i] = e.x; a.out_pos[start + i] = e.y >> 1; a.out_dir[start + i] = (uint8_t)(e.y & 1u);
+                        if (QUAL) a.out_mqual[start + i] = stage_q[i];
                     }
                 }
             }
@@ -1046,6 +1082,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 if (idx < cap) {
                     const uint2 e = stage[i];
                     a.out_min[cap0 + idx] = e.x; a.out_pos[cap0 + idx] = e.y >> 1; a.out_dir[cap0 + idx] = (uint8_t)(e.y & 1u);
+                    if (QUAL) a.out_mqual[cap0 + idx] = stage_q[i];
                 }
             }
             if (lane == 0) {
@@ -1162,9 +1199,13 @@ __global__ void post_scan_lists_kernel(const uint32_t *count, const uint32_t *ca
     if (flags[i] & READ_SUSPECT) suspect_list[atomicAdd(&counters[1], 1u)] = (uint32_t)i;
 }
 
-__global__ void apply_low_quality_kernel(const uint8_t *low, uint32_t n_reads, uint32_t *count, uint8_t *flags) {
+__global__ void apply_low_quality_kernel(const uint8_t *low, uint32_t n_reads, uint32_t *count, uint8_t *flags,
+                                         unsigned long long *dropped /* may be null: sum of the counts cleared */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_reads && low[i]) { count[i] = 0; flags[i] |= (uint8_t)MDBG_READ_LOW_QUALITY; }
+    if (i < n_reads && low[i]) {
+        if (dropped && count[i]) atomicAdd(dropped, (unsigned long long)count[i]);
+        count[i] = 0; flags[i] |= (uint8_t)MDBG_READ_LOW_QUALITY;
+    }
 }
 
 }  // namespace mdbg
@@ -1209,14 +1250,15 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
     {
         LaunchTimer timer(ctx, "scan");
         static const bool no_fast = getenv("MDBG_SCAN_NO_FAST") != nullptr;      // A/B: the general kernel for everything
-        if (!has_q && !has_n && !a.subset && !no_fast) {
+        if ((!has_q || (!hpc && a.cursor)) && !has_n && !a.subset && !no_fast) {
             // plain ACGT without qualities: the block-structured kernel; a few reads per wave, then the wave retires
             const uint64_t per_wave = ctx->scan_reads_per_wave;
             uint64_t blocks = ((uint64_t)n_items + FAST_WAVES * per_wave - 1) / (FAST_WAVES * per_wave);
             if (blocks < 1) blocks = 1;
             if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
-            if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((scan_fast_kernel<false>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
+            if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
+            else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((scan_fast_kernel<false, false>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
         } else if (hpc) {
             if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }
             else { if (has_q) launch_variant<true, true, false>(ctx, a, max_blocks, n_items); else launch_variant<true, false, false>(ctx, a, max_blocks, n_items); }
@@ -1320,7 +1362,9 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // (mdbg_minimizers::scattered); one read-back instead of four.  Batches it cannot take -- a read selecting more than the
     // LDS stage holds, more rows than the estimate allowed for -- go through the general path below.
     static const bool no_bump = getenv("MDBG_SCAN_NO_BUMP") != nullptr || getenv("MDBG_SCAN_NO_FAST") != nullptr;
-    if (n && !has_q && !has_n && !no_bump && p->density < 0.2f) {
+    // (a read may stage STAGE_CAP minimizers: batches whose longest read is expected to select more go straight to the general path)
+    if (n && (!has_q || !hpc) && !has_n && !no_bump && p->density < 0.2f &&
+        (double)reads->max_len * (double)p->density * (hpc ? 0.8 : 1.0) * 1.4 + 24.0 < (double)STAGE_CAP) {
         // the output arrays are cut into regions, each with its own cursor (reads are dealt to the waves round-robin, so the regions
         // fill evenly); small batches use one
         uint32_t n_regions = 1;
@@ -1337,19 +1381,21 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         (void)hipMemsetAsync(d_ctl.p, 0, CTL_WORDS * 8, ctx->stream);
         ScanArgs a{};
         a.words = reads->d_words.p; a.word_off = reads->d_word_off.p; a.len = reads->d_len.p;
+        a.qual = has_q ? reads->d_qual.p : nullptr;
+        a.qual_off = has_q ? reads->d_qual_off.p : nullptr;
         a.K = p->minimizer_size;
         a.threshold = density_threshold(p->density);
         a.trim = p->no_end_trim ? 0u : 1u;
         a.rep = d_rep.p; a.n_rep = p->n_repetitive;
         a.apply_filters = p->apply_read_filters;
-        a.out_min = m->d_min.p; a.out_pos = m->d_pos.p; a.out_dir = m->d_dir.p;
+        a.out_min = m->d_min.p; a.out_pos = m->d_pos.p; a.out_dir = m->d_dir.p; a.out_mqual = m->d_mqual.p;
         a.out_count = m->d_cnt.p; a.out_flags = m->d_flags.p;
         a.cursor = d_ctl.p; a.n_regions = n_regions; a.out_capacity = region_cap; a.out_begin = m->d_begin.p;
         a.over_list = d_over.p; a.suspect_list = d_susp.p; a.list_counters = (uint32_t *)(d_ctl.p + CTL_OVER);
         unsigned long long h_ctl[CTL_WORDS];
         {
             std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));      // one scan kernel at a time per device (see below)
-            if ((rc = launch_scan(ctx, a, hpc, false, false, n))) return fail(rc);
+            if ((rc = launch_scan(ctx, a, hpc, has_q, false, n))) return fail(rc);
             e = memcpy_sync(ctx, h_ctl, d_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost);
         }
         if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan counters copy failed: %s", hipGetErrorString(e)));
@@ -1367,7 +1413,17 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
                 if ((e = memcpy_sync(ctx, &dropped, d_ctl.p + CTL_DROPPED, 8, hipMemcpyDeviceToHost)) != hipSuccess)
                     return fail(set_error(ctx, MDBG_EHIP, "complexity pass failed: %s", hipGetErrorString(e)));
             }
-            (void)hipMemsetAsync(m->d_mqual.p, 1, capacity, ctx->stream);     // no qualities: ReadSelection.hpp:1047-1051
+            if (any_low_quality) {          // reads below --min-read-quality keep their (empty) record (ReadSelection.hpp:901-909)
+                DevBuf<uint8_t> d_low;
+                if ((rc = d_low.alloc(ctx, n))) return fail(rc);
+                if ((e = memcpy_sync(ctx, d_low.p, low_quality.data(), n, hipMemcpyHostToDevice)) != hipSuccess)
+                    return fail(set_error(ctx, MDBG_EHIP, "low-quality flags upload failed: %s", hipGetErrorString(e)));
+                hipLaunchKernelGGL(apply_low_quality_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_low.p, n, m->d_cnt.p, m->d_flags.p,
+                                   d_ctl.p + CTL_DROPPED);
+                if ((e = memcpy_sync(ctx, &dropped, d_ctl.p + CTL_DROPPED, 8, hipMemcpyDeviceToHost)) != hipSuccess)
+                    return fail(set_error(ctx, MDBG_EHIP, "low-quality pass failed: %s", hipGetErrorString(e)));
+            }
+            if (!has_q) (void)hipMemsetAsync(m->d_mqual.p, 1, capacity, ctx->stream);     // no qualities: ReadSelection.hpp:1047-1051
             m->scattered = true;
             m->owner = ctx;
             m->n_rows = capacity;        // extent of the row arrays (regions are not filled to the brim)
@@ -1440,7 +1496,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         if ((rc = d_low.alloc(ctx, n))) return fail(rc);
         if ((e = memcpy_sync(ctx, d_low.p, low_quality.data(), n, hipMemcpyHostToDevice)) != hipSuccess)
             return fail(set_error(ctx, MDBG_EHIP, "low-quality flags upload failed: %s", hipGetErrorString(e)));
-        hipLaunchKernelGGL(apply_low_quality_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_low.p, n, d_count.p, m->d_flags.p);
+        hipLaunchKernelGGL(apply_low_quality_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_low.p, n, d_count.p, m->d_flags.p, (unsigned long long *)nullptr);
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "low-quality pass failed"));
     }
 
