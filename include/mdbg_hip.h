@@ -247,6 +247,19 @@ int  mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_recv,
 /* d_replies: n_sent u64, the replies for the rows of mdbg_shard_begin in the order they were sent. */
 int  mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out);
 void mdbg_shard_free(mdbg_shard *shard);
+/* Sharded k > firstK (the refined pass and the index passes, graph/CreateMdbg.cpp:391-468).  The abundance of a k-min-mer at
+ * these k is a function of the key and the previous table, not of a count, so nothing is summed: every rank holds the whole
+ * previous table (20 bytes per key: a few hundred MB at 40 M reads -- all-gather the records of the previous step and load them
+ * with mdbg_prev_from_records), runs mdbg_kminmer_count_refined / mdbg_kminmer_index over ITS reads, and the ranks then only
+ * agree on who lists a key that several of them found:
+ *     mdbg_shard_from_table  rows [hash_lo, hash_hi, abundance] of the local table grouped by owner           (send: all-to-all)
+ *     mdbg_shard_reduce      the owner marks the first row of every key (bit 63 of its reply), as in the first pass
+ *     mdbg_shard_keep        the rows this rank was told to list, vectors included when the table has them
+ * The union over ranks of the kept tables equals the single-GPU table over the union of the reads.  `local` must stay alive
+ * until mdbg_shard_free; the exchange in between is mdbg_shard_exchange or the caller's own. */
+int  mdbg_shard_from_table(mdbg_ctx *ctx, const mdbg_table *local, uint32_t n_ranks, mdbg_shard **shard, const uint64_t **d_rows,
+                           uint64_t *counts);
+int  mdbg_shard_keep(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_replies, mdbg_table **out);
 
 /* ---- the exchange inside the library: RCCL point-to-point over xGMI -----------------------------------------------
  * For callers that do not want to move the bytes themselves (the C++ pipeline: src/pipeline has no communication layer).

@@ -83,6 +83,8 @@ SIGNATURES = {
     "mdbg_shard_reduce": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(_P)]),
     "mdbg_shard_finish": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_shard_free": (None, [_P]),
+    "mdbg_shard_from_table": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P), C.POINTER(_P), _u64p]),
+    "mdbg_shard_keep": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
     "mdbg_comm_unique_id": (C.c_int, [_P]),
     "mdbg_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "mdbg_comm_adopt": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -298,6 +300,13 @@ class Context:
         return Table(self, h)
 
     # -- sharded first pass (one process per GPU) ---------------------------------------------------
+    def shard_from_table(self, local: "Table", n_ranks: int) -> "Shard":
+        """Sharded k > firstK: the rows of a local refined / index table grouped by owner rank (reduce -> keep)."""
+        h, d_rows = C.c_void_p(), C.c_void_p()
+        counts = np.zeros(n_ranks, dtype=np.uint64)
+        self.check(lib().mdbg_shard_from_table(self.h, local.h, n_ranks, C.byref(h), C.byref(d_rows), counts.ctypes.data_as(_u64p)))
+        return Shard(self, h, local.info()["k"], d_rows.value or 0, counts)
+
     def shard_begin(self, m: "Minimizers", k: int, n_ranks: int) -> "Shard":
         h, d_rows = C.c_void_p(), C.c_void_p()
         counts = np.zeros(n_ranks, dtype=np.uint64)
@@ -351,6 +360,12 @@ class Shard:
     def finish(self, d_replies: int, min_abundance: int) -> "Table":
         h = C.c_void_p()
         self.ctx.check(lib().mdbg_shard_finish(self.ctx.h, self.h, C.c_void_p(d_replies), min_abundance, C.byref(h)))
+        return Table(self.ctx, h)
+
+    def keep(self, d_replies: int) -> "Table":
+        """Sharded k > firstK: the rows of the local table this rank was told to list."""
+        h = C.c_void_p()
+        self.ctx.check(lib().mdbg_shard_keep(self.ctx.h, self.h, C.c_void_p(d_replies), C.byref(h)))
         return Table(self.ctx, h)
 
     def free(self):

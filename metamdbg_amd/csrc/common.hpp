@@ -116,7 +116,9 @@ struct mdbg_ctx {
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
     unsigned table_blocks_per_cu = 1024;                   // resident blocks per CU of the kernels that walk every k-min-mer instance (mdbg_set_option)
     unsigned scan_reads_per_wave = 2;                      // reads a scan wave processes before it retires (mdbg_set_option)
-    double key_ratio_hint = 0.0625;                        // distinct keys per k-min-mer instance seen last time (table sizing)
+    // distinct keys per k-min-mer instance seen by the last call OF THE SAME KIND (table sizing): the first pass keeps every
+    // key, refined / index only those above abundance 1 -- one shared hint made every first pass after an index pass rebuild its table
+    double key_ratio_hint[4] = {0.0625, 0.0625, 0.0625, 0.0625};   // [0] first pass, [1] refined, [2] index, [3] sharded first pass
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out
 };
 

@@ -517,8 +517,8 @@ static uint32_t rescue_m_star() {
 
 // Size the next table of this kind for the distinct keys just seen (+12.5 %): build_table_adaptive doubles that and
 // rounds up to a power of two, i.e. 25-45 % load.
-static void update_key_hint(mdbg_ctx *ctx, uint64_t distinct, uint64_t instances) {
-    if (instances) ctx->key_ratio_hint = 1.125 * (double)distinct / (double)instances;
+static void update_key_hint(mdbg_ctx *ctx, int kind, uint64_t distinct, uint64_t instances) {
+    if (instances) ctx->key_ratio_hint[kind] = 1.125 * (double)distinct / (double)instances;
 }
 
 struct InstIndex {
@@ -613,7 +613,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     MDBG_TRY(inst_slot.alloc(ctx, I));
     // distinct keys are usually a small fraction of the instances (coverage): start small so the table
     // stays cache-resident, grow and rebuild when a probe sequence gets long
-    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint[0]), I, [&](TableView v) {
         if (I) {
             LaunchTimer timer(ctx, "kminmer_insert");
             hipLaunchKernelGGL(count_insert_kernel, dim3(instance_grid(ctx, sv.n_reads)), dim3(256), 0, ctx->stream, sv, k, v, inst_slot.p, (uint64_t)0);
@@ -641,7 +641,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     uint64_t n_solid = 0, n_resc = 0, n_keys = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_solid, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     MDBG_TRY(tab.occupied(ctx, &n_keys));
-    update_key_hint(ctx, n_keys, I);
+    update_key_hint(ctx, 0, n_keys, I);
 
     if (do_rescue) {
         MDBG_TRY(plan_rescue(ctx, tab, ix, reads->n_reads, inst_slot.p, plan));
@@ -749,7 +749,7 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     if (I >= (1ull << 32) || a.n_min + b.n_min >= (1ull << 32))
         return set_error(ctx, MDBG_ERANGE, "more than 2^32 minimizers / k-min-mer instances in one call");
     DeviceTable tab;
-    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint[1]), I, [&](TableView v) {
         LaunchTimer timer(ctx, "kminmer_insert");
         if (a.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, a.n_reads)), dim3(256), 0, ctx->stream, a, k, v, (uint64_t)0);
         if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, b.n_reads)), dim3(256), 0, ctx->stream, b, k, v, a.n_min);
@@ -771,7 +771,7 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     {
         uint64_t n_keys = 0;
         MDBG_TRY(tab.occupied(ctx, &n_keys));
-        update_key_hint(ctx, n_keys, I);
+        update_key_hint(ctx, 1, n_keys, I);
     }
     uint64_t n_rows = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
@@ -822,7 +822,7 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     // upper bound on distinct keys: total k-windows
     uint64_t bound = reads->n_min + (unitigs ? unitigs->n_min : 0);
     DeviceTable tab;
-    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)bound * ctx->key_ratio_hint), bound, [&](TableView v) {
+    MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)bound * ctx->key_ratio_hint[2]), bound, [&](TableView v) {
         MDBG_TRY(index_one_set(ctx, reads, k, pv, v));
         if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, v));
         return MDBG_OK;
@@ -837,7 +837,7 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
     uint64_t n_rows = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
-    update_key_hint(ctx, n_rows, bound);   // every occupied slot is a row
+    update_key_hint(ctx, 2, n_rows, bound);   // every occupied slot is a row
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_rows;
@@ -1096,11 +1096,58 @@ __global__ __launch_bounds__(256) void apply_global_counts_kernel(const uint64_t
     else { t.slots[s].val = v; flag[s] = emit ? 1u : 0u; }
 }
 
+// ---- the same grouping by owner for the rows of a finished local table (sharded k > firstK) ----
+constexpr uint32_t SHARD_RPB = 2048;   // rows per block
+
+__global__ __launch_bounds__(256) void table_owner_hist_kernel(const uint64_t *hi, uint64_t n, uint32_t n_ranks, uint32_t *block_hist) {
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * SHARD_RPB;
+    for (uint32_t j = threadIdx.x; j < SHARD_RPB; j += 256)
+        if (r0 + j < n) atomicAdd(&h[owner_of(hi[r0 + j], n_ranks)], 1u);
+    __syncthreads();
+    if (threadIdx.x < n_ranks) block_hist[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void table_owner_scatter_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *ab, uint64_t n,
+                                                                  uint32_t n_ranks, const uint64_t *block_base, uint64_t *rows, uint32_t *row_index) {
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * SHARD_RPB;
+    for (uint32_t j = threadIdx.x; j < SHARD_RPB; j += 256) {
+        const uint64_t i = r0 + j;
+        if (i >= n) continue;
+        const uint32_t own = owner_of(hi[i], n_ranks);
+        const uint64_t row = block_base[(uint64_t)own * gridDim.x + blockIdx.x] + atomicAdd(&h[own], 1u);
+        uint64_t *o = rows + row * SHARD_ROW_WORDS;
+        o[0] = lo[i]; o[1] = hi[i]; o[2] = ab[i];
+        row_index[row] = (uint32_t)i;
+    }
+}
+
+__global__ void keep_flag_kernel(const uint64_t *reply, const uint32_t *row_index, uint64_t n, uint32_t *flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[row_index[i]] = (reply[i] & SHARD_EMIT_BIT) ? 1u : 0u;
+}
+
+__global__ void keep_rows_kernel(const uint32_t *flag, const uint64_t *pos, uint64_t n, uint32_t k, const uint64_t *lo, const uint64_t *hi,
+                                 const uint32_t *ab, const uint32_t *vec, uint64_t *olo, uint64_t *ohi, uint32_t *oab, uint32_t *ovec) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint64_t d = pos[i];
+    olo[d] = lo[i]; ohi[d] = hi[i]; oab[d] = ab[i];
+    if (vec) for (uint32_t j = 0; j < k; j++) ovec[d * k + j] = vec[i * k + j];
+}
+
 }  // namespace mdbg
 
 struct mdbg_shard {
     uint32_t k = 0, n_ranks = 1;
     const mdbg_minimizers *reads = nullptr;
+    const mdbg_table *table = nullptr;       // mdbg_shard_from_table: the local table whose rows are being deduplicated
+    mdbg::DevBuf<uint32_t> row_index;        // ... and the table row every sent row came from
     mdbg::InstIndex ix;
     mdbg::DeviceTable local, owner;
     mdbg::DevBuf<uint32_t> inst_slot, row_slot;
@@ -1123,7 +1170,7 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     const uint64_t I = sh->ix.total;
     SeqView sv = make_view(reads, sh->ix);
     MDBG_TRY(sh->inst_slot.alloc(ctx, I));
-    MDBG_TRY(build_table_adaptive(ctx, sh->local, (uint64_t)((double)I * ctx->key_ratio_hint), I, [&](TableView v) {
+    MDBG_TRY(build_table_adaptive(ctx, sh->local, (uint64_t)((double)I * ctx->key_ratio_hint[3]), I, [&](TableView v) {
         if (I) {
             LaunchTimer timer(ctx, "kminmer_insert");
             hipLaunchKernelGGL(count_insert_kernel, dim3(instance_grid(ctx, sv.n_reads)), dim3(256), 0, ctx->stream, sv, k, v, sh->inst_slot.p, (uint64_t)0);
@@ -1148,7 +1195,7 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     for (uint32_t r = 0; r < n_ranks; r++) counts[r] = base[(uint64_t)(r + 1) * nb] - base[(uint64_t)r * nb];
     const uint64_t total = base[nh];
     if (total >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 distinct local keys");
-    update_key_hint(ctx, total, I);        // one row per distinct local key
+    update_key_hint(ctx, 3, total, I);        // one row per distinct local key
     MDBG_TRY(sh->rows.alloc(ctx, total * SHARD_ROW_WORDS));
     MDBG_TRY(sh->row_slot.alloc(ctx, total));
     sh->n_rows = total;
@@ -1231,6 +1278,70 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "mdbg_shard_finish failed: %s", hipGetErrorString(e)); }
     *out = t;
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+// ---- sharded k > firstK -------------------------------------------------------------------------------------------
+extern "C" int mdbg_shard_from_table(mdbg_ctx *ctx, const mdbg_table *local, uint32_t n_ranks, mdbg_shard **out, const uint64_t **d_rows,
+                                     uint64_t *counts) try {
+    if (!ctx || !local || !out || !d_rows || !counts || n_ranks < 1 || n_ranks > 64)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_shard_from_table: bad argument");
+    if (local->n_records >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "mdbg_shard_from_table: more than 2^32 rows");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<mdbg_shard> sh(new mdbg_shard());
+    sh->k = local->k; sh->n_ranks = n_ranks; sh->table = local;
+    const uint64_t n = local->n_records;
+    const unsigned nb = grid_for(n, SHARD_RPB);
+    const uint64_t nh = (uint64_t)nb * n_ranks;
+    DevBuf<uint32_t> block_hist;
+    DevBuf<uint64_t> block_base;
+    MDBG_TRY(block_hist.alloc(ctx, nh));
+    MDBG_TRY(block_base.alloc(ctx, nh + 1));
+    {
+        LaunchTimer timer(ctx, "shard_rows");
+        hipLaunchKernelGGL(table_owner_hist_kernel, dim3(nb), dim3(256), 0, ctx->stream, local->d_hi.p, n, n_ranks, block_hist.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, block_hist.p, block_base.p, nh));
+    std::vector<uint64_t> base(nh + 1);
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, base.data(), block_base.p, (nh + 1) * 8, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_ranks; r++) counts[r] = base[(uint64_t)(r + 1) * nb] - base[(uint64_t)r * nb];
+    MDBG_TRY(sh->rows.alloc(ctx, n * SHARD_ROW_WORDS));
+    MDBG_TRY(sh->row_index.alloc(ctx, n));
+    sh->n_rows = n;
+    {
+        LaunchTimer timer(ctx, "shard_rows");
+        hipLaunchKernelGGL(table_owner_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, local->d_lo.p, local->d_hi.p, local->d_ab.p, n, n_ranks,
+                           block_base.p, sh->rows.p, sh->row_index.p);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *d_rows = sh->rows.p;
+    *out = sh.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_shard_keep(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_replies, mdbg_table **out) try {
+    if (!ctx || !sh || !out || !sh->table || (sh->n_rows && !d_replies)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_keep: bad argument");
+    if (!sh->reduced) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_keep: mdbg_shard_reduce has not run");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const mdbg_table *src = sh->table;
+    const uint64_t n = sh->n_rows;
+    DevBuf<uint32_t> flag;
+    DevBuf<uint64_t> pos;
+    MDBG_TRY(flag.alloc(ctx, n));
+    MDBG_TRY(pos.alloc(ctx, n + 1));
+    if (n) hipLaunchKernelGGL(keep_flag_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_replies, sh->row_index.p, n, flag.p);
+    MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, n));
+    uint64_t kept = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &kept, pos.p + n, 8, hipMemcpyDeviceToHost));
+    std::unique_ptr<mdbg_table> t(new mdbg_table());
+    t->k = src->k;
+    MDBG_TRY(alloc_rows(ctx, t.get(), kept, src->has_vectors));
+    t->n_solid = kept;
+    if (n) hipLaunchKernelGGL(keep_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, flag.p, pos.p, n, src->k, src->d_lo.p, src->d_hi.p,
+                              src->d_ab.p, src->has_vectors ? src->d_vec.p : nullptr, t->d_lo.p, t->d_hi.p, t->d_ab.p,
+                              src->has_vectors ? t->d_vec.p : nullptr);
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = t.release();
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 

@@ -49,3 +49,55 @@ def reply_to_senders(reply: torch.Tensor, recv_counts: list[int], sent_counts: l
     out = torch.empty((sum(sent_counts),) + tuple(reply.shape[1:]), dtype=reply.dtype, device=reply.device)
     _all_to_all(out, reply, list(sent_counts), list(recv_counts), group)
     return out
+
+
+# ---- whole sharded passes over torch.distributed (the harness's counterpart of mdbg_kminmer_count_first_sharded) ----------
+def _device_rows(ptr: int, shape: tuple) -> torch.Tensor:
+    from . import capi
+    n = 1
+    for s in shape:
+        n *= s
+    if n == 0:
+        return torch.empty(shape, dtype=torch.int64, device="cuda")
+    return torch.as_tensor(capi.DeviceView(ptr, shape), device="cuda")
+
+
+def _exchange_shard(sh, finish, group=None):
+    """rows of `sh` to their owners, mdbg_shard_reduce there, replies back; finish(device pointer of the replies) -> table."""
+    rw = sh.row_words
+    sent = [int(c) for c in sh.counts]
+    mine, got = exchange_by_owner(_device_rows(sh.d_rows, (sh.n_rows, rw)), sent, group)
+    torch.cuda.current_stream().synchronize()
+    d_reply = sh.reduce(mine.data_ptr(), mine.shape[0])
+    glob = reply_to_senders(_device_rows(d_reply, (mine.shape[0],)), got, sent, group)
+    torch.cuda.current_stream().synchronize()
+    table = finish(glob.data_ptr())
+    sh.free()
+    return table
+
+
+def first_pass_sharded(ctx, reads, k: int, min_abundance: int = 0, group=None):
+    """k = firstK over reads sharded across the ranks of `group`: this rank's share of the global table."""
+    sh = ctx.shard_begin(reads, k, dist.get_world_size(group))
+    return _exchange_shard(sh, lambda d: sh.finish(d, min_abundance), group)
+
+
+def allgather_records(table, group=None) -> bytes:
+    """The 20-byte records of every rank's share, concatenated: the complete table of this k, which every rank loads as the
+    previous table of the next (mdbg_prev_from_records).  20 bytes per key: a few hundred MB at 40 M reads."""
+    rec, _ = table.to_host()
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, rec.tobytes(), group=group)
+    return b"".join(parts)
+
+
+def next_k_sharded(ctx, reads, unitigs, k: int, first_k: int, prev_records: bytes, group=None):
+    """k > firstK (graph/CreateMdbg.cpp:391-468) over sharded reads: the ordinary refined / index pass over this rank's reads
+    against the complete previous table, then mdbg_shard_from_table -> owners -> mdbg_shard_keep decide who lists the keys
+    several ranks found.  `unitigs` (unitig_data.txt sequences, may be None) belong to one rank only."""
+    prev = ctx.prev_from_records(prev_records)
+    local = ctx.kminmer_count_refined(reads, unitigs, k, prev) if k == first_k + 1 else ctx.kminmer_index(reads, unitigs, k, prev)
+    sh = ctx.shard_from_table(local, dist.get_world_size(group))
+    out = _exchange_shard(sh, lambda d: sh.keep(d), group)
+    local.free(); prev.free()
+    return out

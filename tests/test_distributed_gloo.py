@@ -108,3 +108,78 @@ def test_exchange_reduce_reply_world2(k):
     assert all(r[1] for r in res), res
     assert res[0][2] > 0 and res[1][2] > 0
     assert res[0][3] + res[1][3] == res[0][2] + res[1][2]        # every key is listed by exactly one rank
+
+
+# ---- sharded k > firstK: every rank runs the ordinary pass over its reads against the whole previous table; the ranks only
+# agree on who lists a key several of them found (mdbg_shard_from_table -> mdbg_shard_reduce -> mdbg_shard_keep on the GPU box;
+# the oracle and numpy stand in for the device here) ----
+def _worker_next_k(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metamdbg_amd import distributed as D, formats
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(19)
+    lens = rng.integers(0, 45, 160)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    genome = rng.permutation(300).astype(np.uint32)
+    mins = np.concatenate([genome[a:a + n] for a, n in zip(rng.integers(0, 250, len(lens)), lens)]).astype(np.uint32)
+    per = len(lens) // world
+    lo_r, hi_r = rank * per, (rank + 1) * per
+    soffs = offs[lo_r: hi_r + 1] - offs[lo_r]
+    smins = mins[int(offs[lo_r]): int(offs[hi_r])]
+    records = orc.table_abundance_records(orc.kminmer_count_first(mins, offs, 4, 0)).tobytes()     # the complete k = 4 table
+    ok = True
+    sizes = []
+    for k in (5, 6, 7):
+        prev = orc.PrevAbundance(records); prev.overlay_unitigs([], k - 1)
+        fn = orc.kminmer_count_refined if k == 5 else orc.kminmer_index
+        local = orc.table_abundance_records(fn(smins, soffs, k, prev))
+        rows = np.zeros((len(local), 3), dtype=np.uint64)
+        rows[:, 0], rows[:, 1], rows[:, 2] = local["lo"], local["hi"], local["abundance"]
+        own = owner_of(rows[:, 1], world) if len(rows) else np.zeros(0, np.int64)
+        order = np.argsort(own, kind="stable")
+        counts = [int((own == r).sum()) for r in range(world)]
+        sent = rows[order]
+        mine, got = D.exchange_by_owner(torch.from_numpy(sent.view(np.int64).copy()), counts)
+        reply = owner_reply(mine.numpy())                      # bit 63 on the first row of every key
+        glob = D.reply_to_senders(torch.from_numpy(reply), got, counts).numpy().view(np.uint64)
+        kept = sent[(glob >> np.uint64(63)) == 1]
+        mine_rec = np.zeros(len(kept), dtype=formats.ABUNDANCE_DTYPE)
+        mine_rec["lo"], mine_rec["hi"], mine_rec["abundance"] = kept[:, 0], kept[:, 1], kept[:, 2].astype(np.uint32)
+        parts = [None] * world
+        dist.all_gather_object(parts, mine_rec.tobytes())
+        records = b"".join(parts)                              # the complete table of this k on every rank
+        # expected: the single-rank pass over all the reads, previous table = the single-rank table of k - 1
+        if k == 5:
+            exp_prev = orc.table_abundance_records(orc.kminmer_count_first(mins, offs, 4, 0)).tobytes()
+        p2 = orc.PrevAbundance(exp_prev); p2.overlay_unitigs([], k - 1)
+        exp = orc.table_abundance_records(fn(mins, offs, k, p2))
+        exp_prev = exp.tobytes()
+        ok = ok and np.array_equal(formats.sorted_abundance_records(records), formats.sorted_abundance_records(exp))
+        sizes.append((len(local), len(kept), len(exp)))
+    q.put((rank, bool(ok), sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_next_k_dedup_by_owner_world2():
+    """k = 5 (refined), 6 and 7 (index) with the reads sharded over two ranks equal the single-rank tables; keys found by both
+    ranks are listed by exactly one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_next_k, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    for i in range(3):
+        local0, kept0, exp = res[0][2][i]
+        local1, kept1, _ = res[1][2][i]
+        assert exp > 20 and kept0 + kept1 == exp and local0 + local1 > exp, res     # overlapping keys, each listed once

@@ -62,3 +62,30 @@ def test_library_rccl_exchange_two_gpus(tmp_path):
     corr = ctx.purge_palindromes(ctx.scan(ctx.reads_synthetic(spec), K=15, density=0.005, hpc=True), 4, 100)
     one, _ = ctx.kminmer_count_first(corr, 4, 0).to_host()
     assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(one))
+
+
+def test_two_ranks_multik_equal_one(tmp_path):
+    """BASELINE.json configs[2] on more than one rank: the multi-k loop k = 4 .. 8 (benchmark mode: reads only, previous table =
+    the gathered records of k - 1) with the reads sharded over two real ranks (gloo, both on GPU 0) against one rank doing all the
+    reads: the gathered records must be the same table at every k."""
+    import socket as _s
+    import numpy as np
+    from metamdbg_amd import capi, formats, synth
+    n_total, last_k = 6000, 8
+    with _s.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "rank_multik.py"), str(tmp_path), str(n_total), str(last_k)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ctx = capi.Context(0)
+    spec = synth.hifi_spec(n_total, seed=77, read_len=6000, coverage=25.0)
+    corr = ctx.purge_palindromes(ctx.scan(ctx.reads_synthetic(spec), K=15, density=0.005, hpc=True), 4, 100)
+    t = ctx.kminmer_count_first(corr, 4, 0)
+    for k in range(4, last_k + 1):
+        if k > 4:
+            t = ctx.kminmer_count_refined(corr, None, k, t) if k == 5 else ctx.kminmer_index(corr, None, k, t)
+        rec, _ = t.to_host()
+        got = np.load(tmp_path / f"k{k}.npy")
+        assert len(rec) > 100 and np.array_equal(formats.sorted_abundance_records(got), formats.sorted_abundance_records(rec)), k

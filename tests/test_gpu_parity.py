@@ -831,3 +831,96 @@ def test_library_exchange_one_rank(ctx, orc):
         assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(orc.table_abundance_records(t)))
     finally:
         comm.destroy()
+
+
+def _emulate_exchange(sh_list):
+    """Both all-to-alls of the sharded passes on one device (host copies stand in for the wire): rows to their owners,
+    mdbg_shard_reduce on every owner, replies back to the senders in the order sent.  Returns one device buffer of replies
+    per rank (the caller frees with hipFree) and the hip handle."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    n_ranks = len(sh_list)
+    rw = sh_list[0].row_words
+
+    def to_host(ptr, shape):
+        out = np.zeros(shape, dtype=np.uint64)
+        if out.nbytes:
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def to_device(a):
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), C.c_size_t(max(a.nbytes, 8))) == 0
+        if a.nbytes:
+            assert hip.hipMemcpy(buf, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+        return buf
+
+    sent = [to_host(s.d_rows, (s.n_rows, rw)) for s in sh_list]
+    per_owner = [[] for _ in range(n_ranks)]
+    for r in range(n_ranks):
+        o = 0
+        for dst in range(n_ranks):
+            c = int(sh_list[r].counts[dst])
+            per_owner[dst].append(sent[r][o: o + c]); o += c
+    replies = []
+    for dst in range(n_ranks):
+        rows = np.ascontiguousarray(np.concatenate(per_owner[dst]))
+        buf = to_device(rows)
+        replies.append(to_host(sh_list[dst].reduce(buf.value, len(rows)), (len(rows),)))
+        hip.hipFree(buf)
+    out = []
+    for r in range(n_ranks):
+        glob = []
+        for dst in range(n_ranks):
+            o = sum(int(sh_list[src].counts[dst]) for src in range(r))
+            glob.append(replies[dst][o: o + int(sh_list[r].counts[dst])])
+        out.append(to_device(np.ascontiguousarray(np.concatenate(glob))))
+    return out, hip
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_sharded_next_k_on_one_gpu(ctx, orc, n_ranks):
+    """BASELINE.json configs[2] on more than one GPU: k = firstK+1 (refined) and the index passes with the reads sharded.  Every
+    rank holds the whole previous table and runs the ordinary pass over ITS reads; mdbg_shard_from_table -> reduce -> mdbg_shard_keep
+    make the ranks agree on who lists a key several of them found (exchanges emulated on one device).  The union of the kept
+    tables must be the single-GPU table at every k, vectors included at firstK+1, and it is the next k's previous table."""
+    rng = np.random.default_rng(31 + n_ranks)
+    genome = rng.permutation(2500).astype(np.uint32)          # reads = windows of one minimizer-space genome, both strands, ~12x
+    rl = []
+    for _ in range(700):
+        a = int(rng.integers(0, 2450)); n = int(rng.integers(0, 70))
+        seg = genome[a:a + n]
+        rl.append(seg[::-1].copy() if rng.integers(0, 2) else seg.copy())
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in rl])]).astype(np.uint64)
+    mins = np.concatenate(rl).astype(np.uint32)
+    n_reads = len(offs) - 1
+    cuts = np.linspace(0, n_reads, n_ranks + 1).astype(int)
+    shards = [ctx.minimizers_from_host(mins[int(offs[cuts[r]]): int(offs[cuts[r + 1]])], offs[cuts[r]: cuts[r + 1] + 1] - offs[cuts[r]])
+              for r in range(n_ranks)]
+    whole = ctx.minimizers_from_host(mins, offs)
+    prev_rec, _ = ctx.kminmer_count_first(whole, 4, 0).to_host()
+    for k in (5, 6, 7):
+        prev = ctx.prev_from_records(prev_rec)
+        single = ctx.kminmer_count_refined(whole, None, k, prev) if k == 5 else ctx.kminmer_index(whole, None, k, prev)
+        exp_rec, exp_vec = single.to_host()
+        assert len(exp_rec) > 50
+        locals_ = [ctx.kminmer_count_refined(s, None, k, prev) if k == 5 else ctx.kminmer_index(s, None, k, prev) for s in shards]
+        assert sum(t.info()["n_records"] for t in locals_) > len(exp_rec)          # the shards do overlap in keys
+        sh = [ctx.shard_from_table(t, n_ranks) for t in locals_]
+        bufs, hip = _emulate_exchange(sh)
+        recs, vecs = [], []
+        for r in range(n_ranks):
+            kept = sh[r].keep(bufs[r].value)
+            rec, vec = kept.to_host()
+            recs.append(rec); vecs.append(vec)
+            hip.hipFree(bufs[r]); sh[r].free(); kept.free()
+        rec = np.concatenate(recs)
+        assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(exp_rec)), k
+        if exp_vec is not None:
+            v = np.concatenate(vecs)
+            assert np.array_equal(formats.sorted_vector_records(v.astype("<u4").tobytes(), k), formats.sorted_vector_records(exp_vec.astype("<u4").tobytes(), k)), k
+        # against the oracle too
+        oprev = orc.PrevAbundance(prev_rec.tobytes()); oprev.overlay_unitigs([], k - 1)
+        t_orc = (orc.kminmer_count_refined if k == 5 else orc.kminmer_index)(mins, offs, k, oprev)
+        assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(orc.table_abundance_records(t_orc))), k
+        prev_rec = rec                         # what an all-gather of the ranks' records gives every rank
