@@ -643,7 +643,7 @@ def main() -> None:
                        "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
                        "exchange": (None if not exchange else "library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
                                     else "torch.distributed all_to_all_single")},
-            "roofline": {"bound": "hbm", "kernel": "scan_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "scan_fast_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "concurrent_launches": n_slots,
@@ -651,8 +651,9 @@ def main() -> None:
                                               "table kernels and lasts longer than alone (--in-flight 1 shows it alone); scans of different batches "
                                               "never overlap each other")
                                              if n_slots > 1 else None,
-                         "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies, half-rate VALU) "
-                                 "puts the ceiling at the VALU, far below HBM (DESIGN.md 4.1)",
+                         "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies at 4.7 cycles per wave64 "
+                                 "each) puts the ceiling at the VALU, far below HBM; the PMC counters show the VALU saturated "
+                                 "(profiles/r02h_pmc_scan_fast_kernel.txt, DESIGN.md 4.1)",
                          # the hash alone, measured in isolation at full occupancy (tools/ubench/hash_rates.hip,
                          # profiles/r01_hash_rates_gfx950.txt): 186 cycles per 64 hashes per SIMD
                          "valu_floor": {"hash_cycles_per_64": 186, "hpc_positions_per_launch": hpc_positions,
