@@ -150,6 +150,7 @@ struct Args {
     bool skipCorrection = false, outputQuality = false, firstPass = false;
     uint32_t minAbundance = 0;
     size_t batchBases = (size_t)32 << 20;  // bytes of input per device batch (not a reference flag)
+    int gpus = 1;                          // contexts / devices the work is spread over (not a reference flag)
 };
 Args parse_args(int argc, char **argv, int first) {
     Args a;
@@ -163,6 +164,7 @@ Args parse_args(int argc, char **argv, int first) {
         else if (s == "--output-quality") a.outputQuality = true;
         else if (s == "--firstpass") a.firstPass = true;
         else if (s == "--batch-bases") a.batchBases = (size_t)atoll(val().c_str());
+        else if (s == "--gpus") a.gpus = std::max(1, std::min(64, atoi(val().c_str())));
         else if (s.rfind("--", 0) == 0) die("unknown flag " + s);
         else a.pos.push_back(s);
     }
@@ -297,10 +299,17 @@ int run_read_selection(int argc, char **argv) {
     };
     struct Kept { uint64_t seq; mdbg_ctx *ctx; mdbg_minimizers *mins; };
     std::vector<Kept> kept;                 // device-resident minimizer reads, purged once N50 is known
-    int nConsumers = 1;
-    if (const char *e = getenv("MDBG_TOOL_CONSUMERS")) nConsumers = std::max(1, std::min(4, atoi(e)));
+    // --gpus G: one consumer per device; batches go to the consumers in turn, every batch is scanned (and later purged) where it
+    // landed, and the ordered writer, N50 and read_stats.txt see the batches in read order whatever device produced them
+    // (contiguous read ranges, stats reduced on the host).
+    int nConsumers = std::max(1, a.gpus);
+    if (const char *e = getenv("MDBG_TOOL_CONSUMERS")) nConsumers = std::max(nConsumers, std::max(1, std::min(4 * std::max(1, a.gpus), atoi(e))));
     std::vector<mdbg_ctx *> ctxs{g_ctx};
-    for (int i = 1; i < nConsumers; i++) { mdbg_ctx *c = nullptr; check(mdbg_create(0, &c), "mdbg_create"); ctxs.push_back(c); }
+    for (int i = 1; i < nConsumers; i++) {
+        mdbg_ctx *c = nullptr;
+        if (mdbg_create(i % std::max(1, a.gpus), &c) != MDBG_OK) die(std::string("mdbg_create(device ") + std::to_string(i % a.gpus) + "): " + mdbg_last_error(nullptr));
+        ctxs.push_back(c);
+    }
 
     std::map<uint64_t, std::unique_ptr<HostBatch>> pending;     // finished batches waiting for their turn at the writer
     uint64_t nextWrite = 0;
@@ -488,126 +497,191 @@ void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t
     }
 }
 
-mdbg_minimizers *upload_reads(const std::string &path, bool required) {
-    std::vector<uint8_t> raw = read_file(path, required);
-    std::vector<uint32_t> mins;
-    std::vector<uint64_t> offs;
-    parse_minimizer_reads(raw, mins, offs);
-    mdbg_minimizers *m = nullptr;
-    check(mdbg_minimizers_from_host(g_ctx, mins.data(), offs.data(), (uint32_t)(offs.size() - 1), &m), "mdbg_minimizers_from_host");
-    return m;
+// What `graph` reads besides the reads when k > firstK, parsed once on the host (every rank builds its own device copy).
+struct PrevInputs {
+    std::vector<uint8_t> prevRec;                 // kminmerData_abundance_prev.txt
+    std::vector<uint32_t> um, uab;                // unitigGraph_prev.nodes.bin sequences + the refined abundance of each (0xFFFFFFFF = none)
+    std::vector<uint64_t> uoff{0};
+    std::vector<uint32_t> unitigMins;             // unitig_data.txt
+    std::vector<uint64_t> unitigOffs;
+    std::vector<uint8_t> unitigCirc;
+    bool hasUnitigs = false;
+};
+
+void load_prev_inputs(const std::string &dir, PrevInputs &in) {
+    // loadRefinedAbundances (graph/CreateMdbg.cpp:3401-3709)
+    in.prevRec = read_file(dir + "/kminmerData_abundance_prev.txt");
+    // unitigGraph.nodes.refined_abundances.bin: (u32 unitigName, u32 abundance)*
+    std::vector<uint8_t> ab = read_file(dir + "/unitigGraph.nodes.refined_abundances.bin", false);
+    std::vector<std::pair<uint32_t, uint32_t>> name2ab(ab.size() / 8);
+    for (size_t i = 0; i < name2ab.size(); i++) { memcpy(&name2ab[i].first, ab.data() + 8 * i, 4); memcpy(&name2ab[i].second, ab.data() + 8 * i + 4, 4); }
+    std::sort(name2ab.begin(), name2ab.end());
+    // unitigGraph_prev.nodes.bin: (u32 size; u32 m[size]; u32 unitigIndex)*, name = index / 2
+    std::vector<uint8_t> nodes = read_file(dir + "/unitigGraph_prev.nodes.bin", false);
+    for (size_t o = 0; o + 4 <= nodes.size();) {
+        uint32_t n; memcpy(&n, nodes.data() + o, 4); o += 4;
+        if (o + (size_t)n * 4 + 4 > nodes.size()) die("truncated unitigGraph_prev.nodes.bin");
+        const size_t base = in.um.size();
+        in.um.resize(base + n);
+        if (n) memcpy(in.um.data() + base, nodes.data() + o, (size_t)n * 4);
+        o += (size_t)n * 4;
+        uint32_t idx; memcpy(&idx, nodes.data() + o, 4); o += 4;
+        in.uoff.push_back(in.um.size());
+        auto it = std::lower_bound(name2ab.begin(), name2ab.end(), std::make_pair(idx / 2, 0u));
+        // several entries for one name: the reference's map keeps the last one
+        uint32_t v = 0; bool found = false;
+        for (; it != name2ab.end() && it->first == idx / 2; ++it) { v = it->second; found = true; }
+        in.uab.push_back(found ? v : 0xFFFFFFFFu);   // 0xFFFFFFFF = no refined abundance: skipped (CreateMdbg.cpp:3483)
+    }
+    std::ifstream probe(dir + "/unitig_data.txt", std::ios::binary);
+    if (probe) {
+        parse_minimizer_reads(read_file(dir + "/unitig_data.txt", true), in.unitigMins, in.unitigOffs, &in.unitigCirc);
+        in.hasUnitigs = true;
+    }
+}
+
+struct RankTable {
+    std::vector<uint8_t> rec;
+    std::vector<uint32_t> vec;
+    uint64_t n = 0, nSolid = 0;
+    int hasVec = 0;
+    std::string smallContigs;        // records for smallContigs_k<k>.bin (the rank that holds unitig_data.txt)
+};
+
+// One rank's part of `graph`: reads [r0, r1) of read_data_corrected.txt on `ctx`; with a communicator the table is built
+// across the ranks (include/mdbg_hip.h "the exchange inside the library") and `out` is this rank's share of it.
+// unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
+void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const std::vector<uint32_t> &mins,
+                const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out) {
+    const uint32_t k = (uint32_t)P.kminmerSize;
+    std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
+    mdbg_minimizers *reads = nullptr;
+    check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(r1 - r0), &reads), "mdbg_minimizers_from_host");
+    mdbg_table *table = nullptr;
+    if (a.firstPass) {
+        if (comm) check_on(ctx, mdbg_kminmer_count_first_sharded(ctx, comm, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first_sharded");
+        else check_on(ctx, mdbg_kminmer_count_first(ctx, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first");
+    } else {
+        mdbg_table *prev = nullptr;
+        check_on(ctx, mdbg_prev_from_records(ctx, in.prevRec.data(), in.prevRec.size() / 20, &prev), "mdbg_prev_from_records");
+        if (!in.uab.empty()) {
+            mdbg_minimizers *un = nullptr;
+            check_on(ctx, mdbg_minimizers_from_host(ctx, in.um.data(), in.uoff.data(), (uint32_t)in.uab.size(), &un), "mdbg_minimizers_from_host");
+            check_on(ctx, mdbg_prev_overlay_unitigs(ctx, prev, un, in.uab.data(), (uint32_t)P.prevK), "mdbg_prev_overlay_unitigs");
+            mdbg_minimizers_free(un);
+        }
+        mdbg_minimizers *unitigs = nullptr;
+        if (in.hasUnitigs && rank == 0)
+            check_on(ctx, mdbg_minimizers_from_host(ctx, in.unitigMins.data(), in.unitigOffs.data(), (uint32_t)(in.unitigOffs.size() - 1), &unitigs),
+                     "mdbg_minimizers_from_host");
+        // smallContigs_k<k>.bin is filled by the unitig pass of IndexKminmerFunctor when k > 8 (graph/CreateMdbg.hpp:1330-1352);
+        // those unitigs have no k-min-mer, so they add nothing to the table below.
+        if (unitigs && k > 8 && k != P.firstK + 1) {
+            const uint32_t nUnitigs = (uint32_t)(in.unitigOffs.size() - 1);
+            std::vector<uint8_t> isSmall(nUnitigs);
+            check_on(ctx, mdbg_small_contigs(ctx, unitigs, k, (uint32_t)P.prevK, prev, isSmall.data()), "mdbg_small_contigs");
+            for (uint32_t u = 0; u < nUnitigs; u++) {
+                if (!isSmall[u]) continue;
+                const uint32_t n = (uint32_t)(in.unitigOffs[u + 1] - in.unitigOffs[u]);
+                const uint8_t circ = in.unitigCirc[u];   // the record's own flag byte (Commons.hpp:7413, :7485)
+                out.smallContigs.append((const char *)&n, 4); out.smallContigs.append((const char *)&circ, 1);
+                out.smallContigs.append((const char *)(in.unitigMins.data() + in.unitigOffs[u]), (size_t)n * 4);
+            }
+        }
+        mdbg_table *local = nullptr;
+        if (k == P.firstK + 1) check_on(ctx, mdbg_kminmer_count_refined(ctx, reads, unitigs, k, prev, &local), "mdbg_kminmer_count_refined");
+        else check_on(ctx, mdbg_kminmer_index(ctx, reads, unitigs, k, prev, &local), "mdbg_kminmer_index");
+        if (comm) {
+            // the ranks agree on who lists a key several of them found (include/mdbg_hip.h, "Sharded k > firstK")
+            mdbg_shard *sh = nullptr;
+            const uint64_t *dRows = nullptr, *dReplies = nullptr;
+            std::vector<uint64_t> counts(64, 0);
+            check_on(ctx, mdbg_shard_from_table(ctx, local, (uint32_t)a.gpus, &sh, &dRows, counts.data()), "mdbg_shard_from_table");
+            check_on(ctx, mdbg_shard_exchange(ctx, comm, sh, dRows, counts.data(), &dReplies), "mdbg_shard_exchange");
+            check_on(ctx, mdbg_shard_keep(ctx, sh, dReplies, &table), "mdbg_shard_keep");
+            mdbg_shard_free(sh);
+            mdbg_table_free(local);
+        } else table = local;
+        if (unitigs) mdbg_minimizers_free(unitigs);
+        mdbg_table_free(prev);
+    }
+    mdbg_table_info(table, nullptr, &out.n, &out.nSolid, &out.hasVec);
+    out.rec.resize(out.n * 20);
+    out.vec.resize(out.hasVec ? out.n * k : 0);
+    check_on(ctx, mdbg_table_to_host(ctx, table, out.rec.data(), out.hasVec ? out.vec.data() : nullptr), "mdbg_table_to_host");
+    mdbg_table_free(table);
+    mdbg_minimizers_free(reads);
 }
 
 int run_graph(int argc, char **argv) {
     Args a = parse_args(argc, argv, 2);
-    if (a.pos.size() != 1) die("usage: mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass]");
+    if (a.pos.size() != 1) die("usage: mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass] [--gpus G]");
     const std::string dir = a.pos[0];
     Parameters P;
     P.load(dir + "/parameters.gz");
     g_log.open(dir);
-    check(mdbg_create(0, &g_ctx), "mdbg_create");
     const uint32_t k = (uint32_t)P.kminmerSize;
-    g_log.line("mdbg_tool graph (MI355X) k = " + std::to_string(k) + (a.firstPass ? " --firstpass" : ""));
-    mdbg_minimizers *reads = upload_reads(dir + "/read_data_corrected.txt", true);
-    mdbg_table *table = nullptr;
+    g_log.line("mdbg_tool graph (MI355X) k = " + std::to_string(k) + (a.firstPass ? " --firstpass" : "") +
+               (a.gpus > 1 ? " --gpus " + std::to_string(a.gpus) : ""));
+    std::vector<uint32_t> mins;
+    std::vector<uint64_t> offs;
+    parse_minimizer_reads(read_file(dir + "/read_data_corrected.txt", true), mins, offs);
+    const size_t nReads = offs.size() - 1;
+    PrevInputs in;
+    if (!a.firstPass) load_prev_inputs(dir, in);
     // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
     std::ofstream small(dir + "/smallContigs/smallContigs_k" + std::to_string(k) + ".bin", std::ios::binary);
-    if (a.firstPass) {
-        check(mdbg_kminmer_count_first(g_ctx, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first");
+
+    // --gpus G: contiguous read ranges, one context (device r, one host thread) per rank, the exchange inside the library over
+    // RCCL.  MDBG_TOOL_SHARDED=1 takes the same path with one rank (a communicator of one: what a one-GPU box can exercise).
+    const int G = std::max(1, a.gpus);
+    const bool sharded = G > 1 || getenv("MDBG_TOOL_SHARDED") != nullptr;
+    std::vector<RankTable> parts((size_t)G);
+    if (!sharded) {
+        check(mdbg_create(0, &g_ctx), "mdbg_create");
+        graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0]);
     } else {
-        // loadRefinedAbundances (graph/CreateMdbg.cpp:3401-3709)
-        std::vector<uint8_t> prevRec = read_file(dir + "/kminmerData_abundance_prev.txt");
-        mdbg_table *prev = nullptr;
-        check(mdbg_prev_from_records(g_ctx, prevRec.data(), prevRec.size() / 20, &prev), "mdbg_prev_from_records");
-        // unitigGraph.nodes.refined_abundances.bin: (u32 unitigName, u32 abundance)*
-        std::vector<uint8_t> ab = read_file(dir + "/unitigGraph.nodes.refined_abundances.bin", false);
-        std::vector<std::pair<uint32_t, uint32_t>> name2ab(ab.size() / 8);
-        for (size_t i = 0; i < name2ab.size(); i++) { memcpy(&name2ab[i].first, ab.data() + 8 * i, 4); memcpy(&name2ab[i].second, ab.data() + 8 * i + 4, 4); }
-        std::sort(name2ab.begin(), name2ab.end());
-        // unitigGraph_prev.nodes.bin: (u32 size; u32 m[size]; u32 unitigIndex)*, name = index / 2
-        std::vector<uint8_t> nodes = read_file(dir + "/unitigGraph_prev.nodes.bin", false);
-        std::vector<uint32_t> um, uab;
-        std::vector<uint64_t> uoff{0};
-        for (size_t o = 0; o + 4 <= nodes.size();) {
-            uint32_t n; memcpy(&n, nodes.data() + o, 4); o += 4;
-            if (o + (size_t)n * 4 + 4 > nodes.size()) die("truncated unitigGraph_prev.nodes.bin");
-            const size_t base = um.size();
-            um.resize(base + n);
-            if (n) memcpy(um.data() + base, nodes.data() + o, (size_t)n * 4);
-            o += (size_t)n * 4;
-            uint32_t idx; memcpy(&idx, nodes.data() + o, 4); o += 4;
-            uoff.push_back(um.size());
-            auto it = std::lower_bound(name2ab.begin(), name2ab.end(), std::make_pair(idx / 2, 0u));
-            // several entries for one name: the reference's map keeps the last one
-            uint32_t v = 0; bool found = false;
-            for (; it != name2ab.end() && it->first == idx / 2; ++it) { v = it->second; found = true; }
-            uab.push_back(found ? v : 0xFFFFFFFFu);   // 0xFFFFFFFF = no refined abundance: skipped (CreateMdbg.cpp:3483)
+        uint8_t id[MDBG_COMM_ID_BYTES];
+        check(mdbg_comm_unique_id(id), "mdbg_comm_unique_id");
+        std::vector<mdbg_ctx *> ctxs((size_t)G, nullptr);
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; r++) {
+            th.emplace_back([&, r] {
+                mdbg_ctx *ctx = nullptr;
+                if (mdbg_create(r, &ctx) != MDBG_OK) die(std::string("mdbg_create(device ") + std::to_string(r) + "): " + mdbg_last_error(nullptr));
+                ctxs[(size_t)r] = ctx;
+                mdbg_comm *comm = nullptr;
+                check_on(ctx, mdbg_comm_create(ctx, id, r, G, &comm), "mdbg_comm_create");
+                graph_rank(ctx, comm, r, P, a, mins, offs, nReads * (size_t)r / (size_t)G, nReads * (size_t)(r + 1) / (size_t)G, in, parts[(size_t)r]);
+                mdbg_comm_destroy(comm);
+            });
         }
-        if (!uab.empty()) {
-            mdbg_minimizers *un = nullptr;
-            check(mdbg_minimizers_from_host(g_ctx, um.data(), uoff.data(), (uint32_t)uab.size(), &un), "mdbg_minimizers_from_host");
-            check(mdbg_prev_overlay_unitigs(g_ctx, prev, un, uab.data(), (uint32_t)P.prevK), "mdbg_prev_overlay_unitigs");
-            mdbg_minimizers_free(un);
-        }
-        mdbg_minimizers *unitigs = nullptr;
-        std::vector<uint32_t> unitigMins;
-        std::vector<uint64_t> unitigOffs;
-        std::vector<uint8_t> unitigCirc;
-        {
-            std::ifstream probe(dir + "/unitig_data.txt", std::ios::binary);
-            if (probe) {
-                parse_minimizer_reads(read_file(dir + "/unitig_data.txt", true), unitigMins, unitigOffs, &unitigCirc);
-                check(mdbg_minimizers_from_host(g_ctx, unitigMins.data(), unitigOffs.data(), (uint32_t)(unitigOffs.size() - 1), &unitigs),
-                      "mdbg_minimizers_from_host");
-            }
-        }
-        // smallContigs_k<k>.bin is filled by the unitig pass of IndexKminmerFunctor when k > 8 (graph/CreateMdbg.hpp:1330-1352);
-        // those unitigs have no k-min-mer, so they add nothing to the table below.
-        {
-            if (unitigs && k > 8 && k != P.firstK + 1) {
-                const uint32_t nUnitigs = (uint32_t)(unitigOffs.size() - 1);
-                std::vector<uint8_t> isSmall(nUnitigs);
-                check(mdbg_small_contigs(g_ctx, unitigs, k, (uint32_t)P.prevK, prev, isSmall.data()), "mdbg_small_contigs");
-                for (uint32_t u = 0; u < nUnitigs; u++) {
-                    if (!isSmall[u]) continue;
-                    const uint32_t n = (uint32_t)(unitigOffs[u + 1] - unitigOffs[u]);
-                    const uint8_t circ = unitigCirc[u];   // the record's own flag byte (Commons.hpp:7413, :7485)
-                    small.write((const char *)&n, 4); small.write((const char *)&circ, 1);
-                    small.write((const char *)(unitigMins.data() + unitigOffs[u]), (std::streamsize)n * 4);
-                }
-            }
-        }
-        if (k == P.firstK + 1) check(mdbg_kminmer_count_refined(g_ctx, reads, unitigs, k, prev, &table), "mdbg_kminmer_count_refined");
-        else check(mdbg_kminmer_index(g_ctx, reads, unitigs, k, prev, &table), "mdbg_kminmer_index");
-        if (unitigs) mdbg_minimizers_free(unitigs);
-        mdbg_table_free(prev);
+        for (auto &t : th) t.join();
+        g_ctx = ctxs[0];
+        for (int r = 1; r < G; r++) mdbg_destroy(ctxs[(size_t)r]);
     }
     uint64_t n = 0, nSolid = 0;
-    int hasVec = 0;
-    mdbg_table_info(table, nullptr, &n, &nSolid, &hasVec);
+    int hasVec = parts[0].hasVec;
+    for (const RankTable &t : parts) { n += t.n; nSolid += t.nSolid; small.write(t.smallContigs.data(), (std::streamsize)t.smallContigs.size()); }
     if (a.firstPass) {   // the two counts the reference logs after its first pass (graph/CreateMdbg.cpp:300-328)
         g_log.line("\tNb solid kminmers: " + std::to_string(nSolid));
         g_log.line("\tNb rescued kminmers: " + std::to_string(n - nSolid));
     } else {
         g_log.line("\tNb kminmers: " + std::to_string(n));
     }
-    std::vector<uint8_t> rec(n * 20);
-    std::vector<uint32_t> vec(hasVec ? n * k : 0);
-    check(mdbg_table_to_host(g_ctx, table, rec.data(), hasVec ? vec.data() : nullptr), "mdbg_table_to_host");
-    {
-        std::ofstream f(dir + "/kminmerData_abundance.txt", std::ios::binary);
-        f.write((const char *)rec.data(), (std::streamsize)rec.size());
-    }
+    // the ranks' shares one after the other: the record order of these files is unspecified in the reference as well
+    auto write_records = [&](const std::string &to) {
+        std::ofstream f(dir + to, std::ios::binary);
+        for (const RankTable &t : parts) f.write((const char *)t.rec.data(), (std::streamsize)t.rec.size());
+    };
+    write_records("/kminmerData_abundance.txt");
     if (hasVec) {
         std::ofstream f(dir + "/kminmerData_min.txt", std::ios::binary);
-        f.write((const char *)vec.data(), (std::streamsize)(vec.size() * 4));
+        for (const RankTable &t : parts) f.write((const char *)t.vec.data(), (std::streamsize)(t.vec.size() * 4));
     }
     // graph/CreateMdbg.cpp:515-522
-    auto copy = [&](const std::string &to) { std::ofstream f(dir + to, std::ios::binary); f.write((const char *)rec.data(), (std::streamsize)rec.size()); };
-    if (a.firstPass) copy("/kminmerData_abundance_init.txt");
-    if (k == P.firstK + 1) copy("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
-    mdbg_table_free(table);
-    mdbg_minimizers_free(reads);
+    if (a.firstPass) write_records("/kminmerData_abundance_init.txt");
+    if (k == P.firstK + 1) write_records("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
     write_perf(dir);
     mdbg_destroy(g_ctx);
     return 0;

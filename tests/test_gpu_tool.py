@@ -330,3 +330,43 @@ def test_handover_into_reference_graph_stage(tmp_path, kind):
         log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
         return [ln.split("Checksum", 1)[1] for ln in log.splitlines() if "Checksum unitig" in ln]
     assert checksums(t_ref) == checksums(t_hyb) and len(checksums(t_ref)) >= 6
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_tool_graph_through_the_library_exchange(tmp_path, gpus):
+    """`mdbg_tool graph --gpus G`: contiguous read ranges per rank, one context and one host thread per device, the exchange
+    inside the library (mdbg_comm_create, mdbg_kminmer_count_first_sharded; mdbg_shard_from_table / _exchange / _keep at k >
+    firstK).  G = 1 runs the same code with a communicator of one rank (MDBG_TOOL_SHARDED=1: what a one-GPU box can exercise;
+    G = 2 needs two GPUs).  The tables must be the reference's: first pass (hifi_200) and k = 5, 6, 9 of the reference's own
+    multi-k loop (hifi_multik)."""
+    import shutil
+    import torch
+    from tests import multik_fixture as mk
+    if gpus > torch.cuda.device_count():
+        pytest.skip(f"needs {gpus} GPUs")
+    env = {"MDBG_TOOL_SHARDED": "1"}
+    m = H.load_manifest("hifi_200")
+    tmp = make_tmp(tmp_path / "first", formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                                          hpc=True, data_type=0), ["unused"])
+    for name in ("read_data_corrected.txt", "read_stats.txt"):
+        shutil.copy(os.path.join(H.GOLDEN, "hifi_200", name), os.path.join(tmp, name))
+    run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass", "--gpus", str(gpus), env=env)
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
+    exp_v = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), m["k"]), exp_v)
+    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+    assert f"Nb solid kminmers: {m['reference_log']['n_solid']}\n" in log and f"Nb rescued kminmers: {m['reference_log']['n_rescued']}\n" in log
+    for k in (5, 6, 9):
+        fx = mk.load("hifi_multik", k)
+        tmp = make_tmp(tmp_path / f"k{k}", fx["params"], ["unused"])
+        for f in ("parameters.gz", "kminmerData_abundance_prev.txt", "unitigGraph_prev.nodes.bin",
+                  "unitigGraph.nodes.refined_abundances.bin", "unitig_data.txt"):
+            shutil.copy(os.path.join(fx["dir"], f), os.path.join(tmp, f))
+        shutil.copy(os.path.join(mk.GOLDEN, "hifi_multik", "read_data_corrected.txt"), os.path.join(tmp, "read_data_corrected.txt"))
+        run(TOOL, "graph", tmp, "--threads", "1", "--gpus", str(gpus), env=env)
+        assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), fx["abundance_sorted"]), k
+        if fx["min_sorted"] is not None:
+            assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k), fx["min_sorted"]), k
+        got = fbytes(tmp, os.path.join("smallContigs", f"smallContigs_k{k}.bin"))
+        assert mk.small_contig_records(got) == mk.small_contig_records(fx["small_contigs"]), k
