@@ -924,3 +924,82 @@ def test_sharded_next_k_on_one_gpu(ctx, orc, n_ranks):
         t_orc = (orc.kminmer_count_refined if k == 5 else orc.kminmer_index)(mins, offs, k, oprev)
         assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(orc.table_abundance_records(t_orc))), k
         prev_rec = rec                         # what an all-gather of the ranks' records gives every rank
+
+
+def test_full_size_properties_ont(ctx, orc):
+    """BASELINE.json configs[3] preset at a FULL-size batch (1 M x 20 kb ONT reads with qualities = 20 Gbp: 1 % substitutions,
+    0.5 % insertions, 0.5 % deletions; no HPC, repetitive filter from the 0.025 census), checked through properties:
+      * the census (over the first 200 000 reads) picks max(1, floor(1e-5 x distinct)) values, each with a count at or above
+        the cut of an independent count;
+      * the oracle on a sample of the batch equals the corresponding slice of the full scan (values, positions, directions,
+        per-minimizer minimum qualities, mean read quality, lengths);
+      * shard invariance of the scan (the two halves scanned separately, with the same repetitive set); purge idempotent;
+      * on the first 200 000 reads (the table of 1 M such reads holds 75 M records: comparing them as sorted multisets on the
+        host would take minutes): linearity of the counts -- the sharded first pass over two halves (exchanges emulated)
+        equals the single call as a multiset; rescued rows carry abundance 1 and dominate (2 % errors)."""
+    n, L, k, n_sub = 1_000_000, 20_000, 4, 200_000
+    spec = synth.ont_spec(n, seed=44, read_len=L, coverage=50.0)
+    head = ctx.reads_synthetic(spec, first_read=0, n_reads=n_sub)
+    pre = ctx.scan(head, K=15, density=0.025, hpc=False, apply_read_filters=False)
+    rep = ctx.repetitive_minimizers(pre)
+    vals, counts = np.unique(pre.to_host(full=False)["minimizers"], return_counts=True)
+    pre.free(); head.free()
+    n_keep = max(int(np.float32(0.00001) * np.float32(len(vals))), 1)
+    cut = np.sort(counts)[::-1][n_keep - 1]
+    top = set(vals[counts >= cut].tolist())
+    assert len(rep) == n_keep > 50 and len(set(rep.tolist())) == n_keep and all(int(v) in top for v in rep)
+    assert set(vals[counts > cut].tolist()) <= set(rep.tolist())
+    del vals, counts
+    reads = ctx.reads_synthetic(spec)
+    full = ctx.scan(reads, K=15, density=0.005, hpc=False, repetitive=rep)
+    h = full.to_host()
+    assert int(h["offsets"][-1]) == len(h["minimizers"]) > 90 * n
+    for first in (0, n - 200):
+        for r in range(0, 200, 9):
+            b, q = reads.get(first + r, with_quality=True)
+            o = orc.read_selection(b, q, K=15, density=0.005, hpc=False, repetitive=rep)
+            a, e = int(h["offsets"][first + r]), int(h["offsets"][first + r + 1])
+            assert h["minimizers"][a:e].tolist() == o["minimizers"].tolist() and h["pos"][a:e].tolist() == o["pos"].tolist()
+            assert h["dir"][a:e].tolist() == o["dir"].tolist() and h["qual"][a:e].tolist() == o["qual"].tolist()
+            assert _nan_eq([h["mean_quality"][first + r]], [o["mean_quality"]]) and int(h["read_length"][first + r]) == L
+    reads.free()
+    cutm = int(h["offsets"][n // 2])
+    for f, lo, hi in ((0, 0, cutm), (n // 2, cutm, len(h["minimizers"]))):
+        part = ctx.reads_synthetic(spec, first_read=f, n_reads=n // 2)
+        m = ctx.scan(part, K=15, density=0.005, hpc=False, repetitive=rep)
+        part.free()
+        hp = m.to_host(full=False)
+        assert np.array_equal(hp["minimizers"], h["minimizers"][lo:hi])
+        assert np.array_equal(hp["offsets"], h["offsets"][f: f + n // 2 + 1] - h["offsets"][f])
+        m.free()
+    corr = ctx.purge_palindromes(full, 4, 200)
+    corr2 = ctx.purge_palindromes(corr, 4, 200)
+    hc, hc2 = corr.to_host(full=False), corr2.to_host(full=False)
+    assert np.array_equal(hc["minimizers"], hc2["minimizers"]) and np.array_equal(hc["offsets"], hc2["offsets"])
+    corr2.free(); full.free(); corr.free()
+    # tables: the first n_sub reads, whole and as two shards
+    o_sub = hc["offsets"][: n_sub + 1]
+    m_sub = hc["minimizers"][: int(o_sub[-1])]
+    whole = ctx.minimizers_from_host(m_sub, o_sub)
+    t = ctx.kminmer_count_first(whole, k, 0)
+    rec, vec = t.to_host()
+    info = t.info()
+    assert (rec[: info["n_solid"]]["abundance"] > 1).all() and (rec[info["n_solid"]:]["abundance"] == 1).all()
+    assert info["n_records"] - info["n_solid"] > info["n_solid"]
+    t.free(); whole.free()
+    mid = n_sub // 2
+    shards = [ctx.minimizers_from_host(m_sub[: int(o_sub[mid])], o_sub[: mid + 1]),
+              ctx.minimizers_from_host(m_sub[int(o_sub[mid]):], o_sub[mid:] - o_sub[mid])]
+    sh = [ctx.shard_begin(s_, k, 2) for s_ in shards]
+    bufs, hip = _emulate_exchange(sh)
+    recs, vecs, n_solid = [], [], 0
+    for r in range(2):
+        ts = sh[r].finish(bufs[r].value, 0)
+        hip.hipFree(bufs[r])
+        rs, vs = ts.to_host()
+        recs.append(rs); vecs.append(vs); n_solid += ts.info()["n_solid"]
+        ts.free(); sh[r].free()
+    assert n_solid == info["n_solid"]
+    assert np.array_equal(formats.sorted_abundance_records(np.concatenate(recs)), formats.sorted_abundance_records(rec))
+    assert np.array_equal(formats.sorted_vector_records(np.concatenate(vecs).astype("<u4").tobytes(), k),
+                          formats.sorted_vector_records(vec.astype("<u4").tobytes(), k))
