@@ -594,7 +594,7 @@ def main() -> None:
         tot = [c.timing_get(name) for c, _ in slots]
         return sum(t[0] for t in tot), sum(t[1] for t in tot)
 
-    names = ["scan", "scan_compact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit"]
+    names = ["scan", "scan_compact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan"]
     if exchange:
         names += ["shard_rows", "shard_reduce", "shard_exchange"]
     ktimes = {k: timing_get(k) for k in names}

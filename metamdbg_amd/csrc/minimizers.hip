@@ -255,7 +255,10 @@ extern "C" int mdbg_minimizers_to_host(mdbg_ctx *ctx, const mdbg_minimizers *m, 
     if (qualities && t) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, qualities, m->d_mqual.p, t, hipMemcpyDeviceToHost));
     if (read_lengths && n) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, read_lengths, m->d_len.p, n * 4, hipMemcpyDeviceToHost));
     if (read_flags && n) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, read_flags, m->d_flags.p, n, hipMemcpyDeviceToHost));
-    if (mean_quality && n) memcpy(mean_quality, m->h_mean_quality.data(), n * sizeof(float));
+    if (mean_quality && n) {
+        if (m->h_mean_quality.size() == n) memcpy(mean_quality, m->h_mean_quality.data(), n * sizeof(float));
+        else for (size_t i = 0; i < n; i++) mean_quality[i] = m->mean_quality_all;
+    }
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
@@ -303,6 +306,7 @@ extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers
     m->n_reads = n;
     m->from_scan = in->from_scan;
     m->h_mean_quality = in->h_mean_quality;
+    m->mean_quality_all = in->mean_quality_all;
     DevBuf<uint32_t> flag;
     DevBuf<uint64_t> pos;
     MDBG_TRY(flag.alloc(ctx, total));

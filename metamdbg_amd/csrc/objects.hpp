@@ -42,7 +42,8 @@ struct mdbg_minimizers {
     mdbg::DevBuf<uint8_t> d_mqual;    // n_min (scan output only)
     mdbg::DevBuf<uint32_t> d_len;     // n_reads: original read length (scan output only)
     mdbg::DevBuf<uint8_t> d_flags;    // n_reads: MDBG_READ_* (scan output only)
-    std::vector<float> h_mean_quality;  // n_reads, finished on the host from per-read quality histograms
+    std::vector<float> h_mean_quality;  // n_reads, finished on the host from per-read quality sums; empty: every read has mean_quality_all
+    float mean_quality_all = 0.0f;
     bool from_scan = false;
     // Fresh output of the block-structured scan kernel: the rows of read r sit at [d_begin[r], d_begin[r] + d_cnt[r]) of
     // d_min / d_pos / d_dir in the order the waves finished their reads (each wave takes room with one atomic add when its

@@ -118,6 +118,7 @@ static int exclusive_scan_impl(mdbg_ctx *ctx, const Tin *d_in, uint64_t *d_out, 
     uint64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     DevBuf<uint64_t> sums;
     MDBG_TRY(sums.alloc(ctx, nblocks + 1));
+    LaunchTimer timer(ctx, "prefix_scan");
     hipLaunchKernelGGL(scan_reduce_kernel<Tin>, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in, n, sums.p);
     if (nblocks <= 64 * 1024) {
         hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, sums.p, nblocks);

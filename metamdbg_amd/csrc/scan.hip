@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             }
             if (lane == 0) {
                 a.out_begin[r] = start;
-                a.out_count[r] = outgrown ? 0u : nout;
+                a.out_count[r] = nout;              // also for a read that outgrew the stage: the host places and re-runs it
                 a.out_flags[r] = flags;
                 if (outgrown) a.over_list[atomicAdd(&a.list_counters[0], 1u)] = r;
                 if (flags & READ_SUSPECT) a.suspect_list[atomicAdd(&a.list_counters[1], 1u)] = r;
@@ -1197,6 +1197,22 @@ __global__ void post_scan_lists_kernel(const uint32_t *count, const uint32_t *ca
     if (i >= n_reads) return;
     if (count[i] > cap[i]) over_list[atomicAdd(&counters[0], 1u)] = (uint32_t)i;
     if (flags[i] & READ_SUSPECT) suspect_list[atomicAdd(&counters[1], 1u)] = (uint32_t)i;
+}
+
+// reads that outgrew the fast kernel's stage: their counts, then their places behind the regions
+__global__ void gather_counts_kernel(const uint32_t *list, uint32_t n_list, const uint32_t *count, uint32_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_list) out[i] = count[list[i]];
+}
+
+__global__ void place_overflow_kernel(const uint32_t *list, const uint64_t *start, const uint32_t *cnt, uint32_t n_list, uint64_t *cap_off,
+                                      uint64_t *begin) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+    const uint32_t r = list[i];
+    cap_off[r] = start[i];
+    cap_off[r + 1] = start[i] + cnt[i];      // consecutive listed reads (the list is sorted) agree on this entry
+    begin[r] = start[i];
 }
 
 __global__ void apply_low_quality_kernel(const uint8_t *low, uint32_t n_reads, uint32_t *count, uint8_t *flags,
@@ -1355,7 +1371,10 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         }
         for (char c : any) any_low_quality |= c != 0;
     } else {
-        m->h_mean_quality.assign(n, mean_quality_from_sum(0, 0));
+        // no qualities: every read's mean quality is the NaN the reference writes; kept as one value, not n of them (a 40 MB
+        // host fill per 10 M reads sat on the critical path in front of the kernel launch)
+        m->h_mean_quality.clear();
+        m->mean_quality_all = mean_quality_from_sum(0, 0);
     }
 
     // ---- plain ACGT without qualities: the block-structured kernel writes every read's rows once, where a wave found room
@@ -1363,20 +1382,23 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // LDS stage holds, more rows than the estimate allowed for -- go through the general path below.
     static const bool no_bump = getenv("MDBG_SCAN_NO_BUMP") != nullptr || getenv("MDBG_SCAN_NO_FAST") != nullptr;
     // (a read may stage STAGE_CAP minimizers: batches whose longest read is expected to select more go straight to the general path)
-    if (n && (!has_q || !hpc) && !has_n && !no_bump && p->density < 0.2f &&
-        (double)reads->max_len * (double)p->density * (hpc ? 0.8 : 1.0) * 1.4 + 24.0 < (double)STAGE_CAP) {
+    // A read may stage STAGE_CAP minimizers; the few that select more are re-run by the general kernel into a reserve behind
+    // the regions.  Batches whose AVERAGE read is expected to outgrow the stage go straight to the general path.
+    if (n && (!has_q || !hpc) && !has_n && !no_bump && p->density < 0.2f && reads->max_len < (1u << 31) &&
+        (double)reads->n_bases / (double)n * (double)p->density * (hpc ? 0.8 : 1.0) * 1.4 + 24.0 < (double)STAGE_CAP) {
         // the output arrays are cut into regions, each with its own cursor (reads are dealt to the waves round-robin, so the regions
         // fill evenly); small batches use one
         uint32_t n_regions = 1;
         while (n_regions < 64u && (uint64_t)n_regions * 8192ull <= n) n_regions <<= 1;
         const uint64_t region_cap = ((uint64_t)((double)reads->n_bases * (double)p->density * 1.3) + 64ull * n) / n_regions + 4096ull;
         const uint64_t capacity = region_cap * n_regions;
+        const uint64_t reserve = capacity / 16 + 65536;       // rows behind the regions for reads that outgrow the stage
         constexpr uint32_t CTL_OVER = 64, CTL_DROPPED = 65, CTL_WORDS = 66;     // u64 words: cursors, {n_over, n_suspect}, rows dropped
         DevBuf<uint32_t> d_over, d_susp;
         DevBuf<unsigned long long> d_ctl;
         if ((rc = m->d_begin.alloc(ctx, n)) || (rc = m->d_cnt.alloc(ctx, n)) || (rc = d_over.alloc(ctx, n)) || (rc = d_susp.alloc(ctx, n)) ||
-            (rc = d_ctl.alloc(ctx, CTL_WORDS)) || (rc = m->d_min.alloc(ctx, capacity)) || (rc = m->d_pos.alloc(ctx, capacity)) ||
-            (rc = m->d_dir.alloc(ctx, capacity)) || (rc = m->d_mqual.alloc(ctx, capacity)))
+            (rc = d_ctl.alloc(ctx, CTL_WORDS)) || (rc = m->d_min.alloc(ctx, capacity + reserve)) || (rc = m->d_pos.alloc(ctx, capacity + reserve)) ||
+            (rc = m->d_dir.alloc(ctx, capacity + reserve)) || (rc = m->d_mqual.alloc(ctx, capacity + reserve)))
             return fail(rc);
         (void)hipMemsetAsync(d_ctl.p, 0, CTL_WORDS * 8, ctx->stream);
         ScanArgs a{};
@@ -1403,7 +1425,48 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         bool fits = true;
         for (uint32_t g = 0; g < n_regions; g++) { rows += h_ctl[g]; fits = fits && h_ctl[g] <= region_cap; }
         const uint32_t n_over = (uint32_t)h_ctl[CTL_OVER], n_suspect = (uint32_t)(h_ctl[CTL_OVER] >> 32);
-        if (n_over == 0 && fits) {
+        // reads that outgrew the stage (long reads): placed in read order behind the regions and re-run by the general kernel
+        bool placed = n_over == 0;
+        if (fits && n_over && n_over <= n / 4 + 16) {
+            std::vector<uint32_t> list(n_over), cnts(n_over);
+            DevBuf<uint32_t> d_oc;
+            if ((rc = d_oc.alloc(ctx, n_over))) return fail(rc);
+            hipLaunchKernelGGL(gather_counts_kernel, dim3(grid_for(n_over, 256)), dim3(256), 0, ctx->stream, d_over.p, n_over, m->d_cnt.p, d_oc.p);
+            if ((e = memcpy_sync(ctx, list.data(), d_over.p, (size_t)n_over * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+                (e = memcpy_sync(ctx, cnts.data(), d_oc.p, (size_t)n_over * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+                return fail(set_error(ctx, MDBG_EHIP, "overflow list copy failed: %s", hipGetErrorString(e)));
+            std::vector<uint32_t> order(n_over);
+            for (uint32_t i = 0; i < n_over; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return list[x] < list[y]; });
+            std::vector<uint32_t> slist(n_over), scnt(n_over);
+            std::vector<uint64_t> sstart(n_over);
+            uint64_t at = capacity;
+            for (uint32_t i = 0; i < n_over; i++) { slist[i] = list[order[i]]; scnt[i] = cnts[order[i]]; sstart[i] = at; at += scnt[i]; }
+            if (at - capacity <= reserve) {
+                DevBuf<uint64_t> d_start;
+                DevBuf<uint32_t> scratch_count;
+                DevBuf<uint8_t> scratch_flags;
+                if ((rc = d_start.alloc(ctx, n_over)) || (rc = scratch_count.alloc(ctx, n)) || (rc = scratch_flags.alloc(ctx, n))) return fail(rc);
+                if ((e = memcpy_sync(ctx, d_over.p, slist.data(), (size_t)n_over * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = memcpy_sync(ctx, d_oc.p, scnt.data(), (size_t)n_over * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = memcpy_sync(ctx, d_start.p, sstart.data(), (size_t)n_over * 8, hipMemcpyHostToDevice)) != hipSuccess)
+                    return fail(set_error(ctx, MDBG_EHIP, "overflow plan upload failed: %s", hipGetErrorString(e)));
+                hipLaunchKernelGGL(place_overflow_kernel, dim3(grid_for(n_over, 256)), dim3(256), 0, ctx->stream, d_over.p, d_start.p, d_oc.p, n_over,
+                                   d_cap_off.p, m->d_begin.p);
+                ScanArgs b = a;
+                b.cursor = nullptr;
+                b.subset = d_over.p;
+                b.cap_off = d_cap_off.p;
+                b.q_last = p->quality_window == 1 ? 1u : 0u;
+                b.inline_minq = 1;
+                b.out_count = scratch_count.p; b.out_flags = scratch_flags.p;
+                if ((rc = launch_scan(ctx, b, hpc, has_q, false, n_over))) return fail(rc);
+                if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "overflow re-run failed: %s", hipGetErrorString(e)));
+                rows += at - capacity;
+                placed = true;
+            }
+        }
+        if (placed && fits) {
             uint64_t dropped = 0;
             if (n_suspect) {
                 LaunchTimer timer(ctx, "complexity_exact");
@@ -1423,10 +1486,10 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
                 if ((e = memcpy_sync(ctx, &dropped, d_ctl.p + CTL_DROPPED, 8, hipMemcpyDeviceToHost)) != hipSuccess)
                     return fail(set_error(ctx, MDBG_EHIP, "low-quality pass failed: %s", hipGetErrorString(e)));
             }
-            if (!has_q) (void)hipMemsetAsync(m->d_mqual.p, 1, capacity, ctx->stream);     // no qualities: ReadSelection.hpp:1047-1051
+            if (!has_q) (void)hipMemsetAsync(m->d_mqual.p, 1, capacity + reserve, ctx->stream);     // no qualities: ReadSelection.hpp:1047-1051
             m->scattered = true;
             m->owner = ctx;
-            m->n_rows = capacity;        // extent of the row arrays (regions are not filled to the brim)
+            m->n_rows = capacity + reserve;        // extent of the row arrays (regions are not filled to the brim)
             m->n_min = rows - dropped;
             if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan failed: %s", hipGetErrorString(e)));
             *out = m;

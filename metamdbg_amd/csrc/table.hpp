@@ -189,6 +189,7 @@ struct DeviceTable {
         return clear(ctx);
     }
     int clear(mdbg_ctx *ctx) {
+        LaunchTimer timer(ctx, "table_clear");
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(slots.p, 0, cap * sizeof(TableSlot), ctx->stream));
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(exc_val.p, 0, TABLE_EXC_CAP * 4, ctx->stream));
         MDBG_HIP_CHECK(ctx, hipMemsetAsync(ctl.p, 0, (4 + TABLE_OCC_WAYS) * 4, ctx->stream));

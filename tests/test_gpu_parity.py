@@ -1003,3 +1003,30 @@ def test_full_size_properties_ont(ctx, orc):
     assert np.array_equal(formats.sorted_abundance_records(np.concatenate(recs)), formats.sorted_abundance_records(rec))
     assert np.array_equal(formats.sorted_vector_records(np.concatenate(vecs).astype("<u4").tobytes(), k),
                           formats.sorted_vector_records(vec.astype("<u4").tobytes(), k))
+
+
+@pytest.mark.parametrize("hpc,with_q", [(True, False), (False, False), (False, True)])
+def test_scan_long_reads_among_short(ctx, orc, hpc, with_q):
+    """A batch of ordinary reads with a few that select more minimizers than the block kernel's LDS stage holds (several
+    hundred kb: ONT's long tail): those reads are placed behind the regions and re-run by the general kernel; every record,
+    and the order of the reads, must be the oracle's."""
+    rng = np.random.default_rng(5 + 2 * int(hpc) + int(with_q))
+    lens = [int(x) for x in rng.integers(2000, 9000, 300)]
+    for at, n in ((7, 210_000), (150, 400_000), (151, 120_000), (299, 95_000)):
+        lens[at] = n
+    seqs = [bytes(synth.CODE2ASCII[rng.integers(0, 4, n)]) for n in lens]
+    quals = [bytes((rng.integers(2, 60, n) + 33).astype(np.uint8)) for n in lens] if with_q else None
+    reads = ctx.reads_from_ascii(seqs, quals)
+    m = ctx.scan(reads, K=15, density=0.005, hpc=hpc)
+    h = m.to_host()
+    counts = np.diff(h["offsets"].astype(np.int64))
+    assert counts[150] > 1200 and counts[7] > 600          # really beyond the stage (384)
+    exp = b"".join(orc.read_selection(s, quals[i] if with_q else None, K=15, density=0.005, hpc=hpc)["record"] for i, s in enumerate(seqs))
+    assert formats.build_read_data_init(h) == exp
+    # and through the purge, which reads the scattered form
+    m2 = ctx.scan(reads, K=15, density=0.005, hpc=hpc)
+    hc = ctx.purge_palindromes(m2, 4, 100).to_host(full=False)
+    assert int(hc["offsets"][-1]) <= int(h["offsets"][-1]) and len(hc["offsets"]) == len(seqs) + 1
+    want = [orc.purge_palindrome(h["minimizers"][int(h["offsets"][i]): int(h["offsets"][i + 1])], 4, 100) for i in (7, 150, 151, 0, 299)]
+    for i, w in zip((7, 150, 151, 0, 299), want):
+        assert hc["minimizers"][int(hc["offsets"][i]): int(hc["offsets"][i + 1])].tolist() == w.tolist()
