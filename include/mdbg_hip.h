@@ -53,6 +53,10 @@ int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uin
  *   "table_blocks_per_cu"   resident blocks per CU of the kernels that walk every k-min-mer instance (default: unlimited;
  *                           1..3 when several contexts share a device, so that they do not displace another context's scan)
  *   "scan_reads_per_wave"   reads a scan wave processes before it retires (default 2)
+ *   "scan_candidate_slack"  tests only: the block-structured scan records candidate positions by the upper half of the
+ *                           hash and confirms each with the full hash; a read with a false candidate is re-run.  False
+ *                           candidates occur about once in 2^31 positions; this widens the test (units of 2^32 of the
+ *                           hash range) so that the re-run path can be exercised.  Default 0; results never depend on it
  * The environment variables MDBG_TABLE_BLOCKS_PER_CU / MDBG_SCAN_READS_PER_WAVE set the defaults at mdbg_create. */
 int  mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value);
 

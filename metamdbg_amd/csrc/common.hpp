@@ -107,6 +107,9 @@ struct TimedLaunch {
 struct mdbg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;      // copies that must not queue behind the main stream's kernel (quality sums during the scan)
+    void *pinned = nullptr;                 // grow-only pinned host buffer for them
+    size_t pinned_bytes = 0;
     std::string err;
     std::string arch;
     int n_cu = 0;
@@ -116,6 +119,7 @@ struct mdbg_ctx {
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
     unsigned table_blocks_per_cu = 1024;                   // resident blocks per CU of the kernels that walk every k-min-mer instance (mdbg_set_option)
     unsigned scan_reads_per_wave = 2;                      // reads a scan wave processes before it retires (mdbg_set_option)
+    uint32_t scan_cand_slack = 0;           // tests: widens the candidate test of the block-structured scan (see span_step)
     // distinct keys per k-min-mer instance seen by the last call OF THE SAME KIND (table sizing): the first pass keeps every
     // key, refined / index only those above abundance 1 -- one shared hint made every first pass after an index pass rebuild its table
     double key_ratio_hint[4] = {0.0625, 0.0625, 0.0625, 0.0625};   // [0] first pass, [1] refined, [2] index, [3] sharded first pass
@@ -193,15 +197,16 @@ struct LaunchTimer {
     mdbg_ctx *ctx;
     TimedLaunch t{};
     bool on;
-    LaunchTimer(mdbg_ctx *c, const char *name) : ctx(c), on(c->timing) {
+    hipStream_t stream;
+    LaunchTimer(mdbg_ctx *c, const char *name, hipStream_t s = nullptr) : ctx(c), on(c->timing), stream(s ? s : c->stream) {
         if (!on) return;
         t.name = name;
         if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(t.start, ctx->stream);
+        (void)hipEventRecord(t.start, stream);
     }
     ~LaunchTimer() {
         if (!on) return;
-        (void)hipEventRecord(t.stop, ctx->stream);
+        (void)hipEventRecord(t.stop, stream);
         ctx->launches.push_back(t);
     }
 };

@@ -21,6 +21,7 @@ int set_error(mdbg_ctx *ctx, int code, const char *fmt, ...) {
 static void fold_timers(mdbg_ctx *ctx) {
     if (ctx->launches.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     for (auto &t : ctx->launches) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
@@ -64,7 +65,9 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     if (const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU")) if (atoi(e) > 0) ctx->table_blocks_per_cu = (unsigned)atoi(e);
     if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
     ctx->hbm_bytes = prop.totalGlobalMem;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return set_error(nullptr, MDBG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
@@ -84,6 +87,8 @@ extern "C" void mdbg_destroy(mdbg_ctx *ctx) {
     fold_timers(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pool) ctx->pool->close();      // cached blocks are freed now; blocks still handed out free themselves
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -104,6 +109,7 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: null argument");
     const std::string n(name);
     if (n == "table_blocks_per_cu") { ctx->table_blocks_per_cu = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 1024u; return MDBG_OK; }
+    if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }
     if (n == "scan_reads_per_wave") { ctx->scan_reads_per_wave = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 2u; return MDBG_OK; }
     return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: unknown option '%s'", name);
 }

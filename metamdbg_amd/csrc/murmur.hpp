@@ -57,6 +57,22 @@ __host__ __device__ __forceinline__ uint64_t kmer_hash32(uint32_t v) {
     return (((uint64_t)ah << 32) | al) + (((uint64_t)bh << 32) | bl);
 }
 
+// The upper 32 bits of kmer_hash32(v) without the carry out of the lower halves: the final k ^= k >> 33 of either finaliser
+// touches only the lower half, so hi(h1) = hi(mix(a)) + hi(mix(b)) + carry, carry in {0, 1}.  Four operations per hash less
+// than the full value (two shift/xor pairs, the 64-bit add); hi(kmer_hash32(v)) is the result or the result + 1 (mod 2^32).
+__host__ __device__ __forceinline__ uint32_t kmer_hash32_hi_nocarry(uint32_t v) {
+    const uint64_t p = (uint64_t)v * 0x114253d5u;
+    uint32_t l = (uint32_t)p, h = (uint32_t)(p >> 32) + v * 0x87c37b91u;
+    const uint32_t rl = (l << 31) | (h >> 1), rh = (h << 31) | (l >> 1);
+    l = rl; h = rh;
+    mul64_halves(l, h, 0x2745937fu, 0x4cf5ad43u);
+    const uint64_t h1 = ((((uint64_t)h << 32) | l) ^ 34ull) + 34ull, h2 = h1 + 34ull;
+    uint32_t al = (uint32_t)h1, ah = (uint32_t)(h1 >> 32), bl = (uint32_t)h2, bh = (uint32_t)(h2 >> 32);
+    al ^= ah >> 1; mul64_halves(al, ah, 0xed558ccdu, 0xff51afd7u); al ^= ah >> 1; mul64_halves(al, ah, 0x1a85ec53u, 0xc4ceb9feu);
+    bl ^= bh >> 1; mul64_halves(bl, bh, 0xed558ccdu, 0xff51afd7u); bl ^= bh >> 1; mul64_halves(bl, bh, 0x1a85ec53u, 0xc4ceb9feu);
+    return ah + bh;
+}
+
 // Streaming Murmur3 x64-128 over a sequence of u32 words (little-endian), seed 0.
 struct Murmur128Stream {
     uint64_t h1 = 0, h2 = 0;

@@ -82,6 +82,7 @@ struct ScanArgs {
     uint64_t *out_begin;          // per read: first row
     uint32_t *over_list, *suspect_list;
     uint32_t *list_counters;      // [0] = reads in over_list, [1] = reads in suspect_list
+    uint32_t cand_slack;          // scan_fast_kernel<.., APPROX>: extra width of the candidate test (0 but in tests)
 };
 
 // squeeze the 2-bit fields of x whose flag bit (bit 2i of d) is set down to the low end
@@ -764,15 +765,25 @@ struct SpanState {
     uint32_t bits;
 };
 
+// APPROX: the verdict is taken on the upper half of the hash without the carry out of the lower one
+// (kmer_hash32_hi_nocarry): s = that + 1 is hi(hash) or hi(hash) + 1, so  hash < threshold  implies  s < hi(threshold) + 2.
+// The positions recorded are a superset of the selected ones, off by about one in 2^31; every one of them is hashed in
+// full when it is materialised (emit), and a read with a false one is handed to the general kernel.
+template <bool APPROX>
 __device__ __forceinline__ void span_step(SpanState &st, uint32_t T, bool first, uint32_t kmask, uint32_t comp_mask, unsigned top_shift,
-                                          unsigned K, uint64_t threshold) {
+                                          unsigned K, uint64_t threshold, uint32_t cand_limit) {
     const uint32_t rev = (T ^ comp_mask) & kmask;                      // complement of every digit, already in reversed order
     // forward k-mer: digits in reading order; rolled: drop the oldest digit, append the newest (the top digit of T's k-mer)
     st.fwd = first ? digit_reverse(T & kmask, K) : (((st.fwd << 2) | ((T >> top_shift) & 3u)) & kmask);
     const uint32_t val = st.fwd < rev ? st.fwd : rev;
-    const uint64_t h = kmer_hash32(val);
-    // bits = 2 * bits + (h < threshold): one compare into vcc, one add-with-carry
-    asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(st.bits) : "v"(h), "s"(threshold) : "vcc");
+    if (APPROX) {
+        const uint32_t s1 = kmer_hash32_hi_nocarry(val) + 1u;
+        asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(st.bits) : "v"(s1), "s"(cand_limit) : "vcc");
+    } else {
+        const uint64_t h = kmer_hash32(val);
+        // bits = 2 * bits + (h < threshold): one compare into vcc, one add-with-carry
+        asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(st.bits) : "v"(h), "s"(threshold) : "vcc");
+    }
 }
 
 // the 32 stream bits that start at ring position p (any p), from LDS
@@ -781,13 +792,18 @@ __device__ __forceinline__ uint32_t ring_window(const uint32_t *S, unsigned p) {
     return __builtin_amdgcn_alignbit(S[(w + 1) & RING_WMASK], S[w], sh);
 }
 
-// QUAL (reads with qualities; without homopolymer compression only, where original and compressed coordinates coincide): the
-// minimum quality over every minimizer's bases (getMinQuality, ReadSelection.hpp:1302-1320; ReadCorrection.hpp:2467-2481) is
-// taken when the minimizer is materialised and travels with its row.
-template <bool HPC, bool QUAL>
+// QUAL (reads with qualities): the minimum quality over every minimizer's ORIGINAL bases (getMinQuality,
+// ReadSelection.hpp:1302-1320; ReadCorrection.hpp:2467-2481) is taken when the minimizer is materialised and travels with its
+// row.  Without homopolymer compression original and compressed coordinates coincide.  With it, rlePositions[j] -- the original
+// start of run j (Commons.hpp:4188-4190) -- is looked up for the few selected positions only, instead of being stored for all
+// of them: per tile every lane keeps its offset in the compressed stream (HIST_TILES tiles back, 2 bytes per word), a selected
+// lane finds the tile, then the word (binary search over the 64 offsets), re-reads that word and picks the k-th run start.
+constexpr int HIST_TILES = 8;
+template <bool HPC, bool QUAL, bool APPROX>
 __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
-    static_assert(!(HPC && QUAL), "qualities under homopolymer compression take the general kernel");
     __shared__ uint8_t lds_stage_q[QUAL ? FAST_WAVES : 1][QUAL ? STAGE_CAP : 1];
+    __shared__ uint16_t lds_hist_o[(QUAL && HPC) ? FAST_WAVES * HIST_TILES * 64 : 1];
+    __shared__ uint32_t lds_hist_c[(QUAL && HPC) ? FAST_WAVES : 1][(QUAL && HPC) ? HIST_TILES : 1];
     __shared__ uint32_t lds_ring[FAST_WAVES][RING_WORDS];
     __shared__ uint2 lds_stage[FAST_WAVES][STAGE_CAP];
     __shared__ uint16_t lds_lut[HPC ? HPC_LUT_SIZE : 1];
@@ -801,11 +817,16 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     uint32_t *S = lds_ring[wv];
     uint2 *stage = lds_stage[wv];
     uint8_t *stage_q = lds_stage_q[QUAL ? wv : 0];
+    uint16_t *hist_o = lds_hist_o + ((QUAL && HPC) ? wv * HIST_TILES * 64 : 0);      // [tile % HIST_TILES][lane]
+    uint32_t *hist_c = lds_hist_c[(QUAL && HPC) ? wv : 0];
     const unsigned K = a.K;
     const uint32_t kmask = (K >= 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
     const uint32_t comp_mask = 0xAAAAAAAAu & kmask;
     const unsigned top_shift = 2u * K - 2u;
     const uint64_t threshold = a.threshold;
+    // APPROX (bump mode only: a read with a false candidate needs the host's re-run): see span_step.  cand_slack widens the
+    // superset on purpose (tests of the re-run path)
+    const uint32_t cand_limit = (uint32_t)(threshold >> 32) + 2u + a.cand_slack;
 
     const uint32_t wave_global = blockIdx.x * FAST_WAVES + wv;
     const uint32_t n_waves = gridDim.x * FAST_WAVES;
@@ -818,24 +839,74 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
         const bool bump = a.cursor != nullptr;
         const uint64_t cap0 = bump ? 0ull : a.cap_off[r];
         const uint32_t cap = bump ? 0u : (uint32_t)(a.cap_off[r + 1] - cap0);
-        bool outgrown = false;     // bump mode: the read selected more than the stage holds -> listed, re-run by the host
+        uint32_t t_done = 0;       // raw tiles appended to the ring so far (HPC && QUAL: their offsets are in hist_*)
+        uint32_t fill = 0;         // compressed bases written to the ring so far (= stream length)
+        bool outgrown = false;     // the read selected more than the stage holds, or needs a run start the history no longer has:
+                                   // listed, placed and re-run by the host with the general kernel
 
-        const uint8_t *qq = QUAL ? a.qual + a.qual_off[r] : nullptr;
-        auto min_quality = [&](uint32_t j) {       // the l bases of the l-mer at j (no HPC: [rle[pos], rle[pos + l]) = [j, j + l))
-            // l <= 16 bytes in two unaligned 8-byte loads (the quality buffer is padded by 16 bytes at both ends) instead of a
-            // chain of l dependent byte loads: a selected lane would otherwise wait longer than its whole block took to hash
-            uint64_t w[2];
-            __builtin_memcpy(w, qq + j, 16);
-            uint8_t mq = 255;
+        // rlePositions[j]: the original coordinate of compressed position j (HPC && QUAL); j == fill at the end of the read is the
+        // sentinel `length` (Commons.hpp:4188-4190).  0xFFFFFFFF: the tile is no longer in the history.
+        auto orig_of = [&](uint32_t j, bool at_end) -> uint32_t {
+            if (at_end && j >= fill) return L;
+            uint32_t tt = t_done - 1u;
+            const uint32_t t_low = t_done > (uint32_t)HIST_TILES ? t_done - (uint32_t)HIST_TILES : 0u;
+            while (tt > t_low && hist_c[tt % HIST_TILES] > j) tt--;
+            const uint32_t c0 = hist_c[tt % HIST_TILES];
+            if (c0 > j) return 0xFFFFFFFFu;
+            const uint32_t rel = j - c0;
+            const uint16_t *o = hist_o + (tt % HIST_TILES) * 64u;
+            uint32_t lo = 0;           // last word whose first run starts at or before rel: three rounds of three reads each
 #pragma unroll
-            for (unsigned b = 0; b < 16; b++) {
-                const uint8_t q = (uint8_t)((uint8_t)(w[b >> 3] >> (8 * (b & 7))) - 33);
-                if (b < K && q < mq) mq = q;
+            for (uint32_t st = 16; st >= 1; st >>= 2) {
+                const uint32_t o1 = o[lo + st], o2 = o[lo + 2 * st], o3 = o[lo + 3 * st];
+                lo += st * ((o1 <= rel ? 1u : 0u) + (o2 <= rel ? 1u : 0u) + (o3 <= rel ? 1u : 0u));
+            }
+            uint32_t k = rel - o[lo];
+            const uint32_t wi = tt * TILE_WORDS + lo;
+            const uint64_t x = rw[wi];
+            const uint32_t pl = wi ? (uint32_t)(rw[wi - 1] >> 62) : (((uint32_t)x & 3u) ^ 1u);   // the first base of the read starts a run
+            const int rem = (int)L - (int)(wi * 32u);
+            const unsigned nvalid = rem >= 32 ? 32u : (unsigned)rem;
+            const uint64_t vspread = nvalid == 32 ? M5 : (((1ull << (2 * nvalid)) - 1ull) & M5);
+            const uint64_t diff = x ^ ((x << 2) | (uint64_t)pl);
+            uint64_t m = (diff | (diff >> 1)) & vspread;          // bit 2i: base i starts a run
+            uint32_t pos = 0;
+#pragma unroll
+            for (int sh = 32; sh >= 2; sh >>= 1) {                // the k-th set bit (k counted from 0)
+                const uint32_t c = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
+                if (k >= c) { k -= c; m >>= sh; pos += (uint32_t)sh; }
+            }
+            return wi * 32u + (pos >> 1);
+        };
+        const uint8_t *qq = QUAL ? a.qual + a.qual_off[r] : nullptr;
+        // minimum quality of the minimizer at compressed position j; unknown = false when a run start has left the history
+        auto min_quality = [&](uint32_t j, bool &known) -> uint8_t {
+            uint32_t os = j, oe = j + K;
+            if (HPC) {     // [rle[pos], rle[pos + l]) (ReadSelection.hpp:1135) or [rle[pos], rle[pos + l - 1]] (ReadCorrection.hpp:2340)
+                os = orig_of(j, false);
+                const uint32_t last = orig_of(j + K - a.q_last, true);
+                if (os == 0xFFFFFFFFu || last == 0xFFFFFFFFu) { known = false; return 0; }
+                oe = last + a.q_last;
+            }
+            // 16 bytes per step in two unaligned 8-byte loads (the quality buffer is padded by 32 bytes) instead of a chain of
+            // dependent byte loads: a selected lane would otherwise wait longer than its whole block took to hash
+            uint8_t mq = 255;
+            for (uint32_t b0 = os; b0 < oe; b0 += 16) {
+                uint64_t w[2];
+                __builtin_memcpy(w, qq + b0, 16);
+                const uint32_t nb = oe - b0 < 16u ? oe - b0 : 16u;
+#pragma unroll
+                for (unsigned b = 0; b < 16; b++) {
+                    const uint8_t q = (uint8_t)((uint8_t)(w[b >> 3] >> (8 * (b & 7))) - 33);
+                    if (b < nb && q < mq) mq = q;
+                }
             }
             return mq;
         };
 
-        uint32_t fill = 0;         // compressed bases written to the ring so far (= stream length)
+        bool lost = false;         // per lane: a quality span could not be resolved, or a recorded position turned out not to be
+                                   // selected (APPROX): folded into `outgrown` at the end of the read
+        uint32_t n_false = 0;      // APPROX: recorded positions the full hash rejected (the read's count is nout - n_false)
         uint32_t done = 0;         // positions already evaluated (= ring position of the next block, a multiple of 2048)
         uint32_t nout = 0;         // minimizers of this read so far
         uint32_t flushed = 0;      // ... of which already written to the output slot
@@ -871,7 +942,20 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             if (total == 0u) return;
             if (bump) {
-                if (outgrown || nout + total > (unsigned)STAGE_CAP) { outgrown = true; nout += total; return; }
+                if (outgrown || nout + total > (unsigned)STAGE_CAP) {
+                    if (APPROX) {          // the count the host places the read by must be exact: hash the candidates in full
+                        uint32_t bad = 0;
+                        while (bits) {
+                            const unsigned bit = 31u - (unsigned)__clz((int)bits);
+                            bits &= ~(1u << bit);
+                            const uint32_t e = ring_window(S, done + lane * P + (P - 1u - bit)) & kmask;
+                            const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
+                            if (!(kmer_hash32(fw < rev ? fw : rev) < threshold)) bad++;
+                        }
+                        n_false += (uint32_t)wave_sum_u64(bad);
+                    }
+                    outgrown = true; nout += total; return;
+                }
             } else if (nout - flushed + total > (unsigned)STAGE_CAP) {       // make room: the staged rows leave for the output slot
                 const uint32_t ns = nout - flushed;
                 for (uint32_t i = lane; i < ns; i += 64) {
@@ -886,19 +970,31 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 wave_lds_sync();
             }
             if (total <= (unsigned)STAGE_CAP) {
-                uint32_t at = nout - flushed + incl - cnt;
+                // the selected positions are first listed in the stage, then taken one per lane: the long part (window, canonical
+                // form and, with qualities, the look-ups behind min_quality) runs once per 64 minimizers instead of once per
+                // round of the lane that holds the most of them
+                const uint32_t base = nout - flushed;
+                uint32_t at = base + incl - cnt;
                 while (bits) {
                     const unsigned bit = 31u - (unsigned)__clz((int)bits);
                     bits &= ~(1u << bit);
-                    const unsigned u = P - 1u - bit;
-                    const uint32_t j = done + lane * P + u;                    // position in the compressed read
+                    stage[at++].y = done + lane * P + (P - 1u - bit);          // position in the compressed read
+                }
+                wave_lds_sync();
+                for (uint32_t i = lane; i < total; i += 64) {
+                    const uint32_t j = stage[base + i].y;
                     const uint32_t e = ring_window(S, j) & kmask;
                     const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
                     // direction 1 iff the reverse complement is the canonical form, ties included (Kmer.hpp:427)
                     const uint32_t d = fw < rev ? 0u : 1u;
-                    if (QUAL) stage_q[at] = min_quality(j);
-                    stage[at++] = make_uint2(d ? rev : fw, (j << 1) | d);
+                    if (QUAL) { bool known = true; stage_q[base + i] = min_quality(j, known); if (!known) lost = true; }
+                    stage[base + i] = make_uint2(d ? rev : fw, (j << 1) | d);
+                    if (APPROX) {          // the full hash of every recorded position; a false one loses the read to the re-run
+                        const uint64_t fb = __ballot(!(kmer_hash32(d ? rev : fw) < threshold));
+                        if (fb) { n_false += (uint32_t)__popcll(fb); lost = true; }
+                    }
                 }
+                wave_lds_sync();
             } else {
                 // more selected positions in one block than the stage holds (densities near 1): straight to the slot
                 uint32_t at = nout + incl - cnt;
@@ -912,7 +1008,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     const uint32_t d = fw < rev ? 0u : 1u;
                     if (at < cap) {
                         a.out_min[cap0 + at] = d ? rev : fw; a.out_pos[cap0 + at] = j; a.out_dir[cap0 + at] = (uint8_t)d;
-                        if (QUAL) a.out_mqual[cap0 + at] = min_quality(j);
+                        if (QUAL) { bool known = true; a.out_mqual[cap0 + at] = min_quality(j, known); if (!known) lost = true; }
                     }
                     at++;
                 }
@@ -933,7 +1029,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             for (int u = 0; u < SP; u++) {
                 const uint32_t T = u == 0 ? W0 : (u < 16 ? __builtin_amdgcn_alignbit(W1, W0, 2 * u)
                                                          : (u == 16 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * (u - 16))));
-                span_step(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold);
+                span_step<APPROX>(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold, cand_limit);
             }
             emit(st.bits, (unsigned)SP, 64u * (unsigned)SP);
             wave_lds_sync();
@@ -1006,6 +1102,11 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 if (p1) atomicOr(&S[(w + 1) & RING_WMASK], p1);
                 if (p2) atomicOr(&S[(w + 2) & RING_WMASK], p2);
             }
+            if (HPC && QUAL) {         // where this tile's words start in the compressed stream (for rlePositions look-ups)
+                hist_o[(t % HIST_TILES) * 64u + lane] = (uint16_t)o;
+                if (lane == 0) hist_c[t % HIST_TILES] = fill;
+                t_done = t + 1u;
+            }
             fill += C;
             wave_lds_sync();
 
@@ -1032,7 +1133,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint32_t T = u == 0 ? a0 : __builtin_amdgcn_alignbit(a1, a0, 2 * u);
-                        span_step(st, T, g == 0 && u == 0, kmask, comp_mask, top_shift, K, threshold);
+                        span_step<APPROX>(st, T, g == 0 && u == 0, kmask, comp_mask, top_shift, K, threshold, cand_limit);
                     }
                 }
                 emit(st.bits, P, npos);
@@ -1045,6 +1146,8 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             }
         }
 
+        if (((QUAL && HPC) || APPROX) && __ballot(lost) != 0ull) outgrown = true;      // a run start had left the history, or a false candidate:
+                                                                                        // the general kernel redoes the read
         uint8_t flags = 0;
         if (a.apply_filters && L >= 66) {
             const uint64_t bound = wave_sum_u64(cx_acc);
@@ -1070,7 +1173,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             }
             if (lane == 0) {
                 a.out_begin[r] = start;
-                a.out_count[r] = nout;              // also for a read that outgrew the stage: the host places and re-runs it
+                a.out_count[r] = nout - n_false;    // also for a read that outgrew the stage: the host places and re-runs it
                 a.out_flags[r] = flags;
                 if (outgrown) a.over_list[atomicAdd(&a.list_counters[0], 1u)] = r;
                 if (flags & READ_SUSPECT) a.suspect_list[atomicAdd(&a.list_counters[1], 1u)] = r;
@@ -1238,6 +1341,18 @@ static float mean_quality_from_sum(long double error_sum_in, size_t n_in) {
     return -10.0f * log10f(mean_err);
 }
 
+// grow-only pinned host buffer of the context (device -> host copies that must not wait for the main stream)
+static int pinned_reserve(mdbg_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) return MDBG_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->pinned = nullptr; return set_error(ctx, MDBG_ENOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); }
+    ctx->pinned_bytes = want;
+    return MDBG_OK;
+}
+
 static std::mutex &device_scan_mutex(int device) {
     static std::mutex m[64];
     return m[(unsigned)device % 64u];
@@ -1266,15 +1381,26 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
     {
         LaunchTimer timer(ctx, "scan");
         static const bool no_fast = getenv("MDBG_SCAN_NO_FAST") != nullptr;      // A/B: the general kernel for everything
-        if ((!has_q || (!hpc && a.cursor)) && !has_n && !a.subset && !no_fast) {
+        static const bool no_approx = getenv("MDBG_SCAN_NO_APPROX") != nullptr;  // A/B: full 64-bit verdict at every position
+        if ((!has_q || a.cursor) && !has_n && !a.subset && !no_fast) {
             // plain ACGT without qualities: the block-structured kernel; a few reads per wave, then the wave retires
             const uint64_t per_wave = ctx->scan_reads_per_wave;
             uint64_t blocks = ((uint64_t)n_items + FAST_WAVES * per_wave - 1) / (FAST_WAVES * per_wave);
             if (blocks < 1) blocks = 1;
             if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
-            if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
-            else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((scan_fast_kernel<false, false>), dim3((unsigned)blocks), dim3(FAST_BLOCK), 0, ctx->stream, a);
+            // bump mode: candidates by the upper half of the hash (span_step<APPROX>); the host's re-run of a read covers a false one
+            const dim3 g((unsigned)blocks), b(FAST_BLOCK);
+            if (a.cursor && !no_approx) {
+                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, true>), g, b, 0, ctx->stream, a);
+                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, true>), g, b, 0, ctx->stream, a);
+                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, true>), g, b, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((scan_fast_kernel<false, false, true>), g, b, 0, ctx->stream, a);
+            } else {
+                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, false>), g, b, 0, ctx->stream, a);
+                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, false>), g, b, 0, ctx->stream, a);
+                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, false>), g, b, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((scan_fast_kernel<false, false, false>), g, b, 0, ctx->stream, a);
+            }
         } else if (hpc) {
             if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }
             else { if (has_q) launch_variant<true, true, false>(ctx, a, max_blocks, n_items); else launch_variant<true, false, false>(ctx, a, max_blocks, n_items); }
@@ -1320,36 +1446,20 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // ---- mean read quality (exact 128-bit sums on the device, long double finish on the host) ----
     std::vector<uint8_t> low_quality;
     bool any_low_quality = false;
-    if (has_q && n) {
-        // table exactly as the reference builds it (ReadSelection.hpp:101-104, Commons.hpp:2338-2341)
-        std::vector<uint64_t> tsh(QBINS, 0);
-        for (int q = 33; q <= 127; q++) {
-            float qq = (float)(uint8_t)(q - 33);
-            float t = powf(10.0f, -qq / 10.0f);
-            long double scaled = (long double)t * 18446744073709551616.0L;   // * 2^64, exact (24-bit mantissa)
-            unsigned __int128 v = (unsigned __int128)scaled;
-            if ((uint64_t)v & ((1ull << QSHIFT) - 1ull)) return fail(set_error(ctx, MDBG_EINVAL, "quality table entry %d is not a multiple of 2^%d", q, QSHIFT));
-            tsh[q - 33] = (uint64_t)(v >> QSHIFT);
-        }
-        DevBuf<uint64_t> d_tab, d_slo, d_shi;
-        if ((rc = d_tab.alloc(ctx, QBINS)) || (rc = d_slo.alloc(ctx, n)) || (rc = d_shi.alloc(ctx, n))) return fail(rc);
-        if ((e = memcpy_sync(ctx, d_tab.p, tsh.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess)
-            return fail(set_error(ctx, MDBG_EHIP, "quality table upload failed: %s", hipGetErrorString(e)));
-        {
-            LaunchTimer timer(ctx, "quality_sum");
-            unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 8u);
-            hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_qual.p, reads->d_qual_off.p,
-                               reads->d_len.p, n, d_tab.p, d_slo.p, d_shi.p);
-        }
-        std::vector<uint64_t> slo(n), shi(n);
-        std::vector<uint32_t> lens(n);
-        if ((e = memcpy_sync(ctx, slo.data(), d_slo.p, (size_t)n * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
-            (e = memcpy_sync(ctx, shi.data(), d_shi.p, (size_t)n * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
-            (e = memcpy_sync(ctx, lens.data(), reads->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess)
-            return fail(set_error(ctx, MDBG_EHIP, "quality sums download failed: %s", hipGetErrorString(e)));
+    DevBuf<uint64_t> d_qtab, d_slo, d_shi;
+    struct SideGuard { hipStream_t s = nullptr; ~SideGuard() { if (s) (void)hipStreamSynchronize(s); } } side_guard;   // before the buffers go
+    bool quality_pending = false;
+    // the host's share of the mean qualities: the reference's long double division and log10 per read, on a few host threads
+    auto quality_finish = [&]() -> int {
+        if (!quality_pending) return MDBG_OK;
+        quality_pending = false;
+        hipError_t qe;
+        if ((qe = hipStreamSynchronize(ctx->side_stream)) != hipSuccess)
+            return set_error(ctx, MDBG_EHIP, "quality sums download failed: %s", hipGetErrorString(qe));
+        const uint64_t *slo = (const uint64_t *)ctx->pinned, *shi = slo + n;
+        const uint32_t *lens = (const uint32_t *)(shi + n);
         m->h_mean_quality.resize(n);
         low_quality.assign(n, 0);
-        // the reference's long double division and log10 per read, on a few host threads
         const bool filter = p->apply_read_filters != 0;
         const float min_q = p->min_read_quality;
         const unsigned n_thr = n < 65536 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -1370,6 +1480,45 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
             for (auto &th : pool) th.join();
         }
         for (char c : any) any_low_quality |= c != 0;
+        return MDBG_OK;
+    };
+    if (has_q && n) {
+        // table exactly as the reference builds it (ReadSelection.hpp:101-104, Commons.hpp:2338-2341)
+        std::vector<uint64_t> tsh(QBINS, 0);
+        for (int q = 33; q <= 127; q++) {
+            float qq = (float)(uint8_t)(q - 33);
+            float t = powf(10.0f, -qq / 10.0f);
+            long double scaled = (long double)t * 18446744073709551616.0L;   // * 2^64, exact (24-bit mantissa)
+            unsigned __int128 v = (unsigned __int128)scaled;
+            if ((uint64_t)v & ((1ull << QSHIFT) - 1ull)) return fail(set_error(ctx, MDBG_EINVAL, "quality table entry %d is not a multiple of 2^%d", q, QSHIFT));
+            tsh[q - 33] = (uint64_t)(v >> QSHIFT);
+        }
+        if ((rc = d_qtab.alloc(ctx, QBINS)) || (rc = d_slo.alloc(ctx, n)) || (rc = d_shi.alloc(ctx, n))) return fail(rc);
+        if ((e = memcpy_sync(ctx, d_qtab.p, tsh.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(set_error(ctx, MDBG_EHIP, "quality table upload failed: %s", hipGetErrorString(e)));
+        // The sums run in front of the scan; their way to the host (side stream, pinned memory) and the host's share
+        // (quality_finish) overlap the scan kernel: nothing of the mean quality is needed before the rows are counted
+        {
+            LaunchTimer timer(ctx, "quality_sum");
+            unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 8u);
+            hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_qual.p, reads->d_qual_off.p,
+                               reads->d_len.p, n, d_qtab.p, d_slo.p, d_shi.p);
+        }
+        if ((rc = pinned_reserve(ctx, (size_t)n * 20))) return fail(rc);
+        {
+            hipEvent_t summed;
+            if ((e = hipEventCreateWithFlags(&summed, hipEventDisableTiming)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "hipEventCreate: %s", hipGetErrorString(e)));
+            (void)hipEventRecord(summed, ctx->stream);
+            (void)hipStreamWaitEvent(ctx->side_stream, summed, 0);
+            (void)hipEventDestroy(summed);
+            uint8_t *h = (uint8_t *)ctx->pinned;
+            if ((e = hipMemcpyAsync(h, d_slo.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->side_stream)) != hipSuccess ||
+                (e = hipMemcpyAsync(h + (size_t)n * 8, d_shi.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->side_stream)) != hipSuccess ||
+                (e = hipMemcpyAsync(h + (size_t)n * 16, reads->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->side_stream)) != hipSuccess)
+                return fail(set_error(ctx, MDBG_EHIP, "quality sums download failed: %s", hipGetErrorString(e)));
+        }
+        side_guard.s = ctx->side_stream;
+        quality_pending = true;
     } else {
         // no qualities: every read's mean quality is the NaN the reference writes; kept as one value, not n of them (a 40 MB
         // host fill per 10 M reads sat on the critical path in front of the kernel launch)
@@ -1384,7 +1533,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // (a read may stage STAGE_CAP minimizers: batches whose longest read is expected to select more go straight to the general path)
     // A read may stage STAGE_CAP minimizers; the few that select more are re-run by the general kernel into a reserve behind
     // the regions.  Batches whose AVERAGE read is expected to outgrow the stage go straight to the general path.
-    if (n && (!has_q || !hpc) && !has_n && !no_bump && p->density < 0.2f && reads->max_len < (1u << 31) &&
+    if (n && !has_n && !no_bump && p->density < 0.2f && reads->max_len < (1u << 31) &&
         (double)reads->n_bases / (double)n * (double)p->density * (hpc ? 0.8 : 1.0) * 1.4 + 24.0 < (double)STAGE_CAP) {
         // the output arrays are cut into regions, each with its own cursor (reads are dealt to the waves round-robin, so the regions
         // fill evenly); small batches use one
@@ -1408,16 +1557,19 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         a.K = p->minimizer_size;
         a.threshold = density_threshold(p->density);
         a.trim = p->no_end_trim ? 0u : 1u;
+        a.q_last = p->quality_window == 1 ? 1u : 0u;
         a.rep = d_rep.p; a.n_rep = p->n_repetitive;
         a.apply_filters = p->apply_read_filters;
         a.out_min = m->d_min.p; a.out_pos = m->d_pos.p; a.out_dir = m->d_dir.p; a.out_mqual = m->d_mqual.p;
         a.out_count = m->d_cnt.p; a.out_flags = m->d_flags.p;
         a.cursor = d_ctl.p; a.n_regions = n_regions; a.out_capacity = region_cap; a.out_begin = m->d_begin.p;
         a.over_list = d_over.p; a.suspect_list = d_susp.p; a.list_counters = (uint32_t *)(d_ctl.p + CTL_OVER);
+        a.cand_slack = ctx->scan_cand_slack;
         unsigned long long h_ctl[CTL_WORDS];
         {
             std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));      // one scan kernel at a time per device (see below)
             if ((rc = launch_scan(ctx, a, hpc, has_q, false, n))) return fail(rc);
+            if ((rc = quality_finish())) return fail(rc);          // host work while the kernel runs
             e = memcpy_sync(ctx, h_ctl, d_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost);
         }
         if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "scan counters copy failed: %s", hipGetErrorString(e)));
@@ -1535,6 +1687,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // launch and is released when the kernel has finished (the counter download below waits for it).
     std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));
     if (n && (rc = launch_scan(ctx, a, hpc, has_q, has_n, n))) return fail(rc);
+    if ((rc = quality_finish())) return fail(rc);                  // host work while the kernel runs (once: the call above may have done it)
 
     // overflow handling (reads that selected more than their padded capacity are re-run with exact room)
     // and the exact complexity pass over the few reads the 2-mer bound could not clear
