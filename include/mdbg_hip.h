@@ -124,6 +124,9 @@ typedef struct {
     int32_t  no_end_trim;         /* 0: MinimizerParser's default _trimBps = 1, the first and last l-mer of a read are never
                                      selected (utils/kmer/Kmer.hpp:1362, :1395); 1: _trimBps = 0 as GenerateGfa's
                                      LoadUnitigsFunctor sets it for unitig sequences (graph/GenerateGfa.hpp:366) */
+    int32_t  ignore_qualities;    /* 1: the read set's qualities are not looked at, as if it had none (every minimizer's quality
+                                     is 1, the mean read quality NaN): CountMinimizerFunctor's census of minimizer values
+                                     (ReadSelection.hpp:565-625) over reads that are resident with their qualities */
 } mdbg_scan_params;
 
 /* Replaces, for a whole batch, EncoderRLE::execute + MinimizerParser::parse + complexity /

@@ -26,7 +26,8 @@ class MdbgError(RuntimeError):
 class ScanParams(C.Structure):
     _fields_ = [("minimizer_size", C.c_uint32), ("density", C.c_float), ("hpc", C.c_int32),
                 ("min_read_quality", C.c_float), ("repetitive", C.POINTER(C.c_uint32)),
-                ("n_repetitive", C.c_uint32), ("apply_read_filters", C.c_int32), ("quality_window", C.c_int32), ("no_end_trim", C.c_int32)]
+                ("n_repetitive", C.c_uint32), ("apply_read_filters", C.c_int32), ("quality_window", C.c_int32), ("no_end_trim", C.c_int32),
+                ("ignore_qualities", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/mdbg_hip.h declares
@@ -206,10 +207,10 @@ class Context:
 
     def scan(self, reads: "Reads", K: int = 15, density: float = 0.005, hpc: bool = True,
              min_read_quality: float = 0.0, repetitive=None, apply_read_filters: bool = True,
-             quality_window: int = 0, no_end_trim: bool = False) -> "Minimizers":
+             quality_window: int = 0, no_end_trim: bool = False, ignore_qualities: bool = False) -> "Minimizers":
         rep = np.ascontiguousarray(repetitive if repetitive is not None else [], dtype=np.uint32)
         p = ScanParams(K, density, int(hpc), min_read_quality, rep.ctypes.data_as(C.POINTER(C.c_uint32)), len(rep),
-                       int(apply_read_filters), int(quality_window), int(no_end_trim))
+                       int(apply_read_filters), int(quality_window), int(no_end_trim), int(ignore_qualities))
         h = C.c_void_p()
         self.check(lib().mdbg_scan(self.h, reads.h, C.byref(p), C.byref(h)))
         return Minimizers(self, h)

@@ -217,15 +217,30 @@ __global__ __launch_bounds__(256) void census_insert_kernel(const uint32_t *vals
     }
 }
 
-__global__ void census_flag_kernel(const unsigned long long *keys, uint64_t cap, uint32_t *flag) {
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < cap) flag[s] = keys[s] != 0ull ? 1u : 0u;
+// How many distinct values were seen 1, 2, ... CENSUS_BINS-1 (or more) times: the cut-off count of the top fraction is
+// read off this histogram, so only the values at or above it travel to the host (tens to hundreds of 13 M distinct values
+// at the ONT census; downloading and partially sorting all of them took longer than counting them)
+constexpr uint32_t CENSUS_BINS = 4096;
+__global__ __launch_bounds__(256) void census_hist_kernel(const unsigned long long *keys, const uint32_t *counts, uint64_t cap,
+                                                          unsigned long long *hist) {
+    __shared__ uint32_t h[CENSUS_BINS];
+    for (uint32_t i = threadIdx.x; i < CENSUS_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * 256) {
+        if (keys[s] != 0ull) { const uint32_t c = counts[s]; atomicAdd(&h[c < CENSUS_BINS - 1u ? c : CENSUS_BINS - 1u], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CENSUS_BINS; i += 256) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-__global__ void census_emit_kernel(const unsigned long long *keys, const uint32_t *counts, uint64_t cap, const uint32_t *flag,
-                                   const uint64_t *pos, uint32_t *out_val, uint32_t *out_cnt) {
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < cap && flag[s]) { out_val[pos[s]] = (uint32_t)(keys[s] - 1ull); out_cnt[pos[s]] = counts[s]; }
+__global__ __launch_bounds__(256) void census_top_kernel(const unsigned long long *keys, const uint32_t *counts, uint64_t cap, uint32_t cut,
+                                                         uint32_t *out_val, uint32_t *out_cnt, unsigned long long *cursor, uint64_t room) {
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * 256) {
+        if (keys[s] != 0ull && counts[s] >= cut) {
+            const unsigned long long at = atomicAdd(cursor, 1ull);
+            if (at < room) { out_val[at] = (uint32_t)(keys[s] - 1ull); out_cnt[at] = counts[s]; }
+        }
+    }
 }
 
 }  // namespace mdbg
@@ -428,39 +443,52 @@ extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *
     const uint64_t n = m->n_min;
     uint64_t cap = 1024;
     while (cap < n * 2) cap <<= 1;
-    DevBuf<unsigned long long> keys;
-    DevBuf<uint32_t> counts, flag, oval, ocnt;
-    DevBuf<uint64_t> pos;
+    DevBuf<unsigned long long> keys, hist;
+    DevBuf<uint32_t> counts, oval, ocnt;
     MDBG_TRY(keys.alloc(ctx, cap));
     MDBG_TRY(counts.alloc(ctx, cap));
-    MDBG_TRY(flag.alloc(ctx, cap));
-    MDBG_TRY(pos.alloc(ctx, cap + 1));
+    MDBG_TRY(hist.alloc(ctx, CENSUS_BINS + 1));               // + the cursor of the second pass
     MDBG_HIP_CHECK(ctx, hipMemsetAsync(keys.p, 0, cap * 8, ctx->stream));
     MDBG_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, cap * 4, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(hist.p, 0, (CENSUS_BINS + 1) * 8, ctx->stream));
     if (n) {
         LaunchTimer timer(ctx, "minimizer_census");
         hipLaunchKernelGGL(census_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, keys.p, counts.p, cap - 1);
     }
-    hipLaunchKernelGGL(census_flag_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, ctx->stream, keys.p, cap, flag.p);
-    MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, cap));
-    uint64_t distinct = 0;
-    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &distinct, pos.p + cap, 8, hipMemcpyDeviceToHost));
-    MDBG_TRY(oval.alloc(ctx, distinct));
-    MDBG_TRY(ocnt.alloc(ctx, distinct));
-    hipLaunchKernelGGL(census_emit_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, flag.p, pos.p, oval.p, ocnt.p);
-    std::vector<uint32_t> hv(distinct), hc(distinct);
-    if (distinct) {
-        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hv.data(), oval.p, distinct * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), ocnt.p, distinct * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const unsigned sweep_blocks = grid_for(cap, 256, (unsigned)ctx->n_cu * 8u);
+    std::vector<unsigned long long> h_hist(CENSUS_BINS);
+    {
+        LaunchTimer timer(ctx, "minimizer_census");
+        hipLaunchKernelGGL(census_hist_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, hist.p);
     }
-    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // top-N selection on the host (O(distinct), ReadSelection.hpp:515-540)
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h_hist.data(), hist.p, CENSUS_BINS * 8, hipMemcpyDeviceToHost));
+    uint64_t distinct = 0;
+    for (unsigned long long c : h_hist) distinct += c;
+    // the top max(1, fraction * distinct) values by count (ReadSelection.hpp:515-540)
     float fraction = 0.00001f;
     int keep = (int)(fraction * (float)distinct);
     if (keep < 1) keep = 1;
     if ((uint64_t)keep > distinct) keep = (int)distinct;
-    std::vector<uint64_t> order(distinct);
-    for (uint64_t i = 0; i < distinct; i++) order[i] = i;
+    // smallest count such that the values seen at least that often are `keep` or more: everything above it is in, the ties at it
+    // are ordered on the host.  (The last bin holds every count >= CENSUS_BINS - 1: a cut there takes them all.)
+    uint32_t cut = CENSUS_BINS - 1u;
+    uint64_t n_top = h_hist[cut];
+    while (cut > 1u && n_top < (uint64_t)keep) n_top += h_hist[--cut];
+    std::vector<uint32_t> hv(n_top), hc(n_top);
+    if (n_top) {
+        MDBG_TRY(oval.alloc(ctx, n_top));
+        MDBG_TRY(ocnt.alloc(ctx, n_top));
+        {
+            LaunchTimer timer(ctx, "minimizer_census");
+            hipLaunchKernelGGL(census_top_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, cut, oval.p, ocnt.p,
+                               hist.p + CENSUS_BINS, n_top);
+        }
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hv.data(), oval.p, n_top * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), ocnt.p, n_top * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> order(n_top);
+    for (uint64_t i = 0; i < n_top; i++) order[i] = i;
     std::partial_sort(order.begin(), order.begin() + keep, order.end(), [&](uint64_t a, uint64_t b) {
         if (hc[a] != hc[b]) return hc[a] > hc[b];
         return hv[a] < hv[b];

@@ -123,26 +123,23 @@ __device__ __forceinline__ uint16_t hpc_lut_entry(unsigned idx) {
 }
 
 // x squeezed to its run starts given the base `pl` preceding the word; *nbits = 2 * kept
-__device__ __forceinline__ uint64_t compress_pairs_lut(const uint16_t *lut, uint64_t x, uint32_t pl, unsigned *nbits) {
+// (the two halves of an entry live in two tables: LDS reads are not what this kernel is short of, and the merge below
+// then is one shift-or and one add per entry instead of four operations)
+struct HpcLut { const uint8_t *bits, *twice_kept; };
+__device__ __forceinline__ uint64_t compress_pairs_lut(HpcLut lut, uint64_t x, uint32_t pl, unsigned *nbits) {
     const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
-    const uint32_t e0 = lut[((xl & 0xFFu) << 2) | pl];
-    const uint32_t e1 = lut[(xl >> 6) & 0x3FFu];
-    const uint32_t e2 = lut[(xl >> 14) & 0x3FFu];
-    const uint32_t e3 = lut[xl >> 22];
-    const uint32_t e4 = lut[__builtin_amdgcn_alignbit(xh, xl, 30) & 0x3FFu];
-    const uint32_t e5 = lut[(xh >> 6) & 0x3FFu];
-    const uint32_t e6 = lut[(xh >> 14) & 0x3FFu];
-    const uint32_t e7 = lut[xh >> 22];
-    uint32_t lo = e0 & 0xFFu;
-    unsigned n = e0 >> 8;
-    lo |= (e1 & 0xFFu) << n; n += e1 >> 8;
-    lo |= (e2 & 0xFFu) << n; n += e2 >> 8;
-    lo |= (e3 & 0xFFu) << n; n += e3 >> 8;
-    uint32_t hi = e4 & 0xFFu;
-    unsigned m = e4 >> 8;
-    hi |= (e5 & 0xFFu) << m; m += e5 >> 8;
-    hi |= (e6 & 0xFFu) << m; m += e6 >> 8;
-    hi |= (e7 & 0xFFu) << m; m += e7 >> 8;
+    const uint32_t i0 = ((xl & 0xFFu) << 2) | pl, i1 = (xl >> 6) & 0x3FFu, i2 = (xl >> 14) & 0x3FFu, i3 = xl >> 22;
+    const uint32_t i4 = __builtin_amdgcn_alignbit(xh, xl, 30) & 0x3FFu, i5 = (xh >> 6) & 0x3FFu, i6 = (xh >> 14) & 0x3FFu, i7 = xh >> 22;
+    uint32_t lo = lut.bits[i0];
+    unsigned n = lut.twice_kept[i0];
+    lo |= (uint32_t)lut.bits[i1] << n; n += lut.twice_kept[i1];
+    lo |= (uint32_t)lut.bits[i2] << n; n += lut.twice_kept[i2];
+    lo |= (uint32_t)lut.bits[i3] << n; n += lut.twice_kept[i3];
+    uint32_t hi = lut.bits[i4];
+    unsigned m = lut.twice_kept[i4];
+    hi |= (uint32_t)lut.bits[i5] << m; m += lut.twice_kept[i5];
+    hi |= (uint32_t)lut.bits[i6] << m; m += lut.twice_kept[i6];
+    hi |= (uint32_t)lut.bits[i7] << m; m += lut.twice_kept[i7];
     *nbits = n + m;
     return (uint64_t)lo | ((uint64_t)hi << n);
 }
@@ -470,9 +467,9 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
     __shared__ uint32_t lds_stream[SCAN_WAVES][STREAM_WORDS];
     __shared__ uint32_t lds_istream[HAS_N ? SCAN_WAVES : 1][HAS_N ? ISTREAM_WORDS : 1];
     __shared__ QualMap lds_qmap[(HAS_QUAL && HPC) ? SCAN_WAVES : 1];
-    __shared__ uint16_t lds_lut[(HPC && !HAS_N) ? HPC_LUT_SIZE : 1];
+    __shared__ uint8_t lds_lut_b[(HPC && !HAS_N) ? HPC_LUT_SIZE : 1], lds_lut_n[(HPC && !HAS_N) ? HPC_LUT_SIZE : 1];
     if (HPC && !HAS_N) {
-        for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += SCAN_BLOCK) lds_lut[i] = hpc_lut_entry(i);
+        for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += SCAN_BLOCK) { const uint16_t e = hpc_lut_entry(i); lds_lut_b[i] = (uint8_t)e; lds_lut_n[i] = (uint8_t)(e >> 8); }
         __syncthreads();
     }
     const unsigned lane = threadIdx.x & 63u;
@@ -559,7 +556,7 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
                     // the first base of the read starts a run whatever precedes it: pretend a different base does
                     if (wi == 0) pl = ((uint32_t)x & 3u) ^ 1u;
                     unsigned nbits;
-                    y = compress_pairs_lut(lds_lut, x, pl, &nbits);
+                    y = compress_pairs_lut(HpcLut{lds_lut_b, lds_lut_n}, x, pl, &nbits);
                     c = nbits >> 1;
                     d = 0;
                     if (HAS_QUAL || nvalid < 32) {
@@ -806,9 +803,9 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     __shared__ uint32_t lds_hist_c[(QUAL && HPC) ? FAST_WAVES : 1][(QUAL && HPC) ? HIST_TILES : 1];
     __shared__ uint32_t lds_ring[FAST_WAVES][RING_WORDS];
     __shared__ uint2 lds_stage[FAST_WAVES][STAGE_CAP];
-    __shared__ uint16_t lds_lut[HPC ? HPC_LUT_SIZE : 1];
+    __shared__ uint8_t lds_lut_b[HPC ? HPC_LUT_SIZE : 1], lds_lut_n[HPC ? HPC_LUT_SIZE : 1];
     if (HPC) {
-        for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += FAST_BLOCK) lds_lut[i] = hpc_lut_entry(i);
+        for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += FAST_BLOCK) { const uint16_t e = hpc_lut_entry(i); lds_lut_b[i] = (uint8_t)e; lds_lut_n[i] = (uint8_t)(e >> 8); }
     }
     for (unsigned i = threadIdx.x; i < FAST_WAVES * RING_WORDS; i += FAST_BLOCK) (&lds_ring[0][0])[i] = 0;
     __syncthreads();
@@ -1073,7 +1070,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 uint32_t pl = lane_below((uint32_t)(x >> 62), prev_last);
                 if (wi == 0) pl = ((uint32_t)x & 3u) ^ 1u;      // the first base of the read starts a run whatever precedes it
                 unsigned nbits;
-                y = compress_pairs_lut(lds_lut, x, pl, &nbits);
+                y = compress_pairs_lut(HpcLut{lds_lut_b, lds_lut_n}, x, pl, &nbits);
                 c = nbits >> 1;
                 if (nvalid < 32) {
                     const uint64_t vspread = ((1ull << (2 * nvalid)) - 1ull) & M5;
@@ -1420,7 +1417,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         return set_error(ctx, MDBG_EINVAL, "mdbg_scan: minimizer_size %u outside [2,16]", p->minimizer_size);
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = reads->n_reads;
-    const bool hpc = p->hpc != 0, has_q = reads->has_qual, has_n = reads->has_invalid;
+    const bool hpc = p->hpc != 0, has_q = reads->has_qual && !p->ignore_qualities, has_n = reads->has_invalid;
     mdbg_minimizers *m = new mdbg_minimizers();
     m->n_reads = n;
     m->from_scan = true;

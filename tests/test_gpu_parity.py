@@ -1056,3 +1056,18 @@ def test_scan_false_candidates_are_rerun(ctx, orc, hpc, with_q):
     assert widened == plain
     exp = b"".join(orc.read_selection(s, quals[i] if with_q else None, K=15, density=0.005, hpc=hpc)["record"] for i, s in enumerate(seqs[:200]))
     assert plain[:len(exp)] == exp
+
+
+def test_scan_ignoring_the_qualities_of_a_read_set(ctx):
+    """ignore_qualities (the census of minimizer values over reads that are resident with their qualities,
+    ReadSelection.hpp:565-625): the records are those of the same reads without qualities."""
+    rng = np.random.default_rng(77)
+    lens = [int(x) for x in rng.integers(50, 30000, 400)]
+    seqs = [bytes(synth.CODE2ASCII[rng.integers(0, 4, n)]) for n in lens]
+    quals = [bytes((rng.integers(2, 60, n) + 33).astype(np.uint8)) for n in lens]
+    with_q, without = ctx.reads_from_ascii(seqs, quals), ctx.reads_from_ascii(seqs, None)
+    for density in (0.005, 0.025):
+        a = formats.build_read_data_init(ctx.scan(with_q, K=15, density=density, hpc=False, apply_read_filters=False, ignore_qualities=True).to_host())
+        b = formats.build_read_data_init(ctx.scan(without, K=15, density=density, hpc=False, apply_read_filters=False).to_host())
+        c = formats.build_read_data_init(ctx.scan(with_q, K=15, density=density, hpc=False, apply_read_filters=False).to_host())
+        assert a == b and a != c
