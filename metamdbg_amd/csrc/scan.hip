@@ -904,6 +904,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
         bool lost = false;         // per lane: a quality span could not be resolved, or a recorded position turned out not to be
                                    // selected (APPROX): folded into `outgrown` at the end of the read
         uint32_t n_false = 0;      // APPROX: recorded positions the full hash rejected (the read's count is nout - n_false)
+        uint32_t n_staged_at_outgrowth = 0;     // APPROX: rows in the stage when the read outgrew it
         uint32_t done = 0;         // positions already evaluated (= ring position of the next block, a multiple of 2048)
         uint32_t nout = 0;         // minimizers of this read so far
         uint32_t flushed = 0;      // ... of which already written to the output slot
@@ -940,6 +941,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             if (total == 0u) return;
             if (bump) {
                 if (outgrown || nout + total > (unsigned)STAGE_CAP) {
+                    if (!outgrown) n_staged_at_outgrowth = nout;
                     if (APPROX) {          // the count the host places the read by must be exact: hash the candidates in full
                         uint32_t bad = 0;
                         while (bits) {
@@ -986,10 +988,6 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     const uint32_t d = fw < rev ? 0u : 1u;
                     if (QUAL) { bool known = true; stage_q[base + i] = min_quality(j, known); if (!known) lost = true; }
                     stage[base + i] = make_uint2(d ? rev : fw, (j << 1) | d);
-                    if (APPROX) {          // the full hash of every recorded position; a false one loses the read to the re-run
-                        const uint64_t fb = __ballot(!(kmer_hash32(d ? rev : fw) < threshold));
-                        if (fb) { n_false += (uint32_t)__popcll(fb); lost = true; }
-                    }
                 }
                 wave_lds_sync();
             } else {
@@ -1143,6 +1141,16 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             }
         }
 
+        if (APPROX) {
+            // the full hash of every staged position, once per read (a block stages about ten of them: confirming them there kept
+            // five lanes in six idle); a false one loses the read to the re-run.  The positions of a read that outgrew the stage
+            // after these were confirmed as they came (emit)
+            const uint32_t n_staged = outgrown ? n_staged_at_outgrowth : nout;
+            for (uint32_t i = lane; i < ((n_staged + 63u) & ~63u); i += 64) {
+                const uint64_t fb = __ballot(i < n_staged && !(kmer_hash32(stage[i].x) < threshold));
+                if (fb) { n_false += (uint32_t)__popcll(fb); lost = true; }
+            }
+        }
         if (((QUAL && HPC) || APPROX) && __ballot(lost) != 0ull) outgrown = true;      // a run start had left the history, or a false candidate:
                                                                                         // the general kernel redoes the read
         uint8_t flags = 0;
