@@ -119,6 +119,7 @@ struct mdbg_ctx {
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
     unsigned table_blocks_per_cu = 1024;                   // resident blocks per CU of the kernels that walk every k-min-mer instance (mdbg_set_option)
     unsigned scan_reads_per_wave = 2;                      // reads a scan wave processes before it retires (mdbg_set_option)
+    uint32_t scan_wave_priority = 0;        // s_setprio level of the block-structured scan's waves (mdbg_set_option)
     uint32_t scan_cand_slack = 0;           // tests: widens the candidate test of the block-structured scan (see span_step)
     // distinct keys per k-min-mer instance seen by the last call OF THE SAME KIND (table sizing): the first pass keeps every
     // key, refined / index only those above abundance 1 -- one shared hint made every first pass after an index pass rebuild its table

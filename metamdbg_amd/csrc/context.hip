@@ -63,6 +63,7 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     ctx->n_cu = prop.multiProcessorCount;
     // defaults of the per-context options from the environment (mdbg_set_option changes them later)
     if (const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU")) if (atoi(e) > 0) ctx->table_blocks_per_cu = (unsigned)atoi(e);
+    if (const char *e = getenv("MDBG_SCAN_WAVE_PRIORITY")) ctx->scan_wave_priority = (uint32_t)std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
     ctx->hbm_bytes = prop.totalGlobalMem;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -109,6 +110,7 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: null argument");
     const std::string n(name);
     if (n == "table_blocks_per_cu") { ctx->table_blocks_per_cu = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 1024u; return MDBG_OK; }
+    if (n == "scan_wave_priority") { ctx->scan_wave_priority = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }
     if (n == "scan_reads_per_wave") { ctx->scan_reads_per_wave = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 2u; return MDBG_OK; }
     return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: unknown option '%s'", name);

@@ -83,6 +83,7 @@ struct ScanArgs {
     uint32_t *over_list, *suspect_list;
     uint32_t *list_counters;      // [0] = reads in over_list, [1] = reads in suspect_list
     uint32_t cand_slack;          // scan_fast_kernel<.., APPROX>: extra width of the candidate test (0 but in tests)
+    uint32_t wave_priority;       // scan_fast_kernel: s_setprio level of its waves (0 = leave alone)
 };
 
 // squeeze the 2-bit fields of x whose flag bit (bit 2i of d) is set down to the low end
@@ -809,6 +810,11 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     }
     for (unsigned i = threadIdx.x; i < FAST_WAVES * RING_WORDS; i += FAST_BLOCK) (&lds_ring[0][0])[i] = 0;
     __syncthreads();
+    // the kernel is bound by instruction issue: next to the table kernels of other batches (bound by memory latency) its waves
+    // go first on their SIMD
+    if (a.wave_priority == 1u) __builtin_amdgcn_s_setprio(1);
+    else if (a.wave_priority == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (a.wave_priority >= 3u) __builtin_amdgcn_s_setprio(3);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *S = lds_ring[wv];
@@ -1570,6 +1576,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         a.cursor = d_ctl.p; a.n_regions = n_regions; a.out_capacity = region_cap; a.out_begin = m->d_begin.p;
         a.over_list = d_over.p; a.suspect_list = d_susp.p; a.list_counters = (uint32_t *)(d_ctl.p + CTL_OVER);
         a.cand_slack = ctx->scan_cand_slack;
+        a.wave_priority = ctx->scan_wave_priority;
         unsigned long long h_ctl[CTL_WORDS];
         {
             std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));      // one scan kernel at a time per device (see below)
