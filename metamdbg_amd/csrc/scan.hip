@@ -749,7 +749,8 @@ __global__ __launch_bounds__(SCAN_BLOCK, (HAS_QUAL || HAS_N) ? 1 : SCAN_MIN_WAVE
 // ================================================================================================================
 constexpr int FAST_BLOCK = 256;                       // threads per workgroup (4 independent waves)
 constexpr int FAST_WAVES = FAST_BLOCK / 64;
-constexpr unsigned RING_BASES = 8192;                 // per wave: live bases never exceed 2 * 2048 + 16 + 1
+constexpr unsigned RING_BASES = 16384;                // per wave: DEFER_BLOCKS blocks awaiting materialisation + 2 * 2048 + 16 + 1 live bases
+constexpr unsigned DEFER_BLOCKS = 3;                  // blocks whose selected positions may wait in the list before they are materialised
 constexpr unsigned RING_WORDS = RING_BASES / 16;      // u32
 constexpr unsigned RING_WMASK = RING_WORDS - 1;
 constexpr unsigned SPAN = 32;                         // positions per lane in a full block
@@ -914,12 +915,41 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
         uint32_t done = 0;         // positions already evaluated (= ring position of the next block, a multiple of 2048)
         uint32_t nout = 0;         // minimizers of this read so far
         uint32_t flushed = 0;      // ... of which already written to the output slot
+        uint32_t n_mat = 0;        // ... of which materialised (rows [n_mat, nout) of the stage hold a position only)
+        uint32_t zero_from = 0;    // ring position from which bases are still kept (<= done): the oldest block with listed positions
         uint32_t prev_last = 0;
         uint64_t cx_acc = 0;       // per lane: sum of weight x Q over its words
         uint64_t prev_word = 0;
         const uint32_t cx_nW = L >= 66u ? (L - 66u) / 32u + 1u : 0u;      // number of complexity windows (ReadSelection.hpp:1171-1228)
 
-        // ---- emission: materialise the positions recorded in `bits` (span length P per lane, oldest position in bit P-1) ----
+        // ---- materialisation of the listed positions, one per lane: window, canonical form, direction and, with qualities, the
+        // look-ups behind min_quality.  Deferred over up to DEFER_BLOCKS blocks (a block lists about ten positions: materialised
+        // there, five lanes in six idled through the longest dependent chain of the kernel) ----
+        auto materialise = [&]() {
+            const uint32_t pend = nout - n_mat;
+            if (pend == 0u) return;
+            if (outgrown) { n_mat = nout; return; }       // counted only: the read is re-run by the general kernel
+            const uint32_t base = n_mat - flushed;
+            for (uint32_t i = lane; i < pend; i += 64) {
+                const uint32_t j = stage[base + i].y;
+                const uint32_t e = ring_window(S, j) & kmask;
+                const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
+                // direction 1 iff the reverse complement is the canonical form, ties included (Kmer.hpp:427)
+                const uint32_t d = fw < rev ? 0u : 1u;
+                if (QUAL) { bool known = true; stage_q[base + i] = min_quality(j, known); if (!known) lost = true; }
+                stage[base + i] = make_uint2(d ? rev : fw, (j << 1) | d);
+            }
+            n_mat = nout;
+            wave_lds_sync();
+        };
+        // bases of [zero_from, upto) are not needed any more: back to zero for the next lap of the ring
+        auto release_ring = [&](uint32_t upto) {
+            const unsigned zb = zero_from >> 4, nz = (upto - zero_from) >> 4;
+            for (unsigned i = lane; i < nz; i += 64) S[(zb + i) & RING_WMASK] = 0;
+            zero_from = upto;
+        };
+
+        // ---- emission: list the positions recorded in `bits` (span length P per lane, oldest position in bit P-1) ----
         auto emit = [&](uint32_t bits, unsigned P, uint32_t npos_limit) {
             // positions at or beyond npos_limit (tail lanes past the end) and the trimmed first position of the read
             if (P < 32u) bits &= (1u << P) - 1u;
@@ -947,7 +977,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             if (total == 0u) return;
             if (bump) {
                 if (outgrown || nout + total > (unsigned)STAGE_CAP) {
-                    if (!outgrown) n_staged_at_outgrowth = nout;
+                    if (!outgrown) { materialise(); n_staged_at_outgrowth = nout; }
                     if (APPROX) {          // the count the host places the read by must be exact: hash the candidates in full
                         uint32_t bad = 0;
                         while (bits) {
@@ -962,6 +992,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     outgrown = true; nout += total; return;
                 }
             } else if (nout - flushed + total > (unsigned)STAGE_CAP) {       // make room: the staged rows leave for the output slot
+                materialise();
                 const uint32_t ns = nout - flushed;
                 for (uint32_t i = lane; i < ns; i += 64) {
                     const uint32_t idx = flushed + i;
@@ -975,25 +1006,12 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 wave_lds_sync();
             }
             if (total <= (unsigned)STAGE_CAP) {
-                // the selected positions are first listed in the stage, then taken one per lane: the long part (window, canonical
-                // form and, with qualities, the look-ups behind min_quality) runs once per 64 minimizers instead of once per
-                // round of the lane that holds the most of them
-                const uint32_t base = nout - flushed;
-                uint32_t at = base + incl - cnt;
+                // the selected positions are listed in the stage; materialise() takes them one per lane later
+                uint32_t at = nout - flushed + incl - cnt;
                 while (bits) {
                     const unsigned bit = 31u - (unsigned)__clz((int)bits);
                     bits &= ~(1u << bit);
                     stage[at++].y = done + lane * P + (P - 1u - bit);          // position in the compressed read
-                }
-                wave_lds_sync();
-                for (uint32_t i = lane; i < total; i += 64) {
-                    const uint32_t j = stage[base + i].y;
-                    const uint32_t e = ring_window(S, j) & kmask;
-                    const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
-                    // direction 1 iff the reverse complement is the canonical form, ties included (Kmer.hpp:427)
-                    const uint32_t d = fw < rev ? 0u : 1u;
-                    if (QUAL) { bool known = true; stage_q[base + i] = min_quality(j, known); if (!known) lost = true; }
-                    stage[base + i] = make_uint2(d ? rev : fw, (j << 1) | d);
                 }
                 wave_lds_sync();
             } else {
@@ -1014,6 +1032,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     at++;
                 }
                 flushed = nout + total;
+                n_mat = nout + total;
             }
             nout += total;
         };
@@ -1034,13 +1053,14 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             }
             emit(st.bits, (unsigned)SP, 64u * (unsigned)SP);
             wave_lds_sync();
-            // the block's bases are not needed any more: back to zero for the next lap of the ring
-            {
-                const unsigned zb = (done >> 4);
-                S[(zb + lane) & RING_WMASK] = 0;
-                if (SP > 16) S[(zb + 64u + lane) & RING_WMASK] = 0;
-            }
             done += 64u * (unsigned)SP;
+            // materialise when most of a wave's lanes have a position to take, or when the ring cannot keep the blocks any longer
+            // (with qualities under HPC the run starts of a listed position must still be in the tile history: one block less)
+            constexpr unsigned defer = (QUAL && HPC) ? DEFER_BLOCKS - 1u : DEFER_BLOCKS;
+            if (nout - n_mat >= 48u || nout == n_mat || done - zero_from > defer * BLOCK_POS) {
+                materialise();
+                release_ring(done);
+            }
             wave_lds_sync();
         };
 
@@ -1140,11 +1160,9 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 emit(st.bits, P, npos);
             }
             wave_lds_sync();
-            // leave the ring zero for the next read: everything from `done` to `fill`
-            {
-                const unsigned zb = done >> 4, nz = ((fill + 15u) >> 4) - zb + 1u;
-                for (unsigned i = lane; i < nz; i += 64) S[(zb + i) & RING_WMASK] = 0;
-            }
+            materialise();
+            // leave the ring zero for the next read: everything from `zero_from` to `fill`
+            release_ring(((fill + 15u) & ~15u) + 16u);
         }
 
         if (APPROX) {
