@@ -653,11 +653,13 @@ def main() -> None:
                                               "never overlap each other")
                                              if n_slots > 1 else None,
                          "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies at 4.7 cycles per wave64 "
-                                 "each) puts the ceiling at the VALU, far below HBM; the PMC counters show the VALU saturated "
-                                 "(profiles/r02h_pmc_scan_fast_kernel.txt, DESIGN.md 4.1)",
+                                 "each; the kernel computes the upper half without the carry at every position, 15 multiplies, and the full "
+                                 "hash of the selected ones) puts the ceiling at the VALU, far below HBM; the PMC counters show the VALU "
+                                 "saturated (profiles/r02w_pmc_scan.txt, DESIGN.md 4.1)",
                          # the hash alone, measured in isolation at full occupancy (tools/ubench/hash_rates.hip,
-                         # profiles/r01_hash_rates_gfx950.txt): 186 cycles per 64 hashes per SIMD
-                         "valu_floor": {"hash_cycles_per_64": 186, "hpc_positions_per_launch": hpc_positions,
+                         # profiles/r02w_hash_rates.txt): 186 cycles per 64 full hashes per SIMD, 162 per 64 candidate tests
+                         "valu_floor": {"hash_cycles_per_64": 186, "candidate_test_cycles_per_64": 162, "hpc_positions_per_launch": hpc_positions,
+                                        "floor_ms_candidate_test": hash_floor_ms * 162.0 / 186.0,
                                         "floor_ms": hash_floor_ms, "frac": hash_floor_ms / (scan_avg_s * 1e3) if scan_avg_s > 0 else None}},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()},
             "cpu_baseline": base,

@@ -132,12 +132,17 @@ __device__ __forceinline__ const uint32_t *rep_window(const SeqView &a, const Se
 // Visit every instance with 16 lanes per sequence (4 sequences per wave): sequences hold a few dozen
 // windows, the minimizers of neighbouring windows are loaded coalesced, and no per-instance binary search
 // over the offsets is needed.  f(read, global instance id, pointer to the window's first minimizer).
+// `give_up` (a table's overflow flag, may be null): once set the pass is void -- the host grows the table and repeats it --
+// so the remaining sequences are skipped.  (Without this, a table sized for another kind of data -- HiFi's one key per ten
+// instances, then an ONT batch with nine per ten -- was filled to the brim at 96 probes per insert: 3.9 s for a pass that
+// was going to be thrown away.)
 template <typename F>
-__device__ __forceinline__ void for_each_instance(const SeqView &s, F f) {
+__device__ __forceinline__ void for_each_instance(const SeqView &s, F f, const uint32_t *give_up = nullptr) {
     const unsigned sub = threadIdx.x & 15u;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
     for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (give_up && __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         const uint64_t base = s.inst_off[r];
         const uint32_t n = (uint32_t)(s.inst_off[r + 1] - base);
         const uint32_t *m0 = s.mins + s.off[r];
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void count_insert_kernel(SeqView s, uint32_t k
         if (inst_slot && slot == 0x7FFFFFFEu) inst_slot[g] = slot;                                  // ablation: no slot store
 #endif
 #endif
-    });
+    }, t.overflow);
 }
 
 // ---- rescue (graph/CreateMdbg.hpp:4514-4640) --------------------------------------------------------
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void distinct_insert_kernel(SeqView s, uint32_
         uint64_t hi, lo;
         window_hash_uniform(m, k, hi, lo);
         table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + (uint64_t)(m - s.mins)));
-    });
+    }, t.overflow);
 }
 
 // refined abundance of every distinct key (graph/CreateMdbg.hpp:3933-3970): min over the two
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, co
         uint64_t hi, lo;
         window_hash_uniform(m, k, hi, lo);
         table_upsert_set(t, lo, hi, a, 0u);
-    });
+    }, t.overflow);
 }
 
 // ---- prev tables ---------------------------------------------------------------------------------------

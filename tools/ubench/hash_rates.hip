@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
     for (int i = 0; i < iters; i++) {
 #pragma unroll
         for (int c = 0; c < CHAINS; c++) {
+            if (V == 3) {         // the candidate test of scan_fast_kernel<.., APPROX>: upper half without the carry (murmur.hpp)
+                const uint32_t s1 = kmer_hash32_hi_nocarry(v[c]) + 1u;
+                acc += (s1 < (uint32_t)(92233718306963448ull >> 32) + 2u) ? 1u : 0u;
+                v[c] = v[c] * 1664525u + 1013904223u + (s1 >> 28);
+                continue;
+            }
             uint64_t h = V == 0 ? kmer_hash32(v[c]) : (V == 1 ? hash_v1(v[c]) : hash_v2(v[c]));
             acc += (h < 92233718306963448ull) ? 1u : 0u;
             v[c] = v[c] * 1664525u + 1013904223u + (uint32_t)(h >> 60);   // next input (cheap, dependent)
@@ -92,6 +98,7 @@ int main() {
         run<0, 1>("compiler", d, w); run<0, 2>("compiler", d, w);
         run<1, 1>("mad_u64", d, w);  run<1, 2>("mad_u64", d, w);
         run<2, 1>("mul_lo_hi", d, w); run<2, 2>("mul_lo_hi", d, w);
+        run<3, 1>("hi_nocarry", d, w); run<3, 2>("hi_nocarry", d, w);
     }
     return 0;
 }
