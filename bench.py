@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--in-flight", type=int, default=3, help="batches processed concurrently per GPU (own context, stream and host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads in the CPU-baseline / parity sample (0 = skip)")
-    ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,ont ('all', 'none')")
+    ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,pcie,ont ('all', 'none')")
     ap.add_argument("--ont-reads", type=int, default=5_000_000, help="reads (20 kb, with qualities) of the ont leg")
     a = ap.parse_args()
     if a.reads <= 0:
@@ -253,6 +253,101 @@ def multik_leg(ctx, reads, n_bases: int, last_k: int = 11) -> dict:
     return r
 
 
+def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int = 8) -> dict:
+    """The step when the reads arrive over PCIe (never `value`): the first n_sub reads of the batch are brought to page-locked
+    host memory (2-bit packed as the host feed delivers them, and as ASCII), then uploaded through the boundary's own entry
+    points (mdbg_reads_from_packed / _from_ascii) and put through scan + purge + table, `repeats` times: one context doing
+    upload and step in turn, and two contexts on two host threads so that one's upload runs under the other's kernels."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    from metamdbg_amd import capi
+    n_sub = min(n_sub, reads.info()["n_reads"])
+    bases, offs = reads.export_ascii(0, n_sub)
+    lens = np.diff(offs).astype(np.uint32)
+    L = int(lens[0])
+    assert (lens == L).all()
+    wpr = ((L + 31) // 32 + 1) & ~1                                    # words per read, even: reads start on 16-byte boundaries
+    codes = (bases.reshape(n_sub, L) >> 1) & 3
+    bits = np.zeros((n_sub, wpr * 32, 2), dtype=np.uint8)
+    bits[:, :L, 0] = codes & 1
+    bits[:, :L, 1] = codes >> 1
+    packed = np.packbits(bits.reshape(n_sub, -1), axis=1, bitorder="little").view("<u8").reshape(-1)
+    del bits, codes
+    word_off = (np.arange(n_sub + 1, dtype=np.uint64) * np.uint64(wpr))
+
+    def pinned_copy(arr: np.ndarray):
+        p = C.c_void_p()
+        ctx.check(capi.lib().mdbg_host_alloc(ctx.h, arr.nbytes, C.byref(p)))
+        view = np.frombuffer((C.c_uint8 * arr.nbytes).from_address(p.value), dtype=arr.dtype)
+        view[:] = arr.reshape(-1)
+        return p, view
+    p_words, h_words = pinned_copy(packed)
+    p_ascii, h_ascii = pinned_copy(bases)
+    n_bases = int(lens.sum())
+
+    def step(c, ascii_input: bool):
+        h = C.c_void_p()
+        if ascii_input:
+            c.check(capi.lib().mdbg_reads_from_ascii(c.h, p_ascii, None, capi._ptr(offs), n_sub, C.byref(h)))
+        else:
+            c.check(capi.lib().mdbg_reads_from_packed(c.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
+        r = capi.Reads(c, h)
+        m = c.scan(r, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = c.purge_palindromes(m, 4, 100)
+        t = c.kminmer_count_first(corr, KMINMER, 0)
+        c.synchronize()
+        out = (int(m.info()["n_minimizers"]), int(t.info()["n_records"]))
+        for o in (t, corr, m, r):
+            o.free()
+        return out
+
+    res = {"workload": f"{n_sub} reads ({n_bases / 1e9:.1f} Gbp) in page-locked host memory, uploaded and put through scan + purge + k=4 table "
+                       f"{repeats} times", "packed_bytes": int(packed.nbytes), "ascii_bytes": int(bases.nbytes)}
+    # what the same reads give as they were generated in HBM
+    sub = ctx.reads_synthetic(spec, first_read=0, n_reads=n_sub)
+    m = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=True)
+    corr = ctx.purge_palindromes(m, 4, 100)
+    t = ctx.kminmer_count_first(corr, KMINMER, 0)
+    want = (int(m.info()["n_minimizers"]), int(t.info()["n_records"]))
+    for o in (t, corr, m, sub):
+        o.free()
+    for name, ascii_input in (("packed", False), ("ascii", True)):
+        got = step(ctx, ascii_input)                                   # warm-up, and the results must be the resident form's
+        if got != want:
+            raise SystemExit(f"pcie leg ({name}): {got} != {want}")
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            step(ctx, ascii_input)
+        dt = time.perf_counter() - t0
+        res[f"{name}_one_context_gbps"] = n_bases * repeats / 1e9 / dt
+    other = capi.Context(device)
+    step(other, False)
+    def worker(c, n):
+        for _ in range(n):
+            step(c, False)
+    threads = [threading.Thread(target=worker, args=(c, repeats // 2)) for c in (ctx, other)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    res["packed_two_contexts_gbps"] = n_bases * (repeats // 2) * 2 / 1e9 / dt
+    other.close()
+    # the upload alone
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        ctx.check(capi.lib().mdbg_reads_from_packed(ctx.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
+        capi.lib().mdbg_reads_free(h)
+    res["upload_packed_GBps"] = packed.nbytes * 4 / 1e9 / (time.perf_counter() - t0)
+    del h_words, h_ascii
+    capi.lib().mdbg_host_free(ctx.h, p_words)
+    capi.lib().mdbg_host_free(ctx.h, p_ascii)
+    return res
+
+
 def ont_leg(ctx, n_reads: int, sample: int) -> dict:
     """BASELINE.json configs[3] preset: 20 kb reads with qualities (1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred
     10..39), no HPC, l = 15, density 0.005, repetitive-minimizer filter from the census of the first 1,000,000 reads at
@@ -415,12 +510,33 @@ def main() -> None:
     comms = None
     if (world > 1 or force_exchange) and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("MDBG_BENCH_EXCHANGE", "library") == "library":
         comms = []
+        comm_error = None
         for c, _ in slots:
             t = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
-                t.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(t, 0)
-            comms.append(c.comm_create(bytes(t.cpu().numpy().tobytes()), rank, world))
+                try:
+                    t.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+                except Exception as ex:              # RCCL not loadable: every rank will see the zero id and fall back together
+                    comm_error = str(ex)
+            if dist is not None:
+                dist.broadcast(t, 0)
+            raw = bytes(t.cpu().numpy().tobytes())
+            if comm_error is None and any(raw):
+                try:
+                    comms.append(c.comm_create(raw, rank, world))
+                except Exception as ex:
+                    comm_error = str(ex)
+            elif comm_error is None:
+                comm_error = "no communicator id from rank 0"
+        # all ranks or none: a rank without its communicators sends everybody to torch.distributed's all-to-all
+        ok = torch.tensor([0 if comm_error else 1], device="cuda")
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            print(f"[bench] library exchange unavailable ({comm_error or 'another rank failed'}): using torch.distributed", file=sys.stderr)
+            for cm in comms:
+                cm.destroy()
+            comms = None
     ctx, reads = slots[0]
     info = ctx.device_info()
     n_bases = reads.info()["n_bases"]
@@ -611,7 +727,7 @@ def main() -> None:
 
     if rank == 0:
         legs_on = set() if (world > 1 or args.legs == "none") else \
-            ({"end_to_end", "multik", "ont"} if args.legs == "all" else set(args.legs.split(",")))
+            ({"end_to_end", "multik", "pcie", "ont"} if args.legs == "all" else set(args.legs.split(",")))
         side = sample_legs(ctx, reads, spec, rank * args.reads, min(args.cpu_sample, args.reads), "end_to_end" in legs_on) if world == 1 else {}
         base = side.get("cpu_baseline")
         legs = {}
@@ -620,6 +736,9 @@ def main() -> None:
         if "multik" in legs_on:
             ctx.set_option("table_blocks_per_cu", 0)       # this context runs alone now
             legs["multik"] = multik_leg(ctx, reads, n_bases)
+        if "pcie" in legs_on:
+            ctx.set_option("table_blocks_per_cu", 0)
+            legs["pcie"] = pcie_leg(ctx, reads, spec, local_rank)
         if "ont" in legs_on:
             # the HiFi batch and the other contexts' pools make room first
             for c, _ in slots[1:]:
