@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void emit_rescued_kernel(SeqView s, uint32_t k
                 const uint64_t dst = row + (uint32_t)__popc(bal & ((1u << sub) - 1u));
                 const uint32_t *m = m0 + i;
                 uint64_t hi, lo;
-                bool reversed = window_hash(m, k, hi, lo);
+                bool reversed = window_hash_uniform(m, k, hi, lo);
                 o.lo[dst] = lo; o.hi[dst] = hi; o.ab[dst] = 1u;
                 for (uint32_t j = 0; j < k; j++) o.vec[dst * k + j] = reversed ? m[k - 1 - j] : m[j];
             }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t
     uint32_t min_ab = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < 2; i++) {
         uint64_t hi, lo;
-        window_hash(m + i, k - 1, hi, lo);
+        window_hash_uniform(m + i, k - 1, hi, lo);
         uint32_t v;
         if (table_lookup(prev, lo, hi, v)) {
             if (v == 0u) { min_ab = 1u; break; }

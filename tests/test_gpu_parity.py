@@ -1071,3 +1071,65 @@ def test_scan_ignoring_the_qualities_of_a_read_set(ctx):
         b = formats.build_read_data_init(ctx.scan(without, K=15, density=density, hpc=False, apply_read_filters=False).to_host())
         c = formats.build_read_data_init(ctx.scan(with_q, K=15, density=density, hpc=False, apply_read_filters=False).to_host())
         assert a == b and a != c
+
+
+def test_scan_fastq_hpc_long_homopolymers(ctx, orc):
+    """Qualities under HPC: the block kernel looks the original coordinates of a selected position up in the offsets of the
+    last few tiles.  Homopolymer stretches of tens of kb squeeze many tiles into a few compressed positions, so listed
+    positions lose their tile before they are materialised: those reads go to the general kernel.  Records as the oracle's."""
+    rng = np.random.default_rng(123)
+    seqs = []
+    for i in range(60):
+        parts = []
+        for _ in range(int(rng.integers(1, 5))):
+            parts.append(synth.CODE2ASCII[rng.integers(0, 4, int(rng.integers(500, 6000)))])
+            if i % 3 != 2:       # every third read is ordinary
+                parts.append(np.full(int(rng.integers(3000, 60000)), ord("ACGT"[int(rng.integers(0, 4))]), dtype=np.uint8))
+        parts.append(synth.CODE2ASCII[rng.integers(0, 4, int(rng.integers(500, 6000)))])
+        seqs.append(bytes(np.concatenate(parts)))
+    quals = [bytes((rng.integers(2, 60, len(s)) + 33).astype(np.uint8)) for s in seqs]
+    reads = ctx.reads_from_ascii(seqs, quals)
+    # without the read filters (these reads are low-complexity by construction): the correction scan's form of the call,
+    # ReadCorrection.hpp:2269-2372, with homopolymer compression
+    h = ctx.scan(reads, K=15, density=0.005, hpc=True, apply_read_filters=False, quality_window=1).to_host()
+    n_total = 0
+    for i, s_ in enumerate(seqs):
+        exp = orc.correction_scan(s_, quals[i], K=15, density=0.005, hpc=True)
+        a, b = int(h["offsets"][i]), int(h["offsets"][i + 1])
+        assert h["minimizers"][a:b].tolist() == exp["minimizers"].tolist(), i
+        assert h["pos"][a:b].tolist() == exp["pos"].tolist(), i
+        assert h["dir"][a:b].tolist() == exp["dir"].tolist(), i
+        assert h["qual"][a:b].tolist() == exp["qual"].tolist(), i
+        n_total += b - a
+    assert n_total > 500
+
+
+def test_full_size_fastq_hpc(ctx, orc):
+    """The bench batch's size with qualities under HPC (1 M x 10 kb reads, FASTQ form): selection must not depend on the
+    qualities (values, positions, directions equal the FASTA scan of the same bases), the per-minimizer minimum qualities and the
+    mean read quality equal the oracle's on a sample, both quality windows, and no read may have been lost on the way (every
+    read of such a batch stays in the block kernel: one launch)."""
+    import dataclasses
+    n, L = 1_000_000, 10_000
+    spec = synth.hifi_spec(n, seed=42, read_len=L, coverage=50.0)
+    plain = ctx.reads_synthetic(spec)
+    hp = ctx.scan(plain, K=15, density=0.005, hpc=True).to_host()
+    plain.free()
+    reads = ctx.reads_synthetic(dataclasses.replace(spec, with_quality=True))
+    for window in (0, 1):
+        ctx.timing(True); ctx.timing_reset()
+        hq = ctx.scan(reads, K=15, density=0.005, hpc=True, quality_window=window).to_host()
+        launches = ctx.timing_get("scan")[1]
+        ctx.timing(False)
+        assert launches == 1
+        for f in ("offsets", "minimizers", "pos", "dir", "read_length"):
+            assert np.array_equal(hq[f], hp[f]), f
+        for r in list(range(0, 2000, 41)) + list(range(n - 2000, n, 41)):
+            b, q = reads.get(r, with_quality=True)
+            o = orc.correction_scan(b, q, K=15, density=0.005, hpc=True) if window else orc.read_selection(b, q, K=15, density=0.005, hpc=True)
+            a, e = int(hq["offsets"][r]), int(hq["offsets"][r + 1])
+            assert hq["minimizers"][a:e].tolist() == o["minimizers"].tolist()
+            assert hq["qual"][a:e].tolist() == o["qual"].tolist(), (window, r)
+            if not window:
+                assert _nan_eq([hq["mean_quality"][r]], [o["mean_quality"]])
+    assert (hp["qual"] == 1).all()          # no qualities: ReadSelection.hpp:1047-1051
