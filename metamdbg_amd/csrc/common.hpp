@@ -1,6 +1,9 @@
 // common.hpp -- context, error plumbing, device buffers and wave64 helpers shared by the
 // HIP translation units of libmdbg_hip.so.  gfx950 (MI355X) only: 64-lane wavefronts.
 #pragma once
+#include <ctime>
+#include <cstdio>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -194,6 +197,12 @@ struct DevBuf {
 };
 
 // Scoped kernel timer: records HIP events on ctx->stream around a launch when timing is on.
+// MDBG_DEBUG=1: wall-clock stamped progress lines on stderr from the long calls (which stage a call that does not come
+// back is in)
+inline bool debug_on() { static const bool on = getenv("MDBG_DEBUG") != nullptr; return on; }
+#define MDBG_DBG(ctx, ...) do { if (mdbg::debug_on()) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); \
+    fprintf(stderr, "[mdbg %p %ld.%03ld] ", (void *)(ctx), (long)ts_.tv_sec, ts_.tv_nsec / 1000000); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 struct LaunchTimer {
     mdbg_ctx *ctx;
     TimedLaunch t{};

@@ -141,8 +141,10 @@ __device__ __forceinline__ void for_each_instance(const SeqView &s, F f, const u
     const unsigned sub = threadIdx.x & 15u;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t trip = 0;
     for (uint64_t r = group; r < s.n_reads; r += ngroups) {
-        if (give_up && __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        // (looked at every 32nd sequence: thousands of groups reading one address at every step is a hot spot of its own)
+        if (give_up && (trip++ & 31u) == 0u && __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         const uint64_t base = s.inst_off[r];
         const uint32_t n = (uint32_t)(s.inst_off[r + 1] - base);
         const uint32_t *m0 = s.mins + s.off[r];
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void count_insert_kernel(SeqView s, uint32_t k
         if (inst_slot && slot == 0x7FFFFFFEu) inst_slot[g] = slot;                                  // ablation: no slot store
 #endif
 #endif
-    }, t.overflow);
+    }, t.poll_overflow ? t.overflow : nullptr);
 }
 
 // ---- rescue (graph/CreateMdbg.hpp:4514-4640) --------------------------------------------------------
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void distinct_insert_kernel(SeqView s, uint32_
         uint64_t hi, lo;
         window_hash_uniform(m, k, hi, lo);
         table_upsert_count(t, lo, hi, 0u, (uint32_t)(rep_base + (uint64_t)(m - s.mins)));
-    }, t.overflow);
+    }, t.poll_overflow ? t.overflow : nullptr);
 }
 
 // refined abundance of every distinct key (graph/CreateMdbg.hpp:3933-3970): min over the two
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, co
         uint64_t hi, lo;
         window_hash_uniform(m, k, hi, lo);
         table_upsert_set(t, lo, hi, a, 0u);
-    }, t.overflow);
+    }, t.poll_overflow ? t.overflow : nullptr);
 }
 
 // ---- prev tables ---------------------------------------------------------------------------------------
@@ -1209,6 +1211,7 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     sh->k = k; sh->n_ranks = n_ranks; sh->reads = reads;
     MDBG_TRY(build_inst_index(ctx, reads, k, sh->ix));
     const uint64_t I = sh->ix.total;
+    MDBG_DBG(ctx, "shard_begin: %llu instances", (unsigned long long)I);
     SeqView sv = make_view(reads, sh->ix);
     MDBG_TRY(sh->inst_slot.alloc(ctx, I));
     MDBG_TRY(build_table_adaptive(ctx, sh->local, (uint64_t)((double)I * ctx->key_ratio_hint[3]), I, [&](TableView v) {
@@ -1246,10 +1249,16 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
                            sh->rows.p, sh->row_slot.p);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MDBG_DBG(ctx, "shard_begin: %llu rows", (unsigned long long)total);
     *d_rows = sh->rows.p;
     *out = sh.release();
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
+
+__global__ void rows_zero_word_kernel(const uint64_t *rows, uint64_t n, unsigned long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (rows[i * SHARD_ROW_WORDS] == 0ull || rows[i * SHARD_ROW_WORDS + 1] == 0ull)) atomicAdd(out, 1ull);
+}
 
 extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) try {
     if (!ctx || !sh || !d_reply || (n_recv && !d_recv)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_reduce: bad argument");
@@ -1258,6 +1267,16 @@ extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     // every key this rank owns arrives once from each rank that saw it: about n_recv / n_ranks distinct keys.  Sized for
     // that (+50 %), the table is n_ranks times smaller than one sized for the rows; it grows and refills if that was short.
     const uint64_t expected = n_recv / sh->n_ranks + n_recv / (2 * sh->n_ranks) + 1024;
+    MDBG_DBG(ctx, "shard_reduce: %llu rows", (unsigned long long)n_recv);
+    if (debug_on() && n_recv) {
+        DevBuf<unsigned long long> z;
+        MDBG_TRY(z.alloc(ctx, 1));
+        (void)hipMemsetAsync(z.p, 0, 8, ctx->stream);
+        hipLaunchKernelGGL(rows_zero_word_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, z.p);
+        unsigned long long hz = 0;
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &hz, z.p, 8, hipMemcpyDeviceToHost));
+        MDBG_DBG(ctx, "shard_reduce: %llu rows with a zero key word", hz);
+    }
     MDBG_TRY(build_table_adaptive(ctx, sh->owner, expected < n_recv ? expected : n_recv, n_recv, [&](TableView v) {
         if (n_recv) {
             LaunchTimer timer(ctx, "shard_reduce");

@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "objects.hpp"
 
+#include <algorithm>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -131,6 +132,7 @@ extern "C" int mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *s
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const int n = comm->n_ranks, me = comm->rank;
     const uint32_t rw = mdbg_row_words(4);     // the same for every k: vectors never travel
+    MDBG_DBG(ctx, "shard_exchange: enter, %d ranks", n);
 
     // ---- who sends how many rows to whom: every rank's row of the count matrix (n u64 each) to every rank ----
     DevBuf<uint64_t> d_cnt, d_all;
@@ -147,35 +149,61 @@ extern "C" int mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *s
         roff[r + 1] = roff[r] + got[r];
     }
     const uint64_t n_sent = soff[n], n_recv = roff[n];
+    MDBG_DBG(ctx, "shard_exchange: counts known, %llu rows out, %llu in", (unsigned long long)n_sent, (unsigned long long)n_recv);
     if (n_sent && !d_rows) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange: null rows");
 
     // ---- rows to their owners ----
     DevBuf<uint64_t> d_recv;
     MDBG_TRY(d_recv.alloc(ctx, n_recv * rw));
     MDBG_TRY(comm->replies.alloc(ctx, n_sent));
+    // A rank's own share never goes through RCCL: it is a device-to-device copy on the same stream.  (RCCL 2.26's send/receive
+    // to self returned with 531 MiB of a 1.1 GB message in place, the rest still zero when the next kernel on the stream read it;
+    // one rank on the per-rank workload of an 8-GPU job, profiles/r02z_*.)  Messages to peers go in pieces of at most 256 MiB,
+    // the same cut on both sides.
+    constexpr uint64_t PIECE = 1ull << 25;          // u64 elements
+    auto move = [&](const uint64_t *src, uint64_t *dst, uint64_t n_send, uint64_t n_get, int r) -> int {
+        for (uint64_t at = 0; at < n_send; at += PIECE)
+            MDBG_NCCL_CHECK(ctx, api, api->Send(src + at, std::min(PIECE, n_send - at), ncclUint64, r, comm->comm, ctx->stream));
+        for (uint64_t at = 0; at < n_get; at += PIECE)
+            MDBG_NCCL_CHECK(ctx, api, api->Recv(dst + at, std::min(PIECE, n_get - at), ncclUint64, r, comm->comm, ctx->stream));
+        return MDBG_OK;
+    };
     {
         LaunchTimer timer(ctx, "shard_exchange");
-        MDBG_NCCL_CHECK(ctx, api, api->GroupStart());
-        for (int r = 0; r < n; r++) {
-            if (counts[r]) MDBG_NCCL_CHECK(ctx, api, api->Send(d_rows + soff[r] * rw, counts[r] * rw, ncclUint64, r, comm->comm, ctx->stream));
-            if (got[r]) MDBG_NCCL_CHECK(ctx, api, api->Recv(d_recv.p + roff[r] * rw, got[r] * rw, ncclUint64, r, comm->comm, ctx->stream));
+        if (counts[me]) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(d_recv.p + roff[me] * rw, d_rows + soff[me] * rw, counts[me] * rw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (n > 1) {
+            MDBG_NCCL_CHECK(ctx, api, api->GroupStart());
+            for (int r = 0; r < n; r++)
+                if (r != me) MDBG_TRY(move(d_rows + soff[r] * rw, d_recv.p + roff[r] * rw, counts[r] * rw, got[r] * rw, r));
+            MDBG_NCCL_CHECK(ctx, api, api->GroupEnd());
         }
-        MDBG_NCCL_CHECK(ctx, api, api->GroupEnd());
     }
     // ---- the owner sums and answers ----
+    MDBG_DBG(ctx, "shard_exchange: rows queued");
+    if (debug_on()) {
+        hipError_t de = hipStreamSynchronize(ctx->stream);
+        uint64_t a[5] = {0, 0, 0, 0, 0}, b[5] = {0, 0, 0, 0, 0};
+        if (n_sent) (void)hipMemcpy(a, d_rows, sizeof a, hipMemcpyDeviceToHost);
+        if (n_recv) (void)hipMemcpy(b, d_recv.p, sizeof b, hipMemcpyDeviceToHost);
+        MDBG_DBG(ctx, "shard_exchange: rows arrived (%s); first row out %llx %llx %llu, in %llx %llx %llu", hipGetErrorString(de),
+                 (unsigned long long)a[0], (unsigned long long)a[1], (unsigned long long)a[2], (unsigned long long)b[0], (unsigned long long)b[1], (unsigned long long)b[2]);
+    }
     const uint64_t *d_reply = nullptr;
     MDBG_TRY(mdbg_shard_reduce(ctx, shard, d_recv.p, n_recv, &d_reply));
+    MDBG_DBG(ctx, "shard_exchange: reduced");
     // ---- replies back, transposed sizes: what came from rank r returns to rank r, in the order it was sent ----
     {
         LaunchTimer timer(ctx, "shard_exchange");
-        MDBG_NCCL_CHECK(ctx, api, api->GroupStart());
-        for (int r = 0; r < n; r++) {
-            if (got[r]) MDBG_NCCL_CHECK(ctx, api, api->Send(d_reply + roff[r], got[r], ncclUint64, r, comm->comm, ctx->stream));
-            if (counts[r]) MDBG_NCCL_CHECK(ctx, api, api->Recv(comm->replies.p + soff[r], counts[r], ncclUint64, r, comm->comm, ctx->stream));
+        if (got[me]) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(comm->replies.p + soff[me], d_reply + roff[me], got[me] * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (n > 1) {
+            MDBG_NCCL_CHECK(ctx, api, api->GroupStart());
+            for (int r = 0; r < n; r++)
+                if (r != me) MDBG_TRY(move(d_reply + roff[r], comm->replies.p + soff[r], got[r], counts[r], r));
+            MDBG_NCCL_CHECK(ctx, api, api->GroupEnd());
         }
-        MDBG_NCCL_CHECK(ctx, api, api->GroupEnd());
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MDBG_DBG(ctx, "shard_exchange: done");
     *d_replies = comm->replies.p;
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)

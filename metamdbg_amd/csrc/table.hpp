@@ -40,6 +40,7 @@ struct TableView {
     uint32_t *exc_n;          // entries used
     uint32_t *exc_lock;
     uint32_t *overflow;       // set when the table or the side list is full
+    uint32_t poll_overflow;   // passes over the sequences look at `overflow` now and then and stop once it is set (MDBG_NO_GIVE_UP=1: never)
     uint32_t *occ;            // TABLE_OCC_WAYS partial counts of occupied slots, filled by a pass that asks for them
 };
 
@@ -56,6 +57,22 @@ __device__ inline uint32_t table_exc_upsert(const TableView &t, uint64_t lo, uin
                                             bool do_set, uint32_t rep, bool insert_if_absent) {
     uint32_t result = SLOT_NONE;
     bool done = false;
+    // a full list is final: look the key up without the lock (rows of zeros -- a transfer that did not arrive -- otherwise
+    // queue millions of threads on one spin lock for minutes before the overflow is reported)
+    if (__hip_atomic_load(t.exc_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= TABLE_EXC_CAP) {
+        __threadfence();
+        uint32_t i = 0;
+        for (; i < TABLE_EXC_CAP; i++)
+            if (__hip_atomic_load(&t.exc_lo[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lo &&
+                __hip_atomic_load(&t.exc_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hi) break;
+        if (i == TABLE_EXC_CAP) {
+            if (insert_if_absent) atomicExch(t.overflow, 1u);
+            return SLOT_NONE;
+        }
+        if (do_set) __hip_atomic_store(&t.exc_val[i], set_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (add) atomicAdd(&t.exc_val[i], add);
+        return 0x80000000u | i;
+    }
     while (!done) {
         if (atomicCAS(t.exc_lock, 0u, 1u) == 0u) {
             __threadfence();
@@ -75,6 +92,7 @@ __device__ inline uint32_t table_exc_upsert(const TableView &t, uint64_t lo, uin
                     __hip_atomic_store(&t.exc_hi[n], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&t.exc_val[n], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (t.exc_rep) __hip_atomic_store(&t.exc_rep[n], rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence();
                     __hip_atomic_store(t.exc_n, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -200,6 +218,8 @@ struct DeviceTable {
         v.slots = slots.p; v.mask = cap - 1;
         v.exc_lo = exc_lo.p; v.exc_hi = exc_hi.p; v.exc_val = exc_val.p; v.exc_rep = exc_rep.p;
         v.exc_n = ctl.p; v.exc_lock = ctl.p + 1; v.overflow = ctl.p + 2; v.occ = ctl.p + 4;
+        static const bool no_give_up = getenv("MDBG_NO_GIVE_UP") != nullptr;
+        v.poll_overflow = no_give_up ? 0u : 1u;
         return v;
     }
     // 0 = fine, 1 = too full (caller grows and rebuilds), negative = error
@@ -233,10 +253,14 @@ int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uin
     const uint64_t most = upper_bound + upper_bound / 2 + 1024;   // load <= 2/3 even if every key is distinct
     if (want > most) want = most;
     for (;;) {
+        MDBG_DBG(ctx, "build_table_adaptive: %llu slots (expected %llu keys, at most %llu)", (unsigned long long)want, (unsigned long long)expected, (unsigned long long)upper_bound);
         MDBG_TRY(tab.init(ctx, want));
+        MDBG_DBG(ctx, "build_table_adaptive: table allocated");
         MDBG_TRY(fill(tab.view()));
         MDBG_HIP_CHECK(ctx, hipGetLastError());
+        MDBG_DBG(ctx, "build_table_adaptive: fill launched");
         int o = tab.overflowed(ctx);
+        MDBG_DBG(ctx, "build_table_adaptive: filled, overflow %d", o);
         if (o < 0) return o;
         if (!o) return MDBG_OK;
         // At load 2/3 a linear-probing run can still exceed TABLE_MAX_PROBES (nearly all keys distinct: ONT, the edge index),
