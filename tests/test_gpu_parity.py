@@ -1133,3 +1133,34 @@ def test_full_size_fastq_hpc(ctx, orc):
             if not window:
                 assert _nan_eq([hq["mean_quality"][r]], [o["mean_quality"]])
     assert (hp["qual"] == 1).all()          # no qualities: ReadSelection.hpp:1047-1051
+
+
+def test_library_exchange_one_rank_large_share(ctx):
+    """A rank's own share of the rows beyond half a GB (one rank, a read set with hardly any repeated k-min-mer: some 25 M rows
+    of 24 bytes).  RCCL's send / receive to self returned with 531 MiB of such a message in place and the rest unwritten; the
+    library copies a rank's own share itself.  The sharded table must equal the plain one (order-independent digests)."""
+    import dataclasses
+    from metamdbg_amd import capi
+    # 2 % errors: nine k-min-mers in ten are seen once, whatever the coverage
+    spec = dataclasses.replace(synth.ont_spec(380_000, seed=23, read_len=20_000, coverage=50.0), with_quality=False)
+    reads = ctx.reads_synthetic(spec)
+    corr = ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=False), 4, 100)
+    reads.free()
+
+    def digest(table):
+        rec, _ = table.to_host()
+        info = table.info()
+        table.free()
+        lo, hi, ab = rec["lo"].astype(np.uint64), rec["hi"].astype(np.uint64), rec["abundance"].astype(np.uint64)
+        return (info["n_records"], info["n_solid"], int(np.bitwise_xor.reduce(lo)), int(np.bitwise_xor.reduce(hi)),
+                int((lo * (ab + np.uint64(1))).sum(dtype=np.uint64)), int(ab.sum()))
+    want = digest(ctx.kminmer_count_first(corr, 4, 0))
+    comm = ctx.comm_create(capi.Context.comm_unique_id(), 0, 1)
+    try:
+        sh = ctx.shard_begin(corr, 4, 1)
+        assert sh.n_rows * sh.row_words * 8 > 560 << 20          # the share really is beyond what arrived
+        got = digest(sh.finish(sh.exchange(comm), 0))
+        sh.free()
+    finally:
+        comm.destroy()
+    assert got == want and want[0] > 20_000_000
