@@ -1382,6 +1382,12 @@ static int pinned_reserve(mdbg_ctx *ctx, size_t bytes) {
     return MDBG_OK;
 }
 
+// A/B switch for the rule "one scan kernel at a time per device" (profiles/r03b_scan_mutex_ab.txt)
+static bool scans_may_interleave() {
+    static const bool on = getenv("MDBG_SCAN_NO_MUTEX") != nullptr;
+    return on;
+}
+
 static std::mutex &device_scan_mutex(int device) {
     static std::mutex m[64];
     return m[(unsigned)device % 64u];
@@ -1597,7 +1603,8 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         a.wave_priority = ctx->scan_wave_priority;
         unsigned long long h_ctl[CTL_WORDS];
         {
-            std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));      // one scan kernel at a time per device (see below)
+            std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device), std::defer_lock);      // one scan kernel at a time per device (see below)
+            if (!scans_may_interleave()) scan_turn.lock();
             if ((rc = launch_scan(ctx, a, hpc, has_q, false, n))) return fail(rc);
             if ((rc = quality_finish())) return fail(rc);          // host work while the kernel runs
             e = memcpy_sync(ctx, h_ctl, d_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost);
@@ -1715,7 +1722,8 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // workgroup each run at half speed and worse (measured: 2 x 15.5 ms alone, 2 x 30 ms interleaved), while everything
     // else a second context does -- table building, purge, RCCL -- overlaps a running scan nicely.  The lock covers the
     // launch and is released when the kernel has finished (the counter download below waits for it).
-    std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device));
+    std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device), std::defer_lock);
+    if (!scans_may_interleave()) scan_turn.lock();
     if (n && (rc = launch_scan(ctx, a, hpc, has_q, has_n, n))) return fail(rc);
     if ((rc = quality_finish())) return fail(rc);                  // host work while the kernel runs (once: the call above may have done it)
 
@@ -1728,7 +1736,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
                               d_count.p, d_cap.p, m->d_flags.p, n, d_list.p, d_suspects.p, d_nlist.p);
     uint32_t h_counters[2] = {0, 0};
     e = memcpy_sync(ctx, h_counters, d_nlist.p, 8, hipMemcpyDeviceToHost);
-    scan_turn.unlock();
+    if (scan_turn.owns_lock()) scan_turn.unlock();
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "overflow count copy failed: %s", hipGetErrorString(e)));
     const uint32_t n_over = h_counters[0], n_suspect = h_counters[1];
     if (n_suspect) {
