@@ -265,3 +265,17 @@ def test_unitig_edge_index_reference_count(name):
     assert len(hi) == m["reference_log"]["n_unitig_edges"]
     keys = np.stack([hi, lo], axis=1)
     assert len(np.unique(keys, axis=0)) == len(keys)
+
+
+def test_device_hash_header_against_the_oracle(tmp_path):
+    """csrc/murmur.hpp compiled for the host (tests/host/test_murmur_halves.cpp): the closed form of the minimizer hash equals
+    the oracle's MurmurHash3_x64_128(8 bytes, seed 42), and the carry-less upper half the block kernel records candidates by is
+    the upper half of the hash or one below it, so that no selected position can fail the candidate test."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    orc.lib()                                              # builds oracle/liboracle.so when missing
+    exe = str(tmp_path / "murmur_halves")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", os.path.join(root, "tests", "host", "test_murmur_halves.cpp"), "-o", exe,
+                    "-L", os.path.join(root, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(root, "oracle")], check=True)
+    out = subprocess.run([exe, "8000000"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok:"), out.stdout + out.stderr
