@@ -166,6 +166,15 @@ int  mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t f
  * top max(1, floor(1e-5 * distinct)) by count (ties broken by smaller value; the reference's
  * tie order is std::sort-unstable).  out must hold *n_out entries on input. */
 int  mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out);
+/* The same census fed batch by batch -- the reads of determineRepetitiveMinimizers arrive in chunks (the first
+ * 1 000 001 reads of every input file, ReadSelection.hpp:497-561): mdbg_census_add counts the values of one batch's
+ * minimizers on the device (nothing travels), mdbg_census_top is the selection above over everything added so far.
+ * mdbg_repetitive_minimizers(m) = create, add(m), top, free. */
+typedef struct mdbg_census mdbg_census;
+int  mdbg_census_create(mdbg_ctx *ctx, mdbg_census **out);
+int  mdbg_census_add(mdbg_ctx *ctx, mdbg_census *census, const mdbg_minimizers *m);
+int  mdbg_census_top(mdbg_ctx *ctx, const mdbg_census *census, uint32_t *out, uint32_t *n_out);
+void mdbg_census_free(mdbg_census *census);
 
 /* ---- minimizers -> k-min-mer table ----------------------------------------------------- */
 /* First pass, k = firstK: KminmerCounter::execute + rescueKminmers

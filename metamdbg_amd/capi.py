@@ -66,6 +66,10 @@ SIGNATURES = {
     "mdbg_apply_density_threshold": (C.c_int, [_P, _P, C.c_float, C.POINTER(_P)]),
     "mdbg_purge_palindromes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "mdbg_repetitive_minimizers": (C.c_int, [_P, _P, _P, _u32p]),
+    "mdbg_census_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "mdbg_census_add": (C.c_int, [_P, _P, _P]),
+    "mdbg_census_top": (C.c_int, [_P, _P, _P, _u32p]),
+    "mdbg_census_free": (None, [_P]),
     "mdbg_kminmer_count_first": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "mdbg_prev_from_records": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P)]),
     "mdbg_prev_overlay_unitigs": (C.c_int, [_P, _P, _P, _P, C.c_uint32]),
@@ -231,6 +235,11 @@ class Context:
         self.check(lib().mdbg_repetitive_minimizers(self.h, m.h, _ptr(out), C.byref(n)))
         return out[: n.value].copy()
 
+    def census(self) -> "Census":
+        h = C.c_void_p()
+        self.check(lib().mdbg_census_create(self.h, C.byref(h)))
+        return Census(self, h)
+
     # -- k-min-mer tables -----------------------------------------------------------------------
     def kminmer_count_first(self, m: "Minimizers", k: int = 4, min_abundance: int = 0) -> "Table":
         h = C.c_void_p()
@@ -313,6 +322,33 @@ class Context:
         counts = np.zeros(n_ranks, dtype=np.uint64)
         self.check(lib().mdbg_shard_begin(self.h, m.h, k, n_ranks, C.byref(h), C.byref(d_rows), counts.ctypes.data_as(_u64p)))
         return Shard(self, h, k, d_rows.value or 0, counts)
+
+
+class Census:
+    """Counts of minimizer values over several batches (mdbg_census_*)."""
+
+    def __init__(self, ctx: "Context", h):
+        self.ctx, self.h = ctx, h
+
+    def add(self, m: "Minimizers") -> None:
+        self.ctx.check(lib().mdbg_census_add(self.ctx.h, self.h, m.h))
+
+    def top(self, max_out: int = 4096) -> np.ndarray:
+        out = np.zeros(max_out, dtype=np.uint32)
+        n = C.c_uint32(max_out)
+        self.ctx.check(lib().mdbg_census_top(self.ctx.h, self.h, _ptr(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def free(self) -> None:
+        if self.h:
+            lib().mdbg_census_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Comm:

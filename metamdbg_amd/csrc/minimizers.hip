@@ -436,34 +436,106 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
-extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out) try {
-    if (!ctx || !m || !out || !n_out) return set_error(ctx, MDBG_EINVAL, "mdbg_repetitive_minimizers: null argument");
+// The census as an object: determineRepetitiveMinimizers counts the minimizers of the first million reads of every input file
+// (ReadSelection.hpp:497-561); the reads arrive batch by batch, and every batch's values are counted where they are instead of
+// travelling to the host and back.  The table (8-byte key, 4-byte count per slot) is kept at most half full: before a batch
+// is added the number of occupied slots is known exactly, and a table that could not take the whole batch as new values
+// is doubled (or more) and refilled from the old one.
+struct mdbg_census {
+    DevBuf<unsigned long long> keys;
+    DevBuf<uint32_t> counts;
+    uint64_t cap = 0;
+    uint64_t occupied = 0;      // exact, as of the last add
+};
+
+namespace mdbg {
+__global__ __launch_bounds__(256) void census_occupied_kernel(const unsigned long long *keys, uint64_t cap, unsigned long long *out) {
+    unsigned long long mine = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * 256) mine += keys[s] != 0ull;
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(out, mine);
+}
+
+__global__ __launch_bounds__(256) void census_rehash_kernel(const unsigned long long *old_keys, const uint32_t *old_counts, uint64_t old_cap,
+                                                            unsigned long long *keys, uint32_t *counts, uint64_t mask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < old_cap; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long key = old_keys[i];
+        if (key == 0ull) continue;
+        uint64_t s = (key * 0x9E3779B97F4A7C15ull >> 20) & mask;
+        for (;;) {                                   // every key is distinct here: the first free slot is its own
+            if (atomicCAS(&keys[s], 0ull, key) == 0ull) { counts[s] = old_counts[i]; break; }
+            s = (s + 1) & mask;
+        }
+    }
+}
+}  // namespace mdbg
+
+extern "C" int mdbg_census_create(mdbg_ctx *ctx, mdbg_census **out) try {
+    if (!ctx || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_census_create: null argument");
+    *out = new mdbg_census();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" void mdbg_census_free(mdbg_census *c) { delete c; }
+
+extern "C" int mdbg_census_add(mdbg_ctx *ctx, mdbg_census *c, const mdbg_minimizers *m) try {
+    if (!ctx || !c || !m) return set_error(ctx, MDBG_EINVAL, "mdbg_census_add: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     MDBG_TRY(ensure_canonical(ctx, m));
     const uint64_t n = m->n_min;
-    uint64_t cap = 1024;
-    while (cap < n * 2) cap <<= 1;
-    DevBuf<unsigned long long> keys, hist;
-    DevBuf<uint32_t> counts, oval, ocnt;
-    MDBG_TRY(keys.alloc(ctx, cap));
-    MDBG_TRY(counts.alloc(ctx, cap));
-    MDBG_TRY(hist.alloc(ctx, CENSUS_BINS + 1));               // + the cursor of the second pass
-    MDBG_HIP_CHECK(ctx, hipMemsetAsync(keys.p, 0, cap * 8, ctx->stream));
-    MDBG_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, cap * 4, ctx->stream));
-    MDBG_HIP_CHECK(ctx, hipMemsetAsync(hist.p, 0, (CENSUS_BINS + 1) * 8, ctx->stream));
-    if (n) {
-        LaunchTimer timer(ctx, "minimizer_census");
-        hipLaunchKernelGGL(census_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, keys.p, counts.p, cap - 1);
+    if (!n) return MDBG_OK;
+    const unsigned sweep_max = (unsigned)ctx->n_cu * 8u;
+    uint64_t want = 1024;
+    while (want < (c->occupied + n) * 2) want <<= 1;
+    if (want > c->cap) {
+        DevBuf<unsigned long long> keys;
+        DevBuf<uint32_t> counts;
+        MDBG_TRY(keys.alloc(ctx, want));
+        MDBG_TRY(counts.alloc(ctx, want));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(keys.p, 0, want * 8, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, want * 4, ctx->stream));
+        if (c->occupied) {
+            LaunchTimer timer(ctx, "minimizer_census");
+            hipLaunchKernelGGL(census_rehash_kernel, dim3(grid_for(c->cap, 256, sweep_max)), dim3(256), 0, ctx->stream, c->keys.p, c->counts.p, c->cap,
+                               keys.p, counts.p, want - 1);
+            MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the old table goes back to the pool below
+        }
+        c->keys = std::move(keys);
+        c->counts = std::move(counts);
+        c->cap = want;
     }
+    DevBuf<unsigned long long> d_occ;
+    MDBG_TRY(d_occ.alloc(ctx, 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(d_occ.p, 0, 8, ctx->stream));
+    {
+        LaunchTimer timer(ctx, "minimizer_census");
+        hipLaunchKernelGGL(census_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, c->keys.p, c->counts.p, c->cap - 1);
+        hipLaunchKernelGGL(census_occupied_kernel, dim3(grid_for(c->cap, 256, sweep_max)), dim3(256), 0, ctx->stream, c->keys.p, c->cap, d_occ.p);
+    }
+    unsigned long long occ = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &occ, d_occ.p, 8, hipMemcpyDeviceToHost));
+    c->occupied = occ;
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_census_top(mdbg_ctx *ctx, const mdbg_census *c, uint32_t *out, uint32_t *n_out) try {
+    if (!ctx || !c || !out || !n_out) return set_error(ctx, MDBG_EINVAL, "mdbg_census_top: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!c->cap) { *n_out = 0; return MDBG_OK; }
+    const uint64_t cap = c->cap;
+    DevBuf<unsigned long long> hist;
+    DevBuf<uint32_t> oval, ocnt;
+    MDBG_TRY(hist.alloc(ctx, CENSUS_BINS + 1));               // + the cursor of the second pass
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(hist.p, 0, (CENSUS_BINS + 1) * 8, ctx->stream));
     const unsigned sweep_blocks = grid_for(cap, 256, (unsigned)ctx->n_cu * 8u);
     std::vector<unsigned long long> h_hist(CENSUS_BINS);
     {
         LaunchTimer timer(ctx, "minimizer_census");
-        hipLaunchKernelGGL(census_hist_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, hist.p);
+        hipLaunchKernelGGL(census_hist_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, c->keys.p, c->counts.p, cap, hist.p);
     }
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h_hist.data(), hist.p, CENSUS_BINS * 8, hipMemcpyDeviceToHost));
     uint64_t distinct = 0;
-    for (unsigned long long c : h_hist) distinct += c;
+    for (unsigned long long v : h_hist) distinct += v;
     // the top max(1, fraction * distinct) values by count (ReadSelection.hpp:515-540)
     float fraction = 0.00001f;
     int keep = (int)(fraction * (float)distinct);
@@ -480,7 +552,7 @@ extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *
         MDBG_TRY(ocnt.alloc(ctx, n_top));
         {
             LaunchTimer timer(ctx, "minimizer_census");
-            hipLaunchKernelGGL(census_top_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, keys.p, counts.p, cap, cut, oval.p, ocnt.p,
+            hipLaunchKernelGGL(census_top_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, c->keys.p, c->counts.p, cap, cut, oval.p, ocnt.p,
                                hist.p + CENSUS_BINS, n_top);
         }
         MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hv.data(), oval.p, n_top * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -493,8 +565,15 @@ extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *
         if (hc[a] != hc[b]) return hc[a] > hc[b];
         return hv[a] < hv[b];
     });
-    if ((uint32_t)keep > *n_out) return set_error(ctx, MDBG_ERANGE, "mdbg_repetitive_minimizers: need room for %d values", keep);
+    if ((uint32_t)keep > *n_out) return set_error(ctx, MDBG_ERANGE, "mdbg_census_top: need room for %d values", keep);
     for (int i = 0; i < keep; i++) out[i] = hv[order[i]];
     *n_out = (uint32_t)keep;
     return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out) try {
+    if (!ctx || !m || !out || !n_out) return set_error(ctx, MDBG_EINVAL, "mdbg_repetitive_minimizers: null argument");
+    mdbg_census c;
+    MDBG_TRY(mdbg_census_add(ctx, &c, m));
+    return mdbg_census_top(ctx, &c, out, n_out);
 } MDBG_API_CATCH(ctx)

@@ -244,31 +244,24 @@ int run_read_selection(int argc, char **argv) {
     {
         std::ofstream repFile(tmpDir + "/repetitiveMinimizers.bin", std::ios::binary);
         if (!P.hpc) {
-            std::vector<uint32_t> all;
-            std::vector<uint64_t> offs{0};
+            // every batch's minimizer values are counted where they are (mdbg_census_*): nothing but the pick comes back
+            mdbg_census *census = nullptr;
+            check(mdbg_census_create(g_ctx, &census), "mdbg_census_create");
             for_each_batch(inputList, a.batchBases, a.threads, 1000000, [&](ReadBatch &b) {
                 mdbg_reads *reads = nullptr;
                 mdbg_minimizers *mins = nullptr;
                 reads = upload_batch(g_ctx, b, false);
                 mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
                 check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
-                uint32_t n; uint64_t t;
-                mdbg_minimizers_info(mins, &n, &t);
-                std::vector<uint64_t> o((size_t)n + 1);
-                const size_t base = all.size();
-                all.resize(base + t);
-                check(mdbg_minimizers_to_host(g_ctx, mins, o.data(), all.data() + base, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
-                for (uint32_t r = 1; r <= n; r++) offs.push_back(base + o[r]);
+                check(mdbg_census_add(g_ctx, census, mins), "mdbg_census_add");
                 mdbg_minimizers_free(mins);
                 mdbg_reads_free(reads);
             });
-            mdbg_minimizers *census = nullptr;
-            check(mdbg_minimizers_from_host(g_ctx, all.data(), offs.data(), (uint32_t)(offs.size() - 1), &census), "mdbg_minimizers_from_host");
             uint32_t cap = 1u << 16;
             rep.resize(cap);
-            check(mdbg_repetitive_minimizers(g_ctx, census, rep.data(), &cap), "mdbg_repetitive_minimizers");
+            check(mdbg_census_top(g_ctx, census, rep.data(), &cap), "mdbg_census_top");
             rep.resize(cap);
-            mdbg_minimizers_free(census);
+            mdbg_census_free(census);
             // test hook: ties among equally frequent minimizers are broken arbitrarily by the reference
             // (std::sort on counts, ReadSelection.hpp:522-524); a fixture can pin the reference's pick
             if (const char *forced = getenv("MDBG_TOOL_REPETITIVE")) {

@@ -1164,3 +1164,28 @@ def test_library_exchange_one_rank_large_share(ctx):
     finally:
         comm.destroy()
     assert got == want and want[0] > 20_000_000
+
+
+def test_census_batch_by_batch(ctx):
+    """mdbg_census_*: the census fed in batches (the table grows and is refilled on the way) picks what the one-call form
+    picks over all the minimizers, and what an independent count says."""
+    spec = synth.ont_spec(6000, seed=9, read_len=20_000, coverage=40.0)
+    parts = [ctx.reads_synthetic(spec, first_read=f, n_reads=n) for f, n in ((0, 500), (500, 2500), (3000, 3000))]
+    whole = ctx.reads_synthetic(spec)
+    c = ctx.census()
+    for r in parts:
+        m = ctx.scan(r, K=15, density=0.025, hpc=False, apply_read_filters=False, ignore_qualities=True)
+        c.add(m)
+        m.free(); r.free()
+    picked = c.top()
+    c.free()
+    mw = ctx.scan(whole, K=15, density=0.025, hpc=False, apply_read_filters=False, ignore_qualities=True)
+    one_call = ctx.repetitive_minimizers(mw)
+    assert picked.tolist() == one_call.tolist()
+    vals, counts = np.unique(mw.to_host(full=False)["minimizers"], return_counts=True)
+    n_keep = max(int(np.float32(0.00001) * np.float32(len(vals))), 1)
+    order = np.lexsort((vals, -counts.astype(np.int64)))[:n_keep]
+    exp = vals[order].tolist()
+    cnt = dict(zip(vals.tolist(), counts.tolist()))
+    assert n_keep >= 5 and len(picked) == n_keep, (n_keep, len(picked), len(vals))
+    assert picked.tolist() == exp, [(int(v), cnt.get(int(v))) for v in picked][:20] + ["expected"] + [(v, cnt[v]) for v in exp][:20]
