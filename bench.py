@@ -763,7 +763,7 @@ def main() -> None:
                        "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
                        "exchange": (None if not exchange else "library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
                                     else "torch.distributed all_to_all_single")},
-            "roofline": {"bound": "hbm", "kernel": "scan_fast_kernel<HPC>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "scan_fast_kernel<HPC=1,QUAL=0,APPROX=1> (_ZN4mdbg16scan_fast_kernelILb1ELb0ELb1EEEvNS_8ScanArgsE)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "concurrent_launches": n_slots,

@@ -3,8 +3,8 @@
 # Writes under gpurun_out/<tag>/ what profiles/<tag>_* is made of:
 #   bench_stdout.json            python bench.py (default flags: N=1, 10 M reads, parity + cpu_baseline + legs)
 #   bench_in_flight_1.json       one context, no legs
-#   bench_kernel_stats.txt       rocprofv3 --kernel-trace of the default command with fewer steps and a smaller CPU sample: every
-#                                kernel of the timed region and of the legs (multik, ont, parity)
+#   bench_kernel_stats.txt       rocprofv3 --kernel-trace of the timed workload alone (--legs none): the scan launches are the bench's
+#   bench_legs_kernel_stats.txt  the same with the legs (multik, pcie, ont, parity sample): every kernel they run
 #   scan_traffic.json            FETCH_SIZE / WRITE_SIZE of the scan kernel at the bench's 10 M reads (separate --pmc passes)
 #   pmc_scan.txt                 SQ counters of the scan kernel (1 M reads)
 set -u
@@ -15,9 +15,13 @@ export TMPDIR=/tmp
 ROOT=$PWD
 timeout 600 python bench.py > $OUT/bench_stdout.json 2> $OUT/bench_stderr.log
 timeout 300 python bench.py --in-flight 1 --steps 20 --legs none --cpu-sample 0 > $OUT/bench_in_flight_1.json 2>> $OUT/bench_stderr.log
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $ROOT/$OUT/kt -o kt -- python $ROOT/bench.py --steps 10 --warmup 3 --cpu-sample 20000 > $ROOT/$OUT/kt_bench.json 2> $ROOT/$OUT/kt.err )
+# the timed workload alone (warm-up, overlap probe and timed steps: every scan launch is the 10 M-read batch), then the legs
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $ROOT/$OUT/kt -o kt -- python $ROOT/bench.py --steps 10 --warmup 3 --legs none --cpu-sample 0 > $ROOT/$OUT/kt_bench.json 2> $ROOT/$OUT/kt.err )
 python tools/rocpd_summary.py $OUT/kt/kt_results.db > $OUT/bench_kernel_stats.txt 2>&1
 rm -rf $OUT/kt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $ROOT/$OUT/ktl -o kt -- python $ROOT/bench.py --steps 3 --warmup 3 --cpu-sample 20000 > $ROOT/$OUT/kt_legs_bench.json 2> $ROOT/$OUT/kt_legs.err )
+python tools/rocpd_summary.py $OUT/ktl/kt_results.db > $OUT/bench_legs_kernel_stats.txt 2>&1
+rm -rf $OUT/ktl
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$OUT/pmc_$c -o p -- python $ROOT/tools/scan_once.py 10000000 > /dev/null 2> $ROOT/$OUT/pmc_$c.err )
   python tools/rocpd_summary.py $OUT/pmc_$c/p_results.db 2>&1 | grep "n=" | grep "scan_" > $OUT/pmc_$c.txt
