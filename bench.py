@@ -52,7 +52,8 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (10 kb each); default 10 M at N=1, 5 M per rank at N>1")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--in-flight", type=int, default=3, help="batches processed concurrently per GPU (own context, stream and host thread each)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads in the CPU-baseline / parity sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000,
+                    help="reads of the CPU-baseline / parity read set, a HiFi set of its own at 50x (1 M = BASELINE.json configs[1]; 0 = skip)")
     ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,pcie,ont ('all', 'none')")
     ap.add_argument("--ont-reads", type=int, default=5_000_000, help="reads (20 kb, with qualities) of the ont leg")
     a = ap.parse_args()
@@ -76,37 +77,47 @@ def _make_tmp(work: str, name: str, params, inputs: list) -> str:
     return tmp
 
 
-def _run_two_commands(exe: str, tmp: str, threads: int, extra_rs=(), timeout: int = 600) -> dict:
+def _run_two_commands(exe: str, tmp: str, threads: int, extra_rs=(), timeout: int = 1800, stop_after_tables: bool = False) -> dict:
     """`readSelection` then `graph --firstpass` with the reference's argv (AssemblyPipeline.hpp:733-737, :770-783), timed.
     `tables_s` = seconds into `graph` at which kminmerData_abundance_init.txt appears: the reference copies it right after
-    the tables are complete and before it goes on to build the graph (graph/CreateMdbg.cpp:515-553), so
-    read_selection_s + tables_s is the time of the path alone, measured on the reference's own code from outside."""
+    the tables are complete and closed, before it goes on to build the graph (graph/CreateMdbg.cpp:515-553), so
+    read_selection_s + tables_s is the time of the path alone, measured on the reference's own code from outside.
+    stop_after_tables: the process is ended once that copy is complete (same size as kminmerData_abundance.txt) -- the rest of
+    the command is graph construction, out of scope, and at a million reads it is minutes of it; graph_s is then None."""
     t0 = time.perf_counter()
     subprocess.run([exe, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
                     "--threads", str(threads), "--min-read-quality", "0.000000", *extra_rs], check=True, timeout=timeout,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     t1 = time.perf_counter()
     marker = os.path.join(tmp, "kminmerData_abundance_init.txt")
-    seen = [None]
-    stop = threading.Event()
-
-    def watch():
-        while not stop.is_set():
-            if os.path.exists(marker):
-                seen[0] = time.perf_counter()
-                return
-            time.sleep(0.002)
-
-    th = threading.Thread(target=watch)
-    th.start()
+    source = os.path.join(tmp, "kminmerData_abundance.txt")
+    proc = subprocess.Popen([exe, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    seen = None
+    stopped = False
     try:
-        subprocess.run([exe, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], check=True,
-                       timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        while proc.poll() is None:
+            now = time.perf_counter()
+            if seen is None and os.path.exists(marker):
+                seen = now
+            if seen is not None and stop_after_tables and os.path.getsize(marker) == os.path.getsize(source):
+                proc.kill()                      # this very process, by its handle
+                proc.wait()
+                stopped = True
+                break
+            if now - t1 > timeout:
+                proc.kill(); proc.wait()
+                raise subprocess.TimeoutExpired("graph", timeout)
+            time.sleep(0.002)
+        if not stopped and proc.returncode != 0:
+            raise subprocess.CalledProcessError(proc.returncode, "graph")
     finally:
-        t2 = time.perf_counter()
-        stop.set()
-        th.join()
-    return {"read_selection_s": t1 - t0, "graph_s": t2 - t1, "tables_s": (seen[0] - t1) if seen[0] else None}
+        if proc.poll() is None:
+            proc.kill(); proc.wait()
+    t2 = time.perf_counter()
+    if seen is None and os.path.exists(marker):
+        seen = t2
+    return {"read_selection_s": t1 - t0, "graph_s": None if stopped else t2 - t1, "tables_s": (seen - t1) if seen else None}
 
 
 def _fbytes(tmp: str, name: str) -> bytes:
@@ -123,15 +134,32 @@ def _tables_equal(tmp_a: str, tmp_b: str, k: int) -> bool:
                                formats.sorted_vector_records(_fbytes(tmp_b, "kminmerData_min.txt"), k)))
 
 
-def sample_legs(ctx, reads, spec, first_read: int, n_sample: int, with_tool: bool) -> dict:
-    """cpu_baseline + parity (+ end_to_end) on the first n_sample reads of the resident batch.
+def _write_fasta_from_device(path: str, reads, n_reads: int, chunk: int = 50_000) -> int:
+    """The resident reads as a FASTA file (">r<index>" + one line), exported from HBM in pieces; returns the bases written."""
+    nbases = 0
+    with open(path, "wb") as f:
+        for r0 in range(0, n_reads, chunk):
+            n = min(chunk, n_reads - r0)
+            bases, offs = reads.export_ascii(r0, n)
+            nbases += int(offs[n])
+            f.write(b"".join(b">r%d\n%s\n" % (r0 + r, bases[int(offs[r]): int(offs[r + 1])].tobytes()) for r in range(n)))
+    return nbases
 
-    The reads are written as FASTA; the REFERENCE's own code (oracle/_ref/refdrv) runs its two commands on the file with
-    the threads its README uses.  Its files are the expected values: the HIP path, run through the library on exactly those
-    reads as they sit in HBM, must give read_data_init.txt byte for byte and the k-min-mer table as a multiset of records and
-    vectors (the reference's own record order depends on its thread timing).  A mismatch raises."""
+
+def sample_legs(ctx, n_sample: int, read_len: int, with_tool: bool, keep_dir: list | None = None) -> dict:
+    """cpu_baseline + parity (+ end_to_end) on a HiFi read set of its own: n_sample reads at 50x over the metagenome of
+    synth.hifi_spec -- with the default 1 000 000 reads that is BASELINE.json configs[1] ("1 M synthetic HiFi reads (10 kb),
+    single k iteration, 1 x MI355X vs CPU OpenMP") at its stated size, whole.
+
+    The reads are generated in HBM and written as FASTA; the REFERENCE's own code (oracle/_ref/refdrv) runs its two commands
+    on the file with the threads its README uses.  Its files are the expected values: the HIP path, run through the library on
+    exactly those reads as they sit in HBM, must give read_data_init.txt byte for byte, read_data_corrected.txt as a multiset
+    of reads and the k-min-mer table as a multiset of records and vectors (the reference's own record order depends on its
+    thread timing).  When tests/golden/hifi_1m/manifest.json describes this very read set, the digests committed there (made
+    by the reference in the build container) are compared as well.  A mismatch raises."""
+    import hashlib
     import numpy as np
-    from metamdbg_amd import formats
+    from metamdbg_amd import formats, synth
     out: dict = {}
     if n_sample <= 0 or not os.path.exists(REFDRV):
         return out
@@ -139,60 +167,85 @@ def sample_legs(ctx, reads, spec, first_read: int, n_sample: int, with_tool: boo
     # in 60 s with 256 threads on a 0.2 Gbp sample, 0.8 s with 8): use what its README / test scripts use
     cores = min(os.cpu_count() or 1, 32)
     work = tempfile.mkdtemp(prefix="mdbg_cpu_")
+    if keep_dir is not None:
+        keep_dir.append(work)
     try:
-        bases, offs = reads.export_ascii(0, n_sample)
-        nbases = int(offs[n_sample])
+        sspec = synth.hifi_spec(n_sample, seed=42, read_len=read_len, coverage=50.0)
+        sub = ctx.reads_synthetic(sspec)
         fasta = os.path.join(work, "sample.fasta")
-        with open(fasta, "wb") as f:
-            for r in range(n_sample):
-                f.write(b">r%d\n" % r)
-                f.write(bases[int(offs[r]): int(offs[r + 1])].tobytes())
-                f.write(b"\n")
-        del bases
+        nbases = _write_fasta_from_device(fasta, sub, n_sample)
         P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
                                hpc=True, data_type=0)
         t_ref = _make_tmp(work, "ref", P, [fasta])
+        big = n_sample > 300_000       # the rest of `graph` (graph construction, out of scope) is minutes at this size
         try:
-            tr = _run_two_commands(REFDRV, t_ref, cores)
+            tr = _run_two_commands(REFDRV, t_ref, cores, stop_after_tables=big)
         except Exception as exc:  # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": cores, "kind": "reference", "sample": f"failed: {exc}"}
             return out
-        whole = tr["read_selection_s"] + tr["graph_s"]
         path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
+        whole = None if tr["graph_s"] is None else tr["read_selection_s"] + tr["graph_s"]
         out["cpu_baseline"] = {
             "value": nbases / 1e9 / path, "unit": "Gbp/s", "cores": cores, "kind": "reference",
-            "sample": f"first {n_sample} reads ({nbases / 1e9:.2f} Gbp) of the batch as FASTA on local disk, --threads {cores} of "
-                      f"{os.cpu_count()} hardware threads; value = path only: readSelection {tr['read_selection_s']:.2f} s + "
-                      f"graph --firstpass until its tables are written "
-                      f"{(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.2f} s (the whole graph command, "
-                      f"which goes on to build the graph, takes {tr['graph_s']:.2f} s)",
+            "sample": f"{n_sample} synthetic HiFi reads x {read_len} bp at 50x ({nbases / 1e9:.2f} Gbp"
+                      f"{': BASELINE.json configs[1], whole' if n_sample == 1_000_000 and read_len == 10_000 else ''}) as FASTA on local disk, "
+                      f"--threads {cores} of {os.cpu_count()} hardware threads; value = path only: readSelection {tr['read_selection_s']:.2f} s + "
+                      f"graph --firstpass until its tables are written and closed "
+                      f"{(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.2f} s"
+                      + (" (the command was ended there: what follows is graph construction)" if tr["graph_s"] is None else
+                         f" (the whole graph command, which goes on to build the graph, takes {tr['graph_s']:.2f} s)"),
             "path_only": {"read_selection_s": tr["read_selection_s"], "tables_s": tr["tables_s"], "gbps": nbases / 1e9 / path},
-            "whole_commands": {"seconds": whole, "gbps": nbases / 1e9 / whole},
+            "whole_commands": None if whole is None else {"seconds": whole, "gbps": nbases / 1e9 / whole},
             "read_selection_gbps": nbases / 1e9 / tr["read_selection_s"]}
         # ---- parity: the library on the same reads as they sit in HBM
-        sub = ctx.reads_synthetic(spec, first_read=first_read, n_reads=n_sample)
+        t0 = time.perf_counter()
         mins = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=True)
-        init_equal = formats.build_read_data_init(mins.to_host()) == _fbytes(t_ref, "read_data_init.txt")
+        init_bytes = formats.build_read_data_init(mins.to_host())
+        ref_init = _fbytes(t_ref, "read_data_init.txt")
+        init_equal = init_bytes == ref_init
         corr = ctx.purge_palindromes(mins, 4, 100)
         hc = corr.to_host(full=False)
         ref_m, ref_o = formats.parse_minimizer_reads(_fbytes(t_ref, "read_data_corrected.txt"))
         # read_data_corrected.txt: the reference writes its records in thread order -> compare as multisets of reads
-        def read_multiset(m, o):
-            return sorted(m[int(o[i]): int(o[i + 1])].tobytes() for i in range(len(o) - 1))
-        corrected_equal = read_multiset(hc["minimizers"], hc["offsets"]) == read_multiset(ref_m, ref_o)
+        corrected_equal = formats.minimizer_reads_equal_as_multisets(hc["minimizers"], hc["offsets"], ref_m, ref_o)
         table = ctx.kminmer_count_first(corr, KMINMER, 0)
         rec, vec = table.to_host()
+        ti = table.info()
+        ref_rec = _fbytes(t_ref, "kminmerData_abundance.txt")
         table_equal = bool(
-            np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(_fbytes(t_ref, "kminmerData_abundance.txt"))) and
+            np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(ref_rec)) and
             np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), KMINMER),
                            formats.sorted_vector_records(_fbytes(t_ref, "kminmerData_min.txt"), KMINMER)))
+        # the checksum the reference logs when it loads this table again (graph/CreateMdbg.cpp:3321, :3397), from ITS records
+        rr = formats.parse_abundance_table(ref_rec)
+        with np.errstate(over="ignore"):
+            ref_checksum = int((rr["abundance"].astype(np.uint64) * rr["lo"]).sum(dtype=np.uint64))
+        checksum_equal = table.checksum()[0] == ref_checksum
         out["parity"] = {"reads": n_sample, "bases": nbases, "minimizers": int(mins.info()["n_minimizers"]),
-                         "kminmer_records": int(len(rec)), "init_bytes_equal": bool(init_equal),
+                         "kminmer_records": int(len(rec)), "solid": int(ti["n_solid"]), "init_bytes_equal": bool(init_equal),
+                         "init_bytes": len(ref_init),
                          "corrected_multiset_equal": bool(corrected_equal), "table_multiset_equal": table_equal,
-                         "against": "oracle/_ref/refdrv (the reference's own code) on the same reads, this run"}
+                         "abundance_checksum_equal": bool(checksum_equal), "abundance_checksum": ref_checksum,
+                         "against": "oracle/_ref/refdrv (the reference's own code) on the same reads, this run",
+                         "check_seconds": None}
+        ok = init_equal and corrected_equal and table_equal and checksum_equal
+        # ---- the digests committed with the repository (tests/golden/hifi_1m: made by the reference in the build container)
+        gpath = os.path.join(ROOT, "tests", "golden", "hifi_1m", "manifest.json")
+        if os.path.exists(gpath):
+            g = json.load(open(gpath))
+            if g["n_reads"] == n_sample and g["read_len"] == read_len and g["seed"] == 42:
+                mine = {"read_data_init_sha256": hashlib.sha256(init_bytes).hexdigest(),
+                        "read_data_corrected_digest": formats.minimizer_reads_digest(hc["minimizers"], hc["offsets"]),
+                        "n_records": int(len(rec)), "abundance_checksum": table.checksum()[0],
+                        **formats.table_digests(rec, vec.astype("<u4").tobytes(), KMINMER)}
+                same = all(g[key] == v for key, v in mine.items()) and g["reference_log"].get("n_solid") == ti["n_solid"]
+                out["parity"]["golden"] = {"fixture": "tests/golden/hifi_1m/manifest.json", "digests_equal": bool(same)}
+                ok = ok and same
+        out["parity"]["check_seconds"] = time.perf_counter() - t0
+        del init_bytes, ref_init
         for o in (table, corr, mins, sub):
             o.free()
-        if not (init_equal and corrected_equal and table_equal):
+        if not ok:
             raise SystemExit(f"bench.py: PARITY FAILURE against the reference: {out['parity']}")
         # ---- end to end from the file: the C++ drop-in for the two child processes against the reference
         if with_tool and os.path.exists(TOOL):
@@ -213,7 +266,8 @@ def sample_legs(ctx, reads, spec, first_read: int, n_sample: int, with_tool: boo
                 raise SystemExit(f"bench.py: PARITY FAILURE of mdbg_tool against the reference: {out['end_to_end']}")
         return out
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        if keep_dir is None:
+            shutil.rmtree(work, ignore_errors=True)
 
 
 def multik_leg(ctx, reads, n_bases: int, last_k: int = 11) -> dict:
@@ -436,19 +490,80 @@ def ont_leg(ctx, n_reads: int, sample: int) -> dict:
     return r
 
 
+def git_blob_hash(path: str) -> str:
+    """What `git hash-object` prints for the file: identifies the version of a source the way the repository does."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def measured_traffic(reads: int, read_len: int):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/rNN_scan_traffic.json),
-    valid only for the workload they were collected on; None otherwise."""
+    """(HBM bytes per scan launch, note) from the committed rocprofv3 PMC passes (profiles/*_scan_traffic.json): valid only for
+    the workload AND the kernel source they were collected on -- the file records the git blob hash of csrc/scan.hip, and a
+    collection made on another version of the kernel is not reported (None, with the reason)."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scan_traffic.json"))):
+    here = git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", "scan.hip"))
+    best, stale = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_scan_traffic.json")), key=os.path.getmtime):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if d.get("reads") == reads and d.get("read_len") == read_len:
-            best = d
-    return None if best is None else best["traffic_bytes_per_launch"]
+            if d.get("scan_hip_blob") == here:
+                best = (d, os.path.basename(path))
+            else:
+                stale = os.path.basename(path)
+    if best is not None:
+        return best[0]["traffic_bytes_per_launch"], f"profiles/{best[1]} (collected on this version of csrc/scan.hip, blob {here[:12]})"
+    return None, (f"profiles/{stale} was collected on another version of csrc/scan.hip (the tree has blob {here[:12]}): not reported"
+                  if stale else "no PMC collection for this workload under profiles/")
+
+
+# random 4-byte device-scope atomics on gfx950, whatever the table size (1 MB .. 1 GB) or the XCD locality of the address:
+# tools/ubench/atomic_rates.hip, profiles/r01c_atomic_rates_gfx950.txt (25-27 G/s)
+ATOMIC_RATE_GOPS = 26.0
+
+
+def kminmer_roofline(ctx, reads) -> dict:
+    """The k-min-mer step (first pass, k = 4) of the bench workload on the record: algorithmic bytes 4 M + 16 I + 20 D
+    (minimizers read, one 128-bit key per instance, output rows) over the HIP-event time of its kernels with
+    the context ALONE on the device, and the ceiling the insert is judged against: one atomic per instance at the part's
+    random-atomic rate."""
+    ctx.set_option("table_blocks_per_cu", 0)
+    names = ("kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
+    acc = {n: 0.0 for n in names}
+    st = ti = None
+    reps = 2
+    for it in range(reps + 1):
+        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        ctx.synchronize()
+        if it:
+            ctx.timing(True); ctx.timing_reset()
+        t = ctx.kminmer_count_first(corr, KMINMER, 0)
+        ctx.synchronize()
+        if it:
+            ctx.timing(False)
+            for n in names:
+                acc[n] += ctx.timing_get(n)[0] / reps
+        st, ti = t.stats(), t.info()
+        for o in (t, corr, mins):
+            o.free()
+    M, I, D = st["minimizers"], st["instances"], ti["n_records"]
+    alg = 4.0 * M + 16.0 * I + 20.0 * D
+    total_ms = sum(acc.values())
+    ceiling_ms = I / (ATOMIC_RATE_GOPS * 1e9) * 1e3
+    achieved = alg / (total_ms / 1e3) / 1e9 if total_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k-min-mer first pass, k = 4: count_insert_kernel, slot_flag_kernel, emit_slots_kernel, rescue_count_kernel, "
+                                      "emit_rescued_kernel, table clears and prefix scans (one context alone on the device)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes": alg, "minimizers_M": M, "instances_I": I, "rows_D": D, "distinct_keys": st["keys"], "table_slots": st["slots"],
+            "kernel_ms": acc, "kernel_ms_total": total_ms,
+            "atomic_ceiling_ms": ceiling_ms, "atomic_rate_gops": ATOMIC_RATE_GOPS,
+            "insert_ms_over_atomic_ceiling": acc["kminmer_insert"] / ceiling_ms if ceiling_ms > 0 else None,
+            "note": "random 32-byte slots of a hash table: the bound in practice is the device's random-atomic rate (one atomicAdd per "
+                    "instance), not HBM bandwidth; `atomic_ceiling_ms` is I over that rate (profiles/r01c_atomic_rates_gfx950.txt)"}
 
 
 def main() -> None:
@@ -556,7 +671,12 @@ def main() -> None:
     turn = threading.Condition()
     next_exchange = [0]
 
-    def step(slot: int, index: int):
+    wire = {"to_peers": 0, "exchanges": 0, "ms": 0.0}     # the torch.distributed path's own account (the library keeps its own: mdbg_comm_stats)
+    corrupt = [os.environ.get("MDBG_BENCH_CORRUPT_REPLY") == "1"]   # test hook: one wrong global count in the verification step of the last rank
+
+    def step(slot: int, index: int, collect: bool = False):
+        """One pass of the hot path over the resident batch on slot `slot`; collect: also the table's order-independent sums
+        (mdbg_table_checksum) -- the verification step after the timed region."""
         ctx, reads = slots[slot]
         mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
         corr = ctx.purge_palindromes(mins, 4, 100)
@@ -570,13 +690,31 @@ def main() -> None:
                     ctx.synchronize()
                     tr.append(time.perf_counter())
                     phases[name] = phases.get(name, 0.0) + (tr[-1] - tr[-2]) * 1e3
-            sh = ctx.shard_begin(corr, KMINMER, world)
+            spoil = collect and corrupt[0] and rank == world - 1
+            try:
+                sh = ctx.shard_begin(corr, KMINMER, world)
+            except Exception:
+                # the local half failed: the peers are about to enter the exchange of this step and must not wait for this rank
+                with turn:
+                    turn.wait_for(lambda: next_exchange[0] >= index)
+                try:
+                    if comms is not None:
+                        comms[slot].abort(ctx)
+                    else:
+                        D.agree(-1, "before the exchange", device="cuda")
+                finally:
+                    with turn:
+                        next_exchange[0] = index + 1
+                        turn.notify_all()
+                raise
             mark("begin")
             sent = [int(c) for c in sh.counts]
             with turn:
                 turn.wait_for(lambda: next_exchange[0] >= index)
             if comms is not None:
                 try:
+                    if spoil:
+                        ctx.set_option("test_corrupt_replies", 1)
                     d_glob = sh.exchange(comms[slot])
                     mark("exchange")
                 finally:
@@ -586,33 +724,38 @@ def main() -> None:
                 table = sh.finish(d_glob, 0)
                 sh.free()
                 mark("finish")
-                n_min = mins.info()["n_minimizers"]
-                ti = table.info()
-                for o in (table, corr, mins):
-                    o.free()
-                return n_min, ti
-            try:
-                send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
-                    torch.empty((0, rw), dtype=torch.int64, device="cuda")
-                mine, got = D.exchange_by_owner(send, sent)
-                torch.cuda.current_stream().synchronize()      # not the device: the other slot keeps running
-                mark("all_to_all_rows")
-                d_reply = sh.reduce(mine.data_ptr(), mine.shape[0])
-                reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
-                    torch.empty((0,), dtype=torch.int64, device="cuda")
-                mark("reduce")
-                glob = D.reply_to_senders(reply, got, sent)
-                torch.cuda.current_stream().synchronize()
-                mark("all_to_all_reply")
-            finally:
-                with turn:
-                    next_exchange[0] = index + 1
-                    turn.notify_all()
-            table = sh.finish(glob.data_ptr(), 0)
-            sh.free()
-            mark("finish")
+            else:
+                try:
+                    t_x = time.perf_counter()
+                    D.agree(0, "before the exchange", device="cuda")
+                    send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
+                        torch.empty((0, rw), dtype=torch.int64, device="cuda")
+                    mine, got = D.exchange_by_owner(send, sent)
+                    torch.cuda.current_stream().synchronize()      # not the device: the other slot keeps running
+                    mark("all_to_all_rows")
+                    d_reply = D.guarded(lambda: sh.reduce(mine.data_ptr(), mine.shape[0]), "summing the rows it owns", device="cuda")
+                    reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
+                        torch.empty((0,), dtype=torch.int64, device="cuda")
+                    mark("reduce")
+                    glob = D.reply_to_senders(reply, got, sent)
+                    if spoil and glob.numel():
+                        glob[glob.numel() // 2] += 1
+                    torch.cuda.current_stream().synchronize()
+                    mark("all_to_all_reply")
+                    wire["to_peers"] += (sum(sent) - sent[rank]) * rw * 8 + (sum(got) - got[rank]) * 8
+                    wire["exchanges"] += 1
+                    wire["ms"] += (time.perf_counter() - t_x) * 1e3
+                finally:
+                    with turn:
+                        next_exchange[0] = index + 1
+                        turn.notify_all()
+                table = sh.finish(glob.data_ptr(), 0)
+                sh.free()
+                mark("finish")
         n_min = mins.info()["n_minimizers"]
         ti = table.info()
+        if collect:
+            ti = dict(ti, sums=table.checksum(), stats=table.stats())
         for o in (table, corr, mins):
             o.free()
         return n_min, ti
@@ -689,9 +832,18 @@ def main() -> None:
             slots[1] = (capi.Context(local_rank), r)
             slots[1][0].set_option("table_blocks_per_cu", table_blocks)
             # (the communicator of a slot belongs to the rank, not to the context: comms[1] stays)
+    def exchange_account() -> dict:
+        """Bytes this rank put on the wire and the host time it spent inside exchanges so far."""
+        if comms is not None:
+            st = [cm.stats() for cm in comms]
+            return {"to_peers": sum(x["bytes_to_peers"] for x in st), "exchanges": sum(x["exchanges"] for x in st),
+                    "ms": sum(x["exchange_ms"] for x in st), "rccl_ranks": st[0]["rccl_ranks"]}
+        return dict(wire, rccl_ranks=None)
+
     for c, _ in slots:
         c.timing(True)
         c.timing_reset()
+    acct0 = exchange_account() if exchange else None
     barrier()
     t0 = time.perf_counter()
     run_phase(n_warm, args.steps)
@@ -699,6 +851,23 @@ def main() -> None:
     dt = time.perf_counter() - t0
     for c, _ in slots:
         c.timing(False)
+    acct1 = exchange_account() if exchange else None
+
+    # ---- N > 1: the job checks itself (after the timed region).  One more sharded step on every rank, its share of the table
+    # reduced to record count, solid count and the order-independent sums of mdbg_table_checksum (sums[0] is the "Checksum
+    # kminmer abundance" the reference logs, graph/CreateMdbg.cpp:3321, :3397); the sums over the ranks must be those of the
+    # single-GPU first pass over ALL the reads, which rank 0 then runs alone (N x reads_per_gpu reads: 40 M x 10 kb = 100 GB
+    # packed at N = 8, one MI355X holds them).  The union of the shares IS the single-GPU table, so a lost row, a count summed
+    # twice or a key listed by two ranks shows here, in the run that is being scored.
+    verify = None
+    if world > 1:
+        v_min, v_ti = step(0, n_warm + args.steps, collect=True)
+        halves = [v_ti["n_records"], v_ti["n_solid"], v_min] + [h for x in v_ti["sums"] for h in (x & 0xFFFFFFFF, x >> 32)]
+        vt = torch.tensor(halves, dtype=torch.int64, device="cuda")
+        dist.all_reduce(vt, op=dist.ReduceOp.SUM)
+        vt = [int(x) for x in vt.tolist()]
+        verify = {"records": vt[0], "solid": vt[1], "minimizers": vt[2],
+                  "sums": [(vt[3 + 2 * i] + (vt[4 + 2 * i] << 32)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]}
     n_min, ti = results[n_warm + args.steps - 1]
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     totals = torch.tensor([ti["n_records"], ti["n_solid"]], dtype=torch.int64, device="cuda")   # last step, summed over ranks
@@ -722,13 +891,70 @@ def main() -> None:
     achieved = alg_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
     # compute floor of the reference's algorithm on this part: one Murmur3 per homopolymer-compressed position
     hpc_positions = int(0.75 * n_bases)            # HPC keeps 3/4 of uniform random bases
-    clock_hz = 2.4e9
+    clock_hz = (info.get("clock_khz") or 2_400_000) * 1e3       # hipDeviceProp_t::clockRate through the library
     hash_floor_ms = hpc_positions / 64 * 186 / (info["n_cu"] * 4) / clock_hz * 1e3
 
+    # ---- what the exchanges of the timed steps put on the wire (all ranks)
+    exch = None
+    if exchange:
+        et = torch.tensor([acct1["to_peers"] - acct0["to_peers"], acct1["exchanges"] - acct0["exchanges"]], dtype=torch.int64, device="cuda")
+        em = torch.tensor([acct1["ms"] - acct0["ms"]], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(et, op=dist.ReduceOp.SUM)
+            dist.all_reduce(em, op=dist.ReduceOp.MAX)
+        backend_name = os.environ.get("MDBG_BENCH_BACKEND", "nccl")
+        exch = {"path": ("library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
+                         else f"torch.distributed all_to_all_single ({backend_name})"),
+                # what the communicator itself reports (ncclCommCount through mdbg_comm_stats); the torch path: the process group's size
+                "rccl_ranks": acct1["rccl_ranks"] if comms is not None else (dist.get_world_size() if dist is not None and backend_name == "nccl" else None),
+                "ranks": world,
+                "wire_bytes_per_step": int(et[0].item()) / args.steps, "wire_bytes_per_step_per_rank": int(et[0].item()) / args.steps / world,
+                "exchanges_timed": int(et[1].item()),
+                "exchange_ms_per_step": float(em.item()) / args.steps,
+                "note": "wire bytes = rows to their owners (24 B each) + one u64 reply per row, other ranks only (a rank's own share is a "
+                        "device-to-device copy); exchange_ms = host time inside the exchange call incl. waiting for the slowest rank, "
+                        "max over ranks; exchanges overlap the other batches' scans"}
+
+    failed = False
     if rank == 0:
+        # ---- N > 1: the single-GPU pass over all N x reads_per_gpu reads, against the summed shares of the verification step
+        parity_n = None
+        if verify is not None:
+            total_reads = args.reads * world
+            need = total_reads * args.read_len * 0.40          # packed reads + minimizer rows + table, generously
+            if need > 0.8 * info["hbm_bytes"]:
+                parity_n = {"skipped": f"{total_reads} reads need about {need / 1e9:.0f} GB on one GPU, more than this one holds"}
+            else:
+                for c, _ in slots[1:]:
+                    c.close()                                  # their pools make room
+                ctx.set_option("table_blocks_per_cu", 0)
+                t_v = time.perf_counter()
+                allr = ctx.reads_synthetic(spec, first_read=0, n_reads=total_reads)
+                am = ctx.scan(allr, K=K_MINIMIZER, density=DENSITY, hpc=True)
+                ac = ctx.purge_palindromes(am, 4, 100)
+                at = ctx.kminmer_count_first(ac, KMINMER, 0)
+                one = {"records": at.info()["n_records"], "solid": at.info()["n_solid"], "minimizers": am.info()["n_minimizers"],
+                       "sums": list(at.checksum())}
+                for o in (at, ac, am, allr):
+                    o.free()
+                flags = {"minimizers_equal": one["minimizers"] == verify["minimizers"], "records_equal": one["records"] == verify["records"],
+                         "solid_equal": one["solid"] == verify["solid"], "abundance_checksum_equal": one["sums"][0] == verify["sums"][0],
+                         "sum_abundance_equal": one["sums"][1] == verify["sums"][1], "key_sum_equal": one["sums"][2] == verify["sums"][2],
+                         "vector_sum_equal": one["sums"][3] == verify["sums"][3]}
+                parity_n = {"mode": f"the {world} ranks' shares of one more sharded step (record count, solid count, the order-independent sums of "
+                                    "mdbg_table_checksum, all-reduced) against the single-GPU first pass over all the reads, run by rank 0 "
+                                    "after the timed region",
+                            "reads": total_reads, **flags, "table_equal": all(flags.values()),
+                            "sharded": verify, "single_gpu": one, "single_gpu_seconds": time.perf_counter() - t_v}
+                failed = not parity_n["table_equal"]
         legs_on = set() if (world > 1 or args.legs == "none") else \
             ({"end_to_end", "multik", "pcie", "ont"} if args.legs == "all" else set(args.legs.split(",")))
-        side = sample_legs(ctx, reads, spec, rank * args.reads, min(args.cpu_sample, args.reads), "end_to_end" in legs_on) if world == 1 else {}
+        # ---- the table kernels on the record (4 M + 16 I + 20 D bytes per k): two steps of this context ALONE on
+        # the device, timed by HIP events like the scan -- beside another batch's scan they share the CUs, that is not their speed
+        kroof = None
+        if world == 1:
+            kroof = kminmer_roofline(ctx, reads)
+        side = sample_legs(ctx, min(args.cpu_sample, args.reads), args.read_len, "end_to_end" in legs_on) if world == 1 else {}
         base = side.get("cpu_baseline")
         legs = {}
         if "end_to_end" in side:
@@ -749,6 +975,7 @@ def main() -> None:
             legs["ont"] = ont_leg(octx, args.ont_reads, sample=min(10_000, args.cpu_sample))
             octx.close()
         total_bases = n_bases * world * args.steps
+        traffic, traffic_note = measured_traffic(args.reads, args.read_len)
         out = {
             "metric": "Gbp/s through minimizer+k-min-mer step; bit-exact k-min-mer table vs ref",
             "value": total_bases / 1e9 / dt, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -761,10 +988,9 @@ def main() -> None:
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
                        "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
-                       "exchange": (None if not exchange else "library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
-                                    else "torch.distributed all_to_all_single")},
+                       "exchange": exch},
             "roofline": {"bound": "hbm", "kernel": "scan_fast_kernel<HPC=1,QUAL=0,APPROX=1> (_ZN4mdbg16scan_fast_kernelILb1ELb0ELb1EEEvNS_8ScanArgsE)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, args.read_len),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_s * 1e3,
                          "concurrent_launches": n_slots,
                          "concurrency_note": (f"{n_slots} batches are in flight: a scan launch shares the device with the other batches' "
@@ -783,8 +1009,12 @@ def main() -> None:
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()},
             "cpu_baseline": base,
         }
+        if kroof is not None:
+            out["roofline_kminmer"] = kroof
         if "parity" in side:
             out["parity"] = side["parity"]
+        if parity_n is not None:
+            out["parity"] = parity_n
         if legs:
             out["legs"] = legs
         if base and base.get("value"):
@@ -802,6 +1032,8 @@ def main() -> None:
         shared_reads.free()
     for c, _ in slots:
         c.close()
+    if failed:
+        sys.exit("bench.py: PARITY FAILURE: the ranks' tables do not add up to the single-GPU table (see `parity` in the line above)")
 
 
 if __name__ == "__main__":

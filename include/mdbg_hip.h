@@ -36,6 +36,7 @@ extern "C" {
 #define MDBG_ENOMEM   -3   /* device or host allocation failed */
 #define MDBG_EHIP     -4   /* HIP runtime error (see mdbg_last_error) */
 #define MDBG_ERANGE   -5   /* size exceeds an internal limit (see message) */
+#define MDBG_EPEER    -6   /* collective calls: another rank reported a failure; this rank's data is intact, nothing was exchanged */
 
 typedef struct mdbg_ctx mdbg_ctx;
 typedef struct mdbg_reads mdbg_reads;             /* base-space reads resident in HBM, 2-bit packed */
@@ -49,6 +50,7 @@ const char *mdbg_last_error(const mdbg_ctx *ctx);      /* ctx may be NULL: last 
 int  mdbg_synchronize(mdbg_ctx *ctx);
 void *mdbg_stream(mdbg_ctx *ctx);                       /* the hipStream_t every launch goes to */
 int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes);
+int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine clock (hipDeviceProp_t::clockRate) */
 /* Per-context tuning, value <= 0 restores the default:
  *   "table_blocks_per_cu"   resident blocks per CU of the kernels that walk every k-min-mer instance (default: unlimited;
  *                           1..3 when several contexts share a device, so that they do not displace another context's scan)
@@ -57,6 +59,9 @@ int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uin
  *                           hash and confirms each with the full hash; a read with a false candidate is re-run.  False
  *                           candidates occur about once in 2^31 positions; this widens the test (units of 2^32 of the
  *                           hash range) so that the re-run path can be exercised.  Default 0; results never depend on it
+ *   "test_exchange_fail_phase"  tests only: this rank fails inside the next mdbg_shard_exchange before the counts travel (1),
+ *                           when the receive buffers are allocated (2) or in the owner's reduction (3); one-shot
+ *   "test_corrupt_replies"  tests only: the next exchange hands back one reply with a wrong count; one-shot
  * The environment variables MDBG_TABLE_BLOCKS_PER_CU / MDBG_SCAN_READS_PER_WAVE set the defaults at mdbg_create. */
 int  mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value);
 
@@ -213,6 +218,20 @@ int  mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_records, uint
  * (MDBG::writeKminmerAbundance, Commons.hpp:4463-4472); vectors = n_records x k u32
  * (MDBG::writeKminmer, Commons.hpp:4429-4446), same row order.  Either may be NULL. */
 int  mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors);
+/* What the pass that built the table walked: stats[0] = minimizers read (M), [1] = k-min-mer instances (I = sum over the
+ * sequences of max(0, n - k + 1)), [2] = distinct keys it inserted, [3] = slots of the hash table it used.  With the table's
+ * rows D these are the terms of the step's algorithmic bytes 4 M + 16 I + 20 D; zeros for tables that were
+ * not built from sequences (mdbg_prev_from_records, the edge indexes, mdbg_shard_keep); a share of a sharded first pass reports
+ * its rank's own reads and local keys. */
+int  mdbg_table_stats(const mdbg_table *t, uint64_t stats[4]);
+/* Order-independent sums over the rows, wrapping at 2^64, computed on the device (nothing but 32 bytes travels):
+ *   sums[0] = sum abundance * hash_lo -- the "Checksum kminmer abundance" the reference logs when it loads the table again
+ *             (CreateMdbg::loadRefinedAbundances, graph/CreateMdbg.cpp:3300-3321, :3397: `abundance * vecHash` truncated to u64),
+ *   sums[1] = sum abundance, sums[2] = sum hash_hi,
+ *   sums[3] = sum (v[0] + 3 v[1] + 5 v[2] + ...) * (hash_lo | 1) over the rows' vectors (0 when the table has none).
+ * The sums of the per-rank tables of a sharded pass add up to those of the single-GPU table (the union of the shares is the
+ * table): what a multi-GPU job checks itself with. */
+int  mdbg_table_checksum(mdbg_ctx *ctx, const mdbg_table *t, uint64_t sums[4]);
 /* In-process lookup for the reference's graph multiplexer (isEdgeSupported etc.,
  * graph/CreateMdbg.cpp:3990): abundance of each of n keys, 0 when absent. */
 int  mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
@@ -297,6 +316,11 @@ int  mdbg_comm_unique_id(uint8_t *id128);
 int  mdbg_comm_create(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, mdbg_comm **out);
 int  mdbg_comm_adopt(mdbg_ctx *ctx, void *nccl_comm, int rank, int n_ranks, mdbg_comm **out);
 void mdbg_comm_destroy(mdbg_comm *comm);
+/* What the communicator has carried: stats[0] = rank, [1] = ranks as the caller gave them, [2] = ncclCommCount (create / adopt
+ * fail unless it equals [1] and ncclCommUserRank equals [0]), [3] = completed exchanges, [4] / [5] = bytes sent to / received
+ * from OTHER ranks over RCCL (rows and replies), [6] = bytes of the rank's own share (device-to-device copies, never on the
+ * wire), [7] = ncclCommUserRank; *exchange_ms (may be NULL) = host wall time spent inside mdbg_shard_exchange. */
+int  mdbg_comm_stats(const mdbg_comm *comm, uint64_t stats[8], double *exchange_ms);
 int  mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, const mdbg_minimizers *reads, uint32_t k,
                                       uint32_t min_abundance, mdbg_table **out);
 /* The collective middle part alone, between mdbg_shard_begin and mdbg_shard_finish (a caller with several batches in flight
@@ -304,6 +328,16 @@ int  mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, const mdbg
  * u64 per sent row, in the order sent) is what mdbg_shard_finish takes and stays valid until the next exchange on `comm`. */
 int  mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts,
                          const uint64_t **d_replies);
+/* Failure behaviour of the collective calls.  An exchange is: counts all-gathered -> rows to owners -> reduction -> replies.
+ * Before each transfer the ranks agree (a status word per rank, all-gathered) that everybody got that far: a rank that failed
+ * locally -- bad argument, allocation, reduction -- still takes part in that small collective with its error code, returns its
+ * own error, and every other rank returns MDBG_EPEER naming it; nobody is left waiting in a receive.  Send / receive groups
+ * are closed on every path (an open group would swallow the thread's next RCCL call); a communicator on which an RCCL call
+ * itself failed is marked broken: later exchanges on it fail at once and mdbg_comm_destroy aborts it.
+ * mdbg_shard_abort is for the caller that drives begin / exchange / finish itself: when its local half (mdbg_shard_begin,
+ * mdbg_shard_from_table, anything before the exchange) failed with `code`, it calls this INSTEAD of mdbg_shard_exchange so
+ * that the peers, who are about to enter theirs, return MDBG_EPEER.  Returns MDBG_OK once the peers have been told. */
+int  mdbg_shard_abort(mdbg_ctx *ctx, mdbg_comm *comm, int code);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,9 @@ SIGNATURES = {
     "mdbg_kminmer_index": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(_P)]),
     "mdbg_table_info": (C.c_int, [_P, _u32p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "mdbg_table_to_host": (C.c_int, [_P, _P, _P, _P]),
+    "mdbg_table_checksum": (C.c_int, [_P, _P, _u64p]),
+    "mdbg_table_stats": (C.c_int, [_P, _u64p]),
+    "mdbg_device_clock_khz": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
     "mdbg_edge_index": (C.c_int, [_P, _P, C.POINTER(_P), _u64p]),
     "mdbg_unitig_edge_index": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P), _u64p]),
@@ -94,6 +97,8 @@ SIGNATURES = {
     "mdbg_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "mdbg_comm_adopt": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "mdbg_comm_destroy": (None, [_P]),
+    "mdbg_comm_stats": (C.c_int, [_P, _u64p, C.POINTER(C.c_double)]),
+    "mdbg_shard_abort": (C.c_int, [_P, _P, C.c_int]),
     "mdbg_kminmer_count_first_sharded": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "mdbg_shard_exchange": (C.c_int, [_P, _P, _P, _P, _u64p, C.POINTER(_P)]),
 }
@@ -151,7 +156,9 @@ class Context:
         arch = C.create_string_buffer(64)
         ncu, hbm = C.c_int(), C.c_uint64()
         self.check(lib().mdbg_device_info(self.h, arch, 64, C.byref(ncu), C.byref(hbm)))
-        return dict(arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+        clk = C.c_int()
+        lib().mdbg_device_clock_khz(self.h, C.byref(clk))
+        return dict(arch=arch.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value, clock_khz=clk.value)
 
     def set_option(self, name: str, value: int) -> None:
         self.check(lib().mdbg_set_option(self.h, name.encode(), value))
@@ -357,6 +364,18 @@ class Comm:
     def __init__(self, h):
         self.h = h
 
+    def stats(self) -> dict:
+        """What the communicator carried so far (mdbg_comm_stats)."""
+        st = (C.c_uint64 * 8)()
+        ms = C.c_double()
+        lib().mdbg_comm_stats(self.h, st, C.byref(ms))
+        return dict(rank=int(st[0]), n_ranks=int(st[1]), rccl_ranks=int(st[2]), exchanges=int(st[3]), bytes_to_peers=int(st[4]),
+                    bytes_from_peers=int(st[5]), bytes_local=int(st[6]), exchange_ms=float(ms.value))
+
+    def abort(self, ctx: "Context", code: int = -1) -> None:
+        """This rank cannot enter the exchange its peers are about to enter: tell them (mdbg_shard_abort)."""
+        lib().mdbg_shard_abort(ctx.h, self.h, code)
+
     def destroy(self) -> None:
         if self.h:
             lib().mdbg_comm_destroy(self.h)
@@ -505,6 +524,19 @@ class Table:
         vec = np.zeros((i["n_records"], i["k"]), dtype=np.uint32) if i["has_vectors"] else None
         self.ctx.check(lib().mdbg_table_to_host(self.ctx.h, self.h, _ptr(rec), _ptr(vec)))
         return rec, vec
+
+    def stats(self) -> dict:
+        """What the pass that built the table walked (mdbg_table_stats)."""
+        s = (C.c_uint64 * 4)()
+        lib().mdbg_table_stats(self.h, s)
+        return dict(minimizers=int(s[0]), instances=int(s[1]), keys=int(s[2]), slots=int(s[3]))
+
+    def checksum(self) -> tuple:
+        """(sum abundance * hash_lo -- the reference's "Checksum kminmer abundance" --, sum abundance, sum hash_hi, vector sum),
+        all modulo 2^64, computed on the device (mdbg_table_checksum)."""
+        s = (C.c_uint64 * 4)()
+        self.ctx.check(lib().mdbg_table_checksum(self.ctx.h, self.h, s))
+        return tuple(int(x) for x in s)
 
     def keys_to_host(self) -> np.ndarray:
         """(n, 2) u64 array of (lo, hi) -- the 16-byte little-endian u128 records of edges.bin."""

@@ -117,12 +117,15 @@ struct mdbg_ctx {
     std::string arch;
     int n_cu = 0;
     uint64_t hbm_bytes = 0;
+    int clock_khz = 0;                      // hipDeviceProp_t::clockRate (peak engine clock)
     bool timing = false;
     std::vector<mdbg::TimedLaunch> launches;               // pending (not yet folded) timed launches
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
     unsigned table_blocks_per_cu = 1024;                   // resident blocks per CU of the kernels that walk every k-min-mer instance (mdbg_set_option)
     unsigned scan_reads_per_wave = 2;                      // reads a scan wave processes before it retires (mdbg_set_option)
     uint32_t scan_wave_priority = 0;        // s_setprio level of the block-structured scan's waves (mdbg_set_option)
+    int test_exchange_fail_phase = 0;       // tests: this rank fails in phase 1 (before the counts) / 2 (buffers) / 3 (reduction) of the next exchange
+    bool test_corrupt_replies = false;      // tests: the next exchange hands back one reply with a wrong count (the job's self-check must see it)
     uint32_t scan_cand_slack = 0;           // tests: widens the candidate test of the block-structured scan (see span_step)
     // distinct keys per k-min-mer instance seen by the last call OF THE SAME KIND (table sizing): the first pass keeps every
     // key, refined / index only those above abundance 1 -- one shared hint made every first pass after an index pass rebuild its table

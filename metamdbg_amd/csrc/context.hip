@@ -66,6 +66,7 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     if (const char *e = getenv("MDBG_SCAN_WAVE_PRIORITY")) ctx->scan_wave_priority = (uint32_t)std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
     ctx->hbm_bytes = prop.totalGlobalMem;
+    ctx->clock_khz = prop.clockRate;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) {
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -113,6 +114,8 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (n == "scan_wave_priority") { ctx->scan_wave_priority = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }
     if (n == "scan_reads_per_wave") { ctx->scan_reads_per_wave = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 2u; return MDBG_OK; }
+    if (n == "test_exchange_fail_phase") { ctx->test_exchange_fail_phase = (int)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
+    if (n == "test_corrupt_replies") { ctx->test_corrupt_replies = value > 0; return MDBG_OK; }
     return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: unknown option '%s'", name);
 }
 
@@ -126,6 +129,12 @@ extern "C" int mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int 
     if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz) {
+    if (!ctx || !clock_khz) return MDBG_EINVAL;
+    *clock_khz = ctx->clock_khz;
+    return MDBG_OK;
+}
 
 extern "C" int mdbg_timing_enable(mdbg_ctx *ctx, int on) try {
     if (!ctx) return MDBG_EINVAL;

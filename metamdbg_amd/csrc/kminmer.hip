@@ -522,6 +522,30 @@ __global__ __launch_bounds__(256) void sum_u64_kernel(const uint64_t *v, uint64_
     if ((threadIdx.x & 63u) == 0 && x) atomicAdd(out, (unsigned long long)x);
 }
 
+// out[0] += sum abundance * lo (the reference's "Checksum kminmer abundance"), out[1] += sum abundance, out[2] += sum hi,
+// out[3] += sum over rows with a vector of (v[0] + 3 v[1] + 5 v[2] ...) * (lo | 1): ties the vectors to their keys
+__global__ __launch_bounds__(256) void table_checksum_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *ab, const uint32_t *vec,
+                                                             uint32_t k, uint64_t n, unsigned long long *out) {
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t l = lo[i], a = ab[i];
+        s0 += a * l; s1 += a; s2 += hi[i];
+        if (vec) {
+            uint64_t w = 0;
+            for (uint32_t j = 0; j < k; j++) w += (uint64_t)vec[i * k + j] * (2u * j + 1u);
+            s3 += w * (l | 1ull);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64); s3 += __shfl_xor(s3, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(out + 0, (unsigned long long)s0); atomicAdd(out + 1, (unsigned long long)s1);
+        atomicAdd(out + 2, (unsigned long long)s2); atomicAdd(out + 3, (unsigned long long)s3);
+    }
+}
+
 __global__ void interleave_keys_kernel(const uint64_t *lo, const uint64_t *hi, uint64_t n, uint64_t *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[2 * i] = lo[i]; out[2 * i + 1] = hi[i]; }
@@ -694,6 +718,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_solid;
+    t->st_minimizers = reads->n_min; t->st_instances = I; t->st_keys = n_keys; t->st_slots = nslots;
     int rc = alloc_rows(ctx, t, n_solid + n_resc, true);
     if (rc) { delete t; return rc; }
     RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
@@ -811,16 +836,15 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
                            (uint8_t *)nullptr, 0u, tv.occ);
     }
     MDBG_TRY(exclusive_scan_u32(ctx, sflag.p, spos.p, nslots));
-    {
-        uint64_t n_keys = 0;
-        MDBG_TRY(tab.occupied(ctx, &n_keys));
-        update_key_hint(ctx, 1, n_keys, I);
-    }
+    uint64_t n_keys = 0;
+    MDBG_TRY(tab.occupied(ctx, &n_keys));
+    update_key_hint(ctx, 1, n_keys, I);
     uint64_t n_rows = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, spos.p + nslots, 8, hipMemcpyDeviceToHost));
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_rows;
+    t->st_minimizers = a.n_min + b.n_min; t->st_instances = I; t->st_keys = n_keys; t->st_slots = nslots;
     int rc = alloc_rows(ctx, t, n_rows, true);
     if (rc) { delete t; return rc; }
     RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
@@ -834,9 +858,10 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
-static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, const TableView &pv, const TableView &tv) {
+static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, const TableView &pv, const TableView &tv, uint64_t &n_inst) {
     InstIndex ik, ikm1;
     MDBG_TRY(build_inst_index(ctx, s, k, ik));
+    n_inst += ik.total;
     if (!ik.total) return MDBG_OK;
     MDBG_TRY(build_inst_index(ctx, s, k - 1, ikm1));
     DevBuf<uint32_t> prev_ab;
@@ -865,9 +890,11 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     // upper bound on distinct keys: total k-windows
     uint64_t bound = reads->n_min + (unitigs ? unitigs->n_min : 0);
     DeviceTable tab;
+    uint64_t n_inst = 0;
     MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)bound * ctx->key_ratio_hint[2]), bound, [&](TableView v) {
-        MDBG_TRY(index_one_set(ctx, reads, k, pv, v));
-        if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, v));
+        n_inst = 0;
+        MDBG_TRY(index_one_set(ctx, reads, k, pv, v, n_inst));
+        if (unitigs) MDBG_TRY(index_one_set(ctx, unitigs, k, pv, v, n_inst));
         return MDBG_OK;
     }));
     TableView tv = tab.view();
@@ -884,6 +911,7 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_rows;
+    t->st_minimizers = bound; t->st_instances = n_inst; t->st_keys = n_rows; t->st_slots = nslots;
     int rc = alloc_rows(ctx, t, n_rows, false);
     if (rc) { delete t; return rc; }
     RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, nullptr, k};
@@ -905,6 +933,25 @@ extern "C" int mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_rec
     if (has_vectors) *has_vectors = t->has_vectors ? 1 : 0;
     return MDBG_OK;
 }
+
+extern "C" int mdbg_table_stats(const mdbg_table *t, uint64_t stats[4]) {
+    if (!t || !stats) return MDBG_EINVAL;
+    stats[0] = t->st_minimizers; stats[1] = t->st_instances; stats[2] = t->st_keys; stats[3] = t->st_slots;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_table_checksum(mdbg_ctx *ctx, const mdbg_table *t, uint64_t sums[4]) try {
+    if (!ctx || !t || !sums) return set_error(ctx, MDBG_EINVAL, "mdbg_table_checksum: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf<unsigned long long> acc;
+    MDBG_TRY(acc.alloc(ctx, 4));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(acc.p, 0, 32, ctx->stream));
+    if (t->n_records)
+        hipLaunchKernelGGL(table_checksum_kernel, dim3(grid_for(t->n_records, 256 * 8, 4096)), dim3(256), 0, ctx->stream, t->d_lo.p, t->d_hi.p,
+                           t->d_ab.p, t->has_vectors ? t->d_vec.p : nullptr, t->k, t->n_records, acc.p);
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, sums, acc.p, 32, hipMemcpyDeviceToHost));
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors) try {
     if (!ctx || !t) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host: null argument");
@@ -1327,6 +1374,7 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     mdbg_table *t = new mdbg_table();
     t->k = k;
     t->n_solid = n_solid;
+    t->st_minimizers = sv.n_min; t->st_instances = I; t->st_keys = sh->n_rows; t->st_slots = nslots;
     int rc = alloc_rows(ctx, t, n_solid + n_resc, true);
     if (rc) { delete t; return rc; }
     RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};

@@ -72,6 +72,9 @@ struct mdbg_table {
     mdbg::DevBuf<uint64_t> d_lo, d_hi;   // n_records
     mdbg::DevBuf<uint32_t> d_ab;         // n_records
     mdbg::DevBuf<uint32_t> d_vec;        // n_records * k (when has_vectors)
+    // what the pass that built the table walked (mdbg_table_stats): minimizers read, k-min-mer instances, distinct keys inserted,
+    // slots of the hash table it used -- the terms of SURVEY.md 8(d)'s algorithmic bytes 4 M + 16 I + 20 D
+    uint64_t st_minimizers = 0, st_instances = 0, st_keys = 0, st_slots = 0;
     // key -> abundance lookup (always present for prev tables; built on demand for output tables)
     std::unique_ptr<mdbg::DeviceTable> lookup;
 };

@@ -1132,7 +1132,9 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             wave_lds_sync();
 
             // ---- full blocks: 2048 positions, every one followed by a known base ----
-            while (fill - done >= BLOCK_POS + K + 1u) aligned_block(std::integral_constant<int, (int)SPAN>());
+            // (with _trimBps == 0 the last l-mer is a position too: a block also runs at exactly 2048 + K bases, or the tail would
+            // be left with 2049 positions -- 36 per lane, four more than a lane's verdict vector holds)
+            while (fill - done >= BLOCK_POS + K + a.trim) aligned_block(std::integral_constant<int, (int)SPAN>());
         }
         // (a last half block of 1024 positions, 16 per lane, before the tail was measured: 11.73 against 11.76 ms -- the tail's
         // positions cost about what a block's do; not kept)
@@ -1143,7 +1145,10 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             uint32_t npos = live > K ? live - K : 0u;
             if (a.trim == 0u && live >= K) npos = live - K + 1u;
             if (npos) {
-                const unsigned G = (npos + 255u) / 256u;            // groups of four positions per lane (<= 8)
+                // groups of four positions per lane: at most 8, the verdicts of a lane are a 32-bit vector (the block loop above
+                // leaves at most 2048 positions whatever _trimBps is)
+                if (npos > BLOCK_POS) __builtin_trap();
+                const unsigned G = (npos + 255u) / 256u;
                 const unsigned P = 4u * G;
                 SpanState st{0u, 0u};
                 for (unsigned g = 0; g < G; g++) {

@@ -54,6 +54,43 @@ def reply_to_senders(reply: torch.Tensor, recv_counts: list[int], sent_counts: l
     return out
 
 
+class PeerFailure(RuntimeError):
+    """Another rank could not go on (the harness's counterpart of MDBG_EPEER): nothing was exchanged in this phase."""
+
+    def __init__(self, rank: int, code: int, phase: str):
+        super().__init__(f"rank {rank} failed {phase} (code {code}); nothing was exchanged")
+        self.rank, self.code, self.phase = rank, code, phase
+
+
+def agree(local_code: int, phase: str, group=None, device=None) -> None:
+    """Every rank says whether it got this far (0) or not (a negative code) and learns what the others said -- the protocol of
+    mdbg_shard_exchange (include/mdbg_hip.h, "Failure behaviour of the collective calls"): a rank that failed locally still
+    takes part in this small all-gather, so its peers raise PeerFailure instead of waiting in the next all-to-all for rows
+    that never come.  The failing rank itself returns normally: its caller re-raises the local error."""
+    world = dist.get_world_size(group)
+    dev = device if device is not None and not _staged(group) else "cpu"
+    mine = torch.tensor([int(local_code)], dtype=torch.int64, device=dev)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine, group=group)
+    if local_code == 0:
+        for r, t in enumerate(everyone):
+            if int(t.item()) != 0:
+                raise PeerFailure(r, int(t.item()), phase)
+
+
+def guarded(fn, phase: str, group=None, device=None):
+    """fn() is a local step between two transfers: its failure is announced to the peers (agree) before it is re-raised."""
+    try:
+        out = fn()
+    except PeerFailure:
+        raise
+    except Exception as exc:
+        agree(int(getattr(exc, "code", -1) or -1), phase, group, device)
+        raise
+    agree(0, phase, group, device)
+    return out
+
+
 # ---- whole sharded passes over torch.distributed (the harness's counterpart of mdbg_kminmer_count_first_sharded) ----------
 def _device_rows(ptr: int, shape: tuple) -> torch.Tensor:
     from . import capi
@@ -71,7 +108,7 @@ def _exchange_shard(sh, finish, group=None):
     sent = [int(c) for c in sh.counts]
     mine, got = exchange_by_owner(_device_rows(sh.d_rows, (sh.n_rows, rw)), sent, group)
     torch.cuda.current_stream().synchronize()
-    d_reply = sh.reduce(mine.data_ptr(), mine.shape[0])
+    d_reply = guarded(lambda: sh.reduce(mine.data_ptr(), mine.shape[0]), "summing the rows it owns", group, "cuda")
     glob = reply_to_senders(_device_rows(d_reply, (mine.shape[0],)), got, sent, group)
     torch.cuda.current_stream().synchronize()
     table = finish(glob.data_ptr())
@@ -81,7 +118,7 @@ def _exchange_shard(sh, finish, group=None):
 
 def first_pass_sharded(ctx, reads, k: int, min_abundance: int = 0, group=None):
     """k = firstK over reads sharded across the ranks of `group`: this rank's share of the global table."""
-    sh = ctx.shard_begin(reads, k, dist.get_world_size(group))
+    sh = guarded(lambda: ctx.shard_begin(reads, k, dist.get_world_size(group)), "before the exchange", group, "cuda")
     return _exchange_shard(sh, lambda d: sh.finish(d, min_abundance), group)
 
 
@@ -89,18 +126,34 @@ def allgather_records(table, group=None) -> bytes:
     """The 20-byte records of every rank's share, concatenated: the complete table of this k, which every rank loads as the
     previous table of the next (mdbg_prev_from_records).  20 bytes per key: a few hundred MB at 40 M reads."""
     rec, _ = table.to_host()
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, rec.tobytes(), group=group)
-    return b"".join(parts)
+    return allgather_bytes(rec.tobytes(), group)
+
+
+def allgather_bytes(data: bytes, group=None) -> bytes:
+    """Every rank's byte string, concatenated in rank order, as ONE padded tensor all-gather (sizes first) -- not
+    all_gather_object, which pickles hundreds of MB through the host on every rank."""
+    world = dist.get_world_size(group)
+    raw = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+    dev = "cpu" if _staged(group) else "cuda"
+    sizes = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([raw.numel()], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(t.item()) for t in sizes]
+    pad = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=dev)
+    pad[: raw.numel()] = raw.to(dev)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return b"".join(p[:n].cpu().numpy().tobytes() for p, n in zip(parts, sizes))
 
 
 def next_k_sharded(ctx, reads, unitigs, k: int, first_k: int, prev_records: bytes, group=None):
     """k > firstK (graph/CreateMdbg.cpp:391-468) over sharded reads: the ordinary refined / index pass over this rank's reads
     against the complete previous table, then mdbg_shard_from_table -> owners -> mdbg_shard_keep decide who lists the keys
     several ranks found.  `unitigs` (unitig_data.txt sequences, may be None) belong to one rank only."""
-    prev = ctx.prev_from_records(prev_records)
-    local = ctx.kminmer_count_refined(reads, unitigs, k, prev) if k == first_k + 1 else ctx.kminmer_index(reads, unitigs, k, prev)
-    sh = ctx.shard_from_table(local, dist.get_world_size(group))
+    def local_half():
+        prev = ctx.prev_from_records(prev_records)
+        local = ctx.kminmer_count_refined(reads, unitigs, k, prev) if k == first_k + 1 else ctx.kminmer_index(reads, unitigs, k, prev)
+        return prev, local, ctx.shard_from_table(local, dist.get_world_size(group))
+    prev, local, sh = guarded(local_half, "before the exchange", group, "cuda")
     out = _exchange_shard(sh, lambda d: sh.keep(d), group)
     local.free(); prev.free()
     return out

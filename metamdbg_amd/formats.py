@@ -146,17 +146,85 @@ def sorted_vector_records(raw: bytes, k: int) -> np.ndarray:
 
 def build_read_data_init(h: dict) -> bytes:
     """Serialise mdbg_scan output (capi.Minimizers.to_host(full=True)) as ``read_data_init.txt``
-    (readSelection/ReadSelection.hpp:415-467)."""
-    offs = h["offsets"]
-    parts = []
-    mq = np.asarray(h["mean_quality"], dtype="<f4")
-    for r in range(len(offs) - 1):
-        a, b = int(offs[r]), int(offs[r + 1])
-        parts.append(struct.pack("<IB", b - a, 0))
-        parts.append(np.asarray(h["minimizers"][a:b], "<u4").tobytes())
-        parts.append(np.asarray(h["pos"][a:b], "<u4").tobytes())
-        parts.append(np.asarray(h["dir"][a:b], "u1").tobytes())
-        parts.append(np.asarray(h["qual"][a:b], "u1").tobytes())
-        parts.append(mq[r:r + 1].tobytes())
-        parts.append(struct.pack("<I", int(h["read_length"][r])))
-    return b"".join(parts)
+    (readSelection/ReadSelection.hpp:415-467): u32 n; u8 circ; u32 m[n]; u32 pos[n]; u8 dir[n]; u8 qual[n]; f32 meanQ; u32 len."""
+    offs = np.asarray(h["offsets"], dtype=np.int64)
+    n_reads = len(offs) - 1
+    cnt = np.diff(offs)
+    total = int(offs[-1])
+    start = 13 * np.arange(n_reads, dtype=np.int64) + 10 * offs[:-1]            # first byte of every record
+    out = np.zeros(13 * n_reads + 10 * total, dtype=np.uint8)
+
+    def put_u32(at, v):
+        v = np.asarray(v).astype(np.uint32)
+        for b in range(4):
+            out[at + b] = ((v >> np.uint32(8 * b)) & np.uint32(255)).astype(np.uint8)
+
+    put_u32(start, cnt)                                                          # circ byte stays 0
+    if total:
+        rd = np.repeat(np.arange(n_reads, dtype=np.int64), cnt)                  # read of every minimizer
+        j = np.arange(total, dtype=np.int64) - offs[rd]                          # its index inside the read
+        base, n_of = start[rd] + 5, cnt[rd]
+        put_u32(base + 4 * j, h["minimizers"])
+        put_u32(base + 4 * n_of + 4 * j, h["pos"])
+        out[base + 8 * n_of + j] = np.asarray(h["dir"], dtype=np.uint8)
+        out[base + 9 * n_of + j] = np.asarray(h["qual"], dtype=np.uint8)
+    tail = start + 5 + 10 * cnt
+    put_u32(tail, np.asarray(h["mean_quality"], dtype="<f4").view("<u4"))
+    put_u32(tail + 4, h["read_length"])
+    return out.tobytes()
+
+
+# ---- order-independent digests (tests/golden/hifi_1m: tables of a million reads are compared through these) ----
+def _sha(a: np.ndarray) -> str:
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def minimizer_reads_digest(mins: np.ndarray, offs: np.ndarray) -> str:
+    """Digest of a multiset of minimizer-space reads (``read_data_corrected.txt``: the reference writes its records in thread
+    order): one 64-bit hash per read over (length, values in order), the hashes sorted, sha256 of that."""
+    return _sha(np.sort(_read_hashes(mins, offs)))
+
+
+def _read_hashes(mins: np.ndarray, offs: np.ndarray) -> np.ndarray:
+    offs = np.asarray(offs, dtype=np.int64)
+    cnt = np.diff(offs)
+    m = np.asarray(mins).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        h = cnt.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        if len(m):
+            rd = np.repeat(np.arange(len(cnt), dtype=np.int64), cnt)
+            j = (np.arange(len(m), dtype=np.int64) - offs[rd]).astype(np.uint64)
+            w = (j + np.uint64(1)) * np.uint64(0xD6E8FEB86659FD93)
+            w ^= w >> np.uint64(32)
+            w = w * np.uint64(0xD6E8FEB86659FD93) | np.uint64(1)
+            np.add.at(h, rd, (m + np.uint64(0x632BE59BD9B4E019)) * w)
+    return h
+
+
+def minimizer_reads_equal_as_multisets(m1, o1, m2, o2) -> bool:
+    """Exact comparison of two sets of minimizer-space reads as multisets of reads (the reference writes
+    read_data_corrected.txt in thread order): both are put in the order of a per-read hash and compared value for value."""
+    o1, o2 = np.asarray(o1, dtype=np.int64), np.asarray(o2, dtype=np.int64)
+    if len(o1) != len(o2) or int(o1[-1]) != int(o2[-1]):
+        return False
+
+    def ordered(m, o):
+        h = _read_hashes(m, o)
+        order = np.argsort(h, kind="stable")
+        cnt = np.diff(o)[order]
+        start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        idx = np.repeat(o[:-1][order] - start, cnt) + np.arange(int(cnt.sum()), dtype=np.int64)
+        return h[order], cnt, np.asarray(m)[idx]
+    h1, c1, v1 = ordered(m1, o1)
+    h2, c2, v2 = ordered(m2, o2)
+    return bool(np.array_equal(h1, h2) and np.array_equal(c1, c2) and np.array_equal(v1, v2))
+
+
+def table_digests(records, vectors, k: int) -> dict:
+    """sha256 of the canonical (sorted) forms of ``kminmerData_abundance.txt`` / ``kminmerData_min.txt``."""
+    out = {"abundance_sorted_sha256": _sha(sorted_abundance_records(records))}
+    if vectors is not None:
+        raw = vectors if isinstance(vectors, (bytes, bytearray)) else np.asarray(vectors, dtype="<u4").tobytes()
+        out["min_sorted_sha256"] = _sha(sorted_vector_records(raw, k))
+    return out

@@ -16,6 +16,7 @@
 // All compute goes through libmdbg_hip.so; there is no CPU fallback.
 #include <sys/resource.h>
 #include <sys/time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -41,9 +42,13 @@
 
 namespace {
 
+// _exit, not exit: with --gpus G a failing rank thread ends the process while its peers may sit inside an RCCL collective
+// waiting for it; exit() would run the static destructors of HIP / RCCL under them and can hang, and the parent
+// (Utils::executeCommand, Commons.hpp:2855) only needs the non-zero status.  Output files are flushed as they are written.
 [[noreturn]] void die(const std::string &msg) {
     fprintf(stderr, "mdbg_tool: %s\n", msg.c_str());
-    exit(1);
+    fflush(nullptr);
+    _exit(1);
 }
 
 mdbg_ctx *g_ctx = nullptr;
@@ -151,6 +156,7 @@ struct Args {
     uint32_t minAbundance = 0;
     size_t batchBases = (size_t)32 << 20;  // bytes of input per device batch (not a reference flag)
     int gpus = 1;                          // contexts / devices the work is spread over (not a reference flag)
+    bool verify = true;                    // graph --gpus G: rank 0 repeats the pass alone and the job compares (not a reference flag)
 };
 Args parse_args(int argc, char **argv, int first) {
     Args a;
@@ -165,6 +171,8 @@ Args parse_args(int argc, char **argv, int first) {
         else if (s == "--firstpass") a.firstPass = true;
         else if (s == "--batch-bases") a.batchBases = (size_t)atoll(val().c_str());
         else if (s == "--gpus") a.gpus = std::max(1, std::min(64, atoi(val().c_str())));
+        else if (s == "--no-verify") a.verify = false;
+        else if (s == "--verify") a.verify = true;
         else if (s.rfind("--", 0) == 0) die("unknown flag " + s);
         else a.pos.push_back(s);
     }
@@ -538,6 +546,7 @@ struct RankTable {
     std::vector<uint32_t> vec;
     uint64_t n = 0, nSolid = 0;
     int hasVec = 0;
+    uint64_t sums[4] = {0, 0, 0, 0};  // mdbg_table_checksum of the share: [0] is the "Checksum kminmer abundance" the reference logs
     std::string smallContigs;        // records for smallContigs_k<k>.bin (the rank that holds unitig_data.txt)
 };
 
@@ -545,7 +554,7 @@ struct RankTable {
 // across the ranks (include/mdbg_hip.h "the exchange inside the library") and `out` is this rank's share of it.
 // unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
 void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const std::vector<uint32_t> &mins,
-                const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out) {
+                const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
     mdbg_minimizers *reads = nullptr;
@@ -599,16 +608,19 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
         mdbg_table_free(prev);
     }
     mdbg_table_info(table, nullptr, &out.n, &out.nSolid, &out.hasVec);
-    out.rec.resize(out.n * 20);
-    out.vec.resize(out.hasVec ? out.n * k : 0);
-    check_on(ctx, mdbg_table_to_host(ctx, table, out.rec.data(), out.hasVec ? out.vec.data() : nullptr), "mdbg_table_to_host");
+    check_on(ctx, mdbg_table_checksum(ctx, table, out.sums), "mdbg_table_checksum");
+    if (rowsToHost) {
+        out.rec.resize(out.n * 20);
+        out.vec.resize(out.hasVec ? out.n * k : 0);
+        check_on(ctx, mdbg_table_to_host(ctx, table, out.rec.data(), out.hasVec ? out.vec.data() : nullptr), "mdbg_table_to_host");
+    }
     mdbg_table_free(table);
     mdbg_minimizers_free(reads);
 }
 
 int run_graph(int argc, char **argv) {
     Args a = parse_args(argc, argv, 2);
-    if (a.pos.size() != 1) die("usage: mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass] [--gpus G]");
+    if (a.pos.size() != 1) die("usage: mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass] [--gpus G [--no-verify]]");
     const std::string dir = a.pos[0];
     Parameters P;
     P.load(dir + "/parameters.gz");
@@ -653,9 +665,30 @@ int run_graph(int argc, char **argv) {
         g_ctx = ctxs[0];
         for (int r = 1; r < G; r++) mdbg_destroy(ctxs[(size_t)r]);
     }
-    uint64_t n = 0, nSolid = 0;
-    int hasVec = parts[0].hasVec;
-    for (const RankTable &t : parts) { n += t.n; nSolid += t.nSolid; small.write(t.smallContigs.data(), (std::streamsize)t.smallContigs.size()); }
+    uint64_t n = 0, nSolid = 0, sums[4] = {0, 0, 0, 0};
+    int hasVec = 0;                  // any rank's view: a rank without reads (G > reads) still reports the table's kind, but do not rely on it
+    for (const RankTable &t : parts) {
+        n += t.n; nSolid += t.nSolid; hasVec |= t.hasVec;
+        for (int i = 0; i < 4; i++) sums[i] += t.sums[i];
+        small.write(t.smallContigs.data(), (std::streamsize)t.smallContigs.size());
+    }
+    // the line the reference itself logs when it loads this table again at the next k (graph/CreateMdbg.cpp:3321, :3397)
+    g_log.line("\tChecksum kminmer abundance: " + std::to_string(sums[0]));
+    if (sharded && a.verify) {
+        // The job checks itself: rank 0 repeats the pass alone over all the reads, and record count, solid count and the four
+        // order-independent sums of the table (mdbg_table_checksum) must equal the sums over the ranks' shares -- the union of the
+        // shares IS the single-GPU table.  A wrong exchange (a lost row, a count summed twice, two listers for one key) fails here,
+        // in the run that produced it.  --no-verify skips it.
+        RankTable whole;
+        graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, whole, false);
+        const bool same = whole.n == n && whole.nSolid == nSolid && whole.sums[0] == sums[0] && whole.sums[1] == sums[1] &&
+                          whole.sums[2] == sums[2] && whole.sums[3] == sums[3];
+        const std::string what = "records " + std::to_string(n) + " / " + std::to_string(whole.n) + ", solid " + std::to_string(nSolid) + " / " +
+                                 std::to_string(whole.nSolid) + ", checksum " + std::to_string(sums[0]) + " / " + std::to_string(whole.sums[0]);
+        g_log.line(std::string("\tSelf-check of the ") + std::to_string(G) + "-rank table against the single-GPU pass: " + (same ? "ok" : "FAILED") + " (" + what + ")");
+        if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg_tool] self-check %s: %s\n", same ? "ok" : "FAILED", what.c_str());
+        if (!same) die("graph --gpus " + std::to_string(G) + ": the sharded table differs from the single-GPU pass (" + what + ")");
+    }
     if (a.firstPass) {   // the two counts the reference logs after its first pass (graph/CreateMdbg.cpp:300-328)
         g_log.line("\tNb solid kminmers: " + std::to_string(nSolid));
         g_log.line("\tNb rescued kminmers: " + std::to_string(n - nSolid));

@@ -105,6 +105,20 @@ def murmur128(data: bytes, seed: int = 0) -> tuple[int, int]:
     return out[0], out[1]
 
 
+def minimizer_parse(seq: bytes, K: int, density: float, hpc: bool, trim: int = 1, repetitive=None):
+    """EncoderRLE + MinimizerParser::parse with an explicit _trimBps: (values, positions, directions) as lists."""
+    L = lib()
+    L.orc_minimizer_parse_trim.restype = C.c_size_t
+    rle = C.create_string_buffer(len(seq) + 2)
+    rpos = (C.c_uint64 * (len(seq) + 2))()
+    hl = L.orc_hpc_encode(seq, C.c_size_t(len(seq)), int(hpc), rle, rpos)
+    rep = np.ascontiguousarray(repetitive if repetitive is not None else [], dtype=np.uint32)
+    om = (C.c_uint32 * max(hl, 1))(); op = (C.c_uint32 * max(hl, 1))(); od = (C.c_uint8 * max(hl, 1))()
+    n = L.orc_minimizer_parse_trim(rle, C.c_size_t(hl), K, C.c_float(density), rep.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   C.c_size_t(len(rep)), C.c_size_t(trim), om, op, od)
+    return list(om[:n]), list(op[:n]), list(od[:n])
+
+
 def correction_scan(seq: bytes, qual: bytes | None, K: int = 13, density: float = 0.025, hpc: bool = False,
                     repetitive=None) -> dict:
     """One read -> what ReadCorrection::ReadSelectionFunctor hands to its record sink."""

@@ -118,6 +118,42 @@ def make_hifi(work: str) -> None:
         K=15, density=0.005, hpc=True, k=4, min_abundance=0))
 
 
+def make_hifi_1m(work: str, threads: int = 8) -> None:
+    """BASELINE.json configs[1] at its stated size: 1 M synthetic HiFi reads x 10 kb (50x over the metagenome of
+    synth.hifi_spec), readSelection + graph --firstpass by the reference's own code.  10 Gbp of FASTA and 400 MB of products
+    do not go into the repository: only their digests do (sha256 of read_data_init.txt -- it is written in read order whatever
+    the thread count --, order-independent digests of the files the reference writes in thread order: formats.
+    minimizer_reads_digest, formats.table_digests) together with the counts and the checksum the reference logs.  The reads
+    are regenerated from the seed (on the device, bit-identical: tests/test_gpu_parity.py::test_hifi_1m_digests)."""
+    spec = synth.hifi_spec(1_000_000, seed=42, read_len=10_000, coverage=50.0)
+    fasta = os.path.join(work, "hifi_1m.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                last_k=0, hpc=True, data_type=0)
+    tmp = run_ref_pipeline(os.path.join(work, "hifi_1m"), fasta, params, threads=threads)
+    # a second graph --firstpass run in the directory of the next k loads the table again and logs its checksum; here the
+    # checksum is computed from the records with the formula of graph/CreateMdbg.cpp:3321 (abundance * hash, low 64 bits)
+    rec = formats.parse_abundance_table(open(os.path.join(tmp, "kminmerData_abundance.txt"), "rb").read())
+    with np.errstate(over="ignore"):
+        checksum = int((rec["abundance"].astype(np.uint64) * rec["lo"]).sum(dtype=np.uint64))
+    cm, co = formats.parse_minimizer_reads(open(os.path.join(tmp, "read_data_corrected.txt"), "rb").read())
+    manifest = dict(
+        kind="hifi", config="BASELINE.json configs[1]", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed,
+        sub_rate=spec.sub_rate, species_len=spec.species_len, species_weight=spec.species_weight, fasta_sha256=sha256(fasta),
+        K=15, density=0.005, hpc=True, k=4, min_abundance=0, reference_threads=threads,
+        read_data_init_sha256=sha256(os.path.join(tmp, "read_data_init.txt")),
+        read_data_init_bytes=os.path.getsize(os.path.join(tmp, "read_data_init.txt")),
+        read_stats_hex=open(os.path.join(tmp, "read_stats.txt"), "rb").read().hex(),
+        read_data_corrected_digest=formats.minimizer_reads_digest(cm, co), n_corrected_minimizers=int(len(cm)),
+        n_records=int(len(rec)), abundance_checksum=checksum, sum_abundance=int(rec["abundance"].astype(np.uint64).sum()),
+        reference_log=log_known_answers(tmp),
+        **formats.table_digests(rec, open(os.path.join(tmp, "kminmerData_min.txt"), "rb").read(), 4))
+    dst = os.path.join(HERE, "hifi_1m")
+    os.makedirs(dst, exist_ok=True)
+    with open(os.path.join(dst, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
 def make_ont(work: str) -> None:
     # SURVEY 8(d) ONT R10 error model: 1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred 10..39
     spec = synth.SynthSpec(n_reads=100, read_len=20_000, seed=11, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
@@ -461,6 +497,29 @@ def make_fn() -> None:
         for K, dens in ((15, 0.05), (16, 0.05), (11, 0.1)):
             out["scan_case"][f"K{K}_hpc{hpc}"] = dict(K=K, density=dens, hpc=hpc, inputs=cases,
                                                       outputs=refdrv_lines(["fn_scan", str(K), str(dens), str(hpc)], cases))
+    # _trimBps = 0 at the device kernel's block borders: compressed lengths 2048*b + K + {-1, 0, 1}, at a
+    # density low enough for the reads to stay in the block kernel's row stage (own generator: the cases above stay as they were)
+    rng4 = np.random.default_rng(20260928)
+
+    def no_runs(n):          # n bases, no two neighbours equal
+        c = np.empty(n, dtype=np.int64)
+        c[0] = rng4.integers(0, 4)
+        c[1:] = rng4.integers(1, 4, n - 1)
+        return np.cumsum(c) % 4
+
+    def with_compressed_length(n, hpc):
+        codes = no_runs(n)
+        if hpc:
+            codes = np.repeat(codes, rng4.choice([1, 1, 1, 2, 3], n))
+        return bytes(synth.CODE2ASCII[codes]).decode()
+
+    out["scan_notrim_block"] = {}
+    for hpc in (0, 1):
+        for K, dens in ((15, 0.05), (16, 0.05), (11, 0.04)):
+            breads = [with_compressed_length(2048 * b + K + d, hpc) for b in (1, 2, 3) for d in (-1, 0, 1)]
+            out["scan_notrim_block"][f"K{K}_hpc{hpc}"] = dict(
+                K=K, density=dens, hpc=hpc, inputs=breads,
+                outputs=refdrv_lines(["fn_scan_notrim", str(K), str(dens), str(hpc)], breads))
     with open(os.path.join(dst, "fn_golden.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
 
@@ -470,8 +529,12 @@ def main() -> None:
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
     work = tempfile.mkdtemp(prefix="mdbg_golden_")
     try:
-        make_fn()
+        if "--only-1m" not in sys.argv:
+            make_fn()
         if "--only-fn" in sys.argv:
+            return
+        if "--only-1m" in sys.argv:      # minutes of CPU and 10 GB of scratch: not part of the default regeneration
+            make_hifi_1m(work)
             return
         if "--only-multik" in sys.argv:
             make_multik(work)

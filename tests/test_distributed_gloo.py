@@ -147,9 +147,7 @@ def _worker_next_k(rank, world, port, q):
         kept = sent[(glob >> np.uint64(63)) == 1]
         mine_rec = np.zeros(len(kept), dtype=formats.ABUNDANCE_DTYPE)
         mine_rec["lo"], mine_rec["hi"], mine_rec["abundance"] = kept[:, 0], kept[:, 1], kept[:, 2].astype(np.uint32)
-        parts = [None] * world
-        dist.all_gather_object(parts, mine_rec.tobytes())
-        records = b"".join(parts)                              # the complete table of this k on every rank
+        records = D.allgather_bytes(mine_rec.tobytes())        # the complete table of this k on every rank
         # expected: the single-rank pass over all the reads, previous table = the single-rank table of k - 1
         if k == 5:
             exp_prev = orc.table_abundance_records(orc.kminmer_count_first(mins, offs, 4, 0)).tobytes()
@@ -183,3 +181,64 @@ def test_next_k_dedup_by_owner_world2():
         local0, kept0, exp = res[0][2][i]
         local1, kept1, _ = res[1][2][i]
         assert exp > 20 and kept0 + kept1 == exp and local0 + local1 > exp, res     # overlapping keys, each listed once
+
+
+# ---- failure behaviour of the exchange protocol (include/mdbg_hip.h "Failure behaviour of the collective calls"; the library runs
+# the same agreement over RCCL inside mdbg_shard_exchange, metamdbg_amd/distributed.py over torch.distributed) ----
+def _worker_failures(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from metamdbg_amd import distributed as D
+
+    class LocalError(RuntimeError):
+        code = -3
+
+    seen = []
+    for phase, failing in (("before the exchange", 1), ("summing the rows it owns", 0), ("before the exchange", None)):
+        def local_step():
+            if failing == rank:
+                raise LocalError("local failure")
+            return 7
+        try:
+            D.guarded(local_step, phase)
+            seen.append("ok")
+        except D.PeerFailure as pf:
+            seen.append(("peer", pf.rank, pf.code, pf.phase))
+        except LocalError:
+            seen.append("local")
+        # whoever failed, both ranks are in step again: a full exchange works afterwards
+        rows = torch.arange(6, dtype=torch.int64).reshape(2, 3) + 100 * rank
+        mine, got = D.exchange_by_owner(rows, [1, 1])
+        back = D.reply_to_senders(mine[:, 0].contiguous(), got, [1, 1])
+        seen.append(back.tolist())
+    # the padded byte all-gather with unequal and empty parts
+    joined = D.allgather_bytes(b"" if rank == 0 else b"xyz" * 5)
+    q.put((rank, seen, joined))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_local_failures_reach_the_peers_world2():
+    """A rank that fails in a local step between two transfers announces it (agree / guarded): it re-raises its own error, the
+    other rank gets PeerFailure naming it, nobody waits in the next all-to-all, and the following exchange works."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_failures, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=120) for _ in procs))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = res[0][0], res[1][0]
+    assert s0[0] == ("peer", 1, -3, "before the exchange") and s1[0] == "local"
+    assert s0[2] == "local" and s1[2] == ("peer", 0, -3, "summing the rows it owns")
+    assert s0[4] == "ok" and s1[4] == "ok"
+    for i in (1, 3, 5):                 # the exchanges in between: each rank gets back the first word of the rows it sent
+        assert s0[i] == [0, 3] and s1[i] == [100, 103]
+    assert res[0][1] == res[1][1] == b"xyz" * 5

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_env: dict, args: list[str], nproc: int | None) -> dict:
+def _bench(extra_env: dict, args: list[str], nproc: int | None, expect_failure: bool = False) -> dict:
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable]
     if nproc:
@@ -27,7 +27,7 @@ def _bench(extra_env: dict, args: list[str], nproc: int | None) -> dict:
                 "--master-port", str(port)]
     cmd += [os.path.join(ROOT, "bench.py")] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert (out.returncode != 0) == expect_failure, out.stderr[-2000:]
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
 
@@ -40,6 +40,24 @@ def test_two_ranks_equal_one(in_flight):
     assert two["n_gpus"] == 2
     assert two["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
     assert two["config"]["solid"] == one["config"]["solid"] > 0
+    # the N > 1 line checks itself: rank 0 repeats the pass alone over all the reads and compares with the summed shares
+    par = two["parity"]
+    assert par["table_equal"] and par["reads"] == 2 * n and par["records_equal"] and par["abundance_checksum_equal"]
+    assert par["single_gpu"]["records"] == one["config"]["kminmer_records"]
+    ex = two["config"]["exchange"]
+    assert ex["ranks"] == 2 and ex["wire_bytes_per_step"] > 0 and ex["exchanges_timed"] == 2 * 3 and ex["exchange_ms_per_step"] > 0
+
+
+def test_two_ranks_with_a_corrupted_reply_fail_the_run():
+    """MDBG_BENCH_CORRUPT_REPLY=1: one global count of the verification step is off by one on the last rank -- the line still comes
+    out, its parity block says the tables do not add up, and the run exits non-zero."""
+    n = 40_000
+    common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "2"]
+    two = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_CORRUPT_REPLY": "1"},
+                 ["--gpus", "2", "--reads", str(n)] + common, 2, expect_failure=True)
+    par = two["parity"]
+    assert not par["table_equal"] and par["minimizers_equal"]
+    assert not (par["abundance_checksum_equal"] and par["sum_abundance_equal"] and par["solid_equal"] and par["records_equal"])
 
 
 def test_library_rccl_exchange_two_gpus(tmp_path):

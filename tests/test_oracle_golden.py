@@ -95,7 +95,7 @@ def test_scan_without_end_trim(fn_golden):
     L = orc.lib()
     L.orc_minimizer_parse_trim.restype = C.c_size_t
     n_end = 0
-    for key, g in fn_golden["scan_notrim"].items():
+    for key, g in list(fn_golden["scan_notrim"].items()) + list(fn_golden["scan_notrim_block"].items()):
         for seq, out in zip(g["inputs"], g["outputs"]):
             toks = out.split()
             exp = [tuple(int(x) for x in t.split(":")) for t in toks[2:]]
