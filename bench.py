@@ -55,7 +55,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="reads of the CPU-baseline / parity read set, a HiFi set of its own at 50x (1 M = BASELINE.json configs[1]; 0 = skip)")
     ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,pcie,ont ('all', 'none')")
-    ap.add_argument("--ont-reads", type=int, default=5_000_000, help="reads (20 kb, with qualities) of the ont leg")
+    ap.add_argument("--ont-reads", type=int, default=10_000_000, help="reads (20 kb, with qualities) of the ont leg: BASELINE.json configs[3]")
+    ap.add_argument("--ont-sample", type=int, default=100_000, help="reads of the ont leg's parity sample against the reference")
     a = ap.parse_args()
     if a.reads <= 0:
         a.reads = 10_000_000 if a.gpus <= 1 else 5_000_000
@@ -134,15 +135,21 @@ def _tables_equal(tmp_a: str, tmp_b: str, k: int) -> bool:
                                formats.sorted_vector_records(_fbytes(tmp_b, "kminmerData_min.txt"), k)))
 
 
-def _write_fasta_from_device(path: str, reads, n_reads: int, chunk: int = 50_000) -> int:
-    """The resident reads as a FASTA file (">r<index>" + one line), exported from HBM in pieces; returns the bases written."""
+def _write_fasta_from_device(path: str, reads, n_reads: int, chunk: int = 50_000, with_quality: bool = False) -> int:
+    """The resident reads as a FASTA file (">r<index>" + one line) or, with their qualities, as FASTQ, exported from HBM in pieces;
+    returns the bases written."""
     nbases = 0
     with open(path, "wb") as f:
         for r0 in range(0, n_reads, chunk):
             n = min(chunk, n_reads - r0)
             bases, offs = reads.export_ascii(r0, n)
             nbases += int(offs[n])
-            f.write(b"".join(b">r%d\n%s\n" % (r0 + r, bases[int(offs[r]): int(offs[r + 1])].tobytes()) for r in range(n)))
+            if with_quality:
+                q = reads.export_qualities(r0, n)
+                f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (r0 + r, bases[int(offs[r]): int(offs[r + 1])].tobytes(),
+                                                          q[int(offs[r]): int(offs[r + 1])].tobytes()) for r in range(n)))
+            else:
+                f.write(b"".join(b">r%d\n%s\n" % (r0 + r, bases[int(offs[r]): int(offs[r + 1])].tobytes()) for r in range(n)))
     return nbases
 
 
@@ -402,40 +409,56 @@ def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int =
     return res
 
 
-def ont_leg(ctx, n_reads: int, sample: int) -> dict:
-    """BASELINE.json configs[3] preset: 20 kb reads with qualities (1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred
-    10..39), no HPC, l = 15, density 0.005, repetitive-minimizer filter from the census of the first 1,000,000 reads at
-    density 0.025 (nanoMDBG parameters: pipeline/AssemblyPipeline.hpp:309-325, ReadSelection.hpp:497-561), --skip-correction
-    path: purge + k = 4 table.  configs[3] names 10 M reads; with qualities they take 250 GB, so the leg runs on the largest
-    power-of-ten-ish resident set that leaves room for the outputs."""
+def ont_leg(ctx, n_reads: int, sample: int, piece_reads: int = 5_000_000) -> dict:
+    """BASELINE.json configs[3]: 10 M synthetic ONT R10 reads x 20 kb with qualities (1 % substitutions + 0.5 % insertions + 0.5 %
+    deletions, phred 10..39), no HPC, l = 15, density 0.005, repetitive-minimizer filter from the census of the first 1,000,001
+    reads at density 0.025 (nanoMDBG parameters: pipeline/AssemblyPipeline.hpp:309-325, ReadSelection.hpp:497-561, :508-510),
+    --skip-correction path: purge + k = 4 table over ALL the reads.  With their qualities 10 M reads are 250 GB, so they are
+    resident in pieces of `piece_reads` (5 M = 125 GB) one after the other, each scanned as it sits in HBM; the pieces'
+    minimizers (10 bytes each) are appended on the device (mdbg_minimizers_concat) and purge + table run once over the whole
+    set.  The time is the sum of the path's parts (census, scans, concat + purge + table); producing the next piece of synthetic
+    input in between is not part of it (`generate_s`)."""
     import numpy as np
     from metamdbg_amd import formats, synth
     spec = synth.ont_spec(n_reads, seed=43, read_len=20_000, coverage=50.0)
-    t0 = time.perf_counter()
-    reads = ctx.reads_synthetic(spec)
-    ctx.synchronize()
-    gen_s = time.perf_counter() - t0
-    n_bases = reads.info()["n_bases"]
+    pieces = [(f, min(piece_reads, n_reads - f)) for f in range(0, n_reads, piece_reads)]
     n_census = min(n_reads, 1_000_001)
-    head = reads if n_census == n_reads else ctx.reads_synthetic(spec, first_read=0, n_reads=n_census)
+    assert n_census <= pieces[0][1] or len(pieces) == 1
 
     def one_pass():
+        r = {"census_ms": 0.0, "scan_ms": 0.0, "generate_s": 0.0}
+        outs, rep, n_bases = [], None, 0
+        for first, n in pieces:
+            t0 = time.perf_counter()
+            reads = ctx.reads_synthetic(spec, first_read=first, n_reads=n)
+            ctx.synchronize()
+            r["generate_s"] += time.perf_counter() - t0
+            n_bases += reads.info()["n_bases"]
+            if rep is None:          # the census: the first 1,000,001 reads at the correction density, no filters, qualities ignored
+                head = reads if n_census == n else ctx.reads_synthetic(spec, first_read=0, n_reads=n_census)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                pre = ctx.scan(head, K=K_MINIMIZER, density=0.025, hpc=False, apply_read_filters=False, ignore_qualities=True)
+                rep = ctx.repetitive_minimizers(pre)
+                pre.free()
+                r["census_ms"] = (time.perf_counter() - t0) * 1e3
+                if head is not reads:
+                    head.free()
+            t0 = time.perf_counter()
+            outs.append(ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep))
+            ctx.synchronize()
+            r["scan_ms"] += (time.perf_counter() - t0) * 1e3
+            reads.free()
         t0 = time.perf_counter()
-        pre = ctx.scan(head, K=K_MINIMIZER, density=0.025, hpc=False, apply_read_filters=False, ignore_qualities=True)
-        rep = ctx.repetitive_minimizers(pre)
-        pre.free()
-        t1 = time.perf_counter()
-        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep)
-        ctx.synchronize()
-        t2 = time.perf_counter()
+        mins = outs[0] if len(outs) == 1 else ctx.minimizers_concat(outs)
         corr = ctx.purge_palindromes(mins, 4, 100)
         table = ctx.kminmer_count_first(corr, KMINMER, 0)
         ctx.synchronize()
-        t3 = time.perf_counter()
-        r = {"seconds": t3 - t0, "gbps": n_bases / 1e9 / (t3 - t0), "census_ms": (t1 - t0) * 1e3, "scan_ms": (t2 - t1) * 1e3,
-             "purge_table_ms": (t3 - t2) * 1e3, "repetitive": int(len(rep)), "minimizers": int(mins.info()["n_minimizers"]),
-             "kminmer_records": int(table.info()["n_records"]), "solid": int(table.info()["n_solid"])}
-        for o in (table, corr, mins):
+        r["purge_table_ms"] = (time.perf_counter() - t0) * 1e3
+        r["seconds"] = (r["census_ms"] + r["scan_ms"] + r["purge_table_ms"]) / 1e3
+        r.update(gbps=n_bases / 1e9 / r["seconds"], bases=n_bases, repetitive=int(len(rep)), minimizers=int(mins.info()["n_minimizers"]),
+                 kminmer_records=int(table.info()["n_records"]), solid=int(table.info()["n_solid"]), abundance_checksum=table.checksum()[0])
+        for o in [table, corr, mins] + (outs if len(outs) > 1 else []):
             o.free()
         return r
     one_pass()
@@ -445,29 +468,32 @@ def ont_leg(ctx, n_reads: int, sample: int) -> dict:
     r["kernel_ms"] = {k: ctx.timing_get(k)[0] for k in ("scan", "quality_sum", "scan_compact", "complexity_exact", "minimizer_census",
                                                       "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit",
                                                       "table_clear", "prefix_scan") if ctx.timing_get(k)[1]}
-    r["workload"] = (f"{n_reads} synthetic ONT R10 reads x 20 kb with qualities ({n_bases / 1e9:.0f} Gbp; 1 % sub + 0.5 % ins + 0.5 % del), "
-                     "resident in HBM (2-bit bases + 1 byte per quality), no HPC, l=15, density 0.005, repetitive filter from the "
-                     f"0.025 census of the first {n_census} reads, purge + k=4 table (--skip-correction path)")
-    r["generate_s"] = gen_s
-    if head is not reads:
-        head.free()
-    reads.free()
-    # parity on a small sample against the reference's own run (qualities, mean read quality, repetitive filter pinned to
-    # the reference's pick: which of several equally frequent minimizers std::sort leaves first is not defined)
+    r["workload"] = (f"{n_reads} synthetic ONT R10 reads x 20 kb with qualities ({r['bases'] / 1e9:.0f} Gbp; 1 % sub + 0.5 % ins + 0.5 % del), "
+                     f"resident in HBM {len(pieces)} x {pieces[0][1]} reads at a time (2-bit bases + 1 byte per quality), no HPC, l=15, density 0.005, "
+                     f"repetitive filter from the 0.025 census of the first {n_census} reads, minimizers of the pieces appended on the device, "
+                     "purge + k=4 table over all the reads (--skip-correction path)")
+    r["pieces"] = len(pieces)
+    # parity on a sample against the reference's own run (qualities, mean read quality, repetitive filter pinned to
+    # the reference's pick: which of several equally frequent minimizers std::sort leaves first is not defined); the sample is
+    # scanned in two pieces and appended, like the leg
     if sample > 0 and os.path.exists(REFDRV):
         work = tempfile.mkdtemp(prefix="mdbg_ont_")
         try:
             sspec = synth.SynthSpec(**{**spec.__dict__, "n_reads": sample})
             fq = os.path.join(work, "ont.fastq")
-            synth.write_fasta(fq, sspec)
+            whole = ctx.reads_synthetic(sspec)           # written from the device: the host generator makes 15 MB/s of it
+            _write_fasta_from_device(fq, whole, sample, chunk=20_000, with_quality=True)
+            whole.free()
             P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
                                    hpc=False, data_type=1, correction_density=0.025)
             t_ref = _make_tmp(work, "ref", P, [fq])
             cores = min(os.cpu_count() or 1, 32)
-            tr = _run_two_commands(REFDRV, t_ref, cores, extra_rs=["--skip-correction"])
+            tr = _run_two_commands(REFDRV, t_ref, cores, extra_rs=["--skip-correction"], stop_after_tables=sample > 20_000)
             rep_ref = np.frombuffer(_fbytes(t_ref, "repetitiveMinimizers.bin"), "<u4")
-            sub = ctx.reads_synthetic(sspec)
-            mins = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep_ref)
+            cut = sample // 2
+            halves = [ctx.scan(ctx.reads_synthetic(sspec, first_read=f, n_reads=n), K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep_ref)
+                      for f, n in ((0, cut), (cut, sample - cut))]
+            mins = ctx.minimizers_concat(halves)
             init_equal = formats.build_read_data_init(mins.to_host()) == _fbytes(t_ref, "read_data_init.txt")
             st = formats.parse_read_stats(_fbytes(t_ref, "read_stats.txt"))
             last_k = max(int(np.float32(st["n50"]) * np.float32(DENSITY) * np.float32(2)), 6)      # Commons::computeLastK (Commons.hpp:1726-1741)
@@ -480,6 +506,7 @@ def ont_leg(ctx, n_reads: int, sample: int) -> dict:
             nb = sample * 20_000
             path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
             r["parity"] = {"reads": sample, "init_bytes_equal": bool(init_equal), "table_multiset_equal": table_equal,
+                           "kminmer_records": int(len(rec)),
                            "against": "oracle/_ref/refdrv on the same reads as FASTQ, --skip-correction, this run"}
             r["cpu_reference"] = {"gbps_path_only": nb / 1e9 / path, "cores": cores, "read_selection_s": tr["read_selection_s"],
                                   "tables_s": tr["tables_s"], "sample_gbp": nb / 1e9}
@@ -972,7 +999,7 @@ def main() -> None:
             reads.free()
             ctx.close()
             octx = capi.Context(local_rank)
-            legs["ont"] = ont_leg(octx, args.ont_reads, sample=min(10_000, args.cpu_sample))
+            legs["ont"] = ont_leg(octx, args.ont_reads, sample=min(args.ont_sample, args.cpu_sample))
             octx.close()
         total_bases = n_bases * world * args.steps
         traffic, traffic_note = measured_traffic(args.reads, args.read_len)

@@ -109,6 +109,9 @@ int  mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *ba
  * call with bases == NULL to size it: *n_bytes is always set). */
 int  mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t first, uint32_t count,
                              char *bases, uint64_t *offsets, uint64_t *n_bytes);
+/* The phred+33 bytes of reads [first, first+count), concatenated in read order (same offsets as mdbg_reads_export_ascii gives
+ * for the bases: a read has one quality per base); *n_bytes is always set, quals may be NULL to size the buffer. */
+int  mdbg_reads_export_qualities(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t first, uint32_t count, char *quals, uint64_t *n_bytes);
 void mdbg_reads_free(mdbg_reads *r);
 
 /* ---- reads -> minimizers --------------------------------------------------------------- */
@@ -154,6 +157,12 @@ int  mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimizers, const 
 /* Device pointers for zero-copy consumers (torch.from_dlpack-style wrapping in the harness). */
 int  mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers);
 void mdbg_minimizers_free(mdbg_minimizers *m);
+/* The reads of `parts[0]`, then `parts[1]`, ... as one set, appended on the device (CSR offsets rebased; positions, directions,
+ * qualities and the per-read fields follow when every part is a scan output).  For read sets scanned in several resident
+ * pieces -- 10 M ONT reads with their qualities are 250 GB, more than fits beside their outputs -- whose palindrome purge and
+ * k-min-mer table are over ALL the reads: the reference counts k-min-mers over the whole read_data_corrected.txt however the
+ * reads were parsed (graph/CreateMdbg.cpp:290-328).  The parts stay valid and are not modified. */
+int  mdbg_minimizers_concat(mdbg_ctx *ctx, const mdbg_minimizers *const *parts, uint32_t n_parts, mdbg_minimizers **out);
 
 /* Replaces Utils::applyDensityThreshold over every read (Commons.hpp:2507-2550; callers ReadCorrection.hpp:6385, :6435,
  * Commons.hpp:2563 getLowDensityMinimizerRead, :7252-7742 the minimizer-read parsers): keeps the minimizers whose

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mdbg_reads_info": (C.c_int, [_P, _u32p, _u64p, _u64p]),
     "mdbg_reads_get": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _u32p]),
     "mdbg_reads_export_ascii": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _u64p]),
+    "mdbg_reads_export_qualities": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _u64p]),
     "mdbg_memcpy_device": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "mdbg_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "mdbg_host_free": (None, [_P, _P]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mdbg_minimizers_from_host": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_minimizers_device_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "mdbg_minimizers_free": (None, [_P]),
+    "mdbg_minimizers_concat": (C.c_int, [_P, C.POINTER(_P), C.c_uint32, C.POINTER(_P)]),
     "mdbg_apply_density_threshold": (C.c_int, [_P, _P, C.c_float, C.POINTER(_P)]),
     "mdbg_purge_palindromes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "mdbg_repetitive_minimizers": (C.c_int, [_P, _P, _P, _u32p]),
@@ -306,6 +308,13 @@ class Context:
             raise MdbgError(rc, (lib().mdbg_last_error(None) or b"").decode())
         return buf.raw
 
+    def minimizers_concat(self, parts: list) -> "Minimizers":
+        """The reads of the parts, in order, as one set (appended on the device: mdbg_minimizers_concat)."""
+        arr = (C.c_void_p * len(parts))(*[getattr(p.h, "value", p.h) for p in parts])
+        h = C.c_void_p()
+        self.check(lib().mdbg_minimizers_concat(self.h, arr, len(parts), C.byref(h)))
+        return Minimizers(self, h)
+
     def comm_create(self, unique_id: bytes, rank: int, n_ranks: int) -> "Comm":
         h = C.c_void_p()
         self.check(lib().mdbg_comm_create(self.h, unique_id, rank, n_ranks, C.byref(h)))
@@ -455,6 +464,14 @@ class Reads:
         offs = np.zeros(count + 1, dtype=np.uint64)
         self.ctx.check(lib().mdbg_reads_export_ascii(self.ctx.h, self.h, first, count, _ptr(bases), _ptr(offs), C.byref(nb)))
         return bases, offs
+
+    def export_qualities(self, first: int, count: int) -> np.ndarray:
+        """phred+33 bytes of reads [first, first+count), concatenated (offsets as export_ascii's)."""
+        nb = C.c_uint64()
+        self.ctx.check(lib().mdbg_reads_export_qualities(self.ctx.h, self.h, first, count, None, C.byref(nb)))
+        q = np.zeros(nb.value, dtype=np.uint8)
+        self.ctx.check(lib().mdbg_reads_export_qualities(self.ctx.h, self.h, first, count, _ptr(q), C.byref(nb)))
+        return q
 
     def free(self) -> None:
         if self.h:

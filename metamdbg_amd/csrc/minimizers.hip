@@ -310,6 +310,71 @@ extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint6
 
 extern "C" void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
 
+// dst[i] = src[i] + base for i < n (the offsets of an appended part, rebased)
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *src, uint64_t n, uint64_t base, uint64_t *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + base;
+}
+
+extern "C" int mdbg_minimizers_concat(mdbg_ctx *ctx, const mdbg_minimizers *const *parts, uint32_t n_parts, mdbg_minimizers **out) try {
+    if (!ctx || !out || (n_parts && !parts)) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_concat: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint64_t n_reads = 0, n_min = 0;
+    bool side = n_parts > 0, per_read = n_parts > 0, any_mq = false;
+    for (uint32_t p = 0; p < n_parts; p++) {
+        if (!parts[p]) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_concat: part %u is null", p);
+        MDBG_TRY(ensure_canonical(ctx, parts[p]));
+        n_reads += parts[p]->n_reads; n_min += parts[p]->n_min;
+        side = side && parts[p]->from_scan && parts[p]->d_pos.p && parts[p]->d_dir.p && parts[p]->d_mqual.p;
+        per_read = per_read && parts[p]->from_scan && parts[p]->d_len.p && parts[p]->d_flags.p;
+        any_mq = any_mq || !parts[p]->h_mean_quality.empty();
+    }
+    if (n_reads >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "mdbg_minimizers_concat: more than 2^32 reads");
+    std::unique_ptr<mdbg_minimizers> m(new mdbg_minimizers());
+    m->n_reads = (uint32_t)n_reads;
+    m->n_min = n_min;
+    m->from_scan = side && per_read;          // positions, directions, qualities and the per-read fields follow only when every part has them
+    m->owner = ctx;
+    MDBG_TRY(m->d_off.alloc(ctx, n_reads + 1));
+    MDBG_TRY(m->d_min.alloc(ctx, n_min));
+    if (m->from_scan) {
+        MDBG_TRY(m->d_pos.alloc(ctx, n_min)); MDBG_TRY(m->d_dir.alloc(ctx, n_min)); MDBG_TRY(m->d_mqual.alloc(ctx, n_min));
+        MDBG_TRY(m->d_len.alloc(ctx, n_reads)); MDBG_TRY(m->d_flags.alloc(ctx, n_reads));
+        if (any_mq) m->h_mean_quality.reserve(n_reads);
+    }
+    uint64_t r0 = 0, m0 = 0;
+    for (uint32_t p = 0; p < n_parts; p++) {
+        const mdbg_minimizers *q = parts[p];
+        // a part another context produced: its rows are complete once that context's stream is (ensure_canonical and the scans
+        // synchronise before they return, so the data is there; the copies below are ordered on THIS context's stream)
+        const uint64_t nr = q->n_reads, nm = q->n_min;
+        // offsets [0, nr) of the part rebased; the closing offset is written by the next part or below
+        if (nr) hipLaunchKernelGGL(rebase_offsets_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, ctx->stream, q->d_off.p, nr, m0, m->d_off.p + r0);
+        if (nm) {
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_min.p + m0, q->d_min.p, nm * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            if (m->from_scan) {
+                MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_pos.p + m0, q->d_pos.p, nm * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_dir.p + m0, q->d_dir.p, nm, hipMemcpyDeviceToDevice, ctx->stream));
+                MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_mqual.p + m0, q->d_mqual.p, nm, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        if (m->from_scan && nr) {
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_len.p + r0, q->d_len.p, nr * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_flags.p + r0, q->d_flags.p, nr, hipMemcpyDeviceToDevice, ctx->stream));
+            if (any_mq) {
+                if (q->h_mean_quality.size() == nr) m->h_mean_quality.insert(m->h_mean_quality.end(), q->h_mean_quality.begin(), q->h_mean_quality.end());
+                else m->h_mean_quality.insert(m->h_mean_quality.end(), nr, q->mean_quality_all);
+            }
+        }
+        if (p == 0) m->mean_quality_all = q->mean_quality_all;
+        r0 += nr; m0 += nm;
+    }
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_off.p + n_reads, &n_min, 8, hipMemcpyHostToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // n_min is a stack word; the parts may be freed by the caller next
+    *out = m.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
 extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out) try {
     if (!ctx || !in || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: null argument");
     MDBG_TRY(ensure_canonical(ctx, in));

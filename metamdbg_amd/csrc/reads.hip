@@ -437,14 +437,42 @@ extern "C" int mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint3
     std::vector<uint64_t> w(woff[count] - woff[0]);
     if (!w.empty()) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, w.data(), r->d_words.p + woff[0], w.size() * 8, hipMemcpyDeviceToHost));
     static const char code2ascii[4] = {'A', 'C', 'T', 'G'};
+    // four bases per table look-up (a byte of packed codes -> four characters): exports of 10 Gbp are part of every bench run
+    static const std::vector<uint32_t> quad = [] {
+        std::vector<uint32_t> t(256);
+        for (unsigned v = 0; v < 256; v++) {
+            uint32_t x = 0;
+            for (unsigned j = 0; j < 4; j++) x |= (uint32_t)(unsigned char)code2ascii[(v >> (2 * j)) & 3] << (8 * j);
+            t[v] = x;
+        }
+        return t;
+    }();
     uint64_t o = 0;
     for (uint32_t i = 0; i < count; i++) {
         if (offsets) offsets[i] = o;
         const uint64_t *rw = w.data() + (woff[i] - woff[0]);
-        for (uint32_t b = 0; b < lens[i]; b++) bases[o + b] = code2ascii[(rw[b >> 5] >> (2 * (b & 31))) & 3];
-        o += lens[i];
+        const uint32_t L = lens[i], full = L & ~3u;
+        char *dst = bases + o;
+        for (uint32_t b = 0; b < full; b += 4) {
+            const uint32_t q = quad[(rw[b >> 5] >> (2 * (b & 31))) & 255u];
+            memcpy(dst + b, &q, 4);
+        }
+        for (uint32_t b = full; b < L; b++) dst[b] = code2ascii[(rw[b >> 5] >> (2 * (b & 31))) & 3];
+        o += L;
     }
     if (offsets) offsets[count] = o;
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_reads_export_qualities(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t first, uint32_t count, char *quals, uint64_t *n_bytes) try {
+    if (!ctx || !r || (uint64_t)first + count > r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_qualities: bad range");
+    if (!r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_qualities: the batch has no qualities");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint64_t range[2] = {0, 0};
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &range[0], r->d_qual_off.p + first, 8, hipMemcpyDeviceToHost));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &range[1], r->d_qual_off.p + first + count, 8, hipMemcpyDeviceToHost));
+    if (n_bytes) *n_bytes = range[1] - range[0];
+    if (quals && range[1] > range[0]) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, quals, r->d_qual.p + range[0], range[1] - range[0], hipMemcpyDeviceToHost));
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 

@@ -901,6 +901,49 @@ def test_hifi_1m_digests(ctx):
         o.free()
 
 
+def test_minimizers_concat(ctx):
+    """mdbg_minimizers_concat: a read set scanned in pieces (fresh scattered scan outputs, a piece without reads, qualities) and
+    appended on the device is the set scanned whole -- every array of the scan output -- and so are its purge and its table;
+    purged pieces (values and offsets only) append as well."""
+    spec = synth.ont_spec(3000, seed=31, read_len=9000, coverage=30.0)
+    cuts = [(0, 700), (700, 0), (700, 1800), (2500, 500)]
+    whole = ctx.reads_synthetic(spec)
+    kw = dict(K=15, density=0.005, hpc=False)
+    mw = ctx.scan(whole, **kw)
+    parts = [ctx.scan(ctx.reads_synthetic(spec, first_read=f, n_reads=n), **kw) for f, n in cuts]
+    cat = ctx.minimizers_concat(parts)
+    hw, hc = mw.to_host(), cat.to_host()
+    assert sorted(hw) == sorted(hc)
+    for key in hw:
+        assert np.array_equal(hw[key], hc[key], equal_nan=True) if hw[key].dtype.kind == "f" else np.array_equal(hw[key], hc[key]), key
+    assert len(hw["minimizers"]) > 100_000 and hw["qual"].max() > 1
+    tw = ctx.kminmer_count_first(ctx.purge_palindromes(mw, 4, 100), 4, 0)
+    tc = ctx.kminmer_count_first(ctx.purge_palindromes(cat, 4, 100), 4, 0)
+    assert tw.checksum() == tc.checksum() and tw.info() == tc.info()
+    # purged pieces: CSR with values only
+    pc = ctx.minimizers_concat([ctx.purge_palindromes(p, 4, 100) for p in parts])
+    tp = ctx.kminmer_count_first(pc, 4, 0)
+    assert tp.checksum() == tw.checksum() and pc.info() == dict(n_reads=3000, n_minimizers=tw.stats()["minimizers"])
+    assert ctx.minimizers_concat([]).info() == dict(n_reads=0, n_minimizers=0)
+
+
+def test_bulk_export_of_bases_and_qualities(ctx):
+    """mdbg_reads_export_ascii (four bases per look-up, lengths that are not multiples of four) and mdbg_reads_export_qualities
+    against the per-read mdbg_reads_get, on a sub-range of a batch with qualities."""
+    rng = np.random.default_rng(3)
+    seqs = [bytes(synth.CODE2ASCII[rng.integers(0, 4, int(n))]) for n in (1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 1000, 1001, 1002, 1003, 0, 7)]
+    quals = [bytes(rng.integers(33, 90, len(s)).astype(np.uint8)) for s in seqs]
+    reads = ctx.reads_from_ascii(seqs, quals)
+    for first, count in ((0, len(seqs)), (3, 9), (15, 2), (5, 0)):
+        bases, offs = reads.export_ascii(first, count)
+        q = reads.export_qualities(first, count)
+        assert len(q) == len(bases) == sum(len(s) for s in seqs[first:first + count])
+        for i in range(count):
+            a, b = int(offs[i]), int(offs[i + 1])
+            assert bases[a:b].tobytes() == seqs[first + i] and q[a:b].tobytes() == quals[first + i]
+            assert reads.get(first + i, with_quality=True) == (seqs[first + i], quals[first + i])
+
+
 def test_table_checksum_is_the_references_formula(ctx):
     """mdbg_table_checksum on the device = the sums over the host copy of the rows; sums[0] is the "Checksum kminmer abundance" the
     reference logs when it loads a table (graph/CreateMdbg.cpp:3321: abundance * vecHash truncated to u64 -- the low word)."""
