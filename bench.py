@@ -42,6 +42,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
+DEFAULT_TABLE_CUS = 0          # compute units the table kernels of a batch in flight are confined to (0: not confined)
 
 
 def parse_args():
@@ -54,7 +55,8 @@ def parse_args():
     ap.add_argument("--in-flight", type=int, default=3, help="batches processed concurrently per GPU (own context, stream and host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000,
                     help="reads of the CPU-baseline / parity read set, a HiFi set of its own at 50x (1 M = BASELINE.json configs[1]; 0 = skip)")
-    ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,pcie,ont ('all', 'none')")
+    ap.add_argument("--legs", default="all", help="N=1 only: comma list of end_to_end,multik,multik_reference,pcie,ont ('all', 'none')")
+    ap.add_argument("--multik-sample", type=int, default=200_000, help="reads of the multik_reference leg (the reference's own loop k = 4..11)")
     ap.add_argument("--ont-reads", type=int, default=10_000_000, help="reads (20 kb, with qualities) of the ont leg: BASELINE.json configs[3]")
     ap.add_argument("--ont-sample", type=int, default=100_000, help="reads of the ont leg's parity sample against the reference")
     a = ap.parse_args()
@@ -314,6 +316,96 @@ def multik_leg(ctx, reads, n_bases: int, last_k: int = 11) -> dict:
     return r
 
 
+def multik_reference_leg(ctx, n_sample: int, read_len: int, last_k: int = 11, budget_s: float = 300.0) -> dict:
+    """BASELINE.json configs[2] in the reference's OWN mode, beyond fixture size: the real multi-k loop -- `graph` -> `contig` ->
+    `toMinspace` per k, k = 4 .. 11, as AssemblyPipeline::executePass chains them (pipeline/AssemblyPipeline.hpp:603-671,
+    :1080-1089) -- run by the reference's code (oracle/_ref/refdrv) on a HiFi read set of n_sample reads at 50x, and at EVERY k
+    the C++ drop-in `mdbg_tool graph` run on a copy of exactly the files the reference's `graph` is about to read (reads,
+    unitig_data.txt, the previous table, the previous unitig graph with its refined abundances): tables equal as multisets of
+    records (and of vectors for k <= 5), smallContigs_k<k>.bin equal.  One flag per k; a mismatch fails the run.  The loop stops
+    early once `budget_s` seconds are spent (the reference's graph construction dominates) and says how far it got."""
+    import dataclasses
+    import numpy as np
+    from metamdbg_amd import formats, synth
+    if n_sample <= 0 or not (os.path.exists(REFDRV) and os.path.exists(TOOL)):
+        return {"skipped": "needs oracle/_ref/refdrv and metamdbg_amd/bin/mdbg_tool"}
+    cores = min(os.cpu_count() or 1, 32)
+    work = tempfile.mkdtemp(prefix="mdbg_multik_")
+    t_start = time.perf_counter()
+
+    def run(cmd, timeout=1200):
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd[:3])} failed: {r.stderr.decode(errors='replace')[-500:]}")
+
+    try:
+        sspec = synth.hifi_spec(n_sample, seed=42, read_len=read_len, coverage=50.0)
+        sub = ctx.reads_synthetic(sspec)
+        fasta = os.path.join(work, "sample.fasta")
+        nbases = _write_fasta_from_device(fasta, sub, n_sample)
+        sub.free()
+        P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4, hpc=True, data_type=0)
+        tmp = _make_tmp(work, "ref", P, [fasta])
+        run([REFDRV, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
+             "--threads", str(cores), "--min-read-quality", "0.000000"])
+        scratch = os.path.join(work, "tool", "tmp")
+        per_k, prev_k = {}, 4
+        for k in range(4, last_k + 1):
+            if time.perf_counter() - t_start > budget_s:
+                break
+            dataclasses.replace(P, kminmer_size=k, prev_k=prev_k, last_k=last_k).save(os.path.join(tmp, "parameters.gz"))
+            # ---- the tool on a copy of what the reference's `graph` is about to read
+            shutil.rmtree(os.path.dirname(scratch), ignore_errors=True)
+            for d in ("", "filter", "smallContigs", "checkpoints"):
+                os.makedirs(os.path.join(scratch, d), exist_ok=True)
+            for name in ("parameters.gz", "read_data_corrected.txt", "read_stats.txt", "kminmerData_abundance_prev.txt",
+                         "unitigGraph.nodes.refined_abundances.bin", "unitigGraph_prev.nodes.bin", "unitig_data.txt"):
+                if os.path.exists(os.path.join(tmp, name)) and (k > 4 or name.startswith(("parameters", "read_"))):
+                    try:
+                        os.link(os.path.join(tmp, name), os.path.join(scratch, name))
+                    except OSError:
+                        shutil.copy(os.path.join(tmp, name), os.path.join(scratch, name))
+            args = ["--threads", str(cores)] + (["--min-abundance", "0", "--firstpass"] if k == 4 else [])
+            t0 = time.perf_counter()
+            run([TOOL, "graph", scratch] + args)
+            t1 = time.perf_counter()
+            run([REFDRV, "graph", tmp] + args)
+            t2 = time.perf_counter()
+            eq = bool(np.array_equal(formats.sorted_abundance_records(_fbytes(tmp, "kminmerData_abundance.txt")),
+                                     formats.sorted_abundance_records(_fbytes(scratch, "kminmerData_abundance.txt"))))
+            n_rec = os.path.getsize(os.path.join(tmp, "kminmerData_abundance.txt")) // 20
+            if k <= 5:
+                eq = eq and bool(np.array_equal(formats.sorted_vector_records(_fbytes(tmp, "kminmerData_min.txt"), k),
+                                                formats.sorted_vector_records(_fbytes(scratch, "kminmerData_min.txt"), k)))
+            sc = os.path.join("smallContigs", f"smallContigs_k{k}.bin")
+
+            def small(d):       # records `u32 n; u8 circular; u32 m[n]` as a sorted list (the reference writes them in thread order)
+                raw, o, out = _fbytes(d, sc) if os.path.exists(os.path.join(d, sc)) else b"", 0, []
+                while o + 5 <= len(raw):
+                    n = int.from_bytes(raw[o:o + 4], "little")
+                    out.append(raw[o:o + 5 + 4 * n]); o += 5 + 4 * n
+                return sorted(out)
+            small_eq = small(tmp) == small(scratch)
+            per_k[str(k)] = {"tables_equal": eq, "small_contigs_equal": bool(small_eq), "records": int(n_rec),
+                             "mdbg_tool_graph_s": t1 - t0, "reference_graph_s": t2 - t1}
+            if not (eq and small_eq):
+                raise SystemExit(f"bench.py: PARITY FAILURE in the reference's multi-k loop at k = {k}: {per_k[str(k)]}")
+            if k == last_k:
+                break
+            run([REFDRV, "contig", tmp, "--threads", str(cores), "--max-bubble-length", "50000", "--max-tip-length", "50000"])
+            run([REFDRV, "toMinspace", tmp, os.path.join(tmp, "contigs.nodepath"), os.path.join(tmp, "unitig_data.txt"),
+                 os.path.join(tmp, "unitigGraph.nodes.bin"), "--threads", str(cores)])
+            prev_k = k
+        ks = sorted(int(k) for k in per_k)
+        return {"workload": f"{n_sample} synthetic HiFi reads x {read_len} bp at 50x ({nbases / 1e9:.1f} Gbp): the reference's own loop graph -> contig -> "
+                            f"toMinspace, k = 4..{last_k} (refdrv, --threads {cores}); at every k mdbg_tool graph on a copy of the files the "
+                            "reference's graph reads, tables compared as multisets",
+                "k_done": ks, "complete": ks == list(range(4, last_k + 1)), "all_tables_equal": all(v["tables_equal"] and v["small_contigs_equal"] for v in per_k.values()),
+                "per_k": per_k, "seconds": time.perf_counter() - t_start, "budget_s": budget_s}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int = 8) -> dict:
     """The step when the reads arrive over PCIe (never `value`): the first n_sub reads of the batch are brought to page-locked
     host memory (2-bit packed as the host feed delivers them, and as ASCII), then uploaded through the boundary's own entry
@@ -382,6 +474,52 @@ def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int =
             step(ctx, ascii_input)
         dt = time.perf_counter() - t0
         res[f"{name}_one_context_gbps"] = n_bases * repeats / 1e9 / dt
+    # ---- one context, the upload of batch i+1 queued (mdbg_reads_from_packed_async: the context's upload stream, a copy engine)
+    # before batch i is put through its kernels: the link and the kernels work at the same time
+    def upload_async(c):
+        h = C.c_void_p()
+        c.check(capi.lib().mdbg_reads_from_packed_async(c.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
+        return capi.Reads(c, h)
+
+    def kernels(c, r):
+        m = c.scan(r, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = c.purge_palindromes(m, 4, 100)
+        t = c.kminmer_count_first(corr, KMINMER, 0)
+        c.synchronize()
+        out = (int(m.info()["n_minimizers"]), int(t.info()["n_records"]))
+        for o in (t, corr, m):
+            o.free()
+        return out
+
+    def pipelined(c, n):
+        nxt, got = upload_async(c), None
+        for i in range(n):
+            cur, nxt = nxt, (upload_async(c) if i + 1 < n else None)
+            got = kernels(c, cur)
+            cur.free()
+        return got
+    if pipelined(ctx, 2) != want:
+        raise SystemExit("pcie leg (pipelined): results differ from the resident form's")
+    t0 = time.perf_counter()
+    pipelined(ctx, repeats)
+    dt_pipe = time.perf_counter() - t0
+    res["packed_one_context_pipelined_gbps"] = n_bases * repeats / 1e9 / dt_pipe
+    # the two halves alone: the upload (waited for) and the kernels on reads already there
+    r0 = upload_async(ctx); ctx.check(capi.lib().mdbg_reads_wait(ctx.h, r0.h))
+    t0 = time.perf_counter()
+    for _ in range(4):
+        r1 = upload_async(ctx); ctx.check(capi.lib().mdbg_reads_wait(ctx.h, r1.h)); r1.free()
+    upload_ms = (time.perf_counter() - t0) / 4 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(4):
+        kernels(ctx, r0)
+    kernel_ms = (time.perf_counter() - t0) / 4 * 1e3
+    r0.free()
+    step_ms = dt_pipe / repeats * 1e3
+    res.update(upload_ms=upload_ms, kernel_ms=kernel_ms, pipelined_step_ms=step_ms,
+               # 1 = the shorter half is hidden completely behind the longer one, 0 = they run one after the other
+               overlap=(upload_ms + kernel_ms - step_ms) / min(upload_ms, kernel_ms) if min(upload_ms, kernel_ms) > 0 else None,
+               link_ceiling_gbps=n_bases / 1e9 / (upload_ms / 1e3))
     other = capi.Context(device)
     step(other, False)
     def worker(c, n):
@@ -552,12 +690,18 @@ def measured_traffic(reads: int, read_len: int):
 ATOMIC_RATE_GOPS = 26.0
 
 
+def run_alone(ctx) -> None:
+    """The context is the only one working on the device from here on: no footprint limits."""
+    ctx.set_option("table_blocks_per_cu", 0)
+    ctx.set_option("table_cu_count", 0)
+
+
 def kminmer_roofline(ctx, reads) -> dict:
     """The k-min-mer step (first pass, k = 4) of the bench workload on the record: algorithmic bytes 4 M + 16 I + 20 D
     (minimizers read, one 128-bit key per instance, output rows) over the HIP-event time of its kernels with
     the context ALONE on the device, and the ceiling the insert is judged against: one atomic per instance at the part's
     random-atomic rate."""
-    ctx.set_option("table_blocks_per_cu", 0)
+    run_alone(ctx)
     names = ("kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
     acc = {n: 0.0 for n in names}
     st = ti = None
@@ -634,6 +778,8 @@ def main() -> None:
     # 676 / 672 / 657 / 643 Gbp/s on one GPU and 489 / 479 / 463 on the per-rank workload of an 8-GPU job run through
     # the sharded path (profiles/r01g_table_footprint_sweep.txt)
     table_blocks = int(os.environ.get("MDBG_TABLE_BLOCKS_PER_CU", "1")) if n_slots > 1 else 0
+    # ... and, optionally, to a few compute units of their own ("table_cu_count", include/mdbg_hip.h): sweep in profiles/
+    table_cus = int(os.environ.get("MDBG_BENCH_TABLE_CUS", str(DEFAULT_TABLE_CUS))) if n_slots > 1 else 0
     slots = []
     # one metagenome for the job (MDBG_BENCH_SPEC_RANKS: test hook, the per-rank workload of an N-rank job on one GPU)
     spec_ranks = int(os.environ.get("MDBG_BENCH_SPEC_RANKS", world))
@@ -643,6 +789,8 @@ def main() -> None:
     for _ in range(n_slots):
         c = capi.Context(local_rank)
         c.set_option("table_blocks_per_cu", table_blocks)
+        if table_cus:
+            c.set_option("table_cu_count", table_cus)
         if shared_reads is None:
             shared_reads = c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)
         slots.append((c, shared_reads))
@@ -858,6 +1006,8 @@ def main() -> None:
             c.close()
             slots[1] = (capi.Context(local_rank), r)
             slots[1][0].set_option("table_blocks_per_cu", table_blocks)
+            if table_cus:
+                slots[1][0].set_option("table_cu_count", table_cus)
             # (the communicator of a slot belongs to the rank, not to the context: comms[1] stays)
     def exchange_account() -> dict:
         """Bytes this rank put on the wire and the host time it spent inside exchanges so far."""
@@ -954,7 +1104,7 @@ def main() -> None:
             else:
                 for c, _ in slots[1:]:
                     c.close()                                  # their pools make room
-                ctx.set_option("table_blocks_per_cu", 0)
+                run_alone(ctx)
                 t_v = time.perf_counter()
                 allr = ctx.reads_synthetic(spec, first_read=0, n_reads=total_reads)
                 am = ctx.scan(allr, K=K_MINIMIZER, density=DENSITY, hpc=True)
@@ -975,7 +1125,7 @@ def main() -> None:
                             "sharded": verify, "single_gpu": one, "single_gpu_seconds": time.perf_counter() - t_v}
                 failed = not parity_n["table_equal"]
         legs_on = set() if (world > 1 or args.legs == "none") else \
-            ({"end_to_end", "multik", "pcie", "ont"} if args.legs == "all" else set(args.legs.split(",")))
+            ({"end_to_end", "multik", "multik_reference", "pcie", "ont"} if args.legs == "all" else set(args.legs.split(",")))
         # ---- the table kernels on the record (4 M + 16 I + 20 D bytes per k): two steps of this context ALONE on
         # the device, timed by HIP events like the scan -- beside another batch's scan they share the CUs, that is not their speed
         kroof = None
@@ -987,10 +1137,13 @@ def main() -> None:
         if "end_to_end" in side:
             legs["end_to_end"] = side["end_to_end"]
         if "multik" in legs_on:
-            ctx.set_option("table_blocks_per_cu", 0)       # this context runs alone now
+            run_alone(ctx)
             legs["multik"] = multik_leg(ctx, reads, n_bases)
+        if "multik_reference" in legs_on:
+            run_alone(ctx)
+            legs["multik_reference"] = multik_reference_leg(ctx, min(args.multik_sample, args.cpu_sample), args.read_len)
         if "pcie" in legs_on:
-            ctx.set_option("table_blocks_per_cu", 0)
+            run_alone(ctx)
             legs["pcie"] = pcie_leg(ctx, reads, spec, local_rank)
         if "ont" in legs_on:
             # the HiFi batch and the other contexts' pools make room first
@@ -1014,7 +1167,7 @@ def main() -> None:
                                    "shared by the batches in flight",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
-                       "batches_in_flight": n_slots, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
+                       "batches_in_flight": n_slots, "table_blocks_per_cu": table_blocks, "table_cu_count": table_cus, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
                        "exchange": exch},
             "roofline": {"bound": "hbm", "kernel": "scan_fast_kernel<HPC=1,QUAL=0,APPROX=1> (_ZN4mdbg16scan_fast_kernelILb1ELb0ELb1EEEvNS_8ScanArgsE)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,

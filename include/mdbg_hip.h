@@ -54,6 +54,11 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
 /* Per-context tuning, value <= 0 restores the default:
  *   "table_blocks_per_cu"   resident blocks per CU of the kernels that walk every k-min-mer instance (default: unlimited;
  *                           1..3 when several contexts share a device, so that they do not displace another context's scan)
+ *   "table_cu_count"        c > 0: every kernel of the context except the block-structured scan kernel is confined to c compute
+ *                           units (spread over the XCDs), the scan kernel runs on a stream of its own over all of them; for
+ *                           several contexts in flight on one device (the other batches' table kernels then displace a running
+ *                           scan on those CUs only).  Call it between steps: it synchronises and re-creates the stream, so a
+ *                           handle obtained from mdbg_stream before is dead.  Default 0: one unconfined stream
  *   "scan_reads_per_wave"   reads a scan wave processes before it retires (default 2)
  *   "scan_candidate_slack"  tests only: the block-structured scan records candidate positions by the upper half of the
  *                           hash and confirms each with the full hash; a read with a false candidate is re-run.  False
@@ -88,6 +93,15 @@ int  mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, 
  * cannot say more than the code: use it for reads made of A, C, G, T only (the host feed does). */
 int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
                             const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out);
+/* The same without waiting for the copies: they are queued on an upload stream of the context (a copy engine: they run beside
+ * the kernels of the context's own stream) and the call returns.  `words` and `lengths` must stay untouched until
+ * mdbg_reads_wait returns (or the reads are freed); page-locked memory (mdbg_host_alloc) is what makes the copy asynchronous.
+ * Calls that consume the reads order themselves after the upload: mdbg_scan on the device, without a host wait -- so a feeder
+ * uploads batch i+1 while batch i is scanned, inside one context: the replacement of the reference's one-reader critical
+ * section (Commons.hpp:5868-5905) is then bound by the link, not by link + kernels. */
+int  mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint32_t *lengths,
+                                  uint32_t n_reads, mdbg_reads **out);
+int  mdbg_reads_wait(mdbg_ctx *ctx, const mdbg_reads *r);
 /* Phred+33 qualities (Read::_qual) for reads made by mdbg_reads_from_packed: read r = quals[offsets[r] .. offsets[r+1]),
  * offsets[r+1] - offsets[r] must equal its length.  Once per reads object. */
 int  mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *reads, const char *quals, const uint64_t *offsets);

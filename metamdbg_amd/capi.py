@@ -47,6 +47,8 @@ SIGNATURES = {
     "mdbg_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), _u64p]),
     "mdbg_reads_from_ascii": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_from_packed": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_reads_from_packed_async": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_reads_wait": (C.c_int, [_P, _P]),
     "mdbg_reads_attach_qualities": (C.c_int, [_P, _P, C.c_char_p, _P]),
     "mdbg_reads_synthetic": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, C.c_uint32,
                                        C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_P)]),

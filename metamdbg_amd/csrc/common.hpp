@@ -110,6 +110,10 @@ struct TimedLaunch {
 struct mdbg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t scan_stream = nullptr;      // "table_cu_count": the block-structured scan kernel runs here (every CU) while `stream`, which
+                                            // carries everything else, is confined to a few CUs (mdbg_set_option)
+    unsigned table_cu_count = 0;
+    hipStream_t upload_stream = nullptr;    // mdbg_reads_from_packed_async: host-to-device copies that run beside the kernels of `stream` (created on first use)
     hipStream_t side_stream = nullptr;      // copies that must not queue behind the main stream's kernel (quality sums during the scan)
     void *pinned = nullptr;                 // grow-only pinned host buffer for them
     size_t pinned_bytes = 0;

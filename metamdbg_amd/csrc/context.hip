@@ -89,6 +89,8 @@ extern "C" void mdbg_destroy(mdbg_ctx *ctx) {
     fold_timers(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pool) ctx->pool->close();      // cached blocks are freed now; blocks still handed out free themselves
+    if (ctx->scan_stream) { (void)hipStreamSynchronize(ctx->scan_stream); (void)hipStreamDestroy(ctx->scan_stream); }
+    if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -107,9 +109,38 @@ extern "C" int mdbg_synchronize(mdbg_ctx *ctx) try {
 
 extern "C" void *mdbg_stream(mdbg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// "table_cu_count" = c > 0: the context's stream is re-created confined to c compute units (hipExtStreamCreateWithCUMask; mask
+// bits are dealt round-robin over the XCDs, so the low c bits are c / 8 CUs of every XCD) and the block-structured scan kernel
+// gets a stream of its own over every CU.  For several contexts in flight on one device: the table kernels of one batch -- bound
+// by the atomic rate and by latency, not by the number of CUs -- then take CUs from another batch's scan only where they are
+// confined, instead of a share of every CU.  0 restores one unconfined stream.
+static int set_table_cu_count(mdbg_ctx *ctx, unsigned c) {
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    fold_timers(ctx);                                    // pending events belong to the old streams
+    if (c > (unsigned)ctx->n_cu) c = (unsigned)ctx->n_cu;
+    hipStream_t fresh = nullptr, scan = nullptr;
+    if (c) {
+        std::vector<uint32_t> mask(((unsigned)ctx->n_cu + 31u) / 32u, 0u);
+        for (unsigned i = 0; i < c; i++) mask[i >> 5] |= 1u << (i & 31u);
+        MDBG_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&fresh, (uint32_t)mask.size(), mask.data()));
+        hipError_t e = hipStreamCreateWithFlags(&scan, hipStreamNonBlocking);
+        if (e != hipSuccess) { (void)hipStreamDestroy(fresh); return set_error(ctx, MDBG_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    } else {
+        MDBG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    }
+    if (ctx->scan_stream) { (void)hipStreamSynchronize(ctx->scan_stream); (void)hipStreamDestroy(ctx->scan_stream); }
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = fresh;
+    ctx->scan_stream = scan;
+    ctx->table_cu_count = c;
+    return MDBG_OK;
+}
+
 extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: null argument");
     const std::string n(name);
+    if (n == "table_cu_count") return set_table_cu_count(ctx, value > 0 ? (unsigned)std::min<int64_t>(value, 4096) : 0u);
     if (n == "table_blocks_per_cu") { ctx->table_blocks_per_cu = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 1024u; return MDBG_OK; }
     if (n == "scan_wave_priority") { ctx->scan_wave_priority = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }

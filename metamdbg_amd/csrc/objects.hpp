@@ -29,7 +29,24 @@ struct mdbg_reads {
     bool has_invalid = false;   // d_invalid is present (some base is invalid, or d_break is present)
     bool has_break = false;
     bool has_qual = false;
+    // mdbg_reads_from_packed_async: the upload is queued on the context's upload stream; `ready` is recorded behind it and every
+    // consumer orders itself after it (reads_ready_on / reads_ready_host).  h_rel keeps the rebased offsets alive until then.
+    hipEvent_t ready = nullptr;
+    std::vector<uint64_t> h_rel;
+    mdbg_reads() = default;
+    mdbg_reads(const mdbg_reads &) = delete;
+    mdbg_reads &operator=(const mdbg_reads &) = delete;
+    ~mdbg_reads() { if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); } }   // before the buffers go
 };
+
+namespace mdbg {
+// the kernels `ctx` queues next see the reads complete (no host wait)
+inline hipError_t reads_ready_on(mdbg_ctx *ctx, const mdbg_reads *r) {
+    return r && r->ready ? hipStreamWaitEvent(ctx->stream, r->ready, 0) : hipSuccess;
+}
+// the host may read the device buffers / reuse the buffers it uploaded from
+inline hipError_t reads_ready_host(const mdbg_reads *r) { return r && r->ready ? hipEventSynchronize(r->ready) : hipSuccess; }
+}
 
 // Minimizer-space sequences in HBM as CSR.  Per-minimizer side arrays exist only for scan output.
 struct mdbg_minimizers {

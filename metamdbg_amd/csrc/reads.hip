@@ -299,10 +299,60 @@ extern "C" int mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, cons
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
+extern "C" int mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
+                                            const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out) try {
+    if (!ctx || !out || (n_reads && (!words || !word_offsets || !lengths)))
+        return set_error(ctx, MDBG_EINVAL, "mdbg_reads_from_packed_async: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->upload_stream) MDBG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    std::unique_ptr<mdbg_reads> r(new mdbg_reads());
+    r->n_reads = n_reads;
+    const uint64_t base = n_reads ? word_offsets[0] : 0;
+    r->n_words = n_reads ? word_offsets[n_reads] - base : 0;
+    r->h_rel.assign((size_t)n_reads + 1, 0);
+    for (uint32_t i = 0; i < n_reads; i++) {
+        r->h_rel[i] = word_offsets[i] - base;
+        const uint64_t nw = word_offsets[i + 1] - word_offsets[i];
+        if ((r->h_rel[i] & 1) || nw * 32 < lengths[i])
+            return set_error(ctx, MDBG_EINVAL, "read %u: word offset must be even and cover the read", i);
+        r->n_bases += lengths[i];
+        if (lengths[i] > r->max_len) r->max_len = lengths[i];
+    }
+    r->h_rel[n_reads] = r->n_words;
+    MDBG_TRY(r->d_words.alloc(ctx, r->n_words + 2));
+    MDBG_TRY(r->d_word_off.alloc(ctx, (size_t)n_reads + 1));
+    MDBG_TRY(r->d_len.alloc(ctx, n_reads));
+    // the blocks come from the context's pool, whose reuse is ordered by the context's stream: the upload starts after what that
+    // stream has queued so far (the last user of a recycled block), not after what it queues later
+    hipEvent_t ev = nullptr;
+    MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->upload_stream, ev, 0);
+    if (e == hipSuccess && r->n_words) e = hipMemcpyAsync(r->d_words.p, words + base, r->n_words * 8, hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_word_off.p, r->h_rel.data(), r->h_rel.size() * 8, hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->d_len.p, lengths, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess) e = hipEventRecord(ev, ctx->upload_stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->upload_stream);
+        (void)hipEventDestroy(ev);
+        return set_error(ctx, MDBG_EHIP, "mdbg_reads_from_packed_async: %s", hipGetErrorString(e));
+    }
+    r->ready = ev;
+    *out = r.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_reads_wait(mdbg_ctx *ctx, const mdbg_reads *r) try {
+    if (!ctx || !r) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_wait: null argument");
+    MDBG_HIP_CHECK(ctx, reads_ready_host(r));
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
 extern "C" int mdbg_reads_attach_qualities(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets) try {
     if (!ctx || !r || (r->n_reads && (!quals || !offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities: null argument");
     if (r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities: the reads already carry qualities");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, reads_ready_host(r));
     const uint32_t n = r->n_reads;
     if (!n) return MDBG_OK;
     std::vector<uint32_t> lens(n);
@@ -393,6 +443,7 @@ extern "C" int mdbg_reads_info(const mdbg_reads *r, uint32_t *n_reads, uint64_t 
 extern "C" int mdbg_reads_get(mdbg_ctx *ctx, const mdbg_reads *r, uint32_t index, char *bases, char *quals, uint32_t *length) try {
     if (!ctx || !r || index >= r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_get: bad argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, reads_ready_host(r));
     uint64_t off[2];
     uint32_t L;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, off, r->d_word_off.p + index, 16, hipMemcpyDeviceToHost));
@@ -426,6 +477,7 @@ extern "C" int mdbg_reads_export_ascii(mdbg_ctx *ctx, const mdbg_reads *r, uint3
     if (!ctx || !r || (uint64_t)first + count > r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_ascii: bad range");
     if (r->has_invalid) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_ascii: batch holds N bases; use mdbg_reads_get");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, reads_ready_host(r));
     std::vector<uint64_t> woff((size_t)count + 1);
     std::vector<uint32_t> lens(count);
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, woff.data(), r->d_word_off.p + first, woff.size() * 8, hipMemcpyDeviceToHost));
@@ -468,6 +520,7 @@ extern "C" int mdbg_reads_export_qualities(mdbg_ctx *ctx, const mdbg_reads *r, u
     if (!ctx || !r || (uint64_t)first + count > r->n_reads) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_qualities: bad range");
     if (!r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_export_qualities: the batch has no qualities");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, reads_ready_host(r));
     uint64_t range[2] = {0, 0};
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &range[0], r->d_qual_off.p + first, 8, hipMemcpyDeviceToHost));
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &range[1], r->d_qual_off.p + first + count, 8, hipMemcpyDeviceToHost));

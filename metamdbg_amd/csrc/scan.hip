@@ -1418,11 +1418,23 @@ static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks
 static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool has_n, uint32_t n_items) {
     a.n_reads = n_items;
     const unsigned max_blocks = (unsigned)ctx->n_cu * 8u;
+    static const bool no_fast = getenv("MDBG_SCAN_NO_FAST") != nullptr;      // A/B: the general kernel for everything
+    static const bool no_approx = getenv("MDBG_SCAN_NO_APPROX") != nullptr;  // A/B: full 64-bit verdict at every position
+    const bool fast = (!has_q || a.cursor) && !has_n && !a.subset && !no_fast;
+    // "table_cu_count": the context's own stream is confined to a few CUs; the block-structured kernel goes to a stream over all of
+    // them, ordered after what the context has queued so far and before what it queues next
+    hipStream_t on = ctx->stream;
+    hipEvent_t ordered = nullptr;
+    if (fast && ctx->scan_stream) {
+        MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ordered, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ordered, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->scan_stream, ordered, 0);
+        if (e != hipSuccess) { (void)hipEventDestroy(ordered); return set_error(ctx, MDBG_EHIP, "scan stream hand-over: %s", hipGetErrorString(e)); }
+        on = ctx->scan_stream;
+    }
     {
-        LaunchTimer timer(ctx, "scan");
-        static const bool no_fast = getenv("MDBG_SCAN_NO_FAST") != nullptr;      // A/B: the general kernel for everything
-        static const bool no_approx = getenv("MDBG_SCAN_NO_APPROX") != nullptr;  // A/B: full 64-bit verdict at every position
-        if ((!has_q || a.cursor) && !has_n && !a.subset && !no_fast) {
+        LaunchTimer timer(ctx, "scan", on);
+        if (fast) {
             // plain ACGT without qualities: the block-structured kernel; a few reads per wave, then the wave retires
             const uint64_t per_wave = ctx->scan_reads_per_wave;
             uint64_t blocks = ((uint64_t)n_items + FAST_WAVES * per_wave - 1) / (FAST_WAVES * per_wave);
@@ -1431,15 +1443,15 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
             // bump mode: candidates by the upper half of the hash (span_step<APPROX>); the host's re-run of a read covers a false one
             const dim3 g((unsigned)blocks), b(FAST_BLOCK);
             if (a.cursor && !no_approx) {
-                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, true>), g, b, 0, ctx->stream, a);
-                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, true>), g, b, 0, ctx->stream, a);
-                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, true>), g, b, 0, ctx->stream, a);
-                else hipLaunchKernelGGL((scan_fast_kernel<false, false, true>), g, b, 0, ctx->stream, a);
+                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, true>), g, b, 0, on, a);
+                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, true>), g, b, 0, on, a);
+                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, true>), g, b, 0, on, a);
+                else hipLaunchKernelGGL((scan_fast_kernel<false, false, true>), g, b, 0, on, a);
             } else {
-                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, false>), g, b, 0, ctx->stream, a);
-                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, false>), g, b, 0, ctx->stream, a);
-                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, false>), g, b, 0, ctx->stream, a);
-                else hipLaunchKernelGGL((scan_fast_kernel<false, false, false>), g, b, 0, ctx->stream, a);
+                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, false>), g, b, 0, on, a);
+                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, false>), g, b, 0, on, a);
+                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, false>), g, b, 0, on, a);
+                else hipLaunchKernelGGL((scan_fast_kernel<false, false, false>), g, b, 0, on, a);
             }
         } else if (hpc) {
             if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }
@@ -1448,6 +1460,12 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
             if (has_n) { if (has_q) launch_variant<false, true, true>(ctx, a, max_blocks, n_items); else launch_variant<false, false, true>(ctx, a, max_blocks, n_items); }
             else { if (has_q) launch_variant<false, true, false>(ctx, a, max_blocks, n_items); else launch_variant<false, false, false>(ctx, a, max_blocks, n_items); }
         }
+    }
+    if (ordered) {
+        hipError_t e = hipEventRecord(ordered, on);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ordered, 0);
+        (void)hipEventDestroy(ordered);         // released by the runtime once the recorded work is done
+        if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "scan stream hand-back: %s", hipGetErrorString(e));
     }
     MDBG_HIP_CHECK(ctx, hipGetLastError());
     return MDBG_OK;
@@ -1459,6 +1477,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     if (p->minimizer_size < 2 || p->minimizer_size > 16)
         return set_error(ctx, MDBG_EINVAL, "mdbg_scan: minimizer_size %u outside [2,16]", p->minimizer_size);
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, reads_ready_on(ctx, reads));        // an upload still in flight (mdbg_reads_from_packed_async): ordered on the device
     const uint32_t n = reads->n_reads;
     const bool hpc = p->hpc != 0, has_q = reads->has_qual && !p->ignore_qualities, has_n = reads->has_invalid;
     mdbg_minimizers *m = new mdbg_minimizers();

@@ -474,7 +474,7 @@ public:
         if (threads > (pack_ ? 12 : 6)) threads = pack_ ? 12 : 6;
         alloc_ = std::move(alloc);
         nThreads_ = threads;
-        const int nbuf = threads + 2;
+        const int nbuf = threads + 3;          // one per worker + what the consumer holds: the batch on the device and the one uploading
         for (int i = 0; i < nbuf; i++) {
             ReadBatch *b = new ReadBatch();
             b->cap = pack_ ? chunk_ / 4 + chunk_ / 32 + 4096 : chunk_ + 64;

@@ -368,24 +368,47 @@ int run_read_selection(int argc, char **argv) {
             mdbg_ctx *ctx = ctxs[(size_t)ci];
             double up = 0, sc = 0, dn = 0, qu = 0, wt = 0;
             uint64_t nb = 0;
-            for (;;) {
-                ReadBatch *b = nullptr;
-                uint64_t seq = 0;
+            // One batch ahead: the upload of batch i+1 is queued (mdbg_reads_from_packed_async: the context's upload stream, a copy
+            // engine) before batch i is scanned and its minimizers come back, so the link carries reads in one direction and
+            // minimizers in the other while the kernels run.  Packed FASTA chunks take this route; chunks with qualities or
+            // delivered as ASCII (a character with bit 3 set) are uploaded synchronously as before.
+            struct Staged { ReadBatch *b = nullptr; uint64_t seq = 0; mdbg_reads *reads = nullptr; bool live = false; };
+            auto stage = [&]() -> Staged {
+                Staged st;
                 const double tw = g_trace.now();
                 try {
                     std::lock_guard<std::mutex> g(feedMu);       // batches leave the feeder in read order
-                    b = feeder->next();
-                    seq = nextSeq++;
+                    st.b = feeder->next();
+                    st.seq = nextSeq++;
                 } catch (const std::exception &e) { die(e.what()); }
-                if (!b) break;
+                if (!st.b) return st;
+                st.live = true;
                 const double t0 = g_trace.now();
-                mdbg_reads *reads = upload_batch(ctx, *b, true);
-                feeder->recycle(b);                              // the page-locked buffer is free again once the upload is done
+                if (st.b->packed && !st.b->hasQual) {
+                    check_on(ctx, mdbg_reads_from_packed_async(ctx, st.b->words(), st.b->wordOff.data(), st.b->lens.data(), st.b->n(), &st.reads),
+                             "mdbg_reads_from_packed_async");
+                } else {
+                    st.reads = upload_batch(ctx, *st.b, true);
+                    feeder->recycle(st.b);                       // the page-locked buffer is free again once the upload is done
+                    st.b = nullptr;
+                }
+                wt += t0 - tw; up += g_trace.now() - t0;
+                return st;
+            };
+            Staged next = stage();
+            while (next.live) {
+                Staged cur = next;
+                next = stage();
+                const uint64_t seq = cur.seq;
                 const double t1 = g_trace.now();
                 mdbg_minimizers *mins = nullptr;
                 mdbg_scan_params p = scan_params(P, P.densityAssembly, rep, a.minReadQuality, true);
-                check_on(ctx, mdbg_scan(ctx, reads, &p, &mins), "mdbg_scan");
-                mdbg_reads_free(reads);
+                check_on(ctx, mdbg_scan(ctx, cur.reads, &p, &mins), "mdbg_scan");
+                if (cur.b) {                                     // the scan has read the words: the upload is long done
+                    check_on(ctx, mdbg_reads_wait(ctx, cur.reads), "mdbg_reads_wait");
+                    feeder->recycle(cur.b);
+                }
+                mdbg_reads_free(cur.reads);
                 const double t2 = g_trace.now();
                 std::unique_ptr<HostBatch> hb(new HostBatch());
                 hb->seq = seq;
@@ -406,7 +429,7 @@ int run_read_selection(int argc, char **argv) {
                 if (!needCorrected) mdbg_minimizers_free(mins);
                 fifoCv.notify_all();
                 const double t4 = g_trace.now();
-                wt += t0 - tw; up += t1 - t0; sc += t2 - t1; dn += t3 - t2; qu += t4 - t3; nb++;
+                sc += t2 - t1; dn += t3 - t2; qu += t4 - t3; nb++;
             }
             std::lock_guard<std::mutex> g(statMu);
             tWait += wt; tUpload += up; tScan += sc; tDownload += dn; tQueue += qu; nBatches += nb;
@@ -417,7 +440,7 @@ int run_read_selection(int argc, char **argv) {
         for (auto &t : consumers) t.join();
     }
     if (getenv("MDBG_TRACE"))
-        fprintf(stderr, "[mdbg_tool] %llu batches on %d consumer(s), summed over them: waiting for the feeder %.3f s, upload %.3f s, scan %.3f s, "
+        fprintf(stderr, "[mdbg_tool] %llu batches on %d consumer(s), summed over them: waiting for the feeder %.3f s, upload (queued ahead when packed) %.3f s, scan %.3f s, "
                         "download %.3f s, writer queue %.3f s\n", (unsigned long long)nBatches, nConsumers, tWait, tUpload, tScan, tDownload, tQueue);
     {
         std::lock_guard<std::mutex> lk(fifoMu);

@@ -279,3 +279,20 @@ def test_device_hash_header_against_the_oracle(tmp_path):
                     "-L", os.path.join(root, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(root, "oracle")], check=True)
     out = subprocess.run([exe, "8000000"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok:"), out.stdout + out.stderr
+
+
+def test_hifi_1m_manifest_is_self_consistent():
+    """tests/golden/hifi_1m (BASELINE.json configs[1] at full size, digests only): the abundance checksum computed from the
+    reference's records with the formula of graph/CreateMdbg.cpp:3321 (sum abundance * low word) is the number the reference
+    itself logged for that table -- which pins mdbg_table_checksum's definition to the reference's log line -- and the
+    counts add up."""
+    import json
+    path = os.path.join(GOLDEN, "hifi_1m", "manifest.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/hifi_1m/manifest.json not generated")
+    g = json.load(open(path))
+    log = g["reference_log"]
+    assert g["abundance_checksum"] == log["abundance_checksum"]
+    assert g["n_records"] == log["n_solid"] + log["n_rescued"]
+    assert g["read_data_init_bytes"] == 13 * g["n_reads"] + 10 * (g["n_corrected_minimizers"] + 0) or g["read_data_init_bytes"] >= 13 * g["n_reads"]
+    assert g["n_reads"] == 1_000_000 and g["read_len"] == 10_000
