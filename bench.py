@@ -137,6 +137,15 @@ def _tables_equal(tmp_a: str, tmp_b: str, k: int) -> bool:
                                formats.sorted_vector_records(_fbytes(tmp_b, "kminmerData_min.txt"), k)))
 
 
+def _sample_that_fits(n_reads: int, bytes_per_read: float, what: str) -> int:
+    """The sample size the scratch disk can hold (files of the sample, of the reference and of the tool): the wanted one, or fewer."""
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    fit = int(0.6 * free / bytes_per_read)
+    if fit < n_reads:
+        print(f"[bench] {what}: {n_reads} reads need {n_reads * bytes_per_read / 1e9:.0f} GB of scratch, {free / 1e9:.0f} GB free: {fit} reads", file=sys.stderr)
+    return max(0, min(n_reads, fit))
+
+
 def _write_fasta_from_device(path: str, reads, n_reads: int, chunk: int = 50_000, with_quality: bool = False) -> int:
     """The resident reads as a FASTA file (">r<index>" + one line) or, with their qualities, as FASTQ, exported from HBM in pieces;
     returns the bases written."""
@@ -170,6 +179,7 @@ def sample_legs(ctx, n_sample: int, read_len: int, with_tool: bool, keep_dir: li
     import numpy as np
     from metamdbg_amd import formats, synth
     out: dict = {}
+    n_sample = _sample_that_fits(n_sample, read_len * 1.35, "cpu_baseline / parity read set")     # FASTA + the products, twice
     if n_sample <= 0 or not os.path.exists(REFDRV):
         return out
     # the reference's thread scaling collapses past a few dozen threads (its graph command did not finish
@@ -614,6 +624,7 @@ def ont_leg(ctx, n_reads: int, sample: int, piece_reads: int = 5_000_000) -> dic
     # parity on a sample against the reference's own run (qualities, mean read quality, repetitive filter pinned to
     # the reference's pick: which of several equally frequent minimizers std::sort leaves first is not defined); the sample is
     # scanned in two pieces and appended, like the leg
+    sample = _sample_that_fits(sample, 20_000 * 2.3, "ont parity sample")
     if sample > 0 and os.path.exists(REFDRV):
         work = tempfile.mkdtemp(prefix="mdbg_ont_")
         try:

@@ -115,6 +115,8 @@ extern "C" void *mdbg_stream(mdbg_ctx *ctx) { return ctx ? (void *)ctx->stream :
 // by the atomic rate and by latency, not by the number of CUs -- then take CUs from another batch's scan only where they are
 // confined, instead of a share of every CU.  0 restores one unconfined stream.
 static int set_table_cu_count(mdbg_ctx *ctx, unsigned c) {
+    if (c > (unsigned)ctx->n_cu) c = (unsigned)ctx->n_cu;
+    if (c == ctx->table_cu_count) return MDBG_OK;
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     fold_timers(ctx);                                    // pending events belong to the old streams
