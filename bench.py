@@ -1147,15 +1147,21 @@ def main() -> None:
         legs = {}
         if "end_to_end" in side:
             legs["end_to_end"] = side["end_to_end"]
+        def leg(name, fn):
+            """A leg that breaks (a resource limit on this box, a time-out of the reference) is reported as such and does not take
+            the line down with it; a PARITY failure inside a leg is a SystemExit and does."""
+            try:
+                run_alone(ctx)
+                legs[name] = fn()
+            except Exception as exc:
+                legs[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                print(f"[bench] leg {name} failed: {exc}", file=sys.stderr)
         if "multik" in legs_on:
-            run_alone(ctx)
-            legs["multik"] = multik_leg(ctx, reads, n_bases)
+            leg("multik", lambda: multik_leg(ctx, reads, n_bases))
         if "multik_reference" in legs_on:
-            run_alone(ctx)
-            legs["multik_reference"] = multik_reference_leg(ctx, min(args.multik_sample, args.cpu_sample), args.read_len)
+            leg("multik_reference", lambda: multik_reference_leg(ctx, min(args.multik_sample, args.cpu_sample), args.read_len))
         if "pcie" in legs_on:
-            run_alone(ctx)
-            legs["pcie"] = pcie_leg(ctx, reads, spec, local_rank)
+            leg("pcie", lambda: pcie_leg(ctx, reads, spec, local_rank))
         if "ont" in legs_on:
             # the HiFi batch and the other contexts' pools make room first
             for c, _ in slots[1:]:
@@ -1163,7 +1169,11 @@ def main() -> None:
             reads.free()
             ctx.close()
             octx = capi.Context(local_rank)
-            legs["ont"] = ont_leg(octx, args.ont_reads, sample=min(args.ont_sample, args.cpu_sample))
+            try:
+                legs["ont"] = ont_leg(octx, args.ont_reads, sample=min(args.ont_sample, args.cpu_sample))
+            except Exception as exc:
+                legs["ont"] = {"error": f"{type(exc).__name__}: {exc}"}
+                print(f"[bench] leg ont failed: {exc}", file=sys.stderr)
             octx.close()
         total_bases = n_bases * world * args.steps
         traffic, traffic_note = measured_traffic(args.reads, args.read_len)
