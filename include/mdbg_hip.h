@@ -59,6 +59,9 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
  *                           several contexts in flight on one device (the other batches' table kernels then displace a running
  *                           scan on those CUs only).  Call it between steps: it synchronises and re-creates the stream, so a
  *                           handle obtained from mdbg_stream before is dead.  Default 0: one unconfined stream
+ *   "pool_cache_percent"    the context keeps freed device blocks for reuse up to this share of the device memory (default 55:
+ *                           several contexts share a device; a context that has the device to itself may take 90)
+ *   "pool_trim"             any value: the blocks kept for reuse are given back to the device now
  *   "scan_reads_per_wave"   reads a scan wave processes before it retires (default 2)
  *   "scan_candidate_slack"  tests only: the block-structured scan records candidate positions by the upper half of the
  *                           hash and confirms each with the full hash; a read with a false candidate is re-run.  False
@@ -94,7 +97,8 @@ int  mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const char *quals, 
 int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets,
                             const uint32_t *lengths, uint32_t n_reads, mdbg_reads **out);
 /* The same without waiting for the copies: they are queued on an upload stream of the context (a copy engine: they run beside
- * the kernels of the context's own stream) and the call returns.  `words` and `lengths` must stay untouched until
+ * the kernels of the context's own stream) and the call returns (offsets and lengths are copied before it does; the words are
+ * what travels behind the caller's back).  `words` must stay untouched until
  * mdbg_reads_wait returns (or the reads are freed); page-locked memory (mdbg_host_alloc) is what makes the copy asynchronous.
  * Calls that consume the reads order themselves after the upload: mdbg_scan on the device, without a host wait -- so a feeder
  * uploads batch i+1 while batch i is scanned, inside one context: the replacement of the reference's one-reader critical

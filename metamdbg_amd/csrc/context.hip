@@ -142,6 +142,18 @@ static int set_table_cu_count(mdbg_ctx *ctx, unsigned c) {
 extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: null argument");
     const std::string n(name);
+    if (n == "pool_cache_percent") {
+        const int64_t pc = value > 0 ? std::min<int64_t>(value, 95) : 55;
+        std::lock_guard<std::mutex> g(ctx->pool->mu);
+        ctx->pool->cache_limit = std::max<size_t>((size_t)96 << 30, (size_t)((double)ctx->hbm_bytes * (double)pc / 100.0));
+        return MDBG_OK;
+    }
+    if (n == "pool_trim") {
+        MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->pool->trim();
+        return MDBG_OK;
+    }
     if (n == "table_cu_count") return set_table_cu_count(ctx, value > 0 ? (unsigned)std::min<int64_t>(value, 4096) : 0u);
     if (n == "table_blocks_per_cu") { ctx->table_blocks_per_cu = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 1024u; return MDBG_OK; }
     if (n == "scan_wave_priority") { ctx->scan_wave_priority = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }

@@ -331,12 +331,16 @@ int exchange_impl(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint6
         }
         MDBG_TRY(all_to_all(ctx, api, comm, d_reply, roff, got, comm->replies.p, soff, s_cnt));
     }
-    if (ctx->test_corrupt_replies && n_sent) {      // tests: one global count off by one
-        ctx->test_corrupt_replies = false;
-        uint64_t v = 0;
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &v, comm->replies.p + n_sent / 2, 8, hipMemcpyDeviceToHost));
-        v += 1;
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, comm->replies.p + n_sent / 2, &v, 8, hipMemcpyHostToDevice));
+    if (ctx->test_corrupt_replies && n_sent) {      // tests: the global count of one key this rank was told to LIST is off by one
+        ctx->test_corrupt_replies = false;          // (a wrong count for a key another rank lists never reaches a table)
+        std::vector<uint64_t> h(n_sent);
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h.data(), comm->replies.p, n_sent * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n_sent; i++)
+            if (h[i] >> 63) {
+                h[i] += 1;
+                MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, comm->replies.p + i, &h[i], 8, hipMemcpyHostToDevice));
+                break;
+            }
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     MDBG_DBG(ctx, "shard_exchange: done");

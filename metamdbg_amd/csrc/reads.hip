@@ -328,9 +328,11 @@ extern "C" int mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words
     MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipError_t e = hipEventRecord(ev, ctx->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->upload_stream, ev, 0);
-    if (e == hipSuccess && r->n_words) e = hipMemcpyAsync(r->d_words.p, words + base, r->n_words * 8, hipMemcpyHostToDevice, ctx->upload_stream);
+    // the two small arrays first: they usually sit in pageable memory, and a copy from pageable memory returns only when it is
+    // done -- queued behind the words it made this call wait for the whole upload (round 3: the pipelined PCIe leg overlapped nothing)
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_word_off.p, r->h_rel.data(), r->h_rel.size() * 8, hipMemcpyHostToDevice, ctx->upload_stream);
     if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->d_len.p, lengths, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess && r->n_words) e = hipMemcpyAsync(r->d_words.p, words + base, r->n_words * 8, hipMemcpyHostToDevice, ctx->upload_stream);
     if (e == hipSuccess) e = hipEventRecord(ev, ctx->upload_stream);
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(ctx->upload_stream);

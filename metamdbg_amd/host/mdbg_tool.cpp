@@ -655,6 +655,7 @@ int run_graph(int argc, char **argv) {
     std::vector<uint64_t> offs;
     parse_minimizer_reads(read_file(dir + "/read_data_corrected.txt", true), mins, offs);
     const size_t nReads = offs.size() - 1;
+    g_trace.mark("graph: read_data_corrected.txt read and parsed");
     PrevInputs in;
     if (!a.firstPass) load_prev_inputs(dir, in);
     // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
@@ -667,7 +668,9 @@ int run_graph(int argc, char **argv) {
     std::vector<RankTable> parts((size_t)G);
     if (!sharded) {
         check(mdbg_create(0, &g_ctx), "mdbg_create");
+        g_trace.mark("graph: context created");
         graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0]);
+        g_trace.mark("graph: table built and copied back");
     } else {
         uint8_t id[MDBG_COMM_ID_BYTES];
         check(mdbg_comm_unique_id(id), "mdbg_comm_unique_id");
@@ -731,8 +734,10 @@ int run_graph(int argc, char **argv) {
     // graph/CreateMdbg.cpp:515-522
     if (a.firstPass) write_records("/kminmerData_abundance_init.txt");
     if (k == P.firstK + 1) write_records("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
+    g_trace.mark("graph: tables written");
     write_perf(dir);
     mdbg_destroy(g_ctx);
+    g_trace.mark("graph: done");
     return 0;
 }
 

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Steady-state end-to-end measurement of the C++ drop-in (mdbg_tool readSelection + graph --firstpass) from files in /dev/shm
+(page cache), tool only, with the tool's own phase trace (MDBG_TRACE=1):
+
+    python tools/e2e_steady.py --reads 5000000 --fastq-reads 2000000 --gz-reads 1000000 --threads 32,64 --out gpurun_out/e2e.json
+
+  fasta   n x 10 kb synthetic HiFi reads as plain FASTA (50 Gbp at the default)
+  fastq   the same preset with qualities (1 byte per base more over the link; mean read quality, per-minimizer minimum)
+  gzip    the first --gz-reads reads of the FASTA as an ordinary multi-member gzip stream (gzip -1, members compressed by a process
+          pool and concatenated, as `cat a.gz b.gz` would): the several-threads decoder of host/gzip_parallel.hpp at size
+The reference is not run here (bench.py times it on 10 Gbp: cpu_baseline); this tool never touches oracle/."""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TOOL = os.path.join(ROOT, "metamdbg_amd", "bin", "mdbg_tool")
+
+
+def write_reads(path, ctx, spec, n, with_quality):
+    reads = ctx.reads_synthetic(spec)
+    t0 = time.perf_counter()
+    with open(path, "wb") as f:
+        step = 50_000
+        for r0 in range(0, n, step):
+            c = min(step, n - r0)
+            b, o = reads.export_ascii(r0, c)
+            if with_quality:
+                q = reads.export_qualities(r0, c)
+                f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (r0 + r, b[int(o[r]):int(o[r + 1])].tobytes(), q[int(o[r]):int(o[r + 1])].tobytes()) for r in range(c)))
+            else:
+                f.write(b"".join(b">r%d\n%s\n" % (r0 + r, b[int(o[r]):int(o[r + 1])].tobytes()) for r in range(c)))
+    reads.free()
+    return time.perf_counter() - t0
+
+
+def _gz_member(args):
+    path, a, b = args
+    with open(path, "rb") as f:
+        f.seek(a)
+        raw = f.read(b - a)
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    return co.compress(raw) + co.flush()
+
+
+def run_tool(tmp_parent, inputs, threads, P, trace=True):
+    from metamdbg_amd import formats
+    tmp = os.path.join(tmp_parent, "tmp")
+    shutil.rmtree(tmp_parent, ignore_errors=True)
+    for d in ("", "filter", "smallContigs", "checkpoints"):
+        os.makedirs(os.path.join(tmp, d), exist_ok=True)
+    P.save(os.path.join(tmp, "parameters.gz"))
+    open(os.path.join(tmp, "input.txt"), "w").write("\n".join(inputs) + "\n")
+    env = dict(os.environ, MDBG_TRACE="1") if trace else dict(os.environ)
+    t0 = time.perf_counter()
+    r1 = subprocess.run([TOOL, "readSelection", tmp, tmp + "/read_data_init.txt", tmp + "/input.txt", "--threads", str(threads),
+                         "--min-read-quality", "0.000000"], capture_output=True, text=True, env=env)
+    t1 = time.perf_counter()
+    assert r1.returncode == 0, r1.stderr[-1000:]
+    r2 = subprocess.run([TOOL, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], capture_output=True, text=True, env=env)
+    t2 = time.perf_counter()
+    assert r2.returncode == 0, r2.stderr[-1000:]
+    sizes = {n: os.path.getsize(os.path.join(tmp, n)) for n in ("read_data_init.txt", "read_data_corrected.txt", "kminmerData_abundance.txt", "kminmerData_min.txt")}
+    return {"read_selection_s": t1 - t0, "graph_s": t2 - t1, "total_s": t2 - t0,
+            "trace_read_selection": [ln.strip() for ln in r1.stderr.splitlines() if "[mdbg_tool]" in ln],
+            "trace_graph": [ln.strip() for ln in r2.stderr.splitlines() if "[mdbg_tool]" in ln], "output_bytes": sizes}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=5_000_000)
+    ap.add_argument("--fastq-reads", type=int, default=2_000_000)
+    ap.add_argument("--gz-reads", type=int, default=1_000_000)
+    ap.add_argument("--threads", default="32,64")
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    from metamdbg_amd import capi, formats, synth
+    work = tempfile.mkdtemp(prefix="mdbg_e2e_", dir=a.dir)
+    res = {"host_threads": os.cpu_count(), "dir": a.dir}
+    try:
+        P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+        threads = [int(t) for t in a.threads.split(",")]
+        ctx = capi.Context(0)
+        if a.reads:
+            spec = synth.hifi_spec(a.reads, seed=42, read_len=10_000, coverage=50.0)
+            fasta = os.path.join(work, "reads.fasta")
+            res["fasta_write_s"] = write_reads(fasta, ctx, spec, a.reads, False)
+        if a.fastq_reads:
+            qspec = dataclasses.replace(synth.hifi_spec(a.fastq_reads, seed=42, read_len=10_000, coverage=50.0), with_quality=True)
+            fastq = os.path.join(work, "reads.fastq")
+            res["fastq_write_s"] = write_reads(fastq, ctx, qspec, a.fastq_reads, True)
+        ctx.close()
+
+        def best_of(inputs, n_reads, label, reps=2):
+            out = {}
+            for t in threads:
+                runs = [run_tool(os.path.join(work, "run"), inputs, t, P) for _ in range(reps)]
+                b = min(runs, key=lambda r: r["total_s"])
+                gbp = n_reads * 10_000 / 1e9
+                b.update(gbp=gbp, gbps=gbp / b["total_s"], read_selection_gbps=gbp / b["read_selection_s"], all_total_s=[round(r["total_s"], 3) for r in runs])
+                out[f"threads_{t}"] = b
+                print(label, t, "threads: %.2f s total (readSelection %.2f, graph %.2f) = %.1f Gbp/s" % (b["total_s"], b["read_selection_s"], b["graph_s"], b["gbps"]), file=sys.stderr, flush=True)
+            return out
+        if a.reads:
+            res["fasta"] = best_of([fasta], a.reads, "fasta")
+        if a.fastq_reads:
+            res["fastq"] = best_of([fastq], a.fastq_reads, "fastq")
+        if a.gz_reads and a.reads:
+            import multiprocessing as mp
+            n = min(a.gz_reads, a.reads)
+            # member borders at record starts: every record of r<index> is 10 002 + len(">r<index>") bytes; find them by scanning for "\n>"
+            size_est = 0
+            with open(fasta, "rb") as f:
+                # byte offset of read n: walk in big strides (records are ~10 kB)
+                pos, k = 0, 0
+                bounds = [0]
+                per = max(1, n // 32)
+                while k < n:
+                    step = min(per, n - k)
+                    # records k .. k+step: sizes are 1 + len(str(i)) + 1 + 10000 + 1
+                    pos += sum(len(str(i)) for i in range(k, k + step)) + step * 10_003
+                    k += step
+                    bounds.append(pos)
+            t0 = time.perf_counter()
+            with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
+                parts = pool.map(_gz_member, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
+            gz = os.path.join(work, "reads.fasta.gz")
+            with open(gz, "wb") as f:
+                for p in parts:
+                    f.write(p)
+            res["gzip_compress_s"] = time.perf_counter() - t0
+            res["gzip_bytes"] = os.path.getsize(gz)
+            res["gzip_members"] = len(parts)
+            del parts
+            res["gzip"] = best_of([gz], n, "gzip", reps=1)
+            res["gzip_matches_plain"] = None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    line = json.dumps(res)
+    if a.out:
+        open(a.out, "w").write(line + "\n")
+    print(line)
+
+
+if __name__ == "__main__":
+    main()
