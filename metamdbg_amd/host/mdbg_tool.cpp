@@ -53,6 +53,13 @@ namespace {
 
 mdbg_ctx *g_ctx = nullptr;
 
+// Every output file is written and closed: the process ends here.  Tearing the HIP contexts and their memory pools down block by
+// block (mdbg_destroy) took 0.2 s of a 2.6 s run over 50 Gbp; the driver reclaims a process's device memory when it exits.
+[[noreturn]] void finish() {
+    fflush(nullptr);
+    _exit(0);
+}
+
 // phase timings on stderr when MDBG_TRACE is set
 struct Trace {
     double t0;
@@ -293,18 +300,44 @@ int run_read_selection(int argc, char **argv) {
     // writes them in batch order while later batches are on the device.  One consumer is the default: at 28 GB/s of
     // FASTA the pass is bound by the parser workers and the page-locked buffers, and a second consumer measured no
     // faster (profiles/r01f_tool_consumers.json); MDBG_TOOL_CONSUMERS=2..4 is there for slower-to-scan inputs.
+    // the arrays of one batch in ONE page-locked slab (the download is plain DMA, nothing is zero-filled); slabs go round between
+    // the consumers and the writer
     struct HostBatch {
         uint64_t seq = 0;
         uint32_t n = 0; uint64_t t = 0;
-        std::vector<uint64_t> off; std::vector<uint32_t> m, pos, len; std::vector<uint8_t> dir, qual, flags; std::vector<float> meanQ;
+        char *slab = nullptr; size_t cap = 0;
+        uint64_t *off = nullptr; uint32_t *m = nullptr, *pos = nullptr, *len = nullptr; uint8_t *dir = nullptr, *qual = nullptr, *flags = nullptr; float *meanQ = nullptr;
+        void shape(uint32_t n_, uint64_t t_) {
+            n = n_; t = t_;
+            const size_t need = ((size_t)n + 1) * 8 + t * 8 + (size_t)n * 8 + ((t + 7) & ~(size_t)7) * 2 + (((size_t)n + 7) & ~(size_t)7) + 64;
+            if (need > cap) {
+                if (slab) mdbg_host_free(g_ctx, slab);
+                cap = need + need / 4;
+                void *p = nullptr;
+                check(mdbg_host_alloc(g_ctx, cap, &p), "mdbg_host_alloc");
+                slab = (char *)p;
+            }
+            char *q = slab;
+            off = (uint64_t *)q; q += ((size_t)n + 1) * 8;
+            m = (uint32_t *)q; q += t * 4;
+            pos = (uint32_t *)q; q += t * 4;
+            len = (uint32_t *)q; q += (size_t)n * 4;
+            meanQ = (float *)q; q += (size_t)n * 4;
+            dir = (uint8_t *)q; q += (t + 7) & ~(size_t)7;
+            qual = (uint8_t *)q; q += (t + 7) & ~(size_t)7;
+            flags = (uint8_t *)q;
+        }
     };
+    std::vector<HostBatch *> spareBatches;        // guarded by fifoMu
     struct Kept { uint64_t seq; mdbg_ctx *ctx; mdbg_minimizers *mins; };
     std::vector<Kept> kept;                 // device-resident minimizer reads, purged once N50 is known
     // --gpus G: one consumer per device; batches go to the consumers in turn, every batch is scanned (and later purged) where it
     // landed, and the ordered writer, N50 and read_stats.txt see the batches in read order whatever device produced them
     // (contiguous read ranges, stats reduced on the host).
-    int nConsumers = std::max(1, a.gpus);
-    if (const char *e = getenv("MDBG_TOOL_CONSUMERS")) nConsumers = std::max(nConsumers, std::max(1, std::min(4 * std::max(1, a.gpus), atoi(e))));
+    // two consumers per device by default: with the parsers packing on 12 threads it is the consumer -- upload, scan, download, hand-over,
+    // per batch of a few thousand reads -- that a 50 Gbp pass waits for (round 3: the parsers were idle 60 % of the time)
+    int nConsumers = std::max(1, a.gpus) * (a.threads >= 8 ? 2 : 1);
+    if (const char *e = getenv("MDBG_TOOL_CONSUMERS")) nConsumers = std::max(std::max(1, a.gpus), std::min(4 * std::max(1, a.gpus), atoi(e)));
     std::vector<mdbg_ctx *> ctxs{g_ctx};
     for (int i = 1; i < nConsumers; i++) {
         mdbg_ctx *c = nullptr;
@@ -312,7 +345,7 @@ int run_read_selection(int argc, char **argv) {
         ctxs.push_back(c);
     }
 
-    std::map<uint64_t, std::unique_ptr<HostBatch>> pending;     // finished batches waiting for their turn at the writer
+    std::map<uint64_t, HostBatch *> pending;     // finished batches waiting for their turn at the writer
     uint64_t nextWrite = 0;
     std::mutex fifoMu;
     std::condition_variable fifoCv;
@@ -320,13 +353,13 @@ int run_read_selection(int argc, char **argv) {
     std::thread writer([&] {
         std::string rec;
         for (;;) {
-            std::unique_ptr<HostBatch> hb;
+            HostBatch *hb = nullptr;
             {
                 std::unique_lock<std::mutex> lk(fifoMu);
                 fifoCv.wait(lk, [&] { return pending.count(nextWrite) || (fifoDone && pending.empty()); });
                 auto it = pending.find(nextWrite);
                 if (it == pending.end()) return;
-                hb = std::move(it->second);
+                hb = it->second;
                 pending.erase(it);
                 nextWrite++;
             }
@@ -338,10 +371,10 @@ int run_read_selection(int argc, char **argv) {
                 const uint32_t k = (uint32_t)(hb->off[r + 1] - s0);
                 const uint8_t circ = 0;
                 rec.append((const char *)&k, 4); rec.append((const char *)&circ, 1);
-                rec.append((const char *)(hb->m.data() + s0), (size_t)k * 4);
-                rec.append((const char *)(hb->pos.data() + s0), (size_t)k * 4);
-                rec.append((const char *)(hb->dir.data() + s0), k);
-                rec.append((const char *)(hb->qual.data() + s0), k);
+                rec.append((const char *)(hb->m + s0), (size_t)k * 4);
+                rec.append((const char *)(hb->pos + s0), (size_t)k * 4);
+                rec.append((const char *)(hb->dir + s0), k);
+                rec.append((const char *)(hb->qual + s0), k);
                 rec.append((const char *)&hb->meanQ[r], 4);
                 rec.append((const char *)&hb->len[r], 4);
                 allReadSizes.push_back(hb->len[r]);
@@ -349,6 +382,10 @@ int run_read_selection(int argc, char **argv) {
                 nbKmers += (uint64_t)((size_t)hb->len[r] - P.minimizerSize + 1);   // size_t arithmetic as in :480
                 nbBases += hb->len[r];
                 if (!(hb->flags[r] & MDBG_READ_LOW_QUALITY)) { qualitySum += hb->meanQ[r]; qualityN += 1; }   // :911-914
+            }
+            {
+                std::lock_guard<std::mutex> lk(fifoMu);
+                spareBatches.push_back(hb);                  // its slab serves a later batch
             }
             out.write(rec.data(), (std::streamsize)rec.size());
         }
@@ -410,21 +447,26 @@ int run_read_selection(int argc, char **argv) {
                 }
                 mdbg_reads_free(cur.reads);
                 const double t2 = g_trace.now();
-                std::unique_ptr<HostBatch> hb(new HostBatch());
+                HostBatch *hb = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(fifoMu);
+                    if (!spareBatches.empty()) { hb = spareBatches.back(); spareBatches.pop_back(); }
+                }
+                if (!hb) hb = new HostBatch();
                 hb->seq = seq;
-                mdbg_minimizers_info(mins, &hb->n, &hb->t);
-                hb->off.resize((size_t)hb->n + 1);
-                hb->m.resize(hb->t); hb->pos.resize(hb->t); hb->len.resize(hb->n);
-                hb->dir.resize(hb->t); hb->qual.resize(hb->t); hb->flags.resize(hb->n); hb->meanQ.resize(hb->n);
-                check_on(ctx, mdbg_minimizers_to_host(ctx, mins, hb->off.data(), hb->m.data(), hb->pos.data(), hb->dir.data(), hb->qual.data(),
-                                                      hb->len.data(), hb->meanQ.data(), hb->flags.data()), "to_host");
+                {
+                    uint32_t bn; uint64_t bt;
+                    mdbg_minimizers_info(mins, &bn, &bt);
+                    hb->shape(bn, bt);
+                }
+                check_on(ctx, mdbg_minimizers_to_host(ctx, mins, hb->off, hb->m, hb->pos, hb->dir, hb->qual, hb->len, hb->meanQ, hb->flags), "to_host");
                 const double t3 = g_trace.now();
                 {
                     std::unique_lock<std::mutex> lk(fifoMu);
                     if (needCorrected) kept.push_back(Kept{seq, ctx, mins});
                     // bounded, but the batch the writer is waiting for always gets in
                     fifoCv.wait(lk, [&] { return pending.size() < 6 || seq == nextWrite; });
-                    pending.emplace(seq, std::move(hb));
+                    pending.emplace(seq, hb);
                 }
                 if (!needCorrected) mdbg_minimizers_free(mins);
                 fifoCv.notify_all();
@@ -471,34 +513,65 @@ int run_read_selection(int argc, char **argv) {
         const int lastK = compute_last_k(P.densityAssembly, n50, P.firstK, 0);
         std::ofstream corr(tmpDir + "/read_data_corrected.txt", std::ios::binary);
         std::sort(kept.begin(), kept.end(), [](const Kept &x, const Kept &y) { return x.seq < y.seq; });
-        for (const Kept &kp : kept) {
-            mdbg_minimizers *mins = kp.mins;
-            mdbg_minimizers *pur = nullptr;
-            check_on(kp.ctx, mdbg_purge_palindromes(kp.ctx, mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+        // `u32 n; u8 circular = 0; u32 m[n]` per read, built by a few threads into one buffer (the offset of every record is known)
+        auto write_records = [&](const std::vector<uint64_t> &off, const std::vector<uint32_t> &m) {
+            const size_t n = off.size() - 1;
+            std::vector<char> rec((size_t)off[n] * 4 + n * 5);
+            const unsigned nThr = (unsigned)std::max(1, std::min(8, a.threads));
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nThr; t++)
+                pool.emplace_back([&, t] {
+                    for (size_t r = n * t / nThr, r1 = n * (t + 1) / nThr; r < r1; r++) {
+                        const uint32_t k = (uint32_t)(off[r + 1] - off[r]);
+                        char *dst = rec.data() + (size_t)off[r] * 4 + r * 5;
+                        memcpy(dst, &k, 4); dst[4] = 0;
+                        memcpy(dst + 5, m.data() + off[r], (size_t)k * 4);
+                    }
+                });
+            for (auto &th : pool) th.join();
+            corr.write(rec.data(), (std::streamsize)rec.size());
+        };
+        const bool oneDevice = a.gpus <= 1;          // every context sits on device 0
+        if (oneDevice && !kept.empty()) {
+            // every batch purged where it sits, the results appended on the device, ONE copy back (1 500 batches of a 50 Gbp read set
+            // used to be 1 500 purges each followed by its own two downloads and record loop)
+            std::vector<mdbg_minimizers *> purged;
+            purged.reserve(kept.size());
+            for (const Kept &kp : kept) {
+                mdbg_minimizers *pur = nullptr;
+                check_on(kp.ctx, mdbg_purge_palindromes(kp.ctx, kp.mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+                mdbg_minimizers_free(kp.mins);
+                purged.push_back(pur);
+            }
+            mdbg_minimizers *all = nullptr;
+            check(mdbg_minimizers_concat(g_ctx, purged.data(), (uint32_t)purged.size(), &all), "mdbg_minimizers_concat");
+            for (mdbg_minimizers *pm : purged) mdbg_minimizers_free(pm);
             uint32_t n; uint64_t t;
-            mdbg_minimizers_info(pur, &n, &t);
+            mdbg_minimizers_info(all, &n, &t);
             std::vector<uint64_t> off((size_t)n + 1);
             std::vector<uint32_t> m(t);
-            check_on(kp.ctx, mdbg_minimizers_to_host(kp.ctx, pur, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
-            std::string rec;
-            rec.reserve(t * 4 + (size_t)n * 5);
-            for (uint32_t r = 0; r < n; r++) {
-                const uint32_t k = (uint32_t)(off[r + 1] - off[r]);
-                const uint8_t circ = 0;
-                rec.append((const char *)&k, 4); rec.append((const char *)&circ, 1);
-                rec.append((const char *)(m.data() + off[r]), (size_t)k * 4);
+            check(mdbg_minimizers_to_host(g_ctx, all, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
+            mdbg_minimizers_free(all);
+            write_records(off, m);
+        } else {
+            for (const Kept &kp : kept) {
+                mdbg_minimizers *pur = nullptr;
+                check_on(kp.ctx, mdbg_purge_palindromes(kp.ctx, kp.mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+                uint32_t n; uint64_t t;
+                mdbg_minimizers_info(pur, &n, &t);
+                std::vector<uint64_t> off((size_t)n + 1);
+                std::vector<uint32_t> m(t);
+                check_on(kp.ctx, mdbg_minimizers_to_host(kp.ctx, pur, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
+                write_records(off, m);
+                mdbg_minimizers_free(pur);
+                mdbg_minimizers_free(kp.mins);
             }
-            corr.write(rec.data(), (std::streamsize)rec.size());
-            mdbg_minimizers_free(pur);
-            mdbg_minimizers_free(mins);
         }
     }
     g_trace.mark("read_data_corrected.txt written");
     write_perf(tmpDir);
-    for (size_t i = 1; i < ctxs.size(); i++) mdbg_destroy(ctxs[i]);
-    mdbg_destroy(g_ctx);
     g_trace.mark("done");
-    return 0;
+    finish();
 }
 
 // ---- graph ---------------------------------------------------------------------------------------------------------
@@ -506,6 +579,8 @@ int run_read_selection(int argc, char **argv) {
 void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs,
                            std::vector<uint8_t> *circular = nullptr) {
     offs.assign(1, 0);
+    mins.reserve(mins.size() + raw.size() / 4);        // an upper bound: no growing, no copying (a 50 Gbp read set is 0.8 GB of these)
+    offs.reserve(raw.size() / 64 + 16);
     size_t o = 0;
     while (o + 5 <= raw.size()) {
         uint32_t n;
@@ -734,11 +809,11 @@ int run_graph(int argc, char **argv) {
     // graph/CreateMdbg.cpp:515-522
     if (a.firstPass) write_records("/kminmerData_abundance_init.txt");
     if (k == P.firstK + 1) write_records("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
+    small.close();
     g_trace.mark("graph: tables written");
     write_perf(dir);
-    mdbg_destroy(g_ctx);
     g_trace.mark("graph: done");
-    return 0;
+    finish();
 }
 
 }  // namespace
