@@ -105,6 +105,9 @@ int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t
  * section (Commons.hpp:5868-5905) is then bound by the link, not by link + kernels. */
 int  mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint32_t *lengths,
                                   uint32_t n_reads, mdbg_reads **out);
+/* Qualities for reads made by mdbg_reads_from_packed_async, queued behind their words (same rules: `quals` stays untouched until
+ * mdbg_reads_wait; a read has one quality per base, checked at once against the lengths given at upload). */
+int  mdbg_reads_attach_qualities_async(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets);
 int  mdbg_reads_wait(mdbg_ctx *ctx, const mdbg_reads *r);
 /* Phred+33 qualities (Read::_qual) for reads made by mdbg_reads_from_packed: read r = quals[offsets[r] .. offsets[r+1]),
  * offsets[r+1] - offsets[r] must equal its length.  Once per reads object. */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mdbg_reads_from_ascii": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_from_packed": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_from_packed_async": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    "mdbg_reads_attach_qualities_async": (C.c_int, [_P, _P, C.c_char_p, _P]),
     "mdbg_reads_wait": (C.c_int, [_P, _P]),
     "mdbg_reads_attach_qualities": (C.c_int, [_P, _P, C.c_char_p, _P]),
     "mdbg_reads_synthetic": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, C.c_uint32,
@@ -200,6 +201,18 @@ class Context:
             np.cumsum([len(q) for q in quals], out=offs[1:])
             self.check(lib().mdbg_reads_attach_qualities(self.h, h, b"".join(quals), _ptr(offs)))
         return Reads(self, h)
+
+    def reads_from_packed_async(self, words: np.ndarray, word_off: np.ndarray, lens: np.ndarray, quals: bytes | None = None,
+                                qual_off: np.ndarray | None = None) -> "Reads":
+        """The upload is queued on the context's upload stream and the call returns; the arrays must stay alive and untouched until
+        reads.wait() (they are kept on the returned object).  Consumers (scan) order themselves after it on the device."""
+        h = C.c_void_p()
+        self.check(lib().mdbg_reads_from_packed_async(self.h, _ptr(words), _ptr(word_off), _ptr(lens), len(lens), C.byref(h)))
+        r = Reads(self, h)
+        r._keep = (words, word_off, lens, quals, qual_off)
+        if quals is not None:
+            self.check(lib().mdbg_reads_attach_qualities_async(self.h, h, quals, _ptr(qual_off)))
+        return r
 
     def reads_synthetic(self, spec, first_read: int = 0, n_reads: int | None = None) -> "Reads":
         """HBM-resident reads [first_read, first_read + n_reads) of a synth.SynthSpec."""
@@ -466,6 +479,10 @@ class Reads:
         offs = np.zeros(count + 1, dtype=np.uint64)
         self.ctx.check(lib().mdbg_reads_export_ascii(self.ctx.h, self.h, first, count, _ptr(bases), _ptr(offs), C.byref(nb)))
         return bases, offs
+
+    def wait(self) -> None:
+        """An asynchronous upload has arrived (mdbg_reads_wait)."""
+        self.ctx.check(lib().mdbg_reads_wait(self.ctx.h, self.h))
 
     def export_qualities(self, first: int, count: int) -> np.ndarray:
         """phred+33 bytes of reads [first, first+count), concatenated (offsets as export_ascii's)."""

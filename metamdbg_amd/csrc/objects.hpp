@@ -32,7 +32,8 @@ struct mdbg_reads {
     // mdbg_reads_from_packed_async: the upload is queued on the context's upload stream; `ready` is recorded behind it and every
     // consumer orders itself after it (reads_ready_on / reads_ready_host).  h_rel keeps the rebased offsets alive until then.
     hipEvent_t ready = nullptr;
-    std::vector<uint64_t> h_rel;
+    std::vector<uint64_t> h_rel, h_qrel;
+    std::vector<uint32_t> h_len;            // the lengths as uploaded (mdbg_reads_attach_qualities_async checks the qualities against them)
     mdbg_reads() = default;
     mdbg_reads(const mdbg_reads &) = delete;
     mdbg_reads &operator=(const mdbg_reads &) = delete;

@@ -319,6 +319,7 @@ extern "C" int mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words
         if (lengths[i] > r->max_len) r->max_len = lengths[i];
     }
     r->h_rel[n_reads] = r->n_words;
+    r->h_len.assign(lengths, lengths + n_reads);
     MDBG_TRY(r->d_words.alloc(ctx, r->n_words + 2));
     MDBG_TRY(r->d_word_off.alloc(ctx, (size_t)n_reads + 1));
     MDBG_TRY(r->d_len.alloc(ctx, n_reads));
@@ -341,6 +342,42 @@ extern "C" int mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words
     }
     r->ready = ev;
     *out = r.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_reads_attach_qualities_async(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets) try {
+    if (!ctx || !r || (r->n_reads && (!quals || !offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities_async: null argument");
+    if (r->has_qual) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities_async: the reads already carry qualities");
+    if (!r->ready || r->h_len.size() != r->n_reads)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_reads_attach_qualities_async: for reads made by mdbg_reads_from_packed_async");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = r->n_reads;
+    if (!n) return MDBG_OK;
+    r->h_qrel.resize((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; i++) r->h_qrel[i] = offsets[i] - offsets[0];
+    for (uint32_t i = 0; i < n; i++)
+        if (r->h_qrel[i + 1] - r->h_qrel[i] != r->h_len[i])
+            return set_error(ctx, MDBG_EINVAL, "read %u: %llu qualities for %u bases", i, (unsigned long long)(r->h_qrel[i + 1] - r->h_qrel[i]), r->h_len[i]);
+    const uint64_t nb = r->h_qrel[n];
+    MDBG_TRY(r->d_qual.alloc(ctx, nb + 32));
+    MDBG_TRY(r->d_qual_off.alloc(ctx, (size_t)n + 1));
+    // behind the words on the upload stream; `ready` moves behind the qualities.  (The blocks come from the pool: as in
+    // mdbg_reads_from_packed_async the upload is ordered after what the context's stream has queued so far.)
+    hipEvent_t ev = nullptr;
+    MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->upload_stream, ev, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_qual_off.p, r->h_qrel.data(), r->h_qrel.size() * 8, hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess && nb) e = hipMemcpyAsync(r->d_qual.p, quals + offsets[0], nb, hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess) e = hipEventRecord(ev, ctx->upload_stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->upload_stream);
+        (void)hipEventDestroy(ev);
+        return set_error(ctx, MDBG_EHIP, "mdbg_reads_attach_qualities_async: %s", hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(r->ready);        // superseded: the new event is recorded behind everything the old one covered
+    r->ready = ev;
+    r->has_qual = true;
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 

@@ -471,15 +471,16 @@ public:
         // quarter of the chunk (+ padding of every read to a 64-base unit), which pays for 12 packing workers where 6
         // copying ones were the limit; a buffer grows to the full chunk only if its chunk has to be delivered as ASCII.
         gzThreads_ = threads > 24 ? 24 : threads;      // decompression is plain CPU work: it may use more threads than there are buffers
-        if (threads > (pack_ ? 12 : 6)) threads = pack_ ? 12 : 6;
+        // (24 packing workers since round 3: two consumers drain 29 GB/s of FASTA and then wait for the parsers; the buffers are
+        // page-locked by the workers themselves, side by side, the first time each is used)
+        if (threads > (pack_ ? 24 : 6)) threads = pack_ ? 24 : 6;
         alloc_ = std::move(alloc);
         nThreads_ = threads;
         const int nbuf = threads + 3;          // one per worker + what the consumer holds: the batch on the device and the one uploading
         for (int i = 0; i < nbuf; i++) {
             ReadBatch *b = new ReadBatch();
             b->cap = pack_ ? chunk_ / 4 + chunk_ / 32 + 4096 : chunk_ + 64;
-            b->bases = (char *)alloc_(b->cap);      // quality buffers are allocated on first use (FASTQ only)
-            if (!b->bases) throw std::runtime_error("page-locked batch allocation failed");
+            b->bases = nullptr;                     // page-locked on first use (ensure_bases), like the quality buffers (FASTQ only)
             all_.push_back(b);
             freeList_.push_back(b);
         }
@@ -495,7 +496,7 @@ public:
         cvWork_.notify_all(); cvFree_.notify_all(); cvDone_.notify_all();
         if (splitter_.joinable()) splitter_.join();
         for (auto &t : workers_) if (t.joinable()) t.join();
-        for (ReadBatch *b : all_) { free_(b->bases); if (b->quals) free_(b->quals); delete b; }
+        for (ReadBatch *b : all_) { if (b->bases) free_(b->bases); if (b->quals) free_(b->quals); delete b; }
         for (auto &m : maps_) if (m.addr) munmap((void *)m.addr, m.len);
     }
 
@@ -643,7 +644,15 @@ private:
         if (stop_) return nullptr;
         ReadBatch *b = freeList_.back();
         freeList_.pop_back();
+        g.unlock();
+        ensure_bases(b);
         return b;
+    }
+
+    void ensure_bases(ReadBatch *b) {       // outside mu_: page-locking takes about a millisecond per MB
+        if (b->bases) return;
+        b->bases = (char *)alloc_(b->cap);
+        if (!b->bases) throw std::runtime_error("page-locked batch allocation failed");
     }
 
     void deliver(uint64_t seq, ReadBatch *b) {
@@ -819,9 +828,9 @@ private:
         if (!b->quals) { b->quals = (char *)alloc_(chunk_ + 64); if (!b->quals) throw std::runtime_error("page-locked batch allocation failed"); }
     }
     void need_ascii_capacity(ReadBatch *b) {
-        if (b->cap >= chunk_ + 64) return;
-        free_(b->bases);
-        b->cap = chunk_ + 64;
+        if (b->cap >= chunk_ + 64 && b->bases) return;
+        if (b->bases) free_(b->bases);
+        if (b->cap < chunk_ + 64) b->cap = chunk_ + 64;
         b->bases = (char *)alloc_(b->cap);
         if (!b->bases) throw std::runtime_error("page-locked batch allocation failed");
     }
@@ -942,6 +951,7 @@ private:
                     freeList_.pop_back();
                 }
                 cvFree_.notify_all();   // the sequential gzip reader waits for an empty work queue
+                ensure_bases(b);
                 if (!fileDone_[w.file].load()) {
                     if (!pack_ || !parse_packed(w, b)) { b->clear(); parse(w, b); }
                 } else b->file = w.file;

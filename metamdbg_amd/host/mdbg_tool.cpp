@@ -14,7 +14,10 @@
 // Both read <tmpDir>/parameters.gz and write <tmpDir>/perf.bin like Tool::end (Commons.hpp:8088-8107).
 // Exit status: 0 on success, 1 on any failure (the parent aborts on non-zero, Commons.hpp:2862-2876).
 // All compute goes through libmdbg_hip.so; there is no CPU fallback.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -407,7 +410,7 @@ int run_read_selection(int argc, char **argv) {
             uint64_t nb = 0;
             // One batch ahead: the upload of batch i+1 is queued (mdbg_reads_from_packed_async: the context's upload stream, a copy
             // engine) before batch i is scanned and its minimizers come back, so the link carries reads in one direction and
-            // minimizers in the other while the kernels run.  Packed FASTA chunks take this route; chunks with qualities or
+            // minimizers in the other while the kernels run.  Packed chunks take this route, with or without qualities; chunks
             // delivered as ASCII (a character with bit 3 set) are uploaded synchronously as before.
             struct Staged { ReadBatch *b = nullptr; uint64_t seq = 0; mdbg_reads *reads = nullptr; bool live = false; };
             auto stage = [&]() -> Staged {
@@ -421,9 +424,11 @@ int run_read_selection(int argc, char **argv) {
                 if (!st.b) return st;
                 st.live = true;
                 const double t0 = g_trace.now();
-                if (st.b->packed && !st.b->hasQual) {
+                if (st.b->packed) {
                     check_on(ctx, mdbg_reads_from_packed_async(ctx, st.b->words(), st.b->wordOff.data(), st.b->lens.data(), st.b->n(), &st.reads),
                              "mdbg_reads_from_packed_async");
+                    if (st.b->hasQual)
+                        check_on(ctx, mdbg_reads_attach_qualities_async(ctx, st.reads, st.b->quals, st.b->offsets.data()), "mdbg_reads_attach_qualities_async");
                 } else {
                     st.reads = upload_batch(ctx, *st.b, true);
                     feeder->recycle(st.b);                       // the page-locked buffer is free again once the upload is done
@@ -513,60 +518,75 @@ int run_read_selection(int argc, char **argv) {
         const int lastK = compute_last_k(P.densityAssembly, n50, P.firstK, 0);
         std::ofstream corr(tmpDir + "/read_data_corrected.txt", std::ios::binary);
         std::sort(kept.begin(), kept.end(), [](const Kept &x, const Kept &y) { return x.seq < y.seq; });
-        // `u32 n; u8 circular = 0; u32 m[n]` per read, built by a few threads into one buffer (the offset of every record is known)
-        auto write_records = [&](const std::vector<uint64_t> &off, const std::vector<uint32_t> &m) {
-            const size_t n = off.size() - 1;
-            std::vector<char> rec((size_t)off[n] * 4 + n * 5);
-            const unsigned nThr = (unsigned)std::max(1, std::min(8, a.threads));
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nThr; t++)
-                pool.emplace_back([&, t] {
-                    for (size_t r = n * t / nThr, r1 = n * (t + 1) / nThr; r < r1; r++) {
-                        const uint32_t k = (uint32_t)(off[r + 1] - off[r]);
-                        char *dst = rec.data() + (size_t)off[r] * 4 + r * 5;
-                        memcpy(dst, &k, 4); dst[4] = 0;
-                        memcpy(dst + 5, m.data() + off[r], (size_t)k * 4);
-                    }
-                });
-            for (auto &th : pool) th.join();
-            corr.write(rec.data(), (std::streamsize)rec.size());
-        };
-        const bool oneDevice = a.gpus <= 1;          // every context sits on device 0
-        if (oneDevice && !kept.empty()) {
-            // every batch purged where it sits, the results appended on the device, ONE copy back (1 500 batches of a 50 Gbp read set
-            // used to be 1 500 purges each followed by its own two downloads and record loop)
-            std::vector<mdbg_minimizers *> purged;
-            purged.reserve(kept.size());
-            for (const Kept &kp : kept) {
-                mdbg_minimizers *pur = nullptr;
-                check_on(kp.ctx, mdbg_purge_palindromes(kp.ctx, kp.mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
-                mdbg_minimizers_free(kp.mins);
-                purged.push_back(pur);
+        // A second pass shaped like the first: every consumer purges the batches its context holds, copies values and offsets back
+        // into a page-locked slab, and a writer thread builds the `u32 n; u8 circular = 0; u32 m[n]` records in read order while
+        // the next batches are on the device.
+        std::map<uint64_t, HostBatch *> pending2;       // position in read order -> purged batch
+        uint64_t nextWrite2 = 0;
+        bool done2 = false;
+        std::thread writer2([&] {
+            std::string rec;
+            for (;;) {
+                HostBatch *hb = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(fifoMu);
+                    fifoCv.wait(lk, [&] { return pending2.count(nextWrite2) || (done2 && pending2.empty()); });
+                    auto it = pending2.find(nextWrite2);
+                    if (it == pending2.end()) return;
+                    hb = it->second;
+                    pending2.erase(it);
+                    nextWrite2++;
+                }
+                fifoCv.notify_all();
+                rec.resize(hb->t * 4 + (size_t)hb->n * 5);
+                char *dst = &rec[0];
+                for (uint32_t r = 0; r < hb->n; r++) {
+                    const uint32_t k = (uint32_t)(hb->off[r + 1] - hb->off[r]);
+                    memcpy(dst, &k, 4); dst[4] = 0;
+                    memcpy(dst + 5, hb->m + hb->off[r], (size_t)k * 4);
+                    dst += 5 + (size_t)k * 4;
+                }
+                corr.write(rec.data(), (std::streamsize)rec.size());
+                std::lock_guard<std::mutex> lk(fifoMu);
+                spareBatches.push_back(hb);
             }
-            mdbg_minimizers *all = nullptr;
-            check(mdbg_minimizers_concat(g_ctx, purged.data(), (uint32_t)purged.size(), &all), "mdbg_minimizers_concat");
-            for (mdbg_minimizers *pm : purged) mdbg_minimizers_free(pm);
-            uint32_t n; uint64_t t;
-            mdbg_minimizers_info(all, &n, &t);
-            std::vector<uint64_t> off((size_t)n + 1);
-            std::vector<uint32_t> m(t);
-            check(mdbg_minimizers_to_host(g_ctx, all, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
-            mdbg_minimizers_free(all);
-            write_records(off, m);
-        } else {
-            for (const Kept &kp : kept) {
+        });
+        auto purge_own = [&](int ci) {
+            mdbg_ctx *ctx = ctxs[(size_t)ci];
+            for (size_t i = 0; i < kept.size(); i++) {
+                if (kept[i].ctx != ctx) continue;
                 mdbg_minimizers *pur = nullptr;
-                check_on(kp.ctx, mdbg_purge_palindromes(kp.ctx, kp.mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
-                uint32_t n; uint64_t t;
-                mdbg_minimizers_info(pur, &n, &t);
-                std::vector<uint64_t> off((size_t)n + 1);
-                std::vector<uint32_t> m(t);
-                check_on(kp.ctx, mdbg_minimizers_to_host(kp.ctx, pur, off.data(), m.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
-                write_records(off, m);
+                check_on(ctx, mdbg_purge_palindromes(ctx, kept[i].mins, (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+                mdbg_minimizers_free(kept[i].mins);
+                HostBatch *hb = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(fifoMu);
+                    if (!spareBatches.empty()) { hb = spareBatches.back(); spareBatches.pop_back(); }
+                }
+                if (!hb) hb = new HostBatch();
+                uint32_t bn; uint64_t bt;
+                mdbg_minimizers_info(pur, &bn, &bt);
+                hb->shape(bn, bt);
+                check_on(ctx, mdbg_minimizers_to_host(ctx, pur, hb->off, hb->m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
                 mdbg_minimizers_free(pur);
-                mdbg_minimizers_free(kp.mins);
+                {
+                    std::unique_lock<std::mutex> lk(fifoMu);
+                    fifoCv.wait(lk, [&] { return pending2.size() < 8 || i == nextWrite2; });
+                    pending2.emplace((uint64_t)i, hb);
+                }
+                fifoCv.notify_all();
             }
+        };
+        std::vector<std::thread> purgers;
+        for (int i = 1; i < nConsumers; i++) purgers.emplace_back(purge_own, i);
+        purge_own(0);
+        for (auto &t : purgers) t.join();
+        {
+            std::lock_guard<std::mutex> lk(fifoMu);
+            done2 = true;
         }
+        fifoCv.notify_all();
+        writer2.join();
     }
     g_trace.mark("read_data_corrected.txt written");
     write_perf(tmpDir);
@@ -575,26 +595,71 @@ int run_read_selection(int argc, char **argv) {
 }
 
 // ---- graph ---------------------------------------------------------------------------------------------------------
-// "u32 n; u8 circ; u32 m[n]" records (read_data_corrected.txt, unitig_data.txt) -> CSR
-void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs,
-                           std::vector<uint8_t> *circular = nullptr) {
+// "u32 n; u8 circ; u32 m[n]" records (read_data_corrected.txt, unitig_data.txt) -> CSR.  One walk over the record headers for the
+// offsets, then the values are copied by a few threads (a 50 Gbp read set is 0.8 GB of these records: 0.45 s of a 0.75 s `graph` when
+// it was one loop over a zero-filled copy of the file).
+void parse_minimizer_reads(const uint8_t *raw, size_t size, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs,
+                           std::vector<uint8_t> *circular = nullptr, int threads = 1) {
     offs.assign(1, 0);
-    mins.reserve(mins.size() + raw.size() / 4);        // an upper bound: no growing, no copying (a 50 Gbp read set is 0.8 GB of these)
-    offs.reserve(raw.size() / 64 + 16);
+    offs.reserve(size / 64 + 16);
+    std::vector<size_t> at;                       // byte position of every record's values
+    at.reserve(size / 64 + 16);
     size_t o = 0;
-    while (o + 5 <= raw.size()) {
+    uint64_t total = 0;
+    while (o + 5 <= size) {
         uint32_t n;
-        memcpy(&n, raw.data() + o, 4);
+        memcpy(&n, raw + o, 4);
         if (circular) circular->push_back(raw[o + 4]);
         o += 5;
-        if (o + (size_t)n * 4 > raw.size()) die("truncated minimizer read file");
-        const size_t base = mins.size();
-        mins.resize(base + n);
-        if (n) memcpy(mins.data() + base, raw.data() + o, (size_t)n * 4);
+        if (o + (size_t)n * 4 > size) die("truncated minimizer read file");
+        at.push_back(o);
         o += (size_t)n * 4;
-        offs.push_back(mins.size());
+        total += n;
+        offs.push_back(total);
+    }
+    const size_t base = mins.size();
+    mins.resize(base + total);                     // (zero-filled once; the copies below overwrite it)
+    const size_t nRec = at.size();
+    const unsigned nThr = (unsigned)std::max(1, std::min(threads, 16));
+    auto copy = [&](unsigned t) {
+        for (size_t r = nRec * t / nThr, r1 = nRec * (t + 1) / nThr; r < r1; r++) {
+            const size_t k = (size_t)(offs[r + 1] - offs[r]);
+            if (k) memcpy(mins.data() + base + offs[r], raw + at[r], k * 4);
+        }
+    };
+    if (nThr == 1 || total < (1u << 20)) { for (unsigned t = 0; t < nThr; t++) copy(t); }
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nThr; t++) pool.emplace_back(copy, t);
+        for (auto &th : pool) th.join();
     }
 }
+void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs,
+                           std::vector<uint8_t> *circular = nullptr) {
+    parse_minimizer_reads(raw.data(), raw.size(), mins, offs, circular, 1);
+}
+
+// a whole file mapped read-only (no copy, no zero-fill)
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    explicit MappedFile(const std::string &path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) die("File not found: " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) die("cannot stat " + path);
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m == MAP_FAILED) die("cannot map " + path);
+            p = (const uint8_t *)m;
+        }
+        close(fd);
+    }
+    ~MappedFile() { if (p) munmap((void *)p, n); }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
 
 // What `graph` reads besides the reads when k > firstK, parsed once on the host (every rank builds its own device copy).
 struct PrevInputs {
@@ -728,7 +793,10 @@ int run_graph(int argc, char **argv) {
                (a.gpus > 1 ? " --gpus " + std::to_string(a.gpus) : ""));
     std::vector<uint32_t> mins;
     std::vector<uint64_t> offs;
-    parse_minimizer_reads(read_file(dir + "/read_data_corrected.txt", true), mins, offs);
+    {
+        MappedFile corrected(dir + "/read_data_corrected.txt");
+        parse_minimizer_reads(corrected.p, corrected.n, mins, offs, nullptr, std::max(1, a.threads));
+    }
     const size_t nReads = offs.size() - 1;
     g_trace.mark("graph: read_data_corrected.txt read and parsed");
     PrevInputs in;

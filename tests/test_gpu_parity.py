@@ -944,6 +944,37 @@ def test_bulk_export_of_bases_and_qualities(ctx):
             assert reads.get(first + i, with_quality=True) == (seqs[first + i], quals[first + i])
 
 
+def test_async_packed_upload_with_qualities(ctx):
+    """mdbg_reads_from_packed_async + mdbg_reads_attach_qualities_async: the upload queued on the context's upload stream, the scan
+    ordered after it on the device; several batches queued ahead of their scans; the result is the synchronous path's, and the
+    length check of the qualities fails at once."""
+    from metamdbg_amd import capi
+    rng = np.random.default_rng(11)
+    batches = []
+    for _ in range(3):
+        seqs = [synth.CODE2ASCII[rng.integers(0, 4, int(n))] for n in rng.integers(500, 12_000, 300)]
+        quals = [rng.integers(33, 75, len(s)).astype(np.uint8) for s in seqs]
+        words, woff, lens = synth.pack_reads([synth.ascii_to_codes(s) for s in seqs])
+        qoff = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum([len(q) for q in quals], out=qoff[1:])
+        batches.append((seqs, quals, np.ascontiguousarray(words, np.uint64), np.ascontiguousarray(woff, np.uint64),
+                        np.ascontiguousarray(lens, np.uint32), b"".join(q.tobytes() for q in quals), qoff))
+    kw = dict(K=15, density=0.01, hpc=True)
+    queued = [ctx.reads_from_packed_async(b[2], b[3], b[4], b[5], b[6]) for b in batches]        # all three uploads in flight
+    for b, r in zip(batches, queued):
+        got = ctx.scan(r, **kw).to_host()
+        want = ctx.scan(ctx.reads_from_ascii([s.tobytes() for s in b[0]], [q.tobytes() for q in b[1]]), **kw).to_host()
+        for key in want:
+            assert np.array_equal(got[key], want[key], equal_nan=True) if want[key].dtype.kind == "f" else np.array_equal(got[key], want[key]), key
+        assert got["qual"].max() > 1 and len(got["minimizers"]) > 1000
+        r.wait()
+        assert r.get(7, with_quality=True) == (b[0][7].tobytes(), b[1][7].tobytes())
+    b = batches[0]
+    bad = b[6].copy(); bad[5] += 1
+    with pytest.raises(capi.MdbgError):
+        ctx.reads_from_packed_async(b[2], b[3], b[4], b[5], bad)
+
+
 def test_table_checksum_is_the_references_formula(ctx):
     """mdbg_table_checksum on the device = the sums over the host copy of the rows; sums[0] is the "Checksum kminmer abundance" the
     reference logs when it loads a table (graph/CreateMdbg.cpp:3321: abundance * vecHash truncated to u64 -- the low word)."""
