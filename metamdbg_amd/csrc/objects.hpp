@@ -26,6 +26,11 @@ struct mdbg_reads {
     mdbg::DevBuf<uint32_t> d_break;
     mdbg::DevBuf<uint8_t> d_qual;
     mdbg::DevBuf<uint64_t> d_qual_off;
+    // reads with a side-mask bit anywhere (an N, a case flip inside a run ...): one flag per read and their sorted list.  A batch in
+    // which they are few is scanned by the block-structured kernel; these reads alone take the general kernel (mdbg_scan)
+    mdbg::DevBuf<uint8_t> d_masked;         // n_reads (present when has_invalid)
+    mdbg::DevBuf<uint32_t> d_masked_list;   // n_masked, ascending
+    uint32_t n_masked = 0;
     bool has_invalid = false;   // d_invalid is present (some base is invalid, or d_break is present)
     bool has_break = false;
     bool has_qual = false;

@@ -20,7 +20,7 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 
 // although code and invalid bit agree (mixed case, IUPAC letters): EncoderRLE compares characters (Commons.hpp:4177-4178).
 __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, const uint64_t *base_off,
                                                          const uint64_t *word_off, uint32_t n_reads,
-                                                         uint64_t *words, uint32_t *invalid, uint32_t *brk, uint32_t *any_flags) {
+                                                         uint64_t *words, uint32_t *invalid, uint32_t *brk, uint32_t *any_flags, uint8_t *masked) {
     const unsigned lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, c
         const uint8_t *src = bases + base_off[r];
         const uint64_t L = base_off[r + 1] - base_off[r];
         const uint64_t w0 = word_off[r], nw = word_off[r + 1] - w0;
+        uint32_t mine = 0;
         for (uint64_t w = lane; w < nw; w += 64) {
             uint64_t x = 0;
             uint32_t inv = 0, bk = 0;
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, c
             brk[w0 + w] = bk;
             seen |= inv;
             seen_brk |= bk;
+            mine |= inv | bk;
         }
+        const bool any = __ballot(mine != 0u) != 0ull;      // the read carries a side-mask bit somewhere
+        if (lane == 0) masked[r] = any ? 1 : 0;
     }
     if (seen) atomicOr(any_flags, 1u);
     if (seen_brk) atomicOr(any_flags, 2u);
@@ -229,7 +233,8 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
     DevBuf<uint32_t> d_any;
     if ((rc = r->d_words.alloc(ctx, r->n_words)) || (rc = r->d_invalid.alloc(ctx, r->n_words)) || (rc = r->d_break.alloc(ctx, r->n_words)) ||
         (rc = r->d_word_off.alloc(ctx, (size_t)n_reads + 1)) || (rc = r->d_len.alloc(ctx, n_reads)) ||
-        (rc = d_ascii.alloc(ctx, nb)) || (rc = d_boff.alloc(ctx, (size_t)n_reads + 1)) || (rc = d_any.alloc(ctx, 1)))
+        (rc = d_ascii.alloc(ctx, nb)) || (rc = d_boff.alloc(ctx, (size_t)n_reads + 1)) || (rc = d_any.alloc(ctx, 1)) ||
+        (rc = r->d_masked.alloc(ctx, n_reads)))
         return fail(rc);
     std::vector<uint64_t> rel((size_t)n_reads + 1, 0);
     for (uint32_t i = 0; i <= n_reads && n_reads; i++) rel[i] = offsets[i] - offsets[0];
@@ -244,7 +249,7 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
         unsigned blocks = grid_for((uint64_t)n_reads * 64, 256, (unsigned)ctx->n_cu * 16u);
         LaunchTimer timer(ctx, "pack_ascii");
         hipLaunchKernelGGL(pack_ascii_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_ascii.p, d_boff.p,
-                           r->d_word_off.p, n_reads, r->d_words.p, r->d_invalid.p, r->d_break.p, d_any.p);
+                           r->d_word_off.p, n_reads, r->d_words.p, r->d_invalid.p, r->d_break.p, d_any.p, r->d_masked.p);
     }
     uint32_t any = 0;
     CK(hipMemcpyAsync(&any, d_any.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -258,8 +263,19 @@ extern "C" int mdbg_reads_from_ascii(mdbg_ctx *ctx, const char *bases, const cha
 #undef CK
     r->has_break = (any & 2u) != 0;
     r->has_invalid = any != 0;            // the scan's side-mask variant reads d_invalid whenever either mask matters
-    if (!r->has_invalid) r->d_invalid.release();
+    if (!r->has_invalid) { r->d_invalid.release(); r->d_masked.release(); }
     if (!r->has_break) r->d_break.release();
+    if (r->has_invalid) {                 // which reads: the list mdbg_scan hands to the general kernel
+        std::vector<uint8_t> flag(n_reads);
+        if ((e = memcpy_sync(ctx, flag.data(), r->d_masked.p, n_reads, hipMemcpyDeviceToHost)) != hipSuccess)
+            return fail(set_error(ctx, MDBG_EHIP, "masked flags copy failed: %s", hipGetErrorString(e)));
+        std::vector<uint32_t> list;
+        for (uint32_t i = 0; i < n_reads; i++) if (flag[i]) list.push_back(i);
+        r->n_masked = (uint32_t)list.size();
+        if ((rc = r->d_masked_list.alloc(ctx, list.size()))) return fail(rc);
+        if (!list.empty() && (e = memcpy_sync(ctx, r->d_masked_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(set_error(ctx, MDBG_EHIP, "masked list upload failed: %s", hipGetErrorString(e)));
+    }
     *out = r;
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)

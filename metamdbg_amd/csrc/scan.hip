@@ -82,6 +82,7 @@ struct ScanArgs {
     uint64_t *out_begin;          // per read: first row
     uint32_t *over_list, *suspect_list;
     uint32_t *list_counters;      // [0] = reads in over_list, [1] = reads in suspect_list
+    const uint8_t *skip;          // scan_fast_kernel: reads flagged here carry side-mask bits (N, mixed case) and are left to the general kernel
     uint32_t cand_slack;          // scan_fast_kernel<.., APPROX>: extra width of the candidate test (0 but in tests)
     uint32_t wave_priority;       // scan_fast_kernel: s_setprio level of its waves (0 = leave alone)
 };
@@ -835,6 +836,10 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     const uint32_t wave_global = blockIdx.x * FAST_WAVES + wv;
     const uint32_t n_waves = gridDim.x * FAST_WAVES;
     for (uint32_t r = wave_global; r < a.n_reads; r += n_waves) {
+        if (a.skip && a.skip[r]) {          // a read with an N or a case flip: the host sends it through the general kernel
+            if (a.cursor && lane == 0) { a.out_begin[r] = 0; a.out_count[r] = 0; a.out_flags[r] = 0; }
+            continue;
+        }
         const uint32_t L = a.len[r];
         const uint64_t w_base = a.word_off[r];
         const uint64_t *rw = a.words + w_base;
@@ -1342,6 +1347,12 @@ __global__ void gather_counts_kernel(const uint32_t *list, uint32_t n_list, cons
     if (i < n_list) out[i] = count[list[i]];
 }
 
+// suspects of the complexity bound among the listed reads (the general kernel only flags them): appended to the suspect list
+__global__ void listed_suspects_kernel(const uint32_t *list, uint32_t n_list, const uint8_t *flags, uint32_t *suspect_list, uint32_t *n_suspect) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_list && (flags[list[i]] & READ_SUSPECT)) suspect_list[atomicAdd(n_suspect, 1u)] = list[i];
+}
+
 __global__ void place_overflow_kernel(const uint32_t *list, const uint64_t *start, const uint32_t *cnt, uint32_t n_list, uint64_t *cap_off,
                                       uint64_t *begin) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1592,7 +1603,11 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // (a read may stage STAGE_CAP minimizers: batches whose longest read is expected to select more go straight to the general path)
     // A read may stage STAGE_CAP minimizers; the few that select more are re-run by the general kernel into a reserve behind
     // the regions.  Batches whose AVERAGE read is expected to outgrow the stage go straight to the general path.
-    if (n && !has_n && !no_bump && p->density < 0.2f && reads->max_len < (1u << 31) &&
+    // A batch in which a few reads carry side-mask bits (an N here and there, soft-masked stretches) stays on this path: the block
+    // kernel skips those reads (ScanArgs::skip) and they alone are counted, placed and scanned by the general kernel below.
+    const uint32_t n_masked = has_n ? reads->n_masked : 0u;
+    const bool route_masked = has_n && reads->d_masked.p && (uint64_t)n_masked * 8ull <= (uint64_t)n + 128ull;
+    if (n && (!has_n || route_masked) && !no_bump && p->density < 0.2f && reads->max_len < (1u << 31) &&
         (double)reads->n_bases / (double)n * (double)p->density * (hpc ? 0.8 : 1.0) * 1.4 + 24.0 < (double)STAGE_CAP) {
         // the output arrays are cut into regions, each with its own cursor (reads are dealt to the waves round-robin, so the regions
         // fill evenly); small batches use one
@@ -1625,6 +1640,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         a.over_list = d_over.p; a.suspect_list = d_susp.p; a.list_counters = (uint32_t *)(d_ctl.p + CTL_OVER);
         a.cand_slack = ctx->scan_cand_slack;
         a.wave_priority = ctx->scan_wave_priority;
+        a.skip = route_masked ? reads->d_masked.p : nullptr;
         unsigned long long h_ctl[CTL_WORDS];
         {
             std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device), std::defer_lock);      // one scan kernel at a time per device (see below)
@@ -1637,43 +1653,92 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         uint64_t rows = 0;
         bool fits = true;
         for (uint32_t g = 0; g < n_regions; g++) { rows += h_ctl[g]; fits = fits && h_ctl[g] <= region_cap; }
-        const uint32_t n_over = (uint32_t)h_ctl[CTL_OVER], n_suspect = (uint32_t)(h_ctl[CTL_OVER] >> 32);
-        // reads that outgrew the stage (long reads): placed in read order behind the regions and re-run by the general kernel
-        bool placed = n_over == 0;
-        if (fits && n_over && n_over <= n / 4 + 16) {
+        const uint32_t n_over = (uint32_t)h_ctl[CTL_OVER];
+        uint32_t n_suspect = (uint32_t)(h_ctl[CTL_OVER] >> 32);
+        // ---- reads the block kernel did not finish: those that outgrew its stage (long reads; listed with their exact counts) and
+        // those it skipped for their side masks (counted here by the general kernel with no room to write).  Both kinds are placed
+        // in read order behind the regions and scanned by the general kernel, each kind with its own variant.
+        ScanArgs masked_args = a;
+        std::vector<uint32_t> m_cnt;
+        bool counted = true;
+        if (fits && n_masked && route_masked) {
+            if ((e = hipMemsetAsync(d_cap_off.p, 0, ((size_t)n + 1) * 8, ctx->stream)) != hipSuccess)
+                return fail(set_error(ctx, MDBG_EHIP, "capacity clear failed: %s", hipGetErrorString(e)));
+            masked_args.cursor = nullptr; masked_args.skip = nullptr;
+            masked_args.subset = reads->d_masked_list.p;
+            masked_args.cap_off = d_cap_off.p;                       // every read: no room -- the pass only counts
+            masked_args.invalid = reads->d_invalid.p;
+            masked_args.brk = reads->has_break ? reads->d_break.p : nullptr;
+            masked_args.q_last = p->quality_window == 1 ? 1u : 0u;
+            masked_args.inline_minq = 1;
+            masked_args.out_count = m->d_cnt.p; masked_args.out_flags = m->d_flags.p;
+            if ((rc = launch_scan(ctx, masked_args, hpc, has_q, true, n_masked))) return fail(rc);
+            hipLaunchKernelGGL(listed_suspects_kernel, dim3(grid_for(n_masked, 256)), dim3(256), 0, ctx->stream, reads->d_masked_list.p, n_masked,
+                               m->d_flags.p, d_susp.p, (uint32_t *)(d_ctl.p + CTL_OVER) + 1);
+            DevBuf<uint32_t> d_mc;
+            if ((rc = d_mc.alloc(ctx, n_masked))) return fail(rc);
+            hipLaunchKernelGGL(gather_counts_kernel, dim3(grid_for(n_masked, 256)), dim3(256), 0, ctx->stream, reads->d_masked_list.p, n_masked, m->d_cnt.p, d_mc.p);
+            m_cnt.resize(n_masked);
+            unsigned long long ctl_over = 0;
+            if ((e = memcpy_sync(ctx, m_cnt.data(), d_mc.p, (size_t)n_masked * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+                (e = memcpy_sync(ctx, &ctl_over, d_ctl.p + CTL_OVER, 8, hipMemcpyDeviceToHost)) != hipSuccess)
+                return fail(set_error(ctx, MDBG_EHIP, "masked counts copy failed: %s", hipGetErrorString(e)));
+            n_suspect = (uint32_t)(ctl_over >> 32);
+        } else if (n_masked && route_masked) counted = false;
+        bool placed = n_over == 0 && (!route_masked || n_masked == 0);
+        if (fits && counted && !placed && n_over <= n / 4 + 16) {
             std::vector<uint32_t> list(n_over), cnts(n_over);
             DevBuf<uint32_t> d_oc;
-            if ((rc = d_oc.alloc(ctx, n_over))) return fail(rc);
-            hipLaunchKernelGGL(gather_counts_kernel, dim3(grid_for(n_over, 256)), dim3(256), 0, ctx->stream, d_over.p, n_over, m->d_cnt.p, d_oc.p);
-            if ((e = memcpy_sync(ctx, list.data(), d_over.p, (size_t)n_over * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
-                (e = memcpy_sync(ctx, cnts.data(), d_oc.p, (size_t)n_over * 4, hipMemcpyDeviceToHost)) != hipSuccess)
-                return fail(set_error(ctx, MDBG_EHIP, "overflow list copy failed: %s", hipGetErrorString(e)));
-            std::vector<uint32_t> order(n_over);
-            for (uint32_t i = 0; i < n_over; i++) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return list[x] < list[y]; });
-            std::vector<uint32_t> slist(n_over), scnt(n_over);
-            std::vector<uint64_t> sstart(n_over);
+            if ((rc = d_oc.alloc(ctx, (size_t)n_over + 1))) return fail(rc);
+            if (n_over) {
+                hipLaunchKernelGGL(gather_counts_kernel, dim3(grid_for(n_over, 256)), dim3(256), 0, ctx->stream, d_over.p, n_over, m->d_cnt.p, d_oc.p);
+                if ((e = memcpy_sync(ctx, list.data(), d_over.p, (size_t)n_over * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+                    (e = memcpy_sync(ctx, cnts.data(), d_oc.p, (size_t)n_over * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+                    return fail(set_error(ctx, MDBG_EHIP, "overflow list copy failed: %s", hipGetErrorString(e)));
+            }
+            std::vector<uint32_t> m_list(route_masked ? n_masked : 0u);
+            if (!m_list.empty() && (e = memcpy_sync(ctx, m_list.data(), reads->d_masked_list.p, m_list.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+                return fail(set_error(ctx, MDBG_EHIP, "masked list copy failed: %s", hipGetErrorString(e)));
+            // one order over both kinds: (read, count, kind)
+            struct Item { uint32_t read, cnt, kind; };
+            std::vector<Item> items;
+            items.reserve((size_t)n_over + m_list.size());
+            for (uint32_t i = 0; i < n_over; i++) items.push_back(Item{list[i], cnts[i], 0u});
+            for (size_t i = 0; i < m_list.size(); i++) items.push_back(Item{m_list[i], m_cnt[i], 1u});
+            std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.read < y.read; });
+            std::vector<uint32_t> slist[2], scnt[2];
+            std::vector<uint64_t> sstart[2];
             uint64_t at = capacity;
-            for (uint32_t i = 0; i < n_over; i++) { slist[i] = list[order[i]]; scnt[i] = cnts[order[i]]; sstart[i] = at; at += scnt[i]; }
+            for (const Item &it : items) { slist[it.kind].push_back(it.read); scnt[it.kind].push_back(it.cnt); sstart[it.kind].push_back(at); at += it.cnt; }
             if (at - capacity <= reserve) {
-                DevBuf<uint64_t> d_start;
                 DevBuf<uint32_t> scratch_count;
                 DevBuf<uint8_t> scratch_flags;
-                if ((rc = d_start.alloc(ctx, n_over)) || (rc = scratch_count.alloc(ctx, n)) || (rc = scratch_flags.alloc(ctx, n))) return fail(rc);
-                if ((e = memcpy_sync(ctx, d_over.p, slist.data(), (size_t)n_over * 4, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = memcpy_sync(ctx, d_oc.p, scnt.data(), (size_t)n_over * 4, hipMemcpyHostToDevice)) != hipSuccess ||
-                    (e = memcpy_sync(ctx, d_start.p, sstart.data(), (size_t)n_over * 8, hipMemcpyHostToDevice)) != hipSuccess)
-                    return fail(set_error(ctx, MDBG_EHIP, "overflow plan upload failed: %s", hipGetErrorString(e)));
-                hipLaunchKernelGGL(place_overflow_kernel, dim3(grid_for(n_over, 256)), dim3(256), 0, ctx->stream, d_over.p, d_start.p, d_oc.p, n_over,
-                                   d_cap_off.p, m->d_begin.p);
-                ScanArgs b = a;
-                b.cursor = nullptr;
-                b.subset = d_over.p;
-                b.cap_off = d_cap_off.p;
-                b.q_last = p->quality_window == 1 ? 1u : 0u;
-                b.inline_minq = 1;
-                b.out_count = scratch_count.p; b.out_flags = scratch_flags.p;
-                if ((rc = launch_scan(ctx, b, hpc, has_q, false, n_over))) return fail(rc);
+                if ((rc = scratch_count.alloc(ctx, n)) || (rc = scratch_flags.alloc(ctx, n))) return fail(rc);
+                DevBuf<uint64_t> d_start[2];
+                DevBuf<uint32_t> d_list[2], d_cnt2[2];
+                for (int kind = 0; kind < 2; kind++) {
+                    const uint32_t nk = (uint32_t)slist[kind].size();
+                    if (!nk) continue;
+                    if ((rc = d_start[kind].alloc(ctx, nk)) || (rc = d_list[kind].alloc(ctx, nk)) || (rc = d_cnt2[kind].alloc(ctx, nk))) return fail(rc);
+                    if ((e = memcpy_sync(ctx, d_list[kind].p, slist[kind].data(), (size_t)nk * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                        (e = memcpy_sync(ctx, d_cnt2[kind].p, scnt[kind].data(), (size_t)nk * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                        (e = memcpy_sync(ctx, d_start[kind].p, sstart[kind].data(), (size_t)nk * 8, hipMemcpyHostToDevice)) != hipSuccess)
+                        return fail(set_error(ctx, MDBG_EHIP, "overflow plan upload failed: %s", hipGetErrorString(e)));
+                    hipLaunchKernelGGL(place_overflow_kernel, dim3(grid_for(nk, 256)), dim3(256), 0, ctx->stream, d_list[kind].p, d_start[kind].p, d_cnt2[kind].p, nk,
+                                       d_cap_off.p, m->d_begin.p);
+                }
+                for (int kind = 0; kind < 2; kind++) {
+                    const uint32_t nk = (uint32_t)slist[kind].size();
+                    if (!nk) continue;
+                    ScanArgs b = kind ? masked_args : a;
+                    b.cursor = nullptr; b.skip = nullptr;
+                    b.subset = d_list[kind].p;
+                    b.cap_off = d_cap_off.p;
+                    b.q_last = p->quality_window == 1 ? 1u : 0u;
+                    b.inline_minq = 1;
+                    b.out_count = scratch_count.p; b.out_flags = scratch_flags.p;
+                    if ((rc = launch_scan(ctx, b, hpc, has_q, kind == 1, nk))) return fail(rc);
+                }
                 if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "overflow re-run failed: %s", hipGetErrorString(e)));
                 rows += at - capacity;
                 placed = true;
