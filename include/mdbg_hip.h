@@ -14,7 +14,8 @@
  * as the reference uses one functor copy per OpenMP thread: Commons.hpp:5846-5914).
  * Several contexts on one device may be driven concurrently from several threads; that is the intended way to keep
  * two or three batches in flight (the table kernels of one batch overlap the scan of the next -- bench.py).
- * mdbg_scan calls on the same device take turns: one scan kernel runs at a time.
+ * mdbg_scan calls on the same device take turns: one scan kernel runs at a time, also across processes (an advisory file lock named
+ * after the device's PCI address; MDBG_SCAN_NO_XPROC_LOCK=1 keeps the rule inside the process).
  * There is no CPU fallback: without a usable GPU every call fails with MDBG_ENODEV.
  *
  * Environment (read by the library): MDBG_SCAN_READS_PER_WAVE, MDBG_TABLE_BLOCKS_PER_CU -- defaults of the options of
@@ -105,6 +106,14 @@ int  mdbg_reads_from_packed(mdbg_ctx *ctx, const uint64_t *words, const uint64_t
  * section (Commons.hpp:5868-5905) is then bound by the link, not by link + kernels. */
 int  mdbg_reads_from_packed_async(mdbg_ctx *ctx, const uint64_t *words, const uint64_t *word_offsets, const uint32_t *lengths,
                                   uint32_t n_reads, mdbg_reads **out);
+/* The few reads of a PACKED batch (mdbg_reads_from_packed / _async) that hold characters other than upper-case A, C, G, T -- an N,
+ * a soft-masked stretch, an IUPAC letter: the 2-bit words alone lose what the reference still sees (invalid k-mers, utils/kmer/
+ * Kmer.hpp:574-580; a change of character starts a homopolymer run, Commons.hpp:4177-4178).  The caller hands those reads again
+ * as characters (ascending indices; read read_index[i] = ascii[ascii_offsets[i] .. ascii_offsets[i+1])) and the side masks of the
+ * batch are derived from them on the device, exactly as mdbg_reads_from_ascii derives them for every read.  mdbg_scan then keeps
+ * the batch on its fast kernel and sends only the marked reads through the general one.  Once per batch, before any scan. */
+int  mdbg_reads_mark_ascii(mdbg_ctx *ctx, mdbg_reads *r, const uint32_t *read_index, uint32_t n_listed, const char *ascii,
+                           const uint64_t *ascii_offsets);
 /* Qualities for reads made by mdbg_reads_from_packed_async, queued behind their words (same rules: `quals` stays untouched until
  * mdbg_reads_wait; a read has one quality per base, checked at once against the lengths given at upload). */
 int  mdbg_reads_attach_qualities_async(mdbg_ctx *ctx, mdbg_reads *r, const char *quals, const uint64_t *offsets);

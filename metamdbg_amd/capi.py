@@ -49,6 +49,7 @@ SIGNATURES = {
     "mdbg_reads_from_packed": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_from_packed_async": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     "mdbg_reads_attach_qualities_async": (C.c_int, [_P, _P, C.c_char_p, _P]),
+    "mdbg_reads_mark_ascii": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_char_p, _P]),
     "mdbg_reads_wait": (C.c_int, [_P, _P]),
     "mdbg_reads_attach_qualities": (C.c_int, [_P, _P, C.c_char_p, _P]),
     "mdbg_reads_synthetic": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _P, _P, C.c_uint32,
@@ -479,6 +480,13 @@ class Reads:
         offs = np.zeros(count + 1, dtype=np.uint64)
         self.ctx.check(lib().mdbg_reads_export_ascii(self.ctx.h, self.h, first, count, _ptr(bases), _ptr(offs), C.byref(nb)))
         return bases, offs
+
+    def mark_ascii(self, index: list[int], seqs: list[bytes]) -> None:
+        """The listed reads of a packed batch again as characters: their side masks are derived on the device (mdbg_reads_mark_ascii)."""
+        idx = np.ascontiguousarray(index, dtype=np.uint32)
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in seqs], out=offs[1:])
+        self.ctx.check(lib().mdbg_reads_mark_ascii(self.ctx.h, self.h, _ptr(idx), len(idx), b"".join(seqs), _ptr(offs)))
 
     def wait(self) -> None:
         """An asynchronous upload has arrived (mdbg_reads_wait)."""

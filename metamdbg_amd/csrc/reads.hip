@@ -61,6 +61,46 @@ __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *bases, c
     if (seen_brk) atomicOr(any_flags, 2u);
 }
 
+// The side masks of LISTED reads of a batch uploaded as 2-bit words, from their characters: what pack_ascii_kernel derives for every
+// read of an ASCII batch, for the few reads of a packed batch that hold something else than upper-case ACGT.  One wave per listed read.
+__global__ __launch_bounds__(256) void mask_listed_kernel(const uint8_t *ascii, const uint64_t *a_off, const uint32_t *list, uint32_t n_list,
+                                                          const uint64_t *word_off, uint32_t *invalid, uint32_t *brk, uint32_t *any_flags,
+                                                          uint8_t *masked, uint8_t *listed_masked) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t seen = 0, seen_brk = 0;
+    for (uint64_t i = wave; i < n_list; i += nwaves) {
+        const uint32_t r = list[i];
+        const uint8_t *src = ascii + a_off[i];
+        const uint64_t L = a_off[i + 1] - a_off[i];
+        const uint64_t w0 = word_off[r], nw = word_off[r + 1] - w0;
+        uint32_t mine = 0;
+        for (uint64_t w = lane; w < nw; w += 64) {
+            uint32_t inv = 0, bk = 0;
+            const uint64_t b0 = w * 32;
+            uint8_t prev = (b0 > 0 && b0 <= L) ? src[b0 - 1] : 0;
+            bool have_prev = b0 > 0 && b0 <= L;
+            for (int j = 0; j < 32; j++) {
+                const uint64_t bi = b0 + j;
+                if (bi < L) {
+                    const uint8_t c = src[bi];
+                    inv |= (uint32_t)((c >> 3) & 1u) << j;
+                    if (have_prev && c != prev && ((c ^ prev) & 0x0Eu) == 0) bk |= 1u << j;
+                    prev = c; have_prev = true;
+                }
+            }
+            invalid[w0 + w] = inv;
+            brk[w0 + w] = bk;
+            seen |= inv; seen_brk |= bk; mine |= inv | bk;
+        }
+        const bool any = __ballot(mine != 0u) != 0ull;
+        if (lane == 0) { masked[r] = any ? 1 : 0; listed_masked[i] = any ? 1 : 0; }
+    }
+    if (seen) atomicOr(any_flags, 1u);
+    if (seen_brk) atomicOr(any_flags, 2u);
+}
+
 struct SynthArgs {
     uint64_t seed;
     uint32_t n_reads, read_len;
@@ -394,6 +434,67 @@ extern "C" int mdbg_reads_attach_qualities_async(mdbg_ctx *ctx, mdbg_reads *r, c
     (void)hipEventDestroy(r->ready);        // superseded: the new event is recorded behind everything the old one covered
     r->ready = ev;
     r->has_qual = true;
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_reads_mark_ascii(mdbg_ctx *ctx, mdbg_reads *r, const uint32_t *read_index, uint32_t n_listed, const char *ascii,
+                                     const uint64_t *ascii_offsets) try {
+    if (!ctx || !r || (n_listed && (!read_index || !ascii || !ascii_offsets))) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_mark_ascii: null argument");
+    if (r->has_invalid) return set_error(ctx, MDBG_EINVAL, "mdbg_reads_mark_ascii: the batch already carries side masks");
+    if (!n_listed) return MDBG_OK;
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MDBG_HIP_CHECK(ctx, reads_ready_on(ctx, r));          // an upload still in flight: the kernel below runs behind it
+    const uint32_t n = r->n_reads;
+    std::vector<uint32_t> lens = r->h_len;
+    if (lens.size() != n) {
+        lens.resize(n);
+        MDBG_HIP_CHECK(ctx, reads_ready_host(r));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, lens.data(), r->d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint64_t> rel((size_t)n_listed + 1);
+    for (uint32_t i = 0; i <= n_listed; i++) rel[i] = ascii_offsets[i] - ascii_offsets[0];
+    for (uint32_t i = 0; i < n_listed; i++) {
+        if (read_index[i] >= n || (i && read_index[i] <= read_index[i - 1]))
+            return set_error(ctx, MDBG_EINVAL, "mdbg_reads_mark_ascii: read indices must be ascending and inside the batch");
+        if (rel[i + 1] - rel[i] != lens[read_index[i]])
+            return set_error(ctx, MDBG_EINVAL, "mdbg_reads_mark_ascii: read %u has %u bases, %llu characters given", read_index[i], lens[read_index[i]],
+                             (unsigned long long)(rel[i + 1] - rel[i]));
+    }
+    DevBuf<uint8_t> d_ascii, d_lm;
+    DevBuf<uint64_t> d_aoff;
+    DevBuf<uint32_t> d_list, d_any;
+    MDBG_TRY(r->d_invalid.alloc(ctx, r->n_words));
+    MDBG_TRY(r->d_break.alloc(ctx, r->n_words));
+    MDBG_TRY(r->d_masked.alloc(ctx, n));
+    MDBG_TRY(d_ascii.alloc(ctx, rel[n_listed]));
+    MDBG_TRY(d_aoff.alloc(ctx, rel.size()));
+    MDBG_TRY(d_list.alloc(ctx, n_listed));
+    MDBG_TRY(d_lm.alloc(ctx, n_listed));
+    MDBG_TRY(d_any.alloc(ctx, 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(r->d_invalid.p, 0, r->n_words * 4, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(r->d_break.p, 0, r->n_words * 4, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(r->d_masked.p, 0, n, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(d_any.p, 0, 4, ctx->stream));
+    if (rel[n_listed]) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(d_ascii.p, ascii + ascii_offsets[0], rel[n_listed], hipMemcpyHostToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(d_aoff.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(d_list.p, read_index, (size_t)n_listed * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mask_listed_kernel, dim3(grid_for((uint64_t)n_listed * 64, 256, (unsigned)ctx->n_cu * 16u)), dim3(256), 0, ctx->stream, d_ascii.p,
+                       d_aoff.p, d_list.p, n_listed, r->d_word_off.p, r->d_invalid.p, r->d_break.p, d_any.p, r->d_masked.p, d_lm.p);
+    uint32_t any = 0;
+    std::vector<uint8_t> lm(n_listed);
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&any, d_any.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, lm.data(), d_lm.p, n_listed, hipMemcpyDeviceToHost));
+    r->has_break = (any & 2u) != 0;
+    r->has_invalid = any != 0;
+    if (!r->has_invalid) { r->d_invalid.release(); r->d_masked.release(); }
+    if (!r->has_break) r->d_break.release();
+    if (r->has_invalid) {
+        std::vector<uint32_t> list;
+        for (uint32_t i = 0; i < n_listed; i++) if (lm[i]) list.push_back(read_index[i]);
+        r->n_masked = (uint32_t)list.size();
+        MDBG_TRY(r->d_masked_list.alloc(ctx, list.size()));
+        if (!list.empty()) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, r->d_masked_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+    }
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 

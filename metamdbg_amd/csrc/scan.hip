@@ -28,10 +28,17 @@
 #include "murmur.hpp"
 #include "objects.hpp"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <type_traits>
 
@@ -1409,6 +1416,49 @@ static std::mutex &device_scan_mutex(int device) {
     return m[(unsigned)device % 64u];
 }
 
+// The same rule ACROSS processes (two tools on one GPU, the ranks of a test sharing device 0): an advisory lock on a file named after
+// the device's PCI address, taken inside the process-wide mutex.  Best effort: no lock file, no cross-process turn-taking
+// (MDBG_SCAN_NO_XPROC_LOCK=1 switches it off).  flock costs about a microsecond; a scan launch is milliseconds.
+static int device_scan_lockfile(int device) {
+    static int fds[64];
+    static std::once_flag once[64];
+    const unsigned d = (unsigned)device % 64u;
+    std::call_once(once[d], [&] {
+        fds[d] = -1;
+        if (getenv("MDBG_SCAN_NO_XPROC_LOCK")) return;
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "device%d", device);
+        for (char *c = bus; *c; c++) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        for (const char *dir : {"/dev/shm", "/tmp"}) {
+            std::string path = std::string(dir) + "/mdbg_scan_turn_" + bus + ".lock";
+            const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+            if (fd >= 0) { (void)fchmod(fd, 0666); fds[d] = fd; return; }
+        }
+    });
+    return fds[d];
+}
+
+// one scan kernel at a time per device: the turn is held from the launch to the read-back of the counters
+struct ScanTurn {
+    std::unique_lock<std::mutex> in_process;
+    int fd = -1;
+    bool held = false;
+    explicit ScanTurn(int device) : in_process(device_scan_mutex(device), std::defer_lock), fd(device_scan_lockfile(device)) {}
+    void lock() {
+        in_process.lock();
+        if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
+        held = true;
+    }
+    void unlock() {
+        if (!held) return;
+        if (fd >= 0) (void)flock(fd, LOCK_UN);
+        in_process.unlock();
+        held = false;
+    }
+    bool owns_lock() const { return held; }
+    ~ScanTurn() { unlock(); }
+};
+
 template <bool HPC, bool Q, bool N>
 static void launch_variant(mdbg_ctx *ctx, const ScanArgs &a, unsigned max_blocks, uint32_t n_items) {
     // A few reads per wave, then the wave retires.  One resident generation of persistent waves (the first design)
@@ -1643,7 +1693,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         a.skip = route_masked ? reads->d_masked.p : nullptr;
         unsigned long long h_ctl[CTL_WORDS];
         {
-            std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device), std::defer_lock);      // one scan kernel at a time per device (see below)
+            ScanTurn scan_turn(ctx->device);      // one scan kernel at a time per device (see below)
             if (!scans_may_interleave()) scan_turn.lock();
             if ((rc = launch_scan(ctx, a, hpc, has_q, false, n))) return fail(rc);
             if ((rc = quality_finish())) return fail(rc);          // host work while the kernel runs
@@ -1811,7 +1861,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
     // workgroup each run at half speed and worse (measured: 2 x 15.5 ms alone, 2 x 30 ms interleaved), while everything
     // else a second context does -- table building, purge, RCCL -- overlaps a running scan nicely.  The lock covers the
     // launch and is released when the kernel has finished (the counter download below waits for it).
-    std::unique_lock<std::mutex> scan_turn(device_scan_mutex(ctx->device), std::defer_lock);
+    ScanTurn scan_turn(ctx->device);
     if (!scans_may_interleave()) scan_turn.lock();
     if (n && (rc = launch_scan(ctx, a, hpc, has_q, has_n, n))) return fail(rc);
     if ((rc = quality_finish())) return fail(rc);                  // host work while the kernel runs (once: the call above may have done it)

@@ -51,10 +51,18 @@ struct ReadBatch {
     bool packed = false;
     std::vector<uint64_t> wordOff{0};
     std::vector<uint32_t> lens;
+    // packed batches: the few reads that hold something else than upper-case ACGT travel a second time as characters
+    // (mdbg_reads_mark_ascii derives their side masks on the device); a chunk in which they are many is delivered as ASCII
+    std::vector<uint32_t> odd;            // ascending read indices
+    std::string oddBases;
+    std::vector<uint64_t> oddOff{0};
     int file = 0;
     uint32_t n() const { return (uint32_t)(offsets.size() - 1); }
     const uint64_t *words() const { return reinterpret_cast<const uint64_t *>(bases); }
-    void clear() { nbases = 0; offsets.assign(1, 0); hasQual = false; packed = false; wordOff.assign(1, 0); lens.clear(); }
+    void clear() {
+        nbases = 0; offsets.assign(1, 0); hasQual = false; packed = false; wordOff.assign(1, 0); lens.clear();
+        odd.clear(); oddBases.clear(); oddOff.assign(1, 0);
+    }
 };
 
 // ---- 2-bit packing of ASCII bases on the host -------------------------------------------------------------------
@@ -847,6 +855,7 @@ private:
             if (!nl) break;
             p = nl + 1;
             size_t len = 0;
+            const char *seq0 = p;                 // first sequence line of the record
             if (!w.fastq) {
                 while (p < end && *p != '>') {
                     nl = (const char *)memchr(p, '\n', (size_t)(end - p));
@@ -878,7 +887,25 @@ private:
                 p = nl ? nl + 1 : end;
             }
             pc.end_read();
-            if (pc.bad() || len > 0xFFFFFFF0ull) return false;
+            if (pc.overflow || len > 0xFFFFFFF0ull) return false;
+            if (pc.invalid) {
+                // something else than upper-case ACGT in this read: it goes along a second time as characters.  Many such reads
+                // (a lower-case file, an assembly full of N): the chunk is delivered as ASCII as before.
+                if (b->odd.size() >= 64 && b->odd.size() * 8 > b->lens.size() + 64) return false;
+                b->odd.push_back((uint32_t)b->lens.size());
+                if (!w.fastq) {
+                    for (const char *q = seq0; q < end && *q != '>';) {
+                        const char *nl2 = (const char *)memchr(q, '\n', (size_t)(end - q));
+                        const char *le = nl2 ? nl2 : end;
+                        size_t n = (size_t)(le - q);
+                        if (n && q[n - 1] == '\r') n--;
+                        b->oddBases.append(q, n);
+                        q = nl2 ? nl2 + 1 : end;
+                    }
+                } else b->oddBases.append(seq0, len);
+                b->oddOff.push_back(b->oddBases.size());
+                pc.invalid = 0;
+            }
             b->nbases += len;
             b->offsets.push_back(b->nbases);
             b->wordOff.push_back(pc.w);

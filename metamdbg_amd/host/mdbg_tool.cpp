@@ -227,6 +227,8 @@ mdbg_reads *upload_batch(mdbg_ctx *ctx, ReadBatch &b, bool withQual) {
     if (b.packed) {
         check_on(ctx, mdbg_reads_from_packed(ctx, b.words(), b.wordOff.data(), b.lens.data(), b.n(), &reads), "mdbg_reads_from_packed");
         if (withQual && b.hasQual) check_on(ctx, mdbg_reads_attach_qualities(ctx, reads, b.quals, b.offsets.data()), "mdbg_reads_attach_qualities");
+        if (!b.odd.empty())
+            check_on(ctx, mdbg_reads_mark_ascii(ctx, reads, b.odd.data(), (uint32_t)b.odd.size(), b.oddBases.data(), b.oddOff.data()), "mdbg_reads_mark_ascii");
     } else {
         check_on(ctx, mdbg_reads_from_ascii(ctx, b.bases, withQual && b.hasQual ? b.quals : nullptr, b.offsets.data(), b.n(), &reads), "mdbg_reads_from_ascii");
     }
@@ -429,6 +431,9 @@ int run_read_selection(int argc, char **argv) {
                              "mdbg_reads_from_packed_async");
                     if (st.b->hasQual)
                         check_on(ctx, mdbg_reads_attach_qualities_async(ctx, st.reads, st.b->quals, st.b->offsets.data()), "mdbg_reads_attach_qualities_async");
+                    if (!st.b->odd.empty())         // the few reads with an N or lower case, again as characters (a small synchronous copy)
+                        check_on(ctx, mdbg_reads_mark_ascii(ctx, st.reads, st.b->odd.data(), (uint32_t)st.b->odd.size(), st.b->oddBases.data(),
+                                                            st.b->oddOff.data()), "mdbg_reads_mark_ascii");
                 } else {
                     st.reads = upload_batch(ctx, *st.b, true);
                     feeder->recycle(st.b);                       // the page-locked buffer is free again once the upload is done

@@ -42,7 +42,7 @@ int main(int argc, char **argv) {
             expQual.push_back(hq ? q : std::string());
         }
     }
-    size_t i = 0, nbatches = 0, npacked = 0;
+    size_t i = 0, nbatches = 0, npacked = 0, nodd = 0;
     try {
         mdbg_host::ReadFeeder feeder(files, chunk, threads, maxReads, [](size_t n) { return malloc(n); }, [](void *p) { free(p); });
         while (mdbg_host::ReadBatch *b = feeder.next()) {
@@ -50,7 +50,10 @@ int main(int argc, char **argv) {
             if (b->packed) {
                 npacked++;
                 if (b->wordOff.size() != (size_t)b->n() + 1 || b->lens.size() != b->n()) { fprintf(stderr, "packed batch: bad index sizes\n"); return 1; }
-            }
+                if (b->oddOff.size() != b->odd.size() + 1 || b->oddOff.back() != b->oddBases.size()) { fprintf(stderr, "packed batch: bad odd-read index\n"); return 1; }
+                for (size_t o = 1; o < b->odd.size(); o++) if (b->odd[o] <= b->odd[o - 1]) { fprintf(stderr, "odd reads not ascending\n"); return 1; }
+            } else if (!b->odd.empty()) { fprintf(stderr, "ASCII batch with odd reads\n"); return 1; }
+            size_t oddAt = 0;
             for (uint32_t r = 0; r < b->n(); r++, i++) {
                 if (i >= expSeq.size()) { fprintf(stderr, "too many reads\n"); return 1; }
                 if (b->packed) {
@@ -59,10 +62,18 @@ int main(int argc, char **argv) {
                     if (b->lens[r] != e.size() || (w0 & 1) || w1 - w0 != ((e.size() + 63) / 64) * 2 || b->offsets[r + 1] - b->offsets[r] != e.size()) {
                         fprintf(stderr, "packed read %zu: bad layout\n", i); return 1;
                     }
+                    // a read with anything but upper-case ACGT must be listed and carried again as characters; no other read may be
+                    bool plain = true;
+                    for (char c : e) plain = plain && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                    const bool listed = oddAt < b->odd.size() && b->odd[oddAt] == r;
+                    if (listed == plain) { fprintf(stderr, "packed read %zu: %s\n", i, plain ? "listed as odd but plain" : "holds other characters and is not listed"); return 1; }
+                    if (listed) {
+                        if (b->oddBases.substr(b->oddOff[oddAt], b->oddOff[oddAt + 1] - b->oddOff[oddAt]) != e) { fprintf(stderr, "odd read %zu: characters differ\n", i); return 1; }
+                        oddAt++; nodd++;
+                    }
                     for (size_t k = 0; k < (w1 - w0) * 32; k++) {
                         const unsigned got = (unsigned)((b->words()[w0 + k / 32] >> (2 * (k % 32))) & 3u);
                         const unsigned want = k < e.size() ? (((unsigned char)e[k] >> 1) & 3u) : 0u;
-                        if (k < e.size() && ((unsigned char)e[k] & 8u)) { fprintf(stderr, "packed read %zu holds an invalid character\n", i); return 1; }
                         if (got != want) { fprintf(stderr, "packed read %zu differs at base %zu\n", i, k); return 1; }
                     }
                 } else {
@@ -74,10 +85,11 @@ int main(int argc, char **argv) {
                     if (q != expQual[i]) { fprintf(stderr, "qual %zu differs\n", i); return 1; }
                 } else if (!expQual[i].empty()) { fprintf(stderr, "missing qualities at %zu\n", i); return 1; }
             }
+            if (b->packed && oddAt != b->odd.size()) { fprintf(stderr, "odd reads left over\n"); return 1; }
             feeder.recycle(b);
         }
     } catch (const std::exception &e) { fprintf(stderr, "exception: %s\n", e.what()); return 3; }
     if (i != expSeq.size()) { fprintf(stderr, "got %zu reads, expected %zu\n", i, expSeq.size()); return 1; }
-    printf("ok %zu reads %zu batches %zu packed\n", i, nbatches, npacked);
+    printf("ok %zu reads %zu batches %zu packed %zu odd\n", i, nbatches, npacked, nodd);
     return 0;
 }

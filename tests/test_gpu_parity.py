@@ -975,6 +975,50 @@ def test_async_packed_upload_with_qualities(ctx):
         ctx.reads_from_packed_async(b[2], b[3], b[4], b[5], bad)
 
 
+def test_few_marked_reads_are_routed_one_by_one(ctx, orc):
+    """A batch in which a few reads carry an N, lower case or an IUPAC letter stays on the block-structured kernel; those reads alone
+    are counted, placed and scanned by the general kernel (mdbg_scan, ScanArgs::skip) -- together with a read that outgrows the block
+    kernel's stage, the other kind of read the general kernel finishes.  Against the oracle (reference semantics pinned by the
+    scan_n / scan_case fixtures), with and without qualities, HPC on and off; once through mdbg_reads_from_ascii and once as a
+    packed batch whose odd reads are handed again as characters (mdbg_reads_mark_ascii: what the host feed does)."""
+    rng = np.random.default_rng(41)
+    seqs = [bytearray(synth.CODE2ASCII[rng.integers(0, 4, int(n))]) for n in rng.integers(300, 7000, 500)]
+    seqs[250] = bytearray(synth.CODE2ASCII[rng.integers(0, 4, 150_000)])        # selects more than the stage holds at this density
+    odd = sorted(int(x) for x in rng.choice(500, 14, replace=False) if int(x) != 250)
+    for j, r in enumerate(odd):
+        sq = seqs[r]
+        a = int(rng.integers(0, len(sq) - 40))
+        if j % 3 == 0:
+            sq[a:a + int(rng.integers(1, 6))] = b"N" * 5
+        elif j % 3 == 1:
+            sq[a:a + 30] = bytes(sq[a:a + 30]).lower()
+        else:
+            sq[a] = ord(rng.choice(list("RSWVBn")))
+    odd.append(499); seqs[499][0] = ord("N")                                       # first base of the last read
+    odd = sorted(set(odd))
+    seqs = [bytes(x) for x in seqs]
+    quals = [bytes(rng.integers(33, 80, len(x)).astype(np.uint8)) for x in seqs]
+    for hpc in (True, False):
+        for q in (None, quals):
+            m, h = _check_scan_against_oracle(ctx, orc, seqs, q, 15, 0.005, hpc)
+            assert int(np.diff(h["offsets"])[250]) > 384                       # the long read did outgrow the stage
+            # the same batch packed on the host (code (c >> 1) & 3 for any character), the odd reads marked afterwards
+            words, woff, lens = synth.pack_reads([synth.ascii_to_codes(x) for x in seqs])
+            reads = ctx.reads_from_packed(words, woff, lens, [qq for qq in q] if q else None)
+            reads.mark_ascii(odd, [seqs[r] for r in odd])
+            h2 = ctx.scan(reads, K=15, density=0.005, hpc=hpc).to_host()
+            assert formats.build_read_data_init(h2) == formats.build_read_data_init(h)
+    # marking a read that turns out plain is harmless; indices must ascend and lengths must fit
+    from metamdbg_amd import capi
+    words, woff, lens = synth.pack_reads([synth.ascii_to_codes(x) for x in seqs[:20]])
+    reads = ctx.reads_from_packed(words, woff, lens)
+    reads.mark_ascii([3, 7], [seqs[3].upper().replace(b"N", b"A").replace(b"R", b"A"), seqs[7]])
+    with pytest.raises(capi.MdbgError):
+        ctx.reads_from_packed(words, woff, lens).mark_ascii([7, 3], [seqs[7], seqs[3]])
+    with pytest.raises(capi.MdbgError):
+        ctx.reads_from_packed(words, woff, lens).mark_ascii([3], [seqs[3][:-1]])
+
+
 def test_table_checksum_is_the_references_formula(ctx):
     """mdbg_table_checksum on the device = the sums over the host copy of the rows; sums[0] is the "Checksum kminmer abundance" the
     reference logs when it loads a table (graph/CreateMdbg.cpp:3321: abundance * vecHash truncated to u64 -- the low word)."""

@@ -78,6 +78,13 @@ def files(tmp_path_factory):
                 sq[len(sq) // 2] = ord("N") if i != 401 else ord("n")
             f.write(b">n%d\n" % i + bytes(sq) + b"\n")
     out["with_n"] = p
+    # a soft-masked / lower-case FASTA, wrapped lines: every read is odd -- such chunks are delivered as ASCII
+    p = str(d / "lower.fasta")
+    with open(p, "wb") as f:
+        for i in range(500):
+            sq = _rand_seq(rng, int(rng.integers(200, 3000))).lower()
+            f.write(b">l%d\n" % i + b"\n".join(sq[j:j + 70] for j in range(0, len(sq), 70)) + b"\n")
+    out["lower"] = p
     # gzipped FASTA
     p = str(d / "z.fasta.gz")
     with gzip.open(p, "wb") as f:
@@ -166,12 +173,19 @@ def test_per_file_read_cap(exe, files):
 
 
 def test_packed_and_ascii_batches(exe, files):
-    """Workers pack chunks to 2 bits unless a character with bit 3 set shows up (then the chunk is delivered as ASCII)."""
+    """Workers pack chunks to 2 bits; a read with anything but upper-case ACGT is packed all the same (code (c >> 1) & 3) and carried
+    a second time as characters (ReadBatch::odd -> mdbg_reads_mark_ascii); only a chunk in which such reads are many is delivered as
+    ASCII (the harness checks that exactly the reads that need it are listed, with their characters)."""
     r = subprocess.run([exe, "20000", "3", "0", files["with_n"]], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    toks = r.stdout.split()          # ok <reads> reads <batches> batches <packed> packed
-    n_batches, n_packed = int(toks[3]), int(toks[5])
-    assert toks[1] == "600" and 0 < n_packed < n_batches and n_batches - n_packed <= 3
+    toks = r.stdout.split()          # ok <reads> reads <batches> batches <packed> packed <odd> odd
+    n_batches, n_packed, n_odd = int(toks[3]), int(toks[5]), int(toks[7])
+    assert toks[1] == "600" and n_packed == n_batches and 0 < n_odd <= 3
+    # many odd reads (a lower-case file): the chunks come as characters once enough of their reads turned out odd
+    r = subprocess.run([exe, "400000", "3", "0", files["lower"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    toks = r.stdout.split()
+    assert toks[1] == "500" and int(toks[5]) < int(toks[3])
     r = subprocess.run([exe, "20000", "3", "0", files["single"]], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.split()[3] == r.stdout.split()[5]          # all packed
     r = subprocess.run([exe, "20000", "3", "0", files["single"]], capture_output=True, text=True, timeout=120,
