@@ -53,7 +53,7 @@ def _gz_member(args):
     return co.compress(raw) + co.flush()
 
 
-def run_tool(tmp_parent, inputs, threads, P, trace=True):
+def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=()):
     from metamdbg_amd import formats
     tmp = os.path.join(tmp_parent, "tmp")
     shutil.rmtree(tmp_parent, ignore_errors=True)
@@ -64,7 +64,7 @@ def run_tool(tmp_parent, inputs, threads, P, trace=True):
     env = dict(os.environ, MDBG_TRACE="1") if trace else dict(os.environ)
     t0 = time.perf_counter()
     r1 = subprocess.run([TOOL, "readSelection", tmp, tmp + "/read_data_init.txt", tmp + "/input.txt", "--threads", str(threads),
-                         "--min-read-quality", "0.000000"], capture_output=True, text=True, env=env)
+                         "--min-read-quality", "0.000000", *rs_args], capture_output=True, text=True, env=env)
     t1 = time.perf_counter()
     assert r1.returncode == 0, r1.stderr[-1000:]
     r2 = subprocess.run([TOOL, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], capture_output=True, text=True, env=env)
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--threads", default="32,64")
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--out", default="")
+    ap.add_argument("--batch-bases", default="", help="comma list: readSelection --batch-bases values to compare on the FASTA set (tool flag, not a reference flag)")
     a = ap.parse_args()
     from metamdbg_amd import capi, formats, synth
     work = tempfile.mkdtemp(prefix="mdbg_e2e_", dir=a.dir)
@@ -114,6 +115,13 @@ def main():
             return out
         if a.reads:
             res["fasta"] = best_of([fasta], a.reads, "fasta")
+            for bb in [x for x in a.batch_bases.split(",") if x]:
+                runs = [run_tool(os.path.join(work, "run"), [fasta], threads[0], P, rs_args=("--batch-bases", bb)) for _ in range(2)]
+                b = min(runs, key=lambda r: r["total_s"])
+                res[f"fasta_batch_bases_{bb}"] = b
+                print("fasta --batch-bases", bb, "%.2f s total (readSelection %.2f)" % (b["total_s"], b["read_selection_s"]), file=sys.stderr, flush=True)
+                for ln in b["trace_read_selection"]:
+                    print("    ", ln, file=sys.stderr)
         if a.fastq_reads:
             res["fastq"] = best_of([fastq], a.fastq_reads, "fastq")
         if a.gz_reads and a.reads:
