@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint64_t *src_be
 }
 
 int ensure_canonical(mdbg_ctx *ctx, const mdbg_minimizers *cm) {
-    if (!cm || !cm->scattered) return MDBG_OK;
+    if (!cm) return MDBG_OK;
+    // the conversion rewrites the object's arrays: one caller does it, the others wait and find it done (a read-only consumer on
+    // another thread -- a census on one context while another purges -- must not see the arrays half swapped)
+    std::lock_guard<std::mutex> once(cm->canon_mu);
+    if (!cm->scattered) return MDBG_OK;
     mdbg_minimizers *m = const_cast<mdbg_minimizers *>(cm);
     mdbg_ctx *c = m->owner ? m->owner : ctx;            // on the stream that produced the rows
     MDBG_HIP_CHECK(ctx, hipSetDevice(c->device));
@@ -434,6 +438,9 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
                                       mdbg_minimizers **out) try {
     if (!ctx || !in || !out || first_k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_purge_palindromes: bad argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // this call reads the input in whatever form it is in: nobody converts it to CSR order under its kernels (ensure_canonical
+    // takes the same lock; every path out of this function synchronises the stream first or has launched nothing)
+    std::lock_guard<std::mutex> as_it_is(in->canon_mu);
     const uint32_t n = in->n_reads;
     DevBuf<uint32_t> cnt, list, n_list;
     MDBG_TRY(cnt.alloc(ctx, n));

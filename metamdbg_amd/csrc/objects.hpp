@@ -4,6 +4,7 @@
 #include "table.hpp"
 
 #include <memory>
+#include <mutex>
 
 // Base-space reads in HBM.  Layout (DESIGN.md "data layout"):
 //   d_words      u64[n_words]   32 bases per word, base i at bits [2i, 2i+2), code (c>>1)&3
@@ -76,6 +77,7 @@ struct mdbg_minimizers {
     bool scattered = false;
     mdbg::DevBuf<uint64_t> d_begin;   // n_reads (scattered only)
     mdbg::DevBuf<uint32_t> d_cnt;     // n_reads (scattered only)
+    mutable std::mutex canon_mu;      // ensure_canonical: several consumers may meet the same fresh scan output (two contexts, two threads)
     uint64_t n_rows = 0;              // scattered only: extent of the row arrays (>= n_min: the regions the waves fill are not full,
                                       // and rows of reads the complexity filter emptied stay behind)
     mdbg_ctx *owner = nullptr;        // the context whose stream produced the object

@@ -838,7 +838,9 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     const uint64_t threshold = a.threshold;
     // APPROX (bump mode only: a read with a false candidate needs the host's re-run): see span_step.  cand_slack widens the
     // superset on purpose (tests of the re-run path)
-    const uint32_t cand_limit = (uint32_t)(threshold >> 32) + 2u + a.cand_slack;
+    // (saturating: a threshold near 2^64 -- densities close to 1 -- must not wrap the limit around to "nothing is a candidate")
+    const uint64_t cand_limit64 = (threshold >> 32) + 2ull + (uint64_t)a.cand_slack;
+    const uint32_t cand_limit = cand_limit64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cand_limit64;
 
     const uint32_t wave_global = blockIdx.x * FAST_WAVES + wv;
     const uint32_t n_waves = gridDim.x * FAST_WAVES;

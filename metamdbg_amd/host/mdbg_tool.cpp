@@ -425,6 +425,7 @@ int run_read_selection(int argc, char **argv) {
                 } catch (const std::exception &e) { die(e.what()); }
                 if (!st.b) return st;
                 st.live = true;
+                if (st.seq == 0) g_trace.mark("first batch parsed");
                 const double t0 = g_trace.now();
                 if (st.b->packed) {
                     check_on(ctx, mdbg_reads_from_packed_async(ctx, st.b->words(), st.b->wordOff.data(), st.b->lens.data(), st.b->n(), &st.reads),
@@ -486,10 +487,12 @@ int run_read_selection(int argc, char **argv) {
             std::lock_guard<std::mutex> g(statMu);
             tWait += wt; tUpload += up; tScan += sc; tDownload += dn; tQueue += qu; nBatches += nb;
         };
+        g_trace.mark("feeder started");
         std::vector<std::thread> consumers;
         for (int i = 1; i < nConsumers; i++) consumers.emplace_back(consume, i);
         consume(0);
         for (auto &t : consumers) t.join();
+        g_trace.mark("last batch scanned and handed to the writer");
     }
     if (getenv("MDBG_TRACE"))
         fprintf(stderr, "[mdbg_tool] %llu batches on %d consumer(s), summed over them: waiting for the feeder %.3f s, upload (queued ahead when packed) %.3f s, scan %.3f s, "
@@ -600,10 +603,21 @@ int run_read_selection(int argc, char **argv) {
 }
 
 // ---- graph ---------------------------------------------------------------------------------------------------------
+// a vector whose resize() leaves new elements uninitialised (they are overwritten at once: 0.8 GB of zero-filling is 0.1 s)
+template <typename T>
+struct DefaultInit : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInit<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new ((void *)p) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...args) { ::new ((void *)p) U(std::forward<A>(args)...); }
+};
+using U32Vec = std::vector<uint32_t, DefaultInit<uint32_t>>;
+
 // "u32 n; u8 circ; u32 m[n]" records (read_data_corrected.txt, unitig_data.txt) -> CSR.  One walk over the record headers for the
 // offsets, then the values are copied by a few threads (a 50 Gbp read set is 0.8 GB of these records: 0.45 s of a 0.75 s `graph` when
 // it was one loop over a zero-filled copy of the file).
-void parse_minimizer_reads(const uint8_t *raw, size_t size, std::vector<uint32_t> &mins, std::vector<uint64_t> &offs,
+template <typename Vec>
+void parse_minimizer_reads(const uint8_t *raw, size_t size, Vec &mins, std::vector<uint64_t> &offs,
                            std::vector<uint8_t> *circular = nullptr, int threads = 1) {
     offs.assign(1, 0);
     offs.reserve(size / 64 + 16);
@@ -623,7 +637,7 @@ void parse_minimizer_reads(const uint8_t *raw, size_t size, std::vector<uint32_t
         offs.push_back(total);
     }
     const size_t base = mins.size();
-    mins.resize(base + total);                     // (zero-filled once; the copies below overwrite it)
+    mins.resize(base + total);
     const size_t nRec = at.size();
     const unsigned nThr = (unsigned)std::max(1, std::min(threads, 16));
     auto copy = [&](unsigned t) {
@@ -721,7 +735,7 @@ struct RankTable {
 // One rank's part of `graph`: reads [r0, r1) of read_data_corrected.txt on `ctx`; with a communicator the table is built
 // across the ranks (include/mdbg_hip.h "the exchange inside the library") and `out` is this rank's share of it.
 // unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
-void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const std::vector<uint32_t> &mins,
+void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const U32Vec &mins,
                 const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
@@ -796,7 +810,7 @@ int run_graph(int argc, char **argv) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     g_log.line("mdbg_tool graph (MI355X) k = " + std::to_string(k) + (a.firstPass ? " --firstpass" : "") +
                (a.gpus > 1 ? " --gpus " + std::to_string(a.gpus) : ""));
-    std::vector<uint32_t> mins;
+    U32Vec mins;
     std::vector<uint64_t> offs;
     {
         MappedFile corrected(dir + "/read_data_corrected.txt");
