@@ -23,6 +23,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -414,6 +416,22 @@ int run_read_selection(int argc, char **argv) {
     };
     std::vector<std::thread> builders;
     for (int i = 0, nb = std::max(1, std::min(4, a.threads / 4)); i < nb; i++) builders.emplace_back(build);
+    std::thread watchdog;
+    std::atomic<bool> watchStop{false};
+    if (const char *e = getenv("MDBG_TOOL_WATCHDOG_S")) {        // debugging aid: the state of the pipeline every so many seconds
+        const int every = std::max(1, atoi(e));
+        watchdog = std::thread([&, every] {
+            for (int t = 0; !watchStop.load(); t++) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                if (t % (10 * every) != 10 * every - 1) continue;
+                std::lock_guard<std::mutex> lk(fifoMu);
+                fprintf(stderr, "[mdbg_tool watchdog] buildQ %zu pending %zu inFlight %zu nextWrite %llu prefSeq %llu sizeOf %zu offOf %zu spare %zu\n", buildQ.size(),
+                        pending.size(), inFlight, (unsigned long long)nextWrite, (unsigned long long)prefSeq, sizeOf.size(), offOf.size(), spareBatches.size());
+                if (!sizeOf.empty()) fprintf(stderr, "    first registered-but-unplaced batch %llu\n", (unsigned long long)sizeOf.begin()->first);
+                if (!buildQ.empty()) fprintf(stderr, "    buildQ front %llu\n", (unsigned long long)buildQ.front()->seq);
+            }
+        });
+    }
     std::thread writer([&] {
         for (;;) {
             HostBatch *hb = nullptr;
@@ -524,6 +542,8 @@ int run_read_selection(int argc, char **argv) {
                     std::unique_lock<std::mutex> lk(fifoMu);
                     if (needCorrected) kept.push_back(Kept{seq, ctx, mins});
                     register_size(seq, hb->t * 10 + (uint64_t)hb->n * 13);
+                    fifoCv.notify_all();        // builders may be waiting for exactly this size to learn their offsets (and this thread may
+                                                // be about to wait itself: a wake-up left for after the wait below never comes)
                     // bounded, but the batch the statistics thread is waiting for always gets in
                     fifoCv.wait(lk, [&] { return inFlight < 12 || seq == nextWrite; });
                     inFlight++;
@@ -559,6 +579,8 @@ int run_read_selection(int argc, char **argv) {
     }
     fifoCv.notify_all();
     writer.join();
+    watchStop = true;
+    if (watchdog.joinable()) watchdog.join();
     if (close(outFd) != 0) die("closing " + outFile + " failed");
     g_trace.mark("main pass done (parse + scan + read_data_init.txt)");
 

@@ -1,0 +1,129 @@
+// stub_mdbg_hip.cpp -- TEST DOUBLE of libmdbg_hip.so for the host pipeline of metamdbg_amd/host/mdbg_tool.cpp (test infrastructure;
+// never shipped, never loaded by the product: tests/test_tool_host_pipeline.py builds mdbg_tool against it in a scratch directory).
+// No GPU, no minimizer arithmetic: every read of L bases gets max(0, L / 271) fake minimizers whose values are a function of the
+// read's length alone (whatever batch it lands in), so that the tool's threads -- feeder, consumers one batch ahead, record builders writing
+// in place, the statistics thread, the purge pass -- can be driven through tens of thousands of batches on a CPU and their output
+// checked for order and completeness.  What it cannot show is numerics; that is what the -m gpu tests are for.
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mdbg_hip.h"
+
+struct mdbg_ctx { std::string err; };
+struct mdbg_reads { std::vector<uint32_t> len; };
+struct mdbg_minimizers { std::vector<uint64_t> off; std::vector<uint32_t> m, pos, len; std::vector<uint8_t> dir, qual, flags; };
+struct mdbg_table {};
+struct mdbg_census {};
+struct mdbg_comm {};
+struct mdbg_shard {};
+
+static void jitter() {           // a little work of varying length, like kernels of varying batches
+    static std::atomic<uint32_t> x{12345};
+    uint32_t v = x.fetch_add(2654435761u);
+    if (const char *e = getenv("MDBG_STUB_JITTER_US")) {
+        const int us = atoi(e);
+        if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds((v >> 8) % (unsigned)us));
+    }
+}
+
+extern "C" {
+int mdbg_create(int, mdbg_ctx **ctx) { *ctx = new mdbg_ctx(); return MDBG_OK; }
+void mdbg_destroy(mdbg_ctx *c) { delete c; }
+const char *mdbg_last_error(const mdbg_ctx *c) { return c ? c->err.c_str() : "stub"; }
+int mdbg_host_alloc(mdbg_ctx *, size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? MDBG_OK : MDBG_ENOMEM; }
+void mdbg_host_free(mdbg_ctx *, void *p) { free(p); }
+
+static mdbg_reads *make_reads(const uint32_t *lengths, uint32_t n) { mdbg_reads *r = new mdbg_reads(); r->len.assign(lengths, lengths + n); return r; }
+int mdbg_reads_from_packed(mdbg_ctx *, const uint64_t *, const uint64_t *, const uint32_t *lengths, uint32_t n, mdbg_reads **out) { *out = make_reads(lengths, n); return MDBG_OK; }
+int mdbg_reads_from_packed_async(mdbg_ctx *, const uint64_t *, const uint64_t *, const uint32_t *lengths, uint32_t n, mdbg_reads **out) { *out = make_reads(lengths, n); return MDBG_OK; }
+int mdbg_reads_from_ascii(mdbg_ctx *, const char *, const char *, const uint64_t *offsets, uint32_t n, mdbg_reads **out) {
+    mdbg_reads *r = new mdbg_reads();
+    for (uint32_t i = 0; i < n; i++) r->len.push_back((uint32_t)(offsets[i + 1] - offsets[i]));
+    *out = r;
+    return MDBG_OK;
+}
+int mdbg_reads_attach_qualities(mdbg_ctx *, mdbg_reads *, const char *, const uint64_t *) { return MDBG_OK; }
+int mdbg_reads_attach_qualities_async(mdbg_ctx *, mdbg_reads *, const char *, const uint64_t *) { return MDBG_OK; }
+int mdbg_reads_mark_ascii(mdbg_ctx *, mdbg_reads *, const uint32_t *, uint32_t, const char *, const uint64_t *) { return MDBG_OK; }
+int mdbg_reads_wait(mdbg_ctx *, const mdbg_reads *) { return MDBG_OK; }
+void mdbg_reads_free(mdbg_reads *r) { delete r; }
+
+int mdbg_scan(mdbg_ctx *, const mdbg_reads *reads, const mdbg_scan_params *, mdbg_minimizers **out) {
+    jitter();
+    mdbg_minimizers *m = new mdbg_minimizers();
+    const uint32_t n = (uint32_t)reads->len.size();
+    m->off.assign(1, 0);
+    for (uint32_t r = 0; r < n; r++) {
+        const uint32_t L = reads->len[r], k = L / 271;
+        for (uint32_t i = 0; i < k; i++) {
+            m->m.push_back(L * 2654435761u + i * 40503u);
+            m->pos.push_back(i * 271u);
+            m->dir.push_back((uint8_t)((L + i) & 1u));
+            m->qual.push_back(1);
+        }
+        m->off.push_back(m->m.size());
+        m->len.push_back(L);
+        m->flags.push_back(0);
+    }
+    *out = m;
+    return MDBG_OK;
+}
+int mdbg_minimizers_info(const mdbg_minimizers *m, uint32_t *n, uint64_t *t) { if (n) *n = (uint32_t)(m->off.size() - 1); if (t) *t = m->m.size(); return MDBG_OK; }
+int mdbg_minimizers_to_host(mdbg_ctx *, const mdbg_minimizers *m, uint64_t *off, uint32_t *mins, uint32_t *pos, uint8_t *dir, uint8_t *qual,
+                            uint32_t *len, float *meanq, uint8_t *flags) {
+    jitter();
+    const size_t n = m->off.size() - 1, t = m->m.size();
+    if (off) memcpy(off, m->off.data(), (n + 1) * 8);
+    if (mins && t) memcpy(mins, m->m.data(), t * 4);
+    if (pos && t && !m->pos.empty()) memcpy(pos, m->pos.data(), t * 4);
+    if (dir && t && !m->dir.empty()) memcpy(dir, m->dir.data(), t);
+    if (qual && t && !m->qual.empty()) memcpy(qual, m->qual.data(), t);
+    if (len && n && !m->len.empty()) memcpy(len, m->len.data(), n * 4);
+    if (flags && n && !m->flags.empty()) memcpy(flags, m->flags.data(), n);
+    if (meanq) for (size_t i = 0; i < n; i++) { const uint32_t nan = 0xFFC00000u; memcpy(&meanq[i], &nan, 4); }
+    return MDBG_OK;
+}
+int mdbg_minimizers_from_host(mdbg_ctx *, const uint32_t *mins, const uint64_t *off, uint32_t n, mdbg_minimizers **out) {
+    mdbg_minimizers *m = new mdbg_minimizers();
+    m->off.assign(off, off + n + 1);
+    m->m.assign(mins + off[0], mins + off[n]);
+    *out = m;
+    return MDBG_OK;
+}
+void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
+int mdbg_purge_palindromes(mdbg_ctx *, const mdbg_minimizers *in, uint32_t, uint32_t, mdbg_minimizers **out) {
+    jitter();
+    mdbg_minimizers *m = new mdbg_minimizers();
+    m->off = in->off; m->m = in->m;
+    *out = m;
+    return MDBG_OK;
+}
+int mdbg_census_create(mdbg_ctx *, mdbg_census **out) { *out = new mdbg_census(); return MDBG_OK; }
+int mdbg_census_add(mdbg_ctx *, mdbg_census *, const mdbg_minimizers *) { return MDBG_OK; }
+int mdbg_census_top(mdbg_ctx *, const mdbg_census *, uint32_t *, uint32_t *n) { *n = 0; return MDBG_OK; }
+void mdbg_census_free(mdbg_census *c) { delete c; }
+// ---- `graph` is not exercised through the stub: the entry points exist so that the tool links
+int mdbg_kminmer_count_first(mdbg_ctx *, const mdbg_minimizers *, uint32_t, uint32_t, mdbg_table **) { return MDBG_ENODEV; }
+int mdbg_kminmer_count_first_sharded(mdbg_ctx *, mdbg_comm *, const mdbg_minimizers *, uint32_t, uint32_t, mdbg_table **) { return MDBG_ENODEV; }
+int mdbg_prev_from_records(mdbg_ctx *, const uint8_t *, uint64_t, mdbg_table **) { return MDBG_ENODEV; }
+int mdbg_prev_overlay_unitigs(mdbg_ctx *, mdbg_table *, const mdbg_minimizers *, const uint32_t *, uint32_t) { return MDBG_ENODEV; }
+int mdbg_kminmer_count_refined(mdbg_ctx *, const mdbg_minimizers *, const mdbg_minimizers *, uint32_t, const mdbg_table *, mdbg_table **) { return MDBG_ENODEV; }
+int mdbg_kminmer_index(mdbg_ctx *, const mdbg_minimizers *, const mdbg_minimizers *, uint32_t, const mdbg_table *, mdbg_table **) { return MDBG_ENODEV; }
+int mdbg_small_contigs(mdbg_ctx *, const mdbg_minimizers *, uint32_t, uint32_t, const mdbg_table *, uint8_t *) { return MDBG_ENODEV; }
+int mdbg_table_info(const mdbg_table *, uint32_t *, uint64_t *, uint64_t *, int *) { return MDBG_ENODEV; }
+int mdbg_table_checksum(mdbg_ctx *, const mdbg_table *, uint64_t *) { return MDBG_ENODEV; }
+int mdbg_table_to_host(mdbg_ctx *, const mdbg_table *, uint8_t *, uint32_t *) { return MDBG_ENODEV; }
+void mdbg_table_free(mdbg_table *t) { delete t; }
+int mdbg_shard_from_table(mdbg_ctx *, const mdbg_table *, uint32_t, mdbg_shard **, const uint64_t **, uint64_t *) { return MDBG_ENODEV; }
+int mdbg_shard_exchange(mdbg_ctx *, mdbg_comm *, mdbg_shard *, const uint64_t *, const uint64_t *, const uint64_t **) { return MDBG_ENODEV; }
+int mdbg_shard_keep(mdbg_ctx *, mdbg_shard *, const uint64_t *, mdbg_table **) { return MDBG_ENODEV; }
+void mdbg_shard_free(mdbg_shard *s) { delete s; }
+int mdbg_comm_unique_id(uint8_t *) { return MDBG_ENODEV; }
+int mdbg_comm_create(mdbg_ctx *, const uint8_t *, int, int, mdbg_comm **) { return MDBG_ENODEV; }
+void mdbg_comm_destroy(mdbg_comm *c) { delete c; }
+}

@@ -1,0 +1,70 @@
+"""The host pipeline of the C++ drop-in (metamdbg_amd/host/mdbg_tool.cpp readSelection: parser workers -> consumers one batch ahead ->
+record builders writing in place -> the statistics thread in read order -> the purge pass) driven on a CPU through thousands of
+batches against a TEST DOUBLE of the library (tests/host/stub_mdbg_hip.cpp: fake minimizers that depend on the read's length only).
+No GPU, no numerics -- order, completeness and freedom from deadlock, under several batch sizes, thread counts and timings: the output
+must be the same bytes every time, and exactly what the fake minimizers imply.  (A missed wake-up between the consumers and the record
+builders once hung the tool on a 50 Gbp file and took half an hour of GPU time to find out; this test reproduces it in a second.)"""
+from __future__ import annotations
+
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from metamdbg_amd import formats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def stub_tool(tmp_path_factory):
+    d = tmp_path_factory.mktemp("stubtool")
+    lib = str(d / "libmdbg_hip.so")
+    exe = str(d / "mdbg_tool")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", os.path.join(ROOT, "tests", "host", "stub_mdbg_hip.cpp"), "-o", lib, "-lpthread"], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "metamdbg_amd", "host", "mdbg_tool.cpp"), "-o", exe, "-L" + str(d), "-lmdbg_hip",
+                    "-lz", "-lpthread", "-Wl,-rpath," + str(d)], check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def read_set(tmp_path_factory):
+    d = tmp_path_factory.mktemp("stubreads")
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 4000, 30_000).astype(np.int64)
+    lens[::97] = 0
+    pool = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 200_000)]
+    fasta = str(d / "reads.fasta")
+    with open(fasta, "wb") as f:
+        for i, n in enumerate(lens):
+            a = int(rng.integers(0, len(pool) - 4000))
+            f.write(b">r%d\n" % i + pool[a:a + int(n)].tobytes() + b"\n")
+    # what the stub's fake minimizers imply for read_data_init.txt / read_data_corrected.txt
+    init, corr = [], []
+    for n in lens:
+        L, k = int(n), int(n) // 271
+        m = ((L * 2654435761 + np.arange(k, dtype=np.uint64) * 40503) & 0xFFFFFFFF).astype("<u4")
+        init.append(struct.pack("<IB", k, 0) + m.tobytes() + (np.arange(k, dtype="<u4") * 271).astype("<u4").tobytes() +
+                    ((L + np.arange(k)) & 1).astype("u1").tobytes() + np.ones(k, "u1").tobytes() + struct.pack("<II", 0xFFC00000, L))
+        corr.append(struct.pack("<IB", k, 0) + m.tobytes())
+    return fasta, b"".join(init), b"".join(corr), lens
+
+
+@pytest.mark.parametrize("batch_bases,threads,jitter", [(1 << 20, 32, 0), (1 << 20, 32, 30), (1 << 16, 8, 0), (1 << 18, 3, 100), (1 << 25, 16, 0), (1 << 14, 32, 0)])
+def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool, read_set, tmp_path, batch_bases, threads, jitter):
+    fasta, exp_init, exp_corr, lens = read_set
+    tmp = tmp_path / "out" / "tmp"
+    os.makedirs(tmp / "filter")
+    formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0).save(str(tmp / "parameters.gz"))
+    (tmp / "input.txt").write_text(fasta + "\n")
+    env = dict(os.environ, MDBG_STUB_JITTER_US=str(jitter))
+    for rep in range(3):
+        r = subprocess.run([stub_tool, "readSelection", str(tmp), str(tmp / "read_data_init.txt"), str(tmp / "input.txt"), "--threads", str(threads),
+                            "--min-read-quality", "0.000000", "--batch-bases", str(batch_bases)], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-800:]
+        assert (tmp / "read_data_init.txt").read_bytes() == exp_init
+        assert (tmp / "read_data_corrected.txt").read_bytes() == exp_corr
+        st = formats.parse_read_stats((tmp / "read_stats.txt").read_bytes())
+        assert st["n_reads"] == len(lens) and st["n_bases"] == int(lens.sum()) and st["n_minimizers"] == int((lens // 271).sum())

@@ -64,10 +64,10 @@ def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=()):
     env = dict(os.environ, MDBG_TRACE="1") if trace else dict(os.environ)
     t0 = time.perf_counter()
     r1 = subprocess.run([TOOL, "readSelection", tmp, tmp + "/read_data_init.txt", tmp + "/input.txt", "--threads", str(threads),
-                         "--min-read-quality", "0.000000", *rs_args], capture_output=True, text=True, env=env)
+                         "--min-read-quality", "0.000000", *rs_args], capture_output=True, text=True, env=env, timeout=240)
     t1 = time.perf_counter()
     assert r1.returncode == 0, r1.stderr[-1000:]
-    r2 = subprocess.run([TOOL, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], capture_output=True, text=True, env=env)
+    r2 = subprocess.run([TOOL, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], capture_output=True, text=True, env=env, timeout=240)
     t2 = time.perf_counter()
     assert r2.returncode == 0, r2.stderr[-1000:]
     sizes = {n: os.path.getsize(os.path.join(tmp, n)) for n in ("read_data_init.txt", "read_data_corrected.txt", "kminmerData_abundance.txt", "kminmerData_min.txt")}
