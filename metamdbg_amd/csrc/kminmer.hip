@@ -114,6 +114,17 @@ __device__ __forceinline__ uint32_t table_upsert_set(const TableView &t, uint64_
     return s;
 }
 
+// insert-if-absent with a value that is a function of the key (the index passes: min of the previous abundances of the window's two
+// sub-windows, the same for every instance of the key and in either orientation): only the instance that publishes the key stores it.
+// The other instances -- nineteen in twenty at 50x -- stop at the probe instead of each sending its own copy of the value to memory.
+__device__ __forceinline__ uint32_t table_insert_once(const TableView &t, uint64_t lo, uint64_t hi, uint32_t v) {
+    if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, 0, v, true, 0u, true);
+    bool created = false;
+    uint32_t s = table_find_or_insert(t, lo, hi, true, &created);
+    if (s != SLOT_NONE && created) __hip_atomic_store(&t.slots[s].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s;
+}
+
 struct SeqView {
     const uint32_t *mins;
     const uint64_t *off;       // n_reads + 1
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, co
         if (a <= 1u) return;
         uint64_t hi, lo;
         window_hash_uniform(m, k, hi, lo);
-        table_upsert_set(t, lo, hi, a, 0u);
+        table_insert_once(t, lo, hi, a);
     }, t.poll_overflow ? t.overflow : nullptr);
 }
 
