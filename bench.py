@@ -42,6 +42,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
+DEFAULT_TABLE_GRID = 0         # workgroups of the kernels that walk every k-min-mer instance, batches in flight (0: one per CU)
 DEFAULT_TABLE_CUS = 0          # compute units the table kernels of a batch in flight are confined to (0: not confined)
 
 
@@ -713,6 +714,7 @@ ATOMIC_RATE_GOPS = 26.0
 def run_alone(ctx) -> None:
     """The context is the only one working on the device from here on: no footprint limits."""
     ctx.set_option("table_blocks_per_cu", 0)
+    ctx.set_option("table_grid_blocks", 0)
     ctx.set_option("table_cu_count", 0)
 
 
@@ -800,6 +802,8 @@ def main() -> None:
     table_blocks = int(os.environ.get("MDBG_TABLE_BLOCKS_PER_CU", "1")) if n_slots > 1 else 0
     # ... and, optionally, to a few compute units of their own ("table_cu_count", include/mdbg_hip.h): sweep in profiles/
     table_cus = int(os.environ.get("MDBG_BENCH_TABLE_CUS", str(DEFAULT_TABLE_CUS))) if n_slots > 1 else 0
+    # ... or to fewer workgroups than there are CUs ("table_grid_blocks")
+    table_grid = int(os.environ.get("MDBG_BENCH_TABLE_GRID", str(DEFAULT_TABLE_GRID))) if n_slots > 1 else 0
     slots = []
     # one metagenome for the job (MDBG_BENCH_SPEC_RANKS: test hook, the per-rank workload of an N-rank job on one GPU)
     spec_ranks = int(os.environ.get("MDBG_BENCH_SPEC_RANKS", world))
@@ -811,6 +815,8 @@ def main() -> None:
         c.set_option("table_blocks_per_cu", table_blocks)
         if table_cus:
             c.set_option("table_cu_count", table_cus)
+        if table_grid:
+            c.set_option("table_grid_blocks", table_grid)
         if shared_reads is None:
             shared_reads = c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)
         slots.append((c, shared_reads))
@@ -1026,6 +1032,8 @@ def main() -> None:
             c.close()
             slots[1] = (capi.Context(local_rank), r)
             slots[1][0].set_option("table_blocks_per_cu", table_blocks)
+            if table_grid:
+                slots[1][0].set_option("table_grid_blocks", table_grid)
             if table_cus:
                 slots[1][0].set_option("table_cu_count", table_cus)
             # (the communicator of a slot belongs to the rank, not to the context: comms[1] stays)
@@ -1197,7 +1205,7 @@ def main() -> None:
                                    "shared by the batches in flight",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
-                       "batches_in_flight": n_slots, "table_blocks_per_cu": table_blocks, "table_cu_count": table_cus, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
+                       "batches_in_flight": n_slots, "table_blocks_per_cu": table_blocks, "table_grid_blocks": table_grid, "table_cu_count": table_cus, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
                        "exchange": exch},
             "roofline": {"bound": "hbm", "kernel": "scan_fast_kernel<HPC=1,QUAL=0,APPROX=1> (_ZN4mdbg16scan_fast_kernelILb1ELb0ELb1EEEvNS_8ScanArgsE)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,

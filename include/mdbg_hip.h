@@ -55,6 +55,8 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
 /* Per-context tuning, value <= 0 restores the default:
  *   "table_blocks_per_cu"   resident blocks per CU of the kernels that walk every k-min-mer instance (default: unlimited;
  *                           1..3 when several contexts share a device, so that they do not displace another context's scan)
+ *   "table_grid_blocks"     g > 0: those kernels run as exactly g workgroups (grid-stride), e.g. half a block per CU beside a scan;
+ *                           0 (default): "table_blocks_per_cu" decides
  *   "table_cu_count"        c > 0: every kernel of the context except the block-structured scan kernel is confined to c compute
  *                           units (spread over the XCDs), the scan kernel runs on a stream of its own over all of them; for
  *                           several contexts in flight on one device (the other batches' table kernels then displace a running

@@ -125,6 +125,7 @@ struct mdbg_ctx {
     bool timing = false;
     std::vector<mdbg::TimedLaunch> launches;               // pending (not yet folded) timed launches
     std::map<std::string, std::pair<double, uint64_t>> timers;  // name -> (ms, launches)
+    unsigned table_grid_blocks = 0;                        // > 0: the absolute grid of those kernels (fewer blocks than CUs: beside a scan, mdbg_set_option)
     unsigned table_blocks_per_cu = 1024;                   // resident blocks per CU of the kernels that walk every k-min-mer instance (mdbg_set_option)
     unsigned scan_reads_per_wave = 2;                      // reads a scan wave processes before it retires (mdbg_set_option)
     uint32_t scan_wave_priority = 0;        // s_setprio level of the block-structured scan's waves (mdbg_set_option)

@@ -155,6 +155,7 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
         return MDBG_OK;
     }
     if (n == "table_cu_count") return set_table_cu_count(ctx, value > 0 ? (unsigned)std::min<int64_t>(value, 4096) : 0u);
+    if (n == "table_grid_blocks") { ctx->table_grid_blocks = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 0u; return MDBG_OK; }
     if (n == "table_blocks_per_cu") { ctx->table_blocks_per_cu = value > 0 ? (unsigned)std::min<int64_t>(value, 1024) : 1024u; return MDBG_OK; }
     if (n == "scan_wave_priority") { ctx->scan_wave_priority = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }

@@ -168,6 +168,7 @@ __device__ __forceinline__ void for_each_instance(const SeqView &s, F f, const u
 // grid-stride over the reads) keep them from displacing the scan's waves: 3 per CU costs the insert 2.9 -> 3.6 ms and
 // gives the scan back 0.5 ms, which is what the step then runs at.
 static unsigned instance_grid(const mdbg_ctx *ctx, uint32_t n_reads) {
+    if (ctx->table_grid_blocks) return grid_for((uint64_t)n_reads * 16, 256, ctx->table_grid_blocks);
     return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * ctx->table_blocks_per_cu);
 }
 
