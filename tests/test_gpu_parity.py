@@ -1019,6 +1019,38 @@ def test_few_marked_reads_are_routed_one_by_one(ctx, orc):
         ctx.reads_from_packed(words, woff, lens).mark_ascii([3], [seqs[3][:-1]])
 
 
+def test_context_options_do_not_change_results(ctx):
+    """The tuning options of mdbg_set_option change how the work is laid out on the device, never what comes out: the table kernels
+    as a handful of workgroups (table_grid_blocks) or one block per CU, every kernel but the block-structured scan confined to 16 CUs
+    with the scan on a stream of its own (table_cu_count), the memory pool trimmed or allowed 90 % of the device."""
+    from metamdbg_amd import capi
+    spec = synth.hifi_spec(4000, seed=61, read_len=8000, coverage=30.0)
+    base = capi.Context(0)
+    reads = base.reads_synthetic(spec)
+    want_m = base.scan(reads, K=15, density=0.005, hpc=True).to_host()
+    corr = base.purge_palindromes(base.scan(reads, K=15, density=0.005, hpc=True), 4, 100)
+    want = (base.kminmer_count_first(corr, 4, 0).checksum(), base.kminmer_index(corr, None, 6, base.kminmer_count_refined(corr, None, 5, base.kminmer_count_first(corr, 4, 0))).checksum())
+    for options in ({"table_grid_blocks": 7}, {"table_blocks_per_cu": 1}, {"table_cu_count": 16}, {"table_cu_count": 16, "table_grid_blocks": 64},
+                    {"pool_cache_percent": 90, "pool_trim": 1}, {"scan_reads_per_wave": 5}):
+        c = capi.Context(0)
+        for name, value in options.items():
+            c.set_option(name, value)
+        r = c.reads_synthetic(spec)
+        m = c.scan(r, K=15, density=0.005, hpc=True)
+        h = m.to_host()
+        for key in want_m:
+            assert np.array_equal(h[key], want_m[key], equal_nan=True) if want_m[key].dtype.kind == "f" else np.array_equal(h[key], want_m[key]), (options, key)
+        cr = c.purge_palindromes(m, 4, 100)
+        t4 = c.kminmer_count_first(cr, 4, 0)
+        got = (t4.checksum(), c.kminmer_index(cr, None, 6, c.kminmer_count_refined(cr, None, 5, t4)).checksum())
+        assert got == want, options
+        if "table_cu_count" in options:                 # and back: one unconfined stream again
+            c.set_option("table_cu_count", 0)
+            assert c.kminmer_count_first(cr, 4, 0).checksum() == want[0]
+        c.close()
+    base.close()
+
+
 def test_table_checksum_is_the_references_formula(ctx):
     """mdbg_table_checksum on the device = the sums over the host copy of the rows; sums[0] is the "Checksum kminmer abundance" the
     reference logs when it loads a table (graph/CreateMdbg.cpp:3321: abundance * vecHash truncated to u64 -- the low word)."""
