@@ -13,13 +13,19 @@ N>1: one process per GPU, every rank owns its own shard of the same size (weak s
 k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
 all-to-alls over RCCL (metamdbg_amd/distributed.py, include/mdbg_hip.h mdbg_shard_*).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library's
-stream), `cpu_baseline` (the reference's own code, oracle/_ref/refdrv, timed on this box's cores
-on a bounded sample of the same reads; `path_only` = up to the moment its tables are on disk) and, at N=1,
-`parity` (the HIP path's read_data_init bytes and k-min-mer table against the reference's files for that sample;
-a mismatch fails the run) and `legs`: `end_to_end` (the C++ tool against the reference from one FASTA file),
-`multik` (configs[2]: k = 4..11 over the resident batch, benchmark mode) and `ont` (configs[3] preset: 20 kb
-reads with qualities, no HPC, repetitive-minimizer filter from the 0.025 census).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library's stream; `traffic` only from a PMC
+collection made on this very csrc/scan.hip), `roofline_kminmer` (the table kernels alone: 4 M + 16 I + 20 D bytes, and the atomic-rate
+ceiling of the insert), `cpu_baseline` (the reference's own code, oracle/_ref/refdrv, timed on this box's cores on BASELINE.json
+configs[1] whole -- 1 M reads, 10 Gbp; `path_only` = up to the moment its tables are on disk) and, at N=1, `parity` (the HIP path's
+read_data_init bytes, corrected reads, k-min-mer table and abundance checksum against the reference's files for that whole config, plus
+the digests committed under tests/golden/hifi_1m; a mismatch fails the run) and `legs`: `end_to_end` (the C++ tool against the
+reference from the same FASTA file), `multik` (configs[2]: k = 4..11 over the resident batch, benchmark mode), `multik_reference`
+(configs[2] in the reference's own mode: its graph -> contig -> toMinspace loop on 200 000 reads, mdbg_tool graph's tables against the
+reference's at every k), `pcie` (reads arriving over the link, synchronous and pipelined) and `ont` (configs[3] at its stated size: 10 M
+x 20 kb reads with qualities in three resident pieces, parity on a 100 000-read sample).
+At N>1 the line carries a `parity` block too: one more sharded step, its per-rank tables reduced to counts and order-independent sums,
+all-reduced and compared with the single-GPU first pass over ALL the reads that rank 0 runs alone; `config.exchange` reports the
+communicator's rank count, wire bytes and exchange time per step.  A mismatch fails the run.
 """
 from __future__ import annotations
 
