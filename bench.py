@@ -491,8 +491,8 @@ def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int =
             step(ctx, ascii_input)
         dt = time.perf_counter() - t0
         res[f"{name}_one_context_gbps"] = n_bases * repeats / 1e9 / dt
-    # ---- one context, the upload of batch i+1 queued (mdbg_reads_from_packed_async: the context's upload stream, a copy engine)
-    # before batch i is put through its kernels: the link and the kernels work at the same time
+    # ---- one context, the uploads of batches i+1 and i+2 queued (mdbg_reads_from_packed_async: the context's upload stream, a copy
+    # engine) before batch i is put through its kernels: the link and the kernels work at the same time
     def upload_async(c):
         h = C.c_void_p()
         c.check(capi.lib().mdbg_reads_from_packed_async(c.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
@@ -508,10 +508,17 @@ def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int =
             o.free()
         return out
 
-    def pipelined(c, n):
-        nxt, got = upload_async(c), None
+    def pipelined(c, n, ahead=2):
+        """`ahead` uploads queued beyond the batch being processed: the link is the longer half, and with a second upload already
+        behind the first it does not idle while the host gets round to issuing the next."""
+        from collections import deque
+        queue = deque(upload_async(c) for _ in range(min(ahead, n)))
+        issued, got = len(queue), None
         for i in range(n):
-            cur, nxt = nxt, (upload_async(c) if i + 1 < n else None)
+            cur = queue.popleft()
+            if issued < n:
+                queue.append(upload_async(c))
+                issued += 1
             got = kernels(c, cur)
             cur.free()
         return got
