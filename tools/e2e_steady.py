@@ -53,7 +53,7 @@ def _gz_member(args):
     return co.compress(raw) + co.flush()
 
 
-def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=()):
+def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=(), graph_args=("--min-abundance", "0", "--firstpass")):
     from metamdbg_amd import formats
     tmp = os.path.join(tmp_parent, "tmp")
     shutil.rmtree(tmp_parent, ignore_errors=True)
@@ -67,7 +67,7 @@ def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=()):
                          "--min-read-quality", "0.000000", *rs_args], capture_output=True, text=True, env=env, timeout=240)
     t1 = time.perf_counter()
     assert r1.returncode == 0, r1.stderr[-1000:]
-    r2 = subprocess.run([TOOL, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"], capture_output=True, text=True, env=env, timeout=240)
+    r2 = subprocess.run([TOOL, "graph", tmp, "--threads", str(threads), *graph_args], capture_output=True, text=True, env=env, timeout=240)
     t2 = time.perf_counter()
     assert r2.returncode == 0, r2.stderr[-1000:]
     sizes = {n: os.path.getsize(os.path.join(tmp, n)) for n in ("read_data_init.txt", "read_data_corrected.txt", "kminmerData_abundance.txt", "kminmerData_min.txt")}
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--threads", default="32,64")
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--out", default="")
+    ap.add_argument("--ont-reads", type=int, default=0, help="ONT preset: n x 20 kb reads with qualities as FASTQ, no HPC, census + --skip-correction")
     ap.add_argument("--batch-bases", default="", help="comma list: readSelection --batch-bases values to compare on the FASTA set (tool flag, not a reference flag)")
     a = ap.parse_args()
     from metamdbg_amd import capi, formats, synth
@@ -101,6 +102,10 @@ def main():
             qspec = dataclasses.replace(synth.hifi_spec(a.fastq_reads, seed=42, read_len=10_000, coverage=50.0), with_quality=True)
             fastq = os.path.join(work, "reads.fastq")
             res["fastq_write_s"] = write_reads(fastq, ctx, qspec, a.fastq_reads, True)
+        if a.ont_reads:
+            ospec = synth.ont_spec(a.ont_reads, seed=43, read_len=20_000, coverage=50.0)
+            ont_fastq = os.path.join(work, "ont.fastq")
+            res["ont_write_s"] = write_reads(ont_fastq, ctx, ospec, a.ont_reads, True)
         ctx.close()
 
         def best_of(inputs, n_reads, label, reps=2):
@@ -124,6 +129,17 @@ def main():
                     print("    ", ln, file=sys.stderr)
         if a.fastq_reads:
             res["fastq"] = best_of([fastq], a.fastq_reads, "fastq")
+        if a.ont_reads:
+            PO = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=False, data_type=1, correction_density=0.025)
+            out = {}
+            for t in threads:
+                runs = [run_tool(os.path.join(work, "run"), [ont_fastq], t, PO, rs_args=("--skip-correction",)) for _ in range(2)]
+                b = min(runs, key=lambda r: r["total_s"])
+                gbp = a.ont_reads * 20_000 / 1e9
+                b.update(gbp=gbp, gbps=gbp / b["total_s"], read_selection_gbps=gbp / b["read_selection_s"], all_total_s=[round(r["total_s"], 3) for r in runs])
+                out[f"threads_{t}"] = b
+                print("ont", t, "threads: %.2f s total (readSelection %.2f, graph %.2f) = %.1f Gbp/s" % (b["total_s"], b["read_selection_s"], b["graph_s"], b["gbps"]), file=sys.stderr, flush=True)
+            res["ont"] = out
         if a.gz_reads and a.reads:
             import multiprocessing as mp
             n = min(a.gz_reads, a.reads)
