@@ -259,6 +259,9 @@ int  mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_records, uint
  * (MDBG::writeKminmerAbundance, Commons.hpp:4463-4472); vectors = n_records x k u32
  * (MDBG::writeKminmer, Commons.hpp:4429-4446), same row order.  Either may be NULL. */
 int  mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *records20, uint32_t *vectors);
+/* Rows [first, first + count) only, same layout: a writer streams a large table (the ONT preset's first pass leaves 75 M records per
+ * 20 Gbp, most of them rescued singletons) to its files through two page-locked buffers instead of holding it all on the host. */
+int  mdbg_table_to_host_range(mdbg_ctx *ctx, const mdbg_table *t, uint64_t first, uint64_t count, uint8_t *records20, uint32_t *vectors);
 /* What the pass that built the table walked: stats[0] = minimizers read (M), [1] = k-min-mer instances (I = sum over the
  * sequences of max(0, n - k + 1)), [2] = distinct keys it inserted, [3] = slots of the hash table it used.  With the table's
  * rows D these are the terms of the step's algorithmic bytes 4 M + 16 I + 20 D; zeros for tables that were

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mdbg_kminmer_index": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(_P)]),
     "mdbg_table_info": (C.c_int, [_P, _u32p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "mdbg_table_to_host": (C.c_int, [_P, _P, _P, _P]),
+    "mdbg_table_to_host_range": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "mdbg_table_checksum": (C.c_int, [_P, _P, _u64p]),
     "mdbg_table_stats": (C.c_int, [_P, _u64p]),
     "mdbg_device_clock_khz": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -581,6 +582,15 @@ class Table:
         s = (C.c_uint64 * 4)()
         self.ctx.check(lib().mdbg_table_checksum(self.ctx.h, self.h, s))
         return tuple(int(x) for x in s)
+
+    def to_host_range(self, first: int, count: int) -> tuple[np.ndarray, np.ndarray | None]:
+        """Rows [first, first + count) as to_host gives them."""
+        from .formats import ABUNDANCE_DTYPE
+        i = self.info()
+        rec = np.zeros(count, dtype=ABUNDANCE_DTYPE)
+        vec = np.zeros((count, i["k"]), dtype=np.uint32) if i["has_vectors"] else None
+        self.ctx.check(lib().mdbg_table_to_host_range(self.ctx.h, self.h, first, count, _ptr(rec), _ptr(vec)))
+        return rec, vec
 
     def keys_to_host(self) -> np.ndarray:
         """(n, 2) u64 array of (lo, hi) -- the 16-byte little-endian u128 records of edges.bin."""

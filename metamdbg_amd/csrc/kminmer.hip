@@ -983,6 +983,25 @@ extern "C" int mdbg_table_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint8_t *r
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
+extern "C" int mdbg_table_to_host_range(mdbg_ctx *ctx, const mdbg_table *t, uint64_t first, uint64_t count, uint8_t *records20, uint32_t *vectors) try {
+    if (!ctx || !t) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host_range: null argument");
+    if (first > t->n_records || count > t->n_records - first) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host_range: rows [%llu, +%llu) of %llu",
+                                                                               (unsigned long long)first, (unsigned long long)count, (unsigned long long)t->n_records);
+    if (vectors && !t->has_vectors) return set_error(ctx, MDBG_EINVAL, "mdbg_table_to_host_range: table has no vectors (k >= firstK+2)");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!count) return MDBG_OK;
+    DevBuf<uint8_t> d_rec;
+    if (records20) {
+        MDBG_TRY(d_rec.alloc(ctx, count * 20));
+        hipLaunchKernelGGL(pack_records_kernel, dim3(grid_for(count, 256)), dim3(256), 0, ctx->stream, t->d_lo.p + first, t->d_hi.p + first, t->d_ab.p + first,
+                           count, d_rec.p);
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(records20, d_rec.p, count * 20, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (vectors) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(vectors, t->d_vec.p + first * t->k, count * t->k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // one wait for both
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
 extern "C" int mdbg_table_lookup(mdbg_ctx *ctx, const mdbg_table *t, const uint64_t *hash_lo, const uint64_t *hash_hi,
                                  uint64_t n, uint32_t *abundance) try {
     if (!ctx || !t || (n && (!hash_lo || !hash_hi || !abundance))) return set_error(ctx, MDBG_EINVAL, "mdbg_table_lookup: null argument");

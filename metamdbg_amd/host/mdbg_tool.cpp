@@ -219,6 +219,31 @@ void for_each_batch(const std::string &inputList, size_t batchBases, int threads
     } catch (const std::exception &e) { die(e.what()); }
 }
 
+// The same one batch ahead: stage(b) starts bringing batch i+1 to the device (an upload that runs beside the kernels) before
+// process(handle, b) works on batch i; the batch's page-locked buffer is recycled after process.  The feeder is taken apart on a thread
+// of its own (un-pinning its buffers and unmapping the input are not worth waiting for).
+template <typename Handle>
+void for_each_batch_ahead(const std::string &inputList, size_t batchBases, int threads, uint64_t maxReadsPerFile,
+                          const std::function<Handle(ReadBatch &)> &stage, const std::function<void(Handle, ReadBatch &)> &process) {
+    auto alloc = [](size_t n) -> void * { void *p = nullptr; check(mdbg_host_alloc(g_ctx, n, &p), "mdbg_host_alloc"); return p; };
+    auto release = [](void *p) { mdbg_host_free(g_ctx, p); };
+    try {
+        std::unique_ptr<mdbg_host::ReadFeeder> feeder(new mdbg_host::ReadFeeder(read_input_list(inputList), batchBases, threads, maxReadsPerFile, alloc, release));
+        ReadBatch *nb = feeder->next();
+        Handle nh{};
+        if (nb) nh = stage(*nb);
+        while (nb) {
+            ReadBatch *cb = nb;
+            Handle ch = nh;
+            nb = feeder->next();
+            if (nb) nh = stage(*nb);
+            process(ch, *cb);
+            feeder->recycle(cb);
+        }
+        std::thread([f = feeder.release()] { delete f; }).detach();
+    } catch (const std::exception &e) { die(e.what()); }
+}
+
 // a parsed batch -> reads in HBM: 2-bit words when the feeder packed the chunk, ASCII (packed on the device) otherwise
 void check_on(mdbg_ctx *ctx, int rc, const char *what) {
     if (rc) die(std::string(what) + ": " + mdbg_last_error(ctx));
@@ -269,16 +294,27 @@ int run_read_selection(int argc, char **argv) {
             // every batch's minimizer values are counted where they are (mdbg_census_*): nothing but the pick comes back
             mdbg_census *census = nullptr;
             check(mdbg_census_create(g_ctx, &census), "mdbg_census_create");
-            for_each_batch(inputList, a.batchBases, a.threads, 1000000, [&](ReadBatch &b) {
-                mdbg_reads *reads = nullptr;
-                mdbg_minimizers *mins = nullptr;
-                reads = upload_batch(g_ctx, b, false);
-                mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
-                check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
-                check(mdbg_census_add(g_ctx, census, mins), "mdbg_census_add");
-                mdbg_minimizers_free(mins);
-                mdbg_reads_free(reads);
-            });
+            // (the census scan never looks at qualities -- CountMinimizerFunctor, ReadSelection.hpp:565-625 -- so they do not travel)
+            for_each_batch_ahead<mdbg_reads *>(inputList, a.batchBases, a.threads, 1000000,
+                [&](ReadBatch &b) -> mdbg_reads * {
+                    mdbg_reads *reads = nullptr;
+                    if (b.packed) {
+                        check(mdbg_reads_from_packed_async(g_ctx, b.words(), b.wordOff.data(), b.lens.data(), b.n(), &reads), "mdbg_reads_from_packed_async");
+                        if (!b.odd.empty())
+                            check(mdbg_reads_mark_ascii(g_ctx, reads, b.odd.data(), (uint32_t)b.odd.size(), b.oddBases.data(), b.oddOff.data()), "mdbg_reads_mark_ascii");
+                    } else reads = upload_batch(g_ctx, b, false);
+                    return reads;
+                },
+                [&](mdbg_reads *reads, ReadBatch &) {
+                    mdbg_minimizers *mins = nullptr;
+                    mdbg_scan_params p = scan_params(P, P.densityCorrection, {}, 0, false);
+                    check(mdbg_scan(g_ctx, reads, &p, &mins), "mdbg_scan");
+                    check(mdbg_census_add(g_ctx, census, mins), "mdbg_census_add");
+                    mdbg_minimizers_free(mins);
+                    check(mdbg_reads_wait(g_ctx, reads), "mdbg_reads_wait");       // before the batch's buffer is recycled
+                    mdbg_reads_free(reads);
+                });
+            g_trace.mark("census done");
             uint32_t cap = 1u << 16;
             rep.resize(cap);
             check(mdbg_census_top(g_ctx, census, rep.data(), &cap), "mdbg_census_top");
@@ -817,7 +853,8 @@ struct RankTable {
 // across the ranks (include/mdbg_hip.h "the exchange inside the library") and `out` is this rank's share of it.
 // unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
 void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const U32Vec &mins,
-                const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true) {
+                const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true,
+                const std::function<void(mdbg_ctx *, mdbg_table *)> &sink = nullptr) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
     mdbg_minimizers *reads = nullptr;
@@ -872,13 +909,66 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
     }
     mdbg_table_info(table, nullptr, &out.n, &out.nSolid, &out.hasVec);
     check_on(ctx, mdbg_table_checksum(ctx, table, out.sums), "mdbg_table_checksum");
-    if (rowsToHost) {
+    if (sink) sink(ctx, table);            // the rows go straight to their files (one rank: run_graph)
+    else if (rowsToHost) {
         out.rec.resize(out.n * 20);
         out.vec.resize(out.hasVec ? out.n * k : 0);
         check_on(ctx, mdbg_table_to_host(ctx, table, out.rec.data(), out.hasVec ? out.vec.data() : nullptr), "mdbg_table_to_host");
     }
     mdbg_table_free(table);
     mdbg_minimizers_free(reads);
+}
+
+// The rows of a table to their files without a host copy of the whole table: pieces of 2 M rows come down into one of two page-locked
+// buffers while the piece before is written -- every file by a thread of its own (the 20-byte records go to kminmerData_abundance.txt and to
+// its `_init` copy, graph/CreateMdbg.cpp:515-522; the vectors to kminmerData_min.txt).  The ONT preset's first pass leaves 75 M records per
+// 20 Gbp: 2.7 GB of rows, 4.2 GB of files -- 1.2 s of a 1.65 s `graph` when they went through pageable vectors and one writing thread.
+void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const std::vector<std::string> &recFiles, const std::string &vecFile) {
+    uint64_t n = 0;
+    int hasVec = 0;
+    mdbg_table_info(table, nullptr, &n, nullptr, &hasVec);
+    const bool vec = hasVec && !vecFile.empty();
+    std::vector<int> recFd, vecFd;
+    for (const std::string &f : recFiles) {
+        const int fd = open(f.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (fd < 0) die("cannot write " + f);
+        recFd.push_back(fd);
+    }
+    if (vec) {
+        const int fd = open(vecFile.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (fd < 0) die("cannot write " + vecFile);
+        vecFd.push_back(fd);
+    }
+    const uint64_t piece = (uint64_t)1 << 21;
+    struct Buf { uint8_t *rec = nullptr; uint32_t *vec = nullptr; };
+    Buf buf[2];
+    if (n) for (Buf &b : buf) {
+        void *p = nullptr;
+        check_on(ctx, mdbg_host_alloc(ctx, std::min(n, piece) * 20, &p), "mdbg_host_alloc"); b.rec = (uint8_t *)p;
+        if (vec) { check_on(ctx, mdbg_host_alloc(ctx, std::min(n, piece) * k * 4, &p), "mdbg_host_alloc"); b.vec = (uint32_t *)p; }
+    }
+    auto put = [](int fd, const void *data, size_t bytes, uint64_t at) {
+        for (size_t done = 0; done < bytes;) {
+            const ssize_t w = pwrite(fd, (const char *)data + done, bytes - done, (off_t)(at + done));
+            if (w < 0) { if (errno == EINTR) continue; die("writing a table file failed"); }
+            done += (size_t)w;
+        }
+    };
+    std::vector<std::thread> writers;           // of the piece before the one coming down
+    for (uint64_t first = 0, i = 0; first < n; first += piece, i++) {
+        const uint64_t cnt = std::min(piece, n - first);
+        Buf &b = buf[i & 1];
+        if (i >= 2) { /* buf[i & 1] was written out two pieces ago: its writers were joined below */ }
+        check_on(ctx, mdbg_table_to_host_range(ctx, table, first, cnt, b.rec, vec ? b.vec : nullptr), "mdbg_table_to_host_range");
+        for (auto &t : writers) t.join();        // the other buffer is free again, this one is full
+        writers.clear();
+        for (int fd : recFd) writers.emplace_back(put, fd, (const void *)b.rec, (size_t)(cnt * 20), first * 20);
+        for (int fd : vecFd) writers.emplace_back(put, fd, (const void *)b.vec, (size_t)(cnt * k * 4), first * k * 4);
+    }
+    for (auto &t : writers) t.join();
+    for (int fd : recFd) if (close(fd) != 0) die("closing a table file failed");
+    for (int fd : vecFd) if (close(fd) != 0) die("closing a table file failed");
+    for (Buf &b : buf) { if (b.rec) mdbg_host_free(ctx, b.rec); if (b.vec) mdbg_host_free(ctx, b.vec); }
 }
 
 int run_graph(int argc, char **argv) {
@@ -908,12 +998,19 @@ int run_graph(int argc, char **argv) {
     // RCCL.  MDBG_TOOL_SHARDED=1 takes the same path with one rank (a communicator of one: what a one-GPU box can exercise).
     const int G = std::max(1, a.gpus);
     const bool sharded = G > 1 || getenv("MDBG_TOOL_SHARDED") != nullptr;
+    bool streamed = false;               // the table files were written as the rows came down (one rank)
     std::vector<RankTable> parts((size_t)G);
     if (!sharded) {
         check(mdbg_create(0, &g_ctx), "mdbg_create");
         g_trace.mark("graph: context created");
-        graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0]);
-        g_trace.mark("graph: table built and copied back");
+        // one rank: the rows are streamed to their files (graph/CreateMdbg.cpp:451-464, :515-522 for the copies)
+        std::vector<std::string> recFiles{dir + "/kminmerData_abundance.txt"};
+        if (a.firstPass) recFiles.push_back(dir + "/kminmerData_abundance_init.txt");
+        if (k == P.firstK + 1) recFiles.push_back(dir + "/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
+        graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0], false,
+                   [&](mdbg_ctx *c, mdbg_table *t) { stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt"); });
+        streamed = true;
+        g_trace.mark("graph: table built and written");
     } else {
         uint8_t id[MDBG_COMM_ID_BYTES];
         check(mdbg_comm_unique_id(id), "mdbg_comm_unique_id");
@@ -969,14 +1066,16 @@ int run_graph(int argc, char **argv) {
         std::ofstream f(dir + to, std::ios::binary);
         for (const RankTable &t : parts) f.write((const char *)t.rec.data(), (std::streamsize)t.rec.size());
     };
-    write_records("/kminmerData_abundance.txt");
-    if (hasVec) {
-        std::ofstream f(dir + "/kminmerData_min.txt", std::ios::binary);
-        for (const RankTable &t : parts) f.write((const char *)t.vec.data(), (std::streamsize)(t.vec.size() * 4));
+    if (!streamed) {
+        write_records("/kminmerData_abundance.txt");
+        if (hasVec) {
+            std::ofstream f(dir + "/kminmerData_min.txt", std::ios::binary);
+            for (const RankTable &t : parts) f.write((const char *)t.vec.data(), (std::streamsize)(t.vec.size() * 4));
+        }
+        // graph/CreateMdbg.cpp:515-522
+        if (a.firstPass) write_records("/kminmerData_abundance_init.txt");
+        if (k == P.firstK + 1) write_records("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
     }
-    // graph/CreateMdbg.cpp:515-522
-    if (a.firstPass) write_records("/kminmerData_abundance_init.txt");
-    if (k == P.firstK + 1) write_records("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
     small.close();
     g_trace.mark("graph: tables written");
     write_perf(dir);

@@ -118,6 +118,7 @@ int mdbg_small_contigs(mdbg_ctx *, const mdbg_minimizers *, uint32_t, uint32_t, 
 int mdbg_table_info(const mdbg_table *, uint32_t *, uint64_t *, uint64_t *, int *) { return MDBG_ENODEV; }
 int mdbg_table_checksum(mdbg_ctx *, const mdbg_table *, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_table_to_host(mdbg_ctx *, const mdbg_table *, uint8_t *, uint32_t *) { return MDBG_ENODEV; }
+int mdbg_table_to_host_range(mdbg_ctx *, const mdbg_table *, uint64_t, uint64_t, uint8_t *, uint32_t *) { return MDBG_ENODEV; }
 void mdbg_table_free(mdbg_table *t) { delete t; }
 int mdbg_shard_from_table(mdbg_ctx *, const mdbg_table *, uint32_t, mdbg_shard **, const uint64_t **, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_shard_exchange(mdbg_ctx *, mdbg_comm *, mdbg_shard *, const uint64_t *, const uint64_t *, const uint64_t **) { return MDBG_ENODEV; }

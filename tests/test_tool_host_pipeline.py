@@ -52,17 +52,21 @@ def read_set(tmp_path_factory):
     return fasta, b"".join(init), b"".join(corr), lens
 
 
-@pytest.mark.parametrize("batch_bases,threads,jitter", [(1 << 20, 32, 0), (1 << 20, 32, 30), (1 << 16, 8, 0), (1 << 18, 3, 100), (1 << 25, 16, 0), (1 << 14, 32, 0)])
-def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool, read_set, tmp_path, batch_bases, threads, jitter):
+@pytest.mark.parametrize("batch_bases,threads,jitter,ont", [(1 << 20, 32, 0, False), (1 << 20, 32, 30, False), (1 << 16, 8, 0, False), (1 << 18, 3, 100, False),
+                                                            (1 << 25, 16, 0, False), (1 << 14, 32, 0, False), (1 << 18, 16, 20, True), (1 << 15, 32, 0, True)])
+def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool, read_set, tmp_path, batch_bases, threads, jitter, ont):
+    """ont: the ONT preset -- the census pre-pass (one batch ahead, ReadSelection.hpp:497-561) in front of the main pass, --skip-correction."""
     fasta, exp_init, exp_corr, lens = read_set
     tmp = tmp_path / "out" / "tmp"
     os.makedirs(tmp / "filter")
-    formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0).save(str(tmp / "parameters.gz"))
+    formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=not ont, data_type=1 if ont else 0,
+                       correction_density=0.025).save(str(tmp / "parameters.gz"))
     (tmp / "input.txt").write_text(fasta + "\n")
     env = dict(os.environ, MDBG_STUB_JITTER_US=str(jitter))
     for rep in range(3):
         r = subprocess.run([stub_tool, "readSelection", str(tmp), str(tmp / "read_data_init.txt"), str(tmp / "input.txt"), "--threads", str(threads),
-                            "--min-read-quality", "0.000000", "--batch-bases", str(batch_bases)], env=env, capture_output=True, text=True, timeout=120)
+                            "--min-read-quality", "0.000000", "--batch-bases", str(batch_bases)] + (["--skip-correction"] if ont else []),
+                           env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-800:]
         assert (tmp / "read_data_init.txt").read_bytes() == exp_init
         assert (tmp / "read_data_corrected.txt").read_bytes() == exp_corr
