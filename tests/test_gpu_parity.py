@@ -1466,3 +1466,23 @@ def test_census_batch_by_batch(ctx):
     cnt = dict(zip(vals.tolist(), counts.tolist()))
     assert n_keep >= 5 and len(picked) == n_keep, (n_keep, len(picked), len(vals))
     assert picked.tolist() == exp, [(int(v), cnt.get(int(v))) for v in picked][:20] + ["expected"] + [(v, cnt[v]) for v in exp][:20]
+
+
+def test_table_rows_in_pieces(ctx):
+    """mdbg_table_to_host_range: any cut of the rows gives the rows of mdbg_table_to_host (the tool streams large tables through it)."""
+    spec = synth.hifi_spec(1500, seed=8, read_len=7000, coverage=25.0)
+    corr = ctx.purge_palindromes(ctx.scan(ctx.reads_synthetic(spec), K=15, density=0.005, hpc=True), 4, 100)
+    for table in (ctx.kminmer_count_first(corr, 4, 0), ctx.kminmer_index(corr, None, 6, ctx.kminmer_count_refined(corr, None, 5, ctx.kminmer_count_first(corr, 4, 0)))):
+        rec, vec = table.to_host()
+        n = len(rec)
+        cuts = [0, 1, n // 3, n // 3, n - 1, n]
+        got_r, got_v = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            r, v = table.to_host_range(a, b - a)
+            got_r.append(r); got_v.append(v)
+        assert np.array_equal(np.concatenate(got_r), rec)
+        if vec is not None:
+            assert np.array_equal(np.concatenate(got_v), vec)
+        from metamdbg_amd import capi
+        with pytest.raises(capi.MdbgError):
+            table.to_host_range(n, 1)
