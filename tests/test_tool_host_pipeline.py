@@ -72,3 +72,30 @@ def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool
         assert (tmp / "read_data_corrected.txt").read_bytes() == exp_corr
         st = formats.parse_read_stats((tmp / "read_stats.txt").read_bytes())
         assert st["n_reads"] == len(lens) and st["n_bases"] == int(lens.sum()) and st["n_minimizers"] == int((lens // 271).sum())
+
+
+def test_pipeline_under_thread_sanitizer(read_set, tmp_path):
+    """The same pipeline built with -fsanitize=thread (tool and test double): no data race between the feeder's workers, the consumers, the
+    record builders, the statistics thread and the purge pass, in the HiFi and the ONT shape of the run."""
+    fasta, exp_init, exp_corr, lens = read_set
+    d = tmp_path / "tsan"
+    os.makedirs(d)
+    lib, exe = str(d / "libmdbg_hip.so"), str(d / "mdbg_tool")
+    flags = ["-O1", "-g", "-fsanitize=thread", "-std=c++17"]
+    r = subprocess.run(["g++"] + flags + ["-shared", "-fPIC", os.path.join(ROOT, "tests", "host", "stub_mdbg_hip.cpp"), "-o", lib, "-lpthread"], capture_output=True, text=True)
+    if r.returncode == 0:
+        r = subprocess.run(["g++"] + flags + [os.path.join(ROOT, "metamdbg_amd", "host", "mdbg_tool.cpp"), "-o", exe, "-L" + str(d), "-lmdbg_hip", "-lz", "-lpthread",
+                            "-Wl,-rpath," + str(d)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer in this toolchain: " + r.stderr[-200:])
+    for ont in (False, True):
+        tmp = tmp_path / ("ont" if ont else "hifi") / "tmp"
+        os.makedirs(tmp / "filter")
+        formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=not ont, data_type=1 if ont else 0,
+                           correction_density=0.025).save(str(tmp / "parameters.gz"))
+        (tmp / "input.txt").write_text(fasta + "\n")
+        r = subprocess.run([exe, "readSelection", str(tmp), str(tmp / "read_data_init.txt"), str(tmp / "input.txt"), "--threads", "16", "--min-read-quality", "0.000000",
+                            "--batch-bases", str(1 << 17)] + (["--skip-correction"] if ont else []),
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"), capture_output=True, text=True, timeout=300)
+        assert "ThreadSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-1500:]
+        assert (tmp / "read_data_init.txt").read_bytes() == exp_init and (tmp / "read_data_corrected.txt").read_bytes() == exp_corr
