@@ -357,7 +357,10 @@ public:
         }
         groups_.push_back(blocks_.size());
         window_ = (size_t)threads * 2 + 2;
-        for (int i = 0; i < threads; i++) pool_.emplace_back([this] { inflate_loop(); });
+        cum_.assign(blocks_.size() + 1, 0);
+        for (size_t i = 0; i < blocks_.size(); i++) cum_[i + 1] = cum_[i] + blocks_[i].isize;
+        direct_ = !getenv("MDBG_HOST_BGZF_COPY");       // A/B: the round-2 path (groups inflated into buffers of their own, read() copies)
+        for (int i = 0; i < threads; i++) pool_.emplace_back([this] { if (direct_) fill_loop(); else inflate_loop(); });
     }
     ~BgzfReader() {
         {
@@ -367,6 +370,41 @@ public:
         cv_.notify_all();
         for (auto &t : pool_) if (t.joinable()) t.join();
     }
+
+    bool direct() const { return direct_; }
+
+    // Text straight to its place.  A BGZF block says how much text it holds (ISIZE in its trailer), so the place of every block in
+    // the caller's buffer is known before any is inflated: fill_begin() hands the next whole blocks that fit into `room` bytes at
+    // `dst` to the pool and returns at once with the number of bytes they will put there (0: the next block does not fit, or the
+    // file is at its end -- text_left() tells); fill_wait() returns when they are all in place.  One request at a time.
+    // (Round 2 inflated groups of blocks into buffers of their own and one thread copied the text from there into the slabs it
+    // cut: 3.9 GB/s of text on 24 inflating threads, that copy and the page faults of a fresh slab per 32 MB being the limit.)
+    size_t fill_begin(char *dst, size_t room) {
+        const size_t b0 = fillNext_;
+        size_t b1 = b0;
+        while (b1 < blocks_.size() && cum_[b1 + 1] - cum_[b0] <= room) b1++;
+        fillNext_ = b1;
+        if (cum_[b1] == cum_[b0]) return 0;               // (empty blocks -- the end marker is one -- hold nothing)
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            jobDst_ = dst; jobB0_ = b0; jobB1_ = b1; jobNext_ = b0; jobDone_ = 0;
+            pending_ = true;
+        }
+        cv_.notify_all();
+        return cum_[b1] - cum_[b0];
+    }
+    void fill_wait() {
+        if (!pending_) return;
+        std::unique_lock<std::mutex> g(mu_);
+        // (after a failure: not before every thread has let go of the caller's buffer)
+        cvDone_.wait(g, [&] { return (!error_.empty() && jobBusy_ == 0) || jobDone_ == jobB1_ - jobB0_; });
+        pending_ = false;
+        jobNext_ = jobB1_;                                // nothing of a failed request is taken up any more
+        if (!error_.empty()) throw std::runtime_error(error_);
+    }
+    // the same without the exception (a caller unwinding: the buffer must not go before the pool has let go of it)
+    void fill_settle() noexcept { try { fill_wait(); } catch (...) {} }
+    size_t text_left() const { return cum_.back() - cum_[fillNext_]; }
 
     // up to `want` bytes of text; 0 at the end of the file
     size_t read(char *dst, size_t want) {
@@ -444,16 +482,81 @@ private:
         }
         if (use_zlib) inflateEnd(&zs);
     }
+    // a pool thread of the direct mode: takes runs of blocks of the current job; every block is inflated into the thread's own 64 KB
+    // (the decoder may write a few bytes past the end of what it produces, and the neighbouring block's place belongs to another
+    // thread) and copied to its place from there, cache-hot
+    void fill_loop() {
+        const bool use_zlib = zlib_inflate_requested();
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (use_zlib && inflateInit2(&zs, -15) != Z_OK) { fail("zlib initialisation failed"); return; }
+        std::unique_ptr<Inflater> inf(use_zlib ? nullptr : new Inflater());
+        std::vector<uint8_t> scratch(((size_t)1 << 16) + 1024);
+        constexpr size_t RUN = 8;
+        for (;;) {
+            size_t a, b;
+            char *dst;
+            size_t base;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || !error_.empty() || jobNext_ < jobB1_; });
+                if (stop_ || !error_.empty()) break;
+                a = jobNext_;
+                b = std::min(jobB1_, a + RUN);
+                jobNext_ = b;
+                jobBusy_++;
+                dst = jobDst_;
+                base = cum_[jobB0_];
+            }
+            bool ok = true;
+            for (size_t i = a; i < b && ok; i++) {
+                const Block &blk = blocks_[i];
+                if (use_zlib) {
+                    inflateReset(&zs);
+                    zs.next_in = const_cast<Bytef *>(addr_ + blk.payload);
+                    zs.avail_in = blk.csize;
+                    zs.next_out = (Bytef *)scratch.data();
+                    zs.avail_out = blk.isize;
+                    ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+                } else {
+                    inf->reset(addr_ + blk.payload, addr_ + blk.payload + blk.csize);
+                    size_t produced = 0;
+                    ok = inf->run(scratch.data(), scratch.data() + scratch.size(), 0, &produced) == Inflater::STREAM_END && produced == blk.isize;
+                }
+                ok = ok && crc32_fast(0, scratch.data(), blk.isize) == blk.crc;
+                if (ok && blk.isize) memcpy(dst + (cum_[i] - base), scratch.data(), blk.isize);
+            }
+            bool last;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                jobBusy_--;
+                if (ok) jobDone_ += b - a;
+                else if (error_.empty()) error_ = "corrupt BGZF block in " + path_;
+                last = !error_.empty() ? jobBusy_ == 0 : jobDone_ == jobB1_ - jobB0_;
+            }
+            if (last) cvDone_.notify_all();
+            if (!ok) { cv_.notify_all(); break; }
+        }
+        if (use_zlib) inflateEnd(&zs);
+    }
     void fail(const std::string &msg) {
         {
             std::lock_guard<std::mutex> g(mu_);
             if (error_.empty()) error_ = msg;
         }
         cv_.notify_all();
+        cvDone_.notify_all();
     }
 
     const unsigned char *addr_;
     std::vector<Block> blocks_;
+    std::vector<size_t> cum_;              // text bytes in front of every block
+    bool direct_ = true;
+    size_t fillNext_ = 0;                  // first block the next fill() takes
+    char *jobDst_ = nullptr;               // the current job: blocks [jobB0_, jobB1_) to jobDst_ + (cum_[b] - cum_[jobB0_]); mu_ held
+    size_t jobB0_ = 0, jobB1_ = 0, jobNext_ = 0, jobDone_ = 0, jobBusy_ = 0;
+    bool pending_ = false;                 // a request is out (the caller's thread only)
+    std::condition_variable cvDone_;       // the caller waits here; the pool waits on cv_
     std::vector<size_t> groups_;           // first block of every group, then the block count
     std::string path_;
     std::map<size_t, Text> ready_;
@@ -712,7 +815,13 @@ private:
                 madvise(addr, map.len, MADV_SEQUENTIAL);
                 std::vector<BgzfReader::Block> blocks;
                 if (!getenv("MDBG_HOST_NO_BGZF") && BgzfReader::index((const unsigned char *)addr, map.len, blocks))
-                    bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), gzThreads_, path));
+                {
+                    // blocks inflate independently and straight to their place: as many threads as the machine can spare (a quarter
+                    // of its hardware threads, 64 at most; never fewer than the other gzip paths get)
+                    int bthreads = std::max(gzThreads_, std::min(64, (int)std::thread::hardware_concurrency() / 4));
+                    if (const char *e = getenv("MDBG_HOST_BGZF_THREADS")) bthreads = std::max(1, atoi(e));
+                    bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), bthreads, path));
+                }
                 else if (!zlib_inflate_requested()) {
                     // an ordinary gzip stream: several decoding threads when the file is worth it (gzip_parallel.hpp), else one
                     // (decoding without the window costs about twice the work: below six threads one thread is as fast)
@@ -735,19 +844,42 @@ private:
             gzbuffer(fp, 1 << 20);
         }
         struct Closer { gzFile f; ~Closer() { if (f) gzclose(f); } } closer{fp};
+        if (bgzf && bgzf->direct()) {
+            bool multiline = false;
+            seq = stitch_bgzf(*bgzf, path, file, seq, &multiline);
+            if (!multiline) return seq;
+            bgzf.reset();
+            return read_gz_sequential(path, file, seq);
+        }
         std::vector<char> carry;          // text behind the last cut: an incomplete record and the look-ahead
         bool first = true, fastq = false, eof = false;
         const size_t maxSlabs = (size_t)nThreads_ + 2;
         // a record start is recognised from the two lines that follow it, so text is inflated some way past the
         // chunk before the cut is chosen (enough for reads of a few Mbp; longer ones need a larger --batch-bases)
         const size_t cap = chunk_ + std::min<size_t>(chunk_, (size_t)4 << 20);
+        // slabs go round: a fresh 36 MB array per slab is 9 k page faults on the one thread everything waits for
+        struct SlabPool {
+            std::mutex mu;
+            std::vector<char *> idle;
+            ~SlabPool() { for (char *p : idle) delete[] p; }
+        };
+        auto pool = std::make_shared<SlabPool>();
+        auto take_slab = [&]() {
+            char *p = nullptr;
+            {
+                std::lock_guard<std::mutex> g(pool->mu);
+                if (!pool->idle.empty()) { p = pool->idle.back(); pool->idle.pop_back(); }
+            }
+            if (!p) p = new char[cap + 1];
+            return std::shared_ptr<char>(p, [pool](char *q) { std::lock_guard<std::mutex> g(pool->mu); pool->idle.push_back(q); });
+        };
         while ((!eof || !carry.empty()) && !fileDone_[file].load()) {
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cvFree_.wait(g, [&] { return stop_ || slabsOut_ < maxSlabs; });
                 if (stop_) return seq;
             }
-            std::shared_ptr<char> slab(new char[cap + 1], std::default_delete<char[]>());
+            std::shared_ptr<char> slab = take_slab();
             char *buf = slab.get();
             size_t len = carry.size();
             if (len) memcpy(buf, carry.data(), len);
@@ -798,6 +930,111 @@ private:
             }
             push_work({seq++, file, begin, q, fastq, slab});
         }
+        return seq;
+    }
+
+    // BGZF: the pool inflates every block straight to its place in a slab (BgzfReader::fill_begin), and the slab AFTER the one being
+    // cut is already filling while the cut is chosen: its text starts `head` bytes into the slab, and what the cut leaves over (an
+    // incomplete record and the look-ahead) is copied in front of it afterwards -- the only text this thread touches.  How much the
+    // next slab is asked to hold is steered so that the left-over stays about `look` bytes.
+    uint64_t stitch_bgzf(BgzfReader &bgzf, const std::string &path, int file, uint64_t seq, bool *multiline) {
+        const size_t look = std::max<size_t>(std::min<size_t>(chunk_, (size_t)4 << 20), (size_t)128 << 10);   // (a block is up to 64 KB)
+        const size_t head = 2 * look;
+        const size_t cap = head + chunk_ + 2 * look;
+        const size_t maxSlabs = (size_t)nThreads_ + 3;
+        // slabs go round: a fresh 40 MB array per slab is 10 k page faults
+        struct SlabPool {
+            std::mutex mu;
+            std::vector<char *> idle;
+            ~SlabPool() { for (char *p : idle) delete[] p; }
+        };
+        auto pool = std::make_shared<SlabPool>();
+        auto take_slab = [&]() -> std::shared_ptr<char> {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cvFree_.wait(g, [&] { return stop_ || slabsOut_ < maxSlabs; });
+                if (stop_) return nullptr;
+                slabsOut_++;
+            }
+            char *p = nullptr;
+            {
+                std::lock_guard<std::mutex> g(pool->mu);
+                if (!pool->idle.empty()) { p = pool->idle.back(); pool->idle.pop_back(); }
+            }
+            if (!p) p = new char[cap + 1];
+            return std::shared_ptr<char>(p, [pool](char *q) { std::lock_guard<std::mutex> g(pool->mu); pool->idle.push_back(q); });
+        };
+        auto give_back = [&]() {                          // a slab taken and not handed to the parsers
+            std::lock_guard<std::mutex> g(mu_);
+            slabsOut_--;
+        };
+        struct Settle { BgzfReader &b; ~Settle() { b.fill_settle(); } } settle{bgzf};   // declared after the slabs' pool, runs before it goes
+
+        std::shared_ptr<char> cur = take_slab();
+        if (!cur) return seq;
+        size_t got = bgzf.fill_begin(cur.get() + head, chunk_ + look);
+        bgzf.fill_wait();
+        const char *begin = cur.get() + head, *end = begin + got;
+        while (begin < end && (*begin == '\n' || *begin == '\r')) begin++;
+        while (begin == end && bgzf.text_left()) {        // a file that starts with empty lines only, a block's worth of them
+            got = bgzf.fill_begin(cur.get() + head, chunk_ + look);
+            bgzf.fill_wait();
+            begin = cur.get() + head; end = begin + got;
+            while (begin < end && (*begin == '\n' || *begin == '\r')) begin++;
+        }
+        if (begin == end) { give_back(); return seq; }
+        const bool fastq = *begin == '@';
+        if (!fastq && *begin != '>') throw std::runtime_error("not FASTA/FASTQ: " + path);
+        if (fastq && !looks_four_line(begin, end)) { give_back(); *multiline = true; return seq; }
+
+        bool held = true;                                 // `cur` is counted among the slabs out and not with the parsers
+        for (;;) {
+            if (fileDone_[file].load()) break;            // (the per-file read cap was reached)
+            const size_t total = (size_t)(end - begin);
+            const bool lastSlab = bgzf.text_left() == 0;
+            std::shared_ptr<char> nxt;
+            size_t nxtGot = 0;
+            if (!lastSlab) {
+                nxt = take_slab();
+                if (!nxt) return seq;
+                const size_t over = total > chunk_ ? total - chunk_ : 0;        // about what the cut below will leave over
+                size_t want = chunk_ + look > over ? chunk_ + look - over : 0;
+                want = std::max<size_t>(want, (size_t)128 << 10);
+                nxtGot = bgzf.fill_begin(nxt.get() + head, std::min(want, cap - head));
+            }
+            const char *q = end;
+            if (!lastSlab || total > chunk_) {
+                if (total > chunk_) q = last_record_before(begin, begin + chunk_, end, fastq);
+                else q = begin;                           // (cannot be: every request reaches past the chunk) keep everything for the next slab
+                if (q == begin && total > chunk_) throw std::runtime_error("a single read is larger than the batch size; raise --batch-bases");
+            }
+            const size_t left = (size_t)(end - q);
+            if (q > begin) push_work({seq++, file, begin, q, fastq, cur});      // (slabsOut_ counted when the slab was taken)
+            else give_back();
+            held = false;
+            if (lastSlab && !left) break;
+            bgzf.fill_wait();
+            if (lastSlab) {                               // the end of the file behind a cut: the rest moves to the front of its own slab
+                nxt = take_slab();
+                if (!nxt) return seq;
+            }
+            if (left <= head) {
+                memcpy(nxt.get() + head - left, q, left);
+                begin = nxt.get() + head - left;
+                end = nxt.get() + head + nxtGot;
+            } else {
+                // a left-over longer than the room in front (reads of several Mbp): a slab of its own size, outside the pool
+                std::shared_ptr<char> big(new char[left + nxtGot + 1], std::default_delete<char[]>());
+                memcpy(big.get(), q, left);
+                memcpy(big.get() + left, nxt.get() + head, nxtGot);
+                nxt = big;                                // (the pooled slab goes back; the count of slabs out stays)
+                begin = big.get();
+                end = begin + left + nxtGot;
+            }
+            cur = nxt;
+            held = true;
+        }
+        if (held) give_back();
         return seq;
     }
 

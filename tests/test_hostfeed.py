@@ -204,9 +204,19 @@ def test_bgzf_corruption_is_reported(exe, files, tmp_path):
     raw[len(raw) // 2] ^= 0x55
     bad = str(tmp_path / "bad.fastq.gz")
     open(bad, "wb").write(bytes(raw))
-    r = subprocess.run([exe, str(1 << 20), "3", "0", bad], capture_output=True, text=True, timeout=120,
-                       env=dict(os.environ, MDBG_TEST_DRAIN_ONLY="1"))
-    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    # (the pool inflates the blocks straight into the slab; MDBG_HOST_BGZF_COPY=1: into buffers of its own, copied from there)
+    for mode in ({}, {"MDBG_HOST_BGZF_COPY": "1"}, {"MDBG_HOST_ZLIB_INFLATE": "1"}):
+        r = subprocess.run([exe, str(1 << 20), "3", "0", bad], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, MDBG_TEST_DRAIN_ONLY="1", **mode))
+        assert r.returncode == 3, (mode, r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("chunk", [10000, 200000, 1 << 22])
+def test_bgzf_copy_mode_matches(exe, files, chunk):
+    for key in ("bgzf_fastq", "bgzf_fastq_64k", "bgzf_then_gzip"):
+        r = subprocess.run([exe, str(chunk), "4", "0", files[key]], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, MDBG_HOST_BGZF_COPY="1"))
+        assert r.returncode == 0, (key, r.stderr)
 
 
 def test_gzip_damage_and_zlib_switch(exe, files, tmp_path):

@@ -70,7 +70,7 @@ def _gz_member(args):
     return co.compress(raw) + co.flush()
 
 
-def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=(), graph_args=("--min-abundance", "0", "--firstpass")):
+def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=(), graph_args=("--min-abundance", "0", "--firstpass"), extra_env=None):
     from metamdbg_amd import formats
     tmp = os.path.join(tmp_parent, "tmp")
     shutil.rmtree(tmp_parent, ignore_errors=True)
@@ -79,6 +79,7 @@ def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=(), graph_args=
     P.save(os.path.join(tmp, "parameters.gz"))
     open(os.path.join(tmp, "input.txt"), "w").write("\n".join(inputs) + "\n")
     env = dict(os.environ, MDBG_TRACE="1") if trace else dict(os.environ)
+    env.update(extra_env or {})
     t0 = time.perf_counter()
     r1 = subprocess.run([TOOL, "readSelection", tmp, tmp + "/read_data_init.txt", tmp + "/input.txt", "--threads", str(threads),
                          "--min-read-quality", "0.000000", *rs_args], capture_output=True, text=True, env=env, timeout=240)
@@ -102,6 +103,8 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--out", default="")
     ap.add_argument("--ont-reads", type=int, default=0, help="ONT preset: n x 20 kb reads with qualities as FASTQ, no HPC, census + --skip-correction")
+    ap.add_argument("--no-gzip", action="store_true", help="of the compressed legs, BGZF only")
+    ap.add_argument("--bgzf-modes", default="", help="comma list of extra BGZF runs: copy (the round-2 path: MDBG_HOST_BGZF_COPY=1), t<N> (MDBG_HOST_BGZF_THREADS=N)")
     ap.add_argument("--batch-bases", default="", help="comma list: readSelection --batch-bases values to compare on the FASTA set (tool flag, not a reference flag)")
     a = ap.parse_args()
     from metamdbg_amd import capi, formats, synth
@@ -125,10 +128,10 @@ def main():
             res["ont_write_s"] = write_reads(ont_fastq, ctx, ospec, a.ont_reads, True)
         ctx.close()
 
-        def best_of(inputs, n_reads, label, reps=2):
+        def best_of(inputs, n_reads, label, reps=2, extra_env=None):
             out = {}
             for t in threads:
-                runs = [run_tool(os.path.join(work, "run"), inputs, t, P) for _ in range(reps)]
+                runs = [run_tool(os.path.join(work, "run"), inputs, t, P, extra_env=extra_env) for _ in range(reps)]
                 b = min(runs, key=lambda r: r["total_s"])
                 gbp = n_reads * 10_000 / 1e9
                 b.update(gbp=gbp, gbps=gbp / b["total_s"], read_selection_gbps=gbp / b["read_selection_s"], all_total_s=[round(r["total_s"], 3) for r in runs])
@@ -173,18 +176,20 @@ def main():
                     pos += sum(len(str(i)) for i in range(k, k + step)) + step * 10_003
                     k += step
                     bounds.append(pos)
-            t0 = time.perf_counter()
-            with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
-                parts = pool.map(_gz_member, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
-            gz = os.path.join(work, "reads.fasta.gz")
-            with open(gz, "wb") as f:
-                for p in parts:
-                    f.write(p)
-            res["gzip_compress_s"] = time.perf_counter() - t0
-            res["gzip_bytes"] = os.path.getsize(gz)
-            res["gzip_members"] = len(parts)
-            del parts
-            res["gzip"] = best_of([gz], n, "gzip", reps=1)
+            if not a.no_gzip:
+                t0 = time.perf_counter()
+                with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
+                    parts = pool.map(_gz_member, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
+                gz = os.path.join(work, "reads.fasta.gz")
+                with open(gz, "wb") as f:
+                    for p in parts:
+                        f.write(p)
+                res["gzip_compress_s"] = time.perf_counter() - t0
+                res["gzip_bytes"] = os.path.getsize(gz)
+                res["gzip_members"] = len(parts)
+                del parts
+                res["gzip"] = best_of([gz], n, "gzip", reps=1)
+                os.unlink(gz)
             # the same reads as BGZF (what samtools fastq / bam2fastq / bgzip write): every <= 64 KB block is inflated on its own
             t0 = time.perf_counter()
             with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
@@ -197,7 +202,10 @@ def main():
             res["bgzf_compress_s"] = time.perf_counter() - t0
             res["bgzf_bytes"] = os.path.getsize(bg)
             del parts
-            res["bgzf"] = best_of([bg], n, "bgzf", reps=1)
+            res["bgzf"] = best_of([bg], n, "bgzf", reps=2)
+            for mode in [m for m in a.bgzf_modes.split(",") if m]:
+                env = {"MDBG_HOST_BGZF_COPY": "1"} if mode == "copy" else {"MDBG_HOST_BGZF_THREADS": mode[1:]}
+                res[f"bgzf_{mode}"] = best_of([bg], n, "bgzf " + mode, reps=2, extra_env=env)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     line = json.dumps(res)
