@@ -816,9 +816,9 @@ private:
                 std::vector<BgzfReader::Block> blocks;
                 if (!getenv("MDBG_HOST_NO_BGZF") && BgzfReader::index((const unsigned char *)addr, map.len, blocks))
                 {
-                    // blocks inflate independently and straight to their place: as many threads as the machine can spare (a quarter
-                    // of its hardware threads, 64 at most; never fewer than the other gzip paths get)
-                    int bthreads = std::max(gzThreads_, std::min(64, (int)std::thread::hardware_concurrency() / 4));
+                    // (measured on the 10 Gbp set, 256 hardware threads: 24, 64 and 128 inflating threads give 1.48, 1.65 and 1.67 s of
+                    // readSelection -- beyond 24 the threads that drive the GPU start to wait for a core)
+                    int bthreads = gzThreads_;
                     if (const char *e = getenv("MDBG_HOST_BGZF_THREADS")) bthreads = std::max(1, atoi(e));
                     bgzf.reset(new BgzfReader((const unsigned char *)addr, std::move(blocks), bthreads, path));
                 }
