@@ -16,6 +16,7 @@
 // position is known, translated only once its window is.
 #pragma once
 
+#include <emmintrin.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -45,6 +46,8 @@ public:
 
     ParallelGzipReader(const uint8_t *addr, size_t len, int threads, std::string path, size_t chunk_bytes)
         : addr_(addr), len_(len), path_(std::move(path)), chunk_(chunk_bytes < 65536 ? 65536 : chunk_bytes), nthreads_(threads < 1 ? 1 : threads) {
+        pooled_ = !getenv("MDBG_HOST_GZIP_NO_POOL");                           // A/B switches for the two round-3 changes
+        table_translate_ = !getenv("MDBG_HOST_GZIP_BRANCHY");
         start_member(0);
         // A stream without dynamic-Huffman block headers to start from (stored blocks: gzip -0, incompressible data) cannot be
         // cut: ask before the first read() and use one thread then.  Looked for in the second and third chunk.
@@ -91,7 +94,7 @@ public:
                 crc_ = (uint32_t)crc32_combine(crc_, c.crc, (z_off_t)c.ntext);
                 total_ += c.ntext;
                 const uint64_t end_pos = c.member_end;
-                c.text.reset();
+                give_text(c.text, c.text_cap);
                 rpos_ = 0;
                 gen->consumed++;
                 if (end_pos != NONE) {
@@ -116,11 +119,11 @@ private:
         bool find_taken = false, start_known = false, decode_taken = false, decoded = false, window_known = false, translate_taken = false,
              translated = false;
         std::unique_ptr<uint16_t[]> sym;    // WINDOW place-holders, then the symbols
-        size_t nsym = 0;
+        size_t nsym = 0, sym_cap = 0;
         std::unique_ptr<uint8_t[]> window;  // the WINDOW bytes in front of this chunk, right-aligned when fewer exist
         size_t window_valid = 0;
         std::unique_ptr<uint8_t[]> text;
-        size_t ntext = 0;
+        size_t ntext = 0, text_cap = 0;
         uint32_t crc = 0;
         uint64_t member_end = NONE;         // file offset of the member's trailer if the stream ended in this chunk
         std::string error;
@@ -238,6 +241,8 @@ private:
     void work() {
         InflaterT<uint16_t> inf, probe;
         std::vector<uint16_t> scratch;
+        std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]());                  // symbol -> byte (translate_chunk); entries 256 .. 0x7fff are never produced
+        for (unsigned v = 0; v < 256; v++) lut[v] = (uint8_t)v;
         for (;;) {
             std::shared_ptr<Gen> gen;
             size_t k = 0;
@@ -266,7 +271,7 @@ private:
                 } else if (job == DECODE) {
                     decode_chunk(*gen, k, stop, inf);
                 } else {
-                    translate_chunk(*gen, k);
+                    translate_chunk(*gen, k, lut.get());
                 }
             } catch (const std::exception &e) {
                 // the reader meets the error when it gets to this chunk (chunks behind the end of the member never are)
@@ -286,7 +291,7 @@ private:
         inf.reset_at_bit(data, c.start_bit, end);
         if (stop != NONE) inf.set_stop_bit(stop);
         size_t cap = WINDOW + chunk_ * 5 + 65536;                              // symbols: [WINDOW place-holders][output]; grows as needed
-        std::unique_ptr<uint16_t[]> sym(new uint16_t[cap]);
+        std::unique_ptr<uint16_t[]> sym = take_sym(&cap);
         if (k > 0) for (size_t i = 0; i < WINDOW; i++) sym[i] = (uint16_t)(0x8000u + i);
         size_t n = 0;
         uint64_t member_end = NONE;
@@ -315,6 +320,7 @@ private:
         }
         std::lock_guard<std::mutex> g(mu_);
         c.sym = std::move(sym);
+        c.sym_cap = cap;
         if (member_end != NONE) { c.member_end = member_end; if (k < gen.end_chunk) gen.end_chunk = k; }
         finish_decode(gen, k, n);
     }
@@ -349,14 +355,34 @@ private:
         }
     }
 
-    void translate_chunk(Gen &gen, size_t k) {
+    void translate_chunk(Gen &gen, size_t k, uint8_t *lut) {
         Chunk &c = gen.chunks[k];
         if (!c.error.empty()) { std::lock_guard<std::mutex> g(mu_); c.translated = true; return; }
-        std::unique_ptr<uint8_t[]> text(new uint8_t[c.nsym ? c.nsym : 1]);
+        size_t text_cap = c.nsym ? c.nsym : 1;
+        std::unique_ptr<uint8_t[]> text = take_text(&text_cap);
         const uint16_t *s = c.sym ? c.sym.get() + WINDOW : nullptr;
         const uint8_t *win = c.window.get();
         const size_t min_p = WINDOW - c.window_valid;
-        for (size_t i = 0; i < c.nsym; i++) {
+        size_t i = 0;
+        if (win && min_p == 0 && table_translate_) {
+            // The usual case, a whole window in front of the chunk: every symbol the decoder can have produced is valid, and the
+            // translation is one table look-up per symbol -- bytes map to themselves, 0x8000 + p to the window's byte p.  (In reads
+            // the references do not die out behind the first 32 KB: a match copies them along with the bytes, and zlib finds a
+            // match every few bases of a read, so "is it a byte?" is a coin flip the branch predictor loses: 4 ns per symbol.)
+            memcpy(lut + 0x8000, win, WINDOW);
+            uint8_t *t = text.get();
+            for (; i + 16 <= c.nsym; i += 16) {
+                const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
+                const __m128i high = _mm_and_si128(_mm_or_si128(a, b), _mm_set1_epi16((short)0xFF00));
+                if (_mm_movemask_epi8(_mm_cmpeq_epi16(high, _mm_setzero_si128())) == 0xFFFF) {                 // sixteen bytes
+                    _mm_storeu_si128((__m128i *)(t + i), _mm_packus_epi16(a, b));
+                    continue;
+                }
+                for (unsigned j = 0; j < 16; j++) t[i + j] = lut[s[i + j]];
+            }
+            for (; i < c.nsym; i++) t[i] = lut[s[i]];
+        }
+        for (; i < c.nsym; i++) {
             const uint16_t v = s[i];
             if (v < 256) { text[i] = (uint8_t)v; continue; }
             const size_t p = v - 0x8000u;
@@ -366,10 +392,55 @@ private:
         const uint32_t crc = crc32_fast(0, text.get(), c.nsym);
         std::lock_guard<std::mutex> g(mu_);
         c.text = std::move(text);
+        c.text_cap = text_cap;
         c.ntext = c.nsym;
         c.crc = crc;
-        c.sym.reset();
+        give_sym(c.sym, c.sym_cap);
         c.translated = true;
+    }
+
+    // ---- buffers go round ------------------------------------------------------------------------------------------------
+    // A chunk's symbols are 40 MB of address space and its text 12 MB: fresh from the allocator every time, they are mapped, faulted
+    // in page by page and unmapped again by two dozen threads of one process at once -- which the kernel serialises (the parallel
+    // decoder was no faster than one thread for it).  mu_ held in give_*; pool_mu_ guards the lists.
+    std::unique_ptr<uint16_t[]> take_sym(size_t *cap) {
+        {
+            std::lock_guard<std::mutex> g(pool_mu_);
+            for (size_t i = 0; i < idle_sym_.size(); i++)
+                if (idle_sym_[i].second >= *cap) {
+                    auto p = std::move(idle_sym_[i].first);
+                    *cap = idle_sym_[i].second;
+                    idle_sym_.erase(idle_sym_.begin() + (long)i);
+                    return p;
+                }
+        }
+        return std::unique_ptr<uint16_t[]>(new uint16_t[*cap]);
+    }
+    void give_sym(std::unique_ptr<uint16_t[]> &p, size_t cap) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(pool_mu_);
+        if (pooled_ && idle_sym_.size() < (size_t)nthreads_ + 4) idle_sym_.emplace_back(std::move(p), cap);
+        p.reset();
+    }
+    std::unique_ptr<uint8_t[]> take_text(size_t *cap) {
+        {
+            std::lock_guard<std::mutex> g(pool_mu_);
+            for (size_t i = 0; i < idle_text_.size(); i++)
+                if (idle_text_[i].second >= *cap) {
+                    auto p = std::move(idle_text_[i].first);
+                    *cap = idle_text_[i].second;
+                    idle_text_.erase(idle_text_.begin() + (long)i);
+                    return p;
+                }
+        }
+        if (pooled_) *cap = std::max(*cap, chunk_ * 4);                        // (a chunk of reads inflates about three-fold: one size fits most)
+        return std::unique_ptr<uint8_t[]>(new uint8_t[*cap]);
+    }
+    void give_text(std::unique_ptr<uint8_t[]> &p, size_t cap) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(pool_mu_);
+        if (pooled_ && idle_text_.size() < (size_t)nthreads_ + 4) idle_text_.emplace_back(std::move(p), cap);
+        p.reset();
     }
 
     static constexpr size_t PROBE_ROOM = 1u << 18;
@@ -385,9 +456,12 @@ private:
     uint64_t total_ = 0;
     std::mutex mu_;
     std::condition_variable cv_;
+    std::mutex pool_mu_;
+    std::vector<std::pair<std::unique_ptr<uint16_t[]>, size_t>> idle_sym_;
+    std::vector<std::pair<std::unique_ptr<uint8_t[]>, size_t>> idle_text_;
     std::vector<std::thread> pool_;
     std::atomic<long long> t_find_{0}, t_decode_{0}, t_translate_{0};
-    bool stop_ = false, usable_ = false;
+    bool stop_ = false, usable_ = false, pooled_ = true, table_translate_ = true;
     std::string fatal_;
 };
 

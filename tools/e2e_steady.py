@@ -70,6 +70,51 @@ def _gz_member(args):
     return co.compress(raw) + co.flush()
 
 
+def _deflate_piece(args):
+    """A piece of ONE deflate stream, the way pigz makes them: raw deflate, ended on a byte border by a sync flush (the last piece:
+    finished), so that the pieces of all workers concatenated are a single stream; with the piece's CRC-32 and length."""
+    path, a, b, last = args
+    with open(path, "rb") as f:
+        f.seek(a)
+        raw = f.read(b - a)
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    return co.compress(raw) + co.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(raw), len(raw)
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (not exposed by Python): the CRC-32 of A + B from those of A and B and len(B), by GF(2) matrix powers."""
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+    if len2 <= 0:
+        return crc1
+    odd = [0xedb88320] + [1 << n for n in range(31)]      # the operator for one zero bit
+    even = square(odd)                                       # two
+    odd = square(even)                                       # four
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
 def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=(), graph_args=("--min-abundance", "0", "--firstpass"), extra_env=None):
     from metamdbg_amd import formats
     tmp = os.path.join(tmp_parent, "tmp")
@@ -103,6 +148,9 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--out", default="")
     ap.add_argument("--ont-reads", type=int, default=0, help="ONT preset: n x 20 kb reads with qualities as FASTQ, no HPC, census + --skip-correction")
+    ap.add_argument("--gzip-members", action="store_true", help="the gzip file as 32 concatenated members (round 2's measurement) instead of one")
+    ap.add_argument("--gzip-modes", default="", help="comma list of extra gzip runs: t<N> (MDBG_HOST_GZIP_THREADS=N), nopool, branchy, round2 (both)")
+    ap.add_argument("--no-bgzf", action="store_true")
     ap.add_argument("--no-gzip", action="store_true", help="of the compressed legs, BGZF only")
     ap.add_argument("--bgzf-modes", default="", help="comma list of extra BGZF runs: copy (the round-2 path: MDBG_HOST_BGZF_COPY=1), t<N> (MDBG_HOST_BGZF_THREADS=N)")
     ap.add_argument("--batch-bases", default="", help="comma list: readSelection --batch-bases values to compare on the FASTA set (tool flag, not a reference flag)")
@@ -178,34 +226,54 @@ def main():
                     bounds.append(pos)
             if not a.no_gzip:
                 t0 = time.perf_counter()
-                with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
-                    parts = pool.map(_gz_member, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
                 gz = os.path.join(work, "reads.fasta.gz")
-                with open(gz, "wb") as f:
-                    for p in parts:
-                        f.write(p)
+                if a.gzip_members:
+                    with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
+                        parts = pool.map(_gz_member, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
+                    with open(gz, "wb") as f:
+                        for p in parts:
+                            f.write(p)
+                    res["gzip_members"] = len(parts)
+                else:
+                    # ONE gzip member (what gzip / pigz write and sequencers deliver), compressed in pieces by all cores
+                    import struct
+                    with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
+                        parts = pool.map(_deflate_piece, [(fasta, bounds[i], bounds[i + 1], i == len(bounds) - 2) for i in range(len(bounds) - 1)])
+                    crc, total = 0, 0
+                    with open(gz, "wb") as f:
+                        f.write(bytes.fromhex("1f8b08000000000004ff"))
+                        for p, c, ln in parts:
+                            f.write(p)
+                            crc = _crc32_combine(crc, c, ln)
+                            total += ln
+                        f.write(struct.pack("<II", crc & 0xffffffff, total & 0xffffffff))
+                    res["gzip_members"] = 1
                 res["gzip_compress_s"] = time.perf_counter() - t0
                 res["gzip_bytes"] = os.path.getsize(gz)
-                res["gzip_members"] = len(parts)
                 del parts
-                res["gzip"] = best_of([gz], n, "gzip", reps=1)
+                res["gzip"] = best_of([gz], n, "gzip", reps=2)
+                for mode in [m for m in a.gzip_modes.split(",") if m]:
+                    env = {"nopool": {"MDBG_HOST_GZIP_NO_POOL": "1"}, "branchy": {"MDBG_HOST_GZIP_BRANCHY": "1"},
+                           "round2": {"MDBG_HOST_GZIP_NO_POOL": "1", "MDBG_HOST_GZIP_BRANCHY": "1"}}.get(mode) or {"MDBG_HOST_GZIP_THREADS": mode[1:]}
+                    res[f"gzip_{mode}"] = best_of([gz], n, "gzip " + mode, reps=1, extra_env=env)
                 os.unlink(gz)
-            # the same reads as BGZF (what samtools fastq / bam2fastq / bgzip write): every <= 64 KB block is inflated on its own
-            t0 = time.perf_counter()
-            with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
-                parts = pool.map(_bgzf_part, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
-            bg = os.path.join(work, "reads.bgzf.fasta.gz")
-            with open(bg, "wb") as f:
-                for p in parts:
-                    f.write(p)
-                f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))     # the BGZF end-of-file block
-            res["bgzf_compress_s"] = time.perf_counter() - t0
-            res["bgzf_bytes"] = os.path.getsize(bg)
-            del parts
-            res["bgzf"] = best_of([bg], n, "bgzf", reps=2)
-            for mode in [m for m in a.bgzf_modes.split(",") if m]:
-                env = {"MDBG_HOST_BGZF_COPY": "1"} if mode == "copy" else {"MDBG_HOST_BGZF_THREADS": mode[1:]}
-                res[f"bgzf_{mode}"] = best_of([bg], n, "bgzf " + mode, reps=2, extra_env=env)
+            if not a.no_bgzf:
+                # the same reads as BGZF (what samtools fastq / bam2fastq / bgzip write): every <= 64 KB block is inflated on its own
+                t0 = time.perf_counter()
+                with mp.Pool(min(32, os.cpu_count() or 1)) as pool:
+                    parts = pool.map(_bgzf_part, [(fasta, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)])
+                bg = os.path.join(work, "reads.bgzf.fasta.gz")
+                with open(bg, "wb") as f:
+                    for p in parts:
+                        f.write(p)
+                    f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))     # the BGZF end-of-file block
+                res["bgzf_compress_s"] = time.perf_counter() - t0
+                res["bgzf_bytes"] = os.path.getsize(bg)
+                del parts
+                res["bgzf"] = best_of([bg], n, "bgzf", reps=2)
+                for mode in [m for m in a.bgzf_modes.split(",") if m]:
+                    env = {"MDBG_HOST_BGZF_COPY": "1"} if mode == "copy" else {"MDBG_HOST_BGZF_THREADS": mode[1:]}
+                    res[f"bgzf_{mode}"] = best_of([bg], n, "bgzf " + mode, reps=2, extra_env=env)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     line = json.dumps(res)
