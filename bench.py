@@ -87,6 +87,27 @@ def _make_tmp(work: str, name: str, params, inputs: list) -> str:
     return tmp
 
 
+def _cpu_quota() -> float | None:
+    """CPUs the container may use at once (cgroup cpu.max / cfs quota), None when unlimited: the GPU boxes show 256 hardware threads
+    and grant 16 CPU-seconds per second, so this -- not the thread count -- is what a CPU baseline ran on."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else int(quota) / int(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def _cores_used(threads: int) -> int:
+    q = _cpu_quota()
+    return threads if q is None else max(1, min(threads, int(q + 0.5)))
+
+
 def _run_two_commands(exe: str, tmp: str, threads: int, extra_rs=(), timeout: int = 1800, stop_after_tables: bool = False) -> dict:
     """`readSelection` then `graph --firstpass` with the reference's argv (AssemblyPipeline.hpp:733-737, :770-783), timed.
     `tables_s` = seconds into `graph` at which kminmerData_abundance_init.txt appears: the reference copies it right after
@@ -207,15 +228,16 @@ def sample_legs(ctx, n_sample: int, read_len: int, with_tool: bool, keep_dir: li
         try:
             tr = _run_two_commands(REFDRV, t_ref, cores, stop_after_tables=big)
         except Exception as exc:  # the baseline is reported, never required
-            out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": cores, "kind": "reference", "sample": f"failed: {exc}"}
+            out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": _cores_used(cores), "threads": cores, "kind": "reference", "sample": f"failed: {exc}"}
             return out
         path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
         whole = None if tr["graph_s"] is None else tr["read_selection_s"] + tr["graph_s"]
         out["cpu_baseline"] = {
-            "value": nbases / 1e9 / path, "unit": "Gbp/s", "cores": cores, "kind": "reference",
+            "value": nbases / 1e9 / path, "unit": "Gbp/s", "cores": _cores_used(cores), "threads": cores, "cpu_quota": _cpu_quota(), "kind": "reference",
             "sample": f"{n_sample} synthetic HiFi reads x {read_len} bp at 50x ({nbases / 1e9:.2f} Gbp"
                       f"{': BASELINE.json configs[1], whole' if n_sample == 1_000_000 and read_len == 10_000 else ''}) as FASTA on local disk, "
-                      f"--threads {cores} of {os.cpu_count()} hardware threads; value = path only: readSelection {tr['read_selection_s']:.2f} s + "
+                      f"--threads {cores} of {os.cpu_count()} hardware threads"
+                      f"{'' if _cpu_quota() is None else f' under a container quota of {_cpu_quota():g} CPUs (cores = what it could use)'}; value = path only: readSelection {tr['read_selection_s']:.2f} s + "
                       f"graph --firstpass until its tables are written and closed "
                       f"{(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.2f} s"
                       + (" (the command was ended there: what follows is graph construction)" if tr["graph_s"] is None else
@@ -680,7 +702,7 @@ def ont_leg(ctx, n_reads: int, sample: int, piece_reads: int = 3_400_000) -> dic
             r["parity"] = {"reads": sample, "init_bytes_equal": bool(init_equal), "table_multiset_equal": table_equal,
                            "kminmer_records": int(len(rec)),
                            "against": "oracle/_ref/refdrv on the same reads as FASTQ, --skip-correction, this run"}
-            r["cpu_reference"] = {"gbps_path_only": nb / 1e9 / path, "cores": cores, "read_selection_s": tr["read_selection_s"],
+            r["cpu_reference"] = {"gbps_path_only": nb / 1e9 / path, "cores": _cores_used(cores), "threads": cores, "read_selection_s": tr["read_selection_s"],
                                   "tables_s": tr["tables_s"], "sample_gbp": nb / 1e9}
             if not (init_equal and table_equal):
                 raise SystemExit(f"bench.py: PARITY FAILURE (ONT preset) against the reference: {r['parity']}")
