@@ -329,6 +329,8 @@ int run_read_selection(int argc, char **argv) {
             }
             repFile.write((const char *)rep.data(), (std::streamsize)(rep.size() * 4));
         }
+        repFile.close();
+        if (!repFile) die("writing " + tmpDir + "/repetitiveMinimizers.bin failed");
     }
 
     // main pass: read_data_init.txt in read order (ReadSelection.hpp:386-491)
@@ -634,6 +636,8 @@ int run_read_selection(int argc, char **argv) {
         st.write((const char *)&nbReads, 8); st.write((const char *)&n50, 4); st.write((const char *)&density, 4);
         st.write((const char *)&nbBases, 8); st.write((const char *)&avgQ, 4); st.write((const char *)&meanLen, 4);
         st.write((const char *)&nbSelected, 8);
+        st.close();
+        if (!st) die("writing " + tmpDir + "/read_stats.txt failed");
     }
 
     g_log.line("\tNb reads: " + std::to_string(nbReads) + "  bases: " + std::to_string(nbBases) + "  minimizers: " + std::to_string(nbSelected) +
@@ -712,6 +716,8 @@ int run_read_selection(int argc, char **argv) {
         }
         fifoCv.notify_all();
         writer2.join();
+        corr.close();
+        if (!corr) die("writing " + tmpDir + "/read_data_corrected.txt failed");      // (a full disk must not pass for a short read set)
     }
     g_trace.mark("read_data_corrected.txt written");
     write_perf(tmpDir);
@@ -1065,18 +1071,23 @@ int run_graph(int argc, char **argv) {
     auto write_records = [&](const std::string &to) {
         std::ofstream f(dir + to, std::ios::binary);
         for (const RankTable &t : parts) f.write((const char *)t.rec.data(), (std::streamsize)t.rec.size());
+        f.close();
+        if (!f) die("writing " + dir + to + " failed");
     };
     if (!streamed) {
         write_records("/kminmerData_abundance.txt");
         if (hasVec) {
             std::ofstream f(dir + "/kminmerData_min.txt", std::ios::binary);
             for (const RankTable &t : parts) f.write((const char *)t.vec.data(), (std::streamsize)(t.vec.size() * 4));
+            f.close();
+            if (!f) die("writing " + dir + "/kminmerData_min.txt failed");
         }
         // graph/CreateMdbg.cpp:515-522
         if (a.firstPass) write_records("/kminmerData_abundance_init.txt");
         if (k == P.firstK + 1) write_records("/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
     }
     small.close();
+    if (!small) die("writing smallContigs_k" + std::to_string(k) + ".bin failed");
     g_trace.mark("graph: tables written");
     write_perf(dir);
     g_trace.mark("graph: done");
