@@ -19,6 +19,9 @@
  *        stage on top, products compared with a pure reference run.  At k >= firstK+2 the table the graph stage
  *        queries in memory (_mdbgNodesLight: isEdgeSupported :3990, removeUnsupportedUnitigs :4156, createEdgeNode
  *        :5013) is filled from the 20-byte records of kminmerData_abundance.txt.
+ * Built as oracle/_ref/refdrv_hip (with ref_binding.cpp, linked against libmdbg_hip.so) it also has
+ *   refdrv_hip readSelection_hip ... / refdrv_hip graph_hip ...
+ *        the reference's own tools with the hot path replaced by calls through include/mdbg_hip.h, as INTEGRATION.md describes.
  * Function-level probes (text on stdin -> text on stdout), used by tests/golden/make_golden.py:
  *   refdrv fn_scan <K> <density> <hpc>     : lines "<seq>"              -> "n v:pos:dir ..."
  *   refdrv fn_scan_notrim <K> <density> <hpc> : same with MinimizerParser::_trimBps = 0 (GenerateGfa's unitig scan)
@@ -216,6 +219,10 @@ static int fn_murmur()
     return 0;
 }
 
+#ifdef MDBG_WITH_HIP_BINDING
+#include "ref_binding.cpp"      /* refdrv_hip only: readSelection_hip / graph_hip, the reference's tools with the hot path behind the C ABI */
+#endif
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::cerr << "usage: refdrv <sub-command> ...\n"; return 2; }
@@ -241,6 +248,10 @@ int main(int argc, char **argv)
     else if (cmd == "contig") GenerateContigs().run(n, args.data());
     else if (cmd == "toMinspace") ToMinspace().run(n, args.data());
     else if (cmd == "graph_from_tables") return graph_from_tables(n, args.data());
+#ifdef MDBG_WITH_HIP_BINDING
+    else if (cmd == "readSelection_hip") return read_selection_hip(n, args.data());
+    else if (cmd == "graph_hip") return graph_hip(n, args.data());
+#endif
     else { std::cerr << "unknown sub-command " << cmd << "\n"; return 2; }
     return 0;
 }

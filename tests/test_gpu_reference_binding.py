@@ -1,0 +1,119 @@
+"""The C ABI as a drop-in INSIDE the reference: oracle/_ref/refdrv_hip is the reference's own code compiled where it lies
+plus oracle/ref_binding.cpp -- classes DERIVED from the reference's ReadSelection and CreateMdbg in which only what INTEGRATION.md sections
+1 and 2 name is replaced by calls through include/mdbg_hip.h.  Argument parsing, ReadParserParallel + kseq, the ordered record writer
+(writeRead), computeReadStats, computeLastK, Tool::end, and the whole graph stage behind the tables are the reference's, unchanged.
+
+Each test runs the modified and the unmodified reference tool side by side on the same input and compares their files."""
+from __future__ import annotations
+
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+from metamdbg_amd import formats, synth
+from tests import helpers as H
+from tests.test_gpu_tool import REFDRV, fbytes, make_tmp, run
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(REFDRV), "refdrv_hip")), reason="oracle/_ref/refdrv_hip not built")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDRV_HIP = os.path.join(ROOT, "oracle", "_ref", "refdrv_hip")
+
+
+def _corrected_records(raw: bytes) -> list[bytes]:
+    out, o = [], 0
+    while o < len(raw):
+        k = struct.unpack_from("<I", raw, o)[0]
+        out.append(raw[o:o + 5 + 4 * k])
+        o += 5 + 4 * k
+    return sorted(out)
+
+
+def _read_selection(exe, cmd, tmp, threads, extra=(), env=None):
+    run(exe, cmd, tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"), "--threads", str(threads), *extra, env=env)
+
+
+def _stats_equal(a: bytes, b: bytes, exact: bool) -> None:
+    """read_stats.txt: byte for byte when the binding's parser ran on one thread (reads arrive in read order, the long-double quality sum
+    is accumulated in the reference's order); with several threads the reads arrive out of order and the mean quality -- a float of that
+    sum -- may differ in its last bit, as it does between two runs of the reference itself."""
+    if exact:
+        assert a == b
+        return
+    x, y = formats.parse_read_stats(a), formats.parse_read_stats(b)
+    for key in ("n_reads", "n50", "density", "n_bases", "mean_length", "n_minimizers"):
+        assert x[key] == y[key], key
+    assert abs(x["avg_quality"] - y["avg_quality"]) <= 1e-5 * abs(y["avg_quality"])
+
+
+@pytest.mark.parametrize("batch,threads", [("200000", 4), ("67108864", 1)])
+def test_reference_read_selection_with_the_binding_hifi_fastq(tmp_path, batch, threads):
+    """HiFi preset, FASTQ with qualities, a quality threshold that removes reads, soft-masked stretches and Ns: read_data_init.txt and
+    read_stats.txt byte for byte, read_data_corrected.txt as a multiset (the reference writes it in thread-completion order)."""
+    rng = np.random.default_rng(71)
+    genome = np.repeat(synth.CODE2ASCII[rng.integers(0, 4, 50000)], rng.choice([1, 1, 2, 5], 50000))
+    fq = str(tmp_path / "r.fastq")
+    with open(fq, "wb") as f:
+        for i in range(400):
+            a = int(rng.integers(0, len(genome) - 12000)); L = int(rng.integers(100, 12000))
+            s = genome[a:a + L].copy()
+            if i % 17 == 0:
+                s[int(rng.integers(0, L))] = ord("N")
+            if i % 23 == 0:
+                b = int(rng.integers(0, L)); s[b:b + 40] |= 0x20
+            q = (rng.integers(2, 60 if i % 5 else 12, L) + 33).astype(np.uint8)
+            f.write(b"@r%d\n" % i + bytes(s) + b"\n+\n" + bytes(q) + b"\n")
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+    t_ref, t_hip = make_tmp(tmp_path / "ref", P, [fq]), make_tmp(tmp_path / "hip", P, [fq])
+    q = ["--min-read-quality", "9.5"]
+    _read_selection(REFDRV, "readSelection", t_ref, 1, q)
+    _read_selection(REFDRV_HIP, "readSelection_hip", t_hip, threads, q, env={"MDBG_BINDING_BATCH_BASES": batch})
+    for name in ("read_data_init.txt", "repetitiveMinimizers.bin"):
+        assert fbytes(t_hip, name) == fbytes(t_ref, name), name
+    _stats_equal(fbytes(t_hip, "read_stats.txt"), fbytes(t_ref, "read_stats.txt"), exact=threads == 1)
+    assert _corrected_records(fbytes(t_hip, "read_data_corrected.txt")) == _corrected_records(fbytes(t_ref, "read_data_corrected.txt"))
+    st = formats.parse_read_stats(fbytes(t_ref, "read_stats.txt"))
+    assert st["n_reads"] == 400 and 0 < st["n_minimizers"]
+    assert os.path.getsize(os.path.join(t_hip, "perf.bin")) == 16
+
+
+def test_reference_read_selection_with_the_binding_ont_census(tmp_path):
+    """ONT preset (no HPC, repetitive-minimizer census, --skip-correction) on the read set whose pick is unambiguous
+    (tests/golden/ont_rep): the census through the library must choose what the reference's own counting chooses, and the file
+    filtered by it must be the reference's."""
+    m = H.load_manifest("ont_rep")
+    fastq = str(tmp_path / "ont_rep.fastq")
+    synth.write_fasta(fastq, H.spec_from_manifest(m))
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=False, data_type=1, correction_density=0.025)
+    t_ref, t_hip = make_tmp(tmp_path / "ref", P, [fastq]), make_tmp(tmp_path / "hip", P, [fastq])
+    extra = ["--min-read-quality", "0.0", "--skip-correction"]
+    _read_selection(REFDRV, "readSelection", t_ref, 1, extra)
+    _read_selection(REFDRV_HIP, "readSelection_hip", t_hip, 4, extra, env={"MDBG_BINDING_BATCH_BASES": "3000000"})
+    rep = lambda t: set(np.frombuffer(fbytes(t, "repetitiveMinimizers.bin"), "<u4").tolist())
+    assert rep(t_hip) == rep(t_ref) and len(rep(t_ref)) == m["n_keep"]
+    assert fbytes(t_hip, "read_data_init.txt") == fbytes(t_ref, "read_data_init.txt")
+    _stats_equal(fbytes(t_hip, "read_stats.txt"), fbytes(t_ref, "read_stats.txt"), exact=False)
+    assert _corrected_records(fbytes(t_hip, "read_data_corrected.txt")) == _corrected_records(fbytes(t_ref, "read_data_corrected.txt"))
+
+
+def test_reference_multi_k_loop_with_the_binding(tmp_path):
+    """The reference's multi-k loop (graph -> contig -> toMinspace, k = 4 .. 9) twice: with its own `graph`, and with `graph_hip` -- the
+    reference's CreateMdbg whose tables come from the library, its graph stage on top of them in the same command.  Unitig graph
+    files and the inputs of every next k byte-equal, tables equal as multisets, at every k."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from tests import handover as ho
+    spec = synth.hifi_spec(260, seed=93, coverage=30.0)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=True, data_type=0)
+    reads = str(tmp_path / "reads.fasta")
+    synth.write_fasta(reads, spec)
+    t_ref = mg.run_ref_pipeline(str(tmp_path / "ref"), reads, params, graph=False)
+    t_hip = mg.run_ref_pipeline(str(tmp_path / "hip"), reads, params, graph=False)
+    last_k = 9
+    ho.run_loop(t_ref, params, last_k, ho.reference_graph, str(tmp_path / "snap_ref"))
+    ho.run_loop(t_hip, params, last_k, lambda tmp, k, first_k: run(REFDRV_HIP, "graph_hip", *ho.graph_args(tmp, k, first_k)), str(tmp_path / "snap_hip"))
+    seen = ho.compare_dirs(str(tmp_path / "snap_ref"), str(tmp_path / "snap_hip"), 4, last_k)
+    assert seen["graph_files"] >= 4 * 5 and seen["next_inputs"] == 3 * 5 and seen["tables"] == 6, seen
