@@ -51,8 +51,9 @@ def _stats_equal(a: bytes, b: bytes, exact: bool) -> None:
 
 @pytest.mark.parametrize("batch,threads", [("200000", 4), ("67108864", 1)])
 def test_reference_read_selection_with_the_binding_hifi_fastq(tmp_path, batch, threads):
-    """HiFi preset, FASTQ with qualities, a quality threshold that removes reads, soft-masked stretches and Ns: read_data_init.txt and
-    read_stats.txt byte for byte, read_data_corrected.txt as a multiset (the reference writes it in thread-completion order)."""
+    """HiFi preset, FASTQ with qualities, a quality threshold that removes reads, soft-masked stretches: read_data_init.txt and
+    read_stats.txt byte for byte, read_data_corrected.txt as a multiset (the reference writes it in thread-completion order).
+    (No N: the unmodified reference corrupts its heap on a read that holds one -- kmerCounts[-1], ReadSelection.hpp:1196)"""
     rng = np.random.default_rng(71)
     genome = np.repeat(synth.CODE2ASCII[rng.integers(0, 4, 50000)], rng.choice([1, 1, 2, 5], 50000))
     fq = str(tmp_path / "r.fastq")
@@ -60,8 +61,6 @@ def test_reference_read_selection_with_the_binding_hifi_fastq(tmp_path, batch, t
         for i in range(400):
             a = int(rng.integers(0, len(genome) - 12000)); L = int(rng.integers(100, 12000))
             s = genome[a:a + L].copy()
-            if i % 17 == 0:
-                s[int(rng.integers(0, L))] = ord("N")
             if i % 23 == 0:
                 b = int(rng.integers(0, L)); s[b:b + 40] |= 0x20
             q = (rng.integers(2, 60 if i % 5 else 12, L) + 33).astype(np.uint8)
