@@ -1486,3 +1486,63 @@ def test_table_rows_in_pieces(ctx):
         from metamdbg_amd import capi
         with pytest.raises(capi.MdbgError):
             table.to_host_range(n, 1)
+
+
+def test_bad_arguments_are_refused_with_a_code_and_a_message(ctx):
+    """include/mdbg_hip.h: every entry returns MDBG_E* with a message in mdbg_last_error instead of crashing, and the context goes on
+    working -- null handles, null outputs, parameters outside what the path defines (l > 16, k < 2, a row range past the table, vectors of
+    a table that has none, offsets that go backwards, too little room for the census pick)."""
+    import ctypes as C
+    from metamdbg_amd import capi
+    L = capi.lib()
+    spec = synth.hifi_spec(300, seed=5, read_len=4000, coverage=20.0)
+    reads = ctx.reads_synthetic(spec)
+    mins = ctx.scan(reads, K=15, density=0.005, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    table = ctx.kminmer_count_first(corr, 4, 0)
+    out = C.c_void_p()
+    none = C.c_void_p()
+    p_ok = capi.ScanParams(15, 0.005, 1, 0.0, None, 0, 1, 0, 0, 0)
+
+    def refused(rc, codes=(-1,)):
+        assert rc in codes, rc
+        msg = (L.mdbg_last_error(ctx.h) or b"").decode()
+        assert msg, "no message"
+        return msg
+
+    refused(L.mdbg_scan(ctx.h, none, C.byref(p_ok), C.byref(out)))
+    refused(L.mdbg_scan(ctx.h, reads.h, None, C.byref(out)))
+    refused(L.mdbg_scan(ctx.h, reads.h, C.byref(p_ok), None))
+    for bad_l in (0, 1, 17, 32):
+        assert "minimizer_size" in refused(L.mdbg_scan(ctx.h, reads.h, C.byref(capi.ScanParams(bad_l, 0.005, 1, 0.0, None, 0, 1, 0, 0, 0)), C.byref(out)))
+    assert "quality_window" in refused(L.mdbg_scan(ctx.h, reads.h, C.byref(capi.ScanParams(15, 0.005, 1, 0.0, None, 0, 1, 7, 0, 0)), C.byref(out)))
+    refused(L.mdbg_reads_from_ascii(ctx.h, None, None, None, 5, C.byref(out)))
+    refused(L.mdbg_purge_palindromes(ctx.h, mins.h, 1, 100, C.byref(out)))
+    refused(L.mdbg_purge_palindromes(ctx.h, none, 4, 100, C.byref(out)))
+    refused(L.mdbg_apply_density_threshold(ctx.h, mins.h, C.c_float(0.0), C.byref(out)))
+    refused(L.mdbg_kminmer_count_first(ctx.h, corr.h, 1, 0, C.byref(out)))
+    refused(L.mdbg_kminmer_count_first(ctx.h, none, 4, 0, C.byref(out)))
+    refused(L.mdbg_kminmer_count_refined(ctx.h, corr.h, None, 5, none, C.byref(out)))
+    refused(L.mdbg_kminmer_index(ctx.h, corr.h, None, 6, none, C.byref(out)))
+    n_rec = table.info()["n_records"]
+    buf = np.zeros(20 * 4, np.uint8)
+    assert "rows" in refused(L.mdbg_table_to_host_range(ctx.h, table.h, n_rec - 1, 3, buf.ctypes.data_as(C.c_void_p), None))
+    refused(L.mdbg_table_checksum(ctx.h, table.h, None))
+    off_bad = np.array([0, 5, 3], np.uint64)
+    vals = np.arange(8, dtype=np.uint32)
+    assert "non-decreasing" in refused(L.mdbg_minimizers_from_host(ctx.h, vals.ctypes.data_as(C.c_void_p), off_bad.ctypes.data_as(C.c_void_p), 2, C.byref(out)))
+    # a census pick that does not fit the caller's room: MDBG_ERANGE with the size needed
+    room = C.c_uint32(0)
+    one = np.zeros(1, np.uint32)
+    assert "room" in refused(L.mdbg_repetitive_minimizers(ctx.h, mins.h, one.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(room)), codes=(-5,))
+    # a k > firstK+1 table has no vectors to hand out
+    t5 = ctx.kminmer_count_refined(corr, None, 5, table)
+    t6 = ctx.kminmer_index(corr, None, 6, t5)
+    n6 = t6.info()["n_records"]
+    vec = np.zeros(max(1, n6) * 6, np.uint32)
+    rec = np.zeros(max(1, n6) * 20, np.uint8)
+    assert "no vectors" in refused(L.mdbg_table_to_host(ctx.h, t6.h, rec.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p)))
+    assert L.mdbg_set_option(ctx.h, b"no_such_option", 1) != 0
+    # ... and the context is as good as before
+    again = ctx.kminmer_count_first(ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=True), 4, 100), 4, 0)
+    assert again.checksum() == table.checksum() and again.info()["n_records"] == n_rec
