@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--gzip-members", action="store_true", help="the gzip file as 32 concatenated members (round 2's measurement) instead of one")
     ap.add_argument("--gzip-modes", default="", help="comma list of extra gzip runs: t<N> (MDBG_HOST_GZIP_THREADS=N), nopool, branchy, round2 (both)")
     ap.add_argument("--no-bgzf", action="store_true")
+    ap.add_argument("--reps", type=int, default=2, help="runs per thread count of the plain FASTA / FASTQ legs (the best is reported, all are listed)")
     ap.add_argument("--no-gzip", action="store_true", help="of the compressed legs, BGZF only")
     ap.add_argument("--bgzf-modes", default="", help="comma list of extra BGZF runs: copy (the round-2 path: MDBG_HOST_BGZF_COPY=1), t<N> (MDBG_HOST_BGZF_THREADS=N)")
     ap.add_argument("--batch-bases", default="", help="comma list: readSelection --batch-bases values to compare on the FASTA set (tool flag, not a reference flag)")
@@ -176,14 +177,16 @@ def main():
             res["ont_write_s"] = write_reads(ont_fastq, ctx, ospec, a.ont_reads, True)
         ctx.close()
 
-        def best_of(inputs, n_reads, label, reps=2, extra_env=None):
+        def best_of(inputs, n_reads, label, reps=a.reps, extra_env=None):
             out = {}
             for t in threads:
                 runs = [run_tool(os.path.join(work, "run"), inputs, t, P, extra_env=extra_env) for _ in range(reps)]
                 b = min(runs, key=lambda r: r["total_s"])
                 gbp = n_reads * 10_000 / 1e9
-                b.update(gbp=gbp, gbps=gbp / b["total_s"], read_selection_gbps=gbp / b["read_selection_s"], all_total_s=[round(r["total_s"], 3) for r in runs])
+                b.update(gbp=gbp, gbps=gbp / b["total_s"], read_selection_gbps=gbp / b["read_selection_s"], all_total_s=[round(r["total_s"], 3) for r in runs],
+                         all_read_selection_s=[round(r["read_selection_s"], 3) for r in runs])
                 out[f"threads_{t}"] = b
+                print(label, t, "threads: readSelection", sorted(b["all_read_selection_s"]), file=sys.stderr)
                 print(label, t, "threads: %.2f s total (readSelection %.2f, graph %.2f) = %.1f Gbp/s" % (b["total_s"], b["read_selection_s"], b["graph_s"], b["gbps"]), file=sys.stderr, flush=True)
             return out
         if a.reads:
