@@ -794,6 +794,39 @@ def kminmer_roofline(ctx, reads) -> dict:
                     "instance), not HBM bandwidth; `atomic_ceiling_ms` is I over that rate (profiles/r01c_atomic_rates_gfx950.txt)"}
 
 
+_PHASE = ["start"]          # where the run is (the deadline below names it)
+
+
+def _phase(name: str) -> None:
+    _PHASE[0] = name
+
+
+def _arm_deadline(rank: int, world: int, json_fd: int) -> None:
+    """A run that hangs (a collective whose peer never arrives: RCCL with more than one rank has not met hardware yet) must end with a line
+    that says so, not with the driver's kill: after MDBG_BENCH_DEADLINE_S seconds (default 1800; 0 = never) every rank dumps its Python
+    stacks to stderr, rank 0 writes a JSON line with "value": null and the phase it was in, and the process exits with status 3."""
+    secs = float(os.environ.get("MDBG_BENCH_DEADLINE_S", "1800") or 0)
+    if secs <= 0:
+        return
+    import faulthandler
+    import threading
+
+    def fire():
+        print(f"[bench] rank {rank} of {world}: no result after {secs:.0f} s, phase '{_PHASE[0]}'; giving up", file=sys.stderr, flush=True)
+        try:
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        except Exception:
+            pass
+        if rank == 0:
+            line = {"metric": "Gbp/s through minimizer+k-min-mer step; bit-exact k-min-mer table vs ref", "value": None, "unit": "Gbp/s", "n_gpus": world,
+                    "higher_is_better": True, "error": f"deadline of {secs:.0f} s passed in phase '{_PHASE[0]}' (MDBG_BENCH_DEADLINE_S)"}
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os._exit(3)
+    t = threading.Timer(secs, fire)
+    t.daemon = True
+    t.start()
+
+
 def main() -> None:
     args = parse_args()
     # The one JSON line must be the only thing on stdout: RCCL prints a version banner through C stdio, which a redirected
@@ -811,6 +844,7 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    _arm_deadline(rank, world, json_fd)
     if os.environ.get("MDBG_BENCH_SHARE_GPU") == "1":      # test hook: every rank on device 0 (multi-rank logic on a 1-GPU box)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -821,6 +855,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("MDBG_BENCH_BACKEND", "nccl")   # "gloo": exchanges staged through the host (test hook)
+        _phase(f"init_process_group({backend})")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -831,6 +866,7 @@ def main() -> None:
     # rate) and the gaps between launches overlap with the scan of the other (bound by the vector ALU).  Step i runs
     # on slot i % IN_FLIGHT; every step is still the complete pass over one batch.
     n_slots = max(1, args.in_flight)
+    _phase("contexts and the resident read set")
     # beside the other batches' scans the table kernels keep to a small footprint: 1 / 2 / 3 / 4 resident blocks per CU gave
     # 676 / 672 / 657 / 643 Gbp/s on one GPU and 489 / 479 / 463 on the per-rank workload of an 8-GPU job run through
     # the sharded path (profiles/r01g_table_footprint_sweep.txt)
@@ -862,6 +898,7 @@ def main() -> None:
     if (world > 1 or force_exchange) and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("MDBG_BENCH_EXCHANGE", "library") == "library":
         comms = []
         comm_error = None
+        _phase("creating the library's RCCL communicators (mdbg_comm_create)")
         for c, _ in slots:
             t = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
@@ -1026,6 +1063,7 @@ def main() -> None:
     # start on slot 0
     n_warm = max(args.warmup, n_slots)
     n_warm += (-n_warm) % n_slots
+    _phase("warm-up steps")
     run_phase(0, n_warm)
 
     # HIP multiplexes streams onto a few hardware queues; when the streams of two contexts land on the same queue their
@@ -1086,7 +1124,9 @@ def main() -> None:
     acct0 = exchange_account() if exchange else None
     barrier()
     t0 = time.perf_counter()
+    _phase("timed steps")
     run_phase(n_warm, args.steps)
+    _phase("after the timed steps (verification, legs)")
     barrier()
     dt = time.perf_counter() - t0
     for c, _ in slots:
