@@ -96,6 +96,19 @@ int mdbg_minimizers_from_host(mdbg_ctx *, const uint32_t *mins, const uint64_t *
     return MDBG_OK;
 }
 void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
+int mdbg_minimizers_concat(mdbg_ctx *, const mdbg_minimizers *const *parts, uint32_t n_parts, mdbg_minimizers **out) {
+    jitter();
+    mdbg_minimizers *m = new mdbg_minimizers();
+    m->off.assign(1, 0);
+    for (uint32_t p = 0; p < n_parts; p++) {
+        const mdbg_minimizers *q = parts[p];
+        const uint64_t base = m->m.size();
+        for (size_t i = 1; i < q->off.size(); i++) m->off.push_back(base + q->off[i]);
+        m->m.insert(m->m.end(), q->m.begin(), q->m.end());
+    }
+    *out = m;
+    return MDBG_OK;
+}
 int mdbg_purge_palindromes(mdbg_ctx *, const mdbg_minimizers *in, uint32_t, uint32_t, mdbg_minimizers **out) {
     jitter();
     mdbg_minimizers *m = new mdbg_minimizers();
