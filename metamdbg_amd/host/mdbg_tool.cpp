@@ -717,11 +717,16 @@ int run_read_selection(int argc, char **argv) {
         };
         std::vector<std::thread> writers2;
         for (int i = 0, nw = std::max(1, std::min(4, a.threads / 4)); i < nw; i++) writers2.emplace_back(write2);
+        double pConcat = 0, pPurge = 0, pFree = 0, pSlab = 0, pCopy = 0, pPlace = 0;      // MDBG_TRACE: where the purging threads' time goes
         auto purge_own = [&](int ci) {
             mdbg_ctx *ctx = ctxs[(size_t)ci];
             std::vector<const mdbg_minimizers *> parts;
             std::vector<size_t> idx;
             std::vector<uint32_t> nReadsOf;
+            double tc = 0, tp = 0, tf = 0, ts = 0, ty = 0, tl = 0;
+            struct Sum { double &a, &b, &c, &d, &e, &f, &A, &B, &C, &D, &E, &F; std::mutex &mu;
+                         ~Sum() { std::lock_guard<std::mutex> g(mu); A += a; B += b; C += c; D += d; E += e; F += f; } }
+                sum{tc, tp, tf, ts, ty, tl, pConcat, pPurge, pFree, pSlab, pCopy, pPlace, fifoMu};
             for (size_t g0 = 0; g0 < kept.size(); g0 += GROUP) {
                 parts.clear(); idx.clear(); nReadsOf.clear();
                 for (size_t i = g0; i < std::min(kept.size(), g0 + GROUP); i++) {
@@ -731,11 +736,15 @@ int run_read_selection(int argc, char **argv) {
                     parts.push_back(kept[i].mins); idx.push_back(i); nReadsOf.push_back(bn);
                 }
                 if (parts.empty()) continue;
+                const double t0 = g_trace.now();
                 mdbg_minimizers *all = nullptr, *pur = nullptr;
                 if (parts.size() > 1) check_on(ctx, mdbg_minimizers_concat(ctx, parts.data(), (uint32_t)parts.size(), &all), "mdbg_minimizers_concat");
+                const double t1 = g_trace.now();
                 check_on(ctx, mdbg_purge_palindromes(ctx, all ? all : parts[0], (uint32_t)P.firstK, (uint32_t)lastK, &pur), "mdbg_purge_palindromes");
+                const double t2 = g_trace.now();
                 if (all) mdbg_minimizers_free(all);
                 for (size_t i : idx) mdbg_minimizers_free(kept[i].mins);
+                const double t3 = g_trace.now();
                 HostBatch *hb = nullptr;
                 {
                     std::lock_guard<std::mutex> lk(fifoMu);
@@ -745,8 +754,10 @@ int run_read_selection(int argc, char **argv) {
                 uint32_t bn; uint64_t bt;
                 mdbg_minimizers_info(pur, &bn, &bt);
                 hb->shape_values(bn, bt);
+                const double t4 = g_trace.now();
                 check_on(ctx, mdbg_minimizers_to_host(ctx, pur, hb->off, hb->m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
                 mdbg_minimizers_free(pur);
+                const double t5 = g_trace.now();
                 std::atomic<int> *left = new std::atomic<int>((int)idx.size());
                 {
                     std::unique_lock<std::mutex> lk(fifoMu);
@@ -767,6 +778,7 @@ int run_read_selection(int argc, char **argv) {
                     }
                 }
                 fifoCv.notify_all();
+                tc += t1 - t0; tp += t2 - t1; tf += t3 - t2; ts += t4 - t3; ty += t5 - t4; tl += g_trace.now() - t5;
             }
         };
         std::vector<std::thread> purgers;
@@ -778,7 +790,11 @@ int run_read_selection(int argc, char **argv) {
             done2 = true;
         }
         fifoCv.notify_all();
+        g_trace.mark("purge pass: every batch purged");
         for (auto &t : writers2) t.join();
+        if (getenv("MDBG_TRACE"))
+            fprintf(stderr, "[mdbg_tool] purge pass, summed over the %d purging thread(s): appending the batches of a group %.3f s, purging %.3f s, freeing %.3f s, "
+                            "page-locked slab %.3f s, copy back %.3f s, waiting for a place %.3f s\n", nConsumers, pConcat, pPurge, pFree, pSlab, pCopy, pPlace);
         if (prefSeq2 != kept.size()) die("internal error: a purged batch was never placed");
         if (close(corrFd) != 0) die("closing " + tmpDir + "/read_data_corrected.txt failed");
     }
