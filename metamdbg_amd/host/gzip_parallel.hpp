@@ -10,8 +10,10 @@
 //      "position p of the unknown window" (32768 + p), which matches copy around like bytes.  It must end exactly on the
 //      header the next chunk found -- a wrongly guessed header makes the decoder run past it, which is an error;
 //   3. windows are resolved in chunk order (32 KB per chunk) and every chunk's symbols are translated to bytes by the
-//      pool; the CRC-32s of the chunks are combined and checked against the member's trailer, like its length.
-// read() hands the text out in order.  Any inconsistency ends the run with an error naming the switch back to one
+//      pool; the CRC-32s of the pieces are combined and checked against the member's trailer, like its length.
+// fill_begin() / fill_wait() have the pool translate the symbols STRAIGHT INTO the caller's buffer (hostfeed.hpp cuts its slabs
+// from it; the length of every decoded chunk is known, so every piece has its place before it is translated); read() -- kept for
+// comparison, MDBG_HOST_GZIP_COPY=1 -- hands out text the pool translated into buffers of its own.  Any inconsistency ends the run with an error naming the switch back to one
 // decoding thread; nothing is guessed silently.  Jobs never wait for each other: a chunk is decoded only once its stop
 // position is known, translated only once its window is.
 #pragma once
@@ -48,6 +50,7 @@ public:
         : addr_(addr), len_(len), path_(std::move(path)), chunk_(chunk_bytes < 65536 ? 65536 : chunk_bytes), nthreads_(threads < 1 ? 1 : threads) {
         pooled_ = !getenv("MDBG_HOST_GZIP_NO_POOL");                           // A/B switches for the two round-3 changes
         table_translate_ = !getenv("MDBG_HOST_GZIP_BRANCHY");
+        direct_ = !getenv("MDBG_HOST_GZIP_COPY");                              // A/B: chunks translated into buffers of their own, read() copies
         start_member(0);
         // A stream without dynamic-Huffman block headers to start from (stored blocks: gzip -0, incompressible data) cannot be
         // cut: ask before the first read() and use one thread then.  Looked for in the second and third chunk.
@@ -113,6 +116,87 @@ public:
         return got;
     }
 
+    bool direct() const { return direct_; }
+
+    // Text straight to its place (what BgzfReader::fill_begin does for BGZF): the symbols of the next chunks -- as many as fit into
+    // `room` bytes at `dst` -- are translated by the pool INTO `dst`; returns at once with the number of bytes that will be there
+    // (it waits only for chunks that are not decoded yet), 0 at the end of the file.  fill_wait() returns when they are in place
+    // and every member that ended among them has its CRC-32 and length checked.  One request at a time.
+    size_t fill_begin(char *dst, size_t room) {
+        constexpr size_t SUB = (size_t)1 << 20;                                // a job for one thread
+        std::unique_lock<std::mutex> g(mu_);
+        pieces_.clear();
+        piecesNext_ = piecesDone_ = 0;
+        pending_ = false;
+        size_t placed = 0;
+        while (placed < room) {
+            if (!fatal_.empty()) throw std::runtime_error(fatal_);
+            std::shared_ptr<Gen> gen = gen_;
+            if (!gen) break;                                                   // end of file
+            if (gen->consumed >= gen->chunks.size()) throw std::runtime_error("gzip stream without an end in " + path_ + hint());
+            Chunk &c = gen->chunks[gen->consumed];
+            if (!((c.decoded && c.window_known) || !c.error.empty())) {
+                // the pool may be asleep: the chunks it was allowed to decode ahead were all done, and only this call moved the
+                // window on (and handed it pieces to translate)
+                cv_.notify_all();
+                cv_.wait(g, [&] { return (c.decoded && c.window_known) || !c.error.empty() || !fatal_.empty(); });
+            }
+            if (!fatal_.empty()) throw std::runtime_error(fatal_);
+            if (!c.error.empty()) throw std::runtime_error(c.error + hint());
+            size_t n = std::min(c.nsym - rpos_, room - placed);
+            const bool ends_chunk = rpos_ + n == c.nsym;
+            for (size_t o = 0; o < n || (o == 0 && n == 0 && ends_chunk && c.member_end != NONE); o += SUB) {
+                Piece pc;
+                pc.gen = gen; pc.chunk = gen->consumed; pc.from = rpos_ + o; pc.n = std::min(SUB, n - o); pc.dst = dst + placed + o;
+                if (ends_chunk && o + SUB >= n) pc.member_end = c.member_end;
+                pieces_.push_back(std::move(pc));
+                pending_ = true;                                               // (from here on fill_wait / fill_settle have something to wait for,
+                c.pieces_open++;                                               //  also when this call ends in an exception further down)
+                if (n == 0) break;
+            }
+            rpos_ += n; placed += n;
+            if (!ends_chunk) break;                                            // the room is used up
+            c.handed = true;
+            if (c.pieces_open == 0) give_sym(c.sym, c.sym_cap);
+            rpos_ = 0;
+            if (c.member_end != NONE) start_member((size_t)c.member_end + 8);  // next member, or the end (trailing bytes ignored)
+            else gen->consumed++;
+        }
+        g.unlock();
+        cv_.notify_all();
+        return placed;
+    }
+    void fill_wait() {
+        if (!pending_) return;
+        std::vector<Piece> done;
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            // (after a failure: not before every thread has let go of the caller's buffer)
+            cvDone_.wait(g, [&] { return piecesDone_ == pieces_.size() || (!pieceError_.empty() && piecesBusy_ == 0); });
+            pending_ = false;
+            piecesNext_ = pieces_.size();
+            if (!pieceError_.empty()) throw std::runtime_error(pieceError_ + hint());
+            done.swap(pieces_);
+            piecesNext_ = piecesDone_ = 0;
+        }
+        for (const Piece &pc : done) {
+            crc_ = (uint32_t)crc32_combine(crc_, pc.crc, (z_off_t)pc.n);
+            total_ += pc.n;
+            if (pc.member_end == NONE) continue;
+            const uint8_t *t = addr_ + pc.member_end;                          // trailer: CRC-32, ISIZE
+            const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            const uint32_t want_len = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            if (want_crc != crc_ || want_len != (uint32_t)total_) throw std::runtime_error("gzip CRC / length mismatch in " + path_ + hint());
+            total_ = 0;
+            crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
+        }
+    }
+    void fill_settle() noexcept { try { fill_wait(); } catch (...) {} }
+    bool at_end() {                                                            // nothing is left to ask for
+        std::lock_guard<std::mutex> g(mu_);
+        return !gen_ && fatal_.empty();
+    }
+
 private:
     struct Chunk {
         uint64_t start_bit = NONE;          // first block header behind the cut, in bits from the member's deflate data; NONE: none here
@@ -127,6 +211,9 @@ private:
         uint32_t crc = 0;
         uint64_t member_end = NONE;         // file offset of the member's trailer if the stream ended in this chunk
         std::string error;
+        uint64_t uid = 0;                   // set when decoded: names the chunk's window in the translating threads' tables
+        size_t pieces_open = 0;             // direct mode: pieces of this chunk handed out and not yet translated
+        bool handed = false;                //              every symbol has been handed out
     };
     struct Gen {                            // one gzip member
         size_t data = 0;                    // file offset of the deflate data
@@ -201,7 +288,7 @@ private:
     }
 
     // ---- the pool ------------------------------------------------------------------------------------------------------
-    enum Job { NOTHING, FIND, DECODE, TRANSLATE };
+    enum Job { NOTHING, FIND, DECODE, TRANSLATE, PIECE };
 
     // stop position of chunk k: the header found by the next chunk that has one.  false = not decided yet
     static bool stop_of(const Gen &gen, size_t k, uint64_t *stop) {
@@ -216,8 +303,8 @@ private:
     Job next_job(Gen &gen, size_t *k, uint64_t *stop) {                        // mu_ held
         const size_t ahead = (size_t)nthreads_ + 2;
         const size_t hi = std::min(gen.chunks.size(), gen.consumed + ahead);
-        // translation first: it feeds the reader and frees the symbols
-        for (size_t i = gen.consumed; i < hi; i++) {
+        // translation first: it feeds the reader and frees the symbols (direct mode: the reader's own requests, work())
+        for (size_t i = gen.consumed; i < hi && !direct_; i++) {
             Chunk &c = gen.chunks[i];
             if (i > gen.end_chunk) break;
             if (c.decoded && c.window_known && !c.translate_taken) { c.translate_taken = true; *k = i; return TRANSLATE; }
@@ -243,15 +330,27 @@ private:
         std::vector<uint16_t> scratch;
         std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]());                  // symbol -> byte (translate_chunk); entries 256 .. 0x7fff are never produced
         for (unsigned v = 0; v < 256; v++) lut[v] = (uint8_t)v;
+        uint64_t lut_of = 0;                                                   // the chunk (uid) whose window the table's upper half holds
         for (;;) {
             std::shared_ptr<Gen> gen;
-            size_t k = 0;
+            size_t k = 0, piece_index = 0;
             uint64_t stop = NONE;
             Job job = NOTHING;
+            Piece piece;
+            const auto t_start = std::chrono::steady_clock::now();
             {
                 std::unique_lock<std::mutex> g(mu_);
                 for (;;) {
                     if (stop_) return;
+                    if (piecesNext_ < pieces_.size() && pieceError_.empty()) {      // the reader's request goes first: it frees the symbols
+                        piece = pieces_[piecesNext_];
+                        piece_index = piecesNext_++;
+                        piecesBusy_++;
+                        gen = piece.gen;
+                        k = piece.chunk;
+                        job = PIECE;
+                        break;
+                    }
                     gen = gen_;
                     if (gen && fatal_.empty()) job = next_job(*gen, &k, &stop);
                     if (job != NOTHING) break;
@@ -259,6 +358,30 @@ private:
                 }
             }
             Chunk &c = gen->chunks[k];
+            if (job == PIECE) {
+                std::string err;
+                uint32_t crc = 0;
+                try {
+                    if (piece.n) {
+                        translate_symbols(c.sym.get() + WINDOW + piece.from, piece.n, c.window.get(), WINDOW - c.window_valid, (uint8_t *)piece.dst, lut.get(),
+                                          lut_of != c.uid);
+                        lut_of = c.uid;
+                        crc = crc32_fast(0, (const uint8_t *)piece.dst, piece.n);
+                    }
+                } catch (const std::exception &e) { err = e.what(); }
+                bool last;
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    piecesBusy_--;
+                    if (err.empty()) { pieces_[piece_index].crc = crc; piecesDone_++; }
+                    else if (pieceError_.empty()) pieceError_ = err;
+                    if (--c.pieces_open == 0 && c.handed) give_sym(c.sym, c.sym_cap);
+                    last = pieceError_.empty() ? piecesDone_ == pieces_.size() : piecesBusy_ == 0;
+                }
+                t_translate_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count();
+                if (last) cvDone_.notify_all();
+                continue;
+            }
             const auto t0 = std::chrono::steady_clock::now();
             try {
                 if (job == FIND) {
@@ -329,6 +452,7 @@ private:
     // of the text up to the end of chunk i.  (Under the same lock as `decoded`, so that no translation frees symbols the
     // chain still needs.)
     void finish_decode(Gen &gen, size_t k, size_t nsym) {
+        gen.chunks[k].uid = ++uid_counter_;
         gen.chunks[k].nsym = nsym;
         gen.chunks[k].decoded = true;
         while (gen.chain_next < gen.chunks.size()) {
@@ -355,23 +479,17 @@ private:
         }
     }
 
-    void translate_chunk(Gen &gen, size_t k, uint8_t *lut) {
-        Chunk &c = gen.chunks[k];
-        if (!c.error.empty()) { std::lock_guard<std::mutex> g(mu_); c.translated = true; return; }
-        size_t text_cap = c.nsym ? c.nsym : 1;
-        std::unique_ptr<uint8_t[]> text = take_text(&text_cap);
-        const uint16_t *s = c.sym ? c.sym.get() + WINDOW : nullptr;
-        const uint8_t *win = c.window.get();
-        const size_t min_p = WINDOW - c.window_valid;
+    // n symbols -> bytes at t.  win: the WINDOW bytes in front of the chunk (may be null), valid from min_p on.  lut: the thread's
+    // symbol -> byte table; load_window: its upper half does not hold this chunk's window yet.
+    void translate_symbols(const uint16_t *s, size_t n, const uint8_t *win, size_t min_p, uint8_t *t, uint8_t *lut, bool load_window) const {
         size_t i = 0;
         if (win && min_p == 0 && table_translate_) {
             // The usual case, a whole window in front of the chunk: every symbol the decoder can have produced is valid, and the
             // translation is one table look-up per symbol -- bytes map to themselves, 0x8000 + p to the window's byte p.  (In reads
             // the references do not die out behind the first 32 KB: a match copies them along with the bytes, and zlib finds a
             // match every few bases of a read, so "is it a byte?" is a coin flip the branch predictor loses: 4 ns per symbol.)
-            memcpy(lut + 0x8000, win, WINDOW);
-            uint8_t *t = text.get();
-            for (; i + 16 <= c.nsym; i += 16) {
+            if (load_window) memcpy(lut + 0x8000, win, WINDOW);
+            for (; i + 16 <= n; i += 16) {
                 const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
                 const __m128i high = _mm_and_si128(_mm_or_si128(a, b), _mm_set1_epi16((short)0xFF00));
                 if (_mm_movemask_epi8(_mm_cmpeq_epi16(high, _mm_setzero_si128())) == 0xFFFF) {                 // sixteen bytes
@@ -380,15 +498,23 @@ private:
                 }
                 for (unsigned j = 0; j < 16; j++) t[i + j] = lut[s[i + j]];
             }
-            for (; i < c.nsym; i++) t[i] = lut[s[i]];
+            for (; i < n; i++) t[i] = lut[s[i]];
         }
-        for (; i < c.nsym; i++) {
+        for (; i < n; i++) {
             const uint16_t v = s[i];
-            if (v < 256) { text[i] = (uint8_t)v; continue; }
+            if (v < 256) { t[i] = (uint8_t)v; continue; }
             const size_t p = v - 0x8000u;
             if (!win || p < min_p) throw std::runtime_error("gzip data refers to text before the start of the stream in " + path_);
-            text[i] = win[p];
+            t[i] = win[p];
         }
+    }
+
+    void translate_chunk(Gen &gen, size_t k, uint8_t *lut) {
+        Chunk &c = gen.chunks[k];
+        if (!c.error.empty()) { std::lock_guard<std::mutex> g(mu_); c.translated = true; return; }
+        size_t text_cap = c.nsym ? c.nsym : 1;
+        std::unique_ptr<uint8_t[]> text = take_text(&text_cap);
+        if (c.nsym) translate_symbols(c.sym.get() + WINDOW, c.nsym, c.window.get(), WINDOW - c.window_valid, text.get(), lut, true);
         const uint32_t crc = crc32_fast(0, text.get(), c.nsym);
         std::lock_guard<std::mutex> g(mu_);
         c.text = std::move(text);
@@ -461,7 +587,21 @@ private:
     std::vector<std::pair<std::unique_ptr<uint8_t[]>, size_t>> idle_text_;
     std::vector<std::thread> pool_;
     std::atomic<long long> t_find_{0}, t_decode_{0}, t_translate_{0};
-    bool stop_ = false, usable_ = false, pooled_ = true, table_translate_ = true;
+    bool stop_ = false, usable_ = false, pooled_ = true, table_translate_ = true, direct_ = true;
+    // direct mode: the request that is out (fill_begin .. fill_wait); mu_ guards all of it
+    struct Piece {
+        std::shared_ptr<Gen> gen;
+        size_t chunk = 0, from = 0, n = 0;  // symbols [from, from + n) of the chunk ...
+        char *dst = nullptr;                // ... to this place
+        uint32_t crc = 0;
+        uint64_t member_end = NONE;         // the member's trailer lies behind this piece's last byte
+    };
+    std::vector<Piece> pieces_;
+    size_t piecesNext_ = 0, piecesDone_ = 0, piecesBusy_ = 0;
+    bool pending_ = false;                  // (the caller's thread only)
+    std::string pieceError_;
+    std::condition_variable cvDone_;
+    uint64_t uid_counter_ = 0;
     std::string fatal_;
 };
 

@@ -405,6 +405,7 @@ public:
     // the same without the exception (a caller unwinding: the buffer must not go before the pool has let go of it)
     void fill_settle() noexcept { try { fill_wait(); } catch (...) {} }
     size_t text_left() const { return cum_.back() - cum_[fillNext_]; }
+    bool at_end() const { return text_left() == 0; }          // nothing is left to ask for
 
     // up to `want` bytes of text; 0 at the end of the file
     size_t read(char *dst, size_t want) {
@@ -846,9 +847,16 @@ private:
         struct Closer { gzFile f; ~Closer() { if (f) gzclose(f); } } closer{fp};
         if (bgzf && bgzf->direct()) {
             bool multiline = false;
-            seq = stitch_bgzf(*bgzf, path, file, seq, &multiline);
+            seq = stitch_direct(*bgzf, path, file, seq, &multiline);
             if (!multiline) return seq;
             bgzf.reset();
+            return read_gz_sequential(path, file, seq);
+        }
+        if (gzpar && gzpar->direct()) {
+            bool multiline = false;
+            seq = stitch_direct(*gzpar, path, file, seq, &multiline);
+            if (!multiline) return seq;
+            gzpar.reset();
             return read_gz_sequential(path, file, seq);
         }
         std::vector<char> carry;          // text behind the last cut: an incomplete record and the look-ahead
@@ -933,11 +941,13 @@ private:
         return seq;
     }
 
-    // BGZF: the pool inflates every block straight to its place in a slab (BgzfReader::fill_begin), and the slab AFTER the one being
+    // Compressed text whose decoder can put it straight to its place (Src = BgzfReader: the pool inflates every block into the slab;
+    // ParallelGzipReader: the pool translates every chunk's symbols into the slab): the slab AFTER the one being
     // cut is already filling while the cut is chosen: its text starts `head` bytes into the slab, and what the cut leaves over (an
     // incomplete record and the look-ahead) is copied in front of it afterwards -- the only text this thread touches.  How much the
     // next slab is asked to hold is steered so that the left-over stays about `look` bytes.
-    uint64_t stitch_bgzf(BgzfReader &bgzf, const std::string &path, int file, uint64_t seq, bool *multiline) {
+    template <typename Src>
+    uint64_t stitch_direct(Src &bgzf, const std::string &path, int file, uint64_t seq, bool *multiline) {
         const size_t look = std::max<size_t>(std::min<size_t>(chunk_, (size_t)4 << 20), (size_t)128 << 10);   // (a block is up to 64 KB)
         const size_t head = 2 * look;
         const size_t cap = head + chunk_ + 2 * look;
@@ -968,7 +978,7 @@ private:
             std::lock_guard<std::mutex> g(mu_);
             slabsOut_--;
         };
-        struct Settle { BgzfReader &b; ~Settle() { b.fill_settle(); } } settle{bgzf};   // declared after the slabs' pool, runs before it goes
+        struct Settle { Src &b; ~Settle() { b.fill_settle(); } } settle{bgzf};   // declared after the slabs' pool, runs before it goes
 
         std::shared_ptr<char> cur = take_slab();
         if (!cur) return seq;
@@ -976,7 +986,7 @@ private:
         bgzf.fill_wait();
         const char *begin = cur.get() + head, *end = begin + got;
         while (begin < end && (*begin == '\n' || *begin == '\r')) begin++;
-        while (begin == end && bgzf.text_left()) {        // a file that starts with empty lines only, a block's worth of them
+        while (begin == end && !bgzf.at_end()) {        // a file that starts with empty lines only, a block's worth of them
             got = bgzf.fill_begin(cur.get() + head, chunk_ + look);
             bgzf.fill_wait();
             begin = cur.get() + head; end = begin + got;
@@ -991,7 +1001,7 @@ private:
         for (;;) {
             if (fileDone_[file].load()) break;            // (the per-file read cap was reached)
             const size_t total = (size_t)(end - begin);
-            const bool lastSlab = bgzf.text_left() == 0;
+            const bool lastSlab = bgzf.at_end();
             std::shared_ptr<char> nxt;
             size_t nxtGot = 0;
             if (!lastSlab) {

@@ -326,3 +326,27 @@ def test_damaged_gzip_on_several_threads(exe, big_gz, tmp_path):
         open(p, "wb").write(bytes(bad))
         r = subprocess.run([exe, "300000", "3", "0", p], capture_output=True, text=True, timeout=120, env=env)
         assert r.returncode == 3, (t, r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("gzchunk", [65536, 700000])
+def test_one_gzip_stream_copy_mode(exe, big_gz, gzchunk):
+    """MDBG_HOST_GZIP_COPY=1: the round-2 path (chunks translated into buffers of their own, one thread copies them into the slabs) is
+    still there for comparison and must still give the same reads."""
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK=str(gzchunk), MDBG_HOST_GZIP_COPY="1")
+    for key, path in big_gz.items():
+        r = subprocess.run([exe, "300000", "3", "0", path], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (key, r.stderr)
+
+
+def test_damaged_gzip_on_several_threads_copy_mode(exe, big_gz, tmp_path):
+    raw = open(big_gz["l6"], "rb").read()
+    rng = np.random.default_rng(9)
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK="150000", MDBG_TEST_DRAIN_ONLY="1", MDBG_HOST_GZIP_COPY="1")
+    for t in range(6):
+        bad = bytearray(raw)
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(100, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        p = str(tmp_path / "bad.fastq.gz")
+        open(p, "wb").write(bytes(bad))
+        r = subprocess.run([exe, "300000", "3", "0", p], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 3, (t, r.returncode, r.stdout, r.stderr)
