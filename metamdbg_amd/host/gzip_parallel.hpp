@@ -124,6 +124,9 @@ public:
     // and every member that ended among them has its CRC-32 and length checked.  One request at a time.
     size_t fill_begin(char *dst, size_t room) {
         constexpr size_t SUB = (size_t)1 << 20;                                // a job for one thread
+        // the pool hears of the pieces however this call ends: one that throws at a damaged chunk has usually handed out the pieces
+        // of the chunks in front of it, and fill_settle() waits for exactly those
+        struct Wake { std::condition_variable &cv; ~Wake() { cv.notify_all(); } } wake{cv_};
         std::unique_lock<std::mutex> g(mu_);
         pieces_.clear();
         piecesNext_ = piecesDone_ = 0;
@@ -162,8 +165,6 @@ public:
             if (c.member_end != NONE) start_member((size_t)c.member_end + 8);  // next member, or the end (trailing bytes ignored)
             else gen->consumed++;
         }
-        g.unlock();
-        cv_.notify_all();
         return placed;
     }
     void fill_wait() {

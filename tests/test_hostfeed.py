@@ -350,3 +350,34 @@ def test_damaged_gzip_on_several_threads_copy_mode(exe, big_gz, tmp_path):
         open(p, "wb").write(bytes(bad))
         r = subprocess.run([exe, "300000", "3", "0", p], capture_output=True, text=True, timeout=120, env=env)
         assert r.returncode == 3, (t, r.returncode, r.stdout, r.stderr)
+
+
+def test_damaged_and_truncated_inputs_under_load(exe, big_gz, tmp_path):
+    """Damaged and truncated gzip / BGZF files with sixteen readers at once on the machine: an error every time, never a hang.  (A run
+    that threw at a damaged chunk once forgot to tell the pool about the pieces it had already handed out and then waited for them:
+    one run in eight, and only on a busy machine -- which is where this test puts it.)"""
+    import concurrent.futures as cf
+    rng = np.random.default_rng(4)
+    raws = {"gz": open(big_gz["l6"], "rb").read(), "bgzf": _bgzf(gzip.decompress(open(big_gz["l6"], "rb").read()), block=20000)}
+    cases = []
+    for kind, raw in raws.items():
+        for t in range(8):
+            bad = bytearray(raw)
+            if t % 2:
+                bad = bad[: int(rng.integers(len(bad) // 4, len(bad) - 1))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(100, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            p = str(tmp_path / f"bad_{kind}_{t}.fastq.gz")
+            open(p, "wb").write(bytes(bad))
+            cases.append(p)
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK="150000", MDBG_TEST_DRAIN_ONLY="1")
+
+    def one(p):
+        try:
+            return p, subprocess.run([exe, "300000", "3", "0", p], capture_output=True, text=True, timeout=60, env=env).returncode
+        except subprocess.TimeoutExpired:
+            return p, "hang"
+    with cf.ThreadPoolExecutor(16) as ex:
+        res = list(ex.map(one, cases * 6))
+    assert all(rc == 3 for _, rc in res), [(os.path.basename(p), rc) for p, rc in res if rc != 3]
