@@ -5,7 +5,9 @@
 // compressed file is in memory (memory-mapped), so the hot loop refills a 64-bit bit buffer with unaligned 8-byte
 // loads, decodes through wide single-level-mostly tables (11 bits for literals/lengths, 8 for distances), emits up to
 // four literals per table look-up (a second table holds, for every 11-bit index, the run of literals it decodes to on
-// its own) and copies matches 8 bytes at a time.  Output is produced in caller-sized pieces: run()
+// its own), resolves a whole match -- length code, its extra bits and the distance code -- with ONE look-up where the three
+// fit the 11 index bits (a third table; reads compressed at the fast levels are such matches almost exclusively, and the
+// loop is a chain of dependent look-ups) and copies matches 8 bytes at a time.  Output is produced in caller-sized pieces: run()
 // stops in front of a symbol when fewer than MIN_ROOM (288) elements of room are left, so a match is never split and the only
 // state carried between calls is the bit buffer, the current block's tables and the remainder of a stored block.
 // Back-references reach into the text already produced, which the caller keeps directly in front of the output
@@ -233,10 +235,29 @@ private:
         build_table(lens, 288, LIT_BITS, lit_, LIT_CAP, false, litlen_entry);
         build_table(lens + 288, 32, DIST_BITS, dist_, DIST_CAP, false, dist_entry);
         build_literal_runs();
+        build_pairs();
     }
 
     // run_info_[i] / run_lits_[i]: the literals that the index bits i decode to on their own -- up to four, as long as
     // each next code is a literal that lies wholly inside the 11 bits.  info = bits consumed | count << 4; 0 = none.
+    // pair_[i]: a match whose length code, length extra bits and distance code lie wholly inside the index bits i -- reads compressed at
+    // the fast levels are such matches almost exclusively.  bits [0,4) code bits consumed in front of the distance's extra bits,
+    // [4,8) number of those extra bits, [8,17) the length, [17,32) the distance's base.
+    void build_pairs() {
+        for (unsigned i = 0; i < (1u << LIT_BITS); i++) {
+            pair_[i] = 0;
+            const uint32_t e = lit_[i];
+            if (e & (F_LITERAL | F_EOB | F_SUB | F_INVALID)) continue;
+            const unsigned lb = e & 0xFF, lx = (e >> 8) & 15;
+            if (lb + lx >= LIT_BITS) continue;
+            const unsigned len = (e >> 16) + ((i >> lb) & ((1u << lx) - 1));
+            const unsigned rest = LIT_BITS - (lb + lx);
+            const uint32_t d = dist_[(i >> (lb + lx)) & ((1u << DIST_BITS) - 1)];      // the unknown high bits read as zero: fine while the code fits
+            if ((d & (F_SUB | F_INVALID)) || (d & 0xFF) > rest) continue;
+            pair_[i] = (lb + lx + (d & 0xFF)) | (((d >> 8) & 15) << 4) | (len << 8) | ((d >> 16) << 17);
+        }
+    }
+
     void build_literal_runs() {
         for (unsigned i = 0; i < (1u << LIT_BITS); i++) {
             unsigned pos = 0, count = 0;
@@ -298,6 +319,7 @@ private:
         if (!build_table(lens, hlit, LIT_BITS, lit_, LIT_CAP, true, litlen_entry)) return false;
         if (!build_table(lens + hlit, hdist, DIST_BITS, dist_, DIST_CAP, true, dist_entry)) return false;
         build_literal_runs();
+        build_pairs();
         return true;
     }
 
@@ -342,31 +364,40 @@ private:
                     bitcnt |= 56;
                 }
             }
-            uint32_t e = lit[bitbuf & ((1u << LIT_BITS) - 1)];
-            if (e & F_SUB) {
-                e = lit[(e >> 16) + ((bitbuf >> LIT_BITS) & ((1u << ((e >> 8) & 15)) - 1))];
-                if (e & F_LITERAL) {
-                    *out++ = (OutT)(uint8_t)(e >> 16);
-                    bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
-                    continue;
+            unsigned len, off;
+            const uint32_t pe = pair_[bitbuf & ((1u << LIT_BITS) - 1)];
+            if (__builtin_expect(pe != 0, 1)) {
+                const unsigned tb = pe & 15, dx = (pe >> 4) & 15;
+                len = (pe >> 8) & 511;
+                off = (pe >> 17) + (unsigned)((bitbuf >> tb) & ((1u << dx) - 1));
+                bitbuf >>= (tb + dx); bitcnt -= (int)(tb + dx);
+            } else {
+                uint32_t e = lit[bitbuf & ((1u << LIT_BITS) - 1)];
+                if (e & F_SUB) {
+                    e = lit[(e >> 16) + ((bitbuf >> LIT_BITS) & ((1u << ((e >> 8) & 15)) - 1))];
+                    if (e & F_LITERAL) {
+                        *out++ = (OutT)(uint8_t)(e >> 16);
+                        bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
+                        continue;
+                    }
                 }
-            }
-            if (e & (F_EOB | F_INVALID)) {
-                if (e & F_INVALID) { result = -1; break; }
+                if (e & (F_EOB | F_INVALID)) {
+                    if (e & F_INVALID) { result = -1; break; }
+                    bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
+                    result = 1;
+                    break;
+                }
+                // length: code (<= 15) + extra (<= 5); then distance: code (<= 15) + extra (<= 13): 48 <= 56 bits
                 bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
-                result = 1;
-                break;
+                len = (e >> 16) + (unsigned)(bitbuf & ((1u << ((e >> 8) & 15)) - 1));
+                bitbuf >>= ((e >> 8) & 15); bitcnt -= (int)((e >> 8) & 15);
+                uint32_t d = dist[bitbuf & ((1u << DIST_BITS) - 1)];
+                if (d & F_SUB) d = dist[(d >> 16) + ((bitbuf >> DIST_BITS) & ((1u << ((d >> 8) & 15)) - 1))];
+                if (d & F_INVALID) { result = -1; break; }
+                bitbuf >>= (d & 0xFF); bitcnt -= (int)(d & 0xFF);
+                off = (d >> 16) + (unsigned)(bitbuf & ((1u << ((d >> 8) & 15)) - 1));
+                bitbuf >>= ((d >> 8) & 15); bitcnt -= (int)((d >> 8) & 15);
             }
-            // length: code (<= 15) + extra (<= 5); then distance: code (<= 15) + extra (<= 13): 48 <= 56 bits
-            bitbuf >>= (e & 0xFF); bitcnt -= (int)(e & 0xFF);
-            unsigned len = (e >> 16) + (unsigned)(bitbuf & ((1u << ((e >> 8) & 15)) - 1));
-            bitbuf >>= ((e >> 8) & 15); bitcnt -= (int)((e >> 8) & 15);
-            uint32_t d = dist[bitbuf & ((1u << DIST_BITS) - 1)];
-            if (d & F_SUB) d = dist[(d >> 16) + ((bitbuf >> DIST_BITS) & ((1u << ((d >> 8) & 15)) - 1))];
-            if (d & F_INVALID) { result = -1; break; }
-            bitbuf >>= (d & 0xFF); bitcnt -= (int)(d & 0xFF);
-            const unsigned off = (d >> 16) + (unsigned)(bitbuf & ((1u << ((d >> 8) & 15)) - 1));
-            bitbuf >>= ((d >> 8) & 15); bitcnt -= (int)((d >> 8) & 15);
             if ((size_t)(out - lowest) < off) { result = -1; break; }
             const OutT *src = out - off;
             OutT *const end = out + len;
@@ -469,6 +500,7 @@ private:
     uint32_t dist_[DIST_CAP];
     uint32_t run_lits_[1u << LIT_BITS];    // up to four literals per index, little-endian
     uint8_t run_info_[1u << LIT_BITS];
+    uint32_t pair_[1u << LIT_BITS];        // length code + extra + distance code inside the 11 index bits: 0 = no such pair here
 };
 
 using Inflater = InflaterT<uint8_t>;
