@@ -1,21 +1,24 @@
-// gzip_parallel.hpp -- one ordinary gzip stream decoded by several threads.
+// gzip_parallel.hpp -- an ordinary gzip file decoded by several threads.
 //
 // A deflate stream has no index and every block may refer to the 32 KB before it, so it is normally decoded by one
-// thread (0.4 GB/s of text with inflate.hpp).  The two-pass scheme used here (known from pugz / rapidgzip) removes
+// thread (0.5 GB/s of text with inflate.hpp).  The two-pass scheme used here (known from pugz / rapidgzip) removes
 // that dependency:
-//   1. the compressed bytes of a member are cut into chunks; for every chunk but the first a thread looks for the first
-//      deflate block header behind the cut -- a position where a non-final dynamic block parses with complete Huffman
-//      codes, decodes to plain text and is followed by more valid data;
+//   1. the compressed FILE is cut into chunks of equal size, whatever gzip members it is made of; for every chunk but the
+//      first a thread looks for the first deflate block header behind the cut -- a position where a non-final dynamic
+//      block parses with complete Huffman codes, decodes to plain text and is followed by more valid data;
 //   2. a chunk is decoded from its header to the next chunk's header WITHOUT its window, into 16-bit symbols: bytes, or
 //      "position p of the unknown window" (32768 + p), which matches copy around like bytes.  It must end exactly on the
-//      header the next chunk found -- a wrongly guessed header makes the decoder run past it, which is an error;
-//   3. windows are resolved in chunk order (32 KB per chunk) and every chunk's symbols are translated to bytes by the
-//      pool; the CRC-32s of the pieces are combined and checked against the member's trailer, like its length.
-// fill_begin() / fill_wait() have the pool translate the symbols STRAIGHT INTO the caller's buffer (hostfeed.hpp cuts its slabs
-// from it; the length of every decoded chunk is known, so every piece has its place before it is translated); read() -- kept for
-// comparison, MDBG_HOST_GZIP_COPY=1 -- hands out text the pool translated into buffers of its own.  Any inconsistency ends the run with an error naming the switch back to one
-// decoding thread; nothing is guessed silently.  Jobs never wait for each other: a chunk is decoded only once its stop
-// position is known, translated only once its window is.
+//      header the next chunk found -- a wrongly guessed header makes the decoder run past it, which is an error.  Where a
+//      member ends inside the chunk the decoder notes the place (its trailer: CRC-32 and length), reads the next member's
+//      header and goes on: a member has no history, so nothing behind the border can refer to anything in front of it;
+//   3. windows are resolved in chunk order (the last 32 KB of the member the chunk ends in) and every chunk's symbols are
+//      translated to bytes by the pool, STRAIGHT INTO the caller's buffer (fill_begin / fill_wait: hostfeed.hpp cuts its slabs
+//      from it; the length of every decoded chunk is known, so every piece has its place before it is translated); the
+//      CRC-32s of the pieces are combined per member and checked against the member's trailer, like its length.
+// Any inconsistency ends the run with an error naming the switch back to one decoding thread; nothing is guessed silently.
+// Jobs never wait for each other: a chunk is decoded only once its stop position is known, translated only once its window is.
+// (Until round 3 the chunks were cut per MEMBER and a member was started when the one before it had been read: a file of
+// 8 MB members -- each smaller than the pool's look-ahead -- ran at a quarter of the rate of the same text in one member.)
 #pragma once
 
 #include <emmintrin.h>
@@ -29,7 +32,6 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
-#include <deque>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -49,18 +51,21 @@ public:
 
     ParallelGzipReader(const uint8_t *addr, size_t len, int threads, std::string path, size_t chunk_bytes)
         : addr_(addr), len_(len), path_(std::move(path)), chunk_(chunk_bytes < 65536 ? 65536 : chunk_bytes), nthreads_(threads < 1 ? 1 : threads) {
-        pooled_ = !getenv("MDBG_HOST_GZIP_NO_POOL");                           // A/B switches for the two round-3 changes
+        pooled_ = !getenv("MDBG_HOST_GZIP_NO_POOL");                           // A/B switches for two round-3 changes
         table_translate_ = !getenv("MDBG_HOST_GZIP_BRANCHY");
-        direct_ = !getenv("MDBG_HOST_GZIP_COPY");                              // A/B: chunks translated into buffers of their own, read() copies
-        start_member(0);
+        const size_t h = gzip_header_size(addr_, len_);
+        if (!h) { fatal_ = "not a gzip file: " + path_; return; }
+        chunks_.resize(len_ / chunk_ + 1);
+        Chunk &c0 = chunks_[0];
+        c0.start_bit = (uint64_t)h * 8;
+        c0.find_taken = c0.start_known = c0.window_known = true;               // starts with the first member; nothing precedes it
         // A stream without dynamic-Huffman block headers to start from (stored blocks: gzip -0, incompressible data) cannot be
-        // cut: ask before the first read() and use one thread then.  Looked for in the second and third chunk.
-        if (gen_) {
+        // cut: ask before the first request and use one thread then.  Looked for in the second and third chunk.
+        {
             InflaterT<uint16_t> probe;
             std::vector<uint16_t> scratch;
-            const uint8_t *data = addr_ + gen_->data;
-            for (size_t k = 1; k < std::min<size_t>(3, gen_->chunks.size()) && !usable_; k++)
-                usable_ = find_block(data, addr_ + len_, (uint64_t)k * chunk_ * 8, (uint64_t)(k + 1) * chunk_ * 8, probe, scratch) != NONE;
+            for (size_t k = 1; k < std::min<size_t>(3, chunks_.size()) && !usable_; k++)
+                usable_ = find_block(addr_, addr_ + len_, (uint64_t)k * chunk_ * 8, (uint64_t)(k + 1) * chunk_ * 8, probe, scratch) != NONE;
         }
         if (usable_) for (int i = 0; i < nthreads_; i++) pool_.emplace_back([this] { work(); });
     }
@@ -77,47 +82,7 @@ public:
                     t_find_.load() * 1e-9, t_decode_.load() * 1e-9, t_translate_.load() * 1e-9);
     }
 
-    // up to `want` bytes of text; 0 at the end of the file; throws on damaged data
-    size_t read(char *dst, size_t want) {
-        size_t got = 0;
-        while (got < want) {
-            std::unique_lock<std::mutex> g(mu_);
-            if (!fatal_.empty()) throw std::runtime_error(fatal_);
-            if (!gen_) break;                                                  // end of file
-            std::shared_ptr<Gen> gen = gen_;
-            if (gen->consumed >= gen->chunks.size()) throw std::runtime_error("gzip stream without an end in " + path_ + hint());
-            Chunk &c = gen->chunks[gen->consumed];
-            cv_.wait(g, [&] { return c.translated; });
-            if (!c.error.empty()) throw std::runtime_error(c.error + hint());
-            g.unlock();
-            const size_t n = std::min(want - got, c.ntext - rpos_);
-            if (n) memcpy(dst + got, c.text.get() + rpos_, n);
-            got += n; rpos_ += n;
-            if (rpos_ == c.ntext) {
-                g.lock();
-                crc_ = (uint32_t)crc32_combine(crc_, c.crc, (z_off_t)c.ntext);
-                total_ += c.ntext;
-                const uint64_t end_pos = c.member_end;
-                give_text(c.text, c.text_cap);
-                rpos_ = 0;
-                gen->consumed++;
-                if (end_pos != NONE) {
-                    const uint8_t *t = addr_ + end_pos;                        // trailer: CRC-32, ISIZE
-                    const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-                    const uint32_t want_len = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-                    if (want_crc != crc_ || want_len != (uint32_t)total_) throw std::runtime_error("gzip CRC / length mismatch in " + path_ + hint());
-                    total_ = 0;
-                    crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
-                    start_member((size_t)end_pos + 8);                         // next member, or the end (trailing bytes ignored)
-                }
-                g.unlock();
-                cv_.notify_all();
-            }
-        }
-        return got;
-    }
-
-    bool direct() const { return direct_; }
+    bool direct() const { return true; }
 
     // Text straight to its place (what BgzfReader::fill_begin does for BGZF): the symbols of the next chunks -- as many as fit into
     // `room` bytes at `dst` -- are translated by the pool INTO `dst`; returns at once with the number of bytes that will be there
@@ -133,12 +98,10 @@ public:
         piecesNext_ = piecesDone_ = 0;
         pending_ = false;
         size_t placed = 0;
-        while (placed < room) {
+        while (placed < room && !ended_) {
             if (!fatal_.empty()) throw std::runtime_error(fatal_);
-            std::shared_ptr<Gen> gen = gen_;
-            if (!gen) break;                                                   // end of file
-            if (gen->consumed >= gen->chunks.size()) throw std::runtime_error("gzip stream without an end in " + path_ + hint());
-            Chunk &c = gen->chunks[gen->consumed];
+            if (consumed_ >= chunks_.size()) throw std::runtime_error("gzip stream without an end in " + path_ + hint());
+            Chunk &c = chunks_[consumed_];
             if (!((c.decoded && c.window_known) || !c.error.empty())) {
                 // the pool may be asleep: the chunks it was allowed to decode ahead were all done, and only this call moved the
                 // window on (and handed it pieces to translate)
@@ -147,24 +110,34 @@ public:
             }
             if (!fatal_.empty()) throw std::runtime_error(fatal_);
             if (!c.error.empty()) throw std::runtime_error(c.error + hint());
-            size_t n = std::min(c.nsym - rpos_, room - placed);
-            const bool ends_chunk = rpos_ + n == c.nsym;
-            for (size_t o = 0; o < n || (o == 0 && n == 0 && ends_chunk && c.member_end != NONE); o += SUB) {
+            // up to the next member border inside the chunk (a piece never straddles one: the CRC-32s are combined per member),
+            // the end of the chunk or the end of the room
+            while (placed < room || (rborder_ < c.borders.size() && c.borders[rborder_].first == rpos_)) {
+                if (rborder_ < c.borders.size() && c.borders[rborder_].first == rpos_) {
+                    Piece pc;                                                  // a member ends here: its trailer is checked behind the pieces so far
+                    pc.chunk = consumed_; pc.from = rpos_; pc.n = 0; pc.dst = dst + placed; pc.member_end = c.borders[rborder_].second;
+                    pieces_.push_back(pc);
+                    pending_ = true;
+                    c.pieces_open++;
+                    rborder_++;
+                    continue;
+                }
+                const size_t upto = rborder_ < c.borders.size() ? c.borders[rborder_].first : c.nsym;
+                if (rpos_ == upto) break;                                      // the chunk is used up
+                const size_t n = std::min({upto - rpos_, room - placed, SUB});
                 Piece pc;
-                pc.gen = gen; pc.chunk = gen->consumed; pc.from = rpos_ + o; pc.n = std::min(SUB, n - o); pc.dst = dst + placed + o;
-                if (ends_chunk && o + SUB >= n) pc.member_end = c.member_end;
-                pieces_.push_back(std::move(pc));
+                pc.chunk = consumed_; pc.from = rpos_; pc.n = n; pc.dst = dst + placed;
+                pieces_.push_back(pc);
                 pending_ = true;                                               // (from here on fill_wait / fill_settle have something to wait for,
                 c.pieces_open++;                                               //  also when this call ends in an exception further down)
-                if (n == 0) break;
+                rpos_ += n; placed += n;
             }
-            rpos_ += n; placed += n;
-            if (!ends_chunk) break;                                            // the room is used up
+            if (rpos_ < c.nsym || rborder_ < c.borders.size()) break;          // the room is used up
             c.handed = true;
             if (c.pieces_open == 0) give_sym(c.sym, c.sym_cap);
-            rpos_ = 0;
-            if (c.member_end != NONE) start_member((size_t)c.member_end + 8);  // next member, or the end (trailing bytes ignored)
-            else gen->consumed++;
+            if (c.file_end) ended_ = true;                                     // what follows the last member is ignored, as gzread does
+            consumed_++;
+            rpos_ = 0; rborder_ = 0;
         }
         return placed;
     }
@@ -196,83 +169,34 @@ public:
     void fill_settle() noexcept { try { fill_wait(); } catch (...) {} }
     bool at_end() {                                                            // nothing is left to ask for
         std::lock_guard<std::mutex> g(mu_);
-        return !gen_ && fatal_.empty();
+        return ended_ && fatal_.empty();
     }
 
 private:
     struct Chunk {
-        uint64_t start_bit = NONE;          // first block header behind the cut, in bits from the member's deflate data; NONE: none here
-        bool find_taken = false, start_known = false, decode_taken = false, decoded = false, window_known = false, translate_taken = false,
-             translated = false;
+        uint64_t start_bit = NONE;          // first block header behind the cut, in bits from the start of the FILE; NONE: none here
+        bool find_taken = false, start_known = false, decode_taken = false, decoded = false, window_known = false;
         std::unique_ptr<uint16_t[]> sym;    // WINDOW place-holders, then the symbols
         size_t nsym = 0, sym_cap = 0;
         std::unique_ptr<uint8_t[]> window;  // the WINDOW bytes in front of this chunk, right-aligned when fewer exist
         size_t window_valid = 0;
-        std::unique_ptr<uint8_t[]> text;
-        size_t ntext = 0, text_cap = 0;
-        uint32_t crc = 0;
-        uint64_t member_end = NONE;         // file offset of the member's trailer if the stream ended in this chunk
+        // members that end inside the chunk: (symbols in front of the border, file offset of the member's trailer), ascending
+        std::vector<std::pair<size_t, uint64_t>> borders;
+        bool file_end = false;              // the last member ended in this chunk: later ones are never delivered
         std::string error;
         uint64_t uid = 0;                   // set when decoded: names the chunk's window in the translating threads' tables
-        size_t pieces_open = 0;             // direct mode: pieces of this chunk handed out and not yet translated
-        bool handed = false;                //              every symbol has been handed out
+        size_t pieces_open = 0;             // pieces of this chunk handed out and not yet translated
+        bool handed = false;                // every symbol has been handed out
     };
-    struct Gen {                            // one gzip member
-        size_t data = 0;                    // file offset of the deflate data
-        std::vector<Chunk> chunks;
-        size_t consumed = 0, chain_next = 0;
-        size_t end_chunk = (size_t)-1;      // chunk in which the final block ended: later ones are never delivered
+    // the request that is out (fill_begin .. fill_wait); mu_ guards all of it
+    struct Piece {
+        size_t chunk = 0, from = 0, n = 0;  // symbols [from, from + n) of the chunk ...
+        char *dst = nullptr;                // ... to this place
+        uint32_t crc = 0;
+        uint64_t member_end = NONE;         // a member's trailer lies behind this (empty) piece
     };
 
     std::string hint() const { return " (MDBG_HOST_GZIP_THREADS=1 decodes the stream on one thread)"; }
-
-    std::shared_ptr<Gen> make_member(size_t pos) const {                       // null: no gzip member starts at pos
-        const size_t h = pos < len_ ? gzip_header_size(addr_ + pos, len_ - pos) : 0;
-        if (!h) return nullptr;
-        auto gen = std::make_shared<Gen>();
-        gen->data = pos + h;
-        gen->chunks.resize((len_ - gen->data) / chunk_ + 1);
-        Chunk &c0 = gen->chunks[0];
-        c0.start_bit = 0;
-        c0.find_taken = c0.start_known = c0.window_known = true;               // starts with the stream; nothing precedes it
-        return gen;
-    }
-    void start_member(size_t pos) {         // mu_ held, or during construction: the reader moves on to the member at pos
-        if (!next_gens_.empty() && next_gens_.front().first == pos) {          // already being decoded (maybe_prestart)
-            gen_ = std::move(next_gens_.front().second);
-            next_gens_.pop_front();
-        } else {
-            next_gens_.clear();
-            gen_ = make_member(pos);
-        }
-        if (!gen_ && pos == 0) fatal_ = "not a gzip file: " + path_;
-        if (gen_) maybe_prestart();
-    }
-    // mu_ held.  Where a member ends is known once it has been decoded to its end; the reader gets there later.  The member behind
-    // it is started as soon as the end is certain -- every chunk in front of the one that met the final block is decoded -- and the
-    // one behind that when ITS end is certain, and so on while the pool's look-ahead has room (work()), so that the pool does not
-    // meet an empty pipeline at every member border: a file of 8 MB members ran at a sixth of the rate of the same text in one.
-    void maybe_prestart() {
-        while (next_gens_.size() < (size_t)nthreads_ + 2) {
-            const Gen &gen = next_gens_.empty() ? *gen_ : *next_gens_.back().second;
-            if (gen.end_chunk == (size_t)-1 || gen.chain_next <= gen.end_chunk) return;      // its end is not certain yet
-            const Chunk &last = gen.chunks[gen.end_chunk];
-            if (!last.error.empty() || last.member_end == NONE) return;
-            const size_t pos = (size_t)last.member_end + 8;
-            std::shared_ptr<Gen> next = make_member(pos);
-            if (!next) return;                                                 // the end of the file (or bytes that are no member)
-            next_gens_.emplace_back(pos, std::move(next));
-        }
-    }
-    // mu_ held: chunks of `gen` the pool has taken up and the reader has not been given yet
-    static size_t in_flight(const Gen &gen) {
-        size_t n = 0;
-        for (size_t i = gen.consumed; i < gen.chunks.size() && i <= gen.end_chunk; i++) {
-            if (!gen.chunks[i].decode_taken) { if (!gen.chunks[i].find_taken) break; continue; }
-            n++;
-        }
-        return n;
-    }
 
     // ---- finding a block header ------------------------------------------------------------------------------------
     static bool plausible_text(const uint16_t *s, size_t n) {
@@ -322,36 +246,31 @@ private:
     }
 
     // ---- the pool ------------------------------------------------------------------------------------------------------
-    enum Job { NOTHING, FIND, DECODE, TRANSLATE, PIECE };
+    enum Job { NOTHING, FIND, DECODE, PIECE };
 
     // stop position of chunk k: the header found by the next chunk that has one.  false = not decided yet
-    static bool stop_of(const Gen &gen, size_t k, uint64_t *stop) {
+    bool stop_of(size_t k, uint64_t *stop) const {
         size_t j = k + 1;
-        while (j < gen.chunks.size() && gen.chunks[j].start_known && gen.chunks[j].start_bit == NONE) j++;
-        if (j == gen.chunks.size()) { *stop = NONE; return true; }             // runs to the end of the stream
-        if (!gen.chunks[j].start_known) return false;
-        *stop = gen.chunks[j].start_bit;
+        while (j < chunks_.size() && chunks_[j].start_known && chunks_[j].start_bit == NONE) j++;
+        if (j == chunks_.size()) { *stop = NONE; return true; }                // runs to the end of the file
+        if (!chunks_[j].start_known) return false;
+        *stop = chunks_[j].start_bit;
         return true;
     }
 
-    Job next_job(Gen &gen, size_t *k, uint64_t *stop, size_t ahead) {          // mu_ held
-        const size_t hi = std::min(gen.chunks.size(), gen.consumed + ahead);
-        // translation first: it feeds the reader and frees the symbols (direct mode: the reader's own requests, work())
-        for (size_t i = gen.consumed; i < hi && !direct_; i++) {
-            Chunk &c = gen.chunks[i];
-            if (i > gen.end_chunk) break;
-            if (c.decoded && c.window_known && !c.translate_taken) { c.translate_taken = true; *k = i; return TRANSLATE; }
-        }
-        for (size_t i = gen.consumed; i < hi; i++) {
-            Chunk &c = gen.chunks[i];
-            if (i > gen.end_chunk) break;
-            if (c.start_known && c.start_bit != NONE && !c.decode_taken && stop_of(gen, i, stop)) { c.decode_taken = true; *k = i; return DECODE; }
+    Job next_job(size_t *k, uint64_t *stop) {                                  // mu_ held
+        const size_t ahead = (size_t)nthreads_ + 2;
+        const size_t hi = std::min(chunks_.size(), consumed_ + ahead);
+        for (size_t i = consumed_; i < hi; i++) {
+            Chunk &c = chunks_[i];
+            if (i > end_chunk_) break;
+            if (c.start_known && c.start_bit != NONE && !c.decode_taken && stop_of(i, stop)) { c.decode_taken = true; *k = i; return DECODE; }
         }
         // headers are looked for one chunk further than chunks are decoded -- and as far beyond that as it takes to find the
         // stop position of the last chunk in the window (a deflate block may be longer than a chunk)
-        for (size_t i = gen.consumed; i < gen.chunks.size(); i++) {
-            Chunk &c = gen.chunks[i];
-            if (i > gen.end_chunk) break;
+        for (size_t i = consumed_; i < chunks_.size(); i++) {
+            Chunk &c = chunks_[i];
+            if (i > end_chunk_) break;
             if (!c.find_taken) { c.find_taken = true; *k = i; return FIND; }
             if (i >= hi && (!c.start_known || c.start_bit != NONE)) break;      // being looked for, or found: nothing further is needed yet
         }
@@ -361,16 +280,14 @@ private:
     void work() {
         InflaterT<uint16_t> inf, probe;
         std::vector<uint16_t> scratch;
-        std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]());                  // symbol -> byte (translate_chunk); entries 256 .. 0x7fff are never produced
+        std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]());                  // symbol -> byte (translate_symbols); entries 256 .. 0x7fff are never produced
         for (unsigned v = 0; v < 256; v++) lut[v] = (uint8_t)v;
         uint64_t lut_of = 0;                                                   // the chunk (uid) whose window the table's upper half holds
         for (;;) {
-            std::shared_ptr<Gen> gen;
             size_t k = 0, piece_index = 0;
             uint64_t stop = NONE;
             Job job = NOTHING;
             Piece piece;
-            const auto t_start = std::chrono::steady_clock::now();
             {
                 std::unique_lock<std::mutex> g(mu_);
                 for (;;) {
@@ -379,30 +296,17 @@ private:
                         piece = pieces_[piecesNext_];
                         piece_index = piecesNext_++;
                         piecesBusy_++;
-                        gen = piece.gen;
                         k = piece.chunk;
                         job = PIECE;
                         break;
                     }
-                    // the member being read first, then the ones started behind it: together they may hold nthreads + 2 chunks
-                    // that are decoded (or being decoded) and not yet with the reader
-                    gen = gen_;
-                    if (gen && fatal_.empty()) {
-                        size_t room = (size_t)nthreads_ + 2;
-                        job = next_job(*gen, &k, &stop, room);
-                        for (size_t m = 0; job == NOTHING && m < next_gens_.size(); m++) {
-                            const size_t used = in_flight(*gen);
-                            if (used >= room) break;
-                            room -= used;
-                            gen = next_gens_[m].second;
-                            job = next_job(*gen, &k, &stop, room);
-                        }
-                    }
+                    if (fatal_.empty()) job = next_job(&k, &stop);
                     if (job != NOTHING) break;
                     cv_.wait(g);
                 }
             }
-            Chunk &c = gen->chunks[k];
+            Chunk &c = chunks_[k];
+            const auto t0 = std::chrono::steady_clock::now();
             if (job == PIECE) {
                 std::string err;
                 uint32_t crc = 0;
@@ -423,106 +327,118 @@ private:
                     if (--c.pieces_open == 0 && c.handed) give_sym(c.sym, c.sym_cap);
                     last = pieceError_.empty() ? piecesDone_ == pieces_.size() : piecesBusy_ == 0;
                 }
-                t_translate_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count();
+                t_translate_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 if (last) cvDone_.notify_all();
                 continue;
             }
-            const auto t0 = std::chrono::steady_clock::now();
             try {
                 if (job == FIND) {
-                    const uint8_t *data = addr_ + gen->data;
-                    const uint64_t b = find_block(data, addr_ + len_, (uint64_t)k * chunk_ * 8, (uint64_t)(k + 1) * chunk_ * 8, probe, scratch);
+                    const uint64_t b = find_block(addr_, addr_ + len_, (uint64_t)k * chunk_ * 8, (uint64_t)(k + 1) * chunk_ * 8, probe, scratch);
                     std::lock_guard<std::mutex> g(mu_);
                     c.start_bit = b;
                     c.start_known = true;
-                    if (b == NONE) { c.decode_taken = true; finish_decode(*gen, k, 0); }   // nothing starts here: the previous chunk runs through
-                } else if (job == DECODE) {
-                    decode_chunk(*gen, k, stop, inf);
+                    if (b == NONE) { c.decode_taken = true; finish_decode(k, 0); }   // nothing starts here: the previous chunk runs through
                 } else {
-                    translate_chunk(*gen, k, lut.get());
+                    decode_chunk(k, stop, inf);
                 }
             } catch (const std::exception &e) {
-                // the reader meets the error when it gets to this chunk (chunks behind the end of the member never are)
+                // the reader meets the error when it gets to this chunk (chunks behind the end of the file never are)
                 std::lock_guard<std::mutex> g(mu_);
                 c.error = e.what();
-                c.decoded = c.translated = true;
+                c.decoded = true;
             }
             const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            (job == FIND ? t_find_ : job == DECODE ? t_decode_ : t_translate_) += ns;
+            (job == FIND ? t_find_ : t_decode_) += ns;
             cv_.notify_all();
         }
     }
 
-    void decode_chunk(Gen &gen, size_t k, uint64_t stop, InflaterT<uint16_t> &inf) {
-        const uint8_t *data = addr_ + gen.data, *end = addr_ + len_;
-        Chunk &c = gen.chunks[k];
-        inf.reset_at_bit(data, c.start_bit, end);
+    // From the chunk's header to `stop` (the next chunk's), across the borders of the members that end on the way.
+    void decode_chunk(size_t k, uint64_t stop, InflaterT<uint16_t> &inf) {
+        const uint8_t *end = addr_ + len_;
+        Chunk &c = chunks_[k];
+        inf.reset_at_bit(addr_, c.start_bit, end);
         if (stop != NONE) inf.set_stop_bit(stop);
         size_t cap = WINDOW + chunk_ * 5 + 65536;                              // symbols: [WINDOW place-holders][output]; grows as needed
         std::unique_ptr<uint16_t[]> sym = take_sym(&cap);
-        if (k > 0) for (size_t i = 0; i < WINDOW; i++) sym[i] = (uint16_t)(0x8000u + i);
+        for (size_t i = 0; i < WINDOW; i++) sym[i] = (uint16_t)(0x8000u + i);
         size_t n = 0;
-        uint64_t member_end = NONE;
+        size_t member_from = 0;             // symbols in front of the member being decoded (0: it began before this chunk)
+        bool own_history = k == 0;          // the member being decoded began inside this chunk (or with the file): nothing in front of it exists
+        std::vector<std::pair<size_t, uint64_t>> borders;
+        bool file_end = false;
         for (;;) {
             if (cap - (WINDOW + n) < 4096) {
                 // a chunk that never reaches the next header (a long stretch of stored or fixed-code blocks) would grow without
                 // bound: 64 chunks' worth of text is where this gives up
                 if (n > chunk_ * 64 * 4) throw std::runtime_error("no block header to cut at for " + std::to_string(n) + " bytes of text in " + path_);
-                const size_t ncap = cap + cap / 2;
+                size_t ncap = cap + cap / 2;
                 std::unique_ptr<uint16_t[]> bigger(new uint16_t[ncap]);
                 memcpy(bigger.get(), sym.get(), (WINDOW + n) * sizeof(uint16_t));
                 sym = std::move(bigger);
                 cap = ncap;
             }
             size_t produced = 0;
-            const auto st = inf.run(sym.get() + WINDOW + n, sym.get() + cap, k > 0 ? WINDOW + n : n, &produced);
+            // what lies in front of the output and may be referred to: the member's own text in this chunk, and -- for a member
+            // that began before the chunk -- the place-holders of the unknown window
+            const size_t hist = own_history ? n - member_from : WINDOW + n;
+            const auto st = inf.run(sym.get() + WINDOW + n, sym.get() + cap, hist, &produced);
             n += produced;
             if (st == InflaterT<uint16_t>::CORRUPT) throw std::runtime_error("corrupt gzip data or a misjudged block boundary in " + path_);
             if (st == InflaterT<uint16_t>::AT_STOP) break;
             if (st == InflaterT<uint16_t>::STREAM_END) {
                 const uint8_t *t = inf.in_pos();
                 if ((size_t)(end - t) < 8) throw std::runtime_error("truncated gzip file: " + path_);
-                member_end = (uint64_t)(t - addr_);
-                break;
+                borders.emplace_back(n, (uint64_t)(t - addr_));
+                const size_t next = (size_t)(t - addr_) + 8;
+                const size_t h = next < len_ ? gzip_header_size(addr_ + next, len_ - next) : 0;
+                if (!h) { file_end = true; break; }                            // the end of the file (trailing bytes are ignored, as gzread does)
+                if (stop != NONE && (uint64_t)(next + h) * 8 > stop) throw std::runtime_error("a misjudged block boundary in " + path_);
+                inf.reset_at_bit(addr_, (uint64_t)(next + h) * 8, end);
+                if (stop != NONE) inf.set_stop_bit(stop);
+                member_from = n;
+                own_history = true;
             }
         }
         std::lock_guard<std::mutex> g(mu_);
         c.sym = std::move(sym);
         c.sym_cap = cap;
-        if (member_end != NONE) { c.member_end = member_end; if (k < gen.end_chunk) gen.end_chunk = k; }
-        finish_decode(gen, k, n);
+        c.borders = std::move(borders);
+        if (file_end) { c.file_end = true; if (k < end_chunk_) end_chunk_ = k; }
+        finish_decode(k, n);
     }
 
     // mu_ held.  Marks chunk k decoded and resolves windows in chunk order: the window of chunk i + 1 is the last WINDOW bytes
-    // of the text up to the end of chunk i.  (Under the same lock as `decoded`, so that no translation frees symbols the
-    // chain still needs.)
-    void finish_decode(Gen &gen, size_t k, size_t nsym) {
-        gen.chunks[k].uid = ++uid_counter_;
-        gen.chunks[k].nsym = nsym;
-        gen.chunks[k].decoded = true;
-        while (gen.chain_next < gen.chunks.size()) {
-            Chunk &c = gen.chunks[gen.chain_next];
+    // of the member that chunk i ends in -- of its text in chunk i and, when the member began before chunk i, of chunk i's own
+    // window.  (Under the same lock as `decoded`, so that no translation frees symbols the chain still needs.)
+    void finish_decode(size_t k, size_t nsym) {
+        chunks_[k].uid = ++uid_counter_;
+        chunks_[k].nsym = nsym;
+        chunks_[k].decoded = true;
+        while (chain_next_ < chunks_.size()) {
+            Chunk &c = chunks_[chain_next_];
             if (!c.decoded || !c.window_known) break;
-            const size_t i = gen.chain_next++;
-            if (!c.error.empty() || i + 1 >= gen.chunks.size() || i >= gen.end_chunk) continue;
-            Chunk &nx = gen.chunks[i + 1];
+            const size_t i = chain_next_++;
+            if (!c.error.empty() || i + 1 >= chunks_.size() || i >= end_chunk_) continue;
+            Chunk &nx = chunks_[i + 1];
             nx.window.reset(new uint8_t[WINDOW]);
-            const size_t from_text = std::min(c.nsym, WINDOW), from_win = WINDOW - from_text;
+            const size_t member_from = c.borders.empty() ? 0 : c.borders.back().first;       // the member chunk i ends in began here (0: before the chunk)
+            const bool carries = c.borders.empty();                                           // ... and so chunk i's own window is part of its history
+            const size_t from_text = std::min(c.nsym - member_from, WINDOW), from_win = WINDOW - from_text;
             if (from_win) {
-                if (c.window) memcpy(nx.window.get(), c.window.get() + from_text, from_win);
+                if (carries && c.window) memcpy(nx.window.get(), c.window.get() + from_text, from_win);
                 else memset(nx.window.get(), 0, from_win);
             }
-            nx.window_valid = std::min(WINDOW, from_text + std::min(c.window_valid, from_win));
+            nx.window_valid = std::min(WINDOW, from_text + (carries ? std::min(c.window_valid, from_win) : 0));
             for (size_t j = 0; j < from_text; j++) {
                 const uint16_t v = c.sym[WINDOW + c.nsym - from_text + j];
                 if (v < 256) { nx.window[from_win + j] = (uint8_t)v; continue; }
                 const size_t p = v - 0x8000u;
-                if (!c.window || p < WINDOW - c.window_valid) { nx.error = "gzip data refers to text before the start of the stream in " + path_; break; }
+                if (!carries || !c.window || p < WINDOW - c.window_valid) { nx.error = "gzip data refers to text before the start of the stream in " + path_; break; }
                 nx.window[from_win + j] = c.window[p];
             }
             nx.window_known = true;
         }
-        if (gen_) maybe_prestart();
     }
 
     // n symbols -> bytes at t.  win: the WINDOW bytes in front of the chunk (may be null), valid from min_p on.  lut: the thread's
@@ -555,26 +471,10 @@ private:
         }
     }
 
-    void translate_chunk(Gen &gen, size_t k, uint8_t *lut) {
-        Chunk &c = gen.chunks[k];
-        if (!c.error.empty()) { std::lock_guard<std::mutex> g(mu_); c.translated = true; return; }
-        size_t text_cap = c.nsym ? c.nsym : 1;
-        std::unique_ptr<uint8_t[]> text = take_text(&text_cap);
-        if (c.nsym) translate_symbols(c.sym.get() + WINDOW, c.nsym, c.window.get(), WINDOW - c.window_valid, text.get(), lut, true);
-        const uint32_t crc = crc32_fast(0, text.get(), c.nsym);
-        std::lock_guard<std::mutex> g(mu_);
-        c.text = std::move(text);
-        c.text_cap = text_cap;
-        c.ntext = c.nsym;
-        c.crc = crc;
-        give_sym(c.sym, c.sym_cap);
-        c.translated = true;
-    }
-
     // ---- buffers go round ------------------------------------------------------------------------------------------------
-    // A chunk's symbols are 40 MB of address space and its text 12 MB: fresh from the allocator every time, they are mapped, faulted
-    // in page by page and unmapped again by two dozen threads of one process at once -- which the kernel serialises (the parallel
-    // decoder was no faster than one thread for it).  mu_ held in give_*; pool_mu_ guards the lists.
+    // A chunk's symbols are 40 MB of address space: fresh from the allocator every time, they are mapped, faulted in page by page
+    // and unmapped again by two dozen threads of one process at once -- which the kernel serialises (the parallel decoder was
+    // no faster than one thread for it).  mu_ held in give_sym; pool_mu_ guards the list.
     std::unique_ptr<uint16_t[]> take_sym(size_t *cap) {
         {
             std::lock_guard<std::mutex> g(pool_mu_);
@@ -594,26 +494,6 @@ private:
         if (pooled_ && idle_sym_.size() < (size_t)nthreads_ + 4) idle_sym_.emplace_back(std::move(p), cap);
         p.reset();
     }
-    std::unique_ptr<uint8_t[]> take_text(size_t *cap) {
-        {
-            std::lock_guard<std::mutex> g(pool_mu_);
-            for (size_t i = 0; i < idle_text_.size(); i++)
-                if (idle_text_[i].second >= *cap) {
-                    auto p = std::move(idle_text_[i].first);
-                    *cap = idle_text_[i].second;
-                    idle_text_.erase(idle_text_.begin() + (long)i);
-                    return p;
-                }
-        }
-        if (pooled_) *cap = std::max(*cap, chunk_ * 4);                        // (a chunk of reads inflates about three-fold: one size fits most)
-        return std::unique_ptr<uint8_t[]>(new uint8_t[*cap]);
-    }
-    void give_text(std::unique_ptr<uint8_t[]> &p, size_t cap) {
-        if (!p) return;
-        std::lock_guard<std::mutex> g(pool_mu_);
-        if (pooled_ && idle_text_.size() < (size_t)nthreads_ + 4) idle_text_.emplace_back(std::move(p), cap);
-        p.reset();
-    }
 
     static constexpr size_t PROBE_ROOM = 1u << 18;
 
@@ -622,27 +502,21 @@ private:
     std::string path_;
     size_t chunk_;
     int nthreads_;
-    std::shared_ptr<Gen> gen_;              // the member being read
-    std::deque<std::pair<size_t, std::shared_ptr<Gen>>> next_gens_;   // (file offset, member): the members behind it that are decoding already
-    size_t rpos_ = 0;
-    uint32_t crc_ = 0;
+    std::vector<Chunk> chunks_;             // the file, cut every chunk_ bytes
+    size_t consumed_ = 0;                   // first chunk not handed out entirely
+    size_t chain_next_ = 0;                 // first chunk whose successor's window is not resolved yet
+    size_t end_chunk_ = (size_t)-1;         // chunk in which the last member ended
+    bool ended_ = false;                    // ... and it has been handed out
+    size_t rpos_ = 0, rborder_ = 0;         // the reader inside chunk consumed_: symbols and borders handed out
+    uint32_t crc_ = 0;                      // of the member being read, so far (fill_wait; the caller's thread only)
     uint64_t total_ = 0;
     std::mutex mu_;
     std::condition_variable cv_;
     std::mutex pool_mu_;
     std::vector<std::pair<std::unique_ptr<uint16_t[]>, size_t>> idle_sym_;
-    std::vector<std::pair<std::unique_ptr<uint8_t[]>, size_t>> idle_text_;
     std::vector<std::thread> pool_;
     std::atomic<long long> t_find_{0}, t_decode_{0}, t_translate_{0};
-    bool stop_ = false, usable_ = false, pooled_ = true, table_translate_ = true, direct_ = true;
-    // direct mode: the request that is out (fill_begin .. fill_wait); mu_ guards all of it
-    struct Piece {
-        std::shared_ptr<Gen> gen;
-        size_t chunk = 0, from = 0, n = 0;  // symbols [from, from + n) of the chunk ...
-        char *dst = nullptr;                // ... to this place
-        uint32_t crc = 0;
-        uint64_t member_end = NONE;         // the member's trailer lies behind this piece's last byte
-    };
+    bool stop_ = false, usable_ = false, pooled_ = true, table_translate_ = true;
     std::vector<Piece> pieces_;
     size_t piecesNext_ = 0, piecesDone_ = 0, piecesBusy_ = 0;
     bool pending_ = false;                  // (the caller's thread only)

@@ -852,7 +852,7 @@ private:
             bgzf.reset();
             return read_gz_sequential(path, file, seq);
         }
-        if (gzpar && gzpar->direct()) {
+        if (gzpar) {
             bool multiline = false;
             seq = stitch_direct(*gzpar, path, file, seq, &multiline);
             if (!multiline) return seq;
@@ -896,7 +896,6 @@ private:
                 long n;
                 if (bgzf) n = (long)bgzf->read(buf + len, cap - len);
                 else if (gzmem) n = (long)gzmem->read(buf + len, cap - len);
-                else if (gzpar) n = (long)gzpar->read(buf + len, cap - len);
                 else n = gzread(fp, buf + len, (unsigned)std::min<size_t>(cap - len, (size_t)1 << 30));
                 if (n < 0) throw std::runtime_error("gzip read error: " + path);
                 if (n == 0) {
@@ -921,7 +920,6 @@ private:
                     closer.f = nullptr;
                     bgzf.reset();
                     gzmem.reset();
-                    gzpar.reset();
                     return read_gz_sequential(path, file, seq);
                 }
                 first = false;

@@ -328,28 +328,32 @@ def test_damaged_gzip_on_several_threads(exe, big_gz, tmp_path):
         assert r.returncode == 3, (t, r.returncode, r.stdout, r.stderr)
 
 
-@pytest.mark.parametrize("gzchunk", [65536, 700000])
-def test_one_gzip_stream_copy_mode(exe, big_gz, gzchunk):
-    """MDBG_HOST_GZIP_COPY=1: the round-2 path (chunks translated into buffers of their own, one thread copies them into the slabs) is
-    still there for comparison and must still give the same reads."""
-    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK=str(gzchunk), MDBG_HOST_GZIP_COPY="1")
-    for key, path in big_gz.items():
-        r = subprocess.run([exe, "300000", "3", "0", path], capture_output=True, text=True, timeout=300, env=env)
-        assert r.returncode == 0, (key, r.stderr)
+@pytest.mark.parametrize("gzchunk", [65536, 200000, 1000000])
+def test_many_gzip_members_on_several_threads(exe, tmp_path, gzchunk):
+    """The chunks are cut over the FILE, whatever members it is made of: thousands of tiny members, members of a few MB, stored
+    (gzip -0) members in between, garbage behind the last one -- the same reads as the sequential reader, at every chunk size."""
+    rng = np.random.default_rng(18)
+    fa = b"".join(b">m%d\n" % i + _rand_seq(rng, int(rng.integers(1, 30000))) + b"\n" for i in range(1200))
 
-
-def test_damaged_gzip_on_several_threads_copy_mode(exe, big_gz, tmp_path):
-    raw = open(big_gz["l6"], "rb").read()
-    rng = np.random.default_rng(9)
-    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="4", MDBG_HOST_GZIP_CHUNK="150000", MDBG_TEST_DRAIN_ONLY="1", MDBG_HOST_GZIP_COPY="1")
-    for t in range(6):
-        bad = bytearray(raw)
-        for _ in range(int(rng.integers(1, 4))):
-            bad[int(rng.integers(100, len(bad)))] ^= 1 << int(rng.integers(0, 8))
-        p = str(tmp_path / "bad.fastq.gz")
-        open(p, "wb").write(bytes(bad))
-        r = subprocess.run([exe, "300000", "3", "0", p], capture_output=True, text=True, timeout=120, env=env)
-        assert r.returncode == 3, (t, r.returncode, r.stdout, r.stderr)
+    def members(sizes, levels, tail=b""):
+        parts, o = [], 0
+        while o < len(fa):
+            e = fa.find(b"\n>", o + int(rng.choice(sizes)))
+            e = len(fa) if e < 0 else e + 1
+            parts.append(gzip.compress(fa[o:e], int(rng.choice(levels))))
+            o = e
+        return b"".join(parts) + tail
+    files = []
+    for name, data in (("tiny", members([100, 3000, 60000], (1, 6))), ("mid", members([200000, 3000000], (1, 6), b"\0\0garbage")),
+                       ("stored", members([100, 5000, 2000000], (0, 1, 6)))):
+        p = str(tmp_path / f"{name}.fasta.gz")
+        open(p, "wb").write(data)
+        files.append(p)
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="6", MDBG_HOST_GZIP_CHUNK=str(gzchunk))
+    for chunk in ("200000", str(1 << 22)):
+        r = subprocess.run([exe, chunk, "4", "0", *files], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.startswith("ok 3600 reads")
 
 
 def test_damaged_and_truncated_inputs_under_load(exe, big_gz, tmp_path):

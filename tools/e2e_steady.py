@@ -257,8 +257,7 @@ def main():
                 res["gzip"] = best_of([gz], n, "gzip", reps=2)
                 for mode in [m for m in a.gzip_modes.split(",") if m]:
                     env = {"nopool": {"MDBG_HOST_GZIP_NO_POOL": "1"}, "branchy": {"MDBG_HOST_GZIP_BRANCHY": "1"},
-                           "round2": {"MDBG_HOST_GZIP_NO_POOL": "1", "MDBG_HOST_GZIP_BRANCHY": "1", "MDBG_HOST_GZIP_COPY": "1"},
-                           "copy": {"MDBG_HOST_GZIP_COPY": "1"}}.get(mode) or {"MDBG_HOST_GZIP_THREADS": mode[1:]}
+                           "round2": {"MDBG_HOST_GZIP_NO_POOL": "1", "MDBG_HOST_GZIP_BRANCHY": "1"}}.get(mode) or {"MDBG_HOST_GZIP_THREADS": mode[1:]}
                     res[f"gzip_{mode}"] = best_of([gz], n, "gzip " + mode, reps=1, extra_env=env)
                 os.unlink(gz)
             if not a.no_bgzf:
