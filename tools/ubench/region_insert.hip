@@ -9,7 +9,7 @@
 //            R = the whole table down to 16 MB -- the knee, if there is one, says what region size pays;
 //   group    the cost of writing n_ops 24-byte records (128-bit identity + instance index) to P output streams chosen by the slot's
 //            region (per-wave aggregated cursors), and of reading them back: what the grouping adds.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/region_insert.hip -o /tmp/region_insert && /tmp/region_insert
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/region_insert.hip -o /tmp/region_insert && /tmp/region_insert [keys] [operations] [log2 slots]
 //   (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes gives the traffic of each launch)
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -80,9 +80,13 @@ __global__ __launch_bounds__(256) void read_back(const Rec *in, uint64_t n, uint
 }
 
 int main(int argc, char **argv) {
-    const uint64_t table_slots = 1ull << 25;                 // 1 GB of 32-byte slots: the first pass of 10 M x 10 kb reads
-    const uint64_t n_keys = argc > 1 ? strtoull(argv[1], nullptr, 10) : 7000000ull;
+    // defaults = the first pass of the bench batch (10 M x 10 kb reads): 134 M slots of 32 bytes = 4.3 GB, 38.8 M distinct
+    // keys, 344 M instances.  (The one run there has been so far -- profiles/round3_final_region_insert_ubench.txt -- was on 2^25 slots
+    // and 7 M keys: region_insert 7000000 344000000 25.)
+    const uint64_t n_keys = argc > 1 ? strtoull(argv[1], nullptr, 10) : 38800000ull;
     const uint64_t n_ops = argc > 2 ? strtoull(argv[2], nullptr, 10) : 344000000ull;
+    const uint32_t log_slots = argc > 3 ? (uint32_t)atoi(argv[3]) : 27;
+    const uint64_t table_slots = 1ull << log_slots;
     Slot *t = nullptr;
     uint32_t *sink = nullptr;
     CK(hipMalloc(&t, table_slots * sizeof(Slot)));
@@ -93,7 +97,7 @@ int main(int argc, char **argv) {
     CK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0));
     const unsigned grid = (unsigned)n_cu * 8;
     printf("table %.0f MB, %llu keys, %llu operations, grid %u x 256\n", table_slots * 32 / 1048576.0, (unsigned long long)n_keys, (unsigned long long)n_ops, grid);
-    for (uint64_t region_bytes : {1ull << 30, 1ull << 29, 1ull << 28, 1ull << 27, 1ull << 26, 1ull << 25, 1ull << 24}) {
+    for (uint64_t region_bytes = table_slots * 32; region_bytes >= (1ull << 24); region_bytes >>= 1) {
         const uint64_t region_slots = region_bytes / 32, n_regions = table_slots / region_slots;
         const uint64_t keys_per = n_keys / n_regions, ops_per = n_ops / n_regions;
         CK(hipMemset(t, 0, table_slots * sizeof(Slot)));
@@ -116,7 +120,7 @@ int main(int argc, char **argv) {
     }
     // the grouping: 8 regions of 128 MB
     {
-        const uint32_t P = 8, region_shift = 25 - 3;
+        const uint32_t P = 8, region_shift = log_slots - 3;
         const uint64_t stream_cap = n_ops / P + n_ops / (P * 4);
         Rec *out = nullptr;
         unsigned long long *cursor = nullptr;
