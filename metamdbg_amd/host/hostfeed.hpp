@@ -1000,16 +1000,8 @@ private:
             if (fileDone_[file].load()) break;            // (the per-file read cap was reached)
             const size_t total = (size_t)(end - begin);
             const bool lastSlab = bgzf.at_end();
-            std::shared_ptr<char> nxt;
-            size_t nxtGot = 0;
-            if (!lastSlab) {
-                nxt = take_slab();
-                if (!nxt) return seq;
-                const size_t over = total > chunk_ ? total - chunk_ : 0;        // about what the cut below will leave over
-                size_t want = chunk_ + look > over ? chunk_ + look - over : 0;
-                want = std::max<size_t>(want, (size_t)128 << 10);
-                nxtGot = bgzf.fill_begin(nxt.get() + head, std::min(want, cap - head));
-            }
+            // the cut first: the parsers get the slab before the next one is asked for (a request may have to wait for chunks that
+            // are not decoded yet)
             const char *q = end;
             if (!lastSlab || total > chunk_) {
                 if (total > chunk_) q = last_record_before(begin, begin + chunk_, end, fastq);
@@ -1021,13 +1013,18 @@ private:
             else give_back();
             held = false;
             if (lastSlab && !left) break;
-            bgzf.fill_wait();
-            if (lastSlab) {                               // the end of the file behind a cut: the rest moves to the front of its own slab
-                nxt = take_slab();
-                if (!nxt) return seq;
+            // the next slab: its text `head` bytes in, so much of it that with the left-over in front it reaches `look` past the chunk
+            std::shared_ptr<char> nxt = take_slab();
+            if (!nxt) return seq;
+            size_t nxtGot = 0;
+            if (!lastSlab) {
+                size_t want = chunk_ + look > left ? chunk_ + look - left : 0;
+                want = std::max<size_t>(want, (size_t)128 << 10);
+                nxtGot = bgzf.fill_begin(nxt.get() + head, std::min(want, cap - head));
             }
+            if (left <= head) memcpy(nxt.get() + head - left, q, left);         // beside the pool, which writes behind `head`
+            bgzf.fill_wait();
             if (left <= head) {
-                memcpy(nxt.get() + head - left, q, left);
                 begin = nxt.get() + head - left;
                 end = nxt.get() + head + nxtGot;
             } else {
