@@ -385,3 +385,22 @@ def test_damaged_and_truncated_inputs_under_load(exe, big_gz, tmp_path):
     with cf.ThreadPoolExecutor(16) as ex:
         res = list(ex.map(one, cases * 6))
     assert all(rc == 3 for _, rc in res), [(os.path.basename(p), rc) for p, rc in res if rc != 3]
+
+
+def test_reads_nearly_as_long_as_a_batch(exe, tmp_path):
+    """Reads of 0.5 to 1.5 Mbp and of 5 to 5.9 Mbp in turn, batches of 6 MB: a cut behind a short read in front of a long one leaves over
+    more (the long read's start and 4 MB of look-ahead: 9 MB) than the 8 MB kept in front of the next slab's text, and the slab is rebuilt
+    at its own size -- BGZF and gzip on several threads, the paths that fill slabs in place."""
+    rng = np.random.default_rng(31)
+    pool = _rand_seq(rng, 6_000_000)
+    fa = b"".join(b">long%d\n" % i + pool[int(rng.integers(0, 100_000)):][: int(rng.integers(5_000_000, 5_900_000) if i % 2 else rng.integers(500_000, 1_500_000))] + b"\n"
+                  for i in range(10))
+    files = []
+    for name, data in (("long.bgzf.fasta.gz", _bgzf(fa, level=1)), ("long.fasta.gz", gzip.compress(fa, 1))):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        files.append(p)
+    env = dict(os.environ, MDBG_HOST_GZIP_THREADS="6", MDBG_HOST_GZIP_CHUNK="1000000")
+    for f in files:
+        r = subprocess.run([exe, "6000000", "4", "0", f], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and r.stdout.startswith("ok 10 reads"), (f, r.stdout, r.stderr)
