@@ -659,7 +659,7 @@ def ont_leg(ctx, n_reads: int, sample: int, piece_reads: int = 3_400_000) -> dic
     r = one_pass()
     ctx.timing(False)
     r["kernel_ms"] = {k: ctx.timing_get(k)[0] for k in ("scan", "quality_sum", "scan_compact", "complexity_exact", "minimizer_census",
-                                                      "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit",
+                                                      "purge_palindromes", "kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit",
                                                       "table_clear", "prefix_scan") if ctx.timing_get(k)[1]}
     r["workload"] = (f"{n_reads} synthetic ONT R10 reads x 20 kb with qualities ({r['bases'] / 1e9:.0f} Gbp; 1 % sub + 0.5 % ins + 0.5 % del), "
                      f"resident in HBM {len(pieces)} x {pieces[0][1]} reads at a time (2-bit bases + 1 byte per quality), no HPC, l=15, density 0.005, "
@@ -753,45 +753,83 @@ def run_alone(ctx) -> None:
     ctx.set_option("table_cu_count", 0)
 
 
-def kminmer_roofline(ctx, reads) -> dict:
+def kminmer_traffic(reads: int, read_len: int):
+    """(HBM bytes per first pass, note) from the committed rocprofv3 PMC passes (profiles/*_kminmer_traffic.json): valid only for the workload and
+    the kernel sources they were collected on (git blob hashes of csrc/partition.hip and csrc/kminmer.hip), like measured_traffic."""
+    import glob
+    here = {f: git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", f)) for f in ("partition.hip", "kminmer.hip")}
+    best, stale = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kminmer_traffic.json")), key=os.path.getmtime):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("reads") == reads and d.get("read_len") == read_len:
+            if d.get("blobs") == here:
+                best = (d, os.path.basename(path))
+            else:
+                stale = os.path.basename(path)
+    if best is not None:
+        return best[0]["traffic_bytes_per_pass"], f"profiles/{best[1]} (collected on this version of csrc/partition.hip and csrc/kminmer.hip)"
+    return None, (f"profiles/{stale} was collected on another version of the k-min-mer kernels: not reported" if stale
+                  else "no PMC collection for this workload under profiles/")
+
+
+def kminmer_roofline(ctx, reads, n_reads: int = 0, read_len: int = 0) -> dict:
     """The k-min-mer step (first pass, k = 4) of the bench workload on the record: algorithmic bytes 4 M + 16 I + 20 D
     (minimizers read, one 128-bit key per instance, output rows) over the HIP-event time of its kernels with
-    the context ALONE on the device, and the ceiling the insert is judged against: one atomic per instance at the part's
-    random-atomic rate."""
+    the context ALONE on the device -- the partitioned pass the library takes at this size (csrc/partition.hip: instances split by
+    key, buckets counted in LDS), and beside it the one-table pass it replaced (one device-scope atomic per instance: the ceiling
+    that pass was judged against is I over the part's random-atomic rate)."""
     run_alone(ctx)
-    names = ("kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
-    acc = {n: 0.0 for n in names}
-    st = ti = None
+    names = ("kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
+    out = {}
+    st = ti = fp = None
     reps = 2
-    for it in range(reps + 1):
-        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
-        corr = ctx.purge_palindromes(mins, 4, 100)
-        ctx.synchronize()
-        if it:
-            ctx.timing(True); ctx.timing_reset()
-        t = ctx.kminmer_count_first(corr, KMINMER, 0)
-        ctx.synchronize()
-        if it:
-            ctx.timing(False)
-            for n in names:
-                acc[n] += ctx.timing_get(n)[0] / reps
-        st, ti = t.stats(), t.info()
-        for o in (t, corr, mins):
-            o.free()
+    mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    for mode in (0, 1):
+        ctx.set_option("first_pass_mode", mode)
+        acc = {n: 0.0 for n in names}
+        for it in range(reps + 1):
+            ctx.synchronize()
+            if it:
+                ctx.timing(True); ctx.timing_reset()
+            t = ctx.kminmer_count_first(corr, KMINMER, 0)
+            ctx.synchronize()
+            if it:
+                ctx.timing(False)
+                for n in names:
+                    acc[n] += ctx.timing_get(n)[0] / reps
+            if mode == 0:
+                st, ti, fp = t.stats(), t.info(), ctx.first_pass_info()
+            t.free()
+        out[mode] = acc
+    ctx.set_option("first_pass_mode", 0)
+    for o in (corr, mins):
+        o.free()
+    acc = out[0]
     M, I, D = st["minimizers"], st["instances"], ti["n_records"]
     alg = 4.0 * M + 16.0 * I + 20.0 * D
     total_ms = sum(acc.values())
+    one_table_ms = sum(out[1].values())
     ceiling_ms = I / (ATOMIC_RATE_GOPS * 1e9) * 1e3
     achieved = alg / (total_ms / 1e3) / 1e9 if total_ms > 0 else 0.0
-    return {"bound": "hbm", "kernel": "k-min-mer first pass, k = 4: count_insert_kernel, slot_flag_kernel, emit_slots_kernel, rescue_count_kernel, "
-                                      "emit_rescued_kernel, table clears and prefix scans (one context alone on the device)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic, traffic_note = kminmer_traffic(n_reads, read_len) if n_reads else (None, "not looked up")
+    return {"bound": "hbm", "kernel": "k-min-mer first pass, k = 4 (one context alone on the device): " +
+                     ("mark_starts, split_hist / split_scatter per level, bucket_count (LDS), emit_bucket_rows, rescue_count_p, emit_rescued_p, prefix scans"
+                      if fp["path"] == 2 else "count_insert_kernel, slot_flag_kernel, emit_slots_kernel, rescue_count_kernel, emit_rescued_kernel, table clears, prefix scans"),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_note": traffic_note, "traffic_over_algorithmic": (traffic / alg) if traffic else None,
             "algorithmic_bytes": alg, "minimizers_M": M, "instances_I": I, "rows_D": D, "distinct_keys": st["keys"], "table_slots": st["slots"],
-            "kernel_ms": acc, "kernel_ms_total": total_ms,
-            "atomic_ceiling_ms": ceiling_ms, "atomic_rate_gops": ATOMIC_RATE_GOPS,
-            "insert_ms_over_atomic_ceiling": acc["kminmer_insert"] / ceiling_ms if ceiling_ms > 0 else None,
-            "note": "random 32-byte slots of a hash table: the bound in practice is the device's random-atomic rate (one atomicAdd per "
-                    "instance), not HBM bandwidth; `atomic_ceiling_ms` is I over that rate (profiles/r01c_atomic_rates_gfx950.txt)"}
+            "first_pass": fp, "kernel_ms": acc, "kernel_ms_total": total_ms,
+            "one_table_pass": {"kernel_ms": out[1], "kernel_ms_total": one_table_ms, "atomic_ceiling_ms": ceiling_ms, "atomic_rate_gops": ATOMIC_RATE_GOPS,
+                               "insert_ms_over_atomic_ceiling": out[1]["kminmer_insert"] / ceiling_ms if ceiling_ms > 0 else None},
+            "speedup_over_one_table": one_table_ms / total_ms if total_ms > 0 else None,
+            "note": "the partitioned pass streams 20-byte instance records through two radix levels and counts them in LDS: its traffic is "
+                    "sequential and a multiple of the algorithmic bytes by construction (records written and read once per level); the one-table "
+                    "pass moved fewer streams but one random 64-byte sector and one device-scope atomic per instance (I over 26 G atomics/s = "
+                    "`atomic_ceiling_ms`, profiles/r01c_atomic_rates_gfx950.txt)"}
 
 
 _PHASE = ["start"]          # where the run is (the deadline below names it)
@@ -1160,7 +1198,7 @@ def main() -> None:
         tot = [c.timing_get(name) for c, _ in slots]
         return sum(t[0] for t in tot), sum(t[1] for t in tot)
 
-    names = ["scan", "scan_compact", "purge_palindromes", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan"]
+    names = ["scan", "scan_compact", "purge_palindromes", "kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan"]
     if exchange:
         names += ["shard_rows", "shard_reduce", "shard_exchange"]
     ktimes = {k: timing_get(k) for k in names}
@@ -1236,7 +1274,7 @@ def main() -> None:
         # the device, timed by HIP events like the scan -- beside another batch's scan they share the CUs, that is not their speed
         kroof = None
         if world == 1:
-            kroof = kminmer_roofline(ctx, reads)
+            kroof = kminmer_roofline(ctx, reads, args.reads, args.read_len)
         side = sample_legs(ctx, min(args.cpu_sample, args.reads), args.read_len, "end_to_end" in legs_on) if world == 1 else {}
         base = side.get("cpu_baseline")
         legs = {}

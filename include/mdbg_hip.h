@@ -268,6 +268,17 @@ int  mdbg_table_to_host_range(mdbg_ctx *ctx, const mdbg_table *t, uint64_t first
  * not built from sequences (mdbg_prev_from_records, the edge indexes, mdbg_shard_keep); a share of a sharded first pass reports
  * its rank's own reads and local keys. */
 int  mdbg_table_stats(const mdbg_table *t, uint64_t stats[4]);
+/* How the context's last mdbg_kminmer_count_first ran.  The reference counts the first pass's k-min-mers in `_nbPartitions`
+ * partitions chosen by `vecHash % P`, each sorted and run-length counted (KminmerCounter, graph/CreateMdbg.hpp:3714-3851; P from
+ * graph/CreateMdbg.cpp:222-225); the library either partitions the instances by bits of the identity and counts every bucket in LDS
+ * (csrc/partition.hip) or meets them in one table in HBM (csrc/kminmer.hip; small inputs, k > 32).  info[0] = 2 / 1 for the two,
+ * [1] = groups of keys processed one after the other (the analogue of _nbPartitions: more than one when the instance records of
+ * all keys would not fit the memory budget), [2] = bucket bits per group, [3] = levels of the radix split, [4] = attempts (a
+ * bucket that outgrows its LDS table makes the pass repeat with more buckets), [5] = LDS slots per bucket, [6] = buckets per
+ * group, [7] = k-min-mer instances.  Options (mdbg_set_option): "first_pass_mode" 0 by size / 1 one table / 2 partitioned,
+ * "partition_auto_min" (minimizers from which mode 0 partitions), and for tests "partition_bits", "partition_lds_slots"
+ * (256 / 1024 / 2048), "partition_max_records" (instances per group). */
+int  mdbg_first_pass_info(const mdbg_ctx *ctx, uint64_t info[8]);
 /* Order-independent sums over the rows, wrapping at 2^64, computed on the device (nothing but 32 bytes travels):
  *   sums[0] = sum abundance * hash_lo -- the "Checksum kminmer abundance" the reference logs when it loads the table again
  *             (CreateMdbg::loadRefinedAbundances, graph/CreateMdbg.cpp:3300-3321, :3397: `abundance * vecHash` truncated to u64),

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mdbg_table_to_host_range": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "mdbg_table_checksum": (C.c_int, [_P, _P, _u64p]),
     "mdbg_table_stats": (C.c_int, [_P, _u64p]),
+    "mdbg_first_pass_info": (C.c_int, [_P, _u64p]),
     "mdbg_device_clock_khz": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
     "mdbg_edge_index": (C.c_int, [_P, _P, C.POINTER(_P), _u64p]),
@@ -169,6 +170,13 @@ class Context:
 
     def set_option(self, name: str, value: int) -> None:
         self.check(lib().mdbg_set_option(self.h, name.encode(), value))
+
+    def first_pass_info(self) -> dict:
+        """How the last kminmer_count_first of this context ran (mdbg_first_pass_info)."""
+        a = (C.c_uint64 * 8)()
+        self.check(lib().mdbg_first_pass_info(self.h, a))
+        names = ("path", "groups", "bucket_bits", "levels", "attempts", "lds_slots", "buckets", "instances")
+        return {k: int(v) for k, v in zip(names, a)}
 
     # -- timing ---------------------------------------------------------------------------
     def timing(self, on: bool) -> None:

@@ -135,6 +135,14 @@ struct mdbg_ctx {
     // distinct keys per k-min-mer instance seen by the last call OF THE SAME KIND (table sizing): the first pass keeps every
     // key, refined / index only those above abundance 1 -- one shared hint made every first pass after an index pass rebuild its table
     double key_ratio_hint[4] = {0.0625, 0.0625, 0.0625, 0.0625};   // [0] first pass, [1] refined, [2] index, [3] sharded first pass
+    // the first pass (k = firstK): instances partitioned by key and counted in LDS (partition.hip) or one global table (kminmer.hip)
+    int first_pass_mode = 0;                // 0: by size (partitioned from part_auto_min instances up), 1: one table, 2: partitioned
+    uint64_t part_auto_min = 1ull << 22;    // mode 0: fewer minimizers than this take the one-table path
+    uint32_t part_bits = 0;                 // > 0: bucket bits of the first attempt (tests; default: from the key hint)
+    uint32_t part_lds_slots = 0;            // 0: 1024 or 2048 by the key hint; 256 / 1024 / 2048: forced (tests)
+    uint64_t part_max_records = 0;          // > 0: instances per group of keys (tests; default: a quarter of the HBM)
+    uint64_t part_info[8] = {0};            // last first pass: [0] path (1 one table, 2 partitioned), [1] groups, [2] bucket bits, [3] levels,
+                                            // [4] attempts, [5] LDS slots per bucket, [6] buckets, [7] instances
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out
 };
 

@@ -65,6 +65,7 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     if (const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU")) if (atoi(e) > 0) ctx->table_blocks_per_cu = (unsigned)atoi(e);
     if (const char *e = getenv("MDBG_SCAN_WAVE_PRIORITY")) ctx->scan_wave_priority = (uint32_t)std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
+    if (const char *e = getenv("MDBG_FIRST_PASS_MODE")) ctx->first_pass_mode = std::max(0, std::min(2, atoi(e)));
     ctx->hbm_bytes = prop.totalGlobalMem;
     ctx->clock_khz = prop.clockRate;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -160,6 +161,14 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (n == "scan_wave_priority") { ctx->scan_wave_priority = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }
     if (n == "scan_reads_per_wave") { ctx->scan_reads_per_wave = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 2u; return MDBG_OK; }
+    if (n == "first_pass_mode") { ctx->first_pass_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value)); return MDBG_OK; }
+    if (n == "partition_auto_min") { ctx->part_auto_min = value > 0 ? (uint64_t)value : (1ull << 22); return MDBG_OK; }
+    if (n == "partition_bits") { ctx->part_bits = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(24, value)); return MDBG_OK; }
+    if (n == "partition_lds_slots") {
+        if (value != 0 && value != 256 && value != 1024 && value != 2048) return set_error(ctx, MDBG_EINVAL, "partition_lds_slots: 0, 256, 1024 or 2048");
+        ctx->part_lds_slots = (uint32_t)value; return MDBG_OK;
+    }
+    if (n == "partition_max_records") { ctx->part_max_records = value > 0 ? (uint64_t)value : 0; return MDBG_OK; }
     if (n == "test_exchange_fail_phase") { ctx->test_exchange_fail_phase = (int)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "test_corrupt_replies") { ctx->test_corrupt_replies = value > 0; return MDBG_OK; }
     return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: unknown option '%s'", name);

@@ -16,6 +16,7 @@
 #include "murmur.hpp"
 #include "objects.hpp"
 #include "table.hpp"
+#include "kminmer_dev.hpp"
 
 #include <vector>
 
@@ -38,58 +39,6 @@ __device__ __forceinline__ uint32_t find_read(const uint64_t *inst_off, uint32_t
         if (inst_off[mid] <= g) lo = mid; else hi = mid;
     }
     return lo;
-}
-
-// canonical orientation + hash128 of the window m[0..k).  Returns isReversed.
-__device__ __forceinline__ bool window_hash(const uint32_t *m, uint32_t k, uint64_t &hi, uint64_t &lo) {
-    bool reversed = true;  // palindrome => reversed (Commons.hpp:912-913)
-    for (uint32_t i = 0; i < k; i++) {
-        uint32_t a = m[i], b = m[k - 1 - i];
-        if (a == b) continue;
-        reversed = !(a < b);
-        break;
-    }
-    Murmur128Stream h;
-    if (reversed) for (uint32_t i = 0; i < k; i++) h.push(m[k - 1 - i]);
-    else          for (uint32_t i = 0; i < k; i++) h.push(m[i]);
-    h.finish(hi, lo);
-    return reversed;
-}
-
-// The same for a window length known at compile time: the comparison and the four-words-a-block hashing unroll, the
-// stream's state machine folds away (about a third of the instructions of the general form).  k is a kernel argument
-// (wave-uniform), so the dispatch is a scalar branch.
-template <uint32_t KK>
-__device__ __forceinline__ bool window_hash_fixed(const uint32_t *m, uint64_t &hi, uint64_t &lo) {
-    uint32_t v[KK];
-#pragma unroll
-    for (uint32_t i = 0; i < KK; i++) v[i] = m[i];
-    bool reversed = true, decided = false;
-#pragma unroll
-    for (uint32_t i = 0; i < KK / 2; i++) {
-        const bool differ = v[i] != v[KK - 1 - i];
-        if (!decided && differ) { reversed = !(v[i] < v[KK - 1 - i]); decided = true; }
-    }
-    Murmur128Stream h;
-#pragma unroll
-    for (uint32_t i = 0; i < KK; i++) h.push(reversed ? v[KK - 1 - i] : v[i]);
-    h.finish(hi, lo);
-    return reversed;
-}
-
-__device__ __forceinline__ bool window_hash_uniform(const uint32_t *m, uint32_t k, uint64_t &hi, uint64_t &lo) {
-    switch (k) {
-        case 3: return window_hash_fixed<3>(m, hi, lo);
-        case 4: return window_hash_fixed<4>(m, hi, lo);
-        case 5: return window_hash_fixed<5>(m, hi, lo);
-        case 6: return window_hash_fixed<6>(m, hi, lo);
-        case 7: return window_hash_fixed<7>(m, hi, lo);
-        case 8: return window_hash_fixed<8>(m, hi, lo);
-        case 9: return window_hash_fixed<9>(m, hi, lo);
-        case 10: return window_hash_fixed<10>(m, hi, lo);
-        case 11: return window_hash_fixed<11>(m, hi, lo);
-        default: return window_hash(m, k, hi, lo);
-    }
 }
 
 __device__ __forceinline__ uint32_t table_upsert_count(const TableView &t, uint64_t lo, uint64_t hi, uint32_t add, uint32_t rep) {
@@ -123,21 +72,6 @@ __device__ __forceinline__ uint32_t table_insert_once(const TableView &t, uint64
     uint32_t s = table_find_or_insert(t, lo, hi, true, &created);
     if (s != SLOT_NONE && created) __hip_atomic_store(&t.slots[s].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return s;
-}
-
-struct SeqView {
-    const uint32_t *mins;
-    const uint64_t *off;       // n_reads + 1
-    const uint64_t *inst_off;  // n_reads + 1
-    uint32_t n_reads;
-    uint64_t n_inst;
-    uint64_t n_min;            // minimizers in `mins`
-};
-
-// A table slot's `rep` names one instance of its key by the FLAT index of the window's first minimizer
-// (set a first, then set b): reading the window back needs no search over the offsets.
-__device__ __forceinline__ const uint32_t *rep_window(const SeqView &a, const SeqView &b, uint32_t rep) {
-    return rep < a.n_min ? a.mins + rep : b.mins + (rep - a.n_min);
 }
 
 // Visit every instance with 16 lanes per sequence (4 sequences per wave): sequences hold a few dozen
@@ -303,26 +237,6 @@ __global__ __launch_bounds__(256) void slot_flag_kernel(TableView t, uint64_t ca
         const int n = __syncthreads_count(occ);
         if (threadIdx.x == 0 && n) atomicAdd(&occ_count[blockIdx.x % TABLE_OCC_WAYS], (uint32_t)n);
     }
-}
-
-struct RowOut {
-    uint64_t *lo, *hi;
-    uint32_t *ab;
-    uint32_t *vec;   // may be nullptr
-    uint32_t k;
-};
-
-// write the canonical vector of the instance `rep` names (over one or two sequence sets)
-__device__ __forceinline__ void write_instance_vector(const SeqView &a, const SeqView &b, uint32_t rep, uint32_t k, uint32_t *dst) {
-    const uint32_t *m = rep_window(a, b, rep);
-    bool reversed = true;
-    for (uint32_t i = 0; i < k; i++) {
-        uint32_t x = m[i], y = m[k - 1 - i];
-        if (x == y) continue;
-        reversed = !(x < y);
-        break;
-    }
-    for (uint32_t i = 0; i < k; i++) dst[i] = reversed ? m[k - 1 - i] : m[i];
 }
 
 __global__ __launch_bounds__(256) void emit_slots_kernel(TableView t, uint64_t cap, const uint32_t *flag, const uint64_t *pos,
@@ -583,20 +497,9 @@ __global__ void pack_records_kernel(const uint64_t *lo, const uint64_t *hi, cons
 }
 
 // ---- host helpers ------------------------------------------------------------------------------------------
-// largest median for which the reference's `double cutoff = median * 0.1f; if (cutoff > 1) return;` does not skip
-static uint32_t rescue_m_star() {
-    uint32_t m = 0;
-    for (;;) {
-        volatile float c = (float)(m + 1) * 0.1f;
-        if (c > 1.0f) break;
-        m++;
-    }
-    return m;
-}
-
 // Size the next table of this kind for the distinct keys just seen (+12.5 %): build_table_adaptive doubles that and
 // rounds up to a power of two, i.e. 25-45 % load.
-static void update_key_hint(mdbg_ctx *ctx, int kind, uint64_t distinct, uint64_t instances) {
+void update_key_hint(mdbg_ctx *ctx, int kind, uint64_t distinct, uint64_t instances) {
     if (instances) ctx->key_ratio_hint[kind] = 1.125 * (double)distinct / (double)instances;
 }
 
@@ -658,7 +561,7 @@ static SeqView make_view(const mdbg_minimizers *m, const InstIndex &ix) {
     return v;
 }
 
-static int alloc_rows(mdbg_ctx *ctx, mdbg_table *t, uint64_t n, bool vec) {
+int alloc_rows(mdbg_ctx *ctx, mdbg_table *t, uint64_t n, bool vec) {
     MDBG_TRY(t->d_lo.alloc(ctx, n));
     MDBG_TRY(t->d_hi.alloc(ctx, n));
     MDBG_TRY(t->d_ab.alloc(ctx, n));
@@ -683,6 +586,13 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     if (!ctx || !out || k < 2) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_first: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_count_first"));
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // instances partitioned by key and counted in LDS (partition.hip) -- by default from a few million minimizers up, where the one
+    // table below no longer sits in a cache; it hands the input back when it is not for it (k > 32, more keys than its buckets hold)
+    if (ctx->first_pass_mode == 2 || (ctx->first_pass_mode == 0 && reads->n_min >= ctx->part_auto_min)) {
+        bool done = false;
+        MDBG_TRY(count_first_partitioned(ctx, reads, k, min_abundance, out, &done));
+        if (done) return MDBG_OK;
+    }
     InstIndex ix;
     MDBG_TRY(build_inst_index(ctx, reads, k, ix));
     const uint64_t I = ix.total;
@@ -690,6 +600,8 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
     DeviceTable tab;
     DevBuf<uint32_t> inst_slot, sflag;
     MDBG_TRY(inst_slot.alloc(ctx, I));
+    for (uint64_t &v : ctx->part_info) v = 0;
+    ctx->part_info[0] = 1; ctx->part_info[7] = I;
     // distinct keys are usually a small fraction of the instances (coverage): start small so the table
     // stays cache-resident, grow and rebuild when a probe sequence gets long
     MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint[0]), I, [&](TableView v) {
@@ -949,6 +861,12 @@ extern "C" int mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n_rec
 extern "C" int mdbg_table_stats(const mdbg_table *t, uint64_t stats[4]) {
     if (!t || !stats) return MDBG_EINVAL;
     stats[0] = t->st_minimizers; stats[1] = t->st_instances; stats[2] = t->st_keys; stats[3] = t->st_slots;
+    return MDBG_OK;
+}
+
+extern "C" int mdbg_first_pass_info(const mdbg_ctx *ctx, uint64_t info[8]) {
+    if (!ctx || !info) return MDBG_EINVAL;
+    for (int i = 0; i < 8; i++) info[i] = ctx->part_info[i];
     return MDBG_OK;
 }
 

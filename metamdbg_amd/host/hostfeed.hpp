@@ -574,7 +574,10 @@ public:
     using Alloc = std::function<void *(size_t)>;
     using Free = std::function<void(void *)>;
 
-    ReadFeeder(std::vector<std::string> files, size_t chunkBytes, int threads, uint64_t maxReadsPerFile, Alloc alloc, Free freeFn)
+    // consumers: how many threads call next(), each holding up to two batches at a time (the one on the device and the one it staged
+    // ahead).  The pool is sized for that: with fewer buffers than 2 x consumers every buffer can be somebody's scanned-or-staged batch
+    // while all of them wait in next() for a worker that has no buffer to parse into (round-3 ADVICE: --gpus 4 --threads 1 hung).
+    ReadFeeder(std::vector<std::string> files, size_t chunkBytes, int threads, uint64_t maxReadsPerFile, Alloc alloc, Free freeFn, int consumers = 1)
         : files_(std::move(files)), chunk_(chunkBytes), maxReads_(maxReadsPerFile), free_(std::move(freeFn)),
           fileDone_(files_.size() ? files_.size() : 1) {
         for (auto &f : fileDone_) f.store(false);
@@ -588,7 +591,8 @@ public:
         if (threads > (pack_ ? 24 : 6)) threads = pack_ ? 24 : 6;
         alloc_ = std::move(alloc);
         nThreads_ = threads;
-        const int nbuf = threads + 3;          // one per worker + what the consumer holds: the batch on the device and the one uploading
+        if (consumers < 1) consumers = 1;
+        const int nbuf = threads + 1 + 2 * consumers;   // one per worker + what every consumer holds: the batch on the device and the one uploading
         for (int i = 0; i < nbuf; i++) {
             ReadBatch *b = new ReadBatch();
             b->cap = pack_ ? chunk_ / 4 + chunk_ / 32 + 4096 : chunk_ + 64;
@@ -1227,7 +1231,8 @@ private:
                 if (!w.slab && w.end > w.begin) {
                     // a chunk of a memory-mapped plain file, parsed: its pages are let go of here, by the worker, 32 MB at a time --
                     // not at the end, all 50 GB at once, under the process's exit (0.3 s of page-table teardown nobody overlaps)
-                    const uintptr_t page = 4096, a0 = ((uintptr_t)w.begin + page - 1) & ~(page - 1), a1 = (uintptr_t)w.end & ~(page - 1);
+                    static const uintptr_t page = (uintptr_t)std::max<long>(4096, sysconf(_SC_PAGESIZE));
+                    const uintptr_t a0 = ((uintptr_t)w.begin + page - 1) & ~(page - 1), a1 = (uintptr_t)w.end & ~(page - 1);
                     if (a1 > a0) (void)madvise((void *)a0, (size_t)(a1 - a0), MADV_DONTNEED);
                 }
                 if (w.slab) {

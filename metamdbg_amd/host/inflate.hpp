@@ -328,8 +328,9 @@ private:
     // (Two versions of the loop, picked when the program starts: with BMI2 the shifts by a table entry's bit counts are SHRX / BZHI --
     // no detour through CL, no flags -- and the loop, a chain of dependent look-ups and shifts, is 14 % faster on reads.)
     // (not under the sanitizers: the resolver of an ifunc runs before their run-time is up)
-#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(MDBG_HOST_NO_TARGET_CLONES) && !defined(__SANITIZE_THREAD__) && \
-    !defined(__SANITIZE_ADDRESS__)
+    // (glibc only: target_clones needs the dynamic loader's ifunc support -- not musl, not a static link)
+#if defined(__x86_64__) && defined(__GNUC__) && defined(__GLIBC__) && !defined(__clang__) && !defined(MDBG_HOST_NO_TARGET_CLONES) && \
+    !defined(__SANITIZE_THREAD__) && !defined(__SANITIZE_ADDRESS__)
     __attribute__((target_clones("bmi2", "default")))
 #endif
     int decode_block(OutT *&out_ref, OutT *out_end, const OutT *lowest) {

@@ -208,7 +208,7 @@ std::vector<std::string> read_input_list(const std::string &inputList) {
 // `threads` workers into page-locked buffers (hostfeed.hpp) while fn -- upload, kernels, record writing -- runs here.
 void for_each_batch(const std::string &inputList, size_t batchBases, int threads, uint64_t maxReadsPerFile,
                     const std::function<void(ReadBatch &)> &fn) {
-    auto alloc = [](size_t n) -> void * { void *p = nullptr; check(mdbg_host_alloc(g_ctx, n, &p), "mdbg_host_alloc"); return p; };
+    auto alloc = [](size_t n) -> void * { void *p = nullptr; return mdbg_host_alloc(g_ctx, n, &p) == MDBG_OK ? p : nullptr; };
     auto release = [](void *p) { mdbg_host_free(g_ctx, p); };
     try {
         mdbg_host::ReadFeeder feeder(read_input_list(inputList), batchBases, threads, maxReadsPerFile, alloc, release);
@@ -225,7 +225,7 @@ void for_each_batch(const std::string &inputList, size_t batchBases, int threads
 template <typename Handle>
 void for_each_batch_ahead(const std::string &inputList, size_t batchBases, int threads, uint64_t maxReadsPerFile,
                           const std::function<Handle(ReadBatch &)> &stage, const std::function<void(Handle, ReadBatch &)> &process) {
-    auto alloc = [](size_t n) -> void * { void *p = nullptr; check(mdbg_host_alloc(g_ctx, n, &p), "mdbg_host_alloc"); return p; };
+    auto alloc = [](size_t n) -> void * { void *p = nullptr; return mdbg_host_alloc(g_ctx, n, &p) == MDBG_OK ? p : nullptr; };
     auto release = [](void *p) { mdbg_host_free(g_ctx, p); };
     try {
         std::unique_ptr<mdbg_host::ReadFeeder> feeder(new mdbg_host::ReadFeeder(read_input_list(inputList), batchBases, threads, maxReadsPerFile, alloc, release));
@@ -414,11 +414,12 @@ int run_read_selection(int argc, char **argv) {
     // built by a few builder threads and written where they belong in the file (pwrite: the size of every earlier batch is known as
     // soon as it has been scanned); one thread writing 1.9 GB of a 50 Gbp read set alone finished 0.45 s behind the consumers.  The
     // statistics (long-double sums: order matters) are accumulated by one thread in read order behind the builders.
-    std::deque<HostBatch *> buildQ;
+    std::map<uint64_t, HostBatch *> buildQ;             // by batch number: a builder takes the lowest one whose place in the file is known
     std::map<uint64_t, uint64_t> sizeOf, offOf;         // batch -> record bytes / file offset
     uint64_t prefSeq = 0, prefOff = 0;
     bool buildDone = false;
     size_t inFlight = 0;                                // batches between the consumers and the statistics thread
+    const uint64_t inFlightWindow = 12 + 2 * (uint64_t)nConsumers;
     auto register_size = [&](uint64_t seq, uint64_t bytes) {     // fifoMu held
         sizeOf[seq] = bytes;
         for (auto it = sizeOf.find(prefSeq); it != sizeOf.end(); it = sizeOf.find(prefSeq)) {
@@ -435,11 +436,17 @@ int run_read_selection(int argc, char **argv) {
             uint64_t at = 0;
             {
                 std::unique_lock<std::mutex> lk(fifoMu);
-                fifoCv.wait(lk, [&] { return !buildQ.empty() || buildDone; });
-                if (buildQ.empty()) return;
-                hb = buildQ.front();
-                buildQ.pop_front();
-                fifoCv.wait(lk, [&] { return offOf.count(hb->seq) != 0; });
+                // never hold a batch while waiting for its offset (round-3 ADVICE): the offset needs the sizes of all earlier batches, and
+                // with every builder parked on a later batch the one the statistics thread is waiting for sat in the queue unbuilt
+                auto placed = [&]() -> std::map<uint64_t, HostBatch *>::iterator {
+                    for (auto it = buildQ.begin(); it != buildQ.end(); ++it) if (offOf.count(it->first)) return it;
+                    return buildQ.end();
+                };
+                fifoCv.wait(lk, [&] { return placed() != buildQ.end() || (buildDone && buildQ.empty()); });
+                auto it = placed();
+                if (it == buildQ.end()) return;
+                hb = it->second;
+                buildQ.erase(it);
                 at = offOf[hb->seq];
                 offOf.erase(hb->seq);
             }
@@ -481,7 +488,7 @@ int run_read_selection(int argc, char **argv) {
                 fprintf(stderr, "[mdbg_tool watchdog] buildQ %zu pending %zu inFlight %zu nextWrite %llu prefSeq %llu sizeOf %zu offOf %zu spare %zu\n", buildQ.size(),
                         pending.size(), inFlight, (unsigned long long)nextWrite, (unsigned long long)prefSeq, sizeOf.size(), offOf.size(), spareBatches.size());
                 if (!sizeOf.empty()) fprintf(stderr, "    first registered-but-unplaced batch %llu\n", (unsigned long long)sizeOf.begin()->first);
-                if (!buildQ.empty()) fprintf(stderr, "    buildQ front %llu\n", (unsigned long long)buildQ.front()->seq);
+                if (!buildQ.empty()) fprintf(stderr, "    buildQ front %llu\n", (unsigned long long)buildQ.begin()->first);
             }
         });
     }
@@ -518,10 +525,12 @@ int run_read_selection(int argc, char **argv) {
     double tUpload = 0, tScan = 0, tDownload = 0, tQueue = 0, tWait = 0;
     uint64_t nBatches = 0;
     {
-        auto alloc = [](size_t n) -> void * { void *p = nullptr; check(mdbg_host_alloc(g_ctx, n, &p), "mdbg_host_alloc"); return p; };
+        // (nullptr on failure: the feeder's workers -- many threads, page-locking side by side -- throw into its error path; `check` would
+        // have them all write the shared context's error string and _exit at once)
+        auto alloc = [](size_t n) -> void * { void *p = nullptr; return mdbg_host_alloc(g_ctx, n, &p) == MDBG_OK ? p : nullptr; };
         auto release = [](void *p) { mdbg_host_free(g_ctx, p); };
         std::unique_ptr<mdbg_host::ReadFeeder> feeder;
-        try { feeder.reset(new mdbg_host::ReadFeeder(read_input_list(inputList), a.batchBases, a.threads, 0, alloc, release)); }
+        try { feeder.reset(new mdbg_host::ReadFeeder(read_input_list(inputList), a.batchBases, a.threads, 0, alloc, release, nConsumers)); }
         catch (const std::exception &e) { die(e.what()); }
         std::mutex feedMu, statMu;
         uint64_t nextSeq = 0;
@@ -597,10 +606,13 @@ int run_read_selection(int argc, char **argv) {
                     register_size(seq, hb->t * 10 + (uint64_t)hb->n * 13);
                     fifoCv.notify_all();        // builders may be waiting for exactly this size to learn their offsets (and this thread may
                                                 // be about to wait itself: a wake-up left for after the wait below never comes)
-                    // bounded, but the batch the statistics thread is waiting for always gets in
-                    fifoCv.wait(lk, [&] { return inFlight < 12 || seq == nextWrite; });
+                    // Bounded by a WINDOW OF BATCH NUMBERS above the one the statistics thread is waiting for, not by a count (round-3
+                    // ADVICE: with three or more consumers, twelve later batches could fill the count while batch `nextWrite` sat
+                    // staged-ahead and unscanned with a consumer parked right here).  A consumer's staged batch always comes after the one
+                    // it is holding, so whoever holds batch nextWrite -- scanned or staged -- is never the one waiting: no cycle.
+                    fifoCv.wait(lk, [&] { return seq < nextWrite + inFlightWindow; });
                     inFlight++;
-                    buildQ.push_back(hb);
+                    buildQ.emplace(seq, hb);
                 }
                 if (!needCorrected) mdbg_minimizers_free(mins);
                 fifoCv.notify_all();

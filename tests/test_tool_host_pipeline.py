@@ -52,10 +52,16 @@ def read_set(tmp_path_factory):
     return fasta, b"".join(init), b"".join(corr), lens
 
 
-@pytest.mark.parametrize("batch_bases,threads,jitter,ont", [(1 << 20, 32, 0, False), (1 << 20, 32, 30, False), (1 << 16, 8, 0, False), (1 << 18, 3, 100, False),
-                                                            (1 << 25, 16, 0, False), (1 << 14, 32, 0, False), (1 << 18, 16, 20, True), (1 << 15, 32, 0, True)])
-def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool, read_set, tmp_path, batch_bases, threads, jitter, ont):
-    """ont: the ONT preset -- the census pre-pass (one batch ahead, ReadSelection.hpp:497-561) in front of the main pass, --skip-correction."""
+@pytest.mark.parametrize("batch_bases,threads,jitter,ont,gpus,consumers", [
+    (1 << 20, 32, 0, False, 1, 0), (1 << 20, 32, 30, False, 1, 0), (1 << 16, 8, 0, False, 1, 0), (1 << 18, 3, 100, False, 1, 0),
+    (1 << 25, 16, 0, False, 1, 0), (1 << 14, 32, 0, False, 1, 0), (1 << 18, 16, 20, True, 1, 0), (1 << 15, 32, 0, True, 1, 0),
+    # more than two consumers (round-3 ADVICE: both hung): --gpus 2 / 4 / 8 (two consumers per device from 8 threads up), MDBG_TOOL_CONSUMERS
+    (1 << 15, 8, 0, False, 2, 0), (1 << 15, 8, 20, False, 6, 0), (1 << 15, 16, 0, False, 8, 0), (1 << 14, 8, 0, False, 8, 0),
+    (1 << 15, 1, 0, False, 4, 0), (1 << 15, 10, 10, False, 8, 0), (1 << 15, 16, 0, False, 1, 3), (1 << 15, 16, 30, False, 1, 4),
+    (1 << 15, 16, 10, True, 4, 0)])
+def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool, read_set, tmp_path, batch_bases, threads, jitter, ont, gpus, consumers):
+    """ont: the ONT preset -- the census pre-pass (one batch ahead, ReadSelection.hpp:497-561) in front of the main pass, --skip-correction.
+    gpus / consumers: several consumer threads (the test double has as many devices as it is asked for)."""
     fasta, exp_init, exp_corr, lens = read_set
     tmp = tmp_path / "out" / "tmp"
     os.makedirs(tmp / "filter")
@@ -63,9 +69,11 @@ def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool
                        correction_density=0.025).save(str(tmp / "parameters.gz"))
     (tmp / "input.txt").write_text(fasta + "\n")
     env = dict(os.environ, MDBG_STUB_JITTER_US=str(jitter))
+    if consumers:
+        env["MDBG_TOOL_CONSUMERS"] = str(consumers)
     for rep in range(3):
         r = subprocess.run([stub_tool, "readSelection", str(tmp), str(tmp / "read_data_init.txt"), str(tmp / "input.txt"), "--threads", str(threads),
-                            "--min-read-quality", "0.000000", "--batch-bases", str(batch_bases)] + (["--skip-correction"] if ont else []),
+                            "--min-read-quality", "0.000000", "--batch-bases", str(batch_bases), "--gpus", str(gpus)] + (["--skip-correction"] if ont else []),
                            env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-800:]
         assert (tmp / "read_data_init.txt").read_bytes() == exp_init
