@@ -49,6 +49,11 @@ int  mdbg_create(int device, mdbg_ctx **ctx);
 void mdbg_destroy(mdbg_ctx *ctx);
 const char *mdbg_last_error(const mdbg_ctx *ctx);      /* ctx may be NULL: last creation error of the calling thread */
 int  mdbg_synchronize(mdbg_ctx *ctx);
+/* Queues a kernel of one wave that idles for `microseconds` on the context's stream and returns at once.  HIP multiplexes streams
+ * onto a few hardware queues; two contexts whose streams share one never overlap their kernels.  A caller that keeps several
+ * batches in flight on one device finds out by spinning on two contexts at once: different queues finish together, a shared
+ * queue takes twice as long (bench.py's overlap probe; no reference analogue -- the reference's threads share one CPU scheduler). */
+int  mdbg_stream_spin(mdbg_ctx *ctx, uint32_t microseconds);
 void *mdbg_stream(mdbg_ctx *ctx);                       /* the hipStream_t every launch goes to */
 int  mdbg_device_info(mdbg_ctx *ctx, char *arch, size_t arch_len, int *n_cu, uint64_t *hbm_bytes);
 int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine clock (hipDeviceProp_t::clockRate) */
@@ -195,6 +200,10 @@ void mdbg_minimizers_free(mdbg_minimizers *m);
  * k-min-mer table are over ALL the reads: the reference counts k-min-mers over the whole read_data_corrected.txt however the
  * reads were parsed (graph/CreateMdbg.cpp:290-328).  The parts stay valid and are not modified. */
 int  mdbg_minimizers_concat(mdbg_ctx *ctx, const mdbg_minimizers *const *parts, uint32_t n_parts, mdbg_minimizers **out);
+/* The other way round: reads [first_read, first_read + n_reads) of `in` as a set of their own (values and offsets; a device copy).
+ * What a rank of a sharded job holds of a read set (contiguous read ranges); a job that checks the table of a
+ * whole set against the union of its shards cuts the shards with it instead of scanning the reads again. */
+int  mdbg_minimizers_slice(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t first_read, uint32_t n_reads, mdbg_minimizers **out);
 
 /* Replaces Utils::applyDensityThreshold over every read (Commons.hpp:2507-2550; callers ReadCorrection.hpp:6385, :6435,
  * Commons.hpp:2563 getLowDensityMinimizerRead, :7252-7742 the minimizer-read parsers): keeps the minimizers whose
@@ -336,6 +345,15 @@ int  mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, u
 int  mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply);
 /* d_replies: n_sent u64, the replies for the rows of mdbg_shard_begin in the order they were sent. */
 int  mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_replies, uint32_t min_abundance, mdbg_table **out);
+/* Both exchanges of a sharded pass among `n` shards that live on one device (begun with n_ranks = n on contexts of that device):
+ * rows to their owners, mdbg_shard_reduce on every owner, the replies back in the order the rows were sent -- what
+ * mdbg_shard_exchange does between GPUs, with device-to-device copies in place of the wire.  counts[src * n + dst] = rows shard
+ * src holds for owner dst (the `counts` of its mdbg_shard_begin / _from_table), d_rows[src] its rows; d_replies[src] receives the
+ * replies for mdbg_shard_finish / _keep (owned by the shard).  For a job that checks itself against the union of shards (bench.py's
+ * self-checks: the table of a whole read set against the shares of its halves) and for tests; nothing in the reference
+ * corresponds to it -- its partitions meet on disk (graph/CreateMdbg.hpp:3714-3851). */
+int  mdbg_shard_exchange_local(mdbg_ctx *ctx, mdbg_shard *const *shards, uint32_t n, const uint64_t *const *d_rows, const uint64_t *counts,
+                               const uint64_t **d_replies);
 void mdbg_shard_free(mdbg_shard *shard);
 /* Sharded k > firstK (the refined pass and the index passes, graph/CreateMdbg.cpp:391-468).  The abundance of a k-min-mer at
  * these k is a function of the key and the previous table, not of a count, so nothing is summed: every rank holds the whole

@@ -87,6 +87,9 @@ SIGNATURES = {
     "mdbg_table_checksum": (C.c_int, [_P, _P, _u64p]),
     "mdbg_table_stats": (C.c_int, [_P, _u64p]),
     "mdbg_first_pass_info": (C.c_int, [_P, _u64p]),
+    "mdbg_stream_spin": (C.c_int, [_P, C.c_uint32]),
+    "mdbg_minimizers_slice": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "mdbg_shard_exchange_local": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p), _u64p, C.POINTER(C.c_void_p)]),
     "mdbg_device_clock_khz": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "mdbg_table_lookup": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
     "mdbg_edge_index": (C.c_int, [_P, _P, C.POINTER(_P), _u64p]),
@@ -170,6 +173,10 @@ class Context:
 
     def set_option(self, name: str, value: int) -> None:
         self.check(lib().mdbg_set_option(self.h, name.encode(), value))
+
+    def stream_spin(self, microseconds: int) -> None:
+        """One idle wave for that long on the context's stream (mdbg_stream_spin); returns at once."""
+        self.check(lib().mdbg_stream_spin(self.h, microseconds))
 
     def first_pass_info(self) -> dict:
         """How the last kminmer_count_first of this context ran (mdbg_first_pass_info)."""
@@ -340,6 +347,12 @@ class Context:
         self.check(lib().mdbg_minimizers_concat(self.h, arr, len(parts), C.byref(h)))
         return Minimizers(self, h)
 
+    def minimizers_slice(self, m: "Minimizers", first_read: int, n_reads: int) -> "Minimizers":
+        """Reads [first_read, first_read + n_reads) of m as a set of their own (mdbg_minimizers_slice)."""
+        h = C.c_void_p()
+        self.check(lib().mdbg_minimizers_slice(self.h, m.h, first_read, n_reads, C.byref(h)))
+        return Minimizers(self, h)
+
     def comm_create(self, unique_id: bytes, rank: int, n_ranks: int) -> "Comm":
         h = C.c_void_p()
         self.check(lib().mdbg_comm_create(self.h, unique_id, rank, n_ranks, C.byref(h)))
@@ -462,6 +475,17 @@ class Shard:
         if self.h:
             lib().mdbg_shard_free(self.h)
             self.h = None
+
+
+def exchange_local(ctx: Context, shards: list) -> list:
+    """Both exchanges of a sharded pass among shards on one device (mdbg_shard_exchange_local): the replies' device pointers, one per shard."""
+    n = len(shards)
+    hs = (C.c_void_p * n)(*[s.h for s in shards])
+    rows = (C.c_void_p * n)(*[C.c_void_p(s.d_rows) for s in shards])
+    counts = np.ascontiguousarray(np.stack([np.asarray(s.counts, dtype=np.uint64) for s in shards]).reshape(-1))
+    out = (C.c_void_p * n)()
+    ctx.check(lib().mdbg_shard_exchange_local(ctx.h, hs, n, rows, counts.ctypes.data_as(_u64p), out))
+    return [o or 0 for o in out]
 
 
 class Reads:

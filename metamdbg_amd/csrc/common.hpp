@@ -141,6 +141,10 @@ struct mdbg_ctx {
     uint32_t part_bits = 0;                 // > 0: bucket bits of the first attempt (tests; default: from the key hint)
     uint32_t part_lds_slots = 0;            // 0: 1024 or 2048 by the key hint; 256 / 1024 / 2048: forced (tests)
     uint64_t part_max_records = 0;          // > 0: instances per group of keys (tests; default: a quarter of the HBM)
+    uint32_t part_tile = 0;                 // 2048: the scatter regroups tiles of 2048 records (24 KB of LDS instead of 43), else 4096
+    uint32_t part_slot_list = 1;            // 0: bucket_count keeps no slot list (24 KB of LDS per 1024-slot bucket instead of 40)
+    uint32_t scan_lds_pad = 0;              // bytes of unused dynamic LDS per block of the block-structured scan: caps its blocks per CU and so
+                                            // leaves LDS, registers and wave slots to other contexts' kernels (mdbg_set_option)
     uint64_t part_info[8] = {0};            // last first pass: [0] path (1 one table, 2 partitioned), [1] groups, [2] bucket bits, [3] levels,
                                             // [4] attempts, [5] LDS slots per bucket, [6] buckets, [7] instances
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out

@@ -65,6 +65,9 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     if (const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU")) if (atoi(e) > 0) ctx->table_blocks_per_cu = (unsigned)atoi(e);
     if (const char *e = getenv("MDBG_SCAN_WAVE_PRIORITY")) ctx->scan_wave_priority = (uint32_t)std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
+    if (const char *e = getenv("MDBG_SCAN_LDS_PAD")) ctx->scan_lds_pad = (uint32_t)std::max(0, std::min(32768, atoi(e)));
+    if (const char *e = getenv("MDBG_PARTITION_TILE")) ctx->part_tile = atoi(e) == 2048 ? 2048u : 0u;
+    if (const char *e = getenv("MDBG_PARTITION_SLOT_LIST")) ctx->part_slot_list = atoi(e) != 0;
     if (const char *e = getenv("MDBG_FIRST_PASS_MODE")) ctx->first_pass_mode = std::max(0, std::min(2, atoi(e)));
     ctx->hbm_bytes = prop.totalGlobalMem;
     ctx->clock_khz = prop.clockRate;
@@ -105,6 +108,23 @@ extern "C" const char *mdbg_last_error(const mdbg_ctx *ctx) {
 extern "C" int mdbg_synchronize(mdbg_ctx *ctx) try {
     if (!ctx) return MDBG_EINVAL;
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+// one wave that does nothing for `ticks` of the constant-rate wall clock
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int mdbg_stream_spin(mdbg_ctx *ctx, uint32_t microseconds) try {
+    if (!ctx) return MDBG_EINVAL;
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int khz = 0;
+    MDBG_HIP_CHECK(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (khz <= 0) khz = 100000;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)microseconds * khz / 1000);
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
@@ -168,6 +188,9 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
         if (value != 0 && value != 256 && value != 1024 && value != 2048) return set_error(ctx, MDBG_EINVAL, "partition_lds_slots: 0, 256, 1024 or 2048");
         ctx->part_lds_slots = (uint32_t)value; return MDBG_OK;
     }
+    if (n == "partition_tile") { ctx->part_tile = value == 2048 ? 2048u : 0u; return MDBG_OK; }
+    if (n == "partition_slot_list") { ctx->part_slot_list = value != 0; return MDBG_OK; }
+    if (n == "scan_lds_pad") { ctx->scan_lds_pad = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(32768, value)); return MDBG_OK; }
     if (n == "partition_max_records") { ctx->part_max_records = value > 0 ? (uint64_t)value : 0; return MDBG_OK; }
     if (n == "test_exchange_fail_phase") { ctx->test_exchange_fail_phase = (int)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }
     if (n == "test_corrupt_replies") { ctx->test_corrupt_replies = value > 0; return MDBG_OK; }

@@ -1191,6 +1191,7 @@ struct mdbg_shard {
     mdbg::DeviceTable local, owner;
     mdbg::DevBuf<uint32_t> inst_slot, row_slot;
     mdbg::DevBuf<uint64_t> rows, reply;
+    mdbg::DevBuf<uint64_t> local_replies;    // mdbg_shard_exchange_local: the replies to this shard's rows
     uint64_t n_rows = 0;
     bool reduced = false;
 };
@@ -1399,6 +1400,50 @@ extern "C" int mdbg_shard_keep(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *d_
                               src->has_vectors ? t->d_vec.p : nullptr);
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = t.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+// Both all-to-alls of a sharded pass among shards that live on ONE device (a job checking itself, tests): device-to-device copies
+// stand in for the wire, everything else -- mdbg_shard_reduce on every owner, the replies back in the order the rows were sent --
+// is what mdbg_shard_exchange does between GPUs.
+extern "C" int mdbg_shard_exchange_local(mdbg_ctx *ctx, mdbg_shard *const *shards, uint32_t n, const uint64_t *const *d_rows, const uint64_t *counts,
+                                         const uint64_t **d_replies) try {
+    if (!ctx || !shards || !d_rows || !counts || !d_replies || n < 1 || n > 64) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange_local: bad argument");
+    for (uint32_t r = 0; r < n; r++)
+        if (!shards[r] || shards[r]->n_ranks != n) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange_local: shard %u was not begun for %u ranks", r, n);
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t rw = SHARD_ROW_WORDS;
+    // soff[src][dst]: first row of src's rows for dst; roff[dst][src]: first received row on dst that came from src
+    std::vector<uint64_t> soff((size_t)n * (n + 1), 0), roff((size_t)n * (n + 1), 0);
+    for (uint32_t a = 0; a < n; a++)
+        for (uint32_t b = 0; b < n; b++) {
+            soff[(size_t)a * (n + 1) + b + 1] = soff[(size_t)a * (n + 1) + b] + counts[(size_t)a * n + b];
+            roff[(size_t)a * (n + 1) + b + 1] = roff[(size_t)a * (n + 1) + b] + counts[(size_t)b * n + a];
+        }
+    std::vector<const uint64_t *> reply(n, nullptr);
+    for (uint32_t dst = 0; dst < n; dst++) {
+        const uint64_t n_recv = roff[(size_t)dst * (n + 1) + n];
+        DevBuf<uint64_t> recv;
+        MDBG_TRY(recv.alloc(ctx, n_recv * rw));
+        for (uint32_t src = 0; src < n; src++) {
+            const uint64_t c = counts[(size_t)src * n + dst];
+            if (!c) continue;
+            if (!d_rows[src]) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange_local: shard %u has rows but no row pointer", src);
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(recv.p + roff[(size_t)dst * (n + 1) + src] * rw, d_rows[src] + soff[(size_t)src * (n + 1) + dst] * rw, c * rw * 8,
+                                               hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        MDBG_TRY(mdbg_shard_reduce(ctx, shards[dst], recv.p, n_recv, &reply[dst]));   // (synchronises: recv may go)
+    }
+    for (uint32_t src = 0; src < n; src++) {
+        MDBG_TRY(shards[src]->local_replies.alloc(ctx, soff[(size_t)src * (n + 1) + n]));
+        for (uint32_t dst = 0; dst < n; dst++) {
+            const uint64_t c = counts[(size_t)src * n + dst];
+            if (c) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(shards[src]->local_replies.p + soff[(size_t)src * (n + 1) + dst], reply[dst] + roff[(size_t)dst * (n + 1) + src],
+                                                      c * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        d_replies[src] = shards[src]->local_replies.p;
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 

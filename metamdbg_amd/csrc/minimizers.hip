@@ -99,10 +99,14 @@ __device__ __forceinline__ uint32_t purge_replay(Ptr a, uint32_t n, uint32_t fir
 
 // One thread per suspect read.  The replay is a long chain of dependent reads of the same few dozen minimizers, so
 // reads of up to PURGE_LDS_MAX minimizers are staged in LDS (a padded row per thread) and written back once.
+// Sixteen threads a block, 6 KB of LDS: a block must fit into what another context's scan leaves of a CU (five scan blocks hold 150
+// of the 160 KB; with 64 threads and 24 KB this kernel sat out whole scan launches -- 0.08 ms of work, 103 ms from start to end,
+// rocprofv3 trace of round 3 -- and its batch's table pass behind it).
 constexpr uint32_t PURGE_LDS_MAX = 96;
-__global__ __launch_bounds__(64) void purge_fix_kernel(ReadSpans sp, const uint32_t *list, uint32_t n_list, uint32_t *work,
-                                                       uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
-    __shared__ uint32_t stage[64][PURGE_LDS_MAX + 1];
+constexpr uint32_t PURGE_FIX_THREADS = 16;
+__global__ __launch_bounds__(PURGE_FIX_THREADS) void purge_fix_kernel(ReadSpans sp, const uint32_t *list, uint32_t n_list, uint32_t *work,
+                                                                      uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
+    __shared__ uint32_t stage[PURGE_FIX_THREADS][PURGE_LDS_MAX + 1];
     uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n_list) return;
     const uint32_t r = list[li];
@@ -383,6 +387,29 @@ extern "C" int mdbg_minimizers_concat(mdbg_ctx *ctx, const mdbg_minimizers *cons
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
+extern "C" int mdbg_minimizers_slice(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t first_read, uint32_t n_reads, mdbg_minimizers **out) try {
+    if (!ctx || !in || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_slice: null argument");
+    if (first_read > in->n_reads || n_reads > in->n_reads - first_read)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_slice: reads [%u, +%u) of %u", first_read, n_reads, in->n_reads);
+    MDBG_TRY(ensure_canonical(ctx, in));
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint64_t ends[2] = {0, 0};
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], in->d_off.p + first_read, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ends[1], in->d_off.p + first_read + n_reads, 8, hipMemcpyDeviceToHost));
+    std::unique_ptr<mdbg_minimizers> m(new mdbg_minimizers());
+    m->n_reads = n_reads;
+    m->n_min = ends[1] - ends[0];
+    m->owner = ctx;
+    MDBG_TRY(m->d_off.alloc(ctx, (size_t)n_reads + 1));
+    MDBG_TRY(m->d_min.alloc(ctx, m->n_min));
+    hipLaunchKernelGGL(rebase_offsets_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream, in->d_off.p + first_read, (uint64_t)n_reads + 1,
+                       (uint64_t)0 - ends[0], m->d_off.p);
+    if (m->n_min) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_min.p, in->d_min.p + ends[0], m->n_min * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = m.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
 extern "C" int mdbg_apply_density_threshold(mdbg_ctx *ctx, const mdbg_minimizers *in, float density, mdbg_minimizers **out) try {
     if (!ctx || !in || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_apply_density_threshold: null argument");
     MDBG_TRY(ensure_canonical(ctx, in));
@@ -487,7 +514,7 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
             LaunchTimer timer(ctx, "purge_palindromes");
             e = hipMemcpyAsync(work.p, in->d_min.p, work_n * 4, hipMemcpyDeviceToDevice, ctx->stream);
             if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
-            hipLaunchKernelGGL(purge_fix_kernel, dim3(grid_for(n_suspect, 64)), dim3(64), 0, ctx->stream, sp, list.p, n_suspect,
+            hipLaunchKernelGGL(purge_fix_kernel, dim3(grid_for(n_suspect, PURGE_FIX_THREADS)), dim3(PURGE_FIX_THREADS), 0, ctx->stream, sp, list.p, n_suspect,
                                work.p, first_k, last_k, cnt.p);
         }
         if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);

@@ -39,9 +39,8 @@ constexpr uint32_t PART_NT = 512;                      // threads per block of t
 constexpr uint32_t PART_E = 8;                         // records per thread and tile
 constexpr uint32_t PART_TILE = PART_NT * PART_E;       // 4096 records regrouped in LDS at a time
 constexpr uint32_t PART_MAXW = 256;                    // ways per level
-// bucket_count: records whose LDS slot is remembered between its two passes (with the table: under the 64 KB of static LDS)
-// (8000, not 8192: four buckets of 1024 slots then fit a CU's 160 KB)
-template <uint32_t C> struct SlotList { static constexpr uint32_t N = C >= 2048 ? 4096 : 8000; };
+// bucket_count remembers the LDS slot of a bucket's first records between its two passes: 8000 of them beside 1024 slots (not 8192:
+// four such buckets then fit a CU's 160 KB), 4096 beside 2048 (the 64 KB of static LDS), none when the kernel is to fit beside a scan
 constexpr uint32_t PART_MAX_K = 32;                    // window validity is one 64-bit extract of the start bits
 
 struct RecView { unsigned long long *lo, *hi; uint32_t *rep; };
@@ -56,6 +55,7 @@ struct SplitArgs {
     // (the scanned histogram of the level above); null: ONE segment, the n_min flat positions
     const uint64_t *seg_pos; uint32_t seg_stride;
     uint32_t blocks_per_seg;
+    uint32_t tile;                                     // a block's share of a segment is a multiple of this (the scatter's tile)
     uint32_t shift, ways;                              // digit = (hash_lo >> shift) & (ways - 1)
     uint8_t *hll;                                      // level-1 histogram: HLL_M registers per block, see hll_estimate (null: not wanted)
 };
@@ -98,7 +98,7 @@ __device__ __forceinline__ void split_range(const SplitArgs &a, uint32_t &seg, u
     if (a.seg_pos) { s0 = a.seg_pos[(uint64_t)seg * a.seg_stride]; s1 = a.seg_pos[(uint64_t)(seg + 1) * a.seg_stride]; }
     const uint64_t len = s1 - s0;
     uint64_t per = (len + a.blocks_per_seg - 1) / a.blocks_per_seg;
-    per = (per + PART_TILE - 1) / PART_TILE * PART_TILE;
+    per = (per + a.tile - 1) / a.tile * a.tile;
     b = s0 + (uint64_t)j * per; if (b > s1) b = s1;
     e = b + per; if (e > s1) e = s1;
 }
@@ -150,11 +150,15 @@ __global__ __launch_bounds__(256) void hll_merge_kernel(const uint8_t *per_block
     merged[r] = (uint8_t)m;
 }
 
-template <bool FROM_MINS>
+// E records per thread and tile: 8 (tiles of 4096: runs of 16 records per digit and tile at 256 ways) when the kernel has the device to
+// itself, 4 (24 KB of LDS instead of 43) when it is to fit beside another context's scan blocks (mdbg_set_option "partition_tile")
+template <bool FROM_MINS, uint32_t E>
 __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, const uint64_t *place, RecView out) {
-    __shared__ unsigned long long stage[PART_TILE];    // one field of the tile's records at a time, grouped by digit
-    __shared__ uint8_t stage_digit[PART_TILE];
-    __shared__ uint32_t h[PART_MAXW], loff[PART_MAXW], wsum[4];
+    constexpr uint32_t TILE = PART_NT * E;
+    __shared__ unsigned long long stage[TILE];         // one field of the tile's records at a time, grouped by digit
+    __shared__ uint8_t stage_digit[TILE];
+    __shared__ uint32_t h[PART_MAXW], wsum[4];
+    __shared__ uint16_t loff[PART_MAXW];
     __shared__ unsigned long long cur[PART_MAXW], gbase[PART_MAXW];
     uint32_t seg, j; uint64_t b, e;
     split_range(a, seg, j, b, e);
@@ -164,11 +168,11 @@ __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, con
         cur[t] = t < a.ways ? place[((uint64_t)seg * a.ways + t) * a.blocks_per_seg + j] : 0ull;
     }
     __syncthreads();
-    for (uint64_t t0 = b; t0 < e; t0 += PART_TILE) {
-        uint64_t lo[PART_E], hi[PART_E];
-        uint32_t rep[PART_E], meta[PART_E];            // digit | rank << 8 | valid << 31
+    for (uint64_t t0 = b; t0 < e; t0 += TILE) {
+        uint64_t lo[E], hi[E];
+        uint32_t rep[E], meta[E];            // digit | rank << 8 | valid << 31
 #pragma unroll
-        for (uint32_t q = 0; q < PART_E; q++) {
+        for (uint32_t q = 0; q < E; q++) {
             const uint64_t i = t0 + (uint64_t)q * PART_NT + tid;
             bool valid = i < e;
             if (valid) {
@@ -191,19 +195,19 @@ __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, con
         const uint32_t n_tile = w0 + w1 + w2 + w3;
         if (tid < a.ways) {
             const uint32_t excl = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + inc - v;
-            loff[tid] = excl;
+            loff[tid] = (uint16_t)excl;
             gbase[tid] = cur[tid] - excl;              // record at staged place j of this digit goes to gbase + j
             cur[tid] += v;
             h[tid] = 0;
         }
         __syncthreads();
-        uint32_t dst[PART_E];
+        uint32_t dst[E];
 #pragma unroll
-        for (uint32_t q = 0; q < PART_E; q++) {
+        for (uint32_t q = 0; q < E; q++) {
             dst[q] = 0xFFFFFFFFu;
             if (meta[q] & 0x80000000u) {
                 const uint32_t d = meta[q] & 0xFFu;
-                dst[q] = loff[d] + ((meta[q] >> 8) & 0x7FFFFFu);
+                dst[q] = (uint32_t)loff[d] + ((meta[q] >> 8) & 0x7FFFFFu);
                 stage[dst[q]] = lo[q];
                 stage_digit[dst[q]] = (uint8_t)d;
             }
@@ -212,13 +216,13 @@ __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, con
         for (uint32_t s = tid; s < n_tile; s += PART_NT) out.lo[gbase[stage_digit[s]] + s] = stage[s];
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < PART_E; q++) if (dst[q] != 0xFFFFFFFFu) stage[dst[q]] = hi[q];
+        for (uint32_t q = 0; q < E; q++) if (dst[q] != 0xFFFFFFFFu) stage[dst[q]] = hi[q];
         __syncthreads();
         for (uint32_t s = tid; s < n_tile; s += PART_NT) out.hi[gbase[stage_digit[s]] + s] = stage[s];
         __syncthreads();
         uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage);
 #pragma unroll
-        for (uint32_t q = 0; q < PART_E; q++) if (dst[q] != 0xFFFFFFFFu) stage32[dst[q]] = rep[q];
+        for (uint32_t q = 0; q < E; q++) if (dst[q] != 0xFFFFFFFFu) stage32[dst[q]] = rep[q];
         __syncthreads();
         for (uint32_t s = tid; s < n_tile; s += PART_NT) out.rep[gbase[stage_digit[s]] + s] = stage32[s];
         __syncthreads();
@@ -274,13 +278,13 @@ __device__ __forceinline__ uint32_t lds_find(const LdsTable<C> &t, uint64_t lo, 
 constexpr uint32_t BC_NT = 512;                        // threads per bucket: 4 blocks of 40 KB fill a CU's 32 wave slots
 constexpr uint32_t BC_U = 4;                           // records of a thread in flight
 
-template <uint32_t C>
+template <uint32_t C, uint32_t LIST>
 __global__ __launch_bounds__(BC_NT) void bucket_count_kernel(RecView in, const uint64_t *pos, uint32_t stride, uint32_t min_abundance, uint32_t clip,
                                                            int keep_all, RecView keys, uint32_t *kcnt, uint32_t *n_keys, uint32_t *n_kept,
                                                            uint8_t *cnt8, uint32_t cnt8_default, uint32_t *overflow) {
     __shared__ LdsTable<C> t;
-    constexpr uint32_t PART_SLOTLIST = SlotList<C>::N;
-    __shared__ uint16_t slot_of[PART_SLOTLIST];
+    constexpr uint32_t PART_SLOTLIST = LIST;           // 0: none (24 bytes of LDS per slot and nothing else: fits beside a scan)
+    __shared__ uint16_t slot_of[LIST ? LIST : 1];
     __shared__ uint32_t kept, occupied;
     const uint32_t tid = threadIdx.x;
     const uint64_t s0 = pos[(uint64_t)blockIdx.x * stride], s1 = pos[(uint64_t)(blockIdx.x + 1) * stride];
@@ -458,10 +462,10 @@ struct RecBufs {
 
 struct LevelPlan { uint32_t bits, shift, ways, blocks_per_seg; uint64_t n_seg; };
 
-template <uint32_t C>
+template <uint32_t C, uint32_t LIST>
 static void launch_bucket_count(mdbg_ctx *ctx, uint64_t n_buckets, RecView in, const uint64_t *pos, uint32_t stride, uint32_t min_abundance, uint32_t clip,
                                 RecView keys, uint32_t *kcnt, uint32_t *n_keys, uint32_t *n_kept, uint8_t *cnt8, uint32_t cnt8_default, uint32_t *overflow) {
-    hipLaunchKernelGGL(bucket_count_kernel<C>, dim3((unsigned)n_buckets), dim3(BC_NT), 0, ctx->stream, in, pos, stride, min_abundance, clip, 0, keys, kcnt,
+    hipLaunchKernelGGL((bucket_count_kernel<C, LIST>), dim3((unsigned)n_buckets), dim3(BC_NT), 0, ctx->stream, in, pos, stride, min_abundance, clip, 0, keys, kcnt,
                        n_keys, n_kept, cnt8, cnt8_default, overflow);
 }
 
@@ -569,7 +573,9 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             a.mins = reads->d_min.p; a.start_bits = start_bits.p; a.n_min = M; a.k = k;
             a.group_bits = group_bits; a.group = g;
             // level 1: histogram, scan, the group's instance count, scatter
-            const uint64_t tiles = (M + PART_TILE - 1) / PART_TILE;
+            const uint32_t tile = ctx->part_tile == 2048 ? 2048u : PART_TILE;
+            const uint64_t tiles = (M + tile - 1) / tile;
+            a.tile = tile;
             uint64_t I = 0, entries = 0;
             for (;;) {
                 lv[0].blocks_per_seg = (uint32_t)std::min<uint64_t>(tiles, 2048);
@@ -623,18 +629,19 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             if (kcnt.n < I || !kcnt.p) MDBG_TRY(kcnt.alloc(ctx, I));
             {
                 LaunchTimer timer(ctx, "kminmer_split");
-                hipLaunchKernelGGL(split_scatter_kernel<true>, dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
+                if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<true, 4>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
+                else hipLaunchKernelGGL((split_scatter_kernel<true, 8>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
             }
             // deeper levels
             uint32_t cur = 0;
             for (uint32_t l = 1; l < n_levels; l++) {
                 const uint64_t n_seg = lv[l].n_seg;
-                const uint64_t avg_tiles = (I / n_seg + PART_TILE - 1) / PART_TILE;
+                const uint64_t avg_tiles = (I / n_seg + tile - 1) / tile;
                 lv[l].blocks_per_seg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(1, 4096 / n_seg), avg_tiles));
                 SplitArgs d{};
                 d.in = buf[cur].view();
                 d.seg_pos = place[l - 1].p; d.seg_stride = lv[l - 1].blocks_per_seg; d.blocks_per_seg = lv[l].blocks_per_seg;
-                d.shift = lv[l].shift; d.ways = lv[l].ways; d.n_min = 0;
+                d.shift = lv[l].shift; d.ways = lv[l].ways; d.n_min = 0; d.tile = tile;
                 entries = n_seg * lv[l].ways * lv[l].blocks_per_seg;
                 MDBG_TRY(hist.alloc(ctx, entries));
                 MDBG_TRY(place[l].alloc(ctx, entries + 1));
@@ -646,7 +653,8 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
                 MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[l].p, entries));
                 {
                     LaunchTimer timer(ctx, "kminmer_split");
-                    hipLaunchKernelGGL(split_scatter_kernel<false>, dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+                    if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<false, 4>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+                    else hipLaunchKernelGGL((split_scatter_kernel<false, 8>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
                 }
                 cur ^= 1;
             }
@@ -657,9 +665,12 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             {
                 LaunchTimer timer(ctx, "kminmer_insert");
                 uint8_t *c8 = do_rescue ? cnt8.p : nullptr;
-                if (lds_slots == 256) launch_bucket_count<256>(ctx, n_buckets, buf[cur].view(), pos, stride, min_abundance, clip, keys, kcnt.p, n_keys.p, n_kept.p, c8, cnt8_default, overflow.p);
-                else if (lds_slots == 1024) launch_bucket_count<1024>(ctx, n_buckets, buf[cur].view(), pos, stride, min_abundance, clip, keys, kcnt.p, n_keys.p, n_kept.p, c8, cnt8_default, overflow.p);
-                else launch_bucket_count<2048>(ctx, n_buckets, buf[cur].view(), pos, stride, min_abundance, clip, keys, kcnt.p, n_keys.p, n_kept.p, c8, cnt8_default, overflow.p);
+#define MDBG_BC(C, L) launch_bucket_count<C, L>(ctx, n_buckets, buf[cur].view(), pos, stride, min_abundance, clip, keys, kcnt.p, n_keys.p, n_kept.p, c8, cnt8_default, overflow.p)
+                const bool list = ctx->part_slot_list != 0;
+                if (lds_slots == 256) { if (list) MDBG_BC(256, 8000); else MDBG_BC(256, 0); }
+                else if (lds_slots == 1024) { if (list) MDBG_BC(1024, 8000); else MDBG_BC(1024, 0); }
+                else { if (list) MDBG_BC(2048, 4096); else MDBG_BC(2048, 0); }
+#undef MDBG_BC
             }
             MDBG_HIP_CHECK(ctx, hipGetLastError());
             MDBG_TRY(exclusive_scan_u32(ctx, n_keys.p, key_pos.p, n_buckets));

@@ -1505,16 +1505,17 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
             if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
             // bump mode: candidates by the upper half of the hash (span_step<APPROX>); the host's re-run of a read covers a false one
             const dim3 g((unsigned)blocks), b(FAST_BLOCK);
+            const unsigned lds_pad = ctx->scan_lds_pad;     // unused dynamic LDS: fewer blocks of this kernel per CU (mdbg_set_option "scan_lds_pad")
             if (a.cursor && !no_approx) {
-                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, true>), g, b, 0, on, a);
-                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, true>), g, b, 0, on, a);
-                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, true>), g, b, 0, on, a);
-                else hipLaunchKernelGGL((scan_fast_kernel<false, false, true>), g, b, 0, on, a);
+                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, true>), g, b, lds_pad, on, a);
+                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, true>), g, b, lds_pad, on, a);
+                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, true>), g, b, lds_pad, on, a);
+                else hipLaunchKernelGGL((scan_fast_kernel<false, false, true>), g, b, lds_pad, on, a);
             } else {
-                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, false>), g, b, 0, on, a);
-                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, false>), g, b, 0, on, a);
-                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, false>), g, b, 0, on, a);
-                else hipLaunchKernelGGL((scan_fast_kernel<false, false, false>), g, b, 0, on, a);
+                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, false>), g, b, lds_pad, on, a);
+                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, false>), g, b, lds_pad, on, a);
+                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, false>), g, b, lds_pad, on, a);
+                else hipLaunchKernelGGL((scan_fast_kernel<false, false, false>), g, b, lds_pad, on, a);
             }
         } else if (hpc) {
             if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }

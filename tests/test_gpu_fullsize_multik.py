@@ -1,0 +1,72 @@
+"""BASELINE.json configs[2]'s loop k = 4 .. 11 at configs[1]'s size (1 M x 10 kb HiFi reads), beyond what the reference can be run on
+inside a test: (1) shard invariance at every k -- the table of the whole set against the union of the shares of its two halves,
+through the library's sharded passes and its exchange on the device (bench.shard_self_check: counts and the four sums of
+mdbg_table_checksum, sums[0] being the checksum the reference logs, graph/CreateMdbg.cpp:3321); (2) the oracle on the first 2 000
+reads' windows at every k > 4 against the WHOLE set's tables: the abundance of a k-min-mer there is a function of its identity and of
+the previous table (getRefinedAbundance graph/CreateMdbg.hpp:3933-4005; IndexKminmerFunctor :1240-1265, :1450-1459), so what the
+oracle makes of those reads with the whole previous table must be in the whole table, value for value, and the windows it leaves out
+must be absent.  GPU box: python -m pytest tests -m gpu"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from metamdbg_amd import synth
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from metamdbg_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_multik_tables_at_one_million_reads(ctx):
+    import bench
+    from oracle import pyoracle as orc
+    n, n_sample, last_k = 1_000_000, 2_000, 11
+    spec = synth.hifi_spec(n, seed=42, read_len=10_000, coverage=50.0)
+    reads = ctx.reads_synthetic(spec)
+    mins = ctx.scan(reads, K=15, density=0.005, hpc=True)
+    reads.free()
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    mins.free()
+    # (1) every k, the whole set against its two shards (and against three: another cut, another owner map)
+    for shards in (2, 3):
+        r = bench.shard_self_check(ctx, corr, list(range(4, last_k + 1)), n_shards=shards)
+        assert r["all_equal"], r
+        assert r["per_k"]["4"]["records"] == 1_080_243 and r["per_k"]["4"]["solid"] == 1_064_017       # tests/golden/hifi_1m: the reference's own counts
+    # (2) the oracle on the first reads against the whole set's tables
+    head = ctx.minimizers_slice(corr, 0, n_sample).to_host(full=False)
+    m, off = head["minimizers"], head["offsets"].astype(np.int64)
+    prev = ctx.kminmer_count_first(corr, 4, 0)
+    for k in range(5, last_k + 1):
+        whole = ctx.kminmer_count_refined(corr, None, k, prev) if k == 5 else ctx.kminmer_index(corr, None, k, prev)
+        pa = orc.PrevAbundance(prev.to_host()[0].tobytes())
+        exp = (orc.kminmer_count_refined if k == 5 else orc.kminmer_index)(m, head["offsets"], k, pa)
+        assert exp["n"] > 1000, (k, exp["n"])
+        got = whole.lookup(exp["hash_lo"], exp["hash_hi"])
+        assert np.array_equal(got, exp["abundance"]), k
+        # the windows of these reads the oracle did not list are not in the whole table either
+        listed = set(zip(exp["hash_lo"].tolist(), exp["hash_hi"].tolist()))
+        lo, hi = [], []
+        for r0 in range(n_sample):
+            a, b = int(off[r0]), int(off[r0 + 1])
+            for i in range(a, b - k + 1):
+                _, _, h_hi, h_lo = orc.kminmer_normalize_hash(m[i: i + k])
+                if (h_lo, h_hi) not in listed:
+                    lo.append(h_lo); hi.append(h_hi)
+        if lo:
+            assert not whole.lookup(np.array(lo, np.uint64), np.array(hi, np.uint64)).any(), k
+        prev.free()
+        prev = whole
+    prev.free()
+    corr.free()

@@ -1,0 +1,58 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/partition_traffic.sh <tag> [n_reads]
+# HBM traffic and instruction counts of the k = 4 first pass (csrc/partition.hip) over n x 10 kb HiFi reads, one context alone:
+# separate rocprofv3 --pmc passes with --kernel-trace only (as /opt/skills/guides/MI355X_MICROARCH.md prescribes), tools/insert_once.py
+# runs the pass three times.  Writes <tag>/kminmer_pmc.txt (per kernel and counter) and <tag>/kminmer_traffic.json (bytes per pass, with the
+# git blob hashes of the kernel sources they were collected on -- what bench.py's roofline_kminmer.traffic reports).
+set -u
+TAG=${1:-r4_traffic}
+N=${2:-10000000}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROOT=$PWD
+: > $OUT/kminmer_pmc.txt
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_VMEM_WR SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum"; do
+  n=$(echo $c | tr " " "_")
+  ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$OUT/p_$n -o p -- python $ROOT/tools/insert_once.py $N > $ROOT/$OUT/insert_once.log 2> $ROOT/$OUT/p_$n.err )
+  if [ -f $OUT/p_$n/p_results.db ]; then
+    python tools/rocpd_summary.py $OUT/p_$n/p_results.db 2>&1 | grep "n=" | grep -E "split_|bucket_count|mark_starts|emit_bucket|rescue_count_p|emit_rescued_p|hll_merge|scan_reduce|scan_apply|scan_small|fillBuffer|count_insert|slot_flag|emit_slots" >> $OUT/kminmer_pmc.txt
+  else
+    echo "# $c: no result (counter unknown to this rocprofv3?): $(tail -1 $OUT/p_$n.err)" >> $OUT/kminmer_pmc.txt
+  fi
+  rm -rf $OUT/p_$n
+done
+python - $OUT $N <<'PY'
+import hashlib, json, re, sys
+out, n = sys.argv[1], int(sys.argv[2])
+passes = 3
+tot = {}
+per_kernel = {}
+for line in open(f"{out}/kminmer_pmc.txt"):
+    m = re.match(r"\s*(\S+) n=\s*(\d+) sum=\s*([0-9.]+) avg=\s*([0-9.]+)\s+(\S+)", line)
+    if not m:
+        continue
+    c, cnt, s, kern = m.group(1), int(m.group(2)), float(m.group(3)), m.group(5)
+    if "fillBuffer" in kern or "scan_" in kern and "kernel" in kern and "split" not in kern:
+        pass
+    tot[c] = tot.get(c, 0.0) + s
+    per_kernel.setdefault(kern[:60], {})[c] = s / passes
+def blob(path):
+    d = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(d) + d).hexdigest()
+fetch_kb, write_kb = tot.get("FETCH_SIZE", 0.0) / passes, tot.get("WRITE_SIZE", 0.0) / passes
+# FETCH_SIZE on gfx950 tallies a wide coalesced read request at 64 B where 128 B travel (the guide's HBM section): doubled, which
+# over-counts narrower requests -- an upper bound of the pass's read traffic; WRITE_SIZE as reported
+traffic = fetch_kb * 1024 * 2.0 + write_kb * 1024
+json.dump({"round": 4, "kernels": "k = 4 first pass (csrc/partition.hip): every kernel between mark_starts and emit_rescued_p, incl. memsets and prefix scans",
+           "workload": f"{n} x 10000 bp synthetic HiFi reads, one pass, one context alone", "reads": n, "read_len": 10000,
+           "command": "rocprofv3 --kernel-trace --pmc <counter> (separate passes) -- python tools/insert_once.py", "passes_summed": passes,
+           "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "gfx950_fetch_correction": 2.0, "traffic_bytes_per_pass": traffic,
+           "traffic_bytes_per_pass_uncorrected": fetch_kb * 1024 + write_kb * 1024,
+           "counters_per_pass": {k: v / passes for k, v in tot.items()}, "per_kernel_per_pass": per_kernel,
+           "blobs": {f: blob(f"metamdbg_amd/csrc/{f}") for f in ("partition.hip", "kminmer.hip")},
+           "note": "FETCH_SIZE doubled as the guide prescribes for wide coalesced reads on gfx950 (an upper bound here: the record streams are 8- and 4-byte loads per lane); "
+                   "WRITE_SIZE as reported; the split levels' exact byte counts calibrate both: split_hist<false> reads 8 B per instance, split_scatter<false> reads and "
+                   "writes 20 B per instance"}, open(f"{out}/kminmer_traffic.json", "w"), indent=1)
+print(open(f"{out}/kminmer_traffic.json").read()[:1500])
+PY
