@@ -1,4 +1,4 @@
-"""Two real ranks of bench.py's sharded step on ONE GPU (every rank on device 0, exchanges staged through the host with
+"""Two, four and eight real ranks of bench.py's sharded step on ONE GPU (every rank on device 0, exchanges staged through the host with
 gloo -- RCCL refuses two ranks per device): the whole multi-rank orchestration (shard begin / reduce / finish, the two
 all-to-alls, two batches in flight taking turns on the communicator) must give, summed over the ranks, exactly the
 table of one rank over the same reads."""
@@ -31,33 +31,70 @@ def _bench(extra_env: dict, args: list[str], nproc: int | None, expect_failure: 
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("in_flight", [1, 2, 3])
-def test_two_ranks_equal_one(in_flight):
+@pytest.mark.parametrize("nproc,in_flight", [(2, 1), (2, 2), (2, 3), (4, 2), (8, 2)])
+def test_ranks_equal_one(nproc, in_flight):
+    """2, 4 and 8 real processes (round-3 VERDICT: more than two had only ever been emulated inside one process): the 8 x 8 count
+    matrix, the owner map at 8 and the turn-taking of the batches in flight on every rank, against one rank over the same reads."""
     n = 40_000
     common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
-    one = _bench({}, ["--gpus", "1", "--reads", str(2 * n)] + common, None)
-    two = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}, ["--gpus", "2", "--reads", str(n)] + common, 2)
-    assert two["n_gpus"] == 2
-    assert two["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
-    assert two["config"]["solid"] == one["config"]["solid"] > 0
+    one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}, ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
+    assert many["n_gpus"] == nproc and many["scaling"] == "weak"
+    assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
+    assert many["config"]["solid"] == one["config"]["solid"] > 0
     # the N > 1 line checks itself: rank 0 repeats the pass alone over all the reads and compares with the summed shares
-    par = two["parity"]
-    assert par["table_equal"] and par["reads"] == 2 * n and par["records_equal"] and par["abundance_checksum_equal"]
+    par = many["parity"]
+    assert par["table_equal"] and par["reads"] == nproc * n and par["records_equal"] and par["abundance_checksum_equal"]
     assert par["single_gpu"]["records"] == one["config"]["kminmer_records"]
-    ex = two["config"]["exchange"]
-    assert ex["ranks"] == 2 and ex["wire_bytes_per_step"] > 0 and ex["exchanges_timed"] == 2 * 3 and ex["exchange_ms_per_step"] > 0
+    assert par["single_gpu_gbps"] > 0 and par["single_gpu_pass_seconds"] > 0
+    ex = many["config"]["exchange"]
+    assert ex["ranks"] == nproc and ex["wire_bytes_per_step"] > 0 and ex["exchanges_timed"] == nproc * 3 and ex["exchange_ms_per_step"] > 0
 
 
-def test_two_ranks_with_a_corrupted_reply_fail_the_run():
+def test_strong_scaling_over_one_read_set():
+    """--total-reads: ONE read set split over the ranks (north_star's "40 M reads sharded 8 ways at 1 / 2 / 4 / 8 GPUs" is a curve over a
+    fixed set): 4 ranks x 30 000 reads give the table of 1 rank x 120 000, and the line carries the single-GPU throughput of rank 0's
+    verification pass -- the N = 1 point of that curve."""
+    total = 120_000
+    common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--total-reads", str(total)]
+    one = _bench({}, ["--gpus", "1"] + common, None)
+    four = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}, ["--gpus", "4"] + common, 4)
+    assert one["scaling"] == four["scaling"] == "strong"
+    assert one["config"]["reads_per_gpu"] == total and four["config"]["reads_per_gpu"] == total // 4
+    assert four["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
+    assert four["parity"]["table_equal"] and four["parity"]["reads"] == total and four["parity"]["single_gpu_gbps"] > 0
+
+
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_ranks_with_a_corrupted_reply_fail_the_run(nproc):
     """MDBG_BENCH_CORRUPT_REPLY=1: one global count of the verification step is off by one on the last rank -- the line still comes
     out, its parity block says the tables do not add up, and the run exits non-zero."""
     n = 40_000
     common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "2"]
-    two = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_CORRUPT_REPLY": "1"},
-                 ["--gpus", "2", "--reads", str(n)] + common, 2, expect_failure=True)
-    par = two["parity"]
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_CORRUPT_REPLY": "1"},
+                  ["--gpus", str(nproc), "--reads", str(n)] + common, nproc, expect_failure=True)
+    par = many["parity"]
     assert not par["table_equal"] and par["minimizers_equal"]
     assert not (par["abundance_checksum_equal"] and par["sum_abundance_equal"] and par["solid_equal"] and par["records_equal"])
+
+
+def test_a_rank_that_fails_in_the_reduction_ends_the_job_of_eight():
+    """MDBG_BENCH_FAIL_RANK=5: rank 5 of 8 fails summing the rows it owns (the second phase of an exchange) in the verification step.
+    Every rank hears of it in the agreement that follows (metamdbg_amd/distributed.py agree / guarded; mdbg_shard_exchange does the
+    same inside the library) and the job ends non-zero within seconds -- nobody waits for replies that will never come."""
+    import time
+    n = 20_000
+    env = dict(os.environ, MDBG_BENCH_SHARE_GPU="1", MDBG_BENCH_BACKEND="gloo", MDBG_BENCH_FAIL_RANK="5", MDBG_BENCH_DEADLINE_S="200")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--reads", str(n), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none"]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode != 0 and time.time() - t0 < 200
+    assert "test failure on rank 5" in out.stderr and "rank 5 failed summing the rows it owns" in out.stderr, out.stderr[-3000:]
+    assert "deadline" not in out.stderr                       # ended by the protocol, not by the watchdog
 
 
 def test_library_rccl_exchange_two_gpus(tmp_path):
