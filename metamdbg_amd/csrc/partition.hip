@@ -9,9 +9,9 @@
 //   1. mark_starts_kernel      one bit per minimizer: "a sequence starts here" -- a window of k minimizers is an instance iff no
 //                              start lies inside it, so the passes below walk the FLAT minimizer array, fully coalesced
 //   2. split (hist + scatter)  a radix multisplit of instance records {hash_lo, hash_hi, rep} (rep = flat index of the window's
-//                              first minimizer) by bits of hash_lo, <= 256 ways per level, one to three levels.  Level 1 computes
-//                              the records from the minimizers (twice: histogram and scatter; hashing is cheaper than a
-//                              round trip of the records through HBM); deeper levels split every bucket of the level above.
+//                              first minimizer), <= 256 ways per level, one to three levels.  Level 1 makes the records from the
+//                              minimizers and splits them by a cheap symmetric mix of the window (window_mix: the histogram pass
+//                              need not compute the identity); deeper levels split every bucket of the level above by bits of hash_lo.
 //                              Per-block LDS histograms + one device-wide exclusive scan give every (block, digit) its place:
 //                              no global atomic, and a block writes one growing run per digit (tiles are regrouped by digit in
 //                              LDS first, so the stores are runs of TILE / ways records)
@@ -35,8 +35,14 @@
 
 namespace mdbg {
 
-constexpr uint32_t PART_NT = 512;                      // threads per block of the split kernels
-constexpr uint32_t PART_E = 8;                         // records per thread and tile
+#ifndef MDBG_PART_NT
+#define MDBG_PART_NT 512
+#endif
+#ifndef MDBG_PART_E
+#define MDBG_PART_E 8
+#endif
+constexpr uint32_t PART_NT = MDBG_PART_NT;             // threads per block of the split kernels
+constexpr uint32_t PART_E = MDBG_PART_E;               // records per thread and tile
 constexpr uint32_t PART_TILE = PART_NT * PART_E;       // 4096 records regrouped in LDS at a time
 constexpr uint32_t PART_MAXW = 256;                    // ways per level
 // bucket_count remembers the LDS slot of a bucket's first records between its two passes: 8000 of them beside 1024 slots (not 8192:
@@ -56,15 +62,15 @@ struct SplitArgs {
     const uint64_t *seg_pos; uint32_t seg_stride;
     uint32_t blocks_per_seg;
     uint32_t tile;                                     // a block's share of a segment is a multiple of this (the scatter's tile)
-    uint32_t shift, ways;                              // digit = (hash_lo >> shift) & (ways - 1)
+    uint32_t shift, ways;                              // digit = (hash_lo >> shift) & (ways - 1); level 1: the top bits of window_mix
+    uint32_t mix_bits;                                 // level 1: log2(ways) (digit = window_mix >> (64 - mix_bits); 0 bits: one way)
     uint8_t *hll;                                      // level-1 histogram: HLL_M registers per block, see hll_estimate (null: not wanted)
 };
 
 // How many distinct keys are there?  The plan (buckets so that a bucket's keys fit its LDS table) needs to know before the first
 // record is written, and a first pass is usually the only one its process ever runs: nothing to learn from.  The level-1 histogram
-// hashes every instance anyway, so it keeps a HyperLogLog sketch on the side (Flajolet et al. 2007: register = top HLL_P bits of
-// hash_hi -- the split uses hash_lo --, value = position of the first set bit of the rest; one LDS atomic max per instance):
-// 2048 registers, standard error 2.3 %.
+// mixes every instance anyway (window_mix), so it keeps a HyperLogLog sketch on the side (Flajolet et al. 2007: register = 11 bits of
+// the mix, value = position of the first set bit of 56 others; one LDS atomic max per instance): 2048 registers, standard error 2.3 %.
 constexpr uint32_t HLL_P = 11, HLL_M = 1u << HLL_P;
 
 __global__ __launch_bounds__(256) void mark_starts_kernel(const uint64_t *off, uint32_t n_reads, uint32_t *bits) {
@@ -75,8 +81,8 @@ __global__ __launch_bounds__(256) void mark_starts_kernel(const uint64_t *off, u
     atomicOr(&bits[p >> 5], 1u << (p & 31u));
 }
 
-// is there an instance at flat position p?  If so its identity.
-__device__ __forceinline__ bool window_at(const SplitArgs &a, uint64_t p, uint64_t &hi, uint64_t &lo) {
+// is there an instance at flat position p?
+__device__ __forceinline__ bool window_valid(const SplitArgs &a, uint64_t p) {
     if (p + a.k > a.n_min) return false;
     if (a.k > 1) {
         const uint64_t q = p + 1;
@@ -84,12 +90,36 @@ __device__ __forceinline__ bool window_at(const SplitArgs &a, uint64_t p, uint64
         const uint64_t x = (((uint64_t)a.start_bits[w + 1] << 32) | a.start_bits[w]) >> sh;   // bits q .. q + 32 at least
         if (x & ((1ull << (a.k - 1)) - 1ull)) return false;
     }
+    return true;
+}
+
+// ... if so its identity.
+__device__ __forceinline__ bool window_at(const SplitArgs &a, uint64_t p, uint64_t &hi, uint64_t &lo) {
+    if (!window_valid(a, p)) return false;
     window_hash_uniform(a.mins + p, a.k, hi, lo);
     return true;
 }
 
 __device__ __forceinline__ bool in_group(const SplitArgs &a, uint64_t lo) {
     return !a.group_bits || (lo >> (64u - a.group_bits)) == a.group;
+}
+
+// Level 1 does not split by bits of the identity: all it needs is SOME function of the key, the same in the histogram and in the
+// scatter, and the identity costs a hundred vector instructions per window (Murmur3 x64-128) that the histogram pass would spend a
+// second time.  This one is a fifth of that: the window read from both ends, every pair (m[i], m[k-1-i]) folded in through its sum
+// and its xor -- both symmetric, so a window and its reverse (one key: KmerVec::normalize, Commons.hpp:886-916) mix alike without
+// being oriented first -- into one 64-bit multiply-xorshift chain.  Its top bits are the level-1 digit, the sketch (hll_estimate)
+// takes register and rank from it as well.  Deeper levels and the buckets' tables use the identity's own bits.
+__device__ __forceinline__ uint64_t window_mix(const uint32_t *m, uint32_t k) {
+    uint64_t acc = 0x9E3779B97F4A7C15ull ^ k;
+    for (uint32_t i = 0; i < k / 2; i++) {
+        const uint32_t x = m[i], y = m[k - 1 - i];
+        acc = (acc ^ ((uint64_t)(x + y) | ((uint64_t)(x ^ y) << 32))) * 0xff51afd7ed558ccdull;
+        acc ^= acc >> 29;
+    }
+    if (k & 1u) { acc = (acc ^ m[k / 2]) * 0xc4ceb9fe1a85ec53ull; acc ^= acc >> 29; }
+    acc *= 0xc4ceb9fe1a85ec53ull;
+    return acc ^ (acc >> 32);
 }
 
 __device__ __forceinline__ void split_range(const SplitArgs &a, uint32_t &seg, uint32_t &j, uint64_t &b, uint64_t &e) {
@@ -127,11 +157,18 @@ __global__ __launch_bounds__(PART_NT) void split_hist_kernel(SplitArgs a, uint32
                 uint64_t lo, hi;
                 bool valid = true;
                 if (FROM_MINS) {
-                    valid = window_at(a, i, hi, lo);
-                    if (valid && sketching) atomicMax(&sketch[(uint32_t)(hi >> (64u - HLL_P))], (uint32_t)__clzll((long long)((hi << HLL_P) | 1ull)) + 1u);
-                    valid = valid && in_group(a, lo);
-                } else lo = a.in.lo[i];
-                if (valid) digit[q] = (uint32_t)(lo >> a.shift) & (a.ways - 1u);
+                    valid = window_valid(a, i);
+                    if (valid) {
+                        const uint64_t x = window_mix(a.mins + i, a.k);
+                        // (register from the low half, rank from the high one: the digit takes the top bits)
+                        if (sketching) atomicMax(&sketch[(uint32_t)x & (HLL_M - 1u)], (uint32_t)__clzll((long long)((x << 8) | 1ull)) + 1u);
+                        if (a.group_bits) { window_hash_uniform(a.mins + i, a.k, hi, lo); valid = in_group(a, lo); }   // key groups: by the identity
+                        if (valid) digit[q] = a.mix_bits ? (uint32_t)(x >> (64u - a.mix_bits)) : 0u;
+                    }
+                } else {
+                    lo = a.in.lo[i];
+                    digit[q] = (uint32_t)(lo >> a.shift) & (a.ways - 1u);
+                }
             }
         }
 #pragma unroll
@@ -142,12 +179,13 @@ __global__ __launch_bounds__(PART_NT) void split_hist_kernel(SplitArgs a, uint32
     if (sketching) for (uint32_t t = threadIdx.x; t < HLL_M; t += PART_NT) a.hll[(uint64_t)blockIdx.x * HLL_M + t] = (uint8_t)sketch[t];
 }
 
-__global__ __launch_bounds__(256) void hll_merge_kernel(const uint8_t *per_block, uint32_t n_blocks, uint8_t *merged) {
+// (64 slices of the blocks per register, merged by atomic max: one thread per register walking all 2048 blocks took 0.8 ms)
+__global__ __launch_bounds__(256) void hll_merge_kernel(const uint8_t *per_block, uint32_t n_blocks, uint32_t *merged) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= HLL_M) return;
     uint32_t m = 0;
-    for (uint32_t b = 0; b < n_blocks; b++) { const uint32_t v = per_block[(uint64_t)b * HLL_M + r]; m = v > m ? v : m; }
-    merged[r] = (uint8_t)m;
+    for (uint32_t b = blockIdx.y; b < n_blocks; b += gridDim.y) { const uint32_t v = per_block[(uint64_t)b * HLL_M + r]; m = v > m ? v : m; }
+    if (m) atomicMax(&merged[r], m);
 }
 
 // E records per thread and tile: 8 (tiles of 4096: runs of 16 records per digit and tile at 256 ways) when the kernel has the device to
@@ -181,7 +219,8 @@ __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, con
             }
             meta[q] = 0;
             if (valid) {
-                const uint32_t d = (uint32_t)(lo[q] >> a.shift) & (a.ways - 1u);
+                const uint32_t d = FROM_MINS ? (a.mix_bits ? (uint32_t)(window_mix(a.mins + i, a.k) >> (64u - a.mix_bits)) : 0u)
+                                             : ((uint32_t)(lo[q] >> a.shift) & (a.ways - 1u));
                 meta[q] = d | (atomicAdd(&h[d], 1u) << 8) | 0x80000000u;
             }
         }
@@ -213,18 +252,36 @@ __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, con
             }
         }
         __syncthreads();
+#if !defined(MDBG_PART_ABLATE)
         for (uint32_t s = tid; s < n_tile; s += PART_NT) out.lo[gbase[stage_digit[s]] + s] = stage[s];
+#elif MDBG_PART_ABLATE == 1
+        for (uint32_t s = tid; s < n_tile; s += PART_NT) if (stage[s] == 0x123456789ull) out.lo[gbase[stage_digit[s]] + s] = stage[s];   // ablation: LDS work, no stores
+#elif MDBG_PART_ABLATE == 3
+        for (uint32_t s = tid; s < n_tile; s += PART_NT) out.lo[t0 - b + (place[0] & 1) + s] = stage[s];                                // ablation: stores in input order
+#endif
         __syncthreads();
 #pragma unroll
         for (uint32_t q = 0; q < E; q++) if (dst[q] != 0xFFFFFFFFu) stage[dst[q]] = hi[q];
         __syncthreads();
+#if !defined(MDBG_PART_ABLATE)
         for (uint32_t s = tid; s < n_tile; s += PART_NT) out.hi[gbase[stage_digit[s]] + s] = stage[s];
+#elif MDBG_PART_ABLATE == 1
+        for (uint32_t s = tid; s < n_tile; s += PART_NT) if (stage[s] == 0x123456789ull) out.hi[gbase[stage_digit[s]] + s] = stage[s];
+#elif MDBG_PART_ABLATE == 3
+        for (uint32_t s = tid; s < n_tile; s += PART_NT) out.hi[t0 - b + (place[0] & 1) + s] = stage[s];
+#endif
         __syncthreads();
         uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage);
 #pragma unroll
         for (uint32_t q = 0; q < E; q++) if (dst[q] != 0xFFFFFFFFu) stage32[dst[q]] = rep[q];
         __syncthreads();
+#if !defined(MDBG_PART_ABLATE)
         for (uint32_t s = tid; s < n_tile; s += PART_NT) out.rep[gbase[stage_digit[s]] + s] = stage32[s];
+#elif MDBG_PART_ABLATE == 1
+        for (uint32_t s = tid; s < n_tile; s += PART_NT) if (stage32[s] == 0x12345678u) out.rep[gbase[stage_digit[s]] + s] = stage32[s];
+#elif MDBG_PART_ABLATE == 3
+        for (uint32_t s = tid; s < n_tile; s += PART_NT) out.rep[t0 - b + (place[0] & 1) + s] = stage32[s];
+#endif
         __syncthreads();
     }
 }
@@ -383,38 +440,36 @@ __global__ __launch_bounds__(256) void emit_bucket_rows_kernel(RecView keys, con
 // The decision per read (see rescue_count_kernel in kminmer.hip for the derivation): "median * 0.1f > 1" is false iff at least
 // n/2 + 1 counts are <= m*, or -- n even -- exactly n/2 are and (max{<= m*} + min{> m*}) / 2 <= m*.  A count above 2 m* + 1 in
 // the second term gives a median above m* whatever the first is, so "many" needs no value.
+// One lane per read, its windows' bytes four at a time: the sixteen-lanes-a-read form of the one-table pass spent 270 M vector
+// instructions on cross-lane sums for 10 M reads (rocprofv3, round 4) -- instructions another batch's scan would have used.
 __global__ __launch_bounds__(256) void rescue_count_p_kernel(const uint64_t *off, uint32_t n_reads, uint32_t k, const uint8_t *cnt8,
                                                              uint32_t m_star, uint32_t *resc_cnt) {
-    const unsigned sub = threadIdx.x & 15u;
-    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
-    for (uint64_t r0 = 0; r0 < n_reads; r0 += ngroups) {       // uniform trip count: the shuffles need all lanes
-        const uint64_t r = r0 + group;
-        const bool live = r < n_reads;
-        const uint64_t f = live ? off[r] : 0;
-        const uint64_t len = live ? off[r + 1] - f : 0;
-        const uint32_t n = len >= k ? (uint32_t)(len - k + 1) : 0u;
-        uint32_t n_weak = 0, n_small = 0, n_big = 0, mx_le = 1u, mn_gt = 0xFFFFu;
-        for (uint32_t i = sub; i < n; i += 16) {
-            const uint32_t c = cnt8[f + i];
-            if (c == 0u || c > m_star) { n_big++; if (c != 0u && c < mn_gt) mn_gt = c; }
-            else { if (c <= 1u) n_weak++; else n_small++; if (c > mx_le) mx_le = c; }
-        }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) {
-            n_weak += __shfl_xor(n_weak, d, 64); n_small += __shfl_xor(n_small, d, 64); n_big += __shfl_xor(n_big, d, 64);
-            uint32_t x = __shfl_xor(mx_le, d, 64); mx_le = x > mx_le ? x : mx_le;
-            x = __shfl_xor(mn_gt, d, 64); mn_gt = x < mn_gt ? x : mn_gt;
-        }
-        const uint32_t c_le = n_weak + n_small, half = n / 2;
-        const bool any_solid = (n_small + n_big) != 0u;        // all-ones reads are skipped (:4612)
-        bool rescue = n && any_solid && c_le >= half + 1;
-        if (n && any_solid && (n & 1u) == 0u && c_le == half) {
-            const uint32_t median = (mx_le + mn_gt) / 2u;      // Utils::compute_median on u32 (Commons.hpp:2972-2988)
-            rescue = !((float)median * 0.1f > 1.0f);           // :4610
-        }
-        if (live && sub == 0) resc_cnt[r] = rescue ? n_weak : 0u;
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t f = off[r];
+    const uint64_t len = off[r + 1] - f;
+    const uint32_t n = len >= k ? (uint32_t)(len - k + 1) : 0u;
+    uint32_t n_weak = 0, n_small = 0, n_big = 0, mx_le = 1u, mn_gt = 0xFFFFu;
+    auto take = [&](uint32_t c) {
+        if (c == 0u || c > m_star) { n_big++; if (c != 0u && c < mn_gt) mn_gt = c; }
+        else { if (c <= 1u) n_weak++; else n_small++; if (c > mx_le) mx_le = c; }
+    };
+    uint32_t i = 0;
+    const uint8_t *p = cnt8 + f;
+    for (; i < n && ((uintptr_t)(p + i) & 3u); i++) take(p[i]);
+    for (; i + 4 <= n; i += 4) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(p + i);
+        take(w & 0xFFu); take((w >> 8) & 0xFFu); take((w >> 16) & 0xFFu); take(w >> 24);
     }
+    for (; i < n; i++) take(p[i]);
+    const uint32_t c_le = n_weak + n_small, half = n / 2;
+    const bool any_solid = (n_small + n_big) != 0u;            // all-ones reads are skipped (:4612)
+    bool rescue = n && any_solid && c_le >= half + 1;
+    if (n && any_solid && (n & 1u) == 0u && c_le == half) {
+        const uint32_t median = (mx_le + mn_gt) / 2u;          // Utils::compute_median on u32 (Commons.hpp:2972-2988)
+        rescue = !((float)median * 0.1f > 1.0f);               // :4610
+    }
+    resc_cnt[r] = rescue ? n_weak : 0u;
 }
 
 // rows of the rescued reads' count-1 instances, in read order then window order (abundance 1, :4630-4636)
@@ -477,7 +532,7 @@ struct GroupRows {
 };
 
 // HyperLogLog estimate from the merged registers, with the small-range (linear counting) correction
-static double hll_estimate(const uint8_t *regs) {
+static double hll_estimate(const uint32_t *regs) {
     double sum = 0;
     uint32_t zeros = 0;
     for (uint32_t j = 0; j < HLL_M; j++) { sum += std::ldexp(1.0, -(int)regs[j]); zeros += regs[j] == 0; }
@@ -537,16 +592,19 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
         uint64_t segs = 1;
         for (uint32_t l = 0; l < n_levels && l < 3; l++) {
             const uint32_t b = l == 0 ? std::min(left, 8u) : (left + (n_levels - l) - 1) / (n_levels - l);
-            lv[l].bits = b; lv[l].ways = 1u << b; lv[l].shift = 64u - used - b; lv[l].n_seg = segs;
-            if (used + b == 0) lv[l].shift = 0;         // one way: the digit is masked to 0 whatever the shift
-            used += b; left -= b; segs <<= b;
+            lv[l].bits = b; lv[l].ways = 1u << b; lv[l].n_seg = segs;
+            // level 1 splits by window_mix, the deeper levels by the bits of hash_lo below the key group's
+            lv[l].shift = (l == 0 || used + b == 0) ? 0u : 64u - used - b;      // (one way: the digit is masked to 0 whatever the shift)
+            if (l > 0) used += b;
+            left -= b; segs <<= b;
         }
     };
 
     RecBufs buf[2];
     DevBuf<uint32_t> kcnt, hist, n_keys, n_kept, overflow, resc_cnt;
     DevBuf<uint64_t> place[3], key_pos, row_of, resc_pos;
-    DevBuf<uint8_t> hll_blocks, hll_merged;
+    DevBuf<uint8_t> hll_blocks;
+    DevBuf<uint32_t> hll_merged;
     MDBG_TRY(overflow.alloc(ctx, 1));
     std::vector<GroupRows> group_rows;
     bool sketched = ctx->part_bits != 0;                // a forced plan needs no estimate
@@ -573,13 +631,13 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             a.mins = reads->d_min.p; a.start_bits = start_bits.p; a.n_min = M; a.k = k;
             a.group_bits = group_bits; a.group = g;
             // level 1: histogram, scan, the group's instance count, scatter
-            const uint32_t tile = ctx->part_tile == 2048 ? 2048u : PART_TILE;
+            const uint32_t tile = ctx->part_tile == 2048 ? PART_TILE / 2 : PART_TILE;
             const uint64_t tiles = (M + tile - 1) / tile;
             a.tile = tile;
             uint64_t I = 0, entries = 0;
             for (;;) {
                 lv[0].blocks_per_seg = (uint32_t)std::min<uint64_t>(tiles, 2048);
-                a.seg_pos = nullptr; a.seg_stride = 1; a.blocks_per_seg = lv[0].blocks_per_seg; a.shift = lv[0].shift; a.ways = lv[0].ways;
+                a.seg_pos = nullptr; a.seg_stride = 1; a.blocks_per_seg = lv[0].blocks_per_seg; a.shift = lv[0].shift; a.ways = lv[0].ways; a.mix_bits = lv[0].bits;
                 entries = (uint64_t)lv[0].ways * lv[0].blocks_per_seg;
                 MDBG_TRY(hist.alloc(ctx, entries));
                 MDBG_TRY(place[0].alloc(ctx, entries + 1));
@@ -587,27 +645,28 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
                 if (!sketched) {
                     MDBG_TRY(hll_blocks.alloc(ctx, (uint64_t)lv[0].blocks_per_seg * HLL_M));
                     MDBG_TRY(hll_merged.alloc(ctx, HLL_M));
+                    MDBG_HIP_CHECK(ctx, hipMemsetAsync(hll_merged.p, 0, HLL_M * 4, ctx->stream));
                     a.hll = hll_blocks.p;
                 }
                 {
                     LaunchTimer timer(ctx, "kminmer_split");
                     hipLaunchKernelGGL(split_hist_kernel<true>, dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, hist.p);
-                    if (a.hll) hipLaunchKernelGGL(hll_merge_kernel, dim3(HLL_M / 256), dim3(256), 0, ctx->stream, hll_blocks.p, lv[0].blocks_per_seg, hll_merged.p);
+                    if (a.hll) hipLaunchKernelGGL(hll_merge_kernel, dim3(HLL_M / 256, 64), dim3(256), 0, ctx->stream, hll_blocks.p, lv[0].blocks_per_seg, hll_merged.p);
                 }
                 MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[0].p, entries));
-                uint8_t regs[HLL_M];
-                if (a.hll) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(regs, hll_merged.p, HLL_M, hipMemcpyDeviceToHost, ctx->stream));
+                uint32_t regs[HLL_M];
+                if (a.hll) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(regs, hll_merged.p, HLL_M * 4, hipMemcpyDeviceToHost, ctx->stream));
                 MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &I, place[0].p + entries, 8, hipMemcpyDeviceToHost));
                 if (!a.hll) break;
                 // the sketch saw every key of every group: plan on it (+8 %: three and a half standard errors); the histogram is
                 // only repeated when that changes level 1, i.e. for inputs of fewer keys than 2^8 buckets hold
                 sketched = true;
-                const uint32_t old_bits = lv[0].bits, old_shift = lv[0].shift;
+                const uint32_t old_bits = lv[0].bits;
                 keys_est = std::max(1.0, 1.08 * hll_estimate(regs));
                 plan(extra_bits);
                 MDBG_DBG(ctx, "partitioned first pass: about %.0f distinct keys", keys_est / 1.08);
                 if (bucket_bits > 24) return MDBG_OK;
-                if (lv[0].bits == old_bits && lv[0].shift == old_shift) break;
+                if (lv[0].bits == old_bits) break;
             }
             total_inst += I;
             n_buckets = 1ull << bucket_bits;
@@ -629,8 +688,8 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             if (kcnt.n < I || !kcnt.p) MDBG_TRY(kcnt.alloc(ctx, I));
             {
                 LaunchTimer timer(ctx, "kminmer_split");
-                if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<true, 4>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
-                else hipLaunchKernelGGL((split_scatter_kernel<true, 8>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
+                if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<true, PART_E / 2>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
+                else hipLaunchKernelGGL((split_scatter_kernel<true, PART_E>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
             }
             // deeper levels
             uint32_t cur = 0;
@@ -653,8 +712,8 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
                 MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[l].p, entries));
                 {
                     LaunchTimer timer(ctx, "kminmer_split");
-                    if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<false, 4>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
-                    else hipLaunchKernelGGL((split_scatter_kernel<false, 8>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+                    if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<false, PART_E / 2>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+                    else hipLaunchKernelGGL((split_scatter_kernel<false, PART_E>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
                 }
                 cur ^= 1;
             }
@@ -701,8 +760,7 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             MDBG_TRY(resc_pos.alloc(ctx, (size_t)n_reads + 1));
             {
                 LaunchTimer timer(ctx, "kminmer_rescue");
-                const unsigned blocks = grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
-                hipLaunchKernelGGL(rescue_count_p_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_off.p, n_reads, k, cnt8.p, m_star, resc_cnt.p);
+                hipLaunchKernelGGL(rescue_count_p_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, reads->d_off.p, n_reads, k, cnt8.p, m_star, resc_cnt.p);
             }
             MDBG_TRY(exclusive_scan_u32(ctx, resc_cnt.p, resc_pos.p, n_reads));
             MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&n_resc, resc_pos.p + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
