@@ -137,7 +137,7 @@ struct mdbg_ctx {
     double key_ratio_hint[4] = {0.0625, 0.0625, 0.0625, 0.0625};   // [0] first pass, [1] refined, [2] index, [3] sharded first pass
     // the first pass (k = firstK): instances partitioned by key and counted in LDS (partition.hip) or one global table (kminmer.hip)
     int first_pass_mode = 0;                // 0: by size (partitioned from part_auto_min instances up), 1: one table, 2: partitioned
-    uint64_t part_auto_min = 1ull << 22;    // mode 0: fewer minimizers than this take the one-table path
+    uint64_t part_auto_min = 1ull << 17;    // mode 0: fewer minimizers than this take the one-table path (50 000 reads: 0.18 against 0.25 ms)
     uint32_t part_bits = 0;                 // > 0: bucket bits of the first attempt (tests; default: from the key hint)
     uint32_t part_lds_slots = 0;            // 0: 1024 or 2048 by the key hint; 256 / 1024 / 2048: forced (tests)
     uint64_t part_max_records = 0;          // > 0: instances per group of keys (tests; default: a quarter of the HBM)

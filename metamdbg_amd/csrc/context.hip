@@ -182,7 +182,7 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (n == "scan_candidate_slack") { ctx->scan_cand_slack = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 24) : 0u; return MDBG_OK; }
     if (n == "scan_reads_per_wave") { ctx->scan_reads_per_wave = value > 0 ? (unsigned)std::min<int64_t>(value, 1 << 20) : 2u; return MDBG_OK; }
     if (n == "first_pass_mode") { ctx->first_pass_mode = (int)std::max<int64_t>(0, std::min<int64_t>(2, value)); return MDBG_OK; }
-    if (n == "partition_auto_min") { ctx->part_auto_min = value > 0 ? (uint64_t)value : (1ull << 22); return MDBG_OK; }
+    if (n == "partition_auto_min") { ctx->part_auto_min = value > 0 ? (uint64_t)value : (1ull << 17); return MDBG_OK; }
     if (n == "partition_bits") { ctx->part_bits = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(24, value)); return MDBG_OK; }
     if (n == "partition_lds_slots") {
         if (value != 0 && value != 256 && value != 1024 && value != 2048) return set_error(ctx, MDBG_EINVAL, "partition_lds_slots: 0, 256, 1024 or 2048");

@@ -1022,7 +1022,8 @@ def test_few_marked_reads_are_routed_one_by_one(ctx, orc):
 def test_context_options_do_not_change_results(ctx):
     """The tuning options of mdbg_set_option change how the work is laid out on the device, never what comes out: the table kernels
     as a handful of workgroups (table_grid_blocks) or one block per CU, every kernel but the block-structured scan confined to 16 CUs
-    with the scan on a stream of its own (table_cu_count), the memory pool trimmed or allowed 90 % of the device."""
+    with the scan on a stream of its own (table_cu_count), the memory pool trimmed or allowed 90 % of the device, the scan capped at four or
+    three blocks per CU by unused LDS (scan_lds_pad), the first pass on one table or partitioned in either of its kernel forms."""
     from metamdbg_amd import capi
     spec = synth.hifi_spec(4000, seed=61, read_len=8000, coverage=30.0)
     base = capi.Context(0)
@@ -1031,7 +1032,11 @@ def test_context_options_do_not_change_results(ctx):
     corr = base.purge_palindromes(base.scan(reads, K=15, density=0.005, hpc=True), 4, 100)
     want = (base.kminmer_count_first(corr, 4, 0).checksum(), base.kminmer_index(corr, None, 6, base.kminmer_count_refined(corr, None, 5, base.kminmer_count_first(corr, 4, 0))).checksum())
     for options in ({"table_grid_blocks": 7}, {"table_blocks_per_cu": 1}, {"table_cu_count": 16}, {"table_cu_count": 16, "table_grid_blocks": 64},
-                    {"pool_cache_percent": 90, "pool_trim": 1}, {"scan_reads_per_wave": 5}):
+                    {"pool_cache_percent": 90, "pool_trim": 1}, {"scan_reads_per_wave": 5},
+                    # round 4: what a context sharing its device with another batch's scan is given (bench.py), and the first pass's two paths
+                    {"scan_lds_pad": 3072, "partition_tile": 2048, "partition_slot_list": 0}, {"scan_lds_pad": 10304},
+                    {"first_pass_mode": 1}, {"first_pass_mode": 2}, {"first_pass_mode": 2, "partition_tile": 2048, "partition_slot_list": 0},
+                    {"first_pass_mode": 2, "partition_lds_slots": 2048, "partition_slot_list": 0}, {"partition_auto_min": 1}):
         c = capi.Context(0)
         for name, value in options.items():
             c.set_option(name, value)
