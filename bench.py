@@ -361,7 +361,8 @@ def shard_self_check(ctx, corr, ks, n_shards: int = 2) -> dict:
     union of the shards' shares -- record count, solid count and the four order-independent sums of mdbg_table_checksum (sums[0] is
     the `Checksum kminmer abundance` the reference logs, graph/CreateMdbg.cpp:3321, :3397).  k = firstK: the whole set takes
     mdbg_kminmer_count_first (the partitioned pass at these sizes), the shards the sharded pass (mdbg_shard_begin -> exchange ->
-    _finish: one table per shard, counts summed by key owner) -- two implementations that share no counting code.  k > firstK: every
+    _finish: counts summed by key owner), their local passes alternating between one table in HBM and the partitioned pass -- so the whole
+    set's table is also checked against an implementation that shares no counting code with it.  k > firstK: every
     shard runs the refined / index pass over its own reads against the WHOLE previous table and the shards settle who lists a key
     (mdbg_shard_from_table -> exchange -> _keep), as the ranks of an N-GPU job do.  The exchanges are the library's, with
     device-to-device copies for the wire (mdbg_shard_exchange_local)."""
@@ -375,7 +376,11 @@ def shard_self_check(ctx, corr, ks, n_shards: int = 2) -> dict:
         for k in ks:
             if k == ks[0]:
                 whole = ctx.kminmer_count_first(corr, k, 0)
-                shards = [ctx.shard_begin(h, k, n_shards) for h in halves]
+                shards = []
+                for i, h in enumerate(halves):                 # the shards' local passes alternate: one table in HBM, partitioned
+                    ctx.set_option("first_pass_mode", 1 if i % 2 == 0 else 2)
+                    shards.append(ctx.shard_begin(h, k, n_shards))
+                ctx.set_option("first_pass_mode", 0)
                 replies = capi.exchange_local(ctx, shards)
                 shares = [sh.finish(rep, 0) for sh, rep in zip(shards, replies)]
             else:
@@ -932,6 +937,7 @@ def run_alone(ctx) -> None:
     ctx.set_option("scan_lds_pad", 0)
     ctx.set_option("partition_tile", 0)
     ctx.set_option("partition_slot_list", 1)
+    ctx.set_option("partition_lds_slots", 0)
 
 
 def kminmer_traffic(reads: int, read_len: int):
@@ -1107,7 +1113,9 @@ def main() -> None:
     # 1.7 %), and the first pass's kernels take their 24 KB forms ("partition_tile" 2048, "partition_slot_list" 0).
     # tools/overlap_matrix.sh, profiles/round4_*_overlap_matrix.txt.
     shared_opts = {"scan_lds_pad": int(os.environ.get("MDBG_BENCH_SCAN_LDS_PAD", "3072")), "partition_tile": int(os.environ.get("MDBG_BENCH_PARTITION_TILE", "2048")),
-                   "partition_slot_list": int(os.environ.get("MDBG_BENCH_PARTITION_SLOT_LIST", "0"))} if n_slots > 1 else {}
+                   "partition_slot_list": int(os.environ.get("MDBG_BENCH_PARTITION_SLOT_LIST", "0")),
+                   # (buckets of 1024 slots: 24.6 KB; a bucket of 2048 -- what the plan may prefer for many keys per instance -- is 49 KB and would wait)
+                   "partition_lds_slots": int(os.environ.get("MDBG_BENCH_PARTITION_LDS_SLOTS", "1024"))} if n_slots > 1 else {}
 
     def configure_shared(c):
         c.set_option("table_blocks_per_cu", table_blocks)

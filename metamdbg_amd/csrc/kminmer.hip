@@ -1166,6 +1166,15 @@ __global__ __launch_bounds__(256) void table_owner_scatter_kernel(const uint64_t
     }
 }
 
+// the sharded first pass on the partitioned machinery: reply i belongs to local key row_index[i]
+__global__ void replies_to_keys_kernel(const uint64_t *reply, const uint32_t *row_index, uint64_t n, uint32_t min_abundance, uint32_t *gcount, uint32_t *listed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = (uint32_t)reply[i], key = row_index[i];
+    gcount[key] = v;
+    listed[key] = ((reply[i] & SHARD_EMIT_BIT) != 0ull && v > 1u && !(v < min_abundance)) ? 1u : 0u;
+}
+
 __global__ void keep_flag_kernel(const uint64_t *reply, const uint32_t *row_index, uint64_t n, uint32_t *flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[row_index[i]] = (reply[i] & SHARD_EMIT_BIT) ? 1u : 0u;
@@ -1194,6 +1203,9 @@ struct mdbg_shard {
     mdbg::DevBuf<uint64_t> local_replies;    // mdbg_shard_exchange_local: the replies to this shard's rows
     uint64_t n_rows = 0;
     bool reduced = false;
+    // the rank's share counted by the partitioned pass (csrc/partition.hip) instead of a local table: its distinct keys are the rows
+    mdbg::PartLocal *part = nullptr;
+    ~mdbg_shard() { if (part) mdbg::part_local_free(part); }
 };
 
 extern "C" uint32_t mdbg_row_words(uint32_t) { return mdbg::SHARD_ROW_WORDS; }
@@ -1206,6 +1218,44 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<mdbg_shard> sh(new mdbg_shard());
     sh->k = k; sh->n_ranks = n_ranks; sh->reads = reads;
+    // the rank's share through the partitioned pass (as mdbg_kminmer_count_first chooses): its distinct keys with their local counts come out
+    // bucket after bucket and are grouped by owner like the rows of a finished table (mdbg_shard_from_table)
+    if (ctx->first_pass_mode == 2 || (ctx->first_pass_mode == 0 && reads->n_min >= ctx->part_auto_min)) {
+        bool done = false;
+        MDBG_TRY(part_local_keys(ctx, reads, k, &sh->part, &done));
+        if (done) {
+            const uint64_t *klo, *khi; const uint32_t *kcnt; uint64_t n = 0, n_inst = 0;
+            part_local_arrays(sh->part, &klo, &khi, &kcnt, &n, &n_inst);
+            if (n >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 distinct local keys");
+            const unsigned nb = grid_for(n, SHARD_RPB);
+            const uint64_t nh = (uint64_t)nb * n_ranks;
+            DevBuf<uint32_t> block_hist;
+            DevBuf<uint64_t> block_base;
+            MDBG_TRY(block_hist.alloc(ctx, nh));
+            MDBG_TRY(block_base.alloc(ctx, nh + 1));
+            {
+                LaunchTimer timer(ctx, "shard_rows");
+                hipLaunchKernelGGL(table_owner_hist_kernel, dim3(nb), dim3(256), 0, ctx->stream, khi, n, n_ranks, block_hist.p);
+            }
+            MDBG_TRY(exclusive_scan_u32(ctx, block_hist.p, block_base.p, nh));
+            std::vector<uint64_t> base(nh + 1);
+            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, base.data(), block_base.p, (nh + 1) * 8, hipMemcpyDeviceToHost));
+            for (uint32_t r = 0; r < n_ranks; r++) counts[r] = base[(uint64_t)(r + 1) * nb] - base[(uint64_t)r * nb];
+            update_key_hint(ctx, 3, n, n_inst);
+            MDBG_TRY(sh->rows.alloc(ctx, n * SHARD_ROW_WORDS));
+            MDBG_TRY(sh->row_index.alloc(ctx, n));
+            sh->n_rows = n;
+            {
+                LaunchTimer timer(ctx, "shard_rows");
+                hipLaunchKernelGGL(table_owner_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, klo, khi, kcnt, n, n_ranks, block_base.p, sh->rows.p, sh->row_index.p);
+            }
+            MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            MDBG_DBG(ctx, "shard_begin (partitioned): %llu rows", (unsigned long long)n);
+            *d_rows = sh->rows.p;
+            *out = sh.release();
+            return MDBG_OK;
+        }
+    }
     MDBG_TRY(build_inst_index(ctx, reads, k, sh->ix));
     const uint64_t I = sh->ix.total;
     MDBG_DBG(ctx, "shard_begin: %llu instances", (unsigned long long)I);
@@ -1299,6 +1349,16 @@ extern "C" int mdbg_shard_finish(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
     if (!ctx || !sh || !out || (sh->n_rows && !d_replies)) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: bad argument");
     if (!sh->reduced) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_finish: mdbg_shard_reduce has not run");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (sh->part) {
+        // the replies, row by row, back to the order of the local keys: global count, and whether this rank lists the key
+        DevBuf<uint32_t> gcount, listed;
+        MDBG_TRY(gcount.alloc(ctx, sh->n_rows));
+        MDBG_TRY(listed.alloc(ctx, sh->n_rows));
+        if (sh->n_rows)
+            hipLaunchKernelGGL(replies_to_keys_kernel, dim3(grid_for(sh->n_rows, 256)), dim3(256), 0, ctx->stream, d_replies, sh->row_index.p, sh->n_rows, min_abundance,
+                               gcount.p, listed.p);
+        return part_local_finish(ctx, sh->part, gcount.p, listed.p, min_abundance, out);
+    }
     const uint32_t k = sh->k;
     const uint64_t I = sh->ix.total;
     TableView lv = sh->local.view();

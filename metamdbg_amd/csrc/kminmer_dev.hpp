@@ -115,4 +115,13 @@ void update_key_hint(mdbg_ctx *ctx, int kind, uint64_t distinct, uint64_t instan
 // input is not for it (the caller takes the one-table path); otherwise *out holds the table.
 int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance, mdbg_table **out, bool *done);
 
+// partition.hip: the same for a rank's share of a sharded first pass.  part_local_keys: every distinct local key with its local count
+// (device arrays lo / hi / cnt, bucket after bucket) -- what mdbg_shard_begin groups by owner; part_local_finish: the table of this rank's
+// share from the keys' global counts and the keys it was told to list (listed[i] != 0), with its own reads rescued against the global counts.
+struct PartLocal;
+int part_local_keys(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, PartLocal **out, bool *done);
+void part_local_arrays(const PartLocal *p, const uint64_t **lo, const uint64_t **hi, const uint32_t **cnt, uint64_t *n, uint64_t *n_inst);
+int part_local_finish(mdbg_ctx *ctx, PartLocal *p, const uint32_t *gcount, const uint32_t *listed, uint32_t min_abundance, mdbg_table **out);
+void part_local_free(PartLocal *p);
+
 }  // namespace mdbg

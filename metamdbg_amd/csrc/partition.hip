@@ -501,6 +501,72 @@ __global__ __launch_bounds__(256) void emit_rescued_p_kernel(const uint64_t *off
     }
 }
 
+// ---- the sharded first pass on the same buckets (mdbg_shard_begin / _finish) ------------------------------------------------------
+// every distinct local key of every bucket, bucket after bucket, as contiguous arrays (what goes to the owners as rows)
+__global__ __launch_bounds__(256) void gather_bucket_keys_kernel(RecView keys, const uint32_t *kcnt, const uint64_t *pos, uint32_t stride, const uint32_t *n_kept,
+                                                                 const uint64_t *row_of, unsigned long long *lo, unsigned long long *hi, uint32_t *cnt, uint32_t *rep) {
+    const uint64_t s0 = pos[(uint64_t)blockIdx.x * stride], d0 = row_of[blockIdx.x];
+    const uint32_t n = n_kept[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        lo[d0 + i] = keys.lo[s0 + i]; hi[d0 + i] = keys.hi[s0 + i]; cnt[d0 + i] = kcnt[s0 + i]; rep[d0 + i] = keys.rep[s0 + i];
+    }
+}
+
+// The counts of the keys summed over all ranks are back: one workgroup per bucket puts its keys with their GLOBAL counts into an LDS table
+// and walks the bucket's records once more -- cnt8[rep] = the global count of every instance whose key is rare (the rescue pass of the
+// local reads against the global counts, graph/CreateMdbg.hpp:4514-4640).
+template <uint32_t C>
+__global__ __launch_bounds__(BC_NT) void bucket_apply_kernel(RecView in, const uint64_t *pos, uint32_t stride, const uint64_t *row_of, const unsigned long long *c_lo,
+                                                             const unsigned long long *c_hi, const uint32_t *gcount, uint32_t clip, uint8_t *cnt8) {
+    __shared__ LdsTable<C> t;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t s0 = pos[(uint64_t)blockIdx.x * stride], s1 = pos[(uint64_t)(blockIdx.x + 1) * stride];
+    const uint64_t k0 = row_of[blockIdx.x], k1 = row_of[blockIdx.x + 1];
+    for (uint32_t s = tid; s < C; s += BC_NT) { t.lo[s] = 0ull; t.hi[s] = 0ull; t.cnt[s] = 0u; }
+    __syncthreads();
+    for (uint64_t i = k0 + tid; i < k1; i += BC_NT) {
+        const uint32_t s = lds_upsert<C>(t, c_lo[i], c_hi[i], 0u);      // the keys are distinct and fitted this table once already
+        if (s != LDS_NONE) t.cnt[s] = gcount[i];                        // (one thread per key: nobody else touches its slot)
+    }
+    __syncthreads();
+    const uint64_t n = s1 - s0;
+    for (uint64_t i0 = 0; i0 < n; i0 += BC_NT * BC_U) {
+        uint64_t lo[BC_U], hi[BC_U]; uint32_t rep[BC_U];
+#pragma unroll
+        for (uint32_t q = 0; q < BC_U; q++) {
+            const uint64_t i = i0 + (uint64_t)q * BC_NT + tid;
+            if (i < n) { lo[q] = in.lo[s0 + i]; hi[q] = in.hi[s0 + i]; rep[q] = in.rep[s0 + i]; }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < BC_U; q++) {
+            const uint64_t i = i0 + (uint64_t)q * BC_NT + tid;
+            if (i >= n) continue;
+            const uint32_t s = lds_find<C>(t, lo[q], hi[q]);
+            if (s == LDS_NONE) continue;
+            const uint32_t c = t.cnt[s];
+            if (c <= clip && c != 0u) cnt8[rep[q]] = (uint8_t)c;          // the array was filled with 0 = "many"
+        }
+    }
+}
+
+// rows of the keys this rank lists (flag), global counts, the vector through rep
+__global__ __launch_bounds__(256) void emit_listed_rows_kernel(const unsigned long long *c_lo, const unsigned long long *c_hi, const uint32_t *gcount, const uint32_t *c_rep,
+                                                               const uint32_t *flag, const uint64_t *row, uint64_t n, const uint32_t *mins, RowOut o) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint64_t r = row[i];
+    o.lo[r] = c_lo[i]; o.hi[r] = c_hi[i]; o.ab[r] = gcount[i];
+    const uint32_t *m = mins + c_rep[i];
+    bool reversed = true;
+    for (uint32_t q = 0; q < o.k; q++) {
+        const uint32_t x = m[q], y = m[o.k - 1 - q];
+        if (x == y) continue;
+        reversed = !(x < y);
+        break;
+    }
+    for (uint32_t q = 0; q < o.k; q++) o.vec[r * o.k + q] = reversed ? m[o.k - 1 - q] : m[q];
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------------------
 struct RecBufs {
     DevBuf<unsigned long long> lo, hi;
@@ -518,9 +584,9 @@ struct RecBufs {
 struct LevelPlan { uint32_t bits, shift, ways, blocks_per_seg; uint64_t n_seg; };
 
 template <uint32_t C, uint32_t LIST>
-static void launch_bucket_count(mdbg_ctx *ctx, uint64_t n_buckets, RecView in, const uint64_t *pos, uint32_t stride, uint32_t min_abundance, uint32_t clip,
+static void launch_bucket_count(mdbg_ctx *ctx, uint64_t n_buckets, RecView in, const uint64_t *pos, uint32_t stride, uint32_t min_abundance, uint32_t clip, int keep_all,
                                 RecView keys, uint32_t *kcnt, uint32_t *n_keys, uint32_t *n_kept, uint8_t *cnt8, uint32_t cnt8_default, uint32_t *overflow) {
-    hipLaunchKernelGGL((bucket_count_kernel<C, LIST>), dim3((unsigned)n_buckets), dim3(BC_NT), 0, ctx->stream, in, pos, stride, min_abundance, clip, 0, keys, kcnt,
+    hipLaunchKernelGGL((bucket_count_kernel<C, LIST>), dim3((unsigned)n_buckets), dim3(BC_NT), 0, ctx->stream, in, pos, stride, min_abundance, clip, keep_all, keys, kcnt,
                        n_keys, n_kept, cnt8, cnt8_default, overflow);
 }
 
@@ -542,48 +608,45 @@ static double hll_estimate(const uint32_t *regs) {
     return e;
 }
 
-int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance, mdbg_table **out, bool *done) {
-    *done = false;
-    const uint64_t M = reads->n_min;
-    const uint32_t n_reads = reads->n_reads;
-    if (k > PART_MAX_K || M < k || M >= (1ull << 32)) return MDBG_OK;
-    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t m_star = rescue_m_star();
-    const uint32_t clip = 2u * m_star + 1u;
-    const bool do_rescue = min_abundance <= 1;
-    if (do_rescue && clip > 254u) return MDBG_OK;
-
-    // 1. sequence starts, one bit per minimizer
-    const uint64_t n_words = (M >> 5) + 3;
-    DevBuf<uint32_t> start_bits;
-    MDBG_TRY(start_bits.alloc(ctx, n_words));
-    {
-        LaunchTimer timer(ctx, "kminmer_split");
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(start_bits.p, 0, n_words * 4, ctx->stream));
-        hipLaunchKernelGGL(mark_starts_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream, reads->d_off.p, n_reads, start_bits.p);
-    }
-    DevBuf<uint8_t> cnt8;
-    if (do_rescue) MDBG_TRY(cnt8.alloc(ctx, M));
-    uint32_t cnt8_default = 0;
-    bool cnt8_filled = false;
-
-    // 2. the plan: groups x buckets so that a bucket's distinct keys fit its LDS table at a load of about 0.7 and the records of a
-    //    group fit the budget.  The number of distinct keys comes from the sketch the first level-1 histogram keeps (hll_estimate);
-    //    before that the guess is the last first pass's keys per instance (key_ratio_hint), which only decides the ways of level 1
-    //    for small inputs: from 2^8 buckets up level 1 always takes 8 bits, so the histogram is not run twice.
-    const uint64_t I_est = std::max<uint64_t>(M / 8 + 1, M > (uint64_t)(k - 1) * n_reads ? M - (uint64_t)(k - 1) * n_reads : 0);
-    uint64_t max_records = ctx->part_max_records ? ctx->part_max_records : std::max<uint64_t>(1ull << 24, (uint64_t)((double)ctx->hbm_bytes * 0.25 / 44.0));
-    uint32_t group_bits = 0;
-    while (((I_est + ((1ull << group_bits) - 1)) >> group_bits) > max_records && group_bits < 16) group_bits++;
-    const uint64_t n_groups = 1ull << group_bits;
-    double keys_est = std::max(1.0, (double)I_est * ctx->key_ratio_hint[0]);
-    // (1024 slots where they need no level more than 2048 would: four buckets instead of two per CU count a fifth faster)
-    auto bits_for = [&](uint32_t c) { double b = keys_est / (double)n_groups / (0.70 * c); uint32_t n = 0; while ((double)(1ull << n) < b && n < 40) n++; return n; };
-    auto levels_for = [](uint32_t bits) { return bits <= 8 ? 1u : (bits + 7u) / 8u; };
-    uint32_t lds_slots = 0, bucket_bits = 0, n_levels = 1;
+// One partitioned pass over a read set: the plan, the buffers, and the two halves every user runs per group of keys -- split_group (the
+// radix levels) and count_group (one workgroup per bucket) -- which mdbg_kminmer_count_first and the sharded first pass put together
+// differently (the latter keeps every distinct key and walks the records a second time once the global counts are back).
+struct PartRun {
+    mdbg_ctx *ctx = nullptr;
+    const mdbg_minimizers *reads = nullptr;
+    uint32_t k = 0, n_reads = 0;
+    uint64_t M = 0;
+    // the plan: groups x buckets so that a bucket's distinct keys fit its LDS table at a load of at most 0.78 and the records of a
+    // group fit the budget.  The number of distinct keys comes from the sketch the first level-1 histogram keeps (hll_estimate);
+    // before that the guess is the last first pass's keys per instance (key_ratio_hint), which only decides the ways of level 1
+    // for small inputs: from 2^8 buckets up level 1 always takes 8 bits, so the histogram is not run twice.
+    uint64_t I_est = 0, n_groups = 1;
+    uint32_t group_bits = 0, lds_slots = 0, bucket_bits = 0, n_levels = 1, extra_bits = 0, tile = PART_TILE;
+    double keys_est = 1.0;
+    bool sketched = false;
     LevelPlan lv[3];
-    auto plan = [&](uint32_t extra_bits) {
+    // buffers
+    DevBuf<uint32_t> start_bits, kcnt, hist, n_keys, n_kept, overflow, hll_merged;
+    DevBuf<uint64_t> place[3], key_pos, row_of;
+    DevBuf<uint8_t> hll_blocks;
+    RecBufs buf[2];
+    // the group last split / counted
+    uint64_t I = 0, n_buckets = 0;
+    uint32_t cur = 0, stride = 1;
+    const uint64_t *pos = nullptr;
+
+    uint32_t bits_for(uint32_t c) const {
+        // (a mean load of up to 0.78: the fullest of 65 536 buckets is then near 0.9, where an LDS probe sequence is still a dozen slots -- and
+        // one radix level less is worth more than short probes: at 6 x coverage, 46 M keys in 172 M instances, 0.70 asked for a third level)
+        const double b = keys_est / (double)n_groups / (0.78 * c);
+        uint32_t n = 0;
+        while ((double)(1ull << n) < b && n < 40) n++;
+        return n;
+    }
+    static uint32_t levels_for(uint32_t bits) { return bits <= 8 ? 1u : (bits + 7u) / 8u; }
+    void plan() {
         lds_slots = ctx->part_lds_slots;
+        // (1024 slots where they need no level more than 2048 would: four buckets instead of two per CU count a fifth faster)
         if (!lds_slots) lds_slots = levels_for(bits_for(1024) + extra_bits) <= levels_for(bits_for(2048) + extra_bits) ? 1024u : 2048u;
         bucket_bits = (ctx->part_bits ? ctx->part_bits : bits_for(lds_slots)) + extra_bits;
         n_levels = levels_for(bucket_bits);
@@ -598,150 +661,205 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             if (l > 0) used += b;
             left -= b; segs <<= b;
         }
-    };
+    }
+    bool too_many_buckets() const { return bucket_bits > 24; }   // more distinct keys than three levels of buckets hold: not for this path
 
-    RecBufs buf[2];
-    DevBuf<uint32_t> kcnt, hist, n_keys, n_kept, overflow, resc_cnt;
-    DevBuf<uint64_t> place[3], key_pos, row_of, resc_pos;
-    DevBuf<uint8_t> hll_blocks;
-    DevBuf<uint32_t> hll_merged;
-    MDBG_TRY(overflow.alloc(ctx, 1));
+    // sequence starts (one bit per minimizer), the key groups, the first plan
+    int init(mdbg_ctx *c, const mdbg_minimizers *r, uint32_t k_) {
+        ctx = c; reads = r; k = k_; M = r->n_min; n_reads = r->n_reads;
+        const uint64_t n_words = (M >> 5) + 3;
+        MDBG_TRY(start_bits.alloc(ctx, n_words));
+        {
+            LaunchTimer timer(ctx, "kminmer_split");
+            MDBG_HIP_CHECK(ctx, hipMemsetAsync(start_bits.p, 0, n_words * 4, ctx->stream));
+            hipLaunchKernelGGL(mark_starts_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream, reads->d_off.p, n_reads, start_bits.p);
+        }
+        I_est = std::max<uint64_t>(M / 8 + 1, M > (uint64_t)(k - 1) * n_reads ? M - (uint64_t)(k - 1) * n_reads : 0);
+        const uint64_t max_records = ctx->part_max_records ? ctx->part_max_records : std::max<uint64_t>(1ull << 24, (uint64_t)((double)ctx->hbm_bytes * 0.25 / 44.0));
+        group_bits = 0;
+        while (((I_est + ((1ull << group_bits) - 1)) >> group_bits) > max_records && group_bits < 16) group_bits++;
+        n_groups = 1ull << group_bits;
+        keys_est = std::max(1.0, (double)I_est * ctx->key_ratio_hint[0]);
+        sketched = ctx->part_bits != 0;                 // a forced plan needs no estimate
+        tile = ctx->part_tile == 2048 ? PART_TILE / 2 : PART_TILE;
+        MDBG_TRY(overflow.alloc(ctx, 1));
+        plan();
+        return MDBG_OK;
+    }
+    int begin_attempt() {
+        plan();
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(overflow.p, 0, 4, ctx->stream));
+        return MDBG_OK;
+    }
+
+    // the records of key group g through every radix level; leaves I, cur, pos, stride, n_buckets.  *give_up: the sketch asks for more
+    // buckets than this path has (the caller hands the input back)
+    int split_group(uint64_t g, bool *give_up) {
+        *give_up = false;
+        SplitArgs a{};
+        a.mins = reads->d_min.p; a.start_bits = start_bits.p; a.n_min = M; a.k = k;
+        a.group_bits = group_bits; a.group = g;
+        a.tile = tile;
+        // level 1: histogram, scan, the group's instance count, scatter
+        const uint64_t tiles = (M + tile - 1) / tile;
+        uint64_t entries = 0;
+        for (;;) {
+            lv[0].blocks_per_seg = (uint32_t)std::min<uint64_t>(tiles, 2048);
+            a.seg_pos = nullptr; a.seg_stride = 1; a.blocks_per_seg = lv[0].blocks_per_seg; a.shift = lv[0].shift; a.ways = lv[0].ways; a.mix_bits = lv[0].bits;
+            entries = (uint64_t)lv[0].ways * lv[0].blocks_per_seg;
+            MDBG_TRY(hist.alloc(ctx, entries));
+            MDBG_TRY(place[0].alloc(ctx, entries + 1));
+            a.hll = nullptr;
+            if (!sketched) {
+                MDBG_TRY(hll_blocks.alloc(ctx, (uint64_t)lv[0].blocks_per_seg * HLL_M));
+                MDBG_TRY(hll_merged.alloc(ctx, HLL_M));
+                MDBG_HIP_CHECK(ctx, hipMemsetAsync(hll_merged.p, 0, HLL_M * 4, ctx->stream));
+                a.hll = hll_blocks.p;
+            }
+            {
+                LaunchTimer timer(ctx, "kminmer_split");
+                hipLaunchKernelGGL(split_hist_kernel<true>, dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, hist.p);
+                if (a.hll) hipLaunchKernelGGL(hll_merge_kernel, dim3(HLL_M / 256, 64), dim3(256), 0, ctx->stream, hll_blocks.p, lv[0].blocks_per_seg, hll_merged.p);
+            }
+            MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[0].p, entries));
+            uint32_t regs[HLL_M];
+            if (a.hll) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(regs, hll_merged.p, HLL_M * 4, hipMemcpyDeviceToHost, ctx->stream));
+            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &I, place[0].p + entries, 8, hipMemcpyDeviceToHost));
+            if (!a.hll) break;
+            // the sketch saw every key of every group: plan on it (+8 %: three and a half standard errors); the histogram is
+            // only repeated when that changes level 1, i.e. for inputs of fewer keys than 2^8 buckets hold
+            sketched = true;
+            const uint32_t old_bits = lv[0].bits;
+            keys_est = std::max(1.0, 1.08 * hll_estimate(regs));
+            plan();
+            MDBG_DBG(ctx, "partitioned first pass: about %.0f distinct keys", keys_est / 1.08);
+            if (too_many_buckets()) { *give_up = true; return MDBG_OK; }
+            if (lv[0].bits == old_bits) break;
+        }
+        n_buckets = 1ull << bucket_bits;
+        MDBG_DBG(ctx, "partitioned first pass: group %llu of %llu, %llu instances, %u + %u + %u bits, %u LDS slots", (unsigned long long)g,
+                 (unsigned long long)n_groups, (unsigned long long)I, lv[0].bits, n_levels > 1 ? lv[1].bits : 0, n_levels > 2 ? lv[2].bits : 0, lds_slots);
+        MDBG_TRY(buf[0].ensure(ctx, I));
+        MDBG_TRY(buf[1].ensure(ctx, I));
+        if (kcnt.n < I || !kcnt.p) MDBG_TRY(kcnt.alloc(ctx, I));
+        {
+            LaunchTimer timer(ctx, "kminmer_split");
+            if (tile != PART_TILE) hipLaunchKernelGGL((split_scatter_kernel<true, PART_E / 2>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
+            else hipLaunchKernelGGL((split_scatter_kernel<true, PART_E>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
+        }
+        // deeper levels
+        cur = 0;
+        for (uint32_t l = 1; l < n_levels; l++) {
+            const uint64_t n_seg = lv[l].n_seg;
+            const uint64_t avg_tiles = (I / n_seg + tile - 1) / tile;
+            lv[l].blocks_per_seg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(1, 4096 / n_seg), avg_tiles));
+            SplitArgs d{};
+            d.in = buf[cur].view();
+            d.seg_pos = place[l - 1].p; d.seg_stride = lv[l - 1].blocks_per_seg; d.blocks_per_seg = lv[l].blocks_per_seg;
+            d.shift = lv[l].shift; d.ways = lv[l].ways; d.n_min = 0; d.tile = tile;
+            entries = n_seg * lv[l].ways * lv[l].blocks_per_seg;
+            MDBG_TRY(hist.alloc(ctx, entries));
+            MDBG_TRY(place[l].alloc(ctx, entries + 1));
+            const unsigned grid = (unsigned)(n_seg * lv[l].blocks_per_seg);
+            {
+                LaunchTimer timer(ctx, "kminmer_split");
+                hipLaunchKernelGGL(split_hist_kernel<false>, dim3(grid), dim3(PART_NT), 0, ctx->stream, d, hist.p);
+            }
+            MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[l].p, entries));
+            {
+                LaunchTimer timer(ctx, "kminmer_split");
+                if (tile != PART_TILE) hipLaunchKernelGGL((split_scatter_kernel<false, PART_E / 2>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+                else hipLaunchKernelGGL((split_scatter_kernel<false, PART_E>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+            }
+            cur ^= 1;
+        }
+        pos = place[n_levels - 1].p;
+        stride = lv[n_levels - 1].blocks_per_seg;
+        return MDBG_OK;
+    }
+    RecView records() { return buf[cur].view(); }
+    RecView keys() { return buf[cur ^ 1].view(); }      // the free record buffer: every bucket's kept keys, compacted, at its start
+
+    // one workgroup per bucket: counts, the kept keys, (cnt8) the rare instances' counts; then the buckets' key / kept-key offsets
+    int count_group(uint32_t min_abundance, uint32_t clip, int keep_all, uint8_t *cnt8, uint32_t cnt8_default) {
+        if (n_keys.n < n_buckets || !n_keys.p) {
+            MDBG_TRY(n_keys.alloc(ctx, n_buckets));
+            MDBG_TRY(n_kept.alloc(ctx, n_buckets));
+            MDBG_TRY(key_pos.alloc(ctx, n_buckets + 1));
+            MDBG_TRY(row_of.alloc(ctx, n_buckets + 1));
+        }
+        {
+            LaunchTimer timer(ctx, "kminmer_insert");
+#define MDBG_BC(C, L) launch_bucket_count<C, L>(ctx, n_buckets, records(), pos, stride, min_abundance, clip, keep_all, keys(), kcnt.p, n_keys.p, n_kept.p, cnt8, cnt8_default, overflow.p)
+            const bool list = ctx->part_slot_list != 0;
+            if (lds_slots == 256) { if (list) MDBG_BC(256, 8000); else MDBG_BC(256, 0); }
+            else if (lds_slots == 1024) { if (list) MDBG_BC(1024, 8000); else MDBG_BC(1024, 0); }
+            else { if (list) MDBG_BC(2048, 4096); else MDBG_BC(2048, 0); }
+#undef MDBG_BC
+        }
+        MDBG_HIP_CHECK(ctx, hipGetLastError());
+        MDBG_TRY(exclusive_scan_u32(ctx, n_keys.p, key_pos.p, n_buckets));
+        MDBG_TRY(exclusive_scan_u32(ctx, n_kept.p, row_of.p, n_buckets));
+        return MDBG_OK;
+    }
+    void record_info(uint32_t attempt, uint64_t total_inst) const {
+        ctx->part_info[0] = 2; ctx->part_info[1] = n_groups; ctx->part_info[2] = bucket_bits; ctx->part_info[3] = n_levels;
+        ctx->part_info[4] = attempt; ctx->part_info[5] = lds_slots; ctx->part_info[6] = n_buckets; ctx->part_info[7] = total_inst;
+    }
+};
+
+static bool part_applicable(const mdbg_minimizers *reads, uint32_t k) {
+    return k <= PART_MAX_K && reads->n_min >= k && reads->n_min < (1ull << 32);
+}
+
+int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, uint32_t min_abundance, mdbg_table **out, bool *done) {
+    *done = false;
+    if (!part_applicable(reads, k)) return MDBG_OK;
+    const uint64_t M = reads->n_min;
+    const uint32_t n_reads = reads->n_reads;
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t m_star = rescue_m_star();
+    const uint32_t clip = 2u * m_star + 1u;
+    const bool do_rescue = min_abundance <= 1;
+    if (do_rescue && clip > 254u) return MDBG_OK;
+
+    PartRun run;
+    MDBG_TRY(run.init(ctx, reads, k));
+    DevBuf<uint8_t> cnt8;
+    if (do_rescue) MDBG_TRY(cnt8.alloc(ctx, M));
+    uint32_t cnt8_default = 0;
+    DevBuf<uint32_t> resc_cnt;
+    DevBuf<uint64_t> resc_pos;
     std::vector<GroupRows> group_rows;
-    bool sketched = ctx->part_bits != 0;                // a forced plan needs no estimate
-    uint32_t extra_bits = 0;
+    const uint64_t n_groups = run.n_groups;
 
     for (uint32_t attempt = 1;; attempt++) {
-        plan(extra_bits);
-        if (bucket_bits > 24 || attempt > 4) {          // more distinct keys than three levels of buckets hold: not for this path
-            MDBG_DBG(ctx, "partitioned first pass gives up at %u bucket bits", bucket_bits);
+        MDBG_TRY(run.begin_attempt());
+        if (run.too_many_buckets() || attempt > 4) {
+            MDBG_DBG(ctx, "partitioned first pass gives up at %u bucket bits", run.bucket_bits);
             return MDBG_OK;
         }
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(overflow.p, 0, 4, ctx->stream));
-        cnt8_filled = false;
+        bool cnt8_filled = false;
         group_rows.clear();
-
         uint64_t total_inst = 0, total_keys = 0, total_solid = 0;
         bool overflowed = false;
-        // what the single-group case keeps for the emit after the rescue count
-        const uint64_t *last_pos = nullptr; uint32_t last_stride = 1; RecView last_keys{};
-        uint64_t n_buckets = 0;
 
         for (uint64_t g = 0; g < n_groups && !overflowed; g++) {
-            SplitArgs a{};
-            a.mins = reads->d_min.p; a.start_bits = start_bits.p; a.n_min = M; a.k = k;
-            a.group_bits = group_bits; a.group = g;
-            // level 1: histogram, scan, the group's instance count, scatter
-            const uint32_t tile = ctx->part_tile == 2048 ? PART_TILE / 2 : PART_TILE;
-            const uint64_t tiles = (M + tile - 1) / tile;
-            a.tile = tile;
-            uint64_t I = 0, entries = 0;
-            for (;;) {
-                lv[0].blocks_per_seg = (uint32_t)std::min<uint64_t>(tiles, 2048);
-                a.seg_pos = nullptr; a.seg_stride = 1; a.blocks_per_seg = lv[0].blocks_per_seg; a.shift = lv[0].shift; a.ways = lv[0].ways; a.mix_bits = lv[0].bits;
-                entries = (uint64_t)lv[0].ways * lv[0].blocks_per_seg;
-                MDBG_TRY(hist.alloc(ctx, entries));
-                MDBG_TRY(place[0].alloc(ctx, entries + 1));
-                a.hll = nullptr;
-                if (!sketched) {
-                    MDBG_TRY(hll_blocks.alloc(ctx, (uint64_t)lv[0].blocks_per_seg * HLL_M));
-                    MDBG_TRY(hll_merged.alloc(ctx, HLL_M));
-                    MDBG_HIP_CHECK(ctx, hipMemsetAsync(hll_merged.p, 0, HLL_M * 4, ctx->stream));
-                    a.hll = hll_blocks.p;
-                }
-                {
-                    LaunchTimer timer(ctx, "kminmer_split");
-                    hipLaunchKernelGGL(split_hist_kernel<true>, dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, hist.p);
-                    if (a.hll) hipLaunchKernelGGL(hll_merge_kernel, dim3(HLL_M / 256, 64), dim3(256), 0, ctx->stream, hll_blocks.p, lv[0].blocks_per_seg, hll_merged.p);
-                }
-                MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[0].p, entries));
-                uint32_t regs[HLL_M];
-                if (a.hll) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(regs, hll_merged.p, HLL_M * 4, hipMemcpyDeviceToHost, ctx->stream));
-                MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &I, place[0].p + entries, 8, hipMemcpyDeviceToHost));
-                if (!a.hll) break;
-                // the sketch saw every key of every group: plan on it (+8 %: three and a half standard errors); the histogram is
-                // only repeated when that changes level 1, i.e. for inputs of fewer keys than 2^8 buckets hold
-                sketched = true;
-                const uint32_t old_bits = lv[0].bits;
-                keys_est = std::max(1.0, 1.08 * hll_estimate(regs));
-                plan(extra_bits);
-                MDBG_DBG(ctx, "partitioned first pass: about %.0f distinct keys", keys_est / 1.08);
-                if (bucket_bits > 24) return MDBG_OK;
-                if (lv[0].bits == old_bits) break;
-            }
-            total_inst += I;
-            n_buckets = 1ull << bucket_bits;
+            bool give_up = false;
+            MDBG_TRY(run.split_group(g, &give_up));
+            if (give_up) return MDBG_OK;
+            total_inst += run.I;
             if (do_rescue && !cnt8_filled) {            // (the sketch's estimate: more keys than half the instances = mostly singletons)
-                cnt8_default = keys_est > 0.5 * (double)I_est ? 1u : 0u;
+                cnt8_default = run.keys_est > 0.5 * (double)run.I_est ? 1u : 0u;
                 MDBG_HIP_CHECK(ctx, hipMemsetAsync(cnt8.p, (int)cnt8_default, M, ctx->stream));
                 cnt8_filled = true;
             }
-            MDBG_DBG(ctx, "partitioned first pass: group %llu of %llu, %llu instances, %u + %u + %u bits, %u LDS slots", (unsigned long long)g,
-                     (unsigned long long)n_groups, (unsigned long long)I, lv[0].bits, n_levels > 1 ? lv[1].bits : 0, n_levels > 2 ? lv[2].bits : 0, lds_slots);
-            if (n_keys.n < n_buckets) {
-                MDBG_TRY(n_keys.alloc(ctx, n_buckets));
-                MDBG_TRY(n_kept.alloc(ctx, n_buckets));
-                MDBG_TRY(key_pos.alloc(ctx, n_buckets + 1));
-                MDBG_TRY(row_of.alloc(ctx, n_buckets + 1));
-            }
-            MDBG_TRY(buf[0].ensure(ctx, I));
-            MDBG_TRY(buf[1].ensure(ctx, I));
-            if (kcnt.n < I || !kcnt.p) MDBG_TRY(kcnt.alloc(ctx, I));
-            {
-                LaunchTimer timer(ctx, "kminmer_split");
-                if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<true, PART_E / 2>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
-                else hipLaunchKernelGGL((split_scatter_kernel<true, PART_E>), dim3(lv[0].blocks_per_seg), dim3(PART_NT), 0, ctx->stream, a, place[0].p, buf[0].view());
-            }
-            // deeper levels
-            uint32_t cur = 0;
-            for (uint32_t l = 1; l < n_levels; l++) {
-                const uint64_t n_seg = lv[l].n_seg;
-                const uint64_t avg_tiles = (I / n_seg + tile - 1) / tile;
-                lv[l].blocks_per_seg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(1, 4096 / n_seg), avg_tiles));
-                SplitArgs d{};
-                d.in = buf[cur].view();
-                d.seg_pos = place[l - 1].p; d.seg_stride = lv[l - 1].blocks_per_seg; d.blocks_per_seg = lv[l].blocks_per_seg;
-                d.shift = lv[l].shift; d.ways = lv[l].ways; d.n_min = 0; d.tile = tile;
-                entries = n_seg * lv[l].ways * lv[l].blocks_per_seg;
-                MDBG_TRY(hist.alloc(ctx, entries));
-                MDBG_TRY(place[l].alloc(ctx, entries + 1));
-                const unsigned grid = (unsigned)(n_seg * lv[l].blocks_per_seg);
-                {
-                    LaunchTimer timer(ctx, "kminmer_split");
-                    hipLaunchKernelGGL(split_hist_kernel<false>, dim3(grid), dim3(PART_NT), 0, ctx->stream, d, hist.p);
-                }
-                MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[l].p, entries));
-                {
-                    LaunchTimer timer(ctx, "kminmer_split");
-                    if (tile == 2048) hipLaunchKernelGGL((split_scatter_kernel<false, PART_E / 2>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
-                    else hipLaunchKernelGGL((split_scatter_kernel<false, PART_E>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
-                }
-                cur ^= 1;
-            }
-            // count the buckets
-            const uint64_t *pos = place[n_levels - 1].p;
-            const uint32_t stride = lv[n_levels - 1].blocks_per_seg;
-            RecView keys = buf[cur ^ 1].view();
-            {
-                LaunchTimer timer(ctx, "kminmer_insert");
-                uint8_t *c8 = do_rescue ? cnt8.p : nullptr;
-#define MDBG_BC(C, L) launch_bucket_count<C, L>(ctx, n_buckets, buf[cur].view(), pos, stride, min_abundance, clip, keys, kcnt.p, n_keys.p, n_kept.p, c8, cnt8_default, overflow.p)
-                const bool list = ctx->part_slot_list != 0;
-                if (lds_slots == 256) { if (list) MDBG_BC(256, 8000); else MDBG_BC(256, 0); }
-                else if (lds_slots == 1024) { if (list) MDBG_BC(1024, 8000); else MDBG_BC(1024, 0); }
-                else { if (list) MDBG_BC(2048, 4096); else MDBG_BC(2048, 0); }
-#undef MDBG_BC
-            }
-            MDBG_HIP_CHECK(ctx, hipGetLastError());
-            MDBG_TRY(exclusive_scan_u32(ctx, n_keys.p, key_pos.p, n_buckets));
-            MDBG_TRY(exclusive_scan_u32(ctx, n_kept.p, row_of.p, n_buckets));
-            if (n_groups == 1) {                        // totals are read with the rescue count's, below
-                last_pos = pos; last_stride = stride; last_keys = keys;
-                break;
-            }
+            MDBG_TRY(run.count_group(min_abundance, clip, 0, do_rescue ? cnt8.p : nullptr, cnt8_default));
+            if (n_groups == 1) break;                   // totals are read with the rescue count's, below
             uint64_t nk = 0, ns = 0; uint32_t ov = 0;
-            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&nk, key_pos.p + n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
-            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&ns, row_of.p + n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
-            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, overflow.p, 4, hipMemcpyDeviceToHost));
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&nk, run.key_pos.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&ns, run.row_of.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, run.overflow.p, 4, hipMemcpyDeviceToHost));
             if (ov) { overflowed = true; break; }
             total_keys += nk; total_solid += ns;
             group_rows.emplace_back();
@@ -750,7 +868,8 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             MDBG_TRY(gr.lo.alloc(ctx, ns)); MDBG_TRY(gr.hi.alloc(ctx, ns)); MDBG_TRY(gr.ab.alloc(ctx, ns)); MDBG_TRY(gr.vec.alloc(ctx, ns * k));
             RowOut ro{gr.lo.p, gr.hi.p, gr.ab.p, gr.vec.p, k};
             LaunchTimer timer(ctx, "kminmer_emit");
-            hipLaunchKernelGGL(emit_bucket_rows_kernel, dim3((unsigned)n_buckets), dim3(256), 0, ctx->stream, keys, kcnt.p, pos, stride, n_kept.p, row_of.p, reads->d_min.p, ro, (uint64_t)0);
+            hipLaunchKernelGGL(emit_bucket_rows_kernel, dim3((unsigned)run.n_buckets), dim3(256), 0, ctx->stream, run.keys(), run.kcnt.p, run.pos, run.stride, run.n_kept.p,
+                               run.row_of.p, reads->d_min.p, ro, (uint64_t)0);
         }
 
         // rescue decision per read, row positions
@@ -767,17 +886,16 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
         }
         if (!overflowed && n_groups == 1) {
             uint32_t ov = 0;
-            const uint64_t nb = n_buckets;
-            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&total_keys, key_pos.p + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
-            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&total_solid, row_of.p + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
-            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, overflow.p, 4, hipMemcpyDeviceToHost));
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&total_keys, run.key_pos.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+            MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&total_solid, run.row_of.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, run.overflow.p, 4, hipMemcpyDeviceToHost));
             overflowed = ov != 0;
         } else {
             MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         }
         if (overflowed) {
-            MDBG_DBG(ctx, "partitioned first pass: a bucket outgrew its %u LDS slots at %u bucket bits, again with more", lds_slots, bucket_bits);
-            extra_bits += 2;
+            MDBG_DBG(ctx, "partitioned first pass: a bucket outgrew its %u LDS slots at %u bucket bits, again with more", run.lds_slots, run.bucket_bits);
+            run.extra_bits += 2;
             continue;
         }
 
@@ -785,14 +903,14 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
         std::unique_ptr<mdbg_table> t(new mdbg_table());
         t->k = k;
         t->n_solid = total_solid;
-        t->st_minimizers = M; t->st_instances = total_inst; t->st_keys = total_keys; t->st_slots = n_groups * n_buckets * lds_slots;
+        t->st_minimizers = M; t->st_instances = total_inst; t->st_keys = total_keys; t->st_slots = n_groups * run.n_buckets * run.lds_slots;
         MDBG_TRY(alloc_rows(ctx, t.get(), total_solid + n_resc, true));
         RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
         {
             LaunchTimer timer(ctx, "kminmer_emit");
             if (n_groups == 1) {
-                hipLaunchKernelGGL(emit_bucket_rows_kernel, dim3((unsigned)n_buckets), dim3(256), 0, ctx->stream, last_keys, kcnt.p, last_pos, last_stride,
-                                   n_kept.p, row_of.p, reads->d_min.p, ro, (uint64_t)0);
+                hipLaunchKernelGGL(emit_bucket_rows_kernel, dim3((unsigned)run.n_buckets), dim3(256), 0, ctx->stream, run.keys(), run.kcnt.p, run.pos, run.stride,
+                                   run.n_kept.p, run.row_of.p, reads->d_min.p, ro, (uint64_t)0);
             } else {
                 uint64_t at = 0;
                 for (GroupRows &gr : group_rows) {
@@ -813,12 +931,130 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
         }
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "partitioned first pass failed: %s", hipGetErrorString(e));
-        ctx->part_info[0] = 2; ctx->part_info[1] = n_groups; ctx->part_info[2] = bucket_bits; ctx->part_info[3] = n_levels;
-        ctx->part_info[4] = attempt; ctx->part_info[5] = lds_slots; ctx->part_info[6] = n_buckets; ctx->part_info[7] = total_inst;
+        run.record_info(attempt, total_inst);
         *out = t.release();
         *done = true;
         return MDBG_OK;
     }
+}
+
+// ---- the sharded first pass: distinct local keys out, global counts back in ---------------------------------------------------------
+struct PartLocal {
+    PartRun run;
+    DevBuf<unsigned long long> lo, hi;       // the distinct local keys, bucket after bucket
+    DevBuf<uint32_t> cnt, rep;
+    uint64_t n_keys = 0, n_inst = 0;
+    uint32_t attempt = 1;
+};
+
+void part_local_free(PartLocal *p) { delete p; }
+
+void part_local_arrays(const PartLocal *p, const uint64_t **lo, const uint64_t **hi, const uint32_t **cnt, uint64_t *n, uint64_t *n_inst) {
+    *lo = reinterpret_cast<const uint64_t *>(p->lo.p); *hi = reinterpret_cast<const uint64_t *>(p->hi.p); *cnt = p->cnt.p; *n = p->n_keys; *n_inst = p->n_inst;
+}
+
+int part_local_keys(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, PartLocal **out, bool *done) {
+    *done = false;
+    if (!part_applicable(reads, k)) return MDBG_OK;
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<PartLocal> pl(new PartLocal());
+    PartRun &run = pl->run;
+    MDBG_TRY(run.init(ctx, reads, k));
+    if (run.n_groups != 1) return MDBG_OK;            // (a rank's share that needs key groups: the one-table pass takes it)
+    for (uint32_t attempt = 1;; attempt++) {
+        MDBG_TRY(run.begin_attempt());
+        if (run.too_many_buckets() || attempt > 4) return MDBG_OK;
+        bool give_up = false;
+        MDBG_TRY(run.split_group(0, &give_up));
+        if (give_up) return MDBG_OK;
+        MDBG_TRY(run.count_group(0u, 0u, 1, nullptr, 0u));       // keep every key; the instances' counts wait for the global ones
+        uint32_t ov = 0;
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&pl->n_keys, run.key_pos.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, run.overflow.p, 4, hipMemcpyDeviceToHost));
+        if (ov) { run.extra_bits += 2; continue; }
+        pl->attempt = attempt;
+        break;
+    }
+    pl->n_inst = run.I;
+    const uint64_t D = pl->n_keys;
+    MDBG_TRY(pl->lo.alloc(ctx, D)); MDBG_TRY(pl->hi.alloc(ctx, D)); MDBG_TRY(pl->cnt.alloc(ctx, D)); MDBG_TRY(pl->rep.alloc(ctx, D));
+    {
+        LaunchTimer timer(ctx, "shard_rows");
+        hipLaunchKernelGGL(gather_bucket_keys_kernel, dim3((unsigned)run.n_buckets), dim3(256), 0, ctx->stream, run.keys(), run.kcnt.p, run.pos, run.stride, run.n_kept.p,
+                           run.row_of.p, pl->lo.p, pl->hi.p, pl->cnt.p, pl->rep.p);
+    }
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
+    run.record_info(pl->attempt, run.I);
+    // the free record buffer and the per-instance count array are not needed any more; the records, their bucket offsets and row_of are
+    run.buf[run.cur ^ 1] = RecBufs();
+    run.kcnt.release();
+    *out = pl.release();
+    *done = true;
+    return MDBG_OK;
+}
+
+template <uint32_t C>
+static void launch_bucket_apply(mdbg_ctx *ctx, PartLocal *pl, const uint32_t *gcount, uint32_t clip, uint8_t *cnt8) {
+    PartRun &run = pl->run;
+    hipLaunchKernelGGL(bucket_apply_kernel<C>, dim3((unsigned)run.n_buckets), dim3(BC_NT), 0, ctx->stream, run.records(), run.pos, run.stride, run.row_of.p, pl->lo.p, pl->hi.p,
+                       gcount, clip, cnt8);
+}
+
+// gcount[i]: the global count of local key i; listed[i]: this rank lists the key (and it is solid)
+int part_local_finish(mdbg_ctx *ctx, PartLocal *pl, const uint32_t *gcount, const uint32_t *listed, uint32_t min_abundance, mdbg_table **out) {
+    PartRun &run = pl->run;
+    const mdbg_minimizers *reads = run.reads;
+    const uint32_t k = run.k, n_reads = run.n_reads;
+    const uint64_t M = run.M, D = pl->n_keys;
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t m_star = rescue_m_star();
+    const uint32_t clip = 2u * m_star + 1u;
+    const bool do_rescue = min_abundance <= 1 && clip <= 254u;
+    DevBuf<uint64_t> lpos, resc_pos;
+    DevBuf<uint8_t> cnt8;
+    DevBuf<uint32_t> resc_cnt;
+    MDBG_TRY(lpos.alloc(ctx, D + 1));
+    MDBG_TRY(exclusive_scan_u32(ctx, listed, lpos.p, D));
+    uint64_t n_solid = 0, n_resc = 0;
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&n_solid, lpos.p + D, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (do_rescue) {
+        MDBG_TRY(cnt8.alloc(ctx, M));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(cnt8.p, 0, M, ctx->stream));
+        {
+            LaunchTimer timer(ctx, "kminmer_insert");
+            if (run.lds_slots == 256) launch_bucket_apply<256>(ctx, pl, gcount, clip, cnt8.p);
+            else if (run.lds_slots == 1024) launch_bucket_apply<1024>(ctx, pl, gcount, clip, cnt8.p);
+            else launch_bucket_apply<2048>(ctx, pl, gcount, clip, cnt8.p);
+        }
+        MDBG_TRY(resc_cnt.alloc(ctx, n_reads));
+        MDBG_TRY(resc_pos.alloc(ctx, (size_t)n_reads + 1));
+        {
+            LaunchTimer timer(ctx, "kminmer_rescue");
+            hipLaunchKernelGGL(rescue_count_p_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, reads->d_off.p, n_reads, k, cnt8.p, m_star, resc_cnt.p);
+        }
+        MDBG_TRY(exclusive_scan_u32(ctx, resc_cnt.p, resc_pos.p, n_reads));
+        MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&n_resc, resc_pos.p + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::unique_ptr<mdbg_table> t(new mdbg_table());
+    t->k = k;
+    t->n_solid = n_solid;
+    t->st_minimizers = M; t->st_instances = pl->n_inst; t->st_keys = D; t->st_slots = run.n_buckets * run.lds_slots;
+    MDBG_TRY(alloc_rows(ctx, t.get(), n_solid + n_resc, true));
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, t->d_vec.p, k};
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        if (D) hipLaunchKernelGGL(emit_listed_rows_kernel, dim3(grid_for(D, 256)), dim3(256), 0, ctx->stream, pl->lo.p, pl->hi.p, gcount, pl->rep.p, listed, lpos.p, D,
+                                  reads->d_min.p, ro);
+        if (n_resc) {
+            const unsigned blocks = grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 16u);
+            hipLaunchKernelGGL(emit_rescued_p_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_off.p, reads->d_min.p, n_reads, k, cnt8.p, resc_cnt.p, resc_pos.p, ro, n_solid);
+        }
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "sharded first pass (partitioned) failed: %s", hipGetErrorString(e));
+    *out = t.release();
+    return MDBG_OK;
 }
 
 }  // namespace mdbg

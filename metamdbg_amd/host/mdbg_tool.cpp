@@ -1078,6 +1078,15 @@ int run_graph(int argc, char **argv) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     g_log.line("mdbg_tool graph (MI355X) k = " + std::to_string(k) + (a.firstPass ? " --firstpass" : "") +
                (a.gpus > 1 ? " --gpus " + std::to_string(a.gpus) : ""));
+    // --gpus G: contiguous read ranges, one context (device r, one host thread) per rank, the exchange inside the library over
+    // RCCL.  MDBG_TOOL_SHARDED=1 takes the same path with one rank (a communicator of one: what a one-GPU box can exercise).
+    const int G = std::max(1, a.gpus);
+    const bool sharded = G > 1 || getenv("MDBG_TOOL_SHARDED") != nullptr;
+    // one rank: the library context (HIP start-up: 0.09 - 0.17 s, a third of this command on a 10 Gbp read set) is created on a thread of its
+    // own while this one reads the input files
+    int ctxRc = MDBG_OK;
+    std::thread ctxThread;
+    if (!sharded) ctxThread = std::thread([&] { ctxRc = mdbg_create(0, &g_ctx); });
     U32Vec mins;
     std::vector<uint64_t> offs;
     {
@@ -1091,14 +1100,11 @@ int run_graph(int argc, char **argv) {
     // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
     std::ofstream small(dir + "/smallContigs/smallContigs_k" + std::to_string(k) + ".bin", std::ios::binary);
 
-    // --gpus G: contiguous read ranges, one context (device r, one host thread) per rank, the exchange inside the library over
-    // RCCL.  MDBG_TOOL_SHARDED=1 takes the same path with one rank (a communicator of one: what a one-GPU box can exercise).
-    const int G = std::max(1, a.gpus);
-    const bool sharded = G > 1 || getenv("MDBG_TOOL_SHARDED") != nullptr;
     bool streamed = false;               // the table files were written as the rows came down (one rank)
     std::vector<RankTable> parts((size_t)G);
     if (!sharded) {
-        check(mdbg_create(0, &g_ctx), "mdbg_create");
+        ctxThread.join();
+        check(ctxRc, "mdbg_create");
         g_trace.mark("graph: context created");
         // one rank: the rows are streamed to their files (graph/CreateMdbg.cpp:451-464, :515-522 for the copies)
         std::vector<std::string> recFiles{dir + "/kminmerData_abundance.txt"};

@@ -159,3 +159,44 @@ def test_partitioned_hands_back_what_it_does_not_take(ctx, orc):
         assert t2.info()["n_records"] == 0
     finally:
         _options(ctx)
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
+@pytest.mark.parametrize("plan", [0, 2, 4, 5])
+@pytest.mark.parametrize("k,min_ab", [(3, 0), (4, 0), (4, 2), (8, 0)])
+def test_partitioned_share_of_a_sharded_first_pass_vs_oracle(ctx, orc, n_ranks, plan, k, min_ab):
+    """A rank's share counted by the partitioned pass (mdbg_shard_begin takes it like mdbg_kminmer_count_first does): its distinct keys go to
+    their owners as rows, the global counts come back, the records are walked a second time for the rescue pass against the global counts.
+    Ranks alternate between the partitioned and the one-table local pass; the union of the shares must be the oracle's table of all reads,
+    the rescued rows of every rank in its own read order."""
+    from metamdbg_amd import capi
+    rng = np.random.default_rng(7000 + 31 * k + plan + n_ranks)
+    mins, offs = _random_minimizer_reads(rng, 600, 6 if k >= 8 else 25)
+    exp = orc.kminmer_count_first(mins, offs, k, min_ab)
+    cuts = [600 * r // n_ranks for r in range(n_ranks + 1)]
+    whole = ctx.minimizers_from_host(mins, offs)
+    parts = [ctx.minimizers_slice(whole, cuts[r], cuts[r + 1] - cuts[r]) for r in range(n_ranks)]
+    shards = []
+    try:
+        for r, part in enumerate(parts):
+            _options(ctx, first_pass_mode=1 if (r % 2 == 1 and n_ranks > 1) else 2, **PLANS[plan])
+            shards.append(ctx.shard_begin(part, k, n_ranks))
+            if r % 2 == 0 or n_ranks == 1:
+                assert ctx.first_pass_info()["path"] == 2
+        replies = capi.exchange_local(ctx, shards)
+        tables = [sh.finish(rep, min_ab) for sh, rep in zip(shards, replies)]
+    finally:
+        _options(ctx)
+    recs, vecs, n_solid = [], [], 0
+    for t in tables:
+        rec, vec = t.to_host()
+        ns = t.info()["n_solid"]
+        assert (rec[:ns]["abundance"] > 1).all() and (rec[ns:]["abundance"] == 1).all()
+        recs.append(rec); vecs.append(vec); n_solid += ns
+    assert n_solid == exp["n_solid"]
+    assert np.array_equal(formats.sorted_abundance_records(np.concatenate(recs)), formats.sorted_abundance_records(orc.table_abundance_records(exp)))
+    assert np.array_equal(formats.sorted_vector_records(np.concatenate(vecs).astype("<u4").tobytes(), k),
+                          formats.sorted_vector_records(exp["vecs"].astype("<u4").tobytes(), k))
+    # the rescued rows: every rank's in the order of its own reads, the ranks' read ranges in order = the oracle's read order
+    resc = np.concatenate([v[t.info()["n_solid"]:] for v, t in zip(vecs, tables)])
+    assert np.array_equal(resc, exp["vecs"][exp["n_solid"]:])
