@@ -935,6 +935,7 @@ def run_alone(ctx) -> None:
     ctx.set_option("table_grid_blocks", 0)
     ctx.set_option("table_cu_count", 0)
     ctx.set_option("scan_lds_pad", 0)
+    ctx.set_option("scan_lds_reserve", 0)
     ctx.set_option("partition_tile", 0)
     ctx.set_option("partition_slot_list", 1)
     ctx.set_option("partition_lds_slots", 0)
@@ -1109,10 +1110,10 @@ def main() -> None:
     # Several batches in flight: everything a batch runs beside another batch's scan must be able to be RESIDENT beside it, or it waits
     # for whole scan launches (a 24 KB block of purge_fix_kernel once sat out 103 ms; round 4's first runs with the partitioned first
     # pass -- 43 KB blocks -- swung between 830 and 574 Gbp/s).  Five blocks of the scan hold 150 of a CU's 160 KB of LDS, so: the scan
-    # is capped at four blocks per CU by 3 KB of unused LDS per block ("scan_lds_pad": 33 KB x 4 leaves 28 KB; alone it costs the scan
-    # 1.7 %), and the first pass's kernels take their 24 KB forms ("partition_tile" 2048, "partition_slot_list" 0).
+    # leaves 28 KB of every CU's LDS free ("scan_lds_reserve": four blocks of 30 KB padded to 32.5 KB instead of five; alone it costs the
+    # scan 1.7 %), and the first pass's kernels take their 24 KB forms ("partition_tile" 2048, "partition_slot_list" 0).
     # tools/overlap_matrix.sh, profiles/round4_*_overlap_matrix.txt.
-    shared_opts = {"scan_lds_pad": int(os.environ.get("MDBG_BENCH_SCAN_LDS_PAD", "3072")), "partition_tile": int(os.environ.get("MDBG_BENCH_PARTITION_TILE", "2048")),
+    shared_opts = {"scan_lds_reserve": int(os.environ.get("MDBG_BENCH_SCAN_LDS_RESERVE", "28672")), "partition_tile": int(os.environ.get("MDBG_BENCH_PARTITION_TILE", "2048")),
                    "partition_slot_list": int(os.environ.get("MDBG_BENCH_PARTITION_SLOT_LIST", "0")),
                    # (buckets of 1024 slots: 24.6 KB; a bucket of 2048 -- what the plan may prefer for many keys per instance -- is 49 KB and would wait)
                    "partition_lds_slots": int(os.environ.get("MDBG_BENCH_PARTITION_LDS_SLOTS", "1024"))} if n_slots > 1 else {}

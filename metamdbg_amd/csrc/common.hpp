@@ -145,6 +145,8 @@ struct mdbg_ctx {
     uint32_t part_slot_list = 1;            // 0: bucket_count keeps no slot list (24 KB of LDS per 1024-slot bucket instead of 40)
     uint32_t scan_lds_pad = 0;              // bytes of unused dynamic LDS per block of the block-structured scan: caps its blocks per CU and so
                                             // leaves LDS, registers and wave slots to other contexts' kernels (mdbg_set_option)
+    uint32_t scan_lds_reserve = 0;          // the same as a goal: bytes of a CU's LDS the scan leaves free, the padding worked out per kernel variant
+    size_t lds_per_cu = 0;                  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
     uint64_t part_info[8] = {0};            // last first pass: [0] path (1 one table, 2 partitioned), [1] groups, [2] bucket bits, [3] levels,
                                             // [4] attempts, [5] LDS slots per bucket, [6] buckets, [7] instances
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out

@@ -65,11 +65,13 @@ extern "C" int mdbg_create(int device, mdbg_ctx **out) try {
     if (const char *e = getenv("MDBG_TABLE_BLOCKS_PER_CU")) if (atoi(e) > 0) ctx->table_blocks_per_cu = (unsigned)atoi(e);
     if (const char *e = getenv("MDBG_SCAN_WAVE_PRIORITY")) ctx->scan_wave_priority = (uint32_t)std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("MDBG_SCAN_READS_PER_WAVE")) if (atoi(e) > 0) ctx->scan_reads_per_wave = (unsigned)atoi(e);
+    if (const char *e = getenv("MDBG_SCAN_LDS_RESERVE")) ctx->scan_lds_reserve = (uint32_t)std::max(0, std::min(131072, atoi(e)));
     if (const char *e = getenv("MDBG_SCAN_LDS_PAD")) ctx->scan_lds_pad = (uint32_t)std::max(0, std::min(32768, atoi(e)));
     if (const char *e = getenv("MDBG_PARTITION_TILE")) ctx->part_tile = atoi(e) == 2048 ? 2048u : 0u;
     if (const char *e = getenv("MDBG_PARTITION_SLOT_LIST")) ctx->part_slot_list = atoi(e) != 0;
     if (const char *e = getenv("MDBG_FIRST_PASS_MODE")) ctx->first_pass_mode = std::max(0, std::min(2, atoi(e)));
     ctx->hbm_bytes = prop.totalGlobalMem;
+    ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
     ctx->clock_khz = prop.clockRate;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -190,6 +192,7 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     }
     if (n == "partition_tile") { ctx->part_tile = value == 2048 ? 2048u : 0u; return MDBG_OK; }
     if (n == "partition_slot_list") { ctx->part_slot_list = value != 0; return MDBG_OK; }
+    if (n == "scan_lds_reserve") { ctx->scan_lds_reserve = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(131072, value)); return MDBG_OK; }
     if (n == "scan_lds_pad") { ctx->scan_lds_pad = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(32768, value)); return MDBG_OK; }
     if (n == "partition_max_records") { ctx->part_max_records = value > 0 ? (uint64_t)value : 0; return MDBG_OK; }
     if (n == "test_exchange_fail_phase") { ctx->test_exchange_fail_phase = (int)std::max<int64_t>(0, std::min<int64_t>(3, value)); return MDBG_OK; }

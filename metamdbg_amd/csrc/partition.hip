@@ -413,6 +413,17 @@ __global__ __launch_bounds__(BC_NT) void bucket_count_kernel(RecView in, const u
     if (tid == 0) { n_keys[blockIdx.x] = occupied; n_kept[blockIdx.x] = kept; }
 }
 
+// the canonical vector of the window at m into row `row` (k = 4: one 16-byte store instead of four strided ones)
+__device__ __forceinline__ void store_vector(const uint32_t *m, uint32_t k, bool reversed, uint32_t *vec, uint64_t row) {
+    if (k == 4u) {
+        uint4 v;
+        v.x = reversed ? m[3] : m[0]; v.y = reversed ? m[2] : m[1]; v.z = reversed ? m[1] : m[2]; v.w = reversed ? m[0] : m[3];
+        *reinterpret_cast<uint4 *>(vec + row * 4u) = v;          // the row arrays come from the pool: 256-byte aligned
+        return;
+    }
+    for (uint32_t q = 0; q < k; q++) vec[row * k + q] = reversed ? m[k - 1 - q] : m[q];
+}
+
 // rows of the kept keys, bucket by bucket
 __global__ __launch_bounds__(256) void emit_bucket_rows_kernel(RecView keys, const uint32_t *kcnt, const uint64_t *pos, uint32_t stride,
                                                                const uint32_t *n_kept, const uint64_t *row_of, const uint32_t *mins, RowOut o, uint64_t row_base) {
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(256) void emit_bucket_rows_kernel(RecView keys, con
             reversed = !(x < y);
             break;
         }
-        for (uint32_t q = 0; q < o.k; q++) o.vec[row * o.k + q] = reversed ? m[o.k - 1 - q] : m[q];
+        store_vector(m, o.k, reversed, o.vec, row);
     }
 }
 
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(256) void emit_rescued_p_kernel(const uint64_t *off
                 uint64_t hi, lo;
                 const bool reversed = window_hash_uniform(m, k, hi, lo);
                 o.lo[dst] = lo; o.hi[dst] = hi; o.ab[dst] = 1u;
-                for (uint32_t j = 0; j < k; j++) o.vec[dst * k + j] = reversed ? m[k - 1 - j] : m[j];
+                store_vector(m, k, reversed, o.vec, dst);
             }
             row += (uint32_t)__popc(bal);
         }
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(256) void emit_listed_rows_kernel(const unsigned lo
         reversed = !(x < y);
         break;
     }
-    for (uint32_t q = 0; q < o.k; q++) o.vec[r * o.k + q] = reversed ? m[o.k - 1 - q] : m[q];
+    store_vector(m, o.k, reversed, o.vec, r);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------

@@ -1505,18 +1505,28 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
             if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
             // bump mode: candidates by the upper half of the hash (span_step<APPROX>); the host's re-run of a read covers a false one
             const dim3 g((unsigned)blocks), b(FAST_BLOCK);
-            const unsigned lds_pad = ctx->scan_lds_pad;     // unused dynamic LDS: fewer blocks of this kernel per CU (mdbg_set_option "scan_lds_pad")
-            if (a.cursor && !no_approx) {
-                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, true>), g, b, lds_pad, on, a);
-                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, true>), g, b, lds_pad, on, a);
-                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, true>), g, b, lds_pad, on, a);
-                else hipLaunchKernelGGL((scan_fast_kernel<false, false, true>), g, b, lds_pad, on, a);
-            } else {
-                if (hpc && has_q) hipLaunchKernelGGL((scan_fast_kernel<true, true, false>), g, b, lds_pad, on, a);
-                else if (hpc) hipLaunchKernelGGL((scan_fast_kernel<true, false, false>), g, b, lds_pad, on, a);
-                else if (has_q) hipLaunchKernelGGL((scan_fast_kernel<false, true, false>), g, b, lds_pad, on, a);
-                else hipLaunchKernelGGL((scan_fast_kernel<false, false, false>), g, b, lds_pad, on, a);
+            using FastKernel = void (*)(ScanArgs);
+            const bool approx = a.cursor && !no_approx;
+            const FastKernel fk = approx ? (hpc ? (has_q ? scan_fast_kernel<true, true, true> : scan_fast_kernel<true, false, true>)
+                                                : (has_q ? scan_fast_kernel<false, true, true> : scan_fast_kernel<false, false, true>))
+                                         : (hpc ? (has_q ? scan_fast_kernel<true, true, false> : scan_fast_kernel<true, false, false>)
+                                                : (has_q ? scan_fast_kernel<false, true, false> : scan_fast_kernel<false, false, false>));
+            // Unused dynamic LDS caps this kernel's blocks per CU (mdbg_set_option): "scan_lds_pad" gives the bytes as they are;
+            // "scan_lds_reserve" says how much of a CU's LDS the kernel is to LEAVE to other contexts' kernels, whatever the variant
+            // (30 KB a block for FASTA with homopolymer compression, 36.5 KB for FASTQ): as many blocks as fit beside the reserve, and
+            // enough padding that one more does not.
+            unsigned lds_pad = ctx->scan_lds_pad;
+            if (!lds_pad && ctx->scan_lds_reserve) {
+                hipFuncAttributes at;
+                if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(fk)) == hipSuccess && at.sharedSizeBytes > 0) {
+                    const size_t total = ctx->lds_per_cu ? ctx->lds_per_cu : 163840u, lds = at.sharedSizeBytes;
+                    size_t fit = total > ctx->scan_lds_reserve ? (total - ctx->scan_lds_reserve) / lds : 1;
+                    if (fit < 1) fit = 1;
+                    const size_t need = total / (fit + 1) + 1;          // a block of this size: fit + 1 of them are more than a CU has
+                    if (need > lds) lds_pad = (unsigned)(((need - lds) + 255u) / 256u * 256u);
+                } else (void)hipGetLastError();
             }
+            hipLaunchKernelGGL(fk, g, b, lds_pad, on, a);
         } else if (hpc) {
             if (has_n) { if (has_q) launch_variant<true, true, true>(ctx, a, max_blocks, n_items); else launch_variant<true, false, true>(ctx, a, max_blocks, n_items); }
             else { if (has_q) launch_variant<true, true, false>(ctx, a, max_blocks, n_items); else launch_variant<true, false, false>(ctx, a, max_blocks, n_items); }

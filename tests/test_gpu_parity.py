@@ -1034,7 +1034,7 @@ def test_context_options_do_not_change_results(ctx):
     for options in ({"table_grid_blocks": 7}, {"table_blocks_per_cu": 1}, {"table_cu_count": 16}, {"table_cu_count": 16, "table_grid_blocks": 64},
                     {"pool_cache_percent": 90, "pool_trim": 1}, {"scan_reads_per_wave": 5},
                     # round 4: what a context sharing its device with another batch's scan is given (bench.py), and the first pass's two paths
-                    {"scan_lds_pad": 3072, "partition_tile": 2048, "partition_slot_list": 0}, {"scan_lds_pad": 10304},
+                    {"scan_lds_pad": 3072, "partition_tile": 2048, "partition_slot_list": 0}, {"scan_lds_pad": 10304}, {"scan_lds_reserve": 28672, "partition_lds_slots": 1024},
                     {"first_pass_mode": 1}, {"first_pass_mode": 2}, {"first_pass_mode": 2, "partition_tile": 2048, "partition_slot_list": 0},
                     {"first_pass_mode": 2, "partition_lds_slots": 2048, "partition_slot_list": 0}, {"partition_auto_min": 1}):
         c = capi.Context(0)
