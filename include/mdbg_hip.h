@@ -285,8 +285,11 @@ int  mdbg_table_stats(const mdbg_table *t, uint64_t stats[4]);
  * all keys would not fit the memory budget), [2] = bucket bits per group, [3] = levels of the radix split, [4] = attempts (a
  * bucket that outgrows its LDS table makes the pass repeat with more buckets), [5] = LDS slots per bucket, [6] = buckets per
  * group, [7] = k-min-mer instances.  Options (mdbg_set_option): "first_pass_mode" 0 by size / 1 one table / 2 partitioned,
- * "partition_auto_min" (minimizers from which mode 0 partitions), and for tests "partition_bits", "partition_lds_slots"
- * (256 / 1024 / 2048), "partition_max_records" (instances per group). */
+ * "partition_auto_min" (minimizers from which mode 0 partitions); for a context that shares its device with another context's
+ * scan (a block only runs beside a scan if it fits what the scan's blocks leave of a CU) "partition_tile" 2048,
+ * "partition_slot_list" 0 and "partition_lds_slots" 1024 select the kernels' 24 KB forms and "scan_lds_reserve" (bytes) makes
+ * the scan leave that much of every CU's LDS free; for tests "partition_bits", "partition_lds_slots" (256 / 1024 / 2048),
+ * "partition_max_records" (instances per group).  mdbg_shard_begin counts a rank's share the same way. */
 int  mdbg_first_pass_info(const mdbg_ctx *ctx, uint64_t info[8]);
 /* Order-independent sums over the rows, wrapping at 2^64, computed on the device (nothing but 32 bytes travels):
  *   sums[0] = sum abundance * hash_lo -- the "Checksum kminmer abundance" the reference logs when it loads the table again
