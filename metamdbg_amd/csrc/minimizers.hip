@@ -104,36 +104,43 @@ __device__ __forceinline__ uint32_t purge_replay(Ptr a, uint32_t n, uint32_t fir
 // rocprofv3 trace of round 3 -- and its batch's table pass behind it).
 constexpr uint32_t PURGE_LDS_MAX = 96;
 constexpr uint32_t PURGE_FIX_THREADS = 16;
-__global__ __launch_bounds__(PURGE_FIX_THREADS) void purge_fix_kernel(ReadSpans sp, const uint32_t *list, uint32_t n_list, uint32_t *work,
-                                                                      uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
+// The rows of a suspect read are read from the input and written -- purged -- to the same place of `work`, and the read is marked in
+// `fixed`: `work` holds nothing else (round 4: it used to be a copy of the whole input, 1.5 GB and 2.3 ms per 10 M reads, made for the
+// hundred thousand reads this kernel looks at).
+__global__ __launch_bounds__(PURGE_FIX_THREADS) void purge_fix_kernel(ReadSpans sp, const uint32_t *list, uint32_t n_list, const uint32_t *src, uint32_t *work,
+                                                                      uint8_t *fixed, uint32_t first_k, uint32_t last_k, uint32_t *new_count) {
     __shared__ uint32_t stage[PURGE_FIX_THREADS][PURGE_LDS_MAX + 1];
     uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n_list) return;
     const uint32_t r = list[li];
+    const uint32_t *in = src + sp.begin[r];
     uint32_t *a = work + sp.begin[r];
     uint32_t n = sp.n(r);
     if (n <= PURGE_LDS_MAX) {
         uint32_t *row = stage[threadIdx.x];
-        for (uint32_t i = 0; i < n; i++) row[i] = a[i];
-        const uint32_t m = purge_replay(row, n, first_k, last_k);
-        if (m != n) for (uint32_t i = 0; i < m; i++) a[i] = row[i];
-        n = m;
+        for (uint32_t i = 0; i < n; i++) row[i] = in[i];
+        n = purge_replay(row, n, first_k, last_k);
+        for (uint32_t i = 0; i < n; i++) a[i] = row[i];
     } else {
+        for (uint32_t i = 0; i < n; i++) a[i] = in[i];
         n = purge_replay(a, n, first_k, last_k);
     }
+    fixed[r] = 1;
     new_count[r] = n;
 }
 
 // 16 lanes per read: a chain of dependent loads per read, so reads in flight are what it runs on
+// (fixed, alt: the reads marked in `fixed` come from `alt` -- the purged rows -- instead of `src`; both null: all from `src`)
 __global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *src_off, const uint64_t *dst_off, uint32_t n_reads,
-                                                            const uint32_t *src, uint32_t *dst) {
+                                                            const uint32_t *src, uint32_t *dst, const uint8_t *fixed = nullptr, const uint32_t *alt = nullptr) {
     const unsigned lane = threadIdx.x & 15u;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
     for (uint64_t r = group; r < n_reads; r += ngroups) {
         uint64_t s = src_off[r], d = dst_off[r];
         uint32_t n = (uint32_t)(dst_off[r + 1] - d);
-        for (uint32_t i = lane; i < n; i += 16) dst[d + i] = src[s + i];
+        const uint32_t *from = (fixed && fixed[r]) ? alt : src;
+        for (uint32_t i = lane; i < n; i += 16) dst[d + i] = from[s + i];
     }
 }
 
@@ -506,32 +513,31 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
             if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
         }
     } else {
-        // working copy in the input's own layout (a scattered input occupies n_rows entries, rows of dropped reads included)
+        // room for the purged rows of the suspect reads, in the input's own layout (a scattered input occupies n_rows entries, rows of dropped
+        // reads included); nothing else of it is ever written or read
         const size_t work_n = in->scattered ? (size_t)in->n_rows : (size_t)in->n_min;
         DevBuf<uint32_t> work;
-        if ((rc = work.alloc(ctx, work_n))) return fail(rc);
+        DevBuf<uint8_t> fixed;
+        if ((rc = work.alloc(ctx, work_n)) || (rc = fixed.alloc(ctx, n))) return fail(rc);
         {
             LaunchTimer timer(ctx, "purge_palindromes");
-            e = hipMemcpyAsync(work.p, in->d_min.p, work_n * 4, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge copy failed: %s", hipGetErrorString(e)));
+            e = hipMemsetAsync(fixed.p, 0, n, ctx->stream);
+            if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge memset failed: %s", hipGetErrorString(e)));
             hipLaunchKernelGGL(purge_fix_kernel, dim3(grid_for(n_suspect, PURGE_FIX_THREADS)), dim3(PURGE_FIX_THREADS), 0, ctx->stream, sp, list.p, n_suspect,
-                               work.p, first_k, last_k, cnt.p);
+                               in->d_min.p, work.p, fixed.p, first_k, last_k, cnt.p);
         }
         if ((rc = exclusive_scan_u32(ctx, cnt.p, m->d_off.p, n))) return fail(rc);
         e = memcpy_sync(ctx, &m->n_min, m->d_off.p + n, 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge total copy failed: %s", hipGetErrorString(e)));
         if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg] purge: %u suspect reads of %u, %llu minimizers dropped\n", n_suspect, n,
                                           (unsigned long long)(in->n_min - m->n_min));
-        if (m->n_min == in->n_min && !in->scattered) {
-            // suspects, but nothing was palindromic: the working copy is the output
-            m->d_min = std::move(work);
-        } else {
-            if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
+        if ((rc = m->d_min.alloc(ctx, m->n_min))) return fail(rc);
+        {
             LaunchTimer timer(ctx, "purge_palindromes");
-            hipLaunchKernelGGL(gather_prefix_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, sp.begin, m->d_off.p, n, work.p, m->d_min.p);
-            e = hipStreamSynchronize(ctx->stream);   // `work` goes back to the pool on return
-            if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
+            hipLaunchKernelGGL(gather_prefix_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, sp.begin, m->d_off.p, n, in->d_min.p, m->d_min.p, fixed.p, work.p);
         }
+        e = hipStreamSynchronize(ctx->stream);   // `work` goes back to the pool on return
+        if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "purge failed: %s", hipGetErrorString(e)));
