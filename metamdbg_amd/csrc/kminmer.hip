@@ -1324,6 +1324,16 @@ extern "C" int mdbg_shard_reduce(mdbg_ctx *ctx, mdbg_shard *sh, const uint64_t *
         MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &hz, z.p, 8, hipMemcpyDeviceToHost));
         MDBG_DBG(ctx, "shard_reduce: %llu rows with a zero key word", hz);
     }
+    if (ctx->first_pass_mode != 1) {          // the rows bucketed by key, every bucket summed in LDS (csrc/partition.hip)
+        bool done = false;
+        MDBG_TRY(sh->reply.alloc(ctx, n_recv));
+        MDBG_TRY(part_owner_reduce(ctx, d_recv, n_recv, sh->reply.p, &done));
+        if (done) {
+            sh->reduced = true;
+            *d_reply = sh->reply.p;
+            return MDBG_OK;
+        }
+    }
     MDBG_TRY(build_table_adaptive(ctx, sh->owner, expected < n_recv ? expected : n_recv, n_recv, [&](TableView v) {
         if (n_recv) {
             LaunchTimer timer(ctx, "shard_reduce");

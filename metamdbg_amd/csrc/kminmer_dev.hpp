@@ -123,5 +123,8 @@ int part_local_keys(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, Par
 void part_local_arrays(const PartLocal *p, const uint64_t **lo, const uint64_t **hi, const uint32_t **cnt, uint64_t *n, uint64_t *n_inst);
 int part_local_finish(mdbg_ctx *ctx, PartLocal *p, const uint32_t *gcount, const uint32_t *listed, uint32_t min_abundance, mdbg_table **out);
 void part_local_free(PartLocal *p);
+// the owner's side of a sharded pass: n_recv rows [lo, hi, count] summed by key in per-bucket LDS tables; one reply per row, in place
+// (sum | bit 63 for the row that lists the key).  *done = false: not for this path (few rows, a key with a zero word): the one-table pass
+int part_owner_reduce(mdbg_ctx *ctx, const uint64_t *d_rows, uint64_t n_recv, uint64_t *d_reply, bool *done);
 
 }  // namespace mdbg

@@ -578,6 +578,67 @@ __global__ __launch_bounds__(256) void emit_listed_rows_kernel(const unsigned lo
     store_vector(m, o.k, reversed, o.vec, r);
 }
 
+// ---- the owner's side of a sharded pass: the rows it received, summed by key ---------------------------------------------------------
+// rows [lo, hi, count] as they arrived -> records {lo, hi, index of the row}
+__global__ __launch_bounds__(256) void rows_to_records_kernel(const uint64_t *rows, uint64_t n, RecView out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out.lo[i] = rows[3 * i]; out.hi[i] = rows[3 * i + 1]; out.rep[i] = (uint32_t)i;
+}
+
+template <uint32_t C>
+__device__ __forceinline__ uint32_t lds_slot(LdsTable<C> &t, uint64_t lo, uint64_t hi) {      // find or create, nothing counted
+    uint32_t s = (uint32_t)lo & (C - 1u);
+    for (uint32_t probes = 0; probes < C; probes++, s = (s + 1u) & (C - 1u)) {
+        unsigned long long cur = __hip_atomic_load(&t.lo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == 0ull) {
+            cur = atomicCAS(&t.lo[s], 0ull, (unsigned long long)lo);
+            if (cur == 0ull) cur = lo;
+        }
+        if (cur != lo) continue;
+        unsigned long long h = __hip_atomic_load(&t.hi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (h == 0ull) {
+            h = atomicCAS(&t.hi[s], 0ull, (unsigned long long)hi);
+            if (h == 0ull) h = hi;
+        }
+        if (h == hi) return s;
+    }
+    return LDS_NONE;
+}
+
+// One workgroup per bucket of received rows: the counts of equal keys summed in LDS, the row with the smallest index named the key's
+// lister, and every row answered in place: reply[row] = sum | bit 63 for the lister (what rows_add_kernel / rows_reply_kernel do with one
+// table in HBM and two device-scope atomics per row).
+template <uint32_t C>
+__global__ __launch_bounds__(BC_NT) void owner_bucket_kernel(RecView in, const uint64_t *pos, uint32_t stride, const uint64_t *rows, uint64_t *reply, uint32_t *overflow) {
+    __shared__ LdsTable<C> t;
+    __shared__ uint32_t give_up;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t s0 = pos[(uint64_t)blockIdx.x * stride], n = pos[(uint64_t)(blockIdx.x + 1) * stride] - s0;
+    for (uint32_t s = tid; s < C; s += BC_NT) { t.lo[s] = 0ull; t.hi[s] = 0ull; t.cnt[s] = 0u; t.rep[s] = 0xFFFFFFFFu; }
+    if (tid == 0) give_up = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (give_up) return;
+    bool failed = false;
+    for (uint64_t i = tid; i < n; i += BC_NT) {
+        const uint64_t lo = in.lo[s0 + i], hi = in.hi[s0 + i];
+        const uint32_t row = in.rep[s0 + i];
+        uint32_t s = LDS_NONE;
+        if (lo != 0ull && hi != 0ull) s = lds_slot<C>(t, lo, hi);
+        if (s == LDS_NONE) { failed = true; continue; }
+        atomicAdd(&t.cnt[s], (uint32_t)rows[3ull * row + 2]);
+        atomicMin(&t.rep[s], row);
+    }
+    if (failed) { atomicExch(overflow, 1u); __hip_atomic_store(&give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __syncthreads();
+    if (give_up) return;
+    for (uint64_t i = tid; i < n; i += BC_NT) {
+        const uint32_t row = in.rep[s0 + i];
+        const uint32_t s = lds_find<C>(t, in.lo[s0 + i], in.hi[s0 + i]);
+        reply[row] = (uint64_t)t.cnt[s] | (t.rep[s] == row ? (1ull << 63) : 0ull);
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------------------
 struct RecBufs {
     DevBuf<unsigned long long> lo, hi;
@@ -1065,6 +1126,63 @@ int part_local_finish(mdbg_ctx *ctx, PartLocal *pl, const uint32_t *gcount, cons
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "sharded first pass (partitioned) failed: %s", hipGetErrorString(e));
     *out = t.release();
+    return MDBG_OK;
+}
+
+// ---- the owner's side: n_recv rows [lo, hi, count] -> one reply per row (global count | bit 63 = this row's sender lists the key) -------
+template <uint32_t C>
+static void launch_owner_buckets(mdbg_ctx *ctx, uint64_t n_buckets, RecView in, const uint64_t *pos, uint32_t stride, const uint64_t *rows, uint64_t *reply, uint32_t *overflow) {
+    hipLaunchKernelGGL(owner_bucket_kernel<C>, dim3((unsigned)n_buckets), dim3(BC_NT), 0, ctx->stream, in, pos, stride, rows, reply, overflow);
+}
+
+int part_owner_reduce(mdbg_ctx *ctx, const uint64_t *d_rows, uint64_t n_recv, uint64_t *d_reply, bool *done) {
+    *done = false;
+    if (n_recv < (1ull << 17) || n_recv >= (1ull << 32)) return MDBG_OK;
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t lds_slots = ctx->part_lds_slots == 256 || ctx->part_lds_slots == 2048 ? ctx->part_lds_slots : 1024u;
+    // every bucket must hold its rows' distinct keys: sized for the ROWS (a key arrives once from every rank that saw it, so this is generous)
+    uint32_t bits = 0;
+    while ((double)(1ull << bits) < (double)n_recv / (0.78 * lds_slots) && bits < 24) bits++;
+    const uint32_t n_levels = bits <= 8 ? 1u : (bits + 7u) / 8u;
+    const uint32_t tile = ctx->part_tile == 2048 ? PART_TILE / 2 : PART_TILE;
+    RecBufs buf[2];
+    MDBG_TRY(buf[0].ensure(ctx, n_recv));
+    MDBG_TRY(buf[1].ensure(ctx, n_recv));
+    DevBuf<uint32_t> hist, overflow;
+    DevBuf<uint64_t> place[3];
+    MDBG_TRY(overflow.alloc(ctx, 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(overflow.p, 0, 4, ctx->stream));
+    LaunchTimer timer(ctx, "shard_reduce");
+    hipLaunchKernelGGL(rows_to_records_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_rows, n_recv, buf[0].view());
+    uint32_t cur = 0, left = bits, used = 0, prev_bps = 1;
+    uint64_t n_seg = 1;
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t b = (left + (n_levels - l) - 1) / (n_levels - l);
+        SplitArgs d{};
+        d.in = buf[cur].view();
+        d.n_min = n_recv;                                          // level 1: one segment, the rows as they arrived
+        d.seg_pos = l ? place[l - 1].p : nullptr; d.seg_stride = prev_bps;
+        const uint64_t avg_tiles = (n_recv / n_seg + tile - 1) / tile;
+        d.blocks_per_seg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(1, 4096 / n_seg), avg_tiles));
+        d.ways = 1u << b; d.shift = b ? 64u - used - b : 0u; d.tile = tile;
+        const uint64_t entries = n_seg * d.ways * d.blocks_per_seg;
+        MDBG_TRY(hist.alloc(ctx, entries));
+        MDBG_TRY(place[l].alloc(ctx, entries + 1));
+        const unsigned grid = (unsigned)(n_seg * d.blocks_per_seg);
+        hipLaunchKernelGGL(split_hist_kernel<false>, dim3(grid), dim3(PART_NT), 0, ctx->stream, d, hist.p);
+        MDBG_TRY(exclusive_scan_u32(ctx, hist.p, place[l].p, entries));
+        if (tile != PART_TILE) hipLaunchKernelGGL((split_scatter_kernel<false, PART_E / 2>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+        else hipLaunchKernelGGL((split_scatter_kernel<false, PART_E>), dim3(grid), dim3(PART_NT), 0, ctx->stream, d, place[l].p, buf[cur ^ 1].view());
+        cur ^= 1; used += b; left -= b; n_seg <<= b; prev_bps = d.blocks_per_seg;
+    }
+    const uint64_t n_buckets = 1ull << bits;
+    if (lds_slots == 256) launch_owner_buckets<256>(ctx, n_buckets, buf[cur].view(), place[n_levels - 1].p, prev_bps, d_rows, d_reply, overflow.p);
+    else if (lds_slots == 1024) launch_owner_buckets<1024>(ctx, n_buckets, buf[cur].view(), place[n_levels - 1].p, prev_bps, d_rows, d_reply, overflow.p);
+    else launch_owner_buckets<2048>(ctx, n_buckets, buf[cur].view(), place[n_levels - 1].p, prev_bps, d_rows, d_reply, overflow.p);
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
+    uint32_t ov = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, overflow.p, 4, hipMemcpyDeviceToHost));
+    *done = ov == 0;                                               // a key with a zero word, or a bucket of more keys than slots: the one-table pass takes it
     return MDBG_OK;
 }
 
