@@ -247,6 +247,11 @@ inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks
     uint64_t b = (items + per_block - 1) / per_block;
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
+    // (a launch of 2^32 threads or more does not fail, it wraps: kernels over that many items are grid-stride and name their cap)
+    if (b * per_block >= (1ull << 32) && max_blocks == 1u << 30) {
+        fprintf(stderr, "mdbg_hip: a launch over %llu items needs a capped grid\n", (unsigned long long)items);
+        abort();
+    }
     return (unsigned)b;
 }
 

@@ -683,6 +683,8 @@ static double hll_estimate(const uint32_t *regs) {
 // One partitioned pass over a read set: the plan, the buffers, and the two halves every user runs per group of keys -- split_group (the
 // radix levels) and count_group (one workgroup per bucket) -- which mdbg_kminmer_count_first and the sharded first pass put together
 // differently (the latter keeps every distinct key and walks the records a second time once the global counts are back).
+constexpr uint32_t PART_MAX_BITS = 22;
+
 struct PartRun {
     mdbg_ctx *ctx = nullptr;
     const mdbg_minimizers *reads = nullptr;
@@ -719,7 +721,7 @@ struct PartRun {
     void plan() {
         lds_slots = ctx->part_lds_slots;
         // (1024 slots where they need no level more than 2048 would: four buckets instead of two per CU count a fifth faster)
-        if (!lds_slots) lds_slots = levels_for(bits_for(1024) + extra_bits) <= levels_for(bits_for(2048) + extra_bits) ? 1024u : 2048u;
+        if (!lds_slots) lds_slots = levels_for(bits_for(1024) + extra_bits) <= levels_for(bits_for(2048) + extra_bits) && bits_for(1024) + extra_bits <= PART_MAX_BITS ? 1024u : 2048u;
         bucket_bits = (ctx->part_bits ? ctx->part_bits : bits_for(lds_slots)) + extra_bits;
         n_levels = levels_for(bucket_bits);
         // level 1 takes 8 bits whenever there are that many, the deeper levels share the rest
@@ -734,7 +736,9 @@ struct PartRun {
             left -= b; segs <<= b;
         }
     }
-    bool too_many_buckets() const { return bucket_bits > 24; }   // more distinct keys than three levels of buckets hold: not for this path
+    // more distinct keys than the buckets of one launch hold (one 512-thread workgroup per bucket, and a launch of 2^32 threads wraps): not
+    // for this path -- 2^22 buckets of 2048 slots are 6.7 G keys per key group, more than the 2^32 minimizers a call takes
+    bool too_many_buckets() const { return bucket_bits > PART_MAX_BITS; }
 
     // sequence starts (one bit per minimizer), the key groups, the first plan
     int init(mdbg_ctx *c, const mdbg_minimizers *r, uint32_t k_) {
@@ -1142,7 +1146,8 @@ int part_owner_reduce(mdbg_ctx *ctx, const uint64_t *d_rows, uint64_t n_recv, ui
     const uint32_t lds_slots = ctx->part_lds_slots == 256 || ctx->part_lds_slots == 2048 ? ctx->part_lds_slots : 1024u;
     // every bucket must hold its rows' distinct keys: sized for the ROWS (a key arrives once from every rank that saw it, so this is generous)
     uint32_t bits = 0;
-    while ((double)(1ull << bits) < (double)n_recv / (0.78 * lds_slots) && bits < 24) bits++;
+    while ((double)(1ull << bits) < (double)n_recv / (0.78 * lds_slots) && bits <= PART_MAX_BITS) bits++;
+    if (bits > PART_MAX_BITS) return MDBG_OK;
     const uint32_t n_levels = bits <= 8 ? 1u : (bits + 7u) / 8u;
     const uint32_t tile = ctx->part_tile == 2048 ? PART_TILE / 2 : PART_TILE;
     RecBufs buf[2];

@@ -117,38 +117,40 @@ struct SynthArgs {
     uint8_t *qual;                    // nullptr or n_reads * read_len
 };
 
+// (grid-stride: a launch of 2^32 threads or more wraps around -- 40 M reads x 314 words ran as the first 12.64 M reads and left the rest
+// zero, which the N = 1 point of a 40 M-read strong-scaling run showed as 11.8 minimizers per read)
 __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = (uint64_t)a.n_reads * a.words_per_read;
-    if (gid >= total) return;
-    const uint32_t rl = (uint32_t)(gid / a.words_per_read);
-    const uint32_t w = (uint32_t)(gid % a.words_per_read);
-    const uint64_t r = a.first_read + rl;
-    const uint32_t L = a.read_len;
-    // layout (synth.read_layout)
     const uint64_t base = mix64(a.seed ^ 0xA5A5A5A5A5A5A5A5ull);
-    const uint64_t u_species = mix64(base + 4 * r), u_start = mix64(base + 4 * r + 1), u_strand = mix64(base + 4 * r + 2);
-    uint32_t sp = 0;
-    while (sp + 1 < a.n_species && !(u_species < a.species_thr[sp])) sp++;
-    const uint64_t span = a.species_len[sp] - a.window + 1;
-    const uint64_t start = a.species_off[sp] + (u_start % span);
-    const unsigned strand = (unsigned)(u_strand & 1ull);
     const uint64_t gkey = mix64(a.seed);
-    const uint64_t ekey = mix64(mix64(a.seed ^ 0x5EED5EED5EED5EEDull) + r);
-    const uint64_t qkey = mix64(mix64(a.seed ^ 0x0123456789ABCDEFull) + r);
-    uint64_t x = 0;
-    for (int i = 0; i < 32; i++) {
-        uint32_t bi = w * 32 + i;
-        if (bi >= L) break;
-        uint64_t gpos = strand ? (start + (L - 1) - bi) : (start + bi);
-        unsigned code = (unsigned)(mix64(gkey + gpos) >> 62);
-        if (strand) code ^= 2u;
-        uint64_t e = mix64(ekey + bi);
-        if (e < a.sub_thr) code = (code + 1u + (unsigned)(mix64(e) % 3ull)) & 3u;
-        x |= (uint64_t)code << (2 * i);
-        if (a.qual) a.qual[(uint64_t)rl * L + bi] = (uint8_t)(mix64(qkey + bi) % 30ull + 43ull);
+    for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t rl = (uint32_t)(gid / a.words_per_read);
+        const uint32_t w = (uint32_t)(gid % a.words_per_read);
+        const uint64_t r = a.first_read + rl;
+        const uint32_t L = a.read_len;
+        // layout (synth.read_layout)
+        const uint64_t u_species = mix64(base + 4 * r), u_start = mix64(base + 4 * r + 1), u_strand = mix64(base + 4 * r + 2);
+        uint32_t sp = 0;
+        while (sp + 1 < a.n_species && !(u_species < a.species_thr[sp])) sp++;
+        const uint64_t span = a.species_len[sp] - a.window + 1;
+        const uint64_t start = a.species_off[sp] + (u_start % span);
+        const unsigned strand = (unsigned)(u_strand & 1ull);
+        const uint64_t ekey = mix64(mix64(a.seed ^ 0x5EED5EED5EED5EEDull) + r);
+        const uint64_t qkey = mix64(mix64(a.seed ^ 0x0123456789ABCDEFull) + r);
+        uint64_t x = 0;
+        for (int i = 0; i < 32; i++) {
+            uint32_t bi = w * 32 + i;
+            if (bi >= L) break;
+            uint64_t gpos = strand ? (start + (L - 1) - bi) : (start + bi);
+            unsigned code = (unsigned)(mix64(gkey + gpos) >> 62);
+            if (strand) code ^= 2u;
+            uint64_t e = mix64(ekey + bi);
+            if (e < a.sub_thr) code = (code + 1u + (unsigned)(mix64(e) % 3ull)) & 3u;
+            x |= (uint64_t)code << (2 * i);
+            if (a.qual) a.qual[(uint64_t)rl * L + bi] = (uint8_t)(mix64(qkey + bi) % 30ull + 43ull);
+        }
+        a.words[gid] = x;
     }
-    a.words[gid] = x;
 }
 
 // Reads with insertions and deletions (synth.read_codes): read position i shows genome base k(i) = i - #insertions before i
@@ -573,7 +575,7 @@ extern "C" int mdbg_reads_synthetic(mdbg_ctx *ctx, uint64_t seed, uint32_t n_rea
     uint64_t total = (uint64_t)n_reads * wpr;
     if (total) {
         if (indels) hipLaunchKernelGGL(synth_indel_kernel, dim3(grid_for((uint64_t)n_reads * 64, 256, (unsigned)ctx->n_cu * 16u)), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(synth_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(synth_kernel, dim3(grid_for(total, 256, 1u << 22)), dim3(256), 0, ctx->stream, a);
         hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, ctx->stream, r->d_len.p, (uint64_t)n_reads, read_len);
     }
     hipLaunchKernelGGL(iota_scaled_u64_kernel, dim3(grid_for((uint64_t)n_reads + 1, 256)), dim3(256), 0, ctx->stream,
