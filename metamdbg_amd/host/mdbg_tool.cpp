@@ -946,6 +946,45 @@ struct RankTable {
     std::string smallContigs;        // records for smallContigs_k<k>.bin (the rank that holds unitig_data.txt)
 };
 
+// What a pass at k > firstK looks its reads up in, on the device: the previous table with the refined abundances laid over it, and -- on the
+// rank / piece that holds them -- the unitigs of unitig_data.txt, whose short ones become smallContigs_k<k>.bin records.
+struct PrevOnDevice {
+    mdbg_table *prev = nullptr;
+    mdbg_minimizers *unitigs = nullptr;
+    void build(mdbg_ctx *ctx, const Parameters &P, const PrevInputs &in, bool withUnitigs, std::string &smallContigs) {
+        const uint32_t k = (uint32_t)P.kminmerSize;
+        check_on(ctx, mdbg_prev_from_records(ctx, in.prevRec.data(), in.prevRec.size() / 20, &prev), "mdbg_prev_from_records");
+        if (!in.uab.empty()) {
+            mdbg_minimizers *un = nullptr;
+            check_on(ctx, mdbg_minimizers_from_host(ctx, in.um.data(), in.uoff.data(), (uint32_t)in.uab.size(), &un), "mdbg_minimizers_from_host");
+            check_on(ctx, mdbg_prev_overlay_unitigs(ctx, prev, un, in.uab.data(), (uint32_t)P.prevK), "mdbg_prev_overlay_unitigs");
+            mdbg_minimizers_free(un);
+        }
+        if (in.hasUnitigs && withUnitigs)
+            check_on(ctx, mdbg_minimizers_from_host(ctx, in.unitigMins.data(), in.unitigOffs.data(), (uint32_t)(in.unitigOffs.size() - 1), &unitigs),
+                     "mdbg_minimizers_from_host");
+        // smallContigs_k<k>.bin is filled by the unitig pass of IndexKminmerFunctor when k > 8 (graph/CreateMdbg.hpp:1330-1352);
+        // those unitigs have no k-min-mer, so they add nothing to the table.
+        if (unitigs && k > 8 && k != P.firstK + 1) {
+            const uint32_t nUnitigs = (uint32_t)(in.unitigOffs.size() - 1);
+            std::vector<uint8_t> isSmall(nUnitigs);
+            check_on(ctx, mdbg_small_contigs(ctx, unitigs, k, (uint32_t)P.prevK, prev, isSmall.data()), "mdbg_small_contigs");
+            for (uint32_t u = 0; u < nUnitigs; u++) {
+                if (!isSmall[u]) continue;
+                const uint32_t n = (uint32_t)(in.unitigOffs[u + 1] - in.unitigOffs[u]);
+                const uint8_t circ = in.unitigCirc[u];   // the record's own flag byte (Commons.hpp:7413, :7485)
+                smallContigs.append((const char *)&n, 4); smallContigs.append((const char *)&circ, 1);
+                smallContigs.append((const char *)(in.unitigMins.data() + in.unitigOffs[u]), (size_t)n * 4);
+            }
+        }
+    }
+    void free() {
+        if (unitigs) mdbg_minimizers_free(unitigs);
+        if (prev) mdbg_table_free(prev);
+        unitigs = nullptr; prev = nullptr;
+    }
+};
+
 // One rank's part of `graph`: reads [r0, r1) of read_data_corrected.txt on `ctx`; with a communicator the table is built
 // across the ranks (include/mdbg_hip.h "the exchange inside the library") and `out` is this rank's share of it.
 // unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
@@ -961,32 +1000,10 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
         if (comm) check_on(ctx, mdbg_kminmer_count_first_sharded(ctx, comm, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first_sharded");
         else check_on(ctx, mdbg_kminmer_count_first(ctx, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first");
     } else {
-        mdbg_table *prev = nullptr;
-        check_on(ctx, mdbg_prev_from_records(ctx, in.prevRec.data(), in.prevRec.size() / 20, &prev), "mdbg_prev_from_records");
-        if (!in.uab.empty()) {
-            mdbg_minimizers *un = nullptr;
-            check_on(ctx, mdbg_minimizers_from_host(ctx, in.um.data(), in.uoff.data(), (uint32_t)in.uab.size(), &un), "mdbg_minimizers_from_host");
-            check_on(ctx, mdbg_prev_overlay_unitigs(ctx, prev, un, in.uab.data(), (uint32_t)P.prevK), "mdbg_prev_overlay_unitigs");
-            mdbg_minimizers_free(un);
-        }
-        mdbg_minimizers *unitigs = nullptr;
-        if (in.hasUnitigs && rank == 0)
-            check_on(ctx, mdbg_minimizers_from_host(ctx, in.unitigMins.data(), in.unitigOffs.data(), (uint32_t)(in.unitigOffs.size() - 1), &unitigs),
-                     "mdbg_minimizers_from_host");
-        // smallContigs_k<k>.bin is filled by the unitig pass of IndexKminmerFunctor when k > 8 (graph/CreateMdbg.hpp:1330-1352);
-        // those unitigs have no k-min-mer, so they add nothing to the table below.
-        if (unitigs && k > 8 && k != P.firstK + 1) {
-            const uint32_t nUnitigs = (uint32_t)(in.unitigOffs.size() - 1);
-            std::vector<uint8_t> isSmall(nUnitigs);
-            check_on(ctx, mdbg_small_contigs(ctx, unitigs, k, (uint32_t)P.prevK, prev, isSmall.data()), "mdbg_small_contigs");
-            for (uint32_t u = 0; u < nUnitigs; u++) {
-                if (!isSmall[u]) continue;
-                const uint32_t n = (uint32_t)(in.unitigOffs[u + 1] - in.unitigOffs[u]);
-                const uint8_t circ = in.unitigCirc[u];   // the record's own flag byte (Commons.hpp:7413, :7485)
-                out.smallContigs.append((const char *)&n, 4); out.smallContigs.append((const char *)&circ, 1);
-                out.smallContigs.append((const char *)(in.unitigMins.data() + in.unitigOffs[u]), (size_t)n * 4);
-            }
-        }
+        PrevOnDevice dev;
+        dev.build(ctx, P, in, rank == 0, out.smallContigs);
+        mdbg_table *prev = dev.prev;
+        mdbg_minimizers *unitigs = dev.unitigs;
         mdbg_table *local = nullptr;
         if (k == P.firstK + 1) check_on(ctx, mdbg_kminmer_count_refined(ctx, reads, unitigs, k, prev, &local), "mdbg_kminmer_count_refined");
         else check_on(ctx, mdbg_kminmer_index(ctx, reads, unitigs, k, prev, &local), "mdbg_kminmer_index");
@@ -1001,8 +1018,7 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
             mdbg_shard_free(sh);
             mdbg_table_free(local);
         } else table = local;
-        if (unitigs) mdbg_minimizers_free(unitigs);
-        mdbg_table_free(prev);
+        dev.free();
     }
     mdbg_table_info(table, nullptr, &out.n, &out.nSolid, &out.hasVec);
     check_on(ctx, mdbg_table_checksum(ctx, table, out.sums), "mdbg_table_checksum");
@@ -1020,19 +1036,21 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
 // buffers while the piece before is written -- every file by a thread of its own (the 20-byte records go to kminmerData_abundance.txt and to
 // its `_init` copy, graph/CreateMdbg.cpp:515-522; the vectors to kminmerData_min.txt).  The ONT preset's first pass leaves 75 M records per
 // 20 Gbp: 2.7 GB of rows, 4.2 GB of files -- 1.2 s of a 1.65 s `graph` when they went through pageable vectors and one writing thread.
-void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const std::vector<std::string> &recFiles, const std::string &vecFile) {
+// (rowBase > 0: the table is the next share of a pass made in pieces -- its rows follow the rowBase rows already in the files)
+void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const std::vector<std::string> &recFiles, const std::string &vecFile,
+                           uint64_t rowBase = 0, bool firstShare = true) {
     uint64_t n = 0;
     int hasVec = 0;
     mdbg_table_info(table, nullptr, &n, nullptr, &hasVec);
     const bool vec = hasVec && !vecFile.empty();
     std::vector<int> recFd, vecFd;
     for (const std::string &f : recFiles) {
-        const int fd = open(f.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        const int fd = open(f.c_str(), O_CREAT | (firstShare ? O_TRUNC : 0) | O_WRONLY, 0644);
         if (fd < 0) die("cannot write " + f);
         recFd.push_back(fd);
     }
     if (vec) {
-        const int fd = open(vecFile.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        const int fd = open(vecFile.c_str(), O_CREAT | (firstShare ? O_TRUNC : 0) | O_WRONLY, 0644);
         if (fd < 0) die("cannot write " + vecFile);
         vecFd.push_back(fd);
     }
@@ -1059,13 +1077,67 @@ void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const s
         check_on(ctx, mdbg_table_to_host_range(ctx, table, first, cnt, b.rec, vec ? b.vec : nullptr), "mdbg_table_to_host_range");
         for (auto &t : writers) t.join();        // the other buffer is free again, this one is full
         writers.clear();
-        for (int fd : recFd) writers.emplace_back(put, fd, (const void *)b.rec, (size_t)(cnt * 20), first * 20);
-        for (int fd : vecFd) writers.emplace_back(put, fd, (const void *)b.vec, (size_t)(cnt * k * 4), first * k * 4);
+        for (int fd : recFd) writers.emplace_back(put, fd, (const void *)b.rec, (size_t)(cnt * 20), (rowBase + first) * 20);
+        for (int fd : vecFd) writers.emplace_back(put, fd, (const void *)b.vec, (size_t)(cnt * k * 4), (rowBase + first) * k * 4);
     }
     for (auto &t : writers) t.join();
     for (int fd : recFd) if (close(fd) != 0) die("closing a table file failed");
     for (int fd : vecFd) if (close(fd) != 0) die("closing a table file failed");
     for (Buf &b : buf) { if (b.rec) mdbg_host_free(ctx, b.rec); if (b.vec) mdbg_host_free(ctx, b.vec); }
+}
+
+// `graph` in pieces on one device: a read set with more minimizers than one call of the library takes (2^32: the flat index of an instance's first
+// minimizer is 32 bits in the records of the first pass) is cut into contiguous read ranges, every range is put through the pass as ONE RANK OF A
+// SHARDED JOB would be -- mdbg_shard_begin (or the range's own table -> mdbg_shard_from_table at k > firstK), the exchange among the pieces on the
+// device (mdbg_shard_exchange_local), mdbg_shard_finish / _keep -- and the shares are written one after the other: their union IS the table of the
+// whole set (include/mdbg_hip.h, "sharded first pass"; the reference meets the same limit-free way on disk, `vecHash % _nbPartitions`,
+// graph/CreateMdbg.hpp:3714-3851).  The minimizers of all the pieces stay on the device until the last share is written (4 bytes each).
+// cuts: read indexes, cuts[p] .. cuts[p + 1] = piece p.
+void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Vec &mins, const std::vector<uint64_t> &offs, const std::vector<size_t> &cuts,
+                  const PrevInputs &in, RankTable &out, const std::function<void(mdbg_ctx *, mdbg_table *, uint64_t, bool)> &sink) {
+    const uint32_t k = (uint32_t)P.kminmerSize;
+    const uint32_t n = (uint32_t)(cuts.size() - 1);
+    if (n > 64) die("graph: more than 64 pieces (" + std::to_string(n) + "): raise MDBG_TOOL_MAX_MINIMIZERS");
+    std::vector<mdbg_minimizers *> reads(n, nullptr);
+    std::vector<mdbg_shard *> shards(n, nullptr);
+    std::vector<mdbg_table *> local(n, nullptr);
+    std::vector<const uint64_t *> dRows(n, nullptr), dReplies(n, nullptr);
+    std::vector<uint64_t> counts((size_t)n * n + 64, 0);
+    PrevOnDevice dev;
+    if (!a.firstPass) dev.build(ctx, P, in, true, out.smallContigs);
+    for (uint32_t p = 0; p < n; p++) {
+        std::vector<uint64_t> rel(offs.begin() + (long)cuts[p], offs.begin() + (long)cuts[p + 1] + 1);
+        check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(cuts[p + 1] - cuts[p]), &reads[p]), "mdbg_minimizers_from_host");
+        std::vector<uint64_t> c(64, 0);
+        if (a.firstPass) check_on(ctx, mdbg_shard_begin(ctx, reads[p], k, n, &shards[p], &dRows[p], c.data()), "mdbg_shard_begin");
+        else {
+            mdbg_minimizers *unitigs = p == 0 ? dev.unitigs : nullptr;      // sequences, not reads: with the first piece
+            if (k == P.firstK + 1) check_on(ctx, mdbg_kminmer_count_refined(ctx, reads[p], unitigs, k, dev.prev, &local[p]), "mdbg_kminmer_count_refined");
+            else check_on(ctx, mdbg_kminmer_index(ctx, reads[p], unitigs, k, dev.prev, &local[p]), "mdbg_kminmer_index");
+            check_on(ctx, mdbg_shard_from_table(ctx, local[p], n, &shards[p], &dRows[p], c.data()), "mdbg_shard_from_table");
+        }
+        for (uint32_t d = 0; d < n; d++) counts[(size_t)p * n + d] = c[d];
+    }
+    dev.free();
+    check_on(ctx, mdbg_shard_exchange_local(ctx, shards.data(), n, dRows.data(), counts.data(), dReplies.data()), "mdbg_shard_exchange_local");
+    uint64_t rowBase = 0;
+    for (uint32_t p = 0; p < n; p++) {
+        mdbg_table *share = nullptr;
+        if (a.firstPass) check_on(ctx, mdbg_shard_finish(ctx, shards[p], dReplies[p], a.minAbundance, &share), "mdbg_shard_finish");
+        else check_on(ctx, mdbg_shard_keep(ctx, shards[p], dReplies[p], &share), "mdbg_shard_keep");
+        uint64_t rows = 0, solid = 0, sums[4] = {0, 0, 0, 0};
+        int hasVec = 0;
+        mdbg_table_info(share, nullptr, &rows, &solid, &hasVec);
+        check_on(ctx, mdbg_table_checksum(ctx, share, sums), "mdbg_table_checksum");
+        out.n += rows; out.nSolid += solid; out.hasVec |= hasVec;
+        for (int i = 0; i < 4; i++) out.sums[i] += sums[i];
+        sink(ctx, share, rowBase, p == 0);
+        rowBase += rows;
+        mdbg_table_free(share);
+        mdbg_shard_free(shards[p]);
+        if (local[p]) mdbg_table_free(local[p]);
+        mdbg_minimizers_free(reads[p]);
+    }
 }
 
 int run_graph(int argc, char **argv) {
@@ -1110,8 +1182,23 @@ int run_graph(int argc, char **argv) {
         std::vector<std::string> recFiles{dir + "/kminmerData_abundance.txt"};
         if (a.firstPass) recFiles.push_back(dir + "/kminmerData_abundance_init.txt");
         if (k == P.firstK + 1) recFiles.push_back(dir + "/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
-        graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0], false,
-                   [&](mdbg_ctx *c, mdbg_table *t) { stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt"); });
+        // more minimizers than one call of the library takes: the pass in pieces (MDBG_TOOL_MAX_MINIMIZERS: the most one piece may hold)
+        uint64_t maxMins = 3500000000ull;
+        if (const char *e = getenv("MDBG_TOOL_MAX_MINIMIZERS")) maxMins = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        std::vector<size_t> cuts{0};
+        for (size_t r = 0, first = 0; r < nReads; r++) {
+            if (offs[r + 1] - offs[r] > maxMins) die("graph: one read has more minimizers than a piece may hold");
+            if (offs[r + 1] - offs[first] > maxMins) { cuts.push_back(r); first = r; }
+        }
+        cuts.push_back(nReads);
+        if (cuts.size() > 2) {
+            g_log.line("\tThe pass runs in " + std::to_string(cuts.size() - 1) + " pieces of at most " + std::to_string(maxMins) + " minimizers");
+            graph_pieces(g_ctx, P, a, mins, offs, cuts, in, parts[0], [&](mdbg_ctx *c, mdbg_table *t, uint64_t rowBase, bool firstShare) {
+                stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt", rowBase, firstShare);
+            });
+        } else
+            graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0], false,
+                       [&](mdbg_ctx *c, mdbg_table *t) { stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt"); });
         streamed = true;
         g_trace.mark("graph: table built and written");
     } else {

@@ -135,6 +135,9 @@ int mdbg_table_to_host_range(mdbg_ctx *, const mdbg_table *, uint64_t, uint64_t,
 void mdbg_table_free(mdbg_table *t) { delete t; }
 int mdbg_shard_from_table(mdbg_ctx *, const mdbg_table *, uint32_t, mdbg_shard **, const uint64_t **, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_shard_exchange(mdbg_ctx *, mdbg_comm *, mdbg_shard *, const uint64_t *, const uint64_t *, const uint64_t **) { return MDBG_ENODEV; }
+int mdbg_shard_begin(mdbg_ctx *, const mdbg_minimizers *, uint32_t, uint32_t, mdbg_shard **, const uint64_t **, uint64_t *) { return MDBG_ENODEV; }
+int mdbg_shard_finish(mdbg_ctx *, mdbg_shard *, const uint64_t *, uint32_t, mdbg_table **) { return MDBG_ENODEV; }
+int mdbg_shard_exchange_local(mdbg_ctx *, mdbg_shard *const *, uint32_t, const uint64_t *const *, const uint64_t *, const uint64_t **) { return MDBG_ENODEV; }
 int mdbg_shard_keep(mdbg_ctx *, mdbg_shard *, const uint64_t *, mdbg_table **) { return MDBG_ENODEV; }
 void mdbg_shard_free(mdbg_shard *s) { delete s; }
 int mdbg_comm_unique_id(uint8_t *) { return MDBG_ENODEV; }

@@ -370,3 +370,97 @@ def test_tool_graph_through_the_library_exchange(tmp_path, gpus):
             assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k), fx["min_sorted"]), k
         got = fbytes(tmp, os.path.join("smallContigs", f"smallContigs_k{k}.bin"))
         assert mk.small_contig_records(got) == mk.small_contig_records(fx["small_contigs"]), k
+
+
+@pytest.mark.parametrize("n_pieces", [3, 40])
+def test_tool_graph_in_pieces(tmp_path, n_pieces):
+    """`mdbg_tool graph` on a read set with more minimizers than one call of the library takes (2^32), the limit forced low
+    (MDBG_TOOL_MAX_MINIMIZERS): contiguous read ranges put through the pass as the ranks of a sharded job on ONE device
+    (mdbg_shard_begin / the range's own table -> mdbg_shard_from_table, mdbg_shard_exchange_local, mdbg_shard_finish / _keep), the
+    shares written one after the other.  The files must be the reference's: first pass (hifi_200: table, vectors, the two
+    counts it logs) and k = 5, 6, 9 of its own multi-k loop (hifi_multik: table, vectors at firstK+1, smallContigs)."""
+    import shutil
+    from tests import multik_fixture as mk
+
+    def limit(path):
+        mins, offs = formats.parse_minimizer_reads(open(path, "rb").read())
+        return str(max(int(np.diff(offs.astype(np.int64)).max()), len(mins) // n_pieces + 1))
+
+    m = H.load_manifest("hifi_200")
+    tmp = make_tmp(tmp_path / "first", formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                                          hpc=True, data_type=0), ["unused"])
+    for name in ("read_data_corrected.txt", "read_stats.txt"):
+        shutil.copy(os.path.join(H.GOLDEN, "hifi_200", name), os.path.join(tmp, name))
+    env = {"MDBG_TOOL_MAX_MINIMIZERS": limit(os.path.join(tmp, "read_data_corrected.txt"))}
+    run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass", env=env)
+    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+    assert "The pass runs in " in log and int(log.split("The pass runs in ", 1)[1].split()[0]) >= n_pieces
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
+    assert fbytes(tmp, "kminmerData_abundance_init.txt") == fbytes(tmp, "kminmerData_abundance.txt")
+    exp_v = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), m["k"]), exp_v)
+    # (record i of the table and vector i of kminmerData_min.txt belong together across the shares as well)
+    rec = formats.parse_abundance_table(fbytes(tmp, "kminmerData_abundance.txt"))
+    vec = np.frombuffer(fbytes(tmp, "kminmerData_min.txt"), "<u4").reshape(-1, m["k"])
+    assert len(rec) == len(vec)
+    assert f"Nb solid kminmers: {m['reference_log']['n_solid']}\n" in log and f"Nb rescued kminmers: {m['reference_log']['n_rescued']}\n" in log
+    for k in (5, 6, 9):
+        fx = mk.load("hifi_multik", k)
+        tmp = make_tmp(tmp_path / f"k{k}", fx["params"], ["unused"])
+        for f in ("parameters.gz", "kminmerData_abundance_prev.txt", "unitigGraph_prev.nodes.bin",
+                  "unitigGraph.nodes.refined_abundances.bin", "unitig_data.txt"):
+            shutil.copy(os.path.join(fx["dir"], f), os.path.join(tmp, f))
+        shutil.copy(os.path.join(mk.GOLDEN, "hifi_multik", "read_data_corrected.txt"), os.path.join(tmp, "read_data_corrected.txt"))
+        run(TOOL, "graph", tmp, "--threads", "1", env={"MDBG_TOOL_MAX_MINIMIZERS": limit(os.path.join(tmp, "read_data_corrected.txt"))})
+        assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), fx["abundance_sorted"]), k
+        if fx["min_sorted"] is not None:
+            assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), k), fx["min_sorted"]), k
+        got = fbytes(tmp, os.path.join("smallContigs", f"smallContigs_k{k}.bin"))
+        assert mk.small_contig_records(got) == mk.small_contig_records(fx["small_contigs"]), k
+
+
+def test_tool_graph_in_pieces_order_of_vectors(tmp_path):
+    """The first pass in pieces: the vector at position i of kminmerData_min.txt must hash to the key of record i of
+    kminmerData_abundance.txt (the reference's graph stage reads the two files side by side, graph/CreateMdbg.cpp:4156)."""
+    import shutil
+    from oracle import pyoracle as orc
+    tmp = make_tmp(tmp_path / "first", formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
+                                                          hpc=True, data_type=0), ["unused"])
+    for name in ("read_data_corrected.txt", "read_stats.txt"):
+        shutil.copy(os.path.join(H.GOLDEN, "hifi_200", name), os.path.join(tmp, name))
+    run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass", env={"MDBG_TOOL_MAX_MINIMIZERS": "1500"})
+    rec = formats.parse_abundance_table(fbytes(tmp, "kminmerData_abundance.txt"))
+    vec = np.frombuffer(fbytes(tmp, "kminmerData_min.txt"), "<u4").reshape(-1, 4)
+    assert len(rec) == len(vec) > 0
+    for i in range(0, len(rec), max(1, len(rec) // 200)):
+        _, _, hi, lo = orc.kminmer_normalize_hash(vec[i])
+        assert (int(rec[i]["hi"]), int(rec[i]["lo"])) == (hi, lo), i
+
+
+def test_tool_graph_in_pieces_at_partitioned_sizes(tmp_path):
+    """The same on a read set whose pieces are large enough for the partitioned first pass (mdbg_shard_begin counts a piece's
+    share in LDS buckets from 131 072 minimizers up): 24 000 HiFi reads, 0.9 M minimizers, whole against five pieces --
+    equal tables (as multisets), equal counts in the log, equal abundance checksums."""
+    import shutil
+    spec = synth.hifi_spec(24_000, seed=77, coverage=30.0)
+    fasta = str(tmp_path / "reads.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0)
+    whole = make_tmp(tmp_path / "whole", params, [fasta])
+    read_selection(TOOL, whole)
+    parts = make_tmp(tmp_path / "parts", params, [fasta])
+    for name in ("read_data_corrected.txt", "read_stats.txt"):
+        shutil.copy(os.path.join(whole, name), os.path.join(parts, name))
+    mins, _ = formats.parse_minimizer_reads(fbytes(whole, "read_data_corrected.txt"))
+    assert len(mins) > 5 * 131_072
+    run(TOOL, "graph", whole, "--threads", "8", "--min-abundance", "0", "--firstpass")
+    run(TOOL, "graph", parts, "--threads", "8", "--min-abundance", "0", "--firstpass", env={"MDBG_TOOL_MAX_MINIMIZERS": str(len(mins) // 5 + 1)})
+    assert_tables_equal(whole, parts, 4)
+
+    def logged(tmp):
+        log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+        return [ln.strip() for ln in log.splitlines() if "Nb solid" in ln or "Nb rescued" in ln or "Checksum kminmer abundance" in ln]
+    assert logged(whole) == logged(parts) and len(logged(whole)) == 3
+    log = open(os.path.join(os.path.dirname(parts), "metaMDBG.log")).read()
+    assert int(log.split("The pass runs in ", 1)[1].split()[0]) in (5, 6)
