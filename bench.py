@@ -1192,11 +1192,36 @@ def main() -> None:
     # must hear of it and the job must end, non-zero, instead of the peers waiting for replies that never come
     fail_rank = int(os.environ.get("MDBG_BENCH_FAIL_RANK", "-1"))
 
+    # The exchange gate (N > 1 over RCCL): an exchange does not run beside a scan of another batch of this rank.  RCCL's device kernel
+    # (ncclDevKernel_Generic: 248 - 256 VGPRs, 37 664 B of LDS a block -- profiles/round4_g_rccl_device_kernel_resources_gfx950.txt) does
+    # not fit what four scan blocks leave of a CU (31 744 B of LDS: DESIGN.md 4.4's residency rule), and the scan's grid keeps every freed
+    # place refilled until its last block is out: each of the five RCCL launches of an exchange (two all-gathers of status words, two
+    # all-to-alls, one more agreement) would sit out the rest of a scan, one after the other.  So: a batch about to exchange first lets
+    # the scans in flight on this rank finish and holds new ones back (the other batches' purge and first-pass kernels go on: their
+    # blocks are short-lived); the wire time of a step (a few ms over xGMI) is then exposed instead of hidden, which is the bounded price.
+    # MDBG_BENCH_EXCHANGE_GATE=0 / 1 overrides (default: on when the exchange runs over RCCL between more than one rank).
+    gate = threading.Condition()
+    gate_state = {"scans": 0, "exchanging": False, "waited_ms": 0.0}
+    gate_env = os.environ.get("MDBG_BENCH_EXCHANGE_GATE", "auto")
+    use_gate = exchange and (gate_env == "1" or (gate_env == "auto" and world > 1 and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"))
+
     def step(slot: int, index: int, collect: bool = False):
         """One pass of the hot path over the resident batch on slot `slot`; collect: also the table's order-independent sums
         (mdbg_table_checksum) -- the verification step after the timed region."""
         ctx, reads = slots[slot]
-        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        if use_gate:
+            with gate:
+                gate.wait_for(lambda: not gate_state["exchanging"])
+                gate_state["scans"] += 1
+        try:
+            mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+            if use_gate:
+                ctx.synchronize()
+        finally:
+            if use_gate:
+                with gate:
+                    gate_state["scans"] -= 1
+                    gate.notify_all()
         corr = ctx.purge_palindromes(mins, 4, 100)
         if not exchange:
             table = ctx.kminmer_count_first(corr, KMINMER, 0)
@@ -1229,6 +1254,18 @@ def main() -> None:
             sent = [int(c) for c in sh.counts]
             with turn:
                 turn.wait_for(lambda: next_exchange[0] >= index)
+            if use_gate:               # (after the turn: only the batch whose exchange is next holds the scans back)
+                t_g = time.perf_counter()
+                with gate:
+                    gate_state["exchanging"] = True
+                    gate.wait_for(lambda: gate_state["scans"] == 0)
+                    gate_state["waited_ms"] += (time.perf_counter() - t_g) * 1e3
+
+            def gate_open():
+                if use_gate:
+                    with gate:
+                        gate_state["exchanging"] = False
+                        gate.notify_all()
             if comms is not None:
                 try:
                     if spoil:
@@ -1238,6 +1275,7 @@ def main() -> None:
                     d_glob = sh.exchange(comms[slot])
                     mark("exchange")
                 finally:
+                    gate_open()
                     with turn:
                         next_exchange[0] = index + 1
                         turn.notify_all()
@@ -1270,6 +1308,7 @@ def main() -> None:
                     wire["exchanges"] += 1
                     wire["ms"] += (time.perf_counter() - t_x) * 1e3
                 finally:
+                    gate_open()
                     with turn:
                         next_exchange[0] = index + 1
                         turn.notify_all()
@@ -1443,7 +1482,9 @@ def main() -> None:
                 "exchange_ms_per_step": float(em.item()) / args.steps,
                 "note": "wire bytes = rows to their owners (24 B each) + one u64 reply per row, other ranks only (a rank's own share is a "
                         "device-to-device copy); exchange_ms = host time inside the exchange call incl. waiting for the slowest rank, "
-                        "max over ranks; exchanges overlap the other batches' scans"}
+                        "max over ranks; " + ("an exchange waits for the scans in flight on its rank and holds new ones back (gate: RCCL's "
+                        "device kernel does not fit beside the scan's blocks on a CU)" if use_gate else "exchanges overlap the other batches' scans"),
+                "gate": use_gate, "gate_wait_ms_per_step_rank0_incl_warmup": gate_state["waited_ms"] / max(1, args.steps + n_warm)}
 
     failed = False
     if rank == 0:

@@ -51,6 +51,20 @@ def test_ranks_equal_one(nproc, in_flight):
     assert ex["ranks"] == nproc and ex["wire_bytes_per_step"] > 0 and ex["exchanges_timed"] == nproc * 3 and ex["exchange_ms_per_step"] > 0
 
 
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_ranks_equal_one_with_the_exchange_gate(in_flight):
+    """MDBG_BENCH_EXCHANGE_GATE=1 (the default of an N > 1 job over RCCL, forced here on the gloo path): a batch about to exchange waits for
+    the scans in flight on its rank and holds new ones back.  Same tables, no rank left waiting (the run ends), the line says the gate was on."""
+    n, nproc = 40_000, 4
+    common = ["--steps", "4", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
+    one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE_GATE": "1"},
+                  ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
+    assert many["config"]["exchange"]["gate"] is True and many["config"]["exchange"]["exchanges_timed"] == nproc * 4
+    assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
+    assert many["parity"]["table_equal"] and many["parity"]["reads"] == nproc * n
+
+
 def test_strong_scaling_over_one_read_set():
     """--total-reads: ONE read set split over the ranks (north_star's "40 M reads sharded 8 ways at 1 / 2 / 4 / 8 GPUs" is a curve over a
     fixed set): 4 ranks x 30 000 reads give the table of 1 rank x 120 000, and the line carries the single-GPU throughput of rank 0's
