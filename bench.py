@@ -31,6 +31,7 @@ communicator's rank count, wire bytes and exchange time per step.  A mismatch fa
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import shutil
@@ -1200,28 +1201,19 @@ def main() -> None:
     # the scans in flight on this rank finish and holds new ones back (the other batches' purge and first-pass kernels go on: their
     # blocks are short-lived); the wire time of a step (a few ms over xGMI) is then exposed instead of hidden, which is the bounded price.
     # MDBG_BENCH_EXCHANGE_GATE=0 / 1 overrides (default: on when the exchange runs over RCCL between more than one rank).
-    gate = threading.Condition()
-    gate_state = {"scans": 0, "exchanging": False, "waited_ms": 0.0}
     gate_env = os.environ.get("MDBG_BENCH_EXCHANGE_GATE", "auto")
     use_gate = exchange and (gate_env == "1" or (gate_env == "auto" and world > 1 and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"))
+    from metamdbg_amd.distributed import ExchangeGate
+    gate = ExchangeGate(use_gate)
 
     def step(slot: int, index: int, collect: bool = False):
         """One pass of the hot path over the resident batch on slot `slot`; collect: also the table's order-independent sums
         (mdbg_table_checksum) -- the verification step after the timed region."""
         ctx, reads = slots[slot]
-        if use_gate:
-            with gate:
-                gate.wait_for(lambda: not gate_state["exchanging"])
-                gate_state["scans"] += 1
-        try:
+        with gate.scan():
             mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
             if use_gate:
                 ctx.synchronize()
-        finally:
-            if use_gate:
-                with gate:
-                    gate_state["scans"] -= 1
-                    gate.notify_all()
         corr = ctx.purge_palindromes(mins, 4, 100)
         if not exchange:
             table = ctx.kminmer_count_first(corr, KMINMER, 0)
@@ -1254,18 +1246,9 @@ def main() -> None:
             sent = [int(c) for c in sh.counts]
             with turn:
                 turn.wait_for(lambda: next_exchange[0] >= index)
-            if use_gate:               # (after the turn: only the batch whose exchange is next holds the scans back)
-                t_g = time.perf_counter()
-                with gate:
-                    gate_state["exchanging"] = True
-                    gate.wait_for(lambda: gate_state["scans"] == 0)
-                    gate_state["waited_ms"] += (time.perf_counter() - t_g) * 1e3
-
-            def gate_open():
-                if use_gate:
-                    with gate:
-                        gate_state["exchanging"] = False
-                        gate.notify_all()
+            held = contextlib.ExitStack()       # (after the turn: only the batch whose exchange is next holds the scans back)
+            held.enter_context(gate.exchange())
+            gate_open = held.close
             if comms is not None:
                 try:
                     if spoil:
@@ -1484,7 +1467,7 @@ def main() -> None:
                         "device-to-device copy); exchange_ms = host time inside the exchange call incl. waiting for the slowest rank, "
                         "max over ranks; " + ("an exchange waits for the scans in flight on its rank and holds new ones back (gate: RCCL's "
                         "device kernel does not fit beside the scan's blocks on a CU)" if use_gate else "exchanges overlap the other batches' scans"),
-                "gate": use_gate, "gate_wait_ms_per_step_rank0_incl_warmup": gate_state["waited_ms"] / max(1, args.steps + n_warm)}
+                "gate": use_gate, "gate_wait_ms_per_step_rank0_incl_warmup": gate.waited_ms / max(1, args.steps + n_warm)}
 
     failed = False
     if rank == 0:

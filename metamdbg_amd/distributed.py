@@ -11,6 +11,9 @@ replicated here: no rank ever holds the global table.
 """
 from __future__ import annotations
 
+import contextlib
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -52,6 +55,56 @@ def reply_to_senders(reply: torch.Tensor, recv_counts: list[int], sent_counts: l
     out = torch.empty((sum(sent_counts),) + tuple(reply.shape[1:]), dtype=reply.dtype, device=reply.device)
     _all_to_all(out, reply, list(sent_counts), list(recv_counts), group)
     return out
+
+
+class ExchangeGate:
+    """Several batches in flight on one GPU of an N > 1 job: an exchange over RCCL does not run beside a scan of another batch.
+
+    RCCL's device kernel needs 37.6 KB of LDS a block (profiles/round4_g_rccl_device_kernel_resources_gfx950.txt); four blocks of the scan
+    kernel leave 31 KB of a CU and the scan's grid refills every place a retiring block frees, so each RCCL launch of an exchange would wait
+    for a whole scan to drain ("the exchange gate").  Host threads wrap their scan in ``with gate.scan():`` and their exchange in
+    ``with gate.exchange():`` -- an exchange waits for the scans in flight to end and holds new ones back until it is over.  A disabled gate
+    does nothing.  No ordering among exchanges is imposed here (the caller's turn-taking does that); several at once are allowed."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+        self._cv = threading.Condition()
+        self._scans = 0
+        self._exchanges = 0
+        self.waited_ms = 0.0                     # time exchanges spent waiting for scans to end (all threads)
+
+    @contextlib.contextmanager
+    def scan(self):
+        if not self.enabled:
+            yield
+            return
+        with self._cv:
+            self._cv.wait_for(lambda: self._exchanges == 0)
+            self._scans += 1
+        try:
+            yield
+        finally:
+            with self._cv:
+                self._scans -= 1
+                self._cv.notify_all()
+
+    @contextlib.contextmanager
+    def exchange(self):
+        if not self.enabled:
+            yield
+            return
+        import time
+        t0 = time.perf_counter()
+        with self._cv:
+            self._exchanges += 1                 # from here on no new scan starts
+            self._cv.wait_for(lambda: self._scans == 0)
+            self.waited_ms += (time.perf_counter() - t0) * 1e3
+        try:
+            yield
+        finally:
+            with self._cv:
+                self._exchanges -= 1
+                self._cv.notify_all()
 
 
 class PeerFailure(RuntimeError):
