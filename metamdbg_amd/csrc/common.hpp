@@ -248,10 +248,9 @@ inline unsigned grid_for(uint64_t items, unsigned per_block, unsigned max_blocks
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
     // (a launch of 2^32 threads or more does not fail, it wraps: kernels over that many items are grid-stride and name their cap)
-    if (b * per_block >= (1ull << 32) && max_blocks == 1u << 30) {
-        fprintf(stderr, "mdbg_hip: a launch over %llu items needs a capped grid\n", (unsigned long long)items);
-        abort();
-    }
+    // (thrown, not aborted: every entry point of the C ABI turns it into an error code -- MDBG_API_CATCH)
+    if (b * per_block >= (1ull << 32) && max_blocks == 1u << 30)
+        throw std::length_error("a launch over " + std::to_string(items) + " items would be 2^32 threads or more (the kernel needs a capped grid)");
     return (unsigned)b;
 }
 
