@@ -1137,8 +1137,38 @@ def main() -> None:
     # N > 1: the exchange runs inside the library (RCCL send / receive groups on each context's own stream and communicator:
     # mdbg_comm_create, mdbg_shard_exchange); MDBG_BENCH_EXCHANGE=torch moves the bytes with torch.distributed instead (and the
     # gloo test hook always does)
+    # MDBG_BENCH_EXCHANGE: "ipc" = the two all-to-alls as PEER COPIES (metamdbg_amd/distributed.py PeerCopyExchange: every rank's staging
+    # buffers shared with the other processes once by CUDA IPC, owners pull their slices with device-to-device copies, handshakes are host
+    # collectives on a gloo group -- no collective kernel, nothing that has to be resident beside a scan, so no exchange gate either);
+    # "library" = RCCL inside the library; "torch" = torch.distributed's all_to_all_single.  Default ("auto"): peer copies when there is more than
+    # one rank -- after a small exchange of known rows through the shared buffers has come back right on EVERY rank; otherwise the library.
+    rw = capi.lib().mdbg_row_words(KMINMER)
+    exchange_mode = os.environ.get("MDBG_BENCH_EXCHANGE", "auto")
+    peer = None
+    hs_group = None
+    peer_note = None
+    if dist is not None and (exchange_mode == "ipc" or (exchange_mode == "auto" and world > 1)):
+        from metamdbg_amd import distributed as D0
+        _phase("peer-copy exchange: handshake group, staging buffers, self-test")
+        ok_local, why = 1, ""
+        try:
+            hs_group = dist.new_group(backend="gloo") if os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" else None
+            peer = [D0.PeerCopyExchange(torch.device("cuda", local_rank), rw, hs_group) for _ in slots]
+            for px in peer:
+                px.self_test()
+        except Exception as ex:                      # (a rank that fails here has left the others in a host collective: the deadline ends that)
+            ok_local, why = 0, f"{type(ex).__name__}: {ex}"
+        flag = torch.tensor([ok_local], dtype=torch.int64)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=hs_group) if (hs_group is not None or os.environ.get("MDBG_BENCH_BACKEND", "nccl") != "nccl") else None
+        except Exception as ex:
+            flag[0], why = 0, why or f"{type(ex).__name__}: {ex}"
+        if int(flag.item()) == 0 or (hs_group is None and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"):
+            peer_note = f"peer-copy exchange unavailable ({why or 'another rank failed its self-test'})"
+            print(f"[bench] {peer_note}: using " + ("the library's RCCL exchange" if exchange_mode == "auto" else "torch.distributed"), file=sys.stderr)
+            peer, hs_group = None, None
     comms = None
-    if (world > 1 or force_exchange) and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("MDBG_BENCH_EXCHANGE", "library") == "library":
+    if peer is None and (world > 1 or force_exchange) and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" and exchange_mode in ("library", "auto"):
         comms = []
         comm_error = None
         _phase("creating the library's RCCL communicators (mdbg_comm_create)")
@@ -1171,7 +1201,6 @@ def main() -> None:
     ctx, reads = slots[0]
     info = ctx.device_info()
     n_bases = reads.info()["n_bases"]
-    rw = capi.lib().mdbg_row_words(KMINMER)
     exchange = world > 1 or force_exchange
 
     def barrier():
@@ -1202,7 +1231,7 @@ def main() -> None:
     # blocks are short-lived); the wire time of a step (a few ms over xGMI) is then exposed instead of hidden, which is the bounded price.
     # MDBG_BENCH_EXCHANGE_GATE=0 / 1 overrides (default: on when the exchange runs over RCCL between more than one rank).
     gate_env = os.environ.get("MDBG_BENCH_EXCHANGE_GATE", "auto")
-    use_gate = exchange and (gate_env == "1" or (gate_env == "auto" and world > 1 and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"))
+    use_gate = exchange and (gate_env == "1" or (gate_env == "auto" and world > 1 and peer is None and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"))
     from metamdbg_amd.distributed import ExchangeGate
     gate = ExchangeGate(use_gate)
 
@@ -1236,7 +1265,7 @@ def main() -> None:
                     if comms is not None:
                         comms[slot].abort(ctx)
                     else:
-                        D.agree(-1, "before the exchange", device="cuda")
+                        D.agree(-1, "before the exchange", group=hs_group, device="cuda")
                 finally:
                     with turn:
                         next_exchange[0] = index + 1
@@ -1268,21 +1297,21 @@ def main() -> None:
             else:
                 try:
                     t_x = time.perf_counter()
-                    D.agree(0, "before the exchange", device="cuda")
+                    D.agree(0, "before the exchange", group=hs_group, device="cuda")
                     send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
                         torch.empty((0, rw), dtype=torch.int64, device="cuda")
-                    mine, got = D.exchange_by_owner(send, sent)
+                    mine, got = peer[slot].rows_to_owners(send, sent) if peer is not None else D.exchange_by_owner(send, sent)
                     torch.cuda.current_stream().synchronize()      # not the device: the other slot keeps running
                     mark("all_to_all_rows")
                     def owner_sum():
                         if collect and rank == fail_rank:
                             raise RuntimeError(f"test failure on rank {rank} (MDBG_BENCH_FAIL_RANK)")
                         return sh.reduce(mine.data_ptr(), mine.shape[0])
-                    d_reply = D.guarded(owner_sum, "summing the rows it owns", device="cuda")
+                    d_reply = D.guarded(owner_sum, "summing the rows it owns", group=hs_group, device="cuda")
                     reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
                         torch.empty((0,), dtype=torch.int64, device="cuda")
                     mark("reduce")
-                    glob = D.reply_to_senders(reply, got, sent)
+                    glob = peer[slot].replies_to_senders(reply, got, sent) if peer is not None else D.reply_to_senders(reply, got, sent)
                     if spoil and bool((glob < 0).any()):
                         glob[int((glob < 0).nonzero()[0])] += 1       # a key this rank lists (bit 63): its count is off by one
                     torch.cuda.current_stream().synchronize()
@@ -1456,7 +1485,9 @@ def main() -> None:
             dist.all_reduce(em, op=dist.ReduceOp.MAX)
         backend_name = os.environ.get("MDBG_BENCH_BACKEND", "nccl")
         exch = {"path": ("library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
+                         else "peer copies: staging buffers shared by CUDA IPC, owners pull their slices (PeerCopyExchange); host handshakes over gloo" if peer is not None
                          else f"torch.distributed all_to_all_single ({backend_name})"),
+                "staging_shares": peer[0].shares if peer is not None else None, "peer_copy_note": peer_note,
                 # what the communicator itself reports (ncclCommCount through mdbg_comm_stats); the torch path: the process group's size
                 "rccl_ranks": acct1["rccl_ranks"] if comms is not None else (dist.get_world_size() if dist is not None and backend_name == "nccl" else None),
                 "ranks": world,

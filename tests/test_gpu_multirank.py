@@ -38,7 +38,12 @@ def test_ranks_equal_one(nproc, in_flight):
     n = 40_000
     common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
     one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
-    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}, ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
+    # (the default exchange of an N > 1 job is peer copies; the first case keeps torch.distributed's all-to-all, staged through the host by gloo, covered)
+    env = {"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}
+    if (nproc, in_flight) == (2, 1):
+        env["MDBG_BENCH_EXCHANGE"] = "torch"
+    many = _bench(env, ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
+    assert many["config"]["exchange"]["path"].startswith("torch.distributed" if "MDBG_BENCH_EXCHANGE" in env else "peer copies")
     assert many["n_gpus"] == nproc and many["scaling"] == "weak"
     assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
     assert many["config"]["solid"] == one["config"]["solid"] > 0
@@ -63,6 +68,31 @@ def test_ranks_equal_one_with_the_exchange_gate(in_flight):
     assert many["config"]["exchange"]["gate"] is True and many["config"]["exchange"]["exchanges_timed"] == nproc * 4
     assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
     assert many["parity"]["table_equal"] and many["parity"]["reads"] == nproc * n
+
+
+@pytest.mark.parametrize("nproc,in_flight", [(2, 2), (4, 3), (8, 2)])
+def test_ranks_equal_one_by_peer_copies(nproc, in_flight):
+    """MDBG_BENCH_EXCHANGE=ipc: the two all-to-alls as peer copies (metamdbg_amd.distributed.PeerCopyExchange) -- every rank's staging buffers
+    shared with the other processes by CUDA IPC, owners pull their slices device to device, handshakes on the host.  Real processes, real IPC
+    handles (all on GPU 0 here; between GPUs the same copies cross xGMI); the union of the shares must be the table of one rank."""
+    n = 40_000
+    common = ["--steps", "4", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
+    one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE": "ipc"},
+                  ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
+    ex = many["config"]["exchange"]
+    assert ex["path"].startswith("peer copies") and ex["gate"] is False and ex["staging_shares"] >= 1 and ex["exchanges_timed"] == nproc * 4
+    assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0 and many["config"]["solid"] == one["config"]["solid"]
+    par = many["parity"]
+    assert par["table_equal"] and par["reads"] == nproc * n and par["abundance_checksum_equal"] and par["vector_sum_equal"]
+
+
+def test_peer_copies_with_a_corrupted_reply_fail_the_run():
+    n = 40_000
+    common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "2"]
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE": "ipc", "MDBG_BENCH_CORRUPT_REPLY": "1"},
+                  ["--gpus", "2", "--reads", str(n)] + common, 2, expect_failure=True)
+    assert not many["parity"]["table_equal"] and many["parity"]["minimizers_equal"]
 
 
 def test_strong_scaling_over_one_read_set():
