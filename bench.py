@@ -1030,9 +1030,10 @@ def _phase(name: str) -> None:
 
 def _arm_deadline(rank: int, world: int, json_fd: int) -> None:
     """A run that hangs (a collective whose peer never arrives: RCCL with more than one rank has not met hardware yet) must end with a line
-    that says so, not with the driver's kill: after MDBG_BENCH_DEADLINE_S seconds (default 1800; 0 = never) every rank dumps its Python
+    that says so, not with the driver's kill: after MDBG_BENCH_DEADLINE_S seconds (default 1800, 900 for N > 1; 0 = never) every rank dumps its Python
     stacks to stderr, rank 0 writes a JSON line with "value": null and the phase it was in, and the process exits with status 3."""
-    secs = float(os.environ.get("MDBG_BENCH_DEADLINE_S", "1800") or 0)
+    # (N > 1 runs have no legs and no CPU baseline: minutes, not the default N = 1 run's quarter of an hour at worst)
+    secs = float(os.environ.get("MDBG_BENCH_DEADLINE_S", "1800" if world <= 1 else "900") or 0)
     if secs <= 0:
         return
     import faulthandler
