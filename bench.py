@@ -12,7 +12,9 @@ pass over its batch.  (Three until round 3, when the one-table first pass took a
 partitioned pass -- a seventh -- a third batch only adds contention: 840 against 828 Gbp/s, tools/overlap_matrix.sh.)
 N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); only the
 k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
-all-to-alls over RCCL (metamdbg_amd/distributed.py, include/mdbg_hip.h mdbg_shard_*).
+all-to-alls (include/mdbg_hip.h mdbg_shard_*) -- by default as peer copies over xGMI between staging buffers the processes
+share by CUDA IPC (metamdbg_amd/distributed.py PeerCopyExchange: no collective kernel has to find room beside a scan), after a
+self-test; otherwise RCCL inside the library (mdbg_shard_exchange) with the exchange gate.  MDBG_BENCH_EXCHANGE=ipc|library|torch.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library's stream; `traffic` only from a PMC
 collection made on this very csrc/scan.hip), `roofline_kminmer` (the table kernels alone: 4 M + 16 I + 20 D bytes, and the atomic-rate
