@@ -1669,6 +1669,9 @@ def main() -> None:
     if comms is not None:
         for cm in comms:
             cm.destroy()
+    if peer is not None:            # every process lets go of the others' buffers before anybody frees its own
+        for px in peer:
+            px.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

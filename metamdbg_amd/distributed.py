@@ -107,6 +107,19 @@ class PeerCopyExchange:
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
 
+    def close(self) -> None:
+        """Collective: drop the views of the other processes' buffers, wait until everybody has, then free this rank's own (a producer
+        must outlive its consumers' mappings)."""
+        self.peer_S.clear()
+        self.peer_R.clear()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+            torch.cuda.ipc_collect()
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        self.S = self.R = None
+        self.cap_s = self.cap_r = 0
+
     def self_test(self) -> None:
         """A small exchange of known rows through the shared buffers (collective): raises if a slice or a reply came back wrong -- before a
         job relies on peer copies between GPUs it has never used (bench.py falls back to RCCL when any rank fails this)."""

@@ -280,6 +280,7 @@ def _worker_peer_copies(rank, world, port, q):
         back = px.replies_to_senders(reply, got, counts).numpy()
         ok = ok and len(back) == n and (back == rank * 1_000_000 + np.arange(n)).all()
         shares.append(px.shares)
+    px.close()
     q.put((rank, bool(ok), shares))
     dist.barrier()
     dist.destroy_process_group()
