@@ -12,11 +12,13 @@ pass over its batch.  (Three until round 3, when the one-table first pass took a
 partitioned pass -- a seventh -- a third batch only adds contention: 840 against 828 Gbp/s, tools/overlap_matrix.sh.)
 N>1: one process per GPU, every rank owns its own shard of the same size (weak scaling); only the
 k-min-mer counts are global: rows go to their owner rank and the global counts come back, two
-all-to-alls (include/mdbg_hip.h mdbg_shard_*) -- by default as peer copies over xGMI between staging buffers the processes
-share by CUDA IPC (metamdbg_amd/distributed.py PeerCopyExchange: no collective kernel has to find room beside a scan), after a
-self-test; otherwise RCCL inside the library (mdbg_shard_exchange) with the exchange gate.  MDBG_BENCH_EXCHANGE=ipc|library|torch.
+all-to-alls inside the library (include/mdbg_hip.h mdbg_comm_create_mode, mdbg_shard_exchange) -- by default ("auto") as PEER COPIES
+over xGMI between staging buffers the ranks share (owners pull their slices device to device, hand-shakes through shared host memory:
+no collective kernel has to find room beside a scan), after a self-test every rank passed; otherwise RCCL send / receive groups with
+the exchange gate.  MDBG_COMM_MODE=peer|rccl|auto selects; MDBG_BENCH_EXCHANGE=torch moves the bytes with torch.distributed instead.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library's stream; `traffic` only from a PMC
+Prints ONE compact JSON line (rank 0; under 4 KB -- compact_line below; the full result goes to bench_detail.json next to this script
+and to stderr) with `roofline` (dominant kernel, HIP-event timed on the library's stream; `traffic` only from a PMC
 collection made on this very csrc/scan.hip), `roofline_kminmer` (the table kernels alone: 4 M + 16 I + 20 D bytes, and the atomic-rate
 ceiling of the insert), `cpu_baseline` (the reference's own code, oracle/_ref/refdrv, timed on this box's cores on BASELINE.json
 configs[1] whole -- 1 M reads, 10 Gbp; `path_only` = up to the moment its tables are on disk) and, at N=1, `parity` (the HIP path's
@@ -72,6 +74,7 @@ def parse_args():
     ap.add_argument("--multik-sample", type=int, default=200_000, help="reads of the multik_reference leg (the reference's own loop k = 4..11)")
     ap.add_argument("--ont-reads", type=int, default=10_000_000, help="reads (20 kb, with qualities) of the ont leg: BASELINE.json configs[3]")
     ap.add_argument("--ont-sample", type=int, default=100_000, help="reads of the ont leg's parity sample against the reference")
+    ap.add_argument("--detail", default=os.path.join(ROOT, DETAIL_FILE), help="where the full result goes (the stdout line is its compact form)")
     a = ap.parse_args()
     if a.total_reads > 0:
         a.reads = a.total_reads // max(1, a.gpus)          # (a remainder of fewer reads than ranks is left out)
@@ -261,14 +264,13 @@ def sample_legs(ctx, n_sample: int, read_len: int, with_tool: bool, keep_dir: li
                 whole_cmds = {"error": f"{type(exc).__name__}: {exc}"}
         out["cpu_baseline"] = {
             "value": nbases / 1e9 / path, "unit": "Gbp/s", "cores": _cores_used(cores), "threads": cores, "cpu_quota": _cpu_quota(), "kind": "reference",
-            "sample": f"{n_sample} synthetic HiFi reads x {read_len} bp at 50x ({nbases / 1e9:.2f} Gbp"
-                      f"{': BASELINE.json configs[1], whole' if n_sample == 1_000_000 and read_len == 10_000 else ''}) as FASTA on local disk, "
-                      f"--threads {cores} of {os.cpu_count()} hardware threads"
-                      f"{'' if _cpu_quota() is None else f' under a container quota of {_cpu_quota():g} CPUs (cores = what it could use)'}; value = path only: readSelection {tr['read_selection_s']:.2f} s + "
-                      f"graph --firstpass until its tables are written and closed "
-                      f"{(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.2f} s"
-                      + (" (the command was ended there: what follows is graph construction)" if tr["graph_s"] is None else
-                         f" (the whole graph command, which goes on to build the graph, takes {tr['graph_s']:.2f} s)"),
+            # (<= 200 characters: the line's copy is cut there)
+            "sample": f"{n_sample} HiFi reads x {read_len} bp ({nbases / 1e9:.0f} Gbp{', configs[1] whole' if n_sample == 1_000_000 and read_len == 10_000 else ''}), FASTA on disk; "
+                      f"refdrv --threads {cores}{'' if _cpu_quota() is None else f', quota {_cpu_quota():g} CPUs'}; path only: readSelection {tr['read_selection_s']:.1f} s + graph "
+                      f"until tables closed {(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.1f} s",
+            "graph_command": "ended once its tables were written and closed (what follows is graph construction)" if tr["graph_s"] is None else
+                             f"the whole graph command, which goes on to build the graph, takes {tr['graph_s']:.2f} s",
+            "hardware_threads": os.cpu_count(),
             "path_only": {"read_selection_s": tr["read_selection_s"], "tables_s": tr["tables_s"], "gbps": nbases / 1e9 / path},
             "whole_commands": whole_cmds,
             "read_selection_gbps": nbases / 1e9 / tr["read_selection_s"]}
@@ -1030,6 +1032,119 @@ def _phase(name: str) -> None:
     _PHASE[0] = name
 
 
+LINE_LIMIT = 4096               # bytes of the one stdout line; the driver's record keeps an 8 KB tail and parses the line out of it
+DETAIL_FILE = "bench_detail.json"
+
+
+def _num(x, digits: int = 6):
+    """Numbers of the compact line: six significant digits for floats, everything else as it is."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(src, keys) -> dict:
+    src = src or {}
+    return {k: _num(src[k]) for k in keys if k in src}
+
+
+def _short(text, limit: int = 200):
+    if not isinstance(text, str) or len(text) <= limit:
+        return text
+    return text[: limit - 3] + "..."
+
+
+def _flag(block, key="all_equal"):
+    """The boolean a check ended with: None when the check was not made (leg switched off), False when it broke."""
+    if not isinstance(block, dict):
+        return None
+    if "error" in block:
+        return False
+    return block.get(key)
+
+
+def compact_line(out: dict) -> dict:
+    """The ONE line bench.py prints, from the full result: the contract's keys, the rooflines' scalars, the CPU baseline, the parity
+    booleans, one boolean per check and one number per leg -- under LINE_LIMIT bytes whatever the legs produced.  Everything else
+    (per-k blocks, notes, traces) is the detail file's (DETAIL_FILE, next to this script) and stderr's."""
+    cfg = out.get("config") or {}
+    line = {k: _num(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                          "scaling", "vs_baseline", "dtype", "data")}
+    c = {"workload": _short(cfg.get("workload"))}
+    c.update(_pick(cfg, ("reads_per_gpu", "read_len", "minimizers_per_step", "kminmer_records", "solid", "batches_in_flight", "device", "cus")))
+    ex = cfg.get("exchange")
+    if ex:
+        c["exchange"] = dict(_pick(ex, ("transport", "rccl_ranks", "ranks", "wire_bytes_per_step", "exchange_ms_per_step", "gate")), path=_short(ex.get("path"), 80))
+    line["config"] = c
+    roof = out.get("roofline") or {}
+    r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"))
+    r["kernel"] = _short(roof.get("kernel"), 60)
+    r["valu_floor"] = _pick(roof.get("valu_floor"), ("frac", "floor_ms"))
+    line["roofline"] = r
+    kroof = out.get("roofline_kminmer")
+    if kroof:
+        k = _pick(kroof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic"))
+        k["kernel"] = _short(kroof.get("kernel"), 60)
+        k["algorithmic_bytes_per_launch"] = _num(kroof.get("algorithmic_bytes"))
+        k["avg_launch_ms"] = _num(kroof.get("kernel_ms_total"))
+        line["roofline_kminmer"] = k
+    base = out.get("cpu_baseline")
+    if base:
+        b = _pick(base, ("value", "unit", "cores", "threads", "kind"))
+        b["sample"] = _short(base.get("sample"))
+        line["cpu_baseline"] = b
+    else:
+        line["cpu_baseline"] = None
+    par = out.get("parity")
+    if par:
+        p = {k: v for k, v in par.items() if isinstance(v, bool)}
+        p.update(_pick(par, ("reads", "error", "skipped")))
+        if "against" in par:
+            p["against"] = _short(par["against"], 100)
+        if isinstance(par.get("golden"), dict):
+            p["golden_digests_equal"] = par["golden"].get("digests_equal")
+        if "single_gpu_gbps" in par:
+            p["single_gpu_gbps"] = _num(par["single_gpu_gbps"])
+        line["parity"] = p
+    legs = out.get("legs") or {}
+    ont = legs.get("ont") or {}
+    line["checks"] = {"self_check": _flag(out.get("self_check")),
+                      "multik_self_check": _flag(legs["multik"].get("self_check") if isinstance(legs.get("multik"), dict) and "error" not in legs["multik"] else legs.get("multik")),
+                      "multik_reference": _flag(legs.get("multik_reference"), "all_tables_equal"),
+                      "ont_parity": _flag(ont.get("parity") if "error" not in ont else ont, "table_multiset_equal") if ont else None,
+                      "ont_self_check": _flag(ont.get("self_check") if "error" not in ont else ont) if ont else None}
+    numbers = {"multik_s": (legs.get("multik") or {}).get("seconds"), "ont_gbps": ont.get("gbps"),
+               "pcie_gbps": (legs.get("pcie") or {}).get("packed_one_context_pipelined_gbps"),
+               "e2e_gbps": (legs.get("end_to_end") or {}).get("mdbg_tool_gbps")}
+    line["legs"] = {k: _num(v) for k, v in numbers.items() if v is not None}
+    failed_legs = sorted(k for k, v in legs.items() if isinstance(v, dict) and "error" in v)
+    if failed_legs:
+        line["legs"]["errors"] = failed_legs
+    if "kernel_ms_per_step" in out:
+        line["kernel_ms_per_step"] = {k: _num(v, 4) for k, v in out["kernel_ms_per_step"].items() if v}
+    if "speedup_vs_cpu_reference_path_only" in out:
+        line["speedup_vs_cpu_reference_path_only"] = _num(out["speedup_vs_cpu_reference_path_only"])
+    line["detail"] = DETAIL_FILE
+    if len(json.dumps(line)) >= LINE_LIMIT:          # cannot happen with the caps above; if it does the contract's keys still get through
+        for k in ("kernel_ms_per_step", "legs", "checks"):
+            line.pop(k, None)
+    return line
+
+
+def emit(out: dict, json_fd: int, detail_path: str | None = None) -> None:
+    """Full result to the detail file (--detail; DETAIL_FILE next to this script) and stderr, the compact line -- and nothing else -- to
+    the real stdout."""
+    full = json.dumps(out)
+    detail_path = detail_path or os.path.join(ROOT, DETAIL_FILE)
+    try:
+        with open(detail_path, "w") as f:
+            f.write(full + "\n")
+    except OSError as exc:
+        print(f"[bench] {detail_path} not written: {exc}", file=sys.stderr)
+    print("[bench] full result: " + full, file=sys.stderr, flush=True)
+    os.write(json_fd, (json.dumps(compact_line(out)) + "\n").encode())
+
+
 def _arm_deadline(rank: int, world: int, json_fd: int) -> None:
     """A run that hangs (a collective whose peer never arrives: RCCL with more than one rank has not met hardware yet) must end with a line
     that says so, not with the driver's kill: after MDBG_BENCH_DEADLINE_S seconds (default 1800, 900 for N > 1; 0 = never) every rank dumps its Python
@@ -1137,50 +1252,28 @@ def main() -> None:
         if shared_reads is None:
             shared_reads = c.reads_synthetic(spec, first_read=rank * args.reads, n_reads=args.reads)
         slots.append((c, shared_reads))
-    # N > 1: the exchange runs inside the library (RCCL send / receive groups on each context's own stream and communicator:
-    # mdbg_comm_create, mdbg_shard_exchange); MDBG_BENCH_EXCHANGE=torch moves the bytes with torch.distributed instead (and the
-    # gloo test hook always does)
-    # MDBG_BENCH_EXCHANGE: "ipc" = the two all-to-alls as PEER COPIES (metamdbg_amd/distributed.py PeerCopyExchange: every rank's staging
-    # buffers shared with the other processes once by CUDA IPC, owners pull their slices with device-to-device copies, handshakes are host
-    # collectives on a gloo group -- no collective kernel, nothing that has to be resident beside a scan, so no exchange gate either);
-    # "library" = RCCL inside the library; "torch" = torch.distributed's all_to_all_single.  Default ("auto"): peer copies when there is more than
-    # one rank -- after a small exchange of known rows through the shared buffers has come back right on EVERY rank; otherwise the library.
+    # N > 1: the exchange runs inside the library (mdbg_comm_create_mode, mdbg_shard_exchange), one communicator per batch in flight.
+    # Which transport is the library's business: MDBG_COMM_MODE = peer | rccl | auto (include/mdbg_hip.h).  "auto" (the default) takes
+    # PEER COPIES -- staging buffers shared between the ranks, every owner pulls its slices device to device, hand-shakes through a block
+    # of shared host memory: no collective kernel has to find room beside a scan -- after a self-test every rank passed, and RCCL
+    # send / receive groups otherwise (all ranks together; the exchange gate below then keeps scans off the device during an exchange).
+    # MDBG_BENCH_EXCHANGE=torch moves the bytes with torch.distributed's all_to_all_single instead (a harness path: tests).
     rw = capi.lib().mdbg_row_words(KMINMER)
-    exchange_mode = os.environ.get("MDBG_BENCH_EXCHANGE", "auto")
-    peer = None
-    hs_group = None
-    peer_note = None
-    if dist is not None and (exchange_mode == "ipc" or (exchange_mode == "auto" and world > 1)):
-        from metamdbg_amd import distributed as D0
-        _phase("peer-copy exchange: handshake group, staging buffers, self-test")
-        ok_local, why = 1, ""
-        try:
-            hs_group = dist.new_group(backend="gloo") if os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" else None
-            peer = [D0.PeerCopyExchange(torch.device("cuda", local_rank), rw, hs_group) for _ in slots]
-            for px in peer:
-                px.self_test()
-        except Exception as ex:                      # (a rank that fails here has left the others in a host collective: the deadline ends that)
-            ok_local, why = 0, f"{type(ex).__name__}: {ex}"
-        flag = torch.tensor([ok_local], dtype=torch.int64)
-        try:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=hs_group) if (hs_group is not None or os.environ.get("MDBG_BENCH_BACKEND", "nccl") != "nccl") else None
-        except Exception as ex:
-            flag[0], why = 0, why or f"{type(ex).__name__}: {ex}"
-        if int(flag.item()) == 0 or (hs_group is None and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"):
-            peer_note = f"peer-copy exchange unavailable ({why or 'another rank failed its self-test'})"
-            print(f"[bench] {peer_note}: using " + ("the library's RCCL exchange" if exchange_mode == "auto" else "torch.distributed"), file=sys.stderr)
-            peer, hs_group = None, None
+    exchange_mode = os.environ.get("MDBG_BENCH_EXCHANGE", "library")
+    backend_name = os.environ.get("MDBG_BENCH_BACKEND", "nccl")
     comms = None
-    if peer is None and (world > 1 or force_exchange) and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl" and exchange_mode in ("library", "auto"):
+    comm_note = None
+    if (world > 1 or force_exchange) and exchange_mode != "torch":
         comms = []
         comm_error = None
-        _phase("creating the library's RCCL communicators (mdbg_comm_create)")
+        _phase("creating the library's communicators (mdbg_comm_create_mode)")
+        hand = "cuda" if (dist is not None and backend_name == "nccl") else "cpu"       # where torch.distributed carries the id
         for c, _ in slots:
-            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            t = torch.zeros(128, dtype=torch.uint8, device=hand)
             if rank == 0:
                 try:
                     t.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
-                except Exception as ex:              # RCCL not loadable: every rank will see the zero id and fall back together
+                except Exception as ex:              # no id: every rank will see the zero id and fall back together
                     comm_error = str(ex)
             if dist is not None:
                 dist.broadcast(t, 0)
@@ -1193,14 +1286,19 @@ def main() -> None:
             elif comm_error is None:
                 comm_error = "no communicator id from rank 0"
         # all ranks or none: a rank without its communicators sends everybody to torch.distributed's all-to-all
-        ok = torch.tensor([0 if comm_error else 1], device="cuda")
+        ok = torch.tensor([0 if comm_error else 1], device=hand)
         if dist is not None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            print(f"[bench] library exchange unavailable ({comm_error or 'another rank failed'}): using torch.distributed", file=sys.stderr)
+            comm_note = f"library exchange unavailable ({comm_error or 'another rank failed'})"
+            print(f"[bench] {comm_note}: using torch.distributed", file=sys.stderr)
             for cm in comms:
                 cm.destroy()
             comms = None
+        else:
+            comm_note = comms[0].note or None
+            if comm_note:
+                print(f"[bench] the library's communicators fell back to RCCL: {comm_note}", file=sys.stderr)
     ctx, reads = slots[0]
     info = ctx.device_info()
     n_bases = reads.info()["n_bases"]
@@ -1234,7 +1332,8 @@ def main() -> None:
     # blocks are short-lived); the wire time of a step (a few ms over xGMI) is then exposed instead of hidden, which is the bounded price.
     # MDBG_BENCH_EXCHANGE_GATE=0 / 1 overrides (default: on when the exchange runs over RCCL between more than one rank).
     gate_env = os.environ.get("MDBG_BENCH_EXCHANGE_GATE", "auto")
-    use_gate = exchange and (gate_env == "1" or (gate_env == "auto" and world > 1 and peer is None and os.environ.get("MDBG_BENCH_BACKEND", "nccl") == "nccl"))
+    over_rccl = (comms is not None and comms[0].mode == "rccl") or (comms is None and backend_name == "nccl")
+    use_gate = exchange and (gate_env == "1" or (gate_env == "auto" and world > 1 and over_rccl))
     from metamdbg_amd.distributed import ExchangeGate
     gate = ExchangeGate(use_gate)
 
@@ -1268,7 +1367,7 @@ def main() -> None:
                     if comms is not None:
                         comms[slot].abort(ctx)
                     else:
-                        D.agree(-1, "before the exchange", group=hs_group, device="cuda")
+                        D.agree(-1, "before the exchange", device="cuda")
                 finally:
                     with turn:
                         next_exchange[0] = index + 1
@@ -1300,21 +1399,21 @@ def main() -> None:
             else:
                 try:
                     t_x = time.perf_counter()
-                    D.agree(0, "before the exchange", group=hs_group, device="cuda")
+                    D.agree(0, "before the exchange", device="cuda")
                     send = torch.as_tensor(capi.DeviceView(sh.d_rows, (sh.n_rows, rw)), device="cuda") if sh.n_rows else \
                         torch.empty((0, rw), dtype=torch.int64, device="cuda")
-                    mine, got = peer[slot].rows_to_owners(send, sent) if peer is not None else D.exchange_by_owner(send, sent)
+                    mine, got = D.exchange_by_owner(send, sent)
                     torch.cuda.current_stream().synchronize()      # not the device: the other slot keeps running
                     mark("all_to_all_rows")
                     def owner_sum():
                         if collect and rank == fail_rank:
                             raise RuntimeError(f"test failure on rank {rank} (MDBG_BENCH_FAIL_RANK)")
                         return sh.reduce(mine.data_ptr(), mine.shape[0])
-                    d_reply = D.guarded(owner_sum, "summing the rows it owns", group=hs_group, device="cuda")
+                    d_reply = D.guarded(owner_sum, "summing the rows it owns", device="cuda")
                     reply = torch.as_tensor(capi.DeviceView(d_reply, (mine.shape[0],)), device="cuda") if mine.shape[0] else \
                         torch.empty((0,), dtype=torch.int64, device="cuda")
                     mark("reduce")
-                    glob = peer[slot].replies_to_senders(reply, got, sent) if peer is not None else D.reply_to_senders(reply, got, sent)
+                    glob = D.reply_to_senders(reply, got, sent)
                     if spoil and bool((glob < 0).any()):
                         glob[int((glob < 0).nonzero()[0])] += 1       # a key this rank lists (bit 63): its count is off by one
                     torch.cuda.current_stream().synchronize()
@@ -1419,7 +1518,7 @@ def main() -> None:
         if comms is not None:
             st = [cm.stats() for cm in comms]
             return {"to_peers": sum(x["bytes_to_peers"] for x in st), "exchanges": sum(x["exchanges"] for x in st),
-                    "ms": sum(x["exchange_ms"] for x in st), "rccl_ranks": st[0]["rccl_ranks"]}
+                    "ms": sum(x["exchange_ms"] for x in st), "rccl_ranks": st[0]["rccl_ranks"] if st[0]["mode"] == "rccl" else None}
         return dict(wire, rccl_ranks=None)
 
     for c, _ in slots:
@@ -1486,13 +1585,14 @@ def main() -> None:
         if dist is not None:
             dist.all_reduce(et, op=dist.ReduceOp.SUM)
             dist.all_reduce(em, op=dist.ReduceOp.MAX)
-        backend_name = os.environ.get("MDBG_BENCH_BACKEND", "nccl")
-        exch = {"path": ("library: RCCL send/receive groups per context (mdbg_shard_exchange)" if comms is not None
-                         else "peer copies: staging buffers shared by CUDA IPC, owners pull their slices (PeerCopyExchange); host handshakes over gloo" if peer is not None
+        lib_mode = comms[0].mode if comms is not None else None
+        exch = {"path": ("library: peer copies (mdbg_shard_exchange, MDBG_COMM_PEER: owners pull their slices device to device)" if lib_mode == "peer"
+                         else "library: RCCL send/receive groups (mdbg_shard_exchange, MDBG_COMM_RCCL)" if lib_mode == "rccl"
                          else f"torch.distributed all_to_all_single ({backend_name})"),
-                "staging_shares": peer[0].shares if peer is not None else None, "peer_copy_note": peer_note,
-                # what the communicator itself reports (ncclCommCount through mdbg_comm_stats); the torch path: the process group's size
-                "rccl_ranks": acct1["rccl_ranks"] if comms is not None else (dist.get_world_size() if dist is not None and backend_name == "nccl" else None),
+                "transport": lib_mode or "torch", "comm_note": comm_note,
+                # RCCL ranks: what the library's communicator itself reports (ncclCommCount through mdbg_comm_stats) when the rows travel over
+                # it; otherwise the size of torch.distributed's RCCL process group (which then carries barriers and the verification only)
+                "rccl_ranks": acct1["rccl_ranks"] if lib_mode == "rccl" else (dist.get_world_size() if dist is not None and backend_name == "nccl" else None),
                 "ranks": world,
                 "wire_bytes_per_step": int(et[0].item()) / args.steps, "wire_bytes_per_step_per_rank": int(et[0].item()) / args.steps / world,
                 "exchanges_timed": int(et[1].item()),
@@ -1616,10 +1716,10 @@ def main() -> None:
             "value": total_bases / 1e9 / dt, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if args.total_reads > 0 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.reads} synthetic HiFi reads x {args.read_len} bp per GPU (seed 42, 0.1% substitutions, "
-                                   f"4 species, 50x; {n_bases * world / 1e9:.0f} Gbp per step over all GPUs), HPC on, l={K_MINIMIZER}, density {DENSITY}, "
-                                   f"single k iteration k={KMINMER} (count + rescue); inputs 2-bit packed and resident in HBM, one read set per GPU "
-                                   "shared by the batches in flight",
+            # (<= 200 characters: the line's copy is cut there)
+            "config": {"workload": f"{args.reads} synthetic HiFi reads x {args.read_len} bp per GPU (seed 42, 0.1% subst., 50x; {n_bases * world / 1e9:.0f} Gbp/step over all GPUs), HPC, "
+                                   f"l={K_MINIMIZER}, density {DENSITY}, k={KMINMER} count+rescue; 2-bit packed, resident in HBM",
+                       "workload_note": "4 species; one read set per GPU shared by the batches in flight; single k iteration",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "minimizers_per_step": int(n_min),
                        "kminmer_records": int(totals[0].item()), "solid": int(totals[1].item()),
                        "batches_in_flight": n_slots, "table_blocks_per_cu": table_blocks, "table_grid_blocks": table_grid, "table_cu_count": table_cus, "shared_device_options": shared_opts, "overlap_probe": probe, "device": info["arch"], "cus": info["n_cu"],
@@ -1665,13 +1765,10 @@ def main() -> None:
             out["speedup_vs_cpu_reference_path_only"] = out["value"] / base["value"]
         if trace and phases:
             out["exchange_phase_ms_per_step_incl_warmup"] = {k: v / (args.steps + n_warm) for k, v in phases.items()}
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd, args.detail)
     if comms is not None:
         for cm in comms:
             cm.destroy()
-    if peer is not None:            # every process lets go of the others' buffers before anybody frees its own
-        for px in peer:
-            px.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

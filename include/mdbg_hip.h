@@ -372,30 +372,56 @@ int  mdbg_shard_from_table(mdbg_ctx *ctx, const mdbg_table *local, uint32_t n_ra
                            uint64_t *counts);
 int  mdbg_shard_keep(mdbg_ctx *ctx, mdbg_shard *shard, const uint64_t *d_replies, mdbg_table **out);
 
-/* ---- the exchange inside the library: RCCL point-to-point over xGMI -----------------------------------------------
+/* ---- the exchange inside the library: peer copies or RCCL point-to-point, over xGMI --------------------------------
  * For callers that do not want to move the bytes themselves (the C++ pipeline: src/pipeline has no communication layer).
  * One communicator per context that takes part; rank 0 makes the id (128 bytes) and hands it to the other ranks by whatever
  * means it has (a file in the shared tmp dir, a socket, MPI, torch.distributed -- bench.py broadcasts it).  Ranks may be
- * processes (one per GPU) or threads of one process driving one context each.  RCCL is loaded on first use.
- *     mdbg_comm_unique_id   ncclGetUniqueId
- *     mdbg_comm_create      ncclCommInitRank: collective, every rank calls it with the same id
- *     mdbg_comm_adopt       wraps a communicator the caller already has (an ncclComm_t); mdbg_comm_destroy leaves it alive
+ * processes (one per GPU) or threads of one process driving one context each (mdbg_tool graph --gpus G).
+ *     mdbg_comm_unique_id    ncclGetUniqueId (128 random bytes when RCCL is not installed: enough for MDBG_COMM_PEER)
+ *     mdbg_comm_create_mode  collective, every rank calls it with the same id and mode:
+ *         MDBG_COMM_PEER   the two all-to-alls as PEER COPIES.  Every rank stages its rows (grouped by owner) and later its replies in
+ *                          a buffer of its own; every owner PULLS its slice from every sender with a device-to-device copy, one
+ *                          stream per peer, so the seven xGMI links of a GPU carry their slices at once; the replies travel the
+ *                          same way back.  Between processes the buffers are shared by hipIpcGetMemHandle / hipIpcOpenMemHandle,
+ *                          between threads of one process they are plain pointers (peer access enabled between the devices).  The
+ *                          hand-shakes -- the count matrix, "my rows are staged", the status words of the failure protocol below --
+ *                          are words in a block of host memory the ranks share (csrc/peerlink.hpp: a POSIX shared-memory object named
+ *                          after the id, unlinked once everybody is attached), polled with a deadline (MDBG_PEER_TIMEOUT_S, default
+ *                          120): no collective kernel has to become resident beside another batch's scan -- RCCL's needs 37.6 KB of
+ *                          LDS a block, a scan leaves 28 -- and no exchange can hang.  Creation ends with a self-test: a small
+ *                          exchange of known rows through the very buffers, whose verdicts the ranks agree on.
+ *         MDBG_COMM_RCCL   ncclCommInitRank; every transfer an ncclSend / ncclRecv pair inside one group.  RCCL is loaded on first use.
+ *         MDBG_COMM_AUTO   peer copies if every rank attaches and passes the self-test, otherwise -- all ranks together -- RCCL
+ *                          (mdbg_comm_note says why).  A caller with other batches' scans in flight then keeps them off the device
+ *                          during an exchange (bench.py's exchange gate).
+ *         MDBG_COMM_DEFAULT  the environment's MDBG_COMM_MODE = peer | rccl | auto, "auto" when unset
+ *     mdbg_comm_create       = mdbg_comm_create_mode(..., MDBG_COMM_DEFAULT, ...)
+ *     mdbg_comm_adopt        wraps a communicator the caller already has (an ncclComm_t); mdbg_comm_destroy leaves it alive
+ *     mdbg_comm_mode         the transport a communicator ended up with (MDBG_COMM_PEER or MDBG_COMM_RCCL)
+ *     mdbg_comm_destroy      collective in peer mode (a rank frees its staging buffers once its peers have let go of them; bounded wait)
  * mdbg_kminmer_count_first_sharded = mdbg_shard_begin -> rows to their owner ranks -> mdbg_shard_reduce -> replies back ->
- * mdbg_shard_finish, all on the context's stream; every transfer is an ncclSend / ncclRecv pair inside one group, i.e. an
- * all-to-all that keeps every xGMI link of the GPU busy.  Collective: every rank of the communicator calls it, in the same
- * order if a rank drives several communicators.  The union over ranks of the tables equals mdbg_kminmer_count_first over the
- * union of the reads.  Replaces, across GPUs, KminmerCounter's partition-to-disk + per-partition dereplication
- * (graph/CreateMdbg.hpp:3714-3724, :3744-3851). */
+ * mdbg_shard_finish, all on the context's stream (the pulls on side streams it waits for).  Collective: every rank of the
+ * communicator calls it, in the same order if a rank drives several communicators.  The union over ranks of the tables equals
+ * mdbg_kminmer_count_first over the union of the reads.  Replaces, across GPUs, KminmerCounter's partition-to-disk +
+ * per-partition dereplication (graph/CreateMdbg.hpp:3714-3724, :3744-3851). */
 typedef struct mdbg_comm mdbg_comm;
 #define MDBG_COMM_ID_BYTES 128
 int  mdbg_comm_unique_id(uint8_t *id128);
+#define MDBG_COMM_DEFAULT (-1)
+#define MDBG_COMM_RCCL    0
+#define MDBG_COMM_PEER    1
+#define MDBG_COMM_AUTO    2
 int  mdbg_comm_create(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, mdbg_comm **out);
+int  mdbg_comm_create_mode(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, int mode, mdbg_comm **out);
+int  mdbg_comm_mode(const mdbg_comm *comm);
+const char *mdbg_comm_note(const mdbg_comm *comm);     /* "auto" that ended on RCCL: why the peer copies were not taken; else "" */
 int  mdbg_comm_adopt(mdbg_ctx *ctx, void *nccl_comm, int rank, int n_ranks, mdbg_comm **out);
 void mdbg_comm_destroy(mdbg_comm *comm);
-/* What the communicator has carried: stats[0] = rank, [1] = ranks as the caller gave them, [2] = ncclCommCount (create / adopt
- * fail unless it equals [1] and ncclCommUserRank equals [0]), [3] = completed exchanges, [4] / [5] = bytes sent to / received
- * from OTHER ranks over RCCL (rows and replies), [6] = bytes of the rank's own share (device-to-device copies, never on the
- * wire), [7] = ncclCommUserRank; *exchange_ms (may be NULL) = host wall time spent inside mdbg_shard_exchange. */
+/* What the communicator has carried: stats[0] = rank, [1] = ranks as the caller gave them, [2] = ncclCommCount (RCCL: create / adopt
+ * fail unless it equals [1] and ncclCommUserRank equals [0]; 0 for peer copies), [3] = completed exchanges, [4] / [5] = bytes that went
+ * to / came from OTHER ranks (rows and replies; peer copies: what the peers pulled from this rank / what it pulled), [6] = bytes of the
+ * rank's own share (device-to-device copies, never on the wire), [7] = ncclCommUserRank; *exchange_ms (may be NULL) = host wall
+ * time spent inside mdbg_shard_exchange. */
 int  mdbg_comm_stats(const mdbg_comm *comm, uint64_t stats[8], double *exchange_ms);
 int  mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, const mdbg_minimizers *reads, uint32_t k,
                                       uint32_t min_abundance, mdbg_table **out);
@@ -405,7 +431,8 @@ int  mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, const mdbg
 int  mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts,
                          const uint64_t **d_replies);
 /* Failure behaviour of the collective calls.  An exchange is: counts all-gathered -> rows to owners -> reduction -> replies.
- * Before each transfer the ranks agree (a status word per rank, all-gathered) that everybody got that far: a rank that failed
+ * Before each transfer the ranks agree (a status word per rank: all-gathered over RCCL, or written to the shared control block of
+ * the peer copies, where waiting for a rank that died ends at a deadline with MDBG_EPEER) that everybody got that far: a rank that failed
  * locally -- bad argument, allocation, reduction -- still takes part in that small collective with its error code, returns its
  * own error, and every other rank returns MDBG_EPEER naming it; nobody is left waiting in a receive.  Send / receive groups
  * are closed on every path (an open group would swallow the thread's next RCCL call); a communicator on which an RCCL call

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmdbg_hip.so")
 SOURCES = ["context", "prims", "reads", "scan", "minimizers", "kminmer", "partition", "multigpu"]
-HEADERS = ["common.hpp", "murmur.hpp", "objects.hpp", "table.hpp", "kminmer_dev.hpp", os.path.join("..", "..", "include", "mdbg_hip.h")]
+HEADERS = ["common.hpp", "murmur.hpp", "objects.hpp", "table.hpp", "kminmer_dev.hpp", "peerlink.hpp", os.path.join("..", "..", "include", "mdbg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

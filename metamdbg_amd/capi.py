@@ -106,6 +106,9 @@ SIGNATURES = {
     "mdbg_shard_keep": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
     "mdbg_comm_unique_id": (C.c_int, [_P]),
     "mdbg_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mdbg_comm_create_mode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "mdbg_comm_mode": (C.c_int, [_P]),
+    "mdbg_comm_note": (C.c_char_p, [_P]),
     "mdbg_comm_adopt": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "mdbg_comm_destroy": (None, [_P]),
     "mdbg_comm_stats": (C.c_int, [_P, _u64p, C.POINTER(C.c_double)]),
@@ -331,7 +334,7 @@ class Context:
         self.check(lib().mdbg_small_contigs(self.h, unitigs.h, k, k_prev, prev.h, flags.ctypes.data))
         return flags
 
-    # -- the exchange inside the library (RCCL) -----------------------------------------------------
+    # -- the exchange inside the library (peer copies or RCCL) --------------------------------------
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = C.create_string_buffer(128)
@@ -353,9 +356,11 @@ class Context:
         self.check(lib().mdbg_minimizers_slice(self.h, m.h, first_read, n_reads, C.byref(h)))
         return Minimizers(self, h)
 
-    def comm_create(self, unique_id: bytes, rank: int, n_ranks: int) -> "Comm":
+    def comm_create(self, unique_id: bytes, rank: int, n_ranks: int, mode: "int | str" = -1) -> "Comm":
+        """mode: "peer" | "rccl" | "auto" (or the MDBG_COMM_* value); -1: the environment's MDBG_COMM_MODE, "auto" when unset."""
         h = C.c_void_p()
-        self.check(lib().mdbg_comm_create(self.h, unique_id, rank, n_ranks, C.byref(h)))
+        m = COMM_MODES[mode] if isinstance(mode, str) else int(mode)
+        self.check(lib().mdbg_comm_create_mode(self.h, unique_id, rank, n_ranks, m, C.byref(h)))
         return Comm(h)
 
     def kminmer_count_first_sharded(self, comm: "Comm", m: "Minimizers", k: int = 4, min_abundance: int = 0) -> "Table":
@@ -405,11 +410,24 @@ class Census:
             pass
 
 
+COMM_MODES = {"default": -1, "rccl": 0, "peer": 1, "auto": 2}
+
+
 class Comm:
-    """An RCCL communicator owned by the library (mdbg_comm_create)."""
+    """A communicator owned by the library (mdbg_comm_create_mode): peer copies or RCCL."""
 
     def __init__(self, h):
         self.h = h
+
+    @property
+    def mode(self) -> str:
+        """The transport it ended up with: "peer" or "rccl" (mdbg_comm_mode)."""
+        return {0: "rccl", 1: "peer"}.get(int(lib().mdbg_comm_mode(self.h)), "?")
+
+    @property
+    def note(self) -> str:
+        """Why "auto" did not take the peer copies ("" if it did): mdbg_comm_note."""
+        return (lib().mdbg_comm_note(self.h) or b"").decode()
 
     def stats(self) -> dict:
         """What the communicator carried so far (mdbg_comm_stats)."""
@@ -417,7 +435,7 @@ class Comm:
         ms = C.c_double()
         lib().mdbg_comm_stats(self.h, st, C.byref(ms))
         return dict(rank=int(st[0]), n_ranks=int(st[1]), rccl_ranks=int(st[2]), exchanges=int(st[3]), bytes_to_peers=int(st[4]),
-                    bytes_from_peers=int(st[5]), bytes_local=int(st[6]), exchange_ms=float(ms.value))
+                    bytes_from_peers=int(st[5]), bytes_local=int(st[6]), exchange_ms=float(ms.value), mode=self.mode)
 
     def abort(self, ctx: "Context", code: int = -1) -> None:
         """This rank cannot enter the exchange its peers are about to enter: tell them (mdbg_shard_abort)."""

@@ -1,4 +1,11 @@
-// multigpu.hip -- the exchange of the sharded first pass inside the library: RCCL point-to-point over xGMI.
+// multigpu.hip -- the exchange of the sharded passes inside the library, two transports behind one call (mdbg_shard_exchange):
+//   * RCCL point-to-point over xGMI (ncclSend / ncclRecv groups), and
+//   * PEER COPIES: every rank stages its rows, every owner pulls its slices with device-to-device copies (one stream per peer: the
+//     seven links of a GPU carry their slices at once), the hand-shakes are words in host memory the ranks share (peerlink.hpp) --
+//     no collective kernel that has to find room on a compute unit beside another batch's scan, no host collective of another
+//     library.  Ranks are processes (staging buffers shared by hipIpcGetMemHandle / hipIpcOpenMemHandle) or threads of one
+//     process (mdbg_tool graph --gpus G: plain pointers, peer access between the devices).
+// mdbg_comm_create_mode selects; "auto" takes peer copies after a self-test every rank passed, RCCL otherwise.
 //
 // Reads shard across GPUs; only the k-min-mer counts are global.  mdbg_kminmer_count_first_sharded runs
 // mdbg_shard_begin -> rows to their owner ranks -> mdbg_shard_reduce -> replies back -> mdbg_shard_finish in one call, on the
@@ -11,12 +18,14 @@
 // one), so single-GPU users of libmdbg_hip.so do not depend on it.
 #include "common.hpp"
 #include "objects.hpp"
+#include "peerlink.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -73,8 +82,41 @@ static RcclApi *rccl_api() {
 
 using namespace mdbg;
 
+namespace mdbg {
+
+// ---- peer copies: what a rank keeps besides the shared control block ----
+struct PeerOwn {                 // a staging buffer of this rank (plain hipMalloc: it must outlive the peers' mappings, not a pool block)
+    void *p = nullptr;
+    size_t cap = 0;
+    uint64_t generation = 0;
+    hipIpcMemHandle_t handle{};
+};
+struct PeerView {                // a peer's staging buffer as this rank reaches it
+    uint64_t generation = 0;
+    void *p = nullptr;
+    bool opened = false;         // through hipIpcOpenMemHandle (another process): to be closed
+};
+struct PeerLink {
+    PeerCtl ctl;
+    PeerOwn rows, replies;
+    std::vector<PeerView> v_rows, v_replies;
+    std::vector<hipStream_t> streams;        // one per peer: pulls from different peers run at once
+    std::vector<hipEvent_t> events;
+    std::vector<std::pair<void *, uint64_t>> retired;   // replaced staging buffers and the exchange they were replaced in
+    DevBuf<uint64_t> test_reply;             // the self-test's replies
+    uint64_t exchange = 0;
+    double timeout_s = 120.0;
+    uint64_t regrown = 0;                    // how often a staging buffer was replaced
+};
+
+}  // namespace mdbg
+
 struct mdbg_comm {
     ncclComm_t comm = nullptr;
+    int mode = MDBG_COMM_RCCL;   // the transport in use: MDBG_COMM_RCCL or MDBG_COMM_PEER
+    std::unique_ptr<mdbg::PeerLink> link;    // MDBG_COMM_PEER
+    std::string fallback_note;   // "auto" that ended on RCCL: why the peer copies were not taken
+    int device = 0;
     int rank = 0, n_ranks = 1;
     int rccl_count = 0, rccl_rank = -1;   // what the communicator itself reports (ncclCommCount / ncclCommUserRank)
     bool owned = false;          // created by mdbg_comm_create (destroyed with the handle) or adopted from the caller
@@ -98,12 +140,20 @@ struct mdbg_comm {
 extern "C" int mdbg_comm_unique_id(uint8_t *id128) {
     if (!id128) return MDBG_EINVAL;
     RcclApi *api = rccl_api();
-    if (!api->error.empty()) { g_last_error = api->error; return MDBG_ENODEV; }
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-    ncclUniqueId id;
-    ncclResult_t r = api->GetUniqueId(&id);
-    if (r != ncclSuccess) { g_last_error = std::string("ncclGetUniqueId failed: ") + api->GetErrorString(r); return MDBG_EHIP; }
-    memcpy(id128, &id, sizeof id);
+    if (api->error.empty()) {
+        ncclUniqueId id;
+        ncclResult_t r = api->GetUniqueId(&id);
+        if (r != ncclSuccess) { g_last_error = std::string("ncclGetUniqueId failed: ") + api->GetErrorString(r); return MDBG_EHIP; }
+        memcpy(id128, &id, sizeof id);
+        return MDBG_OK;
+    }
+    // no RCCL in this process: 128 random bytes name a communicator of the peer-copy transport just as well (MDBG_COMM_PEER;
+    // mdbg_comm_create_mode with MDBG_COMM_RCCL or a fallback to it then fails with the loader's message)
+    FILE *f = fopen("/dev/urandom", "rb");
+    const size_t got = f ? fread(id128, 1, 128, f) : 0;
+    if (f) fclose(f);
+    if (got != 128) { g_last_error = api->error + "; and /dev/urandom gave no id"; return MDBG_ENODEV; }
     return MDBG_OK;
 }
 
@@ -119,22 +169,6 @@ static int comm_finish_setup(mdbg_ctx *ctx, RcclApi *api, mdbg_comm *c, const ch
     return MDBG_OK;
 }
 
-extern "C" int mdbg_comm_create(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, mdbg_comm **out) try {
-    if (!ctx || !id128 || !out || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
-        return set_error(ctx, MDBG_EINVAL, "mdbg_comm_create: bad argument (ranks 1..64)");
-    RcclApi *api = rccl_api();
-    if (!api->error.empty()) return set_error(ctx, MDBG_ENODEV, "%s", api->error.c_str());
-    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    ncclUniqueId id;
-    memcpy(&id, id128, sizeof id);
-    std::unique_ptr<mdbg_comm, void (*)(mdbg_comm *)> c(new mdbg_comm(), mdbg_comm_destroy);
-    c->rank = rank; c->n_ranks = n_ranks; c->owned = true;
-    MDBG_NCCL_CHECK(ctx, api, api->CommInitRank(&c->comm, n_ranks, id, rank));
-    MDBG_TRY(comm_finish_setup(ctx, api, c.get(), "mdbg_comm_create"));
-    *out = c.release();
-    return MDBG_OK;
-} MDBG_API_CATCH(ctx)
-
 extern "C" int mdbg_comm_adopt(mdbg_ctx *ctx, void *nccl_comm, int rank, int n_ranks, mdbg_comm **out) try {
     if (!ctx || !nccl_comm || !out || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
         return set_error(ctx, MDBG_EINVAL, "mdbg_comm_adopt: bad argument (ranks 1..64)");
@@ -142,18 +176,11 @@ extern "C" int mdbg_comm_adopt(mdbg_ctx *ctx, void *nccl_comm, int rank, int n_r
     if (!api->error.empty()) return set_error(ctx, MDBG_ENODEV, "%s", api->error.c_str());
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<mdbg_comm, void (*)(mdbg_comm *)> c(new mdbg_comm(), mdbg_comm_destroy);
-    c->comm = (ncclComm_t)nccl_comm; c->rank = rank; c->n_ranks = n_ranks; c->owned = false;
+    c->comm = (ncclComm_t)nccl_comm; c->rank = rank; c->n_ranks = n_ranks; c->owned = false; c->device = ctx->device;
     MDBG_TRY(comm_finish_setup(ctx, api, c.get(), "mdbg_comm_adopt"));
     *out = c.release();
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
-
-extern "C" void mdbg_comm_destroy(mdbg_comm *c) {
-    if (!c) return;
-    // a communicator an RCCL call failed on is aborted, not destroyed: ncclCommDestroy waits for operations that will never finish
-    if (c->owned && c->comm) (void)(c->broken ? rccl_api()->CommAbort(c->comm) : rccl_api()->CommDestroy(c->comm));
-    delete c;
-}
 
 extern "C" int mdbg_comm_stats(const mdbg_comm *c, uint64_t stats[8], double *exchange_ms) {
     if (!c || !stats) return MDBG_EINVAL;
@@ -256,7 +283,7 @@ int all_to_all(mdbg_ctx *ctx, RcclApi *api, mdbg_comm *comm, const uint64_t *src
     return MDBG_OK;
 }
 
-int exchange_impl(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts, const uint64_t **d_replies,
+int exchange_rccl(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts, const uint64_t **d_replies,
                   int local_rc) {
     RcclApi *api = rccl_api();
     if (!api->error.empty()) return set_error(ctx, MDBG_ENODEV, "%s", api->error.c_str());
@@ -350,6 +377,366 @@ int exchange_impl(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint6
     return MDBG_OK;
 }
 
+
+// =====================================================================================================================
+// The peer-copy transport
+// =====================================================================================================================
+using ReduceFn = std::function<int(const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply)>;
+
+double peer_timeout_s() {
+    if (const char *e = getenv("MDBG_PEER_TIMEOUT_S")) { const double v = atof(e); if (v > 0) return v; }
+    return 120.0;
+}
+
+// this rank's staging buffer holds at least `bytes`; a replaced buffer stays alive until no peer can have it mapped any more
+int peer_grow(mdbg_ctx *ctx, PeerLink *L, PeerOwn &own, size_t bytes) {
+    if (bytes <= own.cap) return MDBG_OK;
+    const size_t cap = bytes + bytes / 4 + (1u << 20);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) { (void)hipGetLastError(); ctx->pool->trim(); e = hipMalloc(&p, cap); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(ctx, MDBG_ENOMEM, "peer-copy staging buffer of %zu bytes: %s", cap, hipGetErrorString(e)); }
+    hipIpcMemHandle_t h{};
+    if (L->ctl.n_ranks() > 1) {
+        e = hipIpcGetMemHandle(&h, p);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return set_error(ctx, MDBG_EHIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
+    }
+    if (own.p) { L->retired.emplace_back(own.p, L->exchange); L->regrown++; }
+    own.p = p; own.cap = cap; own.handle = h; own.generation++;
+    return MDBG_OK;
+}
+
+void peer_publish(const PeerOwn &own, PeerBufWords &w) {
+    static_assert(sizeof(hipIpcMemHandle_t) == sizeof(w.handle), "hipIpcMemHandle_t is 64 bytes");
+    w.generation = own.generation; w.pointer = (uint64_t)(uintptr_t)own.p; w.capacity = own.cap;
+    memcpy(w.handle, &own.handle, sizeof w.handle);
+}
+
+void peer_unmap(PeerView &v) {
+    if (v.opened && v.p) (void)hipIpcCloseMemHandle(v.p);
+    v = PeerView();
+}
+
+// rank r's staging buffer as published in `w`, reachable from this rank's device
+int peer_map(mdbg_ctx *ctx, PeerLink *L, int r, const PeerBufWords &w, PeerView &v, void **out) {
+    if (v.generation == w.generation && v.p) { *out = v.p; return MDBG_OK; }
+    peer_unmap(v);
+    if (w.generation == 0 || w.pointer == 0) return set_error(ctx, MDBG_EPEER, "rank %d published no staging buffer", r);
+    PeerSlot *ps = L->ctl.slot(r);
+    if (ps->pid == (int32_t)getpid()) {              // a thread of this process: its pointer is ours (one address space)
+        if (ps->device != ctx->device) {
+            hipError_t e = hipDeviceEnablePeerAccess(ps->device, 0);     // (without it the copy is staged by the runtime: slower, still right)
+            if (e != hipSuccess) (void)hipGetLastError();
+        }
+        v.p = (void *)(uintptr_t)w.pointer; v.opened = false;
+    } else {
+        hipIpcMemHandle_t h;
+        memcpy(&h, w.handle, sizeof h);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); return set_error(ctx, MDBG_EHIP, "hipIpcOpenMemHandle (staging buffer of rank %d, pid %d, device %d): %s", r, ps->pid, ps->device, hipGetErrorString(e)); }
+        v.p = p; v.opened = true;
+    }
+    v.generation = w.generation;
+    *out = v.p;
+    return MDBG_OK;
+}
+
+// One phase of an exchange: this rank says `rc` (its words for the phase are written), waits for everybody, reads what they said.
+// MDBG_OK: all can go on.  Otherwise this rank's own code (message already set), MDBG_EPEER naming the first rank that failed, or
+// MDBG_EPEER for a rank that did not arrive in time / has left (the communicator is then broken: nobody can tell how far it came).
+int peer_phase(mdbg_ctx *ctx, mdbg_comm *comm, uint64_t E, int phase, int rc, const char *what) {
+    PeerLink *L = comm->link.get();
+    L->ctl.words(comm->rank, E)->status[phase] = rc;
+    L->ctl.arrive(PeerCtl::tick_of(E, phase));
+    const int late = L->ctl.wait_all(PeerCtl::tick_of(E, phase), L->timeout_s);
+    if (late >= 0) {
+        comm->broken = true;
+        const std::string own = rc != MDBG_OK ? ctx->err : "";
+        set_error(ctx, MDBG_EPEER, "mdbg_shard_exchange (peer copies): rank %d did not arrive %s within %.0f s (MDBG_PEER_TIMEOUT_S)%s%s", late, what, L->timeout_s,
+                  own.empty() ? "" : "; this rank had failed: ", own.c_str());
+        return rc != MDBG_OK ? rc : MDBG_EPEER;
+    }
+    if (rc != MDBG_OK) return rc;
+    for (int r = 0; r < comm->n_ranks; r++) {
+        if (L->ctl.left_before(r, PeerCtl::tick_of(E, phase))) {
+            comm->broken = true;
+            return set_error(ctx, MDBG_EPEER, "mdbg_shard_exchange (peer copies): rank %d has left the communicator", r);
+        }
+        const int64_t st = L->ctl.words(r, E)->status[phase];
+        if (st != 0)
+            return set_error(ctx, MDBG_EPEER, "mdbg_shard_exchange: rank %d failed %s (code %lld); nothing was exchanged", r, what, (long long)st);
+    }
+    return MDBG_OK;
+}
+
+int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const uint64_t *counts, const uint64_t **d_replies, int local_rc,
+                  const ReduceFn &reduce) {
+    PeerLink *L = comm->link.get();
+    if (comm->broken) return set_error(ctx, MDBG_EHIP, "mdbg_shard_exchange: an earlier exchange failed on this communicator (a rank did not arrive or has left)");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int n = comm->n_ranks, me = comm->rank;
+    const uint32_t rw = mdbg_row_words(4);
+    const auto t_enter = std::chrono::steady_clock::now();
+    const uint64_t E = ++L->exchange;
+    PeerWords *mine = L->ctl.words(me, E);
+    MDBG_DBG(ctx, "shard_exchange (peer copies): enter, %d ranks, exchange %llu", n, (unsigned long long)E);
+
+    const int fail_phase = ctx->test_exchange_fail_phase;       // tests: one-shot local failures
+    ctx->test_exchange_fail_phase = 0;
+    if (fail_phase == 1 && local_rc == MDBG_OK) local_rc = set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange: test failure before the counts");
+    // ---- phase 0: who sends how many rows to whom, where they will be staged (and whether everybody got this far) ----
+    uint64_t n_sent = 0;
+    if (local_rc == MDBG_OK) {
+        for (int r = 0; r < n; r++) n_sent += counts[r];
+        if (n_sent && !d_rows) local_rc = set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange: null rows");
+    }
+    if (local_rc == MDBG_OK) local_rc = peer_grow(ctx, L, L->rows, (size_t)n_sent * rw * 8);
+    for (int r = 0; r < n; r++) mine->counts[r] = local_rc == MDBG_OK ? counts[r] : 0;
+    peer_publish(L->rows, mine->rows);
+    MDBG_TRY(peer_phase(ctx, comm, E, 0, local_rc, "before the exchange"));
+    // m(r, d) = rows rank r holds for owner d
+    auto m = [&](int r, int d) { return L->ctl.words(r, E)->counts[d]; };
+    std::vector<uint64_t> s_cnt((size_t)n), got((size_t)n), soff((size_t)n + 1, 0), roff((size_t)n + 1, 0);
+    for (int r = 0; r < n; r++) {
+        s_cnt[r] = counts[r];
+        got[r] = m(r, me);
+        soff[r + 1] = soff[r] + s_cnt[r];
+        roff[r + 1] = roff[r] + got[r];
+    }
+    const uint64_t n_recv = roff[n];
+    MDBG_DBG(ctx, "shard_exchange: counts known, %llu rows out, %llu in", (unsigned long long)n_sent, (unsigned long long)n_recv);
+
+    // ---- phase 1: my rows are staged, my receive buffers exist ----
+    DevBuf<uint64_t> d_recv;
+    int rc = d_recv.alloc(ctx, n_recv * rw);
+    if (rc == MDBG_OK) rc = comm->replies.alloc(ctx, n_sent);
+    if (rc == MDBG_OK) rc = peer_grow(ctx, L, L->replies, (size_t)n_recv * 8);
+    if (fail_phase == 2 && rc == MDBG_OK) rc = set_error(ctx, MDBG_ENOMEM, "mdbg_shard_exchange: test failure allocating the receive buffers");
+    if (rc == MDBG_OK && n_sent - s_cnt[me] > 0) {
+        // (the rows for this rank itself stay where they are: they are copied straight into the receive buffer below)
+        hipError_t e = hipSuccess;
+        if (soff[me]) e = hipMemcpyAsync(L->rows.p, d_rows, soff[me] * rw * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && n_sent > soff[me + 1])
+            e = hipMemcpyAsync((uint64_t *)L->rows.p + soff[me + 1] * rw, d_rows + soff[me + 1] * rw, (n_sent - soff[me + 1]) * rw * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "staging the rows: %s", hipGetErrorString(e));
+    }
+    peer_publish(L->replies, mine->replies);
+    MDBG_TRY(peer_phase(ctx, comm, E, 1, rc, "allocating the receive buffers"));
+
+    // ---- rows to their owners: every owner pulls its slice from every sender, one stream per peer ----
+    rc = MDBG_OK;
+    {
+        LaunchTimer timer(ctx, "shard_exchange");
+        hipError_t e = hipSuccess;
+        if (s_cnt[me]) {
+            e = hipMemcpyAsync(d_recv.p + roff[me] * rw, d_rows + soff[me] * rw, s_cnt[me] * rw * 8, hipMemcpyDeviceToDevice, ctx->stream);
+            comm->bytes_local += s_cnt[me] * rw * 8;
+        }
+        for (int r = 0; r < n && e == hipSuccess && rc == MDBG_OK; r++) {
+            if (r == me || got[r] == 0) continue;
+            void *src = nullptr;
+            rc = peer_map(ctx, L, r, L->ctl.words(r, E)->rows, L->v_rows[r], &src);
+            if (rc != MDBG_OK) break;
+            uint64_t first = 0;                                  // my slice in rank r's staging buffer: behind what it holds for lower owners
+            for (int d = 0; d < me; d++) first += m(r, d);
+            e = hipMemcpyAsync(d_recv.p + roff[r] * rw, (const uint64_t *)src + first * rw, got[r] * rw * 8, hipMemcpyDeviceToDevice, L->streams[r]);
+            if (e == hipSuccess) e = hipEventRecord(L->events[r], L->streams[r]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, L->events[r], 0);
+            comm->bytes_from_peers += got[r] * rw * 8;
+            comm->bytes_to_peers += s_cnt[r] * rw * 8;           // (what the peers pull from this rank: the same matrix read the other way)
+        }
+        if (e != hipSuccess && rc == MDBG_OK) rc = set_error(ctx, MDBG_EHIP, "pulling the rows: %s", hipGetErrorString(e));
+    }
+    for (int r = 0; r < n; r++)                                  // the senders that staged rows for others but none for this rank still count
+        if (r != me && got[r] == 0) comm->bytes_to_peers += s_cnt[r] * rw * 8;
+    // ---- the owner sums and answers; the replies are staged ----
+    const uint64_t *d_reply = nullptr;
+    if (rc == MDBG_OK) rc = reduce(d_recv.p, n_recv, &d_reply);
+    if (fail_phase == 3 && rc == MDBG_OK) rc = set_error(ctx, MDBG_EHIP, "mdbg_shard_exchange: test failure in the reduction");
+    if (rc == MDBG_OK) {
+        hipError_t e = hipSuccess;
+        if (n_recv - got[me] > 0) e = hipMemcpyAsync(L->replies.p, d_reply, n_recv * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (also: every pull of this rank has landed)
+        if (e != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "staging the replies: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    MDBG_TRY(peer_phase(ctx, comm, E, 2, rc, "summing the rows it owns"));
+    MDBG_DBG(ctx, "shard_exchange: reduced");
+
+    // ---- replies back: every sender pulls, from every owner, the answers to the rows it sent there, in the order it sent them ----
+    {
+        LaunchTimer timer(ctx, "shard_exchange");
+        hipError_t e = hipSuccess;
+        if (got[me]) {
+            e = hipMemcpyAsync(comm->replies.p + soff[me], d_reply + roff[me], got[me] * 8, hipMemcpyDeviceToDevice, ctx->stream);
+            comm->bytes_local += got[me] * 8;
+        }
+        for (int d = 0; d < n && e == hipSuccess; d++) {
+            if (d == me || s_cnt[d] == 0) continue;
+            void *src = nullptr;
+            MDBG_TRY(peer_map(ctx, L, d, L->ctl.words(d, E)->replies, L->v_replies[d], &src));
+            uint64_t first = 0;                                  // owner d received the ranks' rows in rank order
+            for (int r = 0; r < me; r++) first += m(r, d);
+            e = hipMemcpyAsync(comm->replies.p + soff[d], (const uint64_t *)src + first, s_cnt[d] * 8, hipMemcpyDeviceToDevice, L->streams[d]);
+            if (e == hipSuccess) e = hipEventRecord(L->events[d], L->streams[d]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, L->events[d], 0);
+            comm->bytes_from_peers += s_cnt[d] * 8;
+            comm->bytes_to_peers += got[d] * 8;
+        }
+        if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "pulling the replies: %s", hipGetErrorString(e));
+    }
+    for (int d = 0; d < n; d++)
+        if (d != me && s_cnt[d] == 0) comm->bytes_to_peers += got[d] * 8;
+    if (ctx->test_corrupt_replies && n_sent) {      // tests: the global count of one key this rank was told to LIST is off by one
+        ctx->test_corrupt_replies = false;
+        std::vector<uint64_t> h(n_sent);
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h.data(), comm->replies.p, n_sent * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n_sent; i++)
+            if (h[i] >> 63) {
+                h[i] += 1;
+                MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, comm->replies.p + i, &h[i], 8, hipMemcpyHostToDevice));
+                break;
+            }
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // a staging buffer replaced during exchange X is mapped by nobody once every rank has arrived in X + 1's last phase (which this
+    // rank has just seen): the owner's replies of X were pulled before its peers entered X + 1
+    for (size_t i = 0; i < L->retired.size();) {
+        if (L->retired[i].second < E) { (void)hipFree(L->retired[i].first); L->retired.erase(L->retired.begin() + i); }
+        else i++;
+    }
+    MDBG_DBG(ctx, "shard_exchange: done");
+    comm->n_exchanges++;
+    comm->exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    *d_replies = comm->replies.p;
+    return MDBG_OK;
+}
+
+void peer_teardown(mdbg_comm *c) {
+    PeerLink *L = c->link.get();
+    if (!L) return;
+    (void)hipSetDevice(c->device);
+    for (auto &v : L->v_rows) peer_unmap(v);
+    for (auto &v : L->v_replies) peer_unmap(v);
+    if (L->ctl.attached()) {
+        // nobody frees a buffer a peer may still have mapped: say "closing" (after unmapping theirs), wait for the others to say it too
+        L->ctl.arrive(PeerCtl::TICK_CLOSING);
+        (void)L->ctl.wait_all(PeerCtl::TICK_CLOSING, c->broken ? 1.0 : 10.0);
+    }
+    for (hipStream_t s : L->streams) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : L->events) if (e) (void)hipEventDestroy(e);
+    for (auto &r : L->retired) (void)hipFree(r.first);
+    if (L->rows.p) (void)hipFree(L->rows.p);
+    if (L->replies.p) (void)hipFree(L->replies.p);
+    L->test_reply.release();
+    L->ctl.detach();
+    c->link.reset();
+}
+
+// The control block, the identities, the per-peer streams.  Collective.
+int peer_setup(mdbg_ctx *ctx, mdbg_comm *c, const uint8_t *id128) {
+    c->link.reset(new PeerLink());
+    PeerLink *L = c->link.get();
+    L->timeout_s = peer_timeout_s();
+    double setup_s = 30.0;
+    if (const char *e = getenv("MDBG_PEER_SETUP_TIMEOUT_S")) { const double v = atof(e); if (v > 0) setup_s = v; }
+    // (tests: MDBG_PEER_TEST_NO_SHM -- rank 1 cannot reach the control block, as when /dev/shm is not shared between the ranks' containers)
+    const std::string err = (getenv("MDBG_PEER_TEST_NO_SHM") && c->rank == 1) ? std::string("test: the control block is out of reach")
+                                                                             : L->ctl.attach(PeerCtl::name_for(id128), c->rank, c->n_ranks, setup_s);
+    if (!err.empty()) return set_error(ctx, MDBG_EHIP, "peer copies: %s", err.c_str());
+    PeerSlot *ps = L->ctl.mine();
+    ps->pid = (int32_t)getpid();
+    ps->device = ctx->device;
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    memcpy(ps->bus_id, bus, sizeof ps->bus_id);
+    L->ctl.arrive(PeerCtl::TICK_ATTACHED);
+    const int late = L->ctl.wait_all(PeerCtl::TICK_ATTACHED, setup_s);
+    L->ctl.unlink_name();
+    if (late >= 0) return set_error(ctx, MDBG_EPEER, "peer copies: rank %d did not attach to the control block within %.0f s", late, setup_s);
+    L->v_rows.resize((size_t)c->n_ranks); L->v_replies.resize((size_t)c->n_ranks);
+    L->streams.assign((size_t)c->n_ranks, nullptr); L->events.assign((size_t)c->n_ranks, nullptr);
+    for (int r = 0; r < c->n_ranks; r++) {
+        if (r == c->rank) continue;
+        MDBG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L->streams[r], hipStreamNonBlocking));
+        MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&L->events[r], hipEventDisableTiming));
+    }
+    return MDBG_OK;
+}
+
+__global__ void peer_test_reply_kernel(const uint64_t *rows, uint64_t n, uint32_t rw, uint64_t *reply) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reply[i] = rows[i * rw] * 1000003ull + rows[i * rw + 2];
+}
+
+// A small exchange of known rows through the very buffers, copies and hand-shakes a job will use; then every rank says whether what
+// came back was right, so that all of them take the same decision ("auto": peer copies or RCCL).  Collective.
+int peer_self_test(mdbg_ctx *ctx, mdbg_comm *c) {
+    PeerLink *L = c->link.get();
+    const int n = c->n_ranks, me = c->rank;
+    const uint32_t rw = mdbg_row_words(4);
+    auto cnt = [&](int r, int d) { return (uint64_t)(3 + ((r + d) % 5)); };
+    std::vector<uint64_t> counts((size_t)n), h;
+    uint64_t total = 0;
+    for (int d = 0; d < n; d++) { counts[d] = cnt(me, d); total += counts[d]; }
+    h.assign((size_t)total * rw, 0);
+    uint64_t at = 0;
+    for (int d = 0; d < n; d++)
+        for (uint64_t i = 0; i < counts[d]; i++, at++) { h[at * rw] = (uint64_t)me + 1; h[at * rw + 1] = (uint64_t)d + 1; h[at * rw + 2] = at; }
+    DevBuf<uint64_t> d_rows;
+    int rc = d_rows.alloc(ctx, h.size());
+    if (rc == MDBG_OK && memcpy_sync(ctx, d_rows.p, h.data(), h.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "peer-copy self-test: upload failed");
+    bool rows_right = true;
+    const ReduceFn check = [&](const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) -> int {
+        std::vector<uint64_t> got((size_t)n_recv * rw);
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, got.data(), d_recv, got.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t i = 0;
+        for (int r = 0; r < n; r++) {
+            uint64_t first = 0;
+            for (int d = 0; d < me; d++) first += cnt(r, d);
+            for (uint64_t j = 0; j < cnt(r, me); j++, i++)
+                rows_right = rows_right && i < n_recv && got[i * rw] == (uint64_t)r + 1 && got[i * rw + 1] == (uint64_t)me + 1 && got[i * rw + 2] == first + j;
+        }
+        rows_right = rows_right && i == n_recv;
+        MDBG_TRY(L->test_reply.alloc(ctx, n_recv));
+        hipLaunchKernelGGL(peer_test_reply_kernel, dim3(grid_for(n_recv, 256)), dim3(256), 0, ctx->stream, d_recv, n_recv, rw, L->test_reply.p);
+        *d_reply = L->test_reply.p;
+        return MDBG_OK;
+    };
+    const uint64_t *d_back = nullptr;
+    rc = exchange_peer(ctx, c, d_rows.p, counts.data(), &d_back, rc, check);
+    if (rc == MDBG_OK) {
+        std::vector<uint64_t> back((size_t)total);
+        if (memcpy_sync(ctx, back.data(), d_back, total * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "peer-copy self-test: download failed");
+        bool good = rows_right;
+        for (uint64_t i = 0; i < total && good; i++) good = back[i] == ((uint64_t)me + 1) * 1000003ull + i;
+        if (rc == MDBG_OK && !good) rc = set_error(ctx, MDBG_EHIP, "peer-copy self-test: %s", rows_right ? "a reply came back wrong" : "a slice of rows arrived wrong");
+    }
+    if (c->broken) return rc != MDBG_OK ? rc : MDBG_EPEER;
+    // the verdicts, agreed: one more (empty) exchange whose first phase carries them
+    static const uint64_t none[PEER_MAX_RANKS] = {0};
+    const std::string keep = ctx->err;
+    const int said = rc;
+    const uint64_t *unused = nullptr;
+    rc = exchange_peer(ctx, c, nullptr, none, &unused, said, [](const uint64_t *, uint64_t, const uint64_t **r) { *r = nullptr; return MDBG_OK; });
+    if (said != MDBG_OK) ctx->err = keep;
+    c->n_exchanges = 0; c->bytes_to_peers = c->bytes_from_peers = c->bytes_local = 0; c->exchange_ms = 0.0;      // the job's account starts here
+    return rc;
+}
+
+}  // namespace
+
+namespace {
+int exchange_any(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts, const uint64_t **d_replies, int local_rc) {
+    if (comm->mode == MDBG_COMM_PEER)
+        return exchange_peer(ctx, comm, d_rows, counts, d_replies, local_rc, [&](const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) {
+            return mdbg_shard_reduce(ctx, shard, d_recv, n_recv, d_reply);
+        });
+    return exchange_rccl(ctx, comm, shard, d_rows, counts, d_replies, local_rc);
+}
 }  // namespace
 
 extern "C" int mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *shard, const uint64_t *d_rows, const uint64_t *counts,
@@ -360,14 +747,14 @@ extern "C" int mdbg_shard_exchange(mdbg_ctx *ctx, mdbg_comm *comm, mdbg_shard *s
     int local_rc = MDBG_OK;
     if (!shard || !counts || !d_replies) local_rc = set_error(ctx, MDBG_EINVAL, "mdbg_shard_exchange: null argument");
     static const uint64_t no_counts[64] = {0};
-    return exchange_impl(ctx, comm, shard, d_rows, counts ? counts : no_counts, d_replies, local_rc);
+    return exchange_any(ctx, comm, shard, d_rows, counts ? counts : no_counts, d_replies, local_rc);
 } MDBG_API_CATCH(ctx)
 
 extern "C" int mdbg_shard_abort(mdbg_ctx *ctx, mdbg_comm *comm, int code) try {
     if (!ctx || !comm) return set_error(ctx, MDBG_EINVAL, "mdbg_shard_abort: null context or communicator");
     static const uint64_t no_counts[64] = {0};
     const std::string keep = ctx->err;              // the message of the failure being reported stays the context's last error
-    const int rc = exchange_impl(ctx, comm, nullptr, nullptr, no_counts, nullptr, code < 0 ? code : MDBG_EINVAL);
+    const int rc = exchange_any(ctx, comm, nullptr, nullptr, no_counts, nullptr, code < 0 ? code : MDBG_EINVAL);
     const bool told = rc == (code < 0 ? code : MDBG_EINVAL);
     if (told) ctx->err = keep;
     return told ? MDBG_OK : rc;
@@ -389,3 +776,68 @@ extern "C" int mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, 
     MDBG_TRY(mdbg_shard_exchange(ctx, comm, sh.get(), d_rows, sent.data(), &d_replies));
     return mdbg_shard_finish(ctx, sh.get(), d_replies, min_abundance, out);
 } MDBG_API_CATCH(ctx)
+
+// ---- communicators ---------------------------------------------------------------------------------------------------
+namespace {
+int rccl_setup(mdbg_ctx *ctx, mdbg_comm *c, const uint8_t *id128) {
+    RcclApi *api = rccl_api();
+    if (!api->error.empty()) return set_error(ctx, MDBG_ENODEV, "%s", api->error.c_str());
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    MDBG_NCCL_CHECK(ctx, api, api->CommInitRank(&c->comm, c->n_ranks, id, c->rank));
+    return comm_finish_setup(ctx, api, c, "mdbg_comm_create");
+}
+
+int default_comm_mode() {
+    const char *e = getenv("MDBG_COMM_MODE");
+    if (!e || !*e) return MDBG_COMM_AUTO;
+    const std::string v(e);
+    if (v == "rccl") return MDBG_COMM_RCCL;
+    if (v == "peer") return MDBG_COMM_PEER;
+    return MDBG_COMM_AUTO;
+}
+}  // namespace
+
+extern "C" int mdbg_comm_create_mode(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, int mode, mdbg_comm **out) try {
+    if (!ctx || !id128 || !out || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_comm_create: bad argument (ranks 1..64)");
+    if (mode == MDBG_COMM_DEFAULT) mode = default_comm_mode();
+    if (mode != MDBG_COMM_RCCL && mode != MDBG_COMM_PEER && mode != MDBG_COMM_AUTO) return set_error(ctx, MDBG_EINVAL, "mdbg_comm_create_mode: unknown mode %d", mode);
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<mdbg_comm, void (*)(mdbg_comm *)> c(new mdbg_comm(), mdbg_comm_destroy);
+    c->rank = rank; c->n_ranks = n_ranks; c->owned = true; c->device = ctx->device;
+    if (mode == MDBG_COMM_PEER || mode == MDBG_COMM_AUTO) {
+        // every step of this is agreed among the ranks through the control block itself (a rank that cannot attach leaves the others
+        // waiting for it until the set-up deadline: they all come out of it on the same side), so "auto" needs nothing from RCCL
+        // unless the copies are not to be had
+        c->mode = MDBG_COMM_PEER;
+        int rc = peer_setup(ctx, c.get(), id128);
+        if (rc == MDBG_OK) rc = peer_self_test(ctx, c.get());
+        if (rc == MDBG_OK) { *out = c.release(); return MDBG_OK; }
+        if (mode == MDBG_COMM_PEER) return rc;
+        c->fallback_note = ctx->err;
+        MDBG_DBG(ctx, "mdbg_comm_create (auto): no peer copies (%s); RCCL", ctx->err.c_str());
+        peer_teardown(c.get());
+        c->broken = false;
+    }
+    c->mode = MDBG_COMM_RCCL;
+    MDBG_TRY(rccl_setup(ctx, c.get(), id128));
+    *out = c.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_comm_create(mdbg_ctx *ctx, const uint8_t *id128, int rank, int n_ranks, mdbg_comm **out) {
+    return mdbg_comm_create_mode(ctx, id128, rank, n_ranks, MDBG_COMM_DEFAULT, out);
+}
+
+extern "C" int mdbg_comm_mode(const mdbg_comm *c) { return c ? c->mode : MDBG_EINVAL; }
+
+extern "C" const char *mdbg_comm_note(const mdbg_comm *c) { return c ? c->fallback_note.c_str() : ""; }
+
+extern "C" void mdbg_comm_destroy(mdbg_comm *c) {
+    if (!c) return;
+    peer_teardown(c);
+    // a communicator an RCCL call failed on is aborted, not destroyed: ncclCommDestroy waits for operations that will never finish
+    if (c->owned && c->comm) (void)(c->broken ? rccl_api()->CommAbort(c->comm) : rccl_api()->CommDestroy(c->comm));
+    delete c;
+}

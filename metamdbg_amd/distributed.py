@@ -1,9 +1,10 @@
-"""Exchange steps of the sharded first pass: one process per GPU, torch.distributed for the bytes
-(backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU tensors in the tests).
+"""Exchange steps of the sharded first pass moved by torch.distributed (a HARNESS path: tests, MDBG_BENCH_EXCHANGE=torch;
+backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU tensors in the tests).  The product's exchange is inside the
+library: mdbg_comm_create_mode / mdbg_shard_exchange (csrc/multigpu.hip: peer copies or RCCL).
 
 Reads are sharded over the ranks; only the k-min-mer counts are global.  Keys are partitioned by
 owner rank (include/mdbg_hip.h, mdbg_shard_*), so the merge is
-    all-to-all   rows [hash_lo, hash_hi, count, packed vector...] -> owner     (exchange_by_owner)
+    all-to-all   rows [hash_lo, hash_hi, count] (3 x u64: vectors never travel) -> owner   (exchange_by_owner)
     all-to-all   one u64 global count per row back to the sender             (reply_to_senders)
 i.e. a reduce-scatter by key and its transpose.  xGMI is point-to-point, so an all-to-all keeps all
 7 links of every GPU busy; a dense all-reduce would need a common key order first and nothing is
@@ -57,146 +58,6 @@ def reply_to_senders(reply: torch.Tensor, recv_counts: list[int], sent_counts: l
     return out
 
 
-class PeerCopyExchange:
-    """The two all-to-alls of a sharded pass as PEER COPIES: no collective kernel, nothing that must be resident on a compute unit.
-
-    Every rank keeps two staging buffers on its GPU -- the rows it sends (grouped by owner) and the replies it gives -- and shares them once with
-    every other process (torch's CUDA IPC: hipIpcGetMemHandle / hipIpcOpenMemHandle underneath).  An exchange is then: write my rows into my
-    staging buffer; a host barrier; every owner PULLS its slice from every sender's buffer (``dst.copy_(peer_view)``: a device-to-device copy on
-    the owner's stream -- over xGMI between GPUs, the copy engines' work); the transpose for the replies.  The handshakes (the n x n counts, the
-    barriers) are host collectives on `group` (gloo): nothing on the device waits for a peer's kernel.  RCCL's device kernel cannot run beside
-    this repository's scan (ExchangeGate below); a copy needs no workgroup slot at all.  The staging buffers grow collectively when a step
-    needs more (every rank sees the whole count matrix, so every rank takes the same decision).
-
-    One instance per batch in flight; its calls are collective and must come in the same order on every rank (bench.py's turn-taking)."""
-
-    def __init__(self, device, row_words: int, group=None):
-        self.device, self.rw, self.group = torch.device(device), int(row_words), group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.S = self.R = None
-        self.cap_s = self.cap_r = 0
-        self.peer_S: dict = {}
-        self.peer_R: dict = {}
-        self._counts = None
-        self.shares = 0                    # how often the staging buffers were (re)shared
-
-    def _share(self, cap_s: int, cap_r: int) -> None:
-        import pickle
-        from multiprocessing.reduction import ForkingPickler
-        import torch.multiprocessing  # noqa: F401  (registers the tensor reductions with ForkingPickler)
-        self.peer_S.clear()
-        self.peer_R.clear()
-        self.S = torch.empty((cap_s, self.rw), dtype=torch.int64, device=self.device)
-        self.R = torch.empty((cap_r,), dtype=torch.int64, device=self.device)
-        self.cap_s, self.cap_r = cap_s, cap_r
-        self.shares += 1
-        if self.world == 1:
-            return
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-        # pickled the way torch.multiprocessing sends a tensor to another process: a handle, not the bytes (CUDA IPC for device memory, a name
-        # under /dev/shm for CPU tensors with the "file_system" sharing strategy)
-        mine = bytes(ForkingPickler.dumps((self.S, self.R)))
-        everyone = [None] * self.world
-        dist.all_gather_object(everyone, mine, group=self.group)
-        for r, blob in enumerate(everyone):
-            if r != self.rank:
-                self.peer_S[r], self.peer_R[r] = pickle.loads(blob)
-
-    def _sync(self) -> None:
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
-
-    def close(self) -> None:
-        """Collective: drop the views of the other processes' buffers, wait until everybody has, then free this rank's own (a producer
-        must outlive its consumers' mappings)."""
-        self.peer_S.clear()
-        self.peer_R.clear()
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-            torch.cuda.ipc_collect()
-        if self.world > 1:
-            dist.barrier(group=self.group)
-        self.S = self.R = None
-        self.cap_s = self.cap_r = 0
-
-    def self_test(self) -> None:
-        """A small exchange of known rows through the shared buffers (collective): raises if a slice or a reply came back wrong -- before a
-        job relies on peer copies between GPUs it has never used (bench.py falls back to RCCL when any rank fails this)."""
-        world, me = self.world, self.rank
-        counts = [3 + ((me + d) % 5) for d in range(world)]
-        n = sum(counts)
-        rows = torch.empty((n, self.rw), dtype=torch.int64)
-        at = 0
-        for d, c in enumerate(counts):
-            rows[at:at + c, 0], rows[at:at + c, 1] = me, d
-            rows[at:at + c, 2] = torch.arange(at, at + c)
-            at += c
-        mine, got = self.rows_to_owners(rows.to(self.device), counts)
-        m = mine.cpu()
-        good = m.shape[0] == sum(got) and bool((m[:, 1] == me).all())
-        at = 0
-        for r in range(world):
-            sl = m[at:at + got[r]]
-            first = sum(3 + ((r + d) % 5) for d in range(me))
-            good = good and got[r] == 3 + ((r + me) % 5) and bool((sl[:, 0] == r).all()) and bool((sl[:, 2] == torch.arange(first, first + got[r])).all())
-            at += got[r]
-        back = self.replies_to_senders((m[:, 0] * 1_000_003 + m[:, 2]).to(self.device), got, counts).cpu()
-        good = good and bool((back == me * 1_000_003 + torch.arange(n)).all())
-        if not good:
-            raise RuntimeError(f"peer-copy self-test failed on rank {me}")
-
-    def rows_to_owners(self, rows: torch.Tensor, counts: list[int]) -> tuple[torch.Tensor, list[int]]:
-        """rows: (sum(counts), rw) on this rank's GPU, grouped by owner.  Returns (the rows this rank owns, how many came from each rank)."""
-        world, me = self.world, self.rank
-        assert len(counts) == world and rows.shape[0] == sum(counts)
-        mine = torch.tensor(counts, dtype=torch.int64)
-        rows_of = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(rows_of, mine, group=self.group)
-        m = torch.stack(rows_of)                                   # m[r][d]: rows rank r holds for owner d
-        need_s, need_r = int(m.sum(1).max()), int(m.sum(0).max())
-        if need_s > self.cap_s or need_r > self.cap_r or self.S is None:
-            self._share(max(self.cap_s, need_s + need_s // 4 + 1024), max(self.cap_r, need_r + need_r // 4 + 1024))
-        n_sent = rows.shape[0]
-        if n_sent:
-            self.S[:n_sent].copy_(rows)
-        self._sync()
-        dist.barrier(group=self.group)                             # every rank's rows are in its staging buffer
-        got = [int(m[r][me]) for r in range(world)]
-        out = torch.empty((sum(got), self.rw), dtype=torch.int64, device=self.device)
-        at = 0
-        for r in range(world):
-            if got[r]:
-                src = self.S if r == me else self.peer_S[r]
-                first = int(m[r][:me].sum())
-                out[at:at + got[r]].copy_(src[first:first + got[r]])
-                at += got[r]
-        self._sync()
-        dist.barrier(group=self.group)                             # everybody has pulled: the staging buffers may be written again
-        self._counts = m
-        return out, got
-
-    def replies_to_senders(self, reply: torch.Tensor, got: list[int], sent: list[int]) -> torch.Tensor:
-        """reply: one u64 per received row, in the order received.  Returns one per SENT row, in the order sent."""
-        world, me, m = self.world, self.rank, self._counts
-        assert reply.shape[0] == sum(got)
-        if reply.shape[0]:
-            self.R[:reply.shape[0]].copy_(reply)
-        self._sync()
-        dist.barrier(group=self.group)                             # every owner's replies are in its staging buffer
-        out = torch.empty((sum(sent),), dtype=torch.int64, device=self.device)
-        at = 0
-        for d in range(world):
-            if sent[d]:
-                src = self.R if d == me else self.peer_R[d]
-                first = int(m[:me, d].sum())                       # owner d received the ranks' rows in rank order
-                out[at:at + sent[d]].copy_(src[first:first + sent[d]])
-            at += sent[d]
-        self._sync()
-        # (no barrier: an owner overwrites its replies only after the next exchange's first barrier, which a rank enters after this pull)
-        return out
-
-
 class ExchangeGate:
     """Several batches in flight on one GPU of an N > 1 job: an exchange over RCCL does not run beside a scan of another batch.
 
@@ -235,16 +96,21 @@ class ExchangeGate:
             return
         import time
         t0 = time.perf_counter()
-        with self._cv:
-            self._exchanges += 1                 # from here on no new scan starts
-            self._cv.wait_for(lambda: self._scans == 0)
-            self.waited_ms += (time.perf_counter() - t0) * 1e3
+        entered = False
         try:
-            yield
-        finally:
             with self._cv:
-                self._exchanges -= 1
-                self._cv.notify_all()
+                self._exchanges += 1             # from here on no new scan starts
+                entered = True
+                try:
+                    self._cv.wait_for(lambda: self._scans == 0)
+                finally:
+                    self.waited_ms += (time.perf_counter() - t0) * 1e3
+            yield
+        finally:                                 # also when the wait itself was interrupted: a count left up would hold every scan for good
+            if entered:
+                with self._cv:
+                    self._exchanges -= 1
+                    self._cv.notify_all()
 
 
 class PeerFailure(RuntimeError):

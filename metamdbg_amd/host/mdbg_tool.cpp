@@ -1209,10 +1209,17 @@ int run_graph(int argc, char **argv) {
         for (int r = 0; r < G; r++) {
             th.emplace_back([&, r] {
                 mdbg_ctx *ctx = nullptr;
-                if (mdbg_create(r, &ctx) != MDBG_OK) die(std::string("mdbg_create(device ") + std::to_string(r) + "): " + mdbg_last_error(nullptr));
+                // (MDBG_TOOL_SHARE_GPU=1, tests: every rank on device 0 -- the G-rank job on a one-GPU box; the exchange then runs as peer
+                // copies between the ranks' staging buffers on that device, RCCL refuses two ranks per device)
+                const int dev = getenv("MDBG_TOOL_SHARE_GPU") ? 0 : r;
+                if (mdbg_create(dev, &ctx) != MDBG_OK) die(std::string("mdbg_create(device ") + std::to_string(dev) + "): " + mdbg_last_error(nullptr));
                 ctxs[(size_t)r] = ctx;
                 mdbg_comm *comm = nullptr;
+                // MDBG_COMM_MODE = peer | rccl | auto (default auto: peer copies between the devices of this process, RCCL if they fail their self-test)
                 check_on(ctx, mdbg_comm_create(ctx, id, r, G, &comm), "mdbg_comm_create");
+                if (r == 0 && getenv("MDBG_TRACE"))
+                    fprintf(stderr, "[mdbg_tool] exchange among %d ranks: %s%s%s\n", G, mdbg_comm_mode(comm) == MDBG_COMM_PEER ? "peer copies" : "RCCL",
+                            *mdbg_comm_note(comm) ? " (no peer copies: " : "", *mdbg_comm_note(comm) ? (std::string(mdbg_comm_note(comm)) + ")").c_str() : "");
                 graph_rank(ctx, comm, r, P, a, mins, offs, nReads * (size_t)r / (size_t)G, nReads * (size_t)(r + 1) / (size_t)G, in, parts[(size_t)r]);
                 mdbg_comm_destroy(comm);
             });

@@ -142,5 +142,8 @@ int mdbg_shard_keep(mdbg_ctx *, mdbg_shard *, const uint64_t *, mdbg_table **) {
 void mdbg_shard_free(mdbg_shard *s) { delete s; }
 int mdbg_comm_unique_id(uint8_t *) { return MDBG_ENODEV; }
 int mdbg_comm_create(mdbg_ctx *, const uint8_t *, int, int, mdbg_comm **) { return MDBG_ENODEV; }
+int mdbg_comm_create_mode(mdbg_ctx *, const uint8_t *, int, int, int, mdbg_comm **) { return MDBG_ENODEV; }
+int mdbg_comm_mode(const mdbg_comm *) { return MDBG_COMM_RCCL; }
+const char *mdbg_comm_note(const mdbg_comm *) { return ""; }
 void mdbg_comm_destroy(mdbg_comm *c) { delete c; }
 }

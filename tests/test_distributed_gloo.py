@@ -242,64 +242,3 @@ def test_local_failures_reach_the_peers_world2():
     for i in (1, 3, 5):                 # the exchanges in between: each rank gets back the first word of the rows it sent
         assert s0[i] == [0, 3] and s1[i] == [100, 103]
     assert res[0][1] == res[1][1] == b"xyz" * 5
-
-
-# ---- the same two all-to-alls as PEER COPIES (metamdbg_amd.distributed.PeerCopyExchange): every rank's staging buffers shared with the
-# other processes once, owners pull their slices.  On the GPU box the buffers are device memory shared by CUDA IPC (tests/test_gpu_multirank.py);
-# here they are CPU tensors in shared memory -- the index arithmetic (ragged counts, empty slices, growth of the buffers) is the same ----
-def _worker_peer_copies(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    mp.set_sharing_strategy("file_system")               # handles that unrelated processes can open (names under /dev/shm)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from metamdbg_amd import distributed as D
-    px = D.PeerCopyExchange("cpu", 3)
-    ok = True
-    shares = []
-    for step, scale in enumerate([5, 0, 40, 7, 4000]):     # growing and shrinking steps: the buffers are shared again only when they must grow
-        rng = np.random.default_rng(100 * step + rank)
-        counts = [int(x) for x in rng.integers(0, scale + 1, world)]
-        if step == 3:
-            counts[(rank + 1) % world] = 0                # an empty slice between two ranks
-        n = sum(counts)
-        # row i of this rank for owner d: [rank, d, running index] -- the owner can tell where every row came from
-        rows = np.zeros((n, 3), dtype=np.int64)
-        at = 0
-        for d, c in enumerate(counts):
-            rows[at:at + c, 0], rows[at:at + c, 1], rows[at:at + c, 2] = rank, d, np.arange(at, at + c)
-            at += c
-        mine, got = px.rows_to_owners(torch.from_numpy(rows.copy()), counts)
-        m = mine.numpy()
-        ok = ok and len(m) == sum(got) and (m[:, 1] == rank).all()
-        at = 0
-        for r in range(world):                            # the slices arrive in rank order, each in the order it was sent
-            sl = m[at:at + got[r]]
-            ok = ok and (sl[:, 0] == r).all() and (np.diff(sl[:, 2]) == 1).all()
-            at += got[r]
-        reply = torch.from_numpy((m[:, 0] * 1_000_000 + m[:, 2] + 7 * rank * 0).astype(np.int64))     # names the row it answers
-        back = px.replies_to_senders(reply, got, counts).numpy()
-        ok = ok and len(back) == n and (back == rank * 1_000_000 + np.arange(n)).all()
-        shares.append(px.shares)
-    px.close()
-    q.put((rank, bool(ok), shares))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_peer_copy_exchange(world):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_peer_copies, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(r[1] for r in res), res
-    assert all(r[2] == res[0][2] for r in res)               # every rank shared its buffers at the same steps
-    assert res[0][2][0] == 1 and res[0][2][1] == 1 and res[0][2][-1] > res[0][2][1]

@@ -1,5 +1,5 @@
-"""Two, four and eight real ranks of bench.py's sharded step on ONE GPU (every rank on device 0, exchanges staged through the host with
-gloo -- RCCL refuses two ranks per device): the whole multi-rank orchestration (shard begin / reduce / finish, the two
+"""Two, four and eight real ranks of bench.py's sharded step on ONE GPU (every rank on device 0; torch.distributed on gloo -- RCCL refuses two
+ranks per device -- the rows moved by the library's peer copies or, staged through the host, by torch.distributed): the whole multi-rank orchestration (shard begin / reduce / finish, the two
 all-to-alls, two batches in flight taking turns on the communicator) must give, summed over the ranks, exactly the
 table of one rank over the same reads."""
 from __future__ import annotations
@@ -17,7 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(extra_env: dict, args: list[str], nproc: int | None, expect_failure: bool = False) -> dict:
+    """One bench.py run; returns its FULL result (--detail) after checking that what it printed is the one compact line of it."""
+    import tempfile
     env = dict(os.environ, **extra_env)
+    detail = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
+    args = list(args) + ["--detail", detail]
     cmd = [sys.executable]
     if nproc:
         with socket.socket() as s:
@@ -28,7 +32,15 @@ def _bench(extra_env: dict, args: list[str], nproc: int | None, expect_failure: 
     cmd += [os.path.join(ROOT, "bench.py")] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert (out.returncode != 0) == expect_failure, out.stderr[-2000:]
-    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[-500:]
+    line = json.loads(lines[0])
+    with open(detail) as f:
+        full = json.load(f)
+    os.unlink(detail)
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["n_gpus"] == full["n_gpus"]
+    assert (line["config"].get("exchange") or {}).get("transport") == (full["config"].get("exchange") or {}).get("transport")
+    return full
 
 
 @pytest.mark.parametrize("nproc,in_flight", [(2, 1), (2, 2), (2, 3), (4, 2), (8, 2)])
@@ -38,12 +50,13 @@ def test_ranks_equal_one(nproc, in_flight):
     n = 40_000
     common = ["--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
     one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
-    # (the default exchange of an N > 1 job is peer copies; the first case keeps torch.distributed's all-to-all, staged through the host by gloo, covered)
+    # (the default exchange of an N > 1 job is the library's, which takes peer copies here: RCCL refuses two ranks on one device; the
+    # first case keeps torch.distributed's all-to-all, staged through the host by gloo, covered)
     env = {"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo"}
     if (nproc, in_flight) == (2, 1):
         env["MDBG_BENCH_EXCHANGE"] = "torch"
     many = _bench(env, ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
-    assert many["config"]["exchange"]["path"].startswith("torch.distributed" if "MDBG_BENCH_EXCHANGE" in env else "peer copies")
+    assert many["config"]["exchange"]["transport"] == ("torch" if "MDBG_BENCH_EXCHANGE" in env else "peer")
     assert many["n_gpus"] == nproc and many["scaling"] == "weak"
     assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
     assert many["config"]["solid"] == one["config"]["solid"] > 0
@@ -63,7 +76,7 @@ def test_ranks_equal_one_with_the_exchange_gate(in_flight):
     n, nproc = 40_000, 4
     common = ["--steps", "4", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
     one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
-    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE_GATE": "1"},
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE_GATE": "1", "MDBG_BENCH_EXCHANGE": "torch"},
                   ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
     assert many["config"]["exchange"]["gate"] is True and many["config"]["exchange"]["exchanges_timed"] == nproc * 4
     assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0
@@ -72,16 +85,18 @@ def test_ranks_equal_one_with_the_exchange_gate(in_flight):
 
 @pytest.mark.parametrize("nproc,in_flight", [(2, 2), (4, 3), (8, 2)])
 def test_ranks_equal_one_by_peer_copies(nproc, in_flight):
-    """MDBG_BENCH_EXCHANGE=ipc: the two all-to-alls as peer copies (metamdbg_amd.distributed.PeerCopyExchange) -- every rank's staging buffers
-    shared with the other processes by CUDA IPC, owners pull their slices device to device, handshakes on the host.  Real processes, real IPC
+    """MDBG_COMM_MODE=peer: the two all-to-alls as peer copies INSIDE THE LIBRARY (csrc/multigpu.hip, mdbg_comm_create_mode + mdbg_shard_exchange):
+    every rank's staging buffers shared with the other processes by hipIpcGetMemHandle / hipIpcOpenMemHandle, owners pull their slices
+    device to device on one stream per peer, hand-shakes through the shared control block (csrc/peerlink.hpp).  Real processes, real IPC
     handles (all on GPU 0 here; between GPUs the same copies cross xGMI); the union of the shares must be the table of one rank."""
     n = 40_000
     common = ["--steps", "4", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", str(in_flight)]
     one = _bench({}, ["--gpus", "1", "--reads", str(nproc * n)] + common, None)
-    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE": "ipc"},
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_COMM_MODE": "peer"},
                   ["--gpus", str(nproc), "--reads", str(n)] + common, nproc)
     ex = many["config"]["exchange"]
-    assert ex["path"].startswith("peer copies") and ex["gate"] is False and ex["staging_shares"] >= 1 and ex["exchanges_timed"] == nproc * 4
+    assert ex["transport"] == "peer" and ex["path"].startswith("library: peer copies") and ex["gate"] is False and ex["exchanges_timed"] == nproc * 4
+    assert ex["wire_bytes_per_step"] > 0 and ex["comm_note"] is None
     assert many["config"]["kminmer_records"] == one["config"]["kminmer_records"] > 0 and many["config"]["solid"] == one["config"]["solid"]
     par = many["parity"]
     assert par["table_equal"] and par["reads"] == nproc * n and par["abundance_checksum_equal"] and par["vector_sum_equal"]
@@ -90,9 +105,23 @@ def test_ranks_equal_one_by_peer_copies(nproc, in_flight):
 def test_peer_copies_with_a_corrupted_reply_fail_the_run():
     n = 40_000
     common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "2"]
-    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_BENCH_EXCHANGE": "ipc", "MDBG_BENCH_CORRUPT_REPLY": "1"},
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_COMM_MODE": "peer", "MDBG_BENCH_CORRUPT_REPLY": "1"},
                   ["--gpus", "2", "--reads", str(n)] + common, 2, expect_failure=True)
+    assert many["config"]["exchange"]["transport"] == "peer"
     assert not many["parity"]["table_equal"] and many["parity"]["minimizers_equal"]
+
+
+def test_auto_falls_back_to_the_next_transport_on_every_rank(tmp_path):
+    """MDBG_COMM_MODE=auto with the control block out of reach (MDBG_PEER_TEST_NO_SHM: rank 1 cannot attach; the others wait for it until the
+    set-up deadline): every rank gives up the peer copies TOGETHER and tries RCCL, which refuses ranks that share a device -- so the job, all
+    ranks agreeing once more, moves its rows with torch.distributed, says so, and its tables still add up."""
+    n = 40_000
+    common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "1"]
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_COMM_MODE": "auto", "MDBG_PEER_TEST_NO_SHM": "1", "MDBG_PEER_SETUP_TIMEOUT_S": "3"},
+                  ["--gpus", "2", "--reads", str(n)] + common, 2)
+    ex = many["config"]["exchange"]
+    assert ex["transport"] == "torch" and "library exchange unavailable" in ex["comm_note"]
+    assert many["parity"]["table_equal"]
 
 
 def test_strong_scaling_over_one_read_set():
@@ -122,13 +151,16 @@ def test_ranks_with_a_corrupted_reply_fail_the_run(nproc):
     assert not (par["abundance_checksum_equal"] and par["sum_abundance_equal"] and par["solid_equal"] and par["records_equal"])
 
 
-def test_a_rank_that_fails_in_the_reduction_ends_the_job_of_eight():
+@pytest.mark.parametrize("exchange", ["library", "torch"])
+def test_a_rank_that_fails_in_the_reduction_ends_the_job_of_eight(exchange):
     """MDBG_BENCH_FAIL_RANK=5: rank 5 of 8 fails summing the rows it owns (the second phase of an exchange) in the verification step.
-    Every rank hears of it in the agreement that follows (metamdbg_amd/distributed.py agree / guarded; mdbg_shard_exchange does the
-    same inside the library) and the job ends non-zero within seconds -- nobody waits for replies that will never come."""
+    Every rank hears of it in the agreement that follows -- the status words of the library's peer copies (csrc/multigpu.hip peer_phase),
+    or metamdbg_amd/distributed.py agree / guarded on the torch.distributed path -- and the job ends non-zero within seconds: nobody
+    waits for replies that will never come."""
     import time
     n = 20_000
-    env = dict(os.environ, MDBG_BENCH_SHARE_GPU="1", MDBG_BENCH_BACKEND="gloo", MDBG_BENCH_FAIL_RANK="5", MDBG_BENCH_DEADLINE_S="200")
+    env = dict(os.environ, MDBG_BENCH_SHARE_GPU="1", MDBG_BENCH_BACKEND="gloo", MDBG_BENCH_FAIL_RANK="5", MDBG_BENCH_DEADLINE_S="200", MDBG_BENCH_EXCHANGE=exchange,
+               MDBG_COMM_MODE="peer")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -137,30 +169,46 @@ def test_a_rank_that_fails_in_the_reduction_ends_the_job_of_eight():
     t0 = time.time()
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert out.returncode != 0 and time.time() - t0 < 200
-    assert "test failure on rank 5" in out.stderr and "rank 5 failed summing the rows it owns" in out.stderr, out.stderr[-3000:]
-    assert "deadline" not in out.stderr                       # ended by the protocol, not by the watchdog
+    own = "test failure in the reduction" if exchange == "library" else "test failure on rank 5"
+    assert own in out.stderr and "rank 5 failed summing the rows it owns" in out.stderr, out.stderr[-3000:]
+    assert "deadline" not in out.stderr and "did not arrive" not in out.stderr       # ended by the protocol, not by a watchdog
 
 
-def test_library_rccl_exchange_two_gpus(tmp_path):
-    """Two ranks, two GPUs, RCCL over xGMI inside the library (mdbg_comm_create + mdbg_kminmer_count_first_sharded): the union of
-    the two tables equals the single-GPU table of all reads.  Skipped on a box with one GPU (one rank: tests/test_gpu_parity.py::
-    test_library_exchange_one_rank; RCCL refuses two ranks on one device)."""
+def _library_exchange_processes(tmp_path, n_ranks: int, mode: str, share: bool, n_total: int = 4000):
     import numpy as np
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
     from metamdbg_amd import capi, formats, synth
-    n_total = 4000
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank.py"), str(r), "2", str(tmp_path / "id"),
-                               str(tmp_path / f"rec{r}.npy"), str(n_total)], cwd=ROOT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "comm_rank.py"), str(r), str(n_ranks), str(tmp_path / "id"),
+                               str(tmp_path / f"rec{r}.npy"), str(n_total), mode, "1" if share else "0"], cwd=ROOT) for r in range(n_ranks)]
     for p in procs:
         assert p.wait(timeout=240) == 0
-    rec = np.concatenate([np.load(tmp_path / f"rec{r}.npy") for r in range(2)])
+    rec = np.concatenate([np.load(tmp_path / f"rec{r}.npy") for r in range(n_ranks)])
+    modes = {open(tmp_path / f"rec{r}.npy.mode").read() for r in range(n_ranks)}
     ctx = capi.Context(0)
     spec = synth.hifi_spec(n_total, seed=23, read_len=6000, coverage=25.0)
     corr = ctx.purge_palindromes(ctx.scan(ctx.reads_synthetic(spec), K=15, density=0.005, hpc=True), 4, 100)
     one, _ = ctx.kminmer_count_first(corr, 4, 0).to_host()
     assert np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(one))
+    return modes
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_library_peer_exchange_processes_sharing_one_gpu(tmp_path, n_ranks):
+    """The library's peer-copy exchange through the C ABI alone -- no torch.distributed anywhere: n processes, the communicator id in a
+    file, mdbg_comm_create_mode(MDBG_COMM_PEER) + mdbg_kminmer_count_first_sharded three times over.  Staging buffers cross the process
+    boundary by hipIpcGetMemHandle / hipIpcOpenMemHandle (all ranks on GPU 0 here); the union of the shares is the single-GPU table."""
+    assert _library_exchange_processes(tmp_path, n_ranks, "peer", share=True) == {"peer"}
+
+
+@pytest.mark.parametrize("mode", ["rccl", "peer", "auto"])
+def test_library_exchange_two_gpus(tmp_path, mode):
+    """Two ranks, two GPUs, the exchange over xGMI inside the library -- RCCL send / receive groups, or peer copies between the
+    two devices -- (mdbg_comm_create_mode + mdbg_kminmer_count_first_sharded): the union of the two tables equals the single-GPU
+    table of all reads.  Skipped on a box with one GPU (one rank: tests/test_gpu_parity.py::test_library_exchange_one_rank; several
+    ranks on one device, peer copies only: above)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    assert _library_exchange_processes(tmp_path, 2, mode, share=False) == {"rccl" if mode == "rccl" else "peer"}
 
 
 def test_two_ranks_multik_equal_one(tmp_path):

@@ -846,16 +846,18 @@ def test_edge_indexes_at_first_k_plus_one_vs_reference_log(ctx, name):
     assert uedges.info()["n_records"] == log["n_unitig_edges"]
 
 
-def test_library_exchange_one_rank(ctx, orc):
-    """The exchange inside the library (mdbg_comm_*, mdbg_shard_exchange, mdbg_kminmer_count_first_sharded: RCCL send / receive
-    groups on the context's stream) with a communicator of one rank: every row is sent to and received from the rank itself
-    through RCCL, and the table must be the single-GPU table.  (Two ranks on two GPUs: tests/test_gpu_multirank.py.)"""
+@pytest.mark.parametrize("mode", ["rccl", "peer", "auto"])
+def test_library_exchange_one_rank(ctx, orc, mode):
+    """The exchange inside the library (mdbg_comm_create_mode, mdbg_shard_exchange, mdbg_kminmer_count_first_sharded) over either
+    transport -- RCCL send / receive groups on the context's stream, or peer copies with their shared control block, self-test and
+    status phases -- with a communicator of one rank: the table must be the single-GPU table.  (More ranks: tests/test_gpu_multirank.py.)"""
     from metamdbg_amd import capi
     spec = synth.hifi_spec(3000, seed=17, read_len=6000, coverage=25.0)
     reads = ctx.reads_synthetic(spec)
     corr = ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=True), 4, 100)
     rec0, vec0 = ctx.kminmer_count_first(corr, 4, 0).to_host()
-    comm = ctx.comm_create(capi.Context.comm_unique_id(), 0, 1)
+    comm = ctx.comm_create(capi.Context.comm_unique_id(), 0, 1, mode)
+    assert comm.mode == ("rccl" if mode == "rccl" else "peer") and comm.note == ""
     try:
         for min_ab in (0, 2):
             exp_rec, exp_vec = (rec0, vec0) if min_ab == 0 else ctx.kminmer_count_first(corr, 4, min_ab).to_host()
@@ -1083,7 +1085,8 @@ def test_table_checksum_is_the_references_formula(ctx):
         assert table.checksum() == exp and len(rec) > 1000
 
 
-def test_exchange_failures_are_reported_and_leave_the_communicator_usable(ctx):
+@pytest.mark.parametrize("mode", ["rccl", "peer"])
+def test_exchange_failures_are_reported_and_leave_the_communicator_usable(ctx, mode):
     """A rank that fails locally inside mdbg_shard_exchange -- before the counts travel, allocating the receive buffers, in the
     owner's reduction (test_exchange_fail_phase 1 / 2 / 3) -- still takes part in the small agreement collectives, returns its own
     error, and leaves no RCCL group open: the next exchange on the same communicator works and gives the single-GPU table.
@@ -1095,10 +1098,10 @@ def test_exchange_failures_are_reported_and_leave_the_communicator_usable(ctx):
     corr = ctx.purge_palindromes(ctx.scan(ctx.reads_synthetic(spec), K=15, density=0.005, hpc=True), 4, 100)
     want = ctx.kminmer_count_first(corr, 4, 0)
     want_sum, want_info = want.checksum(), want.info()
-    comm = ctx.comm_create(capi.Context.comm_unique_id(), 0, 1)
+    comm = ctx.comm_create(capi.Context.comm_unique_id(), 0, 1, mode)
     try:
         st0 = comm.stats()
-        assert (st0["rank"], st0["n_ranks"], st0["rccl_ranks"], st0["exchanges"]) == (0, 1, 1, 0)
+        assert (st0["rank"], st0["n_ranks"], st0["rccl_ranks"], st0["exchanges"], st0["mode"]) == (0, 1, 1 if mode == "rccl" else 0, 0, mode)
         for phase, code in ((1, -1), (2, -3), (3, -4)):
             ctx.set_option("test_exchange_fail_phase", phase)
             sh = ctx.shard_begin(corr, 4, 1)

@@ -35,6 +35,7 @@ def run(exe, *args, env=None):
         e.update(env)
     r = subprocess.run([exe, *args], capture_output=True, text=True, env=e, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
+    return r
 
 
 def read_selection(exe, tmp, extra=(), env=None):
@@ -332,25 +333,29 @@ def test_handover_into_reference_graph_stage(tmp_path, kind):
     assert checksums(t_ref) == checksums(t_hyb) and len(checksums(t_ref)) >= 6
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
-def test_tool_graph_through_the_library_exchange(tmp_path, gpus):
-    """`mdbg_tool graph --gpus G`: contiguous read ranges per rank, one context and one host thread per device, the exchange
+@pytest.mark.parametrize("gpus,mode", [(1, "auto"), (2, "auto"), (4, "peer"), (8, "peer"), (2, "rccl")])
+def test_tool_graph_through_the_library_exchange(tmp_path, gpus, mode):
+    """`mdbg_tool graph --gpus G`: contiguous read ranges per rank, one context and one host thread per rank, the exchange
     inside the library (mdbg_comm_create, mdbg_kminmer_count_first_sharded; mdbg_shard_from_table / _exchange / _keep at k >
-    firstK).  G = 1 runs the same code with a communicator of one rank (MDBG_TOOL_SHARDED=1: what a one-GPU box can exercise;
-    G = 2 needs two GPUs).  The tables must be the reference's: first pass (hifi_200) and k = 5, 6, 9 of the reference's own
-    multi-k loop (hifi_multik)."""
+    firstK).  G = 1 runs the same code with a communicator of one rank (MDBG_TOOL_SHARDED=1).  On a box with fewer than G GPUs
+    the ranks share device 0 (MDBG_TOOL_SHARE_GPU=1) and the rows move as PEER COPIES between the ranks' staging buffers -- the
+    library's own transport (MDBG_COMM_MODE auto / peer), threads of one process here; RCCL needs a GPU per rank (skipped without).
+    The tables must be the reference's: first pass (hifi_200) and k = 5, 6, 9 of the reference's own multi-k loop (hifi_multik)."""
     import shutil
     import torch
     from tests import multik_fixture as mk
+    env = {"MDBG_TOOL_SHARDED": "1", "MDBG_COMM_MODE": mode, "MDBG_TRACE": "1"}
     if gpus > torch.cuda.device_count():
-        pytest.skip(f"needs {gpus} GPUs")
-    env = {"MDBG_TOOL_SHARDED": "1"}
+        if mode == "rccl":
+            pytest.skip(f"RCCL needs {gpus} GPUs")
+        env["MDBG_TOOL_SHARE_GPU"] = "1"
     m = H.load_manifest("hifi_200")
     tmp = make_tmp(tmp_path / "first", formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4,
                                                           hpc=True, data_type=0), ["unused"])
     for name in ("read_data_corrected.txt", "read_stats.txt"):
         shutil.copy(os.path.join(H.GOLDEN, "hifi_200", name), os.path.join(tmp, name))
-    run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass", "--gpus", str(gpus), env=env)
+    r = run(TOOL, "graph", tmp, "--threads", "1", "--min-abundance", "0", "--firstpass", "--gpus", str(gpus), env=env)
+    assert f"exchange among {gpus} ranks: {'RCCL' if mode == 'rccl' else 'peer copies'}" in r.stderr, r.stderr[-1500:]
     exp_ab = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
     assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
     exp_v = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
