@@ -322,14 +322,15 @@ __global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t
     if (s < cap) t.slots[s].val = min_ab; else t.exc_val[s - cap] = min_ab;
 }
 
-// abundance of every (k-1)-window along the sequences (getPrevAbundances, graph/CreateMdbg.hpp:1240-1265)
-__global__ __launch_bounds__(256) void prev_abundance_kernel(SeqView s /* instances of size k-1 */, uint32_t km1, TableView prev,
-                                                             uint32_t *out) {
+// abundance of every (k-1)-window along the sequences (getPrevAbundances, graph/CreateMdbg.hpp:1240-1265); the previous table in
+// either form (TableView: one 32-byte slot per key; BucketView: three keys per 64-byte sector, table.hpp)
+template <typename View>
+__global__ __launch_bounds__(256) void prev_abundance_kernel(SeqView s /* instances of size k-1 */, uint32_t km1, View prev, uint32_t *out) {
     for_each_instance(s, [&](uint32_t, uint64_t g, const uint32_t *m) {
         uint64_t hi, lo;
         window_hash_uniform(m, km1, hi, lo);
         uint32_t v;
-        out[g] = table_lookup(prev, lo, hi, v) ? v : 1u;
+        out[g] = key_lookup(prev, lo, hi, v) ? v : 1u;
     });
 }
 
@@ -345,6 +346,78 @@ __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, co
         window_hash_uniform(m, k, hi, lo);
         table_insert_once(t, lo, hi, a);
     }, t.poll_overflow ? t.overflow : nullptr);
+}
+
+// the same into a bucket table; rep_base + the flat index of the window's first minimizer names the instance that published the key
+// (kept when the table keeps representatives: k = firstK + 1 writes the vectors of its rows)
+__global__ __launch_bounds__(256) void index_insert_b_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
+                                                             uint32_t k, BucketView t, uint64_t rep_base) {
+    for_each_instance(s, [&](uint32_t r, uint64_t g, const uint32_t *m) {
+        uint64_t j = inst_off_km1[r] + (g - s.inst_off[r]);
+        uint32_t a0 = prev_ab[j], a1 = prev_ab[j + 1];
+        uint32_t a = a0 < a1 ? a0 : a1;
+        if (a <= 1u) return;
+        uint64_t hi, lo;
+        window_hash_uniform(m, k, hi, lo);
+        bucket_insert_once(t, lo, hi, a, (uint32_t)(rep_base + (uint64_t)(m - s.mins)));
+    }, t.side.poll_overflow ? t.side.overflow : nullptr);
+}
+
+// which entries of a bucket table are rows (every occupied one: only abundances above 1 were inserted), and how many there are
+__global__ __launch_bounds__(256) void bucket_flag_kernel(BucketView t, uint32_t *flag) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = t.nb * BUCKET_WAYS;
+    if (e >= n + TABLE_EXC_CAP) return;
+    bool occ;
+    if (e < n) occ = t.b[e / BUCKET_WAYS].lo[e % BUCKET_WAYS] != 0ull;
+    else occ = (uint32_t)(e - n) < *t.side.exc_n;
+    flag[e] = occ ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void bucket_emit_kernel(BucketView t, const uint32_t *flag, const uint64_t *pos, SeqView a, SeqView b, RowOut o) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = t.nb * BUCKET_WAYS;
+    if (e >= n + TABLE_EXC_CAP || !flag[e]) return;
+    const uint64_t row = pos[e];
+    uint32_t rep = 0;
+    if (e < n) {
+        const KeyBucket &B = t.b[e / BUCKET_WAYS];
+        const uint32_t j = (uint32_t)(e % BUCKET_WAYS);
+        o.lo[row] = B.lo[j]; o.hi[row] = B.hi[j]; o.ab[row] = B.val[j];
+        if (o.vec) rep = t.rep[e];
+    } else {
+        const uint32_t i = (uint32_t)(e - n);
+        o.lo[row] = t.side.exc_lo[i]; o.hi[row] = t.side.exc_hi[i]; o.ab[row] = t.side.exc_val[i]; rep = t.side.exc_rep[i];
+    }
+    if (o.vec) write_instance_vector(a, b, rep, o.k, o.vec + row * o.k);
+}
+
+// the rows of a finished table into a bucket table (abundance 1 skipped as loadRefinedAbundances does, graph/CreateMdbg.cpp:3445)
+__global__ __launch_bounds__(256) void bucket_rows_insert_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *ab, uint64_t n,
+                                                                 int skip_one, BucketView t) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (skip_one && ab[i] == 1u) return;
+    bucket_upsert_set(t, lo[i], hi[i], ab[i]);
+}
+
+// every key of a one-slot table (a previous table loaded from records, perhaps overlaid with unitig abundances) with its value
+__global__ __launch_bounds__(256) void bucket_from_table_kernel(TableView src, uint64_t cap, BucketView t) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < cap) {
+        const TableSlot &sl = src.slots[s];
+        if (sl.lo != 0ull) bucket_upsert_set(t, sl.lo, sl.hi, sl.val);
+    } else if (s < cap + TABLE_EXC_CAP) {
+        const uint32_t i = (uint32_t)(s - cap);
+        if (i < *src.exc_n) bucket_upsert_set(t, src.exc_lo[i], src.exc_hi[i], src.exc_val[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void table_occupied_kernel(TableView t, uint64_t cap, uint32_t *occ_count) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool occ = s < cap ? t.slots[s].lo != 0ull : (s < cap + TABLE_EXC_CAP && (uint32_t)(s - cap) < *t.exc_n);
+    const int n = __syncthreads_count(occ);
+    if (threadIdx.x == 0 && n) atomicAdd(&occ_count[blockIdx.x % TABLE_OCC_WAYS], (uint32_t)n);
 }
 
 // ---- prev tables ---------------------------------------------------------------------------------------
@@ -715,6 +788,7 @@ extern "C" int mdbg_prev_overlay_unitigs(mdbg_ctx *ctx, mdbg_table *prev, const 
     if (ix.total)
         hipLaunchKernelGGL(overlay_kernel, dim3(grid_for(ix.total, 256)), dim3(256), 0, ctx->stream, sv, k_prev, d_ab.p, prev->lookup->view());
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    prev->image.reset();                 // (made again, from the overlaid table, by the pass that reads it)
     return prev->lookup->check_overflow(ctx);
 } MDBG_API_CATCH(ctx)
 
@@ -725,12 +799,88 @@ static int prev_view(mdbg_ctx *ctx, const mdbg_table *prev, TableView &pv) {
     return MDBG_OK;
 }
 
+// the previous table in its compact form: what the index pass that built it left behind, or made here -- from the one-slot table
+// when there is one (mdbg_prev_from_records, perhaps overlaid: its values, zeros included), else from the rows (abundance 1 skipped)
+static int prev_image(mdbg_ctx *ctx, const mdbg_table *prev_c, BucketView &pv) {
+    if (!prev_c) return set_error(ctx, MDBG_EINVAL, "previous table is null");
+    mdbg_table *prev = const_cast<mdbg_table *>(prev_c);
+    if (!prev->image) {
+        std::unique_ptr<BucketTable> img(new BucketTable());
+        if (prev->lookup) {
+            DeviceTable &src = *prev->lookup;
+            const uint64_t nslots = src.cap + TABLE_EXC_CAP;
+            MDBG_HIP_CHECK(ctx, hipMemsetAsync(src.ctl.p + 4, 0, TABLE_OCC_WAYS * 4, ctx->stream));
+            hipLaunchKernelGGL(table_occupied_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, src.view(), src.cap, src.view().occ);
+            uint64_t n_keys = 0;
+            MDBG_TRY(src.occupied(ctx, &n_keys));
+            for (double load = 0.75;; load *= 0.5) {
+                MDBG_TRY(img->init(ctx, BucketTable::buckets_for(n_keys + 64, load), false));
+                LaunchTimer timer(ctx, "kminmer_prev_image");
+                hipLaunchKernelGGL(bucket_from_table_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, src.view(), src.cap, img->view());
+                const int o = img->overflowed(ctx);
+                if (o < 0) return o;
+                if (!o) break;
+                if (load < 0.05) return set_error(ctx, MDBG_ERANGE, "previous table: bucket table overflow");
+            }
+        } else {
+            for (double load = 0.75;; load *= 0.5) {
+                MDBG_TRY(img->init(ctx, BucketTable::buckets_for(prev->n_records + 64, load), false));
+                if (prev->n_records) {
+                    LaunchTimer timer(ctx, "kminmer_prev_image");
+                    hipLaunchKernelGGL(bucket_rows_insert_kernel, dim3(grid_for(prev->n_records, 256)), dim3(256), 0, ctx->stream,
+                                       prev->d_lo.p, prev->d_hi.p, prev->d_ab.p, prev->n_records, 1, img->view());
+                }
+                const int o = img->overflowed(ctx);
+                if (o < 0) return o;
+                if (!o) break;
+                if (load < 0.05) return set_error(ctx, MDBG_ERANGE, "previous table: bucket table overflow");
+            }
+        }
+        prev->image = std::move(img);
+    }
+    pv = prev->image->view();
+    return MDBG_OK;
+}
+
+// rows of a bucket table into a new mdbg_table (every occupied entry is a row); with vectors when the table kept representatives
+static int rows_from_buckets(mdbg_ctx *ctx, BucketTable &tab, uint32_t k, const SeqView &a, const SeqView &b, bool vectors, mdbg_table **out) {
+    BucketView bv = tab.view();
+    const uint64_t n_ent = tab.entries() + TABLE_EXC_CAP;
+    DevBuf<uint32_t> flag;
+    DevBuf<uint64_t> pos;
+    MDBG_TRY(flag.alloc(ctx, n_ent));
+    MDBG_TRY(pos.alloc(ctx, n_ent + 1));
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(bucket_flag_kernel, dim3(grid_for(n_ent, 256)), dim3(256), 0, ctx->stream, bv, flag.p);
+    }
+    MDBG_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, n_ent));
+    uint64_t n_rows = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &n_rows, pos.p + n_ent, 8, hipMemcpyDeviceToHost));
+    std::unique_ptr<mdbg_table> t(new mdbg_table());
+    t->k = k;
+    t->n_solid = n_rows;
+    MDBG_TRY(alloc_rows(ctx, t.get(), n_rows, vectors));
+    RowOut ro{t->d_lo.p, t->d_hi.p, t->d_ab.p, vectors ? t->d_vec.p : nullptr, k};
+    {
+        LaunchTimer timer(ctx, "kminmer_emit");
+        hipLaunchKernelGGL(bucket_emit_kernel, dim3(grid_for(n_ent, 256)), dim3(256), 0, ctx->stream, bv, flag.p, pos.p, a, b, ro);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = t.release();
+    return MDBG_OK;
+}
+
+static int index_pass_buckets(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs, uint32_t k, const mdbg_table *prev,
+                              bool vectors, int hint_kind, mdbg_table **out);
+
 extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
                                           uint32_t k, const mdbg_table *prev, mdbg_table **out) try {
     if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_refined: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_count_refined"));
     if (unitigs) MDBG_TRY(check_seq(ctx, unitigs, "mdbg_kminmer_count_refined"));
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->refined_form == 0 && ctx->index_table_form == 0) return index_pass_buckets(ctx, reads, unitigs, k, prev, true, 1, out);
     TableView pv;
     MDBG_TRY(prev_view(ctx, prev, pv));
     InstIndex ia, ib;
@@ -793,7 +943,7 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
     {
         LaunchTimer timer(ctx, "kminmer_prev_lookup");
-        hipLaunchKernelGGL(prev_abundance_kernel, dim3(instance_grid(ctx, vkm1.n_reads)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        hipLaunchKernelGGL(prev_abundance_kernel<TableView>, dim3(instance_grid(ctx, vkm1.n_reads)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
     }
     {
         LaunchTimer timer(ctx, "kminmer_insert");
@@ -803,12 +953,68 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     return MDBG_OK;
 }
 
+// the same with both tables in the compact form; `inst` (optional) receives the k-instance index of the set (the refined pass needs the view again)
+static int index_one_set_b(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, const BucketView &pv, const BucketView &tv, uint64_t rep_base, uint64_t &n_inst) {
+    InstIndex ik, ikm1;
+    MDBG_TRY(build_inst_index(ctx, s, k, ik));
+    n_inst += ik.total;
+    if (!ik.total) return MDBG_OK;
+    MDBG_TRY(build_inst_index(ctx, s, k - 1, ikm1));
+    DevBuf<uint32_t> prev_ab;
+    MDBG_TRY(prev_ab.alloc(ctx, ikm1.total));
+    SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
+    {
+        LaunchTimer timer(ctx, "kminmer_prev_lookup");
+        hipLaunchKernelGGL(prev_abundance_kernel<BucketView>, dim3(instance_grid(ctx, vkm1.n_reads)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+    }
+    {
+        LaunchTimer timer(ctx, "kminmer_insert");
+        hipLaunchKernelGGL(index_insert_b_kernel, dim3(instance_grid(ctx, vk.n_reads)), dim3(256), 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv, rep_base);
+    }
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MDBG_OK;
+}
+
+// A pass above firstK over bucket tables (mdbg_kminmer_index; mdbg_kminmer_count_refined with vectors): per (k-1)-window one look-up of
+// the previous table, per k-window whose abundance min(prev[i], prev[i+1]) is above 1 an insert-if-absent (graph/CreateMdbg.hpp:1240-1265,
+// :1440-1459; for k = firstK + 1 the same numbers come out of KminmerCounter::getRefinedAbundance, :3933-4005: the minimum over the
+// vector's two (k-1)-sub-min-mers, missing or 0 => 1, kept when above 1).  The table it fills stays with the result as its look-up image.
+static int index_pass_buckets(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs, uint32_t k, const mdbg_table *prev,
+                              bool vectors, int hint_kind, mdbg_table **out) {
+    BucketView pv;
+    MDBG_TRY(prev_image(ctx, prev, pv));
+    const uint64_t bound = reads->n_min + (unitigs ? unitigs->n_min : 0);          // upper bound on distinct keys: total k-windows
+    if (vectors && bound >= (1ull << 32)) return set_error(ctx, MDBG_ERANGE, "more than 2^32 minimizers in one call");
+    std::unique_ptr<BucketTable> tab(new BucketTable());
+    uint64_t n_inst = 0;
+    MDBG_TRY(build_buckets_adaptive(ctx, *tab, (uint64_t)((double)bound * ctx->key_ratio_hint[hint_kind]), bound, vectors, [&](BucketView v) {
+        n_inst = 0;
+        MDBG_TRY(index_one_set_b(ctx, reads, k, pv, v, 0, n_inst));
+        if (unitigs) MDBG_TRY(index_one_set_b(ctx, unitigs, k, pv, v, reads->n_min, n_inst));
+        return MDBG_OK;
+    }));
+    SeqView a{}, b{};                    // (write_instance_vector only needs the minimizers of the views)
+    if (vectors) {
+        a.mins = reads->d_min.p; a.n_min = reads->n_min;
+        if (unitigs) { b.mins = unitigs->d_min.p; b.n_min = unitigs->n_min; }
+    }
+    mdbg_table *t = nullptr;
+    MDBG_TRY(rows_from_buckets(ctx, *tab, k, a, b, vectors, &t));
+    update_key_hint(ctx, hint_kind, t->n_solid, bound);
+    t->st_minimizers = bound; t->st_instances = n_inst; t->st_keys = t->n_solid; t->st_slots = tab->entries() + TABLE_EXC_CAP;
+    tab->rep.release(); tab->with_rep = false;           // the image of the next pass needs keys and values only
+    t->image = std::move(tab);
+    *out = t;
+    return MDBG_OK;
+}
+
 extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
                                   uint32_t k, const mdbg_table *prev, mdbg_table **out) try {
     if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_index: bad argument");
     MDBG_TRY(check_seq(ctx, reads, "mdbg_kminmer_index"));
     if (unitigs) MDBG_TRY(check_seq(ctx, unitigs, "mdbg_kminmer_index"));
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->index_table_form == 0) return index_pass_buckets(ctx, reads, unitigs, k, prev, false, 2, out);
     TableView pv;
     MDBG_TRY(prev_view(ctx, prev, pv));
     // upper bound on distinct keys: total k-windows

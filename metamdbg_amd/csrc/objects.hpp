@@ -102,4 +102,7 @@ struct mdbg_table {
     uint64_t st_minimizers = 0, st_instances = 0, st_keys = 0, st_slots = 0;
     // key -> abundance lookup (always present for prev tables; built on demand for output tables)
     std::unique_ptr<mdbg::DeviceTable> lookup;
+    // the same map in the compact form the passes above firstK read (table.hpp "buckets of three keys"): left behind by the index
+    // pass that built the table, or made on first use from `lookup` (if present: it may carry a unitig overlay) or from the rows
+    std::unique_ptr<mdbg::BucketTable> image;
 };

@@ -187,6 +187,117 @@ __device__ __forceinline__ uint32_t table_slot_rep(const TableView &t, uint32_t 
 
 #endif  // __HIPCC__
 
+// ---- the compact form: buckets of three keys in one 64-byte sector -------------------------------------------------
+// The passes of the multi-k loop above firstK are look-ups: one per (k-1)-window into the previous table (getPrevAbundances,
+// graph/CreateMdbg.hpp:1240-1265) and one insert-if-absent per k-window (:1450-1459), 344 M of each at 10 M reads, nineteen in
+// twenty of the inserts meeting a key that is already there.  In the one-slot table above each is a random 64-byte sector of a
+// 1 - 2 GB array (12 - 16 M keys in 33 - 67 M 32-byte slots: load 0.18 - 0.48, the power-of-two capacity and the `rep` word
+// nobody reads at k >= firstK + 2).  Here a sector holds THREE keys -- low words, high words, values, side by side, every field
+// aligned for the same claim-then-publish atomics -- the bucket count is any number (multiply-shift, not a mask), and the load is
+// two thirds: the same keys in a third of the bytes, 0.3 - 0.45 GB, most of which the 256 MB memory-side cache keeps.  One probe
+// is still one sector; a bucket whose last entry is empty ends the sequence (entries fill in order).
+constexpr uint32_t BUCKET_WAYS = 3;
+constexpr uint32_t BUCKET_MAX_PROBES = 24;      // buckets: longer sequences mean the table is too full (grow and rebuild)
+
+struct alignas(64) KeyBucket {
+    unsigned long long lo[BUCKET_WAYS];         // 0 = empty
+    unsigned long long hi[BUCKET_WAYS];         // 0 = not yet published
+    uint32_t val[BUCKET_WAYS];
+    uint32_t spare;
+};
+static_assert(sizeof(KeyBucket) == 64, "a bucket is one 64-byte sector");
+
+struct BucketView {
+    KeyBucket *b;
+    uint64_t nb;              // buckets
+    uint32_t *rep;            // nb * BUCKET_WAYS representatives (the refined pass writes vectors), or null
+    TableView side;           // the side list for keys with a zero word, the overflow flag, the occupancy counters (slots == null)
+};
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ uint64_t bucket_home(uint64_t lo, uint64_t hi, uint64_t nb) {
+    return __umul64hi(lo ^ (hi >> 17), nb);     // the key is a Murmur3 output: its top bits are as good as any
+}
+
+// Find or create the entry of (lo, hi): its index bucket * 3 + way (bit 31 set = side list entry), or SLOT_NONE when create ==
+// false and the key is absent / the probe limit was reached.  *created: THIS call published the key (exactly one caller per key).
+__device__ __forceinline__ uint32_t bucket_find_or_insert(const BucketView &t, uint64_t lo, uint64_t hi, bool create, bool *created = nullptr) {
+    uint64_t b = bucket_home(lo, hi, t.nb);
+    const uint64_t limit = t.nb - 1 < BUCKET_MAX_PROBES ? t.nb - 1 : (uint64_t)BUCKET_MAX_PROBES;
+    for (uint64_t probes = 0; probes <= limit; probes++, b = b + 1 == t.nb ? 0 : b + 1) {
+        KeyBucket &B = t.b[b];
+#pragma unroll
+        for (uint32_t j = 0; j < BUCKET_WAYS; j++) {
+            unsigned long long cur = __hip_atomic_load(&B.lo[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull) {
+                if (!create) return SLOT_NONE;
+                cur = atomicCAS(&B.lo[j], 0ull, (unsigned long long)lo);
+                if (cur == 0ull) cur = lo;
+            }
+            if (cur != lo) continue;
+            unsigned long long h = __hip_atomic_load(&B.hi[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h == 0ull) {
+                if (!create) return SLOT_NONE;      // (as in table_find_or_insert: pure look-ups never race with builds)
+                h = atomicCAS(&B.hi[j], 0ull, (unsigned long long)hi);
+                if (h == 0ull) { h = hi; if (created) *created = true; }
+            }
+            if (h == hi) return (uint32_t)(b * BUCKET_WAYS + j);
+        }
+    }
+    if (create) atomicExch(t.side.overflow, 1u);
+    return SLOT_NONE;
+}
+
+// insert-if-absent with a value that is a function of the key (see table_insert_once); `rep` is stored when the view keeps them
+__device__ __forceinline__ uint32_t bucket_insert_once(const BucketView &t, uint64_t lo, uint64_t hi, uint32_t v, uint32_t rep) {
+    if (lo == 0ull || hi == 0ull) return table_exc_upsert(t.side, lo, hi, 0, v, true, rep, true);
+    bool created = false;
+    const uint32_t e = bucket_find_or_insert(t, lo, hi, true, &created);
+    if (e != SLOT_NONE && created) {
+        __hip_atomic_store(&t.b[e / BUCKET_WAYS].val[e % BUCKET_WAYS], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t.rep) t.rep[e] = rep;
+    }
+    return e;
+}
+
+// insert or overwrite (rows of a finished table, each key once)
+__device__ __forceinline__ uint32_t bucket_upsert_set(const BucketView &t, uint64_t lo, uint64_t hi, uint32_t v) {
+    if (lo == 0ull || hi == 0ull) return table_exc_upsert(t.side, lo, hi, 0, v, true, 0u, true);
+    const uint32_t e = bucket_find_or_insert(t, lo, hi, true);
+    if (e != SLOT_NONE) __hip_atomic_store(&t.b[e / BUCKET_WAYS].val[e % BUCKET_WAYS], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return e;
+}
+
+// Read-only look-up after the building kernel has finished: the three low words of a bucket in two loads, the matching way's
+// high word and value from the same sector.
+__device__ __forceinline__ bool bucket_lookup(const BucketView &t, uint64_t lo, uint64_t hi, uint32_t &val) {
+    if (lo == 0ull || hi == 0ull) {
+        const uint32_t n = *t.side.exc_n;
+        for (uint32_t i = 0; i < n; i++)
+            if (t.side.exc_lo[i] == lo && t.side.exc_hi[i] == hi) { val = t.side.exc_val[i]; return true; }
+        return false;
+    }
+    uint64_t b = bucket_home(lo, hi, t.nb);
+    const uint64_t limit = t.nb - 1 < BUCKET_MAX_PROBES ? t.nb - 1 : (uint64_t)BUCKET_MAX_PROBES;
+    for (uint64_t probes = 0; probes <= limit; probes++, b = b + 1 == t.nb ? 0 : b + 1) {
+        const KeyBucket &B = t.b[b];
+        const ulonglong2 l01 = *reinterpret_cast<const ulonglong2 *>(&B.lo[0]);
+        const unsigned long long l2 = B.lo[2];
+        if (l01.x == lo && B.hi[0] == hi) { val = B.val[0]; return true; }
+        if (l01.y == lo && B.hi[1] == hi) { val = B.val[1]; return true; }
+        if (l2 == lo && B.hi[2] == hi) { val = B.val[2]; return true; }
+        if (l2 == 0ull) return false;           // not full: nothing of this home bucket went further
+    }
+    return false;
+}
+
+// one look-up, whatever the table's form
+__device__ __forceinline__ bool key_lookup(const TableView &t, uint64_t lo, uint64_t hi, uint32_t &val) { return table_lookup(t, lo, hi, val); }
+__device__ __forceinline__ bool key_lookup(const BucketView &t, uint64_t lo, uint64_t hi, uint32_t &val) { return bucket_lookup(t, lo, hi, val); }
+
+#endif  // __HIPCC__
+
 // Host-side owner of the table storage.
 struct DeviceTable {
     uint64_t cap = 0;
@@ -267,6 +378,80 @@ int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uin
         // so `most` is not an error yet: grow twice more (load <= 1/3, then <= 1/6) before giving up.
         if (tab.cap >= 4 * most) return set_error(ctx, MDBG_ERANGE, "k-min-mer hash table overflow at %llu slots", (unsigned long long)tab.cap);
         want = tab.cap >= most ? tab.cap * 2 : (tab.cap * 4 > most ? most : tab.cap * 4);
+    }
+}
+
+// Host-side owner of a bucket table.
+struct BucketTable {
+    uint64_t nb = 0;
+    DevBuf<KeyBucket> buckets;
+    DevBuf<uint32_t> rep;
+    DevBuf<unsigned long long> exc_lo, exc_hi;
+    DevBuf<uint32_t> exc_val, exc_rep, ctl;  // ctl as DeviceTable's
+    bool with_rep = false;
+
+    static uint64_t buckets_for(uint64_t keys, double load) {
+        const uint64_t n = (uint64_t)((double)keys / (load * BUCKET_WAYS)) + 1;
+        return n < 1024 ? 1024 : (n + 255) / 256 * 256;      // (a multiple of 256: whole blocks walk whole buckets)
+    }
+    uint64_t entries() const { return nb * BUCKET_WAYS; }
+    int init(mdbg_ctx *ctx, uint64_t n_buckets, bool keep_rep) {
+        nb = n_buckets < 1024 ? 1024 : (n_buckets + 255) / 256 * 256;
+        if (nb * BUCKET_WAYS >= (1ull << 31)) return set_error(ctx, MDBG_ERANGE, "bucket table of %llu entries exceeds 2^31", (unsigned long long)(nb * BUCKET_WAYS));
+        with_rep = keep_rep;
+        MDBG_TRY(buckets.alloc(ctx, nb));
+        if (keep_rep) MDBG_TRY(rep.alloc(ctx, nb * BUCKET_WAYS));
+        MDBG_TRY(exc_lo.alloc(ctx, TABLE_EXC_CAP));
+        MDBG_TRY(exc_hi.alloc(ctx, TABLE_EXC_CAP));
+        MDBG_TRY(exc_val.alloc(ctx, TABLE_EXC_CAP));
+        MDBG_TRY(exc_rep.alloc(ctx, TABLE_EXC_CAP));
+        MDBG_TRY(ctl.alloc(ctx, 4 + TABLE_OCC_WAYS));
+        LaunchTimer timer(ctx, "table_clear");
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(buckets.p, 0, nb * sizeof(KeyBucket), ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(exc_val.p, 0, TABLE_EXC_CAP * 4, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(ctl.p, 0, (4 + TABLE_OCC_WAYS) * 4, ctx->stream));
+        return MDBG_OK;
+    }
+    BucketView view() const {
+        BucketView v;
+        v.b = buckets.p; v.nb = nb; v.rep = with_rep ? rep.p : nullptr;
+        v.side.slots = nullptr; v.side.mask = 0;
+        v.side.exc_lo = exc_lo.p; v.side.exc_hi = exc_hi.p; v.side.exc_val = exc_val.p; v.side.exc_rep = exc_rep.p;
+        v.side.exc_n = ctl.p; v.side.exc_lock = ctl.p + 1; v.side.overflow = ctl.p + 2; v.side.occ = ctl.p + 4;
+        static const bool no_give_up = getenv("MDBG_NO_GIVE_UP") != nullptr;
+        v.side.poll_overflow = no_give_up ? 0u : 1u;
+        return v;
+    }
+    int overflowed(mdbg_ctx *ctx) {
+        uint32_t c[4];
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, c, ctl.p, 16, hipMemcpyDeviceToHost));
+        return c[2] ? 1 : 0;
+    }
+    int check_overflow(mdbg_ctx *ctx) {
+        int o = overflowed(ctx);
+        if (o < 0) return o;
+        if (o) return set_error(ctx, MDBG_ERANGE, "k-min-mer bucket table overflow (%llu buckets)", (unsigned long long)nb);
+        return MDBG_OK;
+    }
+};
+
+// The same growth rule as build_table_adaptive for a bucket table: sized for `expected` keys at two thirds full, doubled until `fill`
+// completes without a probe sequence beyond BUCKET_MAX_PROBES; at most `upper_bound` keys can arrive.
+template <typename Fill>
+int build_buckets_adaptive(mdbg_ctx *ctx, BucketTable &tab, uint64_t expected, uint64_t upper_bound, bool keep_rep, Fill fill) {
+    uint64_t want = BucketTable::buckets_for(expected + 1024, 0.66);
+    const uint64_t most = BucketTable::buckets_for(upper_bound + 1024, 0.66);
+    if (want > most) want = most;
+    for (;;) {
+        MDBG_DBG(ctx, "build_buckets_adaptive: %llu buckets (expected %llu keys, at most %llu)", (unsigned long long)want, (unsigned long long)expected, (unsigned long long)upper_bound);
+        MDBG_TRY(tab.init(ctx, want, keep_rep));
+        MDBG_TRY(fill(tab.view()));
+        MDBG_HIP_CHECK(ctx, hipGetLastError());
+        int o = tab.overflowed(ctx);
+        if (o < 0) return o;
+        if (!o) return MDBG_OK;
+        if (tab.nb >= 4 * most) return set_error(ctx, MDBG_ERANGE, "k-min-mer bucket table overflow at %llu buckets", (unsigned long long)tab.nb);
+        want = tab.nb >= most ? tab.nb * 2 : (tab.nb * 2 > most ? most : tab.nb * 2);
     }
 }
 

@@ -154,6 +154,77 @@ def make_hifi_1m(work: str, threads: int = 8) -> None:
         json.dump(manifest, f, indent=1, sort_keys=True)
 
 
+def _graph_until_tables(tmp: str, threads: int, first_pass: bool, timeout: int = 3600) -> None:
+    """The reference's `graph` up to the moment its tables are written and closed: the log line "Nb small contigs written" follows
+    `_kminmerAbundanceFile.close()` (graph/CreateMdbg.cpp:466-470); what comes after is graph construction (minutes at a million
+    reads, out of this repository's scope) and the process -- this very one, by its handle -- is ended there."""
+    import time
+    log_path = os.path.join(os.path.dirname(tmp), "metaMDBG.log")
+    start = os.path.getsize(log_path) if os.path.exists(log_path) else 0
+    cmd = [REFDRV, "graph", tmp, "--threads", str(threads)] + (["--min-abundance", "0", "--firstpass"] if first_pass else [])
+    proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t0 = time.time()
+    try:
+        while proc.poll() is None:
+            if os.path.exists(log_path):
+                with open(log_path, "rb") as f:
+                    f.seek(start)
+                    if b"Nb small contigs written" in f.read():
+                        break
+            if time.time() - t0 > timeout:
+                raise subprocess.TimeoutExpired(cmd, timeout)
+            time.sleep(0.05)
+        else:
+            if proc.returncode != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+            proc.wait()
+
+
+def make_hifi_1m_multik(work: str, threads: int = 8, last_k: int = 11) -> None:
+    """BASELINE.json configs[2]'s loop k = 4 .. 11 at configs[1]'s size by the reference's own code, in the benchmark mode SURVEY.md 8(d)
+    defines (reads only: no unitig_data.txt, the previous table is the pass's own k - 1 output): per k the reference's `graph` is given
+    kminmerData_abundance_prev.txt = its table of k - 1 and empty unitig files, and is ended once its tables are closed.  Only digests go
+    into the repository (tests/golden/hifi_1m/manifest.json "multik": record count, sha256 of the sorted 20-byte records, the reference's
+    checksum formula, the sum of abundances); tests/test_gpu_fullsize_multik.py checks the HIP path's tables against them at every k."""
+    import dataclasses
+    spec = synth.hifi_spec(1_000_000, seed=42, read_len=10_000, coverage=50.0)
+    fasta = os.path.join(work, "hifi_1m.fasta")
+    synth.write_fasta(fasta, spec)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=last_k, hpc=True, data_type=0)
+    tmp = run_ref_pipeline(os.path.join(work, "hifi_1m_multik"), fasta, params, threads=threads, graph=False)
+    os.unlink(fasta)
+    man_path = os.path.join(HERE, "hifi_1m", "manifest.json")
+    manifest = json.load(open(man_path))
+    cm, co = formats.parse_minimizer_reads(open(os.path.join(tmp, "read_data_corrected.txt"), "rb").read())
+    assert formats.minimizer_reads_digest(cm, co) == manifest["read_data_corrected_digest"]        # the same reads as the k = 4 fixture
+    per_k = {}
+    prev_k = 4
+    for k in range(4, last_k + 1):
+        dataclasses.replace(params, kminmer_size=k, prev_k=prev_k).save(os.path.join(tmp, "parameters.gz"))
+        if k > 4:
+            shutil.copy(os.path.join(tmp, "kminmerData_abundance.txt"), os.path.join(tmp, "kminmerData_abundance_prev.txt"))
+            for name in ("unitig_data.txt", "unitigGraph_prev.nodes.bin", "unitigGraph.nodes.refined_abundances.bin"):
+                open(os.path.join(tmp, name), "wb").close()
+        _graph_until_tables(tmp, threads, first_pass=(k == 4))
+        raw = open(os.path.join(tmp, "kminmerData_abundance.txt"), "rb").read()
+        rec = formats.parse_abundance_table(raw)
+        with np.errstate(over="ignore"):
+            checksum = int((rec["abundance"].astype(np.uint64) * rec["lo"]).sum(dtype=np.uint64))
+        vec = open(os.path.join(tmp, "kminmerData_min.txt"), "rb").read() if k <= 5 else None
+        per_k[str(k)] = dict(n_records=int(len(rec)), abundance_checksum=checksum, sum_abundance=int(rec["abundance"].astype(np.uint64).sum()),
+                             **formats.table_digests(rec, vec, k))
+        print(f"[make_golden] hifi_1m multik k={k}: {len(rec)} records", flush=True)
+        prev_k = k
+    assert per_k["4"]["abundance_sorted_sha256"] == manifest["abundance_sorted_sha256"]
+    manifest["multik"] = dict(mode="benchmark mode (SURVEY.md 8(d)): reads only, previous table = the reference's own table of k - 1, empty unitig files; "
+                                   "`graph` ended once its tables were closed", last_k=last_k, reference_threads=threads, per_k=per_k)
+    with open(man_path, "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
 def make_ont(work: str) -> None:
     # SURVEY 8(d) ONT R10 error model: 1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred 10..39
     spec = synth.SynthSpec(n_reads=100, read_len=20_000, seed=11, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
@@ -534,7 +605,10 @@ def main() -> None:
         if "--only-fn" in sys.argv:
             return
         if "--only-1m" in sys.argv:      # minutes of CPU and 10 GB of scratch: not part of the default regeneration
-            make_hifi_1m(work)
+            if "--multik" in sys.argv:   # ... and the loop k = 4 .. 11 on the same reads (benchmark mode), digests into the same manifest
+                make_hifi_1m_multik(work)
+            else:
+                make_hifi_1m(work)
             return
         if "--only-multik" in sys.argv:
             make_multik(work)

@@ -232,8 +232,26 @@ def test_count_first_vs_oracle(ctx, orc, k, min_ab):
     _assert_tables_equal(rec, vec, exp, k)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _table_form(ctx, form: str):
+    """The passes above firstK over bucket tables (three keys per 64-byte sector; the refined pass by look-ups like an index pass) --
+    the default -- or over the one-slot tables of rounds 1 - 4 (mdbg_set_option "index_table_form" / "refined_form")."""
+    old = form == "slots"
+    ctx.set_option("index_table_form", 1 if old else 0)
+    ctx.set_option("refined_form", 1 if old else 0)
+    try:
+        yield
+    finally:
+        ctx.set_option("index_table_form", 0)
+        ctx.set_option("refined_form", 0)
+
+
+@pytest.mark.parametrize("form", ["buckets", "slots"])
 @pytest.mark.parametrize("k", [5, 6, 9])
-def test_refined_and_index_vs_oracle(ctx, orc, k):
+def test_refined_and_index_vs_oracle(ctx, orc, k, form):
     rng = np.random.default_rng(300 + k)
     # a "genome" of distinct minimizers; reads = random substrings in either orientation; unitigs =
     # disjoint genome segments (as in a compacted graph every k-min-mer belongs to ONE unitig, so the
@@ -269,11 +287,22 @@ def test_refined_and_index_vs_oracle(ctx, orc, k):
     ohi, olo, oab = oprev.arrays()
     assert np.array_equal(dprev.lookup(olo, ohi), oab)
     allm = np.concatenate([mins, umins]); alloff = np.concatenate([offs, offs[-1] + uoffs[1:]])
-    rec, vec = ctx.kminmer_count_refined(d_reads, d_unitigs, k, dprev).to_host()
-    _assert_tables_equal(rec, vec, orc.kminmer_count_refined(allm, alloff, k, oprev), k)
-    rec, vec = ctx.kminmer_index(d_reads, d_unitigs, k, dprev).to_host()
-    assert vec is None
-    _assert_tables_equal(rec, vec, orc.kminmer_index(allm, alloff, k, oprev), k)
+    with _table_form(ctx, form):
+        t5 = ctx.kminmer_count_refined(d_reads, d_unitigs, k, dprev)
+        rec, vec = t5.to_host()
+        _assert_tables_equal(rec, vec, orc.kminmer_count_refined(allm, alloff, k, oprev), k)
+        t6 = ctx.kminmer_index(d_reads, d_unitigs, k, dprev)
+        rec, vec = t6.to_host()
+        assert vec is None
+        _assert_tables_equal(rec, vec, orc.kminmer_index(allm, alloff, k, oprev), k)
+        # the table a pass hands out serves the next as its previous table (the bucket form leaves its own table behind as the image)
+        exp = orc.kminmer_index(allm, alloff, k + 1, orc.PrevAbundance(orc.table_abundance_records(orc.kminmer_index(allm, alloff, k, oprev)).tobytes()))
+        rec, vec = ctx.kminmer_index(d_reads, d_unitigs, k + 1, t6).to_host()
+        _assert_tables_equal(rec, vec, exp, k + 1)
+        # ... and answers look-ups like any table
+        r6 = t6.to_host()[0]
+        if len(r6):
+            assert np.array_equal(t6.lookup(r6["lo"].astype(np.uint64), r6["hi"].astype(np.uint64)), r6["abundance"])
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
@@ -795,8 +824,9 @@ def _multik_cases():
     return [(s, k) for s in mk.SETS for k in mk.steps(s)]
 
 
+@pytest.mark.parametrize("form", ["buckets", "slots"])
 @pytest.mark.parametrize("name,k", _multik_cases())
-def test_next_k_tables_equal_reference_multik(ctx, name, k):
+def test_next_k_tables_equal_reference_multik(ctx, name, k, form):
     """Rows A13 / A14 against the REFERENCE: previous table + unitig overlay, refined count (k = firstK+1), index
     (k >= firstK+2) and the small-contig branch, on the inputs the reference's `graph` read in its own multi-k loop and
     the tables it wrote (tests/golden/*_multik)."""
@@ -812,7 +842,8 @@ def test_next_k_tables_equal_reference_multik(ctx, name, k):
         po = np.concatenate([[0], np.cumsum([len(u) for u, _ in fx["prev_unitigs"]])]).astype(np.uint64)
         pa = np.array([a for _, a in fx["prev_unitigs"]], dtype=np.uint32)
         ctx.prev_overlay_unitigs(dprev, ctx.minimizers_from_host(pm, po), pa, P.prev_k)
-    t = (ctx.kminmer_count_refined if k == P.first_k + 1 else ctx.kminmer_index)(d_reads, d_unitigs, k, dprev)
+    with _table_form(ctx, form):
+        t = (ctx.kminmer_count_refined if k == P.first_k + 1 else ctx.kminmer_index)(d_reads, d_unitigs, k, dprev)
     rec, vec = t.to_host()
     assert np.array_equal(formats.sorted_abundance_records(rec.tobytes()), fx["abundance_sorted"])
     if fx["min_sorted"] is not None:
