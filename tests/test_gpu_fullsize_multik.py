@@ -70,3 +70,51 @@ def test_multik_tables_at_one_million_reads(ctx):
         prev = whole
     prev.free()
     corr.free()
+
+
+def test_configs2_at_its_stated_size_ten_million_reads(ctx):
+    """BASELINE.json configs[2] at the size it names -- 10 M x 10 kb HiFi reads, k = 4 .. 11 -- inside the GPU suite (until round 4 only
+    bench.py ran it): at every k the table of the whole read set against the union of the shares of its halves, through the library's
+    sharded passes and its exchange (bench.shard_self_check).  The k = 4 counts are the ones every bench line of rounds 3 - 5 reports."""
+    import bench
+    ctx.set_option("pool_trim", 1)
+    spec = synth.hifi_spec(10_000_000, seed=42, read_len=10_000, coverage=50.0)
+    reads = ctx.reads_synthetic(spec)
+    mins = ctx.scan(reads, K=15, density=0.005, hpc=True)
+    reads.free()
+    assert mins.info()["n_minimizers"] == 373_753_601
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    mins.free()
+    r = bench.shard_self_check(ctx, corr, list(range(4, 12)), n_shards=2)
+    corr.free()
+    ctx.set_option("pool_trim", 1)
+    assert r["all_equal"] and r["reads"] == 10_000_000, r
+    assert r["per_k"]["4"]["records"] == 10_775_506 and r["per_k"]["4"]["solid"] == 10_613_396
+    assert all(r["per_k"][str(k)]["records"] > 11_000_000 for k in range(5, 12))
+
+
+def test_configs3_at_its_stated_size_ten_million_ont_reads(ctx):
+    """BASELINE.json configs[3] at the size it names -- 10 M x 20 kb ONT reads with qualities (200 Gbp, resident three pieces at a
+    time), nanoMDBG parameters -- inside the GPU suite: bench.ont_leg without its reference sample (tests/test_gpu_parity.py and the
+    bench line compare samples with the reference): census, scans, purge and the first pass over all the reads, and the 752 M-row
+    table against the union of the shares of its halves (ont_leg raises when they differ)."""
+    import bench
+    from metamdbg_amd import capi
+    ctx.set_option("pool_trim", 1)
+    info = ctx.device_info()
+    if info["hbm_bytes"] < 250e9:
+        pytest.skip("needs an MI355X's 288 GB")
+    try:
+        import torch
+        free, _ = torch.cuda.mem_get_info(0)
+        if free < 240e9:
+            pytest.skip(f"only {free / 1e9:.0f} GB of the device are free")
+    except ImportError:
+        pass
+    octx = capi.Context(0)
+    try:
+        r = bench.ont_leg(octx, 10_000_000, sample=0)
+    finally:
+        octx.close()
+    assert r["bases"] == 200_000_000_000 and r["self_check"]["all_equal"] and r["self_check"]["reads"] == 10_000_000
+    assert r["kminmer_records"] > 700_000_000 and r["first_pass"]["path"] == 2 and r["pieces"] == 3
