@@ -341,6 +341,18 @@ def sample_legs(ctx, n_sample: int, read_len: int, with_tool: bool, keep_dir: li
                 "init_bytes_equal": bool(e2e_init), "read_stats_equal": bool(e2e_stats), "table_multiset_equal": bool(e2e_table)}
             if not (e2e_init and e2e_stats and e2e_table):
                 raise SystemExit(f"bench.py: PARITY FAILURE of mdbg_tool against the reference: {out['end_to_end']}")
+            # ... and the two commands as ONE process (`mdbg_tool asmStep`: one library context, the corrected minimizers handed to the first
+            # pass on the device instead of being written, read and parsed back) -- the same files
+            t_one = _make_tmp(work, "gpu_one", P, [fasta])
+            t_a = time.perf_counter()
+            subprocess.run([TOOL, "asmStep", t_one, os.path.join(t_one, "read_data_init.txt"), os.path.join(t_one, "input.txt"), "--threads", str(min(os.cpu_count() or 1, 16)),
+                            "--min-read-quality", "0.000000", "--min-abundance", "0"], check=True, timeout=1800, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            one_s = time.perf_counter() - t_a
+            one_same = all(_fbytes(t_one, f) == _fbytes(t_ref, f) for f in ("read_data_init.txt", "read_stats.txt")) and \
+                _fbytes(t_one, "read_data_corrected.txt") == _fbytes(t_gpu, "read_data_corrected.txt") and _tables_equal(t_one, t_ref, KMINMER)
+            out["end_to_end"].update(asm_step_s=one_s, asm_step_gbps=nbases / 1e9 / one_s, asm_step_files_equal=bool(one_same))
+            if not one_same:
+                raise SystemExit(f"bench.py: PARITY FAILURE of mdbg_tool asmStep against the reference: {out['end_to_end']}")
         return out
     finally:
         if keep_dir is None:
@@ -1115,7 +1127,7 @@ def compact_line(out: dict) -> dict:
                       "ont_self_check": _flag(ont.get("self_check") if "error" not in ont else ont) if ont else None}
     numbers = {"multik_s": (legs.get("multik") or {}).get("seconds"), "ont_gbps": ont.get("gbps"),
                "pcie_gbps": (legs.get("pcie") or {}).get("packed_one_context_pipelined_gbps"),
-               "e2e_gbps": (legs.get("end_to_end") or {}).get("mdbg_tool_gbps")}
+               "e2e_gbps": (legs.get("end_to_end") or {}).get("mdbg_tool_gbps"), "e2e_one_process_gbps": (legs.get("end_to_end") or {}).get("asm_step_gbps")}
     line["legs"] = {k: _num(v) for k, v in numbers.items() if v is not None}
     failed_legs = sorted(k for k, v in legs.items() if isinstance(v, dict) and "error" in v)
     if failed_legs:

@@ -147,9 +147,13 @@ struct mdbg_ctx {
                                             // leaves LDS, registers and wave slots to other contexts' kernels (mdbg_set_option)
     uint32_t scan_lds_reserve = 0;          // the same as a goal: bytes of a CU's LDS the scan leaves free, the padding worked out per kernel variant
     size_t lds_per_cu = 0;                  // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
-    uint32_t index_table_form = 0;          // passes above firstK: 0 = bucket tables (three keys per sector, table.hpp), 1 = one 32-byte slot per key (A/B, tests)
-    uint32_t refined_form = 0;              // k = firstK + 1: 0 = like an index pass (a look-up per (k-1)-window, only kept keys inserted), 1 = every
-                                            // distinct key first, then two look-ups per key (rounds 1 - 4)
+    // the passes above firstK (round 5; measured side by side in profiles/round5_b_index_table_forms_timed.json):
+    uint32_t index_table_form = 1;          // 1 = one 32-byte slot per key (default); 0 = bucket tables, three keys per 64-byte sector (table.hpp): a third of
+                                            // the bytes and no faster -- these passes run at the rate of random sectors whatever the table's size
+    uint32_t refined_form = 1;              // k = firstK + 1: 1 = every distinct key first, then two look-ups per key (default); 0 = like an index pass (a
+                                            // look-up per (k-1)-window, only kept keys inserted: 344 M look-ups instead of 78 M -- slower)
+    uint32_t index_tuning = 7;              // one-slot index passes: bit 0 a slot's key and value in one trip, bit 1 the insert's plain-load first look,
+                                            // bit 2 two windows of a lane in flight (0 = the kernels of rounds 1 - 4)
     uint64_t part_info[8] = {0};            // last first pass: [0] path (1 one table, 2 partitioned), [1] groups, [2] bucket bits, [3] levels,
                                             // [4] attempts, [5] LDS slots per bucket, [6] buckets, [7] instances
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out

@@ -334,6 +334,53 @@ __global__ __launch_bounds__(256) void prev_abundance_kernel(SeqView s /* instan
     });
 }
 
+// The same with U windows of a lane in flight at once (one-slot table).  These passes are random 64-byte sectors, one per window, and a
+// lane that hashes a window, waits for its slot, stores and only then turns to its next window has one request in flight at a time; a
+// sequence holds two or three windows per lane (16 lanes, some 34 windows).  Here a lane hashes U of them, sends U slot loads off
+// together -- each a slot's key and value in one trip (slot_load) -- and then takes the answers.  WIDE = false: the field-by-field
+// look-up of rounds 1 - 4 (A/B: mdbg_set_option "index_tuning").
+template <int U, bool WIDE>
+__global__ __launch_bounds__(256) void prev_abundance_u_kernel(SeqView s /* instances of size k-1 */, uint32_t km1, TableView prev, uint32_t *out) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        const uint64_t base = s.inst_off[r];
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - base);
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i0 = sub; i0 < n; i0 += 16u * U) {
+            uint64_t hi[U], lo[U], home[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + 16u * (uint32_t)u;
+                hi[u] = lo[u] = 0; home[u] = 0;
+                if (i < n) { window_hash_uniform(m0 + i, km1, hi[u], lo[u]); home[u] = table_home(lo[u], hi[u], prev.mask); }
+            }
+            uint32_t v[U];
+            if (WIDE) {
+                SlotWords w[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) w[u] = slot_load(&prev.slots[home[u]]);        // (a lane without a window reads slot 0 and ignores it)
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" : "+v"(w[u].val));             // all loads are out before the first answer is looked at (the
+                                                                                           // compiler otherwise sinks a value's load behind its key's compare: one more trip)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    v[u] = 1u;
+                    if (lo[u] == 0ull || hi[u] == 0ull) { uint32_t x; if (i0 + 16u * (uint32_t)u < n && table_lookup_side(prev, lo[u], hi[u], x)) v[u] = x; }
+                    else if (w[u].lo == lo[u] && w[u].hi == hi[u]) v[u] = w[u].val;
+                    else if (w[u].lo != 0ull) { uint32_t x; if (table_lookup_from(prev, (home[u] + 1) & prev.mask, 1, lo[u], hi[u], x)) v[u] = x; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) { uint32_t x; v[u] = (i0 + 16u * (uint32_t)u < n && table_lookup_narrow(prev, lo[u], hi[u], x)) ? x : 1u; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const uint32_t i = i0 + 16u * (uint32_t)u; if (i < n) out[base + i] = v[u]; }
+        }
+    }
+}
+
 // k-window i of read r gets min(prev[i], prev[i+1]); insert-if-absent when > 1 (graph/CreateMdbg.hpp:1440-1459)
 __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
                                                            uint32_t k, TableView t) {
@@ -346,6 +393,54 @@ __global__ __launch_bounds__(256) void index_insert_kernel(SeqView s /* k */, co
         window_hash_uniform(m, k, hi, lo);
         table_insert_once(t, lo, hi, a);
     }, t.poll_overflow ? t.overflow : nullptr);
+}
+
+// The same with U windows of a lane in flight and, with FAST, a first look at every window's home slot by PLAIN loads: nineteen in
+// twenty of these inserts meet a key that is already there, and a key that a plain load shows in its slot IS there (a slot's words
+// are written once and never change; what a stale cache line can show is an empty or half-published slot, never a wrong key) -- those
+// instances are done without an atomic.  The others -- absent, displaced from its home slot, or not yet visible -- take the claim-and-
+// publish path as before (table_insert_once), whose device-scope loads go to the memory side every time.
+template <int U, bool FAST>
+__global__ __launch_bounds__(256) void index_insert_u_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
+                                                             uint32_t k, TableView t) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t trip = 0;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (t.poll_overflow && (trip++ & 31u) == 0u && __hip_atomic_load(t.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const uint64_t base = s.inst_off[r];
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - base);
+        const uint32_t *m0 = s.mins + s.off[r];
+        const uint64_t j0 = inst_off_km1[r];
+        for (uint32_t i0 = sub; i0 < n; i0 += 16u * U) {
+            uint64_t hi[U], lo[U], home[U];
+            uint32_t a[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + 16u * (uint32_t)u;
+                a[u] = 0; hi[u] = lo[u] = 0; home[u] = 0;
+                if (i < n) {
+                    const uint32_t a0 = prev_ab[j0 + i], a1 = prev_ab[j0 + i + 1];
+                    a[u] = a0 < a1 ? a0 : a1;
+                    if (a[u] > 1u) { window_hash_uniform(m0 + i, k, hi[u], lo[u]); home[u] = table_home(lo[u], hi[u], t.mask); }
+                }
+            }
+            if (FAST) {
+                SlotWords w[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) w[u] = slot_load(&t.slots[home[u]]);
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" : "+v"(w[u].hi));
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (a[u] > 1u && !(lo[u] != 0ull && hi[u] != 0ull && w[u].lo == lo[u] && w[u].hi == hi[u])) table_insert_once(t, lo[u], hi[u], a[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) if (a[u] > 1u) table_insert_once(t, lo[u], hi[u], a[u]);
+            }
+        }
+    }
 }
 
 // the same into a bucket table; rep_base + the flat index of the window's first minimizer names the instance that published the key
@@ -941,13 +1036,25 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     DevBuf<uint32_t> prev_ab;
     MDBG_TRY(prev_ab.alloc(ctx, ikm1.total));
     SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
+    // "index_tuning" (A/B): bit 0 a slot's key and value in one trip, bit 1 the plain-load first look of the insert, bit 2 two windows of
+    // a lane in flight
+    const bool wide = ctx->index_tuning & 1u, fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u;
     {
         LaunchTimer timer(ctx, "kminmer_prev_lookup");
-        hipLaunchKernelGGL(prev_abundance_kernel<TableView>, dim3(instance_grid(ctx, vkm1.n_reads)), dim3(256), 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        const dim3 grid(instance_grid(ctx, vkm1.n_reads)), block(256);
+        if (!ctx->index_tuning) hipLaunchKernelGGL(prev_abundance_kernel<TableView>, grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        else if (two && wide) hipLaunchKernelGGL((prev_abundance_u_kernel<2, true>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        else if (two) hipLaunchKernelGGL((prev_abundance_u_kernel<2, false>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        else if (wide) hipLaunchKernelGGL((prev_abundance_u_kernel<1, true>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        else hipLaunchKernelGGL((prev_abundance_u_kernel<1, false>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
     }
     {
         LaunchTimer timer(ctx, "kminmer_insert");
-        hipLaunchKernelGGL(index_insert_kernel, dim3(instance_grid(ctx, vk.n_reads)), dim3(256), 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        const dim3 grid(instance_grid(ctx, vk.n_reads)), block(256);
+        if (!(fast || two)) hipLaunchKernelGGL(index_insert_kernel, grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        else if (two && fast) hipLaunchKernelGGL((index_insert_u_kernel<2, true>), grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        else if (two) hipLaunchKernelGGL((index_insert_u_kernel<2, false>), grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        else hipLaunchKernelGGL((index_insert_u_kernel<1, true>), grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
     }
     MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MDBG_OK;

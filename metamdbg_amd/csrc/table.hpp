@@ -139,14 +139,46 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const TableView &t, uin
     return SLOT_NONE;
 }
 
+// A slot's key and value in ONE round trip: two loads issued together (the field-by-field form -- low word, then the high word if it
+// matched, then the value -- was three dependent trips to the same sector: the ISA of round 4's prev_abundance_kernel).
+struct SlotWords { unsigned long long lo, hi; uint32_t val; };
+__device__ __forceinline__ SlotWords slot_load(const TableSlot *p) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(p);
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(p) + 16);
+    SlotWords w;
+    w.lo = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+    w.hi = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+    w.val = v;
+    return w;
+}
+
+__device__ __forceinline__ bool table_lookup_side(const TableView &t, uint64_t lo, uint64_t hi, uint32_t &val) {
+    const uint32_t n = *t.exc_n;
+    for (uint32_t i = 0; i < n; i++)
+        if (t.exc_lo[i] == lo && t.exc_hi[i] == hi) { val = t.exc_val[i]; return true; }
+    return false;
+}
+
+// the probe sequence from slot s on (the key has no zero word)
+__device__ __forceinline__ bool table_lookup_from(const TableView &t, uint64_t s, uint64_t probes, uint64_t lo, uint64_t hi, uint32_t &val) {
+    const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
+    for (; probes <= limit; probes++, s = (s + 1) & t.mask) {
+        const SlotWords w = slot_load(&t.slots[s]);
+        if (w.lo == 0ull) return false;
+        if (w.lo == lo && w.hi == hi) { val = w.val; return true; }
+    }
+    return false;   // inserts never place a key beyond the probe limit
+}
+
 // Read-only lookup after the build kernel completed (plain loads are safe across a kernel boundary).
 __device__ __forceinline__ bool table_lookup(const TableView &t, uint64_t lo, uint64_t hi, uint32_t &val) {
-    if (lo == 0ull || hi == 0ull) {
-        uint32_t n = *t.exc_n;
-        for (uint32_t i = 0; i < n; i++)
-            if (t.exc_lo[i] == lo && t.exc_hi[i] == hi) { val = t.exc_val[i]; return true; }
-        return false;
-    }
+    if (lo == 0ull || hi == 0ull) return table_lookup_side(t, lo, hi, val);
+    return table_lookup_from(t, table_home(lo, hi, t.mask), 0, lo, hi, val);
+}
+
+// (the field-by-field form, kept for A/B timing: mdbg_set_option "index_tuning")
+__device__ __forceinline__ bool table_lookup_narrow(const TableView &t, uint64_t lo, uint64_t hi, uint32_t &val) {
+    if (lo == 0ull || hi == 0ull) return table_lookup_side(t, lo, hi, val);
     uint64_t s = table_home(lo, hi, t.mask);
     const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
     for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
@@ -155,7 +187,7 @@ __device__ __forceinline__ bool table_lookup(const TableView &t, uint64_t lo, ui
         if (cur == 0ull) return false;
         if (cur == lo && sl.hi == hi) { val = sl.val; return true; }
     }
-    return false;   // inserts never place a key beyond the probe limit
+    return false;
 }
 
 // Same, returning the slot (bit 31 set = side-list entry) or SLOT_NONE.
@@ -197,7 +229,9 @@ __device__ __forceinline__ uint32_t table_slot_rep(const TableView &t, uint32_t 
 // two thirds: the same keys in a third of the bytes, 0.3 - 0.45 GB, most of which the 256 MB memory-side cache keeps.  One probe
 // is still one sector; a bucket whose last entry is empty ends the sequence (entries fill in order).
 constexpr uint32_t BUCKET_WAYS = 3;
-constexpr uint32_t BUCKET_MAX_PROBES = 24;      // buckets: longer sequences mean the table is too full (grow and rebuild)
+constexpr uint32_t BUCKET_MAX_PROBES = 256;     // buckets: longer sequences mean the table is too full (grow and rebuild).  (24 -- "as many entries as
+                                                // TABLE_MAX_PROBES slots" -- overflowed at two thirds full: a run of 25 full buckets is 75 keys where 47 are
+                                                // expected, one bucket in a thousand starts one; 257 full buckets at that load do not happen)
 
 struct alignas(64) KeyBucket {
     unsigned long long lo[BUCKET_WAYS];         // 0 = empty

@@ -85,7 +85,7 @@ struct LogFile {
         const size_t cut = d.find_last_of('/');
         std::string parent = cut == std::string::npos ? std::string() : d.substr(0, cut == 0 ? 1 : cut);
         if (parent.empty()) parent = tmpDir;
-        f.open(parent + "/metaMDBG.log", std::ios::app);
+        if (!f.is_open()) f.open(parent + "/metaMDBG.log", std::ios::app);       // (asmStep: the second command of the process finds it open)
     }
     void line(const std::string &s) { if (f) { f << s << "\n"; f.flush(); } }
 } g_log;
@@ -169,6 +169,7 @@ struct Args {
     size_t batchBases = (size_t)32 << 20;  // bytes of input per device batch (not a reference flag)
     int gpus = 1;                          // contexts / devices the work is spread over (not a reference flag)
     bool verify = true;                    // graph --gpus G: rank 0 repeats the pass alone and the job compares (not a reference flag)
+    bool thenGraph = false;                // asmStep: graph --firstpass follows in this process, on the minimizers still on the device (not a reference flag)
 };
 Args parse_args(int argc, char **argv, int first) {
     Args a;
@@ -274,10 +275,19 @@ mdbg_scan_params scan_params(const Parameters &P, float density, const std::vect
     return p;
 }
 
+[[noreturn]] void graph_main(Args a, const std::string &dir, mdbg_minimizers *resident);
+
 // ---- readSelection --------------------------------------------------------------------------------------------
-int run_read_selection(int argc, char **argv) {
+// (asmStep = true: `mdbg_tool asmStep <the arguments of readSelection> [--min-abundance M]` -- this command and `graph --firstpass` in ONE
+// process: the reference's pipeline runs them as two children one after the other, pipeline/AssemblyPipeline.hpp:716-740 and :763-792; here the
+// second finds the library context alive and the corrected minimizers still on the device instead of creating one and parsing
+// read_data_corrected.txt back.  Every file of both commands is written as by the two of them.)
+int run_read_selection(int argc, char **argv, bool asmStep = false) {
     Args a = parse_args(argc, argv, 2);
-    if (a.pos.size() != 3) die("usage: mdbg_tool readSelection <tmpDir> <outFile> <inputList> --threads N --min-read-quality F [--skip-correction]");
+    a.thenGraph = asmStep;
+    if (a.pos.size() != 3) die(std::string("usage: mdbg_tool ") + (asmStep ? "asmStep" : "readSelection") + " <tmpDir> <outFile> <inputList> --threads N --min-read-quality F [--skip-correction]" +
+                               (asmStep ? " [--min-abundance M]" : ""));
+    if (asmStep && a.gpus > 1) die("asmStep runs on one device; with --gpus G use the two commands readSelection and graph");
     const std::string tmpDir = a.pos[0], outFile = a.pos[1], inputList = a.pos[2];
     Parameters P;
     P.load(tmpDir + "/parameters.gz");
@@ -340,6 +350,8 @@ int run_read_selection(int argc, char **argv) {
     uint64_t nbKmers = 0, nbBases = 0, nbSelected = 0;
     long double qualitySum = 0, qualityN = 0;
     const bool needCorrected = P.hpc || a.skipCorrection;
+    if (a.thenGraph && !needCorrected) die("asmStep: without --skip-correction an ONT read set goes through the reference's read correction before `graph` (not part of this tool)");
+    std::vector<std::pair<size_t, mdbg_minimizers *>> purgedResident;     // asmStep: the purged groups, by the number of their first batch (guarded by fifoMu)
     // Batches are turned into host arrays by consumer threads, each with its own library context (stream, pool), so the
     // upload of one batch can overlap the scan and the download of another; a writer thread builds the records and
     // writes them in batch order while later batches are on the device.  One consumer is the default: at 28 GB/s of
@@ -768,7 +780,8 @@ int run_read_selection(int argc, char **argv) {
                 hb->shape_values(bn, bt);
                 const double t4 = g_trace.now();
                 check_on(ctx, mdbg_minimizers_to_host(ctx, pur, hb->off, hb->m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "to_host");
-                mdbg_minimizers_free(pur);
+                if (a.thenGraph) { std::lock_guard<std::mutex> lk(fifoMu); purgedResident.emplace_back(idx[0], pur); }
+                else mdbg_minimizers_free(pur);
                 const double t5 = g_trace.now();
                 std::atomic<int> *left = new std::atomic<int>((int)idx.size());
                 {
@@ -811,6 +824,23 @@ int run_read_selection(int argc, char **argv) {
         if (close(corrFd) != 0) die("closing " + tmpDir + "/read_data_corrected.txt failed");
     }
     g_trace.mark("read_data_corrected.txt written");
+    if (a.thenGraph) {
+        // the corrected reads as they sit on the device, in the order of the file (what order they are counted in changes nothing: the
+        // tables are multisets; it is kept all the same)
+        std::sort(purgedResident.begin(), purgedResident.end());
+        std::vector<const mdbg_minimizers *> parts;
+        for (auto &pr : purgedResident) parts.push_back(pr.second);
+        mdbg_minimizers *all = nullptr;
+        if (parts.size() == 1) all = purgedResident[0].second;
+        else if (parts.size() > 1) {
+            check(mdbg_minimizers_concat(g_ctx, parts.data(), (uint32_t)parts.size(), &all), "mdbg_minimizers_concat");
+            for (auto &pr : purgedResident) mdbg_minimizers_free(pr.second);
+        }
+        g_trace.mark("asmStep: the corrected reads appended on the device");
+        a.firstPass = true;
+        a.pos = {tmpDir};
+        graph_main(a, tmpDir, all);        // (all == null: no read at all -- the file path handles that like the reference does)
+    }
     write_perf(tmpDir);
     g_trace.mark("done");
     finish();
@@ -990,11 +1020,13 @@ struct PrevOnDevice {
 // unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
 void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const U32Vec &mins,
                 const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true,
-                const std::function<void(mdbg_ctx *, mdbg_table *)> &sink = nullptr) {
+                const std::function<void(mdbg_ctx *, mdbg_table *)> &sink = nullptr, mdbg_minimizers *resident = nullptr) {
     const uint32_t k = (uint32_t)P.kminmerSize;
-    std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
-    mdbg_minimizers *reads = nullptr;
-    check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(r1 - r0), &reads), "mdbg_minimizers_from_host");
+    mdbg_minimizers *reads = resident;          // asmStep: the reads are on the device already (freed here like an uploaded set)
+    if (!reads) {
+        std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
+        check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(r1 - r0), &reads), "mdbg_minimizers_from_host");
+    }
     mdbg_table *table = nullptr;
     if (a.firstPass) {
         if (comm) check_on(ctx, mdbg_kminmer_count_first_sharded(ctx, comm, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first_sharded");
@@ -1143,7 +1175,11 @@ void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Ve
 int run_graph(int argc, char **argv) {
     Args a = parse_args(argc, argv, 2);
     if (a.pos.size() != 1) die("usage: mdbg_tool graph <tmpDir> --threads N [--min-abundance M] [--firstpass] [--gpus G [--no-verify]]");
-    const std::string dir = a.pos[0];
+    graph_main(a, a.pos[0], nullptr);
+}
+
+// `resident`: the reads of read_data_corrected.txt as asmStep left them on the device of g_ctx (null: the file is read)
+[[noreturn]] void graph_main(Args a, const std::string &dir, mdbg_minimizers *resident) {
     Parameters P;
     P.load(dir + "/parameters.gz");
     g_log.open(dir);
@@ -1154,19 +1190,27 @@ int run_graph(int argc, char **argv) {
     // RCCL.  MDBG_TOOL_SHARDED=1 takes the same path with one rank (a communicator of one: what a one-GPU box can exercise).
     const int G = std::max(1, a.gpus);
     const bool sharded = G > 1 || getenv("MDBG_TOOL_SHARDED") != nullptr;
+    uint64_t maxMins = 3500000000ull;    // more minimizers than one call of the library takes: the pass in pieces (MDBG_TOOL_MAX_MINIMIZERS: the most one piece may hold)
+    if (const char *e = getenv("MDBG_TOOL_MAX_MINIMIZERS")) maxMins = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    if (resident) {                      // only the plain one-rank pass takes the reads where they are; anything else reads the file it has just written
+        uint64_t total = 0;
+        mdbg_minimizers_info(resident, nullptr, &total);
+        if (sharded || total > maxMins) { mdbg_minimizers_free(resident); resident = nullptr; }
+    }
     // one rank: the library context (HIP start-up: 0.09 - 0.17 s, a third of this command on a 10 Gbp read set) is created on a thread of its
     // own while this one reads the input files
     int ctxRc = MDBG_OK;
     std::thread ctxThread;
-    if (!sharded) ctxThread = std::thread([&] { ctxRc = mdbg_create(0, &g_ctx); });
+    if (!sharded && !g_ctx) ctxThread = std::thread([&] { ctxRc = mdbg_create(0, &g_ctx); });
     U32Vec mins;
-    std::vector<uint64_t> offs;
-    {
+    std::vector<uint64_t> offs{0};
+    if (!resident) {
+        offs.clear();
         MappedFile corrected(dir + "/read_data_corrected.txt");
         parse_minimizer_reads(corrected.p, corrected.n, mins, offs, nullptr, std::max(1, a.threads));
+        g_trace.mark("graph: read_data_corrected.txt read and parsed");
     }
     const size_t nReads = offs.size() - 1;
-    g_trace.mark("graph: read_data_corrected.txt read and parsed");
     PrevInputs in;
     if (!a.firstPass) load_prev_inputs(dir, in);
     // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
@@ -1175,16 +1219,13 @@ int run_graph(int argc, char **argv) {
     bool streamed = false;               // the table files were written as the rows came down (one rank)
     std::vector<RankTable> parts((size_t)G);
     if (!sharded) {
-        ctxThread.join();
+        if (ctxThread.joinable()) ctxThread.join();
         check(ctxRc, "mdbg_create");
         g_trace.mark("graph: context created");
         // one rank: the rows are streamed to their files (graph/CreateMdbg.cpp:451-464, :515-522 for the copies)
         std::vector<std::string> recFiles{dir + "/kminmerData_abundance.txt"};
         if (a.firstPass) recFiles.push_back(dir + "/kminmerData_abundance_init.txt");
         if (k == P.firstK + 1) recFiles.push_back(dir + "/kminmerData_abundance_init_k" + std::to_string(P.firstK + 1) + ".txt");
-        // more minimizers than one call of the library takes: the pass in pieces (MDBG_TOOL_MAX_MINIMIZERS: the most one piece may hold)
-        uint64_t maxMins = 3500000000ull;
-        if (const char *e = getenv("MDBG_TOOL_MAX_MINIMIZERS")) maxMins = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
         std::vector<size_t> cuts{0};
         for (size_t r = 0, first = 0; r < nReads; r++) {
             if (offs[r + 1] - offs[r] > maxMins) die("graph: one read has more minimizers than a piece may hold");
@@ -1198,7 +1239,7 @@ int run_graph(int argc, char **argv) {
             });
         } else
             graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0], false,
-                       [&](mdbg_ctx *c, mdbg_table *t) { stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt"); });
+                       [&](mdbg_ctx *c, mdbg_table *t) { stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt"); }, resident);
         streamed = true;
         g_trace.mark("graph: table built and written");
     } else {
@@ -1293,5 +1334,6 @@ int main(int argc, char **argv) {
     const std::string cmd = argv[1];
     if (cmd == "readSelection") return run_read_selection(argc, argv);
     if (cmd == "graph") return run_graph(argc, argv);
-    die("unknown sub-command " + cmd + " (only the hot-path tools exist here: readSelection, graph)");
+    if (cmd == "asmStep") return run_read_selection(argc, argv, true);          // readSelection + graph --firstpass in one process, one context
+    die("unknown sub-command " + cmd + " (only the hot-path tools exist here: readSelection, graph, asmStep)");
 }

@@ -17,7 +17,7 @@
 struct mdbg_ctx { std::string err; };
 struct mdbg_reads { std::vector<uint32_t> len; };
 struct mdbg_minimizers { std::vector<uint64_t> off; std::vector<uint32_t> m, pos, len; std::vector<uint8_t> dir, qual, flags; };
-struct mdbg_table {};
+struct mdbg_table { uint32_t k = 0; std::vector<uint8_t> rec; std::vector<uint32_t> vec; };
 struct mdbg_census {};
 struct mdbg_comm {};
 struct mdbg_shard {};
@@ -120,18 +120,50 @@ int mdbg_census_create(mdbg_ctx *, mdbg_census **out) { *out = new mdbg_census()
 int mdbg_census_add(mdbg_ctx *, mdbg_census *, const mdbg_minimizers *) { return MDBG_OK; }
 int mdbg_census_top(mdbg_ctx *, const mdbg_census *, uint32_t *, uint32_t *n) { *n = 0; return MDBG_OK; }
 void mdbg_census_free(mdbg_census *c) { delete c; }
-// ---- `graph` is not exercised through the stub: the entry points exist so that the tool links
-int mdbg_kminmer_count_first(mdbg_ctx *, const mdbg_minimizers *, uint32_t, uint32_t, mdbg_table **) { return MDBG_ENODEV; }
+// ---- `graph --firstpass` through the stub: one fake row per read that has at least k minimizers (key and abundance a function of the read's
+// minimizers alone, the vector its first k), in the order the reads are given -- enough to check that `asmStep` hands the first pass the same
+// reads as `graph` finds in the file.  The passes above firstK are not exercised: their entry points exist so that the tool links.
+int mdbg_kminmer_count_first(mdbg_ctx *, const mdbg_minimizers *m, uint32_t k, uint32_t, mdbg_table **out) {
+    jitter();
+    mdbg_table *t = new mdbg_table();
+    t->k = k;
+    for (size_t r = 0; r + 1 < m->off.size(); r++) {
+        const uint64_t a = m->off[r], n = m->off[r + 1] - a;
+        if (n < k) continue;
+        const uint64_t lo = m->m[a] | ((uint64_t)m->m[a + 1] << 32), hi = (uint64_t)m->m[a + n - 1] * 0x9E3779B97F4A7C15ull + n;
+        const uint32_t ab = (uint32_t)n;
+        uint8_t rec[20];
+        memcpy(rec, &lo, 8); memcpy(rec + 8, &hi, 8); memcpy(rec + 16, &ab, 4);
+        t->rec.insert(t->rec.end(), rec, rec + 20);
+        t->vec.insert(t->vec.end(), m->m.begin() + (long)a, m->m.begin() + (long)(a + k));
+    }
+    *out = t;
+    return MDBG_OK;
+}
 int mdbg_kminmer_count_first_sharded(mdbg_ctx *, mdbg_comm *, const mdbg_minimizers *, uint32_t, uint32_t, mdbg_table **) { return MDBG_ENODEV; }
 int mdbg_prev_from_records(mdbg_ctx *, const uint8_t *, uint64_t, mdbg_table **) { return MDBG_ENODEV; }
 int mdbg_prev_overlay_unitigs(mdbg_ctx *, mdbg_table *, const mdbg_minimizers *, const uint32_t *, uint32_t) { return MDBG_ENODEV; }
 int mdbg_kminmer_count_refined(mdbg_ctx *, const mdbg_minimizers *, const mdbg_minimizers *, uint32_t, const mdbg_table *, mdbg_table **) { return MDBG_ENODEV; }
 int mdbg_kminmer_index(mdbg_ctx *, const mdbg_minimizers *, const mdbg_minimizers *, uint32_t, const mdbg_table *, mdbg_table **) { return MDBG_ENODEV; }
 int mdbg_small_contigs(mdbg_ctx *, const mdbg_minimizers *, uint32_t, uint32_t, const mdbg_table *, uint8_t *) { return MDBG_ENODEV; }
-int mdbg_table_info(const mdbg_table *, uint32_t *, uint64_t *, uint64_t *, int *) { return MDBG_ENODEV; }
-int mdbg_table_checksum(mdbg_ctx *, const mdbg_table *, uint64_t *) { return MDBG_ENODEV; }
-int mdbg_table_to_host(mdbg_ctx *, const mdbg_table *, uint8_t *, uint32_t *) { return MDBG_ENODEV; }
-int mdbg_table_to_host_range(mdbg_ctx *, const mdbg_table *, uint64_t, uint64_t, uint8_t *, uint32_t *) { return MDBG_ENODEV; }
+int mdbg_table_info(const mdbg_table *t, uint32_t *k, uint64_t *n, uint64_t *solid, int *has_vec) {
+    if (k) *k = t->k;
+    if (n) *n = t->rec.size() / 20;
+    if (solid) *solid = t->rec.size() / 20;
+    if (has_vec) *has_vec = 1;
+    return MDBG_OK;
+}
+int mdbg_table_checksum(mdbg_ctx *, const mdbg_table *t, uint64_t *sums) {
+    sums[0] = sums[1] = sums[2] = sums[3] = 0;
+    for (size_t i = 0; i < t->rec.size(); i += 20) { uint64_t lo; uint32_t ab; memcpy(&lo, &t->rec[i], 8); memcpy(&ab, &t->rec[i + 16], 4); sums[0] += lo * ab; sums[1] += ab; sums[2] += lo; }
+    return MDBG_OK;
+}
+int mdbg_table_to_host_range(mdbg_ctx *, const mdbg_table *t, uint64_t first, uint64_t count, uint8_t *rec, uint32_t *vec) {
+    if (rec && count) memcpy(rec, t->rec.data() + first * 20, count * 20);
+    if (vec && count) memcpy(vec, t->vec.data() + first * t->k, count * t->k * 4);
+    return MDBG_OK;
+}
+int mdbg_table_to_host(mdbg_ctx *c, const mdbg_table *t, uint8_t *rec, uint32_t *vec) { return mdbg_table_to_host_range(c, t, 0, t->rec.size() / 20, rec, vec); }
 void mdbg_table_free(mdbg_table *t) { delete t; }
 int mdbg_shard_from_table(mdbg_ctx *, const mdbg_table *, uint32_t, mdbg_shard **, const uint64_t **, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_shard_exchange(mdbg_ctx *, mdbg_comm *, mdbg_shard *, const uint64_t *, const uint64_t *, const uint64_t **) { return MDBG_ENODEV; }

@@ -237,19 +237,22 @@ import contextlib
 
 @contextlib.contextmanager
 def _table_form(ctx, form: str):
-    """The passes above firstK over bucket tables (three keys per 64-byte sector; the refined pass by look-ups like an index pass) --
-    the default -- or over the one-slot tables of rounds 1 - 4 (mdbg_set_option "index_table_form" / "refined_form")."""
-    old = form == "slots"
-    ctx.set_option("index_table_form", 1 if old else 0)
-    ctx.set_option("refined_form", 1 if old else 0)
+    """The passes above firstK in their forms (mdbg_set_option "index_table_form" / "refined_form" / "index_tuning"): "slots" -- one 32-byte
+    slot per key, two windows of a lane in flight, a slot's words in one trip, the insert's plain-load first look: the default --,
+    "slots_round4" -- the same tables with the kernels of rounds 1 - 4 --, "buckets" -- three keys per 64-byte sector, the refined pass by
+    look-ups like an index pass (measured, not faster: DESIGN.md 4.2)."""
+    ctx.set_option("index_table_form", 0 if form == "buckets" else 1)
+    ctx.set_option("refined_form", 0 if form == "buckets" else 1)
+    ctx.set_option("index_tuning", 0 if form == "slots_round4" else 7)
     try:
         yield
     finally:
-        ctx.set_option("index_table_form", 0)
-        ctx.set_option("refined_form", 0)
+        ctx.set_option("index_table_form", 1)
+        ctx.set_option("refined_form", 1)
+        ctx.set_option("index_tuning", 7)
 
 
-@pytest.mark.parametrize("form", ["buckets", "slots"])
+@pytest.mark.parametrize("form", ["slots", "slots_round4", "buckets"])
 @pytest.mark.parametrize("k", [5, 6, 9])
 def test_refined_and_index_vs_oracle(ctx, orc, k, form):
     rng = np.random.default_rng(300 + k)
@@ -824,7 +827,7 @@ def _multik_cases():
     return [(s, k) for s in mk.SETS for k in mk.steps(s)]
 
 
-@pytest.mark.parametrize("form", ["buckets", "slots"])
+@pytest.mark.parametrize("form", ["slots", "slots_round4", "buckets"])
 @pytest.mark.parametrize("name,k", _multik_cases())
 def test_next_k_tables_equal_reference_multik(ctx, name, k, form):
     """Rows A13 / A14 against the REFERENCE: previous table + unitig overlay, refined count (k = firstK+1), index

@@ -77,6 +77,46 @@ def test_tool_hifi_200_golden(tmp_path):
     assert f"Nb rescued kminmers: {m['reference_log']['n_rescued']}\n" in log
 
 
+@pytest.mark.parametrize("threads", [1, 16])
+def test_tool_asm_step_hifi_200_golden(tmp_path, threads):
+    """`mdbg_tool asmStep` -- readSelection + graph --firstpass in one process, one library context, the corrected minimizers handed to the
+    first pass where they sit on the device (pipeline/AssemblyPipeline.hpp:716-740, :763-792 run two children) -- writes the reference's
+    files: the three of readSelection byte for byte, the tables as multisets, the log lines of both commands, perf.bin.  (16 threads: two
+    consumer contexts, several purged groups appended on the device.)"""
+    m = H.load_manifest("hifi_200")
+    fasta = str(tmp_path / "hifi.fasta")
+    synth.write_fasta(fasta, H.spec_from_manifest(m))
+    tmp = make_tmp(tmp_path, formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=True, data_type=0), [fasta])
+    run(TOOL, "asmStep", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"), "--threads", str(threads), "--min-read-quality", "0.000000",
+        "--min-abundance", "0", "--batch-bases", str(1 << 18))
+    for name in ("read_data_init.txt", "read_stats.txt", "read_data_corrected.txt", "repetitiveMinimizers.bin"):
+        assert fbytes(tmp, name) == H.golden_bytes("hifi_200", name), name
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
+    exp_v = np.fromfile(os.path.join(H.GOLDEN, "hifi_200", "kminmerData_min.sorted.bin"), "<u4").reshape(-1, m["k"])
+    assert np.array_equal(formats.sorted_vector_records(fbytes(tmp, "kminmerData_min.txt"), m["k"]), exp_v)
+    assert fbytes(tmp, "kminmerData_abundance_init.txt") == fbytes(tmp, "kminmerData_abundance.txt")
+    assert len(fbytes(tmp, "perf.bin")) == 16 and fbytes(tmp, "smallContigs/smallContigs_k4.bin") == b""
+    log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
+    assert f"Nb solid kminmers: {m['reference_log']['n_solid']}\n" in log and f"Nb rescued kminmers: {m['reference_log']['n_rescued']}\n" in log
+    assert f"Checksum kminmer abundance: {m['reference_log']['abundance_checksum']}\n" in log
+
+
+def test_tool_asm_step_ont_100_golden(tmp_path):
+    """The same for the ONT preset (--skip-correction: census, repetitive filter pinned to the reference's pick, qualities)."""
+    m = H.load_manifest("ont_100")
+    fastq = str(tmp_path / "ont.fastq")
+    synth.write_fasta(fastq, H.spec_from_manifest(m))
+    tmp = make_tmp(tmp_path, formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=False, data_type=1,
+                                                correction_density=0.025), [fastq])
+    run(TOOL, "asmStep", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"), "--threads", "8", "--min-read-quality", "0.000000",
+        "--skip-correction", "--min-abundance", "0", env={"MDBG_TOOL_REPETITIVE": os.path.join(H.GOLDEN, "ont_100", "repetitiveMinimizers.bin")})
+    for name in ("read_data_init.txt", "read_data_corrected.txt", "repetitiveMinimizers.bin"):
+        assert fbytes(tmp, name) == H.golden_bytes("ont_100", name), name
+    exp_ab = np.fromfile(os.path.join(H.GOLDEN, "ont_100", "kminmerData_abundance.sorted.bin"), formats.ABUNDANCE_DTYPE)
+    assert np.array_equal(formats.sorted_abundance_records(fbytes(tmp, "kminmerData_abundance.txt")), exp_ab)
+
+
 def test_tool_ont_100_golden(tmp_path):
     m = H.load_manifest("ont_100")
     spec = H.spec_from_manifest(m)

@@ -107,3 +107,59 @@ def test_pipeline_under_thread_sanitizer(read_set, tmp_path):
                            env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"), capture_output=True, text=True, timeout=300)
         assert "ThreadSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-1500:]
         assert (tmp / "read_data_init.txt").read_bytes() == exp_init and (tmp / "read_data_corrected.txt").read_bytes() == exp_corr
+
+
+@pytest.mark.parametrize("batch_bases,threads,jitter,ont", [(1 << 18, 16, 0, False), (1 << 15, 8, 30, False), (1 << 16, 3, 0, False), (1 << 17, 16, 10, True), (1 << 25, 4, 0, False)])
+def test_asm_step_is_the_two_commands_in_one_process(stub_tool, read_set, tmp_path, batch_bases, threads, jitter, ont):
+    """`mdbg_tool asmStep` = readSelection + graph --firstpass in ONE process: the second command finds the library context alive and the
+    corrected minimizers still on the device -- no second context, no read_data_corrected.txt parsed back (pipeline/AssemblyPipeline.hpp:716-740,
+    :763-792 run them as two children).  Every file must be what the two commands write: read_data_init.txt, read_stats.txt and
+    read_data_corrected.txt byte for byte, the tables as multisets (the first pass is handed the purged groups in the order they were purged
+    in; the test double's rows are a function of the reads alone), the log lines of both, one perf.bin."""
+    fasta, exp_init, exp_corr, lens = read_set
+    P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=not ont, data_type=1 if ont else 0, correction_density=0.025)
+    env = dict(os.environ, MDBG_STUB_JITTER_US=str(jitter))
+    out = {}
+    for mode in ("two", "one"):
+        tmp = tmp_path / mode / "tmp"
+        for d in ("filter", "smallContigs"):
+            os.makedirs(tmp / d)
+        P.save(str(tmp / "parameters.gz"))
+        (tmp / "input.txt").write_text(fasta + "\n")
+        rs = [str(tmp), str(tmp / "read_data_init.txt"), str(tmp / "input.txt"), "--threads", str(threads), "--min-read-quality", "0.000000",
+              "--batch-bases", str(batch_bases)] + (["--skip-correction"] if ont else [])
+        cmds = [[stub_tool, "readSelection"] + rs, [stub_tool, "graph", str(tmp), "--threads", str(threads), "--min-abundance", "0", "--firstpass"]] if mode == "two" \
+            else [[stub_tool, "asmStep"] + rs + ["--min-abundance", "0"]]
+        for cmd in cmds:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr[-800:]
+        out[mode] = {n: (tmp / n).read_bytes() for n in ("read_data_init.txt", "read_data_corrected.txt", "read_stats.txt", "kminmerData_abundance.txt",
+                                                          "kminmerData_abundance_init.txt", "kminmerData_min.txt", "perf.bin", "smallContigs/smallContigs_k4.bin")}
+        out[mode]["log"] = (tmp_path / mode / "metaMDBG.log").read_text()
+    one, two = out["one"], out["two"]
+    assert one["read_data_init.txt"] == two["read_data_init.txt"] == exp_init
+    assert one["read_data_corrected.txt"] == two["read_data_corrected.txt"] == exp_corr
+    assert one["read_stats.txt"] == two["read_stats.txt"] and len(one["perf.bin"]) == 16 and one["smallContigs/smallContigs_k4.bin"] == b""
+    n_rows = int((lens // 271 >= 4).sum())
+    assert len(two["kminmerData_abundance.txt"]) == 20 * n_rows > 0
+    for name, width in (("kminmerData_abundance.txt", 20), ("kminmerData_abundance_init.txt", 20), ("kminmerData_min.txt", 16)):
+        a = np.frombuffer(one[name], np.uint8).reshape(-1, width)
+        b = np.frombuffer(two[name], np.uint8).reshape(-1, width)
+        assert a.shape == b.shape and np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])]), name
+    assert one["kminmerData_abundance.txt"] == one["kminmerData_abundance_init.txt"]
+    solid = [ln for ln in two["log"].splitlines() if "Nb solid kminmers" in ln or "Checksum kminmer abundance" in ln]
+    assert len(solid) == 2 and [ln for ln in one["log"].splitlines() if "Nb solid kminmers" in ln or "Checksum kminmer abundance" in ln] == solid
+    assert "mdbg_tool readSelection" in one["log"] and "mdbg_tool graph" in one["log"]
+
+
+def test_asm_step_refuses_what_it_cannot_do(stub_tool, read_set, tmp_path):
+    fasta = read_set[0]
+    tmp = tmp_path / "x" / "tmp"
+    os.makedirs(tmp / "filter")
+    formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=False, data_type=1, correction_density=0.025).save(str(tmp / "parameters.gz"))
+    (tmp / "input.txt").write_text(fasta + "\n")
+    rs = [str(tmp), str(tmp / "read_data_init.txt"), str(tmp / "input.txt"), "--threads", "4", "--min-read-quality", "0.000000"]
+    r = subprocess.run([stub_tool, "asmStep"] + rs, capture_output=True, text=True, timeout=60)          # ONT without --skip-correction: read correction lies in between
+    assert r.returncode != 0 and "read correction" in r.stderr
+    r = subprocess.run([stub_tool, "asmStep"] + rs + ["--skip-correction", "--gpus", "2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "one device" in r.stderr

@@ -1,6 +1,7 @@
-"""The passes above firstK in their two table forms, timed (GPU box): scan + purge once over n x 10 kb HiFi reads, then the loop k = 4 .. 11
-(benchmark mode) with bucket tables (three keys per 64-byte sector; the refined pass by look-ups) and with the one-slot tables of rounds 1 - 4
-(mdbg_set_option "index_table_form" / "refined_form"), each twice; per k the HIP-event time of its kernels and the wall time of the call, and
+"""The passes above firstK in their forms, timed (GPU box): scan + purge once over n x 10 kb HiFi reads, then the loop k = 4 .. 11
+(benchmark mode) with the one-slot tables -- the kernels of rounds 1 - 4 and round 5's (a slot's words in one trip, the insert's plain-load
+first look, two windows of a lane in flight: mdbg_set_option "index_tuning"), each alone and together -- and with bucket tables (three keys
+per 64-byte sector; the refined pass by look-ups: "index_table_form" / "refined_form"), each twice; per k the HIP-event time of its kernels and the wall time of the call, and
 the tables' order-independent sums (they must be the same in both forms).
     python tools/index_forms_time.py [n_reads] [last_k] > gpurun_out/.../index_forms.json"""
 import json
@@ -19,9 +20,13 @@ corr = ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=True), 4, 
 reads.free()
 names = ("kminmer_split", "kminmer_prev_lookup", "kminmer_prev_image", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
 out = {"reads": n, "forms": {}}
-for form, (idx, ref) in (("buckets", (0, 0)), ("slots", (1, 1)), ("buckets_refined_by_distinct_keys", (0, 1))):
+# (form, index_table_form, refined_form, index_tuning): tuning bit 0 a slot's words in one trip, bit 1 the insert's plain-load first look, bit 2 two windows in flight
+FORMS = (("slots_round4_kernels", 1, 1, 0), ("slots_wide", 1, 1, 1), ("slots_wide_fast", 1, 1, 3), ("slots_two_in_flight", 1, 1, 4), ("slots_all", 1, 1, 7),
+         ("buckets", 0, 0, 7), ("buckets_refined_by_distinct_keys", 0, 1, 7))
+for form, idx, ref, tune in FORMS:
     ctx.set_option("index_table_form", idx)
     ctx.set_option("refined_form", ref)
+    ctx.set_option("index_tuning", tune)
     best = None
     for rep in range(2):
         per_k, sums = {}, {}
@@ -48,7 +53,7 @@ for form, (idx, ref) in (("buckets", (0, 0)), ("slots", (1, 1)), ("buckets_refin
             best = {"loop_ms_incl_first_pass": round(loop_ms, 2), "per_k": per_k, "sums": sums}
     out["forms"][form] = best
 f = out["forms"]
-out["tables_equal_in_all_forms"] = all(f[x]["sums"] == f["buckets"]["sums"] for x in f)
+out["tables_equal_in_all_forms"] = all(f[x]["sums"] == f["slots_all"]["sums"] for x in f)
 for x in f:
     del f[x]["sums"]
 print(json.dumps(out, indent=1))
