@@ -297,6 +297,44 @@ __global__ __launch_bounds__(256) void distinct_insert_kernel(SeqView s, uint32_
     }, t.poll_overflow ? t.overflow : nullptr);
 }
 
+// The same with U windows of a lane in flight and a first look at every window's home slot by plain loads (see index_insert_u_kernel:
+// nine instances in ten at 50 x meet a key that is already there, and those are done without an atomic).
+template <int U, bool FAST>
+__global__ __launch_bounds__(256) void distinct_insert_u_kernel(SeqView s, uint32_t k, TableView t, uint64_t rep_base) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t trip = 0;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (t.poll_overflow && (trip++ & 31u) == 0u && __hip_atomic_load(t.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - s.inst_off[r]);
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i0 = sub; i0 < n; i0 += 16u * U) {
+            uint64_t hi[U], lo[U], home[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + 16u * (uint32_t)u;
+                hi[u] = lo[u] = 0; home[u] = 0;
+                if (i < n) { window_hash_uniform(m0 + i, k, hi[u], lo[u]); home[u] = table_home(lo[u], hi[u], t.mask); }
+            }
+            SlotWords w[U];
+            if (FAST) {
+#pragma unroll
+                for (int u = 0; u < U; u++) w[u] = slot_load(&t.slots[home[u]]);
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" : "+v"(w[u].hi));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + 16u * (uint32_t)u;
+                if (i >= n) continue;
+                if (FAST && lo[u] != 0ull && hi[u] != 0ull && w[u].lo == lo[u] && w[u].hi == hi[u]) continue;
+                table_upsert_count(t, lo[u], hi[u], 0u, (uint32_t)(rep_base + (uint64_t)(m0 + i - s.mins)));
+            }
+        }
+    }
+}
+
 // refined abundance of every distinct key (graph/CreateMdbg.hpp:3933-3970): min over the two
 // (k-1)-sub-min-mers of the canonical vector; missing or 0 => 1
 __global__ __launch_bounds__(256) void refine_slots_kernel(TableView t, uint64_t cap, SeqView a, SeqView b, uint32_t k,
@@ -988,8 +1026,17 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     DeviceTable tab;
     MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint[1]), I, [&](TableView v) {
         LaunchTimer timer(ctx, "kminmer_insert");
-        if (a.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, a.n_reads)), dim3(256), 0, ctx->stream, a, k, v, (uint64_t)0);
-        if (b.n_inst) hipLaunchKernelGGL(distinct_insert_kernel, dim3(instance_grid(ctx, b.n_reads)), dim3(256), 0, ctx->stream, b, k, v, a.n_min);
+        // ("index_tuning" bits 1 and 2, as in the index passes: the plain-load first look, two windows of a lane in flight)
+        const bool fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u;
+        auto launch = [&](const SeqView &sv, uint64_t rep_base) {
+            const dim3 grid(instance_grid(ctx, sv.n_reads)), block(256);
+            if (!(fast || two)) hipLaunchKernelGGL(distinct_insert_kernel, grid, block, 0, ctx->stream, sv, k, v, rep_base);
+            else if (two && fast) hipLaunchKernelGGL((distinct_insert_u_kernel<2, true>), grid, block, 0, ctx->stream, sv, k, v, rep_base);
+            else if (two) hipLaunchKernelGGL((distinct_insert_u_kernel<2, false>), grid, block, 0, ctx->stream, sv, k, v, rep_base);
+            else hipLaunchKernelGGL((distinct_insert_u_kernel<1, true>), grid, block, 0, ctx->stream, sv, k, v, rep_base);
+        };
+        if (a.n_inst) launch(a, 0);
+        if (b.n_inst) launch(b, a.n_min);
         return MDBG_OK;
     }));
     TableView tv = tab.view();

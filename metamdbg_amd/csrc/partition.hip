@@ -288,6 +288,7 @@ __global__ __launch_bounds__(PART_NT) void split_scatter_kernel(SplitArgs a, con
 
 // ---- counting one bucket in LDS ---------------------------------------------------------------------------------------------
 constexpr uint32_t LDS_NONE = 0xFFFFu;
+constexpr uint32_t PART_OVERFLOW_TABLE = 1u, PART_OVERFLOW_ZERO_KEY = 2u;      // what a void counting pass says went wrong
 
 template <uint32_t C>
 struct LdsTable {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(BC_NT) void bucket_count_kernel(RecView in, const u
     if (tid == 0) give_up = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (give_up) return;
-    bool failed = false;
+    bool failed = false, zero_key = false;
     for (uint64_t i0 = 0; i0 < n; i0 += BC_NT * BC_U) {
         if (__hip_atomic_load(&give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         uint64_t lo[BC_U], hi[BC_U]; uint32_t rep[BC_U];
@@ -369,14 +370,18 @@ __global__ __launch_bounds__(BC_NT) void bucket_count_kernel(RecView in, const u
             const uint64_t i = i0 + (uint64_t)q * BC_NT + tid;
             if (i >= n) continue;
             uint32_t s = LDS_NONE;
-            if (lo[q] != 0ull && hi[q] != 0ull) s = lds_upsert<C>(t, lo[q], hi[q], rep[q]);
-            if (s == LDS_NONE) { failed = true; __hip_atomic_store(&give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            const bool zero_word = lo[q] == 0ull || hi[q] == 0ull;       // 0 marks an empty slot: such a key (2^-63) is not for this pass at all
+            if (!zero_word) s = lds_upsert<C>(t, lo[q], hi[q], rep[q]);
+            if (s == LDS_NONE) { failed = true; zero_key = zero_key || zero_word; __hip_atomic_store(&give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             if (i < PART_SLOTLIST) slot_of[i] = (uint16_t)s;
         }
     }
-    if (failed) atomicExch(overflow, 1u);              // void pass: the host repeats it with more buckets or another way
+    // void pass.  PART_OVERFLOW_TABLE: a bucket outgrew its table -- the host repeats the pass with more buckets; PART_OVERFLOW_ZERO_KEY: no
+    // number of buckets helps -- the host hands the input to the one-table pass at once (round-4 ADVICE: it used to repeat four times first)
+    if (failed) atomicMax(overflow, zero_key ? PART_OVERFLOW_ZERO_KEY : PART_OVERFLOW_TABLE);
     __syncthreads();
-    if (give_up) return;
+    const bool stop = give_up != 0u;                   // (read once, behind the barrier: every wave takes the same way out)
+    if (stop) return;
     uint32_t my_occ = 0;
     for (uint32_t s = tid; s < C; s += BC_NT) {
         const unsigned long long lo = t.lo[s];
@@ -619,19 +624,20 @@ __global__ __launch_bounds__(BC_NT) void owner_bucket_kernel(RecView in, const u
     if (tid == 0) give_up = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (give_up) return;
-    bool failed = false;
+    bool failed = false, zero_key = false;
     for (uint64_t i = tid; i < n; i += BC_NT) {
         const uint64_t lo = in.lo[s0 + i], hi = in.hi[s0 + i];
         const uint32_t row = in.rep[s0 + i];
         uint32_t s = LDS_NONE;
         if (lo != 0ull && hi != 0ull) s = lds_slot<C>(t, lo, hi);
-        if (s == LDS_NONE) { failed = true; continue; }
+        if (s == LDS_NONE) { failed = true; zero_key = zero_key || lo == 0ull || hi == 0ull; continue; }
         atomicAdd(&t.cnt[s], (uint32_t)rows[3ull * row + 2]);
         atomicMin(&t.rep[s], row);
     }
-    if (failed) { atomicExch(overflow, 1u); __hip_atomic_store(&give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    if (failed) { atomicMax(overflow, zero_key ? PART_OVERFLOW_ZERO_KEY : PART_OVERFLOW_TABLE); __hip_atomic_store(&give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __syncthreads();
-    if (give_up) return;
+    const bool stop = give_up != 0u;
+    if (stop) return;
     for (uint64_t i = tid; i < n; i += BC_NT) {
         const uint32_t row = in.rep[s0 + i];
         const uint32_t s = lds_find<C>(t, in.lo[s0 + i], in.hi[s0 + i]);
@@ -936,6 +942,7 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&nk, run.key_pos.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
             MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&ns, run.row_of.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
             MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, run.overflow.p, 4, hipMemcpyDeviceToHost));
+            if (ov == PART_OVERFLOW_ZERO_KEY) { MDBG_DBG(ctx, "partitioned first pass: a key with a zero word: the one-table pass takes the input"); return MDBG_OK; }
             if (ov) { overflowed = true; break; }
             total_keys += nk; total_solid += ns;
             group_rows.emplace_back();
@@ -965,6 +972,7 @@ int count_first_partitioned(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_
             MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&total_keys, run.key_pos.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
             MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&total_solid, run.row_of.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
             MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, run.overflow.p, 4, hipMemcpyDeviceToHost));
+            if (ov == PART_OVERFLOW_ZERO_KEY) { MDBG_DBG(ctx, "partitioned first pass: a key with a zero word: the one-table pass takes the input"); return MDBG_OK; }
             overflowed = ov != 0;
         } else {
             MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1047,6 +1055,7 @@ int part_local_keys(mdbg_ctx *ctx, const mdbg_minimizers *reads, uint32_t k, Par
         uint32_t ov = 0;
         MDBG_HIP_CHECK(ctx, hipMemcpyAsync(&pl->n_keys, run.key_pos.p + run.n_buckets, 8, hipMemcpyDeviceToHost, ctx->stream));
         MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &ov, run.overflow.p, 4, hipMemcpyDeviceToHost));
+        if (ov == PART_OVERFLOW_ZERO_KEY) return MDBG_OK;         // (no number of buckets helps: the one-table path)
         if (ov) { run.extra_bits += 2; continue; }
         pl->attempt = attempt;
         break;

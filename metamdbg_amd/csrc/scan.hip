@@ -1521,9 +1521,14 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
                 if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(fk)) == hipSuccess && at.sharedSizeBytes > 0) {
                     const size_t total = ctx->lds_per_cu ? ctx->lds_per_cu : 163840u, lds = at.sharedSizeBytes;
                     size_t fit = total > ctx->scan_lds_reserve ? (total - ctx->scan_lds_reserve) / lds : 1;
-                    if (fit < 1) fit = 1;
+                    // never fewer than two blocks per CU: one block would have to be padded to more than half a CU's LDS -- beyond the 64 KB
+                    // a block may ask for, the launch would fail with hipErrorInvalidValue instead of capping anything (round-4 ADVICE);
+                    // a reserve that large is answered with the two-block form (and whatever LDS that leaves)
+                    if (fit < 2) fit = 2;
                     const size_t need = total / (fit + 1) + 1;          // a block of this size: fit + 1 of them are more than a CU has
                     if (need > lds) lds_pad = (unsigned)(((need - lds) + 255u) / 256u * 256u);
+                    const size_t most = (size_t)65536 > lds ? (size_t)65536 - lds : 0;        // static + dynamic LDS of a block stay within 64 KB
+                    if (lds_pad > most) lds_pad = (unsigned)(most / 256u * 256u);
                 } else (void)hipGetLastError();
             }
             hipLaunchKernelGGL(fk, g, b, lds_pad, on, a);

@@ -1130,6 +1130,19 @@ void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Ve
     const uint32_t k = (uint32_t)P.kminmerSize;
     const uint32_t n = (uint32_t)(cuts.size() - 1);
     if (n > 64) die("graph: more than 64 pieces (" + std::to_string(n) + "): raise MDBG_TOOL_MAX_MINIMIZERS");
+    // What this way of running the pass keeps on the device AT ONCE (round-4 ADVICE): every piece's minimizers (4 bytes each) and, until the
+    // last share is written, every piece's shard state -- the instance records of the partitioned local pass (20 bytes per k-min-mer instance)
+    // or the local table and its instance slots (up to 36) -- so about 40 bytes per minimizer of the whole read set.  A read set that needs
+    // pieces at the default limit (3.5 * 10^9 minimizers a piece: a terabase of HiFi reads) does not fit one MI355X that way; it is a job for
+    // --gpus G (a piece per device).  Said here, before the first upload, instead of as an allocation failure an hour in.
+    {
+        char arch[64]; int nCu = 0; uint64_t hbm = 0;
+        check_on(ctx, mdbg_device_info(ctx, arch, sizeof arch, &nCu, &hbm), "mdbg_device_info");
+        const uint64_t need = (uint64_t)mins.size() * 40ull;
+        if (hbm && need > hbm - hbm / 8)
+            die("graph: " + std::to_string(mins.size()) + " minimizers in " + std::to_string(n) + " pieces need about " + std::to_string(need >> 30) + " GiB on the device at once, it has " +
+                std::to_string(hbm >> 30) + " GiB: run the pass over several devices (--gpus G)");
+    }
     std::vector<mdbg_minimizers *> reads(n, nullptr);
     std::vector<mdbg_shard *> shards(n, nullptr);
     std::vector<mdbg_table *> local(n, nullptr);

@@ -6,6 +6,7 @@
 // checked for order and completeness.  What it cannot show is numerics; that is what the -m gpu tests are for.
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -35,6 +36,7 @@ extern "C" {
 int mdbg_create(int, mdbg_ctx **ctx) { *ctx = new mdbg_ctx(); return MDBG_OK; }
 void mdbg_destroy(mdbg_ctx *c) { delete c; }
 const char *mdbg_last_error(const mdbg_ctx *c) { return c ? c->err.c_str() : "stub"; }
+int mdbg_device_info(mdbg_ctx *, char *arch, size_t n, int *cu, uint64_t *hbm) { if (arch && n) snprintf(arch, n, "stub"); if (cu) *cu = 1; if (hbm) *hbm = 0; return MDBG_OK; }
 int mdbg_host_alloc(mdbg_ctx *, size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? MDBG_OK : MDBG_ENOMEM; }
 void mdbg_host_free(mdbg_ctx *, void *p) { free(p); }
 

@@ -31,7 +31,13 @@ def _bench(extra_env: dict, args: list[str], nproc: int | None, expect_failure: 
                 "--master-port", str(port)]
     cmd += [os.path.join(ROOT, "bench.py")] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
-    assert (out.returncode != 0) == expect_failure, out.stderr[-2000:]
+    if (out.returncode != 0) != expect_failure:
+        # torchrun's summary of who was killed fills the tail: what the ranks themselves said is further up -- kept whole for the record
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "test_failures"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "test_failures", f"bench_{os.getpid()}_{len(os.listdir(os.path.join(ROOT, 'gpurun_out', 'test_failures')))}.stderr"), "w") as f:
+            f.write(" ".join(cmd) + "\n" + repr(extra_env) + "\n" + out.stderr)
+        said = [ln for ln in out.stderr.splitlines() if any(w in ln for w in ("mdbg", "Mdbg", "[bench]", "Error", "error", "rank ")) and "SIGTERM" not in ln]
+        raise AssertionError(f"bench.py ended with status {out.returncode}:\n" + "\n".join(said[-40:]))
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[-500:]
     line = json.loads(lines[0])
