@@ -471,6 +471,13 @@ def multik_rooflines(ctx, reads, last_k: int) -> dict:
             prev.free()
         prev = t
     prev.free(); corr.free()
+    info = reads.info()
+    traffic, note = index_traffic(info["n_reads"], info["n_bases"] // max(1, info["n_reads"]))
+    for k, v in out.items():
+        kind = "refined" if v["pass"] == "refined" else ("index" if v["pass"] == "index" else None)
+        v["traffic"] = traffic[kind] if traffic and kind and traffic[kind] else None
+        v["traffic_over_algorithmic"] = v["traffic"] / v["algorithmic_bytes"] if v["traffic"] else None
+        v["traffic_source"] = note if kind else "see roofline_kminmer (the first pass)"
     return out
 
 
@@ -980,6 +987,33 @@ def kminmer_traffic(reads: int, read_len: int):
                   else "no PMC collection for this workload under profiles/")
 
 
+def index_traffic(reads: int, read_len: int):
+    """({"refined": bytes, "index": bytes} per pass -- the two kernels that make the pass: distinct_insert + refine_slots, prev_abundance +
+    index_insert --, note) from the committed rocprofv3 PMC passes (profiles/*_index_traffic.json, tools/index_traffic.sh): FETCH_SIZE + WRITE_SIZE
+    as reported (these kernels read random 32-byte slots, not wide coalesced streams: no doubling), averaged over the launches of the loop; valid
+    only for the workload and the sources they were collected on (git blob hashes), like measured_traffic."""
+    import glob
+    here = {f: git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", f)) for f in ("kminmer.hip", "table.hpp", "kminmer_dev.hpp")}
+    best, stale = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_index_traffic.json")), key=os.path.getmtime):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("reads") == reads and d.get("read_len") == read_len:
+            if d.get("blobs") == here:
+                best = (d, os.path.basename(path))
+            else:
+                stale = os.path.basename(path)
+    if best is None:
+        return None, (f"profiles/{stale} was collected on another version of the k-min-mer kernels: not reported" if stale
+                      else "no PMC collection for this workload under profiles/")
+    def of(*needles):
+        return sum(v["traffic_bytes_uncorrected"] for kern, v in best[0]["per_kernel"].items() if any(nd in kern for nd in needles))
+    return ({"refined": of("distinct_insert", "refine_slots"), "index": of("prev_abundance", "index_insert")},
+            f"profiles/{best[1]} (collected on this version of csrc/kminmer.hip and csrc/table.hpp)")
+
+
 def kminmer_roofline(ctx, reads, n_reads: int = 0, read_len: int = 0) -> dict:
     """The k-min-mer step (first pass, k = 4) of the bench workload on the record: algorithmic bytes 4 M + 16 I + 20 D
     (minimizers read, one 128-bit key per instance, output rows) over the HIP-event time of its kernels with
@@ -1100,6 +1134,9 @@ def compact_line(out: dict) -> dict:
         k["algorithmic_bytes_per_launch"] = _num(kroof.get("algorithmic_bytes"))
         k["avg_launch_ms"] = _num(kroof.get("kernel_ms_total"))
         line["roofline_kminmer"] = k
+    per_k = (out.get("roofline_index") or {}).get("per_k") or {}
+    if per_k:          # every pass of the loop k = 4 .. 11 (configs[2]): kernel ms, fraction of the HBM peak, counter traffic
+        line["roofline_index"] = {k: {"ms": _num(v.get("kernel_ms_total"), 4), "frac": _num(v.get("frac"), 3), "traffic": _num(v.get("traffic"), 4)} for k, v in per_k.items()}
     base = out.get("cpu_baseline")
     if base:
         b = _pick(base, ("value", "unit", "cores", "threads", "kind"))
@@ -1138,7 +1175,7 @@ def compact_line(out: dict) -> dict:
         line["speedup_vs_cpu_reference_path_only"] = _num(out["speedup_vs_cpu_reference_path_only"])
     line["detail"] = DETAIL_FILE
     if len(json.dumps(line)) >= LINE_LIMIT:          # cannot happen with the caps above; if it does the contract's keys still get through
-        for k in ("kernel_ms_per_step", "legs", "checks"):
+        for k in ("roofline_index", "kernel_ms_per_step", "legs", "checks"):
             line.pop(k, None)
     return line
 

@@ -413,7 +413,9 @@ void peer_publish(const PeerOwn &own, PeerBufWords &w) {
 }
 
 void peer_unmap(PeerView &v) {
-    if (v.opened && v.p) (void)hipIpcCloseMemHandle(v.p);
+    // (a close that fails must not leave its code behind as the thread's "last error": the kernels launched next -- the owner's
+    // reduction -- are followed by hipGetLastError() checks that would report it as theirs)
+    if (v.opened && v.p && hipIpcCloseMemHandle(v.p) != hipSuccess) (void)hipGetLastError();
     v = PeerView();
 }
 
@@ -605,7 +607,10 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
     // a staging buffer replaced during exchange X is mapped by nobody once every rank has arrived in X + 1's last phase (which this
     // rank has just seen): the owner's replies of X were pulled before its peers entered X + 1
     for (size_t i = 0; i < L->retired.size();) {
-        if (L->retired[i].second < E) { (void)hipFree(L->retired[i].first); L->retired.erase(L->retired.begin() + i); }
+        if (L->retired[i].second < E) {
+            if (hipFree(L->retired[i].first) != hipSuccess) (void)hipGetLastError();
+            L->retired.erase(L->retired.begin() + i);
+        }
         else i++;
     }
     MDBG_DBG(ctx, "shard_exchange: done");

@@ -1634,21 +1634,32 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
         if ((rc = d_qtab.alloc(ctx, QBINS)) || (rc = d_slo.alloc(ctx, n)) || (rc = d_shi.alloc(ctx, n))) return fail(rc);
         if ((e = memcpy_sync(ctx, d_qtab.p, tsh.data(), QBINS * 8, hipMemcpyHostToDevice)) != hipSuccess)
             return fail(set_error(ctx, MDBG_EHIP, "quality table upload failed: %s", hipGetErrorString(e)));
-        // The sums run in front of the scan; their way to the host (side stream, pinned memory) and the host's share
-        // (quality_finish) overlap the scan kernel: nothing of the mean quality is needed before the rows are counted
-        {
-            LaunchTimer timer(ctx, "quality_sum");
-            unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 8u);
-            hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_qual.p, reads->d_qual_off.p,
-                               reads->d_len.p, n, d_qtab.p, d_slo.p, d_shi.p);
-        }
+        // The sums run BESIDE the scan, on the side stream (round 5; until then in front of it, on the context's stream: 61 ms of a 0.52 s
+        // pass over 200 Gbp of ONT reads): they are a second pass over the quality bytes at 3 TB/s -- memory traffic the VALU-bound scan
+        // leaves idle -- in blocks of 768 bytes of LDS that fit beside the scan's.  Their way to the host (pinned memory) and the host's share
+        // (quality_finish) follow on the same stream: nothing of the mean quality is needed before the rows are counted.
+        // ("scan_quality_stream" 0: in front of the scan as before, A/B.)
         if ((rc = pinned_reserve(ctx, (size_t)n * 20))) return fail(rc);
         {
-            hipEvent_t summed;
-            if ((e = hipEventCreateWithFlags(&summed, hipEventDisableTiming)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "hipEventCreate: %s", hipGetErrorString(e)));
-            (void)hipEventRecord(summed, ctx->stream);
-            (void)hipStreamWaitEvent(ctx->side_stream, summed, 0);
-            (void)hipEventDestroy(summed);
+            const bool beside = ctx->scan_quality_beside != 0;
+            hipStream_t qs = beside ? ctx->side_stream : ctx->stream;
+            hipEvent_t ev;
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(set_error(ctx, MDBG_EHIP, "hipEventCreate: %s", hipGetErrorString(e)));
+            if (beside) {                                   // behind whatever the context's stream has queued so far (the reads, the table upload)
+                (void)hipEventRecord(ev, ctx->stream);
+                (void)hipStreamWaitEvent(ctx->side_stream, ev, 0);
+            }
+            {
+                LaunchTimer timer(ctx, "quality_sum", qs);
+                unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 8u);
+                hipLaunchKernelGGL(quality_sum_kernel, dim3(blocks), dim3(256), 0, qs, reads->d_qual.p, reads->d_qual_off.p,
+                                   reads->d_len.p, n, d_qtab.p, d_slo.p, d_shi.p);
+            }
+            if (!beside) {
+                (void)hipEventRecord(ev, ctx->stream);
+                (void)hipStreamWaitEvent(ctx->side_stream, ev, 0);
+            }
+            (void)hipEventDestroy(ev);
             uint8_t *h = (uint8_t *)ctx->pinned;
             if ((e = hipMemcpyAsync(h, d_slo.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->side_stream)) != hipSuccess ||
                 (e = hipMemcpyAsync(h + (size_t)n * 8, d_shi.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->side_stream)) != hipSuccess ||

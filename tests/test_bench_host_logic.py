@@ -60,7 +60,7 @@ def _canned_result(k_blocks: int = 8, note_len: int = 600) -> dict:
         "roofline_kminmer": {"bound": "hbm", "kernel": note, "achieved": 443.2, "peak": 8000.0, "unit": "GB/s", "frac": 0.0554, "traffic": 44954009668.2,
                              "traffic_over_algorithmic": 6.23, "algorithmic_bytes": 7210578340.0, "kernel_ms_total": 16.27, "note": note, "one_table_pass": {"note": note}},
         "self_check": check,
-        "roofline_index": {"per_k": {str(k): {"bound": "hbm", "achieved": 340.0, "frac": 0.0425, "ms": 19.2, "traffic": 2.0e10, "note": note} for k in range(4, 12)}},
+        "roofline_index": {"per_k": {str(k): {"bound": "hbm", "achieved": 340.0, "frac": 0.0425, "kernel_ms_total": 19.2345, "traffic": 2.0e10, "note": note} for k in range(4, 12)}},
         "roofline_ont": {"scan": {"note": note}, "kminmer": {"note": note}},
         "parity": {"reads": 1_000_000, "bases": 10 ** 10, "init_bytes_equal": True, "corrected_multiset_equal": True, "table_multiset_equal": True,
                    "abundance_checksum_equal": True, "abundance_checksum": 17724130310159059115, "against": note, "golden": {"fixture": "x", "digests_equal": True}},
@@ -98,6 +98,7 @@ def test_the_stdout_line_is_compact_and_complete():
                               "reads": 1_000_000, "against": line["parity"]["against"], "golden_digests_equal": True}
     assert line["checks"] == {"self_check": True, "multik_self_check": True, "multik_reference": True, "ont_parity": True, "ont_self_check": True}
     assert line["legs"] == {"multik_s": 0.272299, "ont_gbps": 382.7, "pcie_gbps": 199.7, "e2e_gbps": 9.55}
+    assert line["roofline_index"]["6"] == {"ms": 19.23, "frac": 0.0425, "traffic": 2.0e10} and sorted(line["roofline_index"], key=int) == [str(k) for k in range(4, 12)]
 
 
 def test_the_stdout_line_reports_broken_and_absent_legs():

@@ -238,21 +238,21 @@ import contextlib
 @contextlib.contextmanager
 def _table_form(ctx, form: str):
     """The passes above firstK in their forms (mdbg_set_option "index_table_form" / "refined_form" / "index_tuning"): "slots" -- one 32-byte
-    slot per key, two windows of a lane in flight, a slot's words in one trip, the insert's plain-load first look: the default --,
-    "slots_round4" -- the same tables with the kernels of rounds 1 - 4 --, "buckets" -- three keys per 64-byte sector, the refined pass by
-    look-ups like an index pass (measured, not faster: DESIGN.md 4.2)."""
+    slot per key, a slot's words in one trip, the insert's plain-load first look: the default --, "slots_two" -- the same with two windows of
+    a lane in flight --, "slots_round4" -- the same tables with the kernels of rounds 1 - 4 --, "buckets" -- three keys per 64-byte sector,
+    the refined pass by look-ups like an index pass (both measured, neither faster: DESIGN.md 4.2)."""
     ctx.set_option("index_table_form", 0 if form == "buckets" else 1)
     ctx.set_option("refined_form", 0 if form == "buckets" else 1)
-    ctx.set_option("index_tuning", 0 if form == "slots_round4" else 7)
+    ctx.set_option("index_tuning", {"slots_round4": 0, "slots_two": 7}.get(form, 3))
     try:
         yield
     finally:
         ctx.set_option("index_table_form", 1)
         ctx.set_option("refined_form", 1)
-        ctx.set_option("index_tuning", 7)
+        ctx.set_option("index_tuning", -1)
 
 
-@pytest.mark.parametrize("form", ["slots", "slots_round4", "buckets"])
+@pytest.mark.parametrize("form", ["slots", "slots_two", "slots_round4", "buckets"])
 @pytest.mark.parametrize("k", [5, 6, 9])
 def test_refined_and_index_vs_oracle(ctx, orc, k, form):
     rng = np.random.default_rng(300 + k)

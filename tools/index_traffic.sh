@@ -46,7 +46,7 @@ for kern, cs in per_kernel.items():
     # random 32-byte slots: FETCH_SIZE counts what was fetched (no doubling: that correction is for wide coalesced streams) -> both forms are given
     summary[kern] = {"launches": cs["FETCH_SIZE"]["launches"], "fetch_bytes": f * 1024, "write_bytes": w * 1024, "traffic_bytes_uncorrected": (f + w) * 1024,
                      "traffic_bytes_fetch_doubled": (2 * f + w) * 1024, "l2_hit_rate": hit / (hit + miss) if hit is not None and miss and hit + miss > 0 else None}
-json.dump({"round": 5, "workload": f"{n} x 10000 bp synthetic HiFi reads, loop k = 4 .. {lastk}, benchmark mode, one context alone, two loops (averages per launch over all k of a kernel)",
+json.dump({"round": 5, "reads": n, "read_len": 10000, "last_k": lastk, "workload": f"{n} x 10000 bp synthetic HiFi reads, loop k = 4 .. {lastk}, benchmark mode, one context alone, two loops (averages per launch over all k of a kernel)",
            "command": "rocprofv3 --kernel-trace --pmc <counter> (separate passes) -- python tools/index_once.py", "per_kernel": summary,
            "counters": per_kernel, "blobs": {f: blob(f"metamdbg_amd/csrc/{f}") for f in ("kminmer.hip", "table.hpp", "kminmer_dev.hpp")}},
           open(f"{out}/index_traffic.json", "w"), indent=1)
