@@ -32,6 +32,12 @@ constexpr int WAVE = 64;
 // time, so freed blocks are kept and handed out again.  Everything a context launches goes to ONE
 // stream, so reusing a block is ordered after its previous users by stream order.  The pool is shared
 // (shared_ptr) by the context and every buffer it handed out, so handles may outlive the context.
+// One lock for everything that changes the process's device address space: hipMalloc / hipFree of the pools and the peer-copy staging
+// buffers, hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle.  Several contexts are driven from several host threads; while one
+// thread's exchange opened a peer's buffer and the others' pools were still growing (the warm-up steps of an N > 1 job), one run in ten of
+// tests/test_gpu_multirank.py ended in a GPU memory access fault (round 5).  These calls are rare in steady state; taking turns costs nothing.
+inline std::mutex &hip_mem_mutex() { static std::mutex mu; return mu; }
+
 struct DevPool {
     std::mutex mu;
     std::multimap<size_t, void *> free_list;        // capacity -> block
@@ -60,10 +66,12 @@ struct DevPool {
                 return hipSuccess;
             }
         }
-        hipError_t e = hipMalloc(out, cap);
+        hipError_t e;
+        { std::lock_guard<std::mutex> g(hip_mem_mutex()); e = hipMalloc(out, cap); }
         if (e != hipSuccess) {                      // out of memory: drop the cache and retry once
             trim();
             (void)hipGetLastError();
+            std::lock_guard<std::mutex> g(hip_mem_mutex());
             e = hipMalloc(out, cap);
         }
         if (e == hipSuccess) {
@@ -80,6 +88,7 @@ struct DevPool {
         if (closed || cap == 0 || cached_bytes + cap > cache_limit) {
             if (it != capacity.end()) capacity.erase(it);
             g.unlock();
+            std::lock_guard<std::mutex> gm(hip_mem_mutex());
             (void)hipFree(p);
             return;
         }
@@ -94,6 +103,7 @@ struct DevPool {
             free_list.clear();
             cached_bytes = 0;
         }
+        std::lock_guard<std::mutex> gm(hip_mem_mutex());
         for (void *p : victims) (void)hipFree(p);
     }
     void close() { { std::lock_guard<std::mutex> g(mu); closed = true; } trim(); }
@@ -209,7 +219,7 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) { if (pool) pool->put(p); else (void)hipFree(p); }
+        if (p) { if (pool) pool->put(p); else { std::lock_guard<std::mutex> g(hip_mem_mutex()); (void)hipFree(p); } }
         p = nullptr; n = 0;
     }
     int alloc(mdbg_ctx *ctx, size_t count) {

@@ -95,6 +95,7 @@ struct PeerView {                // a peer's staging buffer as this rank reaches
     uint64_t generation = 0;
     void *p = nullptr;
     bool opened = false;         // through hipIpcOpenMemHandle (another process): to be closed
+    std::vector<void *> stale;   // mappings of buffers the peer has replaced since: closed with the communicator, not in the middle of a job
 };
 struct PeerLink {
     PeerCtl ctl;
@@ -393,11 +394,13 @@ int peer_grow(mdbg_ctx *ctx, PeerLink *L, PeerOwn &own, size_t bytes) {
     if (bytes <= own.cap) return MDBG_OK;
     const size_t cap = bytes + bytes / 4 + (1u << 20);
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, cap);
-    if (e != hipSuccess) { (void)hipGetLastError(); ctx->pool->trim(); e = hipMalloc(&p, cap); }
+    hipError_t e;
+    { std::lock_guard<std::mutex> g(hip_mem_mutex()); e = hipMalloc(&p, cap); }
+    if (e != hipSuccess) { (void)hipGetLastError(); ctx->pool->trim(); std::lock_guard<std::mutex> g(hip_mem_mutex()); e = hipMalloc(&p, cap); }
     if (e != hipSuccess) { (void)hipGetLastError(); return set_error(ctx, MDBG_ENOMEM, "peer-copy staging buffer of %zu bytes: %s", cap, hipGetErrorString(e)); }
     hipIpcMemHandle_t h{};
     if (L->ctl.n_ranks() > 1) {
+        std::lock_guard<std::mutex> g(hip_mem_mutex());
         e = hipIpcGetMemHandle(&h, p);
         if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return set_error(ctx, MDBG_EHIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
     }
@@ -412,17 +415,31 @@ void peer_publish(const PeerOwn &own, PeerBufWords &w) {
     memcpy(w.handle, &own.handle, sizeof w.handle);
 }
 
+// (a close that fails must not leave its code behind as the thread's "last error": the kernels launched next -- the owner's
+// reduction -- are followed by hipGetLastError() checks that would report it as theirs)
+void peer_close(void *p) {
+    std::lock_guard<std::mutex> g(hip_mem_mutex());
+    if (p && hipIpcCloseMemHandle(p) != hipSuccess) (void)hipGetLastError();
+}
+
+// the communicator is going: every mapping of a peer's memory this rank still holds
 void peer_unmap(PeerView &v) {
-    // (a close that fails must not leave its code behind as the thread's "last error": the kernels launched next -- the owner's
-    // reduction -- are followed by hipGetLastError() checks that would report it as theirs)
-    if (v.opened && v.p && hipIpcCloseMemHandle(v.p) != hipSuccess) (void)hipGetLastError();
+    if (v.opened) peer_close(v.p);
+    for (void *p : v.stale) peer_close(p);
     v = PeerView();
+}
+
+// the peer has replaced the buffer this view shows.  Nothing is unmapped and nothing is freed while a job runs (see exchange_peer):
+// the old mapping is set aside until the communicator goes
+void peer_set_aside(PeerView &v) {
+    if (v.opened && v.p) v.stale.push_back(v.p);
+    v.generation = 0; v.p = nullptr; v.opened = false;
 }
 
 // rank r's staging buffer as published in `w`, reachable from this rank's device
 int peer_map(mdbg_ctx *ctx, PeerLink *L, int r, const PeerBufWords &w, PeerView &v, void **out) {
     if (v.generation == w.generation && v.p) { *out = v.p; return MDBG_OK; }
-    peer_unmap(v);
+    peer_set_aside(v);
     if (w.generation == 0 || w.pointer == 0) return set_error(ctx, MDBG_EPEER, "rank %d published no staging buffer", r);
     PeerSlot *ps = L->ctl.slot(r);
     if (ps->pid == (int32_t)getpid()) {              // a thread of this process: its pointer is ours (one address space)
@@ -435,7 +452,8 @@ int peer_map(mdbg_ctx *ctx, PeerLink *L, int r, const PeerBufWords &w, PeerView 
         hipIpcMemHandle_t h;
         memcpy(&h, w.handle, sizeof h);
         void *p = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        hipError_t e;
+        { std::lock_guard<std::mutex> g(hip_mem_mutex()); e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess); }
         if (e != hipSuccess) { (void)hipGetLastError(); return set_error(ctx, MDBG_EHIP, "hipIpcOpenMemHandle (staging buffer of rank %d, pid %d, device %d): %s", r, ps->pid, ps->device, hipGetErrorString(e)); }
         v.p = p; v.opened = true;
     }
@@ -569,6 +587,8 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
     MDBG_DBG(ctx, "shard_exchange: reduced");
 
     // ---- replies back: every sender pulls, from every owner, the answers to the rows it sent there, in the order it sent them ----
+    // (what goes wrong here is told at phase 3 like everything else: nobody is left waiting there for a rank that has returned)
+    rc = MDBG_OK;
     {
         LaunchTimer timer(ctx, "shard_exchange");
         hipError_t e = hipSuccess;
@@ -576,10 +596,11 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
             e = hipMemcpyAsync(comm->replies.p + soff[me], d_reply + roff[me], got[me] * 8, hipMemcpyDeviceToDevice, ctx->stream);
             comm->bytes_local += got[me] * 8;
         }
-        for (int d = 0; d < n && e == hipSuccess; d++) {
+        for (int d = 0; d < n && e == hipSuccess && rc == MDBG_OK; d++) {
             if (d == me || s_cnt[d] == 0) continue;
             void *src = nullptr;
-            MDBG_TRY(peer_map(ctx, L, d, L->ctl.words(d, E)->replies, L->v_replies[d], &src));
+            rc = peer_map(ctx, L, d, L->ctl.words(d, E)->replies, L->v_replies[d], &src);
+            if (rc != MDBG_OK) break;
             uint64_t first = 0;                                  // owner d received the ranks' rows in rank order
             for (int r = 0; r < me; r++) first += m(r, d);
             e = hipMemcpyAsync(comm->replies.p + soff[d], (const uint64_t *)src + first, s_cnt[d] * 8, hipMemcpyDeviceToDevice, L->streams[d]);
@@ -588,31 +609,32 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
             comm->bytes_from_peers += s_cnt[d] * 8;
             comm->bytes_to_peers += got[d] * 8;
         }
-        if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "pulling the replies: %s", hipGetErrorString(e));
+        if (e != hipSuccess && rc == MDBG_OK) rc = set_error(ctx, MDBG_EHIP, "pulling the replies: %s", hipGetErrorString(e));
     }
     for (int d = 0; d < n; d++)
         if (d != me && s_cnt[d] == 0) comm->bytes_to_peers += got[d] * 8;
-    if (ctx->test_corrupt_replies && n_sent) {      // tests: the global count of one key this rank was told to LIST is off by one
+    {
+        const hipError_t e = hipStreamSynchronize(ctx->stream);          // every pull of this rank has landed
+        if (e != hipSuccess && rc == MDBG_OK) rc = set_error(ctx, MDBG_EHIP, "pulling the replies: %s", hipGetErrorString(e));
+    }
+    if (rc == MDBG_OK && ctx->test_corrupt_replies && n_sent) {      // tests: the global count of one key this rank was told to LIST is off by one
         ctx->test_corrupt_replies = false;
         std::vector<uint64_t> h(n_sent);
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h.data(), comm->replies.p, n_sent * 8, hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < n_sent; i++)
+        hipError_t e = memcpy_sync(ctx, h.data(), comm->replies.p, n_sent * 8, hipMemcpyDeviceToHost);
+        for (uint64_t i = 0; i < n_sent && e == hipSuccess; i++)
             if (h[i] >> 63) {
                 h[i] += 1;
-                MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, comm->replies.p + i, &h[i], 8, hipMemcpyHostToDevice));
+                e = memcpy_sync(ctx, comm->replies.p + i, &h[i], 8, hipMemcpyHostToDevice);
                 break;
             }
+        if (e != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "test_corrupt_replies: %s", hipGetErrorString(e));
     }
-    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // a staging buffer replaced during exchange X is mapped by nobody once every rank has arrived in X + 1's last phase (which this
-    // rank has just seen): the owner's replies of X were pulled before its peers entered X + 1
-    for (size_t i = 0; i < L->retired.size();) {
-        if (L->retired[i].second < E) {
-            if (hipFree(L->retired[i].first) != hipSuccess) (void)hipGetLastError();
-            L->retired.erase(L->retired.begin() + i);
-        }
-        else i++;
-    }
+    // ---- phase 3: everybody has pulled its replies.  Until here a peer may still be reading this rank's staging buffers; behind it
+    // nobody reads anything of this exchange any more, whatever a rank does next (the next exchange, another communicator's, leaving).
+    // Replaced staging buffers (L->retired) and the peers' mappings of theirs (PeerView::stale) are NOT released on the way: a staging
+    // buffer grows a handful of times in a job's life (by a quarter each time), and unmapping or freeing memory other processes have
+    // mapped, in the middle of a run, buys nothing worth the ways it can go wrong -- they go with the communicator (peer_teardown).
+    MDBG_TRY(peer_phase(ctx, comm, E, 3, rc, "pulling its replies"));
     MDBG_DBG(ctx, "shard_exchange: done");
     comm->n_exchanges++;
     comm->exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
@@ -633,9 +655,12 @@ void peer_teardown(mdbg_comm *c) {
     }
     for (hipStream_t s : L->streams) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : L->events) if (e) (void)hipEventDestroy(e);
-    for (auto &r : L->retired) (void)hipFree(r.first);
-    if (L->rows.p) (void)hipFree(L->rows.p);
-    if (L->replies.p) (void)hipFree(L->replies.p);
+    {
+        std::lock_guard<std::mutex> g(hip_mem_mutex());
+        for (auto &r : L->retired) (void)hipFree(r.first);
+        if (L->rows.p) (void)hipFree(L->rows.p);
+        if (L->replies.p) (void)hipFree(L->replies.p);
+    }
     L->test_reply.release();
     L->ctl.detach();
     c->link.reset();

@@ -37,7 +37,7 @@
 namespace mdbg {
 
 constexpr int PEER_MAX_RANKS = 64;
-constexpr int PEER_PHASES = 3;           // per exchange: counts known / buffers ready, rows staged / rows pulled, replies staged
+constexpr int PEER_PHASES = 4;           // per exchange: counts known, rows staged + buffers ready, rows summed + replies staged, replies pulled
 constexpr uint32_t PEER_MAGIC = 0x4d444247u;
 
 // a staging buffer as its owner publishes it
