@@ -1,5 +1,6 @@
 """BASELINE.json configs[2]'s loop k = 4 .. 11 at configs[1]'s size (1 M x 10 kb HiFi reads), beyond what the reference can be run on
-inside a test: (1) shard invariance at every k -- the table of the whole set against the union of the shares of its two halves,
+inside a test -- (3) below ties every one of these tables to digests of the reference's own, made in the build container --:
+(1) shard invariance at every k -- the table of the whole set against the union of the shares of its two halves,
 through the library's sharded passes and its exchange on the device (bench.shard_self_check: counts and the four sums of
 mdbg_table_checksum, sums[0] being the checksum the reference logs, graph/CreateMdbg.cpp:3321); (2) the oracle on the first 2 000
 reads' windows at every k > 4 against the WHOLE set's tables: the abundance of a k-min-mer there is a function of its identity and of
@@ -44,12 +45,29 @@ def test_multik_tables_at_one_million_reads(ctx):
         r = bench.shard_self_check(ctx, corr, list(range(4, last_k + 1)), n_shards=shards)
         assert r["all_equal"], r
         assert r["per_k"]["4"]["records"] == 1_080_243 and r["per_k"]["4"]["solid"] == 1_064_017       # tests/golden/hifi_1m: the reference's own counts
-    # (2) the oracle on the first reads against the whole set's tables
+    # (2) the oracle on the first reads against the whole set's tables, and (3) every table whole against THE REFERENCE: the digests of what
+    # its own `graph` wrote at k = 4 .. 11 on this read set in the same mode (tests/golden/hifi_1m/manifest.json "multik", made by
+    # tests/golden/make_golden.py --only-1m --multik: the previous table is the reference's own table of k - 1, no unitigs) -- record count,
+    # sha256 of the sorted 20-byte records (of the sorted vectors at k <= 5), the checksum the reference logs, the sum of abundances
+    import json
+    from metamdbg_amd import formats
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hifi_1m", "manifest.json")))["multik"]["per_k"]
+
+    def assert_reference_digests(table, k):
+        rec, vec = table.to_host()
+        g = golden[str(k)]
+        assert len(rec) == g["n_records"] and int(rec["abundance"].astype(np.uint64).sum()) == g["sum_abundance"], k
+        assert table.checksum()[0] == g["abundance_checksum"], k
+        mine = formats.table_digests(rec, vec.astype("<u4").tobytes() if "min_sorted_sha256" in g else None, k)
+        assert mine == {key: g[key] for key in mine}, k
+
     head = ctx.minimizers_slice(corr, 0, n_sample).to_host(full=False)
     m, off = head["minimizers"], head["offsets"].astype(np.int64)
     prev = ctx.kminmer_count_first(corr, 4, 0)
+    assert_reference_digests(prev, 4)
     for k in range(5, last_k + 1):
         whole = ctx.kminmer_count_refined(corr, None, k, prev) if k == 5 else ctx.kminmer_index(corr, None, k, prev)
+        assert_reference_digests(whole, k)
         pa = orc.PrevAbundance(prev.to_host()[0].tobytes())
         exp = (orc.kminmer_count_refined if k == 5 else orc.kminmer_index)(m, head["offsets"], k, pa)
         assert exp["n"] > 1000, (k, exp["n"])
