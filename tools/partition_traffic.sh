@@ -44,7 +44,7 @@ fetch_kb, write_kb = tot.get("FETCH_SIZE", 0.0) / passes, tot.get("WRITE_SIZE", 
 # FETCH_SIZE on gfx950 tallies a wide coalesced read request at 64 B where 128 B travel (the guide's HBM section): doubled, which
 # over-counts narrower requests -- an upper bound of the pass's read traffic; WRITE_SIZE as reported
 traffic = fetch_kb * 1024 * 2.0 + write_kb * 1024
-json.dump({"round": 4, "kernels": "k = 4 first pass (csrc/partition.hip): every kernel between mark_starts and emit_rescued_p, incl. memsets and prefix scans",
+json.dump({"round": 5, "kernels": "k = 4 first pass (csrc/partition.hip): every kernel between mark_starts and emit_rescued_p, incl. memsets and prefix scans",
            "workload": f"{n} x 10000 bp synthetic HiFi reads, one pass, one context alone", "reads": n, "read_len": 10000,
            "command": "rocprofv3 --kernel-trace --pmc <counter> (separate passes) -- python tools/insert_once.py", "passes_summed": passes,
            "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "gfx950_fetch_correction": 2.0, "traffic_bytes_per_pass": traffic,
