@@ -75,6 +75,15 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
  *                           hash and confirms each with the full hash; a read with a false candidate is re-run.  False
  *                           candidates occur about once in 2^31 positions; this widens the test (units of 2^32 of the
  *                           hash range) so that the re-run path can be exercised.  Default 0; results never depend on it
+ *   "index_tuning"          the passes above firstK over the one-slot tables (bits; default 3; negative: the default): 1 = a slot's key and
+ *                           value fetched in one trip, 2 = the insert first looks at a window's home slot with plain loads (a key found
+ *                           there is done without an atomic), 4 = two windows of a lane in flight (measured: no gain); 0 = the kernels
+ *                           of rounds 1 - 4.  Results never depend on it
+ *   "index_table_form"      0 = those passes over bucket tables (three keys per 64-byte sector: a third of the bytes, measured no
+ *                           faster), 1 or negative = one 32-byte slot per key (default)
+ *   "refined_form"          0 = k = firstK+1 done like an index pass (a look-up per (k-1)-window; measured slower), 1 or negative =
+ *                           every distinct key first, then two look-ups per key (default)
+ *   "scan_quality_stream"   FASTQ: 1 (default) = the per-read quality sums run beside the scan kernel on a side stream, 0 = in front of it
  *   "test_exchange_fail_phase"  tests only: this rank fails inside the next mdbg_shard_exchange before the counts travel (1),
  *                           when the receive buffers are allocated (2) or in the owner's reduction (3); one-shot
  *   "test_corrupt_replies"  tests only: the next exchange hands back one reply with a wrong count; one-shot

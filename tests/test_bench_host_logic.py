@@ -129,3 +129,29 @@ def test_emit_writes_the_detail_file_and_one_line(tmp_path):
     detail = json.load(open(tmp_path / "bench_detail.json"))
     assert detail["legs"]["multik"]["self_check"]["per_k"]["4"]["records"] == 11463338
     assert "[bench] full result: {" in r.stderr
+
+
+def test_counter_traffic_is_reported_only_for_the_sources_it_was_collected_on(tmp_path, monkeypatch):
+    """roofline_index.per_k.*.traffic comes from profiles/*_index_traffic.json (tools/index_traffic.sh) and only when the file's git blob
+    hashes are those of the tree's csrc/kminmer.hip, table.hpp and kminmer_dev.hpp: a collection made on another version of the kernels is
+    not reported (None, with the reason)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    here = {f: bench.git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", f)) for f in ("kminmer.hip", "table.hpp", "kminmer_dev.hpp")}
+    per_kernel = {"_ZN4mdbg23prev_abundance_u_kernelILi1ELb1EEE": {"traffic_bytes_uncorrected": 26.0e9}, "_ZN4mdbg21index_insert_u_kernelILi1ELb1EEE": {"traffic_bytes_uncorrected": 20.0e9},
+                  "_ZN4mdbg24distinct_insert_u_kernelILi1ELb1EEE": {"traffic_bytes_uncorrected": 30.0e9}, "_ZN4mdbg19refine_slots_kernelE": {"traffic_bytes_uncorrected": 5.0e9},
+                  "_ZN4mdbg16slot_flag_kernelE": {"traffic_bytes_uncorrected": 1.9e9}}
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "metamdbg_amd" / "csrc")
+    for f in here:
+        (tmp_path / "metamdbg_amd" / "csrc" / f).write_bytes(open(os.path.join(ROOT, "metamdbg_amd", "csrc", f), "rb").read())
+    assert bench.index_traffic(10_000_000, 10_000) == (None, "no PMC collection for this workload under profiles/")
+    (prof / "x_index_traffic.json").write_text(json.dumps({"reads": 10_000_000, "read_len": 10_000, "blobs": dict(here, **{"kminmer.hip": "0" * 40}), "per_kernel": per_kernel}))
+    t, note = bench.index_traffic(10_000_000, 10_000)
+    assert t is None and "another version" in note
+    (prof / "y_index_traffic.json").write_text(json.dumps({"reads": 10_000_000, "read_len": 10_000, "blobs": here, "per_kernel": per_kernel}))
+    t, note = bench.index_traffic(10_000_000, 10_000)
+    assert t == {"refined": 35.0e9, "index": 46.0e9} and "y_index_traffic.json" in note
+    assert bench.index_traffic(1_000_000, 10_000)[0] is None
