@@ -1600,6 +1600,13 @@ def main() -> None:
         vt = [int(x) for x in vt.tolist()]
         verify = {"records": vt[0], "solid": vt[1], "minimizers": vt[2],
                   "sums": [(vt[3 + 2 * i] + (vt[4 + 2 * i] << 32)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]}
+        # every rank gives the blocks its pools keep for reuse back to the device before rank 0's pass over ALL the reads: nothing on a box
+        # with a GPU per rank, but ranks that share one (MDBG_BENCH_SHARE_GPU, the only way this path has ever run) otherwise sit on the memory
+        # that pass needs (eight ranks of 2 M reads on one MI355X: "out of memory" in the verification, round 5)
+        for c, _ in slots:
+            c.set_option("pool_trim", 1)
+        torch.cuda.synchronize()
+        dist.barrier()
     n_min, ti = results[n_warm + args.steps - 1]
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     totals = torch.tensor([ti["n_records"], ti["n_solid"]], dtype=torch.int64, device="cuda")   # last step, summed over ranks

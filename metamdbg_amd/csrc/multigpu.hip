@@ -389,7 +389,7 @@ double peer_timeout_s() {
     return 120.0;
 }
 
-// this rank's staging buffer holds at least `bytes`; a replaced buffer stays alive until no peer can have it mapped any more
+// this rank's staging buffer holds at least `bytes`; a replaced buffer stays alive until the communicator goes (L->retired)
 int peer_grow(mdbg_ctx *ctx, PeerLink *L, PeerOwn &own, size_t bytes) {
     if (bytes <= own.cap) return MDBG_OK;
     const size_t cap = bytes + bytes / 4 + (1u << 20);
