@@ -77,7 +77,8 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
  *                           hash range) so that the re-run path can be exercised.  Default 0; results never depend on it
  *   "index_tuning"          the passes above firstK over the one-slot tables (bits; default 3; negative: the default): 1 = a slot's key and
  *                           value fetched in one trip, 2 = the insert first looks at a window's home slot with plain loads (a key found
- *                           there is done without an atomic), 4 = two windows of a lane in flight (measured: no gain); 0 = the kernels
+ *                           there is done without an atomic), 4 = two windows of a lane in flight (measured: no gain), 8 = look-up and
+ *                           insert in one kernel (measured: slower); 0 = the kernels
  *                           of rounds 1 - 4.  Results never depend on it
  *   "index_table_form"      0 = those passes over bucket tables (three keys per 64-byte sector: a third of the bytes, measured no
  *                           faster), 1 or negative = one 32-byte slot per key (default)

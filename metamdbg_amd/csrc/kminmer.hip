@@ -481,6 +481,49 @@ __global__ __launch_bounds__(256) void index_insert_u_kernel(SeqView s /* k */, 
     }
 }
 
+// Look-up and insert in ONE kernel (round 5, "index_tuning" bit 3).  The two-kernel form writes the abundance of every (k-1)-window to HBM and
+// reads it back twice (12 bytes per instance, 4 GB a pass at 10 M reads) only to hand a value to the lane next door.  Here the 16 lanes of a
+// sequence take 16 consecutive (k-1)-windows, each looks its own up, a lane gets its right neighbour's answer by a DPP move inside the row of
+// 16 (row_shl:1), and lanes 0 .. 14 insert the k-window that starts where their (k-1)-window does; the group advances by 15, so one look-up
+// in sixteen is made twice.  No instance index at k - 1, no intermediate array.  (The 16 lanes of a group run the same trip count -- one
+// sequence -- so every lane a DPP move reads from is active.)
+template <bool FAST>
+__global__ __launch_bounds__(256) void index_fused_kernel(SeqView s /* k */, uint32_t k, TableView prev, TableView t) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t trip = 0;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (t.poll_overflow && (trip++ & 31u) == 0u && __hip_atomic_load(t.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - s.inst_off[r]);       // k-windows; the sequence has n + 1 (k-1)-windows when n > 0
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 15u) {
+            const uint32_t i = i0 + sub;
+            uint32_t v = 1u;
+            if (i <= n) {                                                         // getPrevAbundances: missing => 1 (graph/CreateMdbg.hpp:1240-1265)
+                uint64_t hi, lo;
+                window_hash_uniform(m0 + i, k - 1u, hi, lo);
+                uint32_t x;
+                if (table_lookup(prev, lo, hi, x)) v = x;
+            }
+            const uint32_t vn = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)v, 0x101, 0xf, 0xf, false);      // row_shl:1: the lane above, inside the row of 16
+            if (sub < 15u && i < n) {
+                const uint32_t a = v < vn ? v : vn;
+                if (a > 1u) {
+                    uint64_t hi, lo;
+                    window_hash_uniform(m0 + i, k, hi, lo);
+                    bool there = false;
+                    if (FAST && lo != 0ull && hi != 0ull) {
+                        const SlotWords w = slot_load(&t.slots[table_home(lo, hi, t.mask)]);
+                        there = w.lo == lo && w.hi == hi;
+                    }
+                    if (!there) table_insert_once(t, lo, hi, a);
+                }
+            }
+        }
+    }
+}
+
 // the same into a bucket table; rep_base + the flat index of the window's first minimizer names the instance that published the key
 // (kept when the table keeps representatives: k = firstK + 1 writes the vectors of its rows)
 __global__ __launch_bounds__(256) void index_insert_b_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
@@ -1079,13 +1122,22 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     MDBG_TRY(build_inst_index(ctx, s, k, ik));
     n_inst += ik.total;
     if (!ik.total) return MDBG_OK;
+    // "index_tuning" (A/B): bit 0 a slot's key and value in one trip, bit 1 the plain-load first look of the insert, bit 2 two windows of
+    // a lane in flight, bit 3 look-up and insert in one kernel
+    const bool wide = ctx->index_tuning & 1u, fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u, fused = ctx->index_tuning & 8u;
+    if (fused) {
+        SeqView vk = make_view(s, ik);
+        LaunchTimer timer(ctx, "kminmer_insert");
+        const dim3 grid(instance_grid(ctx, vk.n_reads)), block(256);
+        if (fast) hipLaunchKernelGGL(index_fused_kernel<true>, grid, block, 0, ctx->stream, vk, k, pv, tv);
+        else hipLaunchKernelGGL(index_fused_kernel<false>, grid, block, 0, ctx->stream, vk, k, pv, tv);
+        MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return MDBG_OK;
+    }
     MDBG_TRY(build_inst_index(ctx, s, k - 1, ikm1));
     DevBuf<uint32_t> prev_ab;
     MDBG_TRY(prev_ab.alloc(ctx, ikm1.total));
     SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
-    // "index_tuning" (A/B): bit 0 a slot's key and value in one trip, bit 1 the plain-load first look of the insert, bit 2 two windows of
-    // a lane in flight
-    const bool wide = ctx->index_tuning & 1u, fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u;
     {
         LaunchTimer timer(ctx, "kminmer_prev_lookup");
         const dim3 grid(instance_grid(ctx, vkm1.n_reads)), block(256);

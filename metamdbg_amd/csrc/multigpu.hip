@@ -103,11 +103,10 @@ struct PeerLink {
     std::vector<PeerView> v_rows, v_replies;
     std::vector<hipStream_t> streams;        // one per peer: pulls from different peers run at once
     std::vector<hipEvent_t> events;
-    std::vector<std::pair<void *, uint64_t>> retired;   // replaced staging buffers and the exchange they were replaced in
+    std::vector<void *> retired;             // staging buffers this rank has replaced by larger ones: freed with the communicator (see exchange_peer, phase 3)
     DevBuf<uint64_t> test_reply;             // the self-test's replies
     uint64_t exchange = 0;
     double timeout_s = 120.0;
-    uint64_t regrown = 0;                    // how often a staging buffer was replaced
 };
 
 }  // namespace mdbg
@@ -404,7 +403,7 @@ int peer_grow(mdbg_ctx *ctx, PeerLink *L, PeerOwn &own, size_t bytes) {
         e = hipIpcGetMemHandle(&h, p);
         if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return set_error(ctx, MDBG_EHIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
     }
-    if (own.p) { L->retired.emplace_back(own.p, L->exchange); L->regrown++; }
+    if (own.p) L->retired.push_back(own.p);
     own.p = p; own.cap = cap; own.handle = h; own.generation++;
     return MDBG_OK;
 }
@@ -657,7 +656,7 @@ void peer_teardown(mdbg_comm *c) {
     for (hipEvent_t e : L->events) if (e) (void)hipEventDestroy(e);
     {
         std::lock_guard<std::mutex> g(hip_mem_mutex());
-        for (auto &r : L->retired) (void)hipFree(r.first);
+        for (void *r : L->retired) (void)hipFree(r);
         if (L->rows.p) (void)hipFree(L->rows.p);
         if (L->replies.p) (void)hipFree(L->replies.p);
     }
@@ -680,9 +679,6 @@ int peer_setup(mdbg_ctx *ctx, mdbg_comm *c, const uint8_t *id128) {
     PeerSlot *ps = L->ctl.mine();
     ps->pid = (int32_t)getpid();
     ps->device = ctx->device;
-    char bus[32] = {0};
-    if (hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
-    memcpy(ps->bus_id, bus, sizeof ps->bus_id);
     L->ctl.arrive(PeerCtl::TICK_ATTACHED);
     const int late = L->ctl.wait_all(PeerCtl::TICK_ATTACHED, setup_s);
     L->ctl.unlink_name();

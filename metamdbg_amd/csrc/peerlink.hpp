@@ -59,8 +59,7 @@ struct PeerWords {
 struct alignas(64) PeerSlot {
     std::atomic<uint64_t> tick;          // the last phase this rank has arrived at (monotonic; see PeerCtl::tick_of); TICK_CLOSING when it leaves
     std::atomic<uint64_t> reached;       // the last phase of an exchange it arrived at (what `tick` was before it left)
-    int32_t pid, device;                 // written before the attach tick
-    char bus_id[32];                     // PCI address of its device ("" unknown): two ranks with the same share a GPU
+    int32_t pid, device;                 // written before the attach tick: ranks with the same pid are threads of one process (plain pointers)
     PeerWords words[2];
 };
 
@@ -96,7 +95,7 @@ class PeerCtl {
     }
 
     // Collective: rank 0 creates and initialises the block, the others wait for it to appear; returns "" or what went wrong.
-    // Every rank must still call arrive_attached() + wait_all(TICK_ATTACHED) (after filling its identity) before anything else.
+    // Every rank then fills its identity, calls arrive(TICK_ATTACHED) and wait_all(TICK_ATTACHED) before anything else.
     std::string attach(const std::string &name, int rank, int n_ranks, double timeout_s) {
         detach();
         if (n_ranks < 1 || n_ranks > PEER_MAX_RANKS || rank < 0 || rank >= n_ranks) return "bad rank / rank count";

@@ -238,12 +238,13 @@ import contextlib
 @contextlib.contextmanager
 def _table_form(ctx, form: str):
     """The passes above firstK in their forms (mdbg_set_option "index_table_form" / "refined_form" / "index_tuning"): "slots" -- one 32-byte
-    slot per key, a slot's words in one trip, the insert's plain-load first look: the default --, "slots_two" -- the same with two windows of
-    a lane in flight --, "slots_round4" -- the same tables with the kernels of rounds 1 - 4 --, "buckets" -- three keys per 64-byte sector,
+    slot per key with the library's default tuning --, "slots_fused" / "slots_two_kernels" -- look-up and insert in one kernel (the neighbour's
+    abundance by a DPP move) or in two with an array in between, both with a slot's words in one trip and the insert's plain-load first look --,
+    "slots_two" -- two windows of a lane in flight --, "slots_round4" -- the same tables with the kernels of rounds 1 - 4 --, "buckets" -- three keys per 64-byte sector,
     the refined pass by look-ups like an index pass (both measured, neither faster: DESIGN.md 4.2)."""
     ctx.set_option("index_table_form", 0 if form == "buckets" else 1)
     ctx.set_option("refined_form", 0 if form == "buckets" else 1)
-    ctx.set_option("index_tuning", {"slots_round4": 0, "slots_two": 7}.get(form, 3))
+    ctx.set_option("index_tuning", {"slots_round4": 0, "slots_two": 7, "slots_fused": 11, "slots_two_kernels": 3}.get(form, -1))
     try:
         yield
     finally:
@@ -252,7 +253,7 @@ def _table_form(ctx, form: str):
         ctx.set_option("index_tuning", -1)
 
 
-@pytest.mark.parametrize("form", ["slots", "slots_two", "slots_round4", "buckets"])
+@pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two_kernels", "slots_two", "slots_round4", "buckets"])
 @pytest.mark.parametrize("k", [5, 6, 9])
 def test_refined_and_index_vs_oracle(ctx, orc, k, form):
     rng = np.random.default_rng(300 + k)
@@ -827,7 +828,7 @@ def _multik_cases():
     return [(s, k) for s in mk.SETS for k in mk.steps(s)]
 
 
-@pytest.mark.parametrize("form", ["slots", "slots_round4", "buckets"])
+@pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two_kernels", "slots_round4", "buckets"])
 @pytest.mark.parametrize("name,k", _multik_cases())
 def test_next_k_tables_equal_reference_multik(ctx, name, k, form):
     """Rows A13 / A14 against the REFERENCE: previous table + unitig overlay, refined count (k = firstK+1), index

@@ -20,8 +20,9 @@ corr = ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=True), 4, 
 reads.free()
 names = ("kminmer_split", "kminmer_prev_lookup", "kminmer_prev_image", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
 out = {"reads": n, "forms": {}}
-# (form, index_table_form, refined_form, index_tuning): tuning bit 0 a slot's words in one trip, bit 1 the insert's plain-load first look, bit 2 two windows in flight
+# (form, index_table_form, refined_form, index_tuning): tuning bit 0 a slot's words in one trip, bit 1 the insert's plain-load first look, bit 2 two windows in flight, bit 3 look-up and insert in one kernel
 FORMS = (("slots_round4_kernels", 1, 1, 0), ("slots_wide", 1, 1, 1), ("slots_wide_fast", 1, 1, 3), ("slots_two_in_flight", 1, 1, 4), ("slots_all", 1, 1, 7),
+         ("slots_fused", 1, 1, 11), ("slots_fused_without_the_first_look", 1, 1, 9),
          ("buckets", 0, 0, 7), ("buckets_refined_by_distinct_keys", 0, 1, 7))
 for form, idx, ref, tune in FORMS:
     ctx.set_option("index_table_form", idx)
