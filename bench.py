@@ -1567,8 +1567,9 @@ def main() -> None:
         if comms is not None:
             st = [cm.stats() for cm in comms]
             return {"to_peers": sum(x["bytes_to_peers"] for x in st), "exchanges": sum(x["exchanges"] for x in st),
-                    "ms": sum(x["exchange_ms"] for x in st), "rccl_ranks": st[0]["rccl_ranks"] if st[0]["mode"] == "rccl" else None}
-        return dict(wire, rccl_ranks=None)
+                    "ms": sum(x["exchange_ms"] for x in st), "rccl_ranks": st[0]["rccl_ranks"] if st[0]["mode"] == "rccl" else None,
+                    "reduce_ms": sum(x["reduce_ms"] for x in st), "wait_ms": sum(x["wait_ms"] for x in st), "host_ms": sum(x["host_ms"] for x in st)}
+        return dict(wire, rccl_ranks=None, reduce_ms=None, wait_ms=None, host_ms=None)
 
     for c, _ in slots:
         c.timing(True)
@@ -1653,6 +1654,9 @@ def main() -> None:
                 "wire_bytes_per_step": int(et[0].item()) / args.steps, "wire_bytes_per_step_per_rank": int(et[0].item()) / args.steps / world,
                 "exchanges_timed": int(et[1].item()),
                 "exchange_ms_per_step": float(em.item()) / args.steps,
+                # rank 0's account of that time (peer copies): the owner's reduction (device work), waiting for its own copies and its peers' phases,
+                # and what is left -- the transport's own host time
+                "exchange_ms_per_step_rank0": {k: (acct1[k] - acct0[k]) / args.steps for k in ("reduce_ms", "wait_ms", "host_ms")} if acct1.get("host_ms") is not None else None,
                 "note": "wire bytes = rows to their owners (24 B each) + one u64 reply per row, other ranks only (a rank's own share is a "
                         "device-to-device copy); exchange_ms = host time inside the exchange call incl. waiting for the slowest rank, "
                         "max over ranks; " + ("an exchange waits for the scans in flight on its rank and holds new ones back (gate: RCCL's "

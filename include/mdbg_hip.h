@@ -433,6 +433,10 @@ void mdbg_comm_destroy(mdbg_comm *comm);
  * rank's own share (device-to-device copies, never on the wire), [7] = ncclCommUserRank; *exchange_ms (may be NULL) = host wall
  * time spent inside mdbg_shard_exchange. */
 int  mdbg_comm_stats(const mdbg_comm *comm, uint64_t stats[8], double *exchange_ms);
+/* Where the time inside mdbg_shard_exchange went (peer copies; RCCL reports [1] = [2] = 0): ms[0] = the whole call (= *exchange_ms above),
+ * ms[1] = the owner's reduction (mdbg_shard_reduce: this rank's device work), ms[2] = waiting -- for this rank's own copies to land and
+ * for its peers to reach a phase.  ms[0] - ms[1] - ms[2] is the transport's own host time. */
+int  mdbg_comm_times(const mdbg_comm *comm, double ms[3]);
 int  mdbg_kminmer_count_first_sharded(mdbg_ctx *ctx, mdbg_comm *comm, const mdbg_minimizers *reads, uint32_t k,
                                       uint32_t min_abundance, mdbg_table **out);
 /* The collective middle part alone, between mdbg_shard_begin and mdbg_shard_finish (a caller with several batches in flight

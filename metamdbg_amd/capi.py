@@ -109,6 +109,7 @@ SIGNATURES = {
     "mdbg_comm_create_mode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "mdbg_comm_mode": (C.c_int, [_P]),
     "mdbg_comm_note": (C.c_char_p, [_P]),
+    "mdbg_comm_times": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "mdbg_comm_adopt": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "mdbg_comm_destroy": (None, [_P]),
     "mdbg_comm_stats": (C.c_int, [_P, _u64p, C.POINTER(C.c_double)]),
@@ -435,7 +436,13 @@ class Comm:
         ms = C.c_double()
         lib().mdbg_comm_stats(self.h, st, C.byref(ms))
         return dict(rank=int(st[0]), n_ranks=int(st[1]), rccl_ranks=int(st[2]), exchanges=int(st[3]), bytes_to_peers=int(st[4]),
-                    bytes_from_peers=int(st[5]), bytes_local=int(st[6]), exchange_ms=float(ms.value), mode=self.mode)
+                    bytes_from_peers=int(st[5]), bytes_local=int(st[6]), exchange_ms=float(ms.value), mode=self.mode, **self.times())
+
+    def times(self) -> dict:
+        """Where the time inside the exchanges went (mdbg_comm_times): the owner's reduction, waiting, and what is left: the transport's host time."""
+        t = (C.c_double * 3)()
+        lib().mdbg_comm_times(self.h, t)
+        return dict(reduce_ms=float(t[1]), wait_ms=float(t[2]), host_ms=max(0.0, float(t[0]) - float(t[1]) - float(t[2])))
 
     def abort(self, ctx: "Context", code: int = -1) -> None:
         """This rank cannot enter the exchange its peers are about to enter: tell them (mdbg_shard_abort)."""

@@ -128,7 +128,19 @@ struct mdbg_comm {
     // mdbg_comm_stats
     uint64_t n_exchanges = 0, bytes_to_peers = 0, bytes_from_peers = 0, bytes_local = 0;
     double exchange_ms = 0.0;    // host wall time inside mdbg_shard_exchange (includes waiting for the slowest peer)
+    // ... of which (peer copies): the owner's reduction (mdbg_shard_reduce: device work of this rank, with its own waits) and the waits
+    // for this rank's copies and for its peers' phases; what is left is the transport's own host time (mdbg_comm_times)
+    double reduce_ms = 0.0, wait_ms = 0.0;
 };
+
+namespace {
+struct MsInto {                  // adds the scope's wall time to a counter
+    double &to;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit MsInto(double &d) : to(d) {}
+    ~MsInto() { to += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 #define MDBG_NCCL_CHECK(ctx, api, expr)                                                                                   \
     do {                                                                                                                  \
@@ -468,7 +480,8 @@ int peer_phase(mdbg_ctx *ctx, mdbg_comm *comm, uint64_t E, int phase, int rc, co
     PeerLink *L = comm->link.get();
     L->ctl.words(comm->rank, E)->status[phase] = rc;
     L->ctl.arrive(PeerCtl::tick_of(E, phase));
-    const int late = L->ctl.wait_all(PeerCtl::tick_of(E, phase), L->timeout_s);
+    int late;
+    { MsInto w(comm->wait_ms); late = L->ctl.wait_all(PeerCtl::tick_of(E, phase), L->timeout_s); }
     if (late >= 0) {
         comm->broken = true;
         const std::string own = rc != MDBG_OK ? ctx->err : "";
@@ -538,7 +551,7 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
         if (soff[me]) e = hipMemcpyAsync(L->rows.p, d_rows, soff[me] * rw * 8, hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess && n_sent > soff[me + 1])
             e = hipMemcpyAsync((uint64_t *)L->rows.p + soff[me + 1] * rw, d_rows + soff[me + 1] * rw, (n_sent - soff[me + 1]) * rw * 8, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) { MsInto w(comm->wait_ms); e = hipStreamSynchronize(ctx->stream); }
         if (e != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "staging the rows: %s", hipGetErrorString(e));
     }
     peer_publish(L->replies, mine->replies);
@@ -572,12 +585,12 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
         if (r != me && got[r] == 0) comm->bytes_to_peers += s_cnt[r] * rw * 8;
     // ---- the owner sums and answers; the replies are staged ----
     const uint64_t *d_reply = nullptr;
-    if (rc == MDBG_OK) rc = reduce(d_recv.p, n_recv, &d_reply);
+    if (rc == MDBG_OK) { MsInto w(comm->reduce_ms); rc = reduce(d_recv.p, n_recv, &d_reply); }
     if (fail_phase == 3 && rc == MDBG_OK) rc = set_error(ctx, MDBG_EHIP, "mdbg_shard_exchange: test failure in the reduction");
     if (rc == MDBG_OK) {
         hipError_t e = hipSuccess;
         if (n_recv - got[me] > 0) e = hipMemcpyAsync(L->replies.p, d_reply, n_recv * 8, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (also: every pull of this rank has landed)
+        if (e == hipSuccess) { MsInto w(comm->wait_ms); e = hipStreamSynchronize(ctx->stream); }          // (also: every pull of this rank has landed)
         if (e != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "staging the replies: %s", hipGetErrorString(e));
     } else {
         (void)hipStreamSynchronize(ctx->stream);
@@ -613,7 +626,8 @@ int exchange_peer(mdbg_ctx *ctx, mdbg_comm *comm, const uint64_t *d_rows, const 
     for (int d = 0; d < n; d++)
         if (d != me && s_cnt[d] == 0) comm->bytes_to_peers += got[d] * 8;
     {
-        const hipError_t e = hipStreamSynchronize(ctx->stream);          // every pull of this rank has landed
+        hipError_t e;
+        { MsInto w(comm->wait_ms); e = hipStreamSynchronize(ctx->stream); }          // every pull of this rank has landed
         if (e != hipSuccess && rc == MDBG_OK) rc = set_error(ctx, MDBG_EHIP, "pulling the replies: %s", hipGetErrorString(e));
     }
     if (rc == MDBG_OK && ctx->test_corrupt_replies && n_sent) {      // tests: the global count of one key this rank was told to LIST is off by one
@@ -749,7 +763,8 @@ int peer_self_test(mdbg_ctx *ctx, mdbg_comm *c) {
     const uint64_t *unused = nullptr;
     rc = exchange_peer(ctx, c, nullptr, none, &unused, said, [](const uint64_t *, uint64_t, const uint64_t **r) { *r = nullptr; return MDBG_OK; });
     if (said != MDBG_OK) ctx->err = keep;
-    c->n_exchanges = 0; c->bytes_to_peers = c->bytes_from_peers = c->bytes_local = 0; c->exchange_ms = 0.0;      // the job's account starts here
+    c->n_exchanges = 0; c->bytes_to_peers = c->bytes_from_peers = c->bytes_local = 0;      // the job's account starts here
+    c->exchange_ms = c->reduce_ms = c->wait_ms = 0.0;
     return rc;
 }
 
@@ -857,6 +872,12 @@ extern "C" int mdbg_comm_create(mdbg_ctx *ctx, const uint8_t *id128, int rank, i
 }
 
 extern "C" int mdbg_comm_mode(const mdbg_comm *c) { return c ? c->mode : MDBG_EINVAL; }
+
+extern "C" int mdbg_comm_times(const mdbg_comm *c, double ms[3]) {
+    if (!c || !ms) return MDBG_EINVAL;
+    ms[0] = c->exchange_ms; ms[1] = c->reduce_ms; ms[2] = c->wait_ms;
+    return MDBG_OK;
+}
 
 extern "C" const char *mdbg_comm_note(const mdbg_comm *c) { return c ? c->fallback_note.c_str() : ""; }
 

@@ -179,5 +179,6 @@ int mdbg_comm_create(mdbg_ctx *, const uint8_t *, int, int, mdbg_comm **) { retu
 int mdbg_comm_create_mode(mdbg_ctx *, const uint8_t *, int, int, int, mdbg_comm **) { return MDBG_ENODEV; }
 int mdbg_comm_mode(const mdbg_comm *) { return MDBG_COMM_RCCL; }
 const char *mdbg_comm_note(const mdbg_comm *) { return ""; }
+int mdbg_comm_times(const mdbg_comm *, double *) { return MDBG_ENODEV; }
 void mdbg_comm_destroy(mdbg_comm *c) { delete c; }
 }
