@@ -13,6 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from metamdbg_amd import capi, synth  # noqa: E402
 
+t_start = time.time()
 rank, n_ranks, id_file, out, n_total = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
 mode = sys.argv[6] if len(sys.argv) > 6 else "auto"
 share = len(sys.argv) > 7 and sys.argv[7] == "1"
@@ -36,8 +37,16 @@ spec = synth.hifi_spec(n_total, seed=23, read_len=6000, coverage=25.0)
 first, last = n_total * rank // n_ranks, n_total * (rank + 1) // n_ranks         # uneven shares when n_ranks does not divide
 reads = ctx.reads_synthetic(spec, first_read=first, n_reads=last - first)
 corr = ctx.purge_palindromes(ctx.scan(reads, K=15, density=0.005, hpc=True), 4, 100)
-for _ in range(3):                       # three times: the communicator is reusable (and the words of its control block alternate)
-    rec, vec = ctx.kminmer_count_first_sharded(comm, corr, 4, 0).to_host()
+# (MDBG_TEST_DIE_BEFORE_PASS=<rank>:<pass>: that rank's process ends -- no destroy, no goodbye -- before its pass number <pass>)
+die_rank, die_pass = (int(x) for x in os.environ.get("MDBG_TEST_DIE_BEFORE_PASS", "-1:-1").split(":"))
+for n_pass in range(3):                  # three times: the communicator is reusable (and the words of its control block alternate)
+    if rank == die_rank and n_pass == die_pass:
+        os._exit(9)
+    try:
+        rec, vec = ctx.kminmer_count_first_sharded(comm, corr, 4, 0).to_host()
+    except capi.MdbgError as exc:
+        print(f"rank {rank}: pass {n_pass} failed after {time.time() - t_start:.1f} s: {exc}", file=sys.stderr, flush=True)
+        os._exit(3)
 np.save(out, rec)
 comm.destroy()
 ctx.close()

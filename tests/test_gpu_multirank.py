@@ -205,6 +205,21 @@ def test_library_peer_exchange_processes_sharing_one_gpu(tmp_path, n_ranks):
     assert _library_exchange_processes(tmp_path, n_ranks, "peer", share=True) == {"peer"}
 
 
+def test_a_rank_that_dies_ends_its_peers_at_the_deadline(tmp_path):
+    """No protocol can be agreed on with a process that is gone.  Rank 1 of 3 ends without a word before its second pass; its peers, already
+    inside that pass's exchange, wait for it at the first phase -- and return MDBG_EPEER naming it when MDBG_PEER_TIMEOUT_S has passed, instead
+    of hanging (an RCCL receive would).  The communicator is broken from then on."""
+    import time
+    env = dict(os.environ, MDBG_TEST_DIE_BEFORE_PASS="1:1", MDBG_PEER_TIMEOUT_S="4")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "comm_rank.py"), str(r), "3", str(tmp_path / "id"), str(tmp_path / f"rec{r}.npy"), "3000", "peer", "1"],
+                              cwd=ROOT, env=env, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=200) for p in procs]
+    assert [p.returncode for p in procs] == [3, 9, 3] and time.time() - t0 < 120
+    for r in (0, 2):
+        assert "pass 1 failed" in outs[r][1] and "rank 1 did not arrive" in outs[r][1] and "within 4 s" in outs[r][1], outs[r][1][-800:]
+
+
 @pytest.mark.parametrize("mode", ["rccl", "peer", "auto"])
 def test_library_exchange_two_gpus(tmp_path, mode):
     """Two ranks, two GPUs, the exchange over xGMI inside the library -- RCCL send / receive groups, or peer copies between the
