@@ -134,7 +134,25 @@ def run_tool(tmp_parent, inputs, threads, P, trace=True, rs_args=(), graph_args=
     t2 = time.perf_counter()
     assert r2.returncode == 0, r2.stderr[-1000:]
     sizes = {n: os.path.getsize(os.path.join(tmp, n)) for n in ("read_data_init.txt", "read_data_corrected.txt", "kminmerData_abundance.txt", "kminmerData_min.txt")}
-    return {"read_selection_s": t1 - t0, "graph_s": t2 - t1, "total_s": t2 - t0,
+    one = None
+    if graph_args == ("--min-abundance", "0", "--firstpass") and os.environ.get("MDBG_E2E_ASM_STEP", "1") == "1":
+        # ... and the two commands as ONE process (mdbg_tool asmStep: one context, the corrected minimizers handed over on the device)
+        tmp1 = os.path.join(tmp_parent, "one", "tmp")
+        for d in ("", "filter", "smallContigs", "checkpoints"):
+            os.makedirs(os.path.join(tmp1, d), exist_ok=True)
+        P.save(os.path.join(tmp1, "parameters.gz"))
+        open(os.path.join(tmp1, "input.txt"), "w").write("\n".join(inputs) + "\n")
+        t3 = time.perf_counter()
+        r3 = subprocess.run([TOOL, "asmStep", tmp1, tmp1 + "/read_data_init.txt", tmp1 + "/input.txt", "--threads", str(threads), "--min-read-quality", "0.000000",
+                             *rs_args, "--min-abundance", "0"], capture_output=True, text=True, env=env, timeout=240)
+        t4 = time.perf_counter()
+        assert r3.returncode == 0, r3.stderr[-1000:]
+        same = all(os.path.getsize(os.path.join(tmp1, n)) == v for n, v in sizes.items()) and \
+            open(os.path.join(tmp1, "read_data_init.txt"), "rb").read(1 << 24) == open(os.path.join(tmp, "read_data_init.txt"), "rb").read(1 << 24)
+        one = {"asm_step_s": t4 - t3, "output_sizes_equal_and_first_16_MB_of_read_data_init_equal": bool(same),
+               "trace": [ln.strip() for ln in r3.stderr.splitlines() if "[mdbg_tool]" in ln]}
+        shutil.rmtree(os.path.join(tmp_parent, "one"), ignore_errors=True)
+    return {"read_selection_s": t1 - t0, "graph_s": t2 - t1, "total_s": t2 - t0, "asm_step": one,
             "trace_read_selection": [ln.strip() for ln in r1.stderr.splitlines() if "[mdbg_tool]" in ln],
             "trace_graph": [ln.strip() for ln in r2.stderr.splitlines() if "[mdbg_tool]" in ln], "output_bytes": sizes}
 
