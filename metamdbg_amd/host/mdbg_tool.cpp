@@ -37,6 +37,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <dlfcn.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -57,13 +58,11 @@ namespace {
 }
 
 mdbg_ctx *g_ctx = nullptr;
+std::vector<mdbg_ctx *> g_more_ctx;      // the other consumers' contexts (readSelection)
 
 // Every output file is written and closed: the process ends here.  Tearing the HIP contexts and their memory pools down block by
 // block (mdbg_destroy) took 0.2 s of a 2.6 s run over 50 Gbp; the driver reclaims a process's device memory when it exits.
-[[noreturn]] void finish() {
-    fflush(nullptr);
-    _exit(0);
-}
+[[noreturn]] void finish();
 
 // phase timings on stderr when MDBG_TRACE is set
 struct Trace {
@@ -72,6 +71,25 @@ struct Trace {
     Trace() : t0(now()) {}
     void mark(const char *what) { if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg_tool] %8.3f s  %s\n", now() - t0, what); }
 } g_trace;
+[[noreturn]] void finish() {
+    fflush(nullptr);
+    // (measuring aid: what part of the time between "done" and the parent's wait() returning is the first context's teardown)
+    if (const char *e = getenv("MDBG_TOOL_EXIT_TRACE")) {
+        const int how = atoi(e);       // 1: only say when; 2: the first context destroyed first; 3: every context; 4: hipDeviceReset; 5: idle for 0.2 s; 6: 3 + 4
+        if (g_ctx && how == 2) { mdbg_destroy(g_ctx); g_trace.mark("exit trace: the first context destroyed"); }
+        if (how == 3 || how == 6) {
+            for (mdbg_ctx *c : g_more_ctx) mdbg_destroy(c);
+            if (g_ctx) mdbg_destroy(g_ctx);
+            g_trace.mark("exit trace: every context destroyed");
+        }
+        if (how == 4 || how == 6) {
+            if (auto reset = (int (*)())dlsym(RTLD_DEFAULT, "hipDeviceReset")) { const int rc = reset(); g_trace.mark(rc ? "exit trace: hipDeviceReset failed" : "exit trace: hipDeviceReset"); }
+        }
+        if (how == 5) { usleep(200000); g_trace.mark("exit trace: idle for 0.2 s"); }
+        fprintf(stderr, "[mdbg_tool] exit trace: clock started at %.6f, _exit at %.6f (epoch seconds)\n", g_trace.t0, Trace::now());
+    }
+    _exit(0);
+}
 void check(int rc, const char *what) {
     if (rc != MDBG_OK) die(std::string(what) + ": " + mdbg_last_error(g_ctx));
 }
@@ -415,6 +433,7 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
         mdbg_ctx *c = nullptr;
         if (mdbg_create(i % std::max(1, a.gpus), &c) != MDBG_OK) die(std::string("mdbg_create(device ") + std::to_string(i % a.gpus) + "): " + mdbg_last_error(nullptr));
         ctxs.push_back(c);
+        g_more_ctx.push_back(c);
     }
 
     std::map<uint64_t, HostBatch *> pending;     // finished batches waiting for their turn at the writer
