@@ -419,6 +419,14 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
         }
     };
     std::vector<HostBatch *> spareBatches;        // guarded by fifoMu
+    // The purge pass copies GROUPS of batches back (see there), each into one slab several times a batch's: taking the main pass's slabs
+    // and growing them on the way (free + allocate page-locked memory, 2 - 4 ms a time) was 0.11 s of the 0.19 s the pass took over 50 Gbp.
+    // A helper allocates them beside the main pass, as soon as the first batch has shown how large a batch is.
+    constexpr size_t GROUP = 32;
+    std::vector<HostBatch *> groupSlabs;          // guarded by fifoMu
+    std::atomic<bool> groupSlabsStop{false};
+    std::thread groupSlabHelper;
+    std::once_flag groupSlabOnce;
     struct Kept { uint64_t seq; mdbg_ctx *ctx; mdbg_minimizers *mins; };
     std::vector<Kept> kept;                 // device-resident minimizer reads, purged once N50 is known
     // --gpus G: one consumer per device; batches go to the consumers in turn, every batch is scanned (and later purged) where it
@@ -628,6 +636,20 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
                     uint32_t bn; uint64_t bt;
                     mdbg_minimizers_info(mins, &bn, &bt);
                     hb->shape(bn, bt);
+                    if (needCorrected)
+                        std::call_once(groupSlabOnce, [&, bn, bt] {
+                            // a consumer's share of a group (batches are handed out as consumers come free: a little more than GROUP / consumers)
+                            const size_t share = GROUP / (size_t)nConsumers + 2;
+                            const uint64_t rn = (uint64_t)share * bn, rt = (uint64_t)share * bt;
+                            groupSlabHelper = std::thread([&, rn, rt] {
+                                for (int i = 0; i < 4 * nConsumers + 2 && !groupSlabsStop.load(); i++) {
+                                    HostBatch *g = new HostBatch();
+                                    g->shape_values((uint32_t)std::min<uint64_t>(rn, 0xFFFFFFFFu), rt);
+                                    std::lock_guard<std::mutex> lk(fifoMu);
+                                    groupSlabs.push_back(g);
+                                }
+                            });
+                        });
                 }
                 check_on(ctx, mdbg_minimizers_to_host(ctx, mins, hb->off, hb->m, hb->pos, hb->dir, hb->qual, hb->len, hb->meanQ, hb->flags), "to_host");
                 const double t3 = g_trace.now();
@@ -709,7 +731,6 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
         // run.  Every consumer appends the batches its context holds of a group of 32 consecutive ones on the device
         // (mdbg_minimizers_concat), purges them with one call, copies values and offsets back into one page-locked slab, and the writer
         // builds the `u32 n; u8 circular = 0; u32 m[n]` records batch by batch in read order from the slabs of both.
-        constexpr size_t GROUP = 32;
         struct Piece { HostBatch *hb; uint64_t firstRead; uint32_t nReads; std::atomic<int> *left; uint64_t bytes; };    // batch i = reads [firstRead, +nReads) of hb
         // Where a batch's records go in the file is known once every earlier batch has been purged (their sizes add up); from then on
         // any thread may build them and write them in place.  (One thread writing the 0.8 GB of a 50 Gbp read set through a stream was
@@ -752,14 +773,17 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
                 if (last) delete pc.left;
                 {
                     std::lock_guard<std::mutex> lk(fifoMu);
-                    if (last) spareBatches.push_back(pc.hb);
+                    if (last) groupSlabs.push_back(pc.hb);
                     outstanding2--;
                 }
                 fifoCv.notify_all();
             }
         };
+        groupSlabsStop = true;
+        if (groupSlabHelper.joinable()) groupSlabHelper.join();
+        // (eight, not four: over 50 Gbp the last record was written 0.16 s after the last group had been purged)
         std::vector<std::thread> writers2;
-        for (int i = 0, nw = std::max(1, std::min(4, a.threads / 4)); i < nw; i++) writers2.emplace_back(write2);
+        for (int i = 0, nw = std::max(1, std::min(8, a.threads / 4)); i < nw; i++) writers2.emplace_back(write2);
         double pConcat = 0, pPurge = 0, pFree = 0, pSlab = 0, pCopy = 0, pPlace = 0;      // MDBG_TRACE: where the purging threads' time goes
         auto purge_own = [&](int ci) {
             mdbg_ctx *ctx = ctxs[(size_t)ci];
@@ -791,7 +815,8 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
                 HostBatch *hb = nullptr;
                 {
                     std::lock_guard<std::mutex> lk(fifoMu);
-                    if (!spareBatches.empty()) { hb = spareBatches.back(); spareBatches.pop_back(); }
+                    if (!groupSlabs.empty()) { hb = groupSlabs.back(); groupSlabs.pop_back(); }
+                    else if (!spareBatches.empty()) { hb = spareBatches.back(); spareBatches.pop_back(); }
                 }
                 if (!hb) hb = new HostBatch();
                 uint32_t bn; uint64_t bt;
