@@ -642,7 +642,7 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
                             const size_t share = GROUP / (size_t)nConsumers + 2;
                             const uint64_t rn = (uint64_t)share * bn, rt = (uint64_t)share * bt;
                             groupSlabHelper = std::thread([&, rn, rt] {
-                                for (int i = 0; i < 4 * nConsumers + 2 && !groupSlabsStop.load(); i++) {
+                                for (int i = 0; i < 7 * nConsumers + 2 && !groupSlabsStop.load(); i++) {      // (six groups' pieces may wait for the writers, one is being filled)
                                     HostBatch *g = new HostBatch();
                                     g->shape_values((uint32_t)std::min<uint64_t>(rn, 0xFFFFFFFFu), rt);
                                     std::lock_guard<std::mutex> lk(fifoMu);
