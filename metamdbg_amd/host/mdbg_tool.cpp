@@ -436,6 +436,16 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
     // per batch of a few thousand reads -- that a 50 Gbp pass waits for (round 3: the parsers were idle 60 % of the time)
     int nConsumers = std::max(1, a.gpus) * (a.threads >= 8 ? 2 : 1);
     if (const char *e = getenv("MDBG_TOOL_CONSUMERS")) nConsumers = std::max(std::max(1, a.gpus), std::min(4 * std::max(1, a.gpus), atoi(e)));
+    // how many: what the purge pass can have in flight (six groups' pieces waiting for the writers, one being filled, per consumer) --
+    // of a long input.  A short one (10 Gbp: ten groups) gets a third of its groups' worth: pinning 200 MB beside a main pass of
+    // 0.25 s measured no faster than growing slabs on the way (0.53 against 0.50 s inside the tool, ten runs each, noise as large)
+    size_t groupSlabsWanted = 0;
+    {
+        uint64_t inputBytes = 0;
+        for (const std::string &f : read_input_list(inputList)) { struct stat st; if (stat(f.c_str(), &st) == 0) inputBytes += (uint64_t)st.st_size; }
+        const uint64_t groups = inputBytes / ((uint64_t)std::max<size_t>(1, a.batchBases) * GROUP);
+        groupSlabsWanted = (size_t)std::min<uint64_t>(7 * (uint64_t)nConsumers + 2, groups * (uint64_t)nConsumers / 3);
+    }
     std::vector<mdbg_ctx *> ctxs{g_ctx};
     for (int i = 1; i < nConsumers; i++) {
         mdbg_ctx *c = nullptr;
@@ -636,13 +646,13 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
                     uint32_t bn; uint64_t bt;
                     mdbg_minimizers_info(mins, &bn, &bt);
                     hb->shape(bn, bt);
-                    if (needCorrected)
+                    if (needCorrected && groupSlabsWanted && !getenv("MDBG_TOOL_NO_GROUP_SLABS"))       // (the variable: A/B of the helper)
                         std::call_once(groupSlabOnce, [&, bn, bt] {
                             // a consumer's share of a group (batches are handed out as consumers come free: a little more than GROUP / consumers)
                             const size_t share = GROUP / (size_t)nConsumers + 2;
                             const uint64_t rn = (uint64_t)share * bn, rt = (uint64_t)share * bt;
                             groupSlabHelper = std::thread([&, rn, rt] {
-                                for (int i = 0; i < 7 * nConsumers + 2 && !groupSlabsStop.load(); i++) {      // (six groups' pieces may wait for the writers, one is being filled)
+                                for (size_t i = 0; i < groupSlabsWanted && !groupSlabsStop.load(); i++) {
                                     HostBatch *g = new HostBatch();
                                     g->shape_values((uint32_t)std::min<uint64_t>(rn, 0xFFFFFFFFu), rt);
                                     std::lock_guard<std::mutex> lk(fifoMu);

@@ -66,14 +66,13 @@ def main():
         fasta = os.path.join(work, "reads.fasta")
         e2e_steady.write_reads(fasta, ctx, synth.hifi_spec(a.reads, seed=42, read_len=10_000, coverage=50.0), a.reads, False)
         ctx.close()
-        cases = [("as_shipped", {}), ("every_context_destroyed_before_exit", {"MDBG_TOOL_EXIT_TRACE": "3"}), ("device_reset_before_exit", {"MDBG_TOOL_EXIT_TRACE": "4"}),
-                 ("idle_200_ms_before_exit", {"MDBG_TOOL_EXIT_TRACE": "5"}), ("contexts_destroyed_and_device_reset", {"MDBG_TOOL_EXIT_TRACE": "6"}), ("as_shipped_again", {})]
+        cases = [("as_shipped", {}), ("no_group_slabs_ahead", {"MDBG_TOOL_NO_GROUP_SLABS": "1"}), ("as_shipped_again", {}), ("no_group_slabs_ahead_again", {"MDBG_TOOL_NO_GROUP_SLABS": "1"})]
         cases = [(n, e, "asmStep") for n, e in cases]
         for name, env, cmd in cases:
             runs = [one(work, fasta, P, a.threads, env, cmd) for _ in range(a.reps)]
             res[name] = {"env": env, "command": cmd, "runs": runs, "best_wall_s": min(r["wall_s"] for r in runs), "median_outside_s": sorted(r["outside_s"] for r in runs)[len(runs) // 2],
                          "median_before_s": sorted(r["spawn_to_the_tools_clock_s"] for r in runs)[len(runs) // 2], "median_after_s": sorted(r["exit_to_the_parents_wait_s"] for r in runs)[len(runs) // 2]}
-            print(name, [(r["wall_s"], r["spawn_to_the_tools_clock_s"], r["exit_to_the_parents_wait_s"]) for r in runs], file=sys.stderr, flush=True)
+            print(name, [(r["wall_s"], r["tool_last_line_s"], r["exit_to_the_parents_wait_s"]) for r in runs], file=sys.stderr, flush=True)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     if a.out:
