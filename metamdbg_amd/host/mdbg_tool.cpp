@@ -791,6 +791,7 @@ int run_read_selection(int argc, char **argv, bool asmStep = false) {
         };
         groupSlabsStop = true;
         if (groupSlabHelper.joinable()) groupSlabHelper.join();
+        if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg_tool] %zu of %zu group slabs were allocated beside the main pass\n", groupSlabs.size(), groupSlabsWanted);
         // (eight, not four: over 50 Gbp the last record was written 0.16 s after the last group had been purged)
         std::vector<std::thread> writers2;
         for (int i = 0, nw = std::max(1, std::min(8, a.threads / 4)); i < nw; i++) writers2.emplace_back(write2);

@@ -7,6 +7,7 @@ builders once hung the tool on a 50 Gbp file and took half an hour of GPU time t
 from __future__ import annotations
 
 import os
+import re
 import struct
 import subprocess
 
@@ -68,7 +69,7 @@ def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool
     formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=not ont, data_type=1 if ont else 0,
                        correction_density=0.025).save(str(tmp / "parameters.gz"))
     (tmp / "input.txt").write_text(fasta + "\n")
-    env = dict(os.environ, MDBG_STUB_JITTER_US=str(jitter))
+    env = dict(os.environ, MDBG_STUB_JITTER_US=str(jitter), MDBG_TRACE="1")
     if consumers:
         env["MDBG_TOOL_CONSUMERS"] = str(consumers)
     for rep in range(3):
@@ -78,6 +79,11 @@ def test_read_selection_pipeline_is_ordered_complete_and_does_not_hang(stub_tool
         assert r.returncode == 0, r.stderr[-800:]
         assert (tmp / "read_data_init.txt").read_bytes() == exp_init
         assert (tmp / "read_data_corrected.txt").read_bytes() == exp_corr
+        # the purge pass's group slabs: allocated beside the main pass when the input is many groups long, never more than wanted
+        m = re.search(r"(\d+) of (\d+) group slabs were allocated beside the main pass", r.stderr)
+        assert m, r.stderr[-800:]
+        assert int(m.group(1)) <= int(m.group(2))
+        assert (int(m.group(2)) > 0) == (os.path.getsize(fasta) // (batch_bases * 32) >= 2)
         st = formats.parse_read_stats((tmp / "read_stats.txt").read_bytes())
         assert st["n_reads"] == len(lens) and st["n_bases"] == int(lens.sum()) and st["n_minimizers"] == int((lens // 271).sum())
 
