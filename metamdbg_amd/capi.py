@@ -480,7 +480,7 @@ class Shard:
         return d_reply.value or 0
 
     def exchange(self, comm: "Comm") -> int:
-        """Rows to their owners, reduce, replies back (RCCL inside the library): device pointer of the replies for finish()."""
+        """Rows to their owners, reduce, replies back (inside the library, over the communicator's transport: peer copies or RCCL): device pointer of the replies for finish()."""
         d = C.c_void_p()
         self.ctx.check(lib().mdbg_shard_exchange(self.ctx.h, comm.h, self.h, C.c_void_p(self.d_rows), self.counts.ctypes.data_as(_u64p), C.byref(d)))
         return d.value or 0
