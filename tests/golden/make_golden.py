@@ -308,7 +308,7 @@ MULTIK_INPUTS = ("parameters.gz", "kminmerData_abundance_prev.txt", "unitigGraph
                  "unitigGraph.nodes.refined_abundances.bin", "unitig_data.txt")
 
 
-def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, manifest: dict) -> None:
+def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, manifest: dict, snapshot_ks=None) -> None:
     """The reference's own multi-k loop after readSelection (pipeline/AssemblyPipeline.hpp:609-671, executePass :1076-1145):
     per k write parameters.gz (k, prevK), run `graph`, then `contig` and `toMinspace`, which produce the next iteration's
     unitig_data.txt / *_prev files.  For every k > firstK the fixture keeps the INPUTS `graph` read (data files) and its
@@ -323,7 +323,7 @@ def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, 
         log_path = os.path.join(os.path.dirname(tmp), "metaMDBG.log")
         log_start = os.path.getsize(log_path) if os.path.exists(log_path) else 0
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        if k > first_k:
+        if k > first_k and (snapshot_ks is None or k in snapshot_ks):
             d = os.path.join(dst, f"k{k}")
             os.makedirs(d, exist_ok=True)
             for name in MULTIK_INPUTS:
@@ -349,7 +349,8 @@ def run_ref_multik(tmp: str, params: formats.Parameters, last_k: int, dst: str, 
         prev_k = k
     shutil.copy(os.path.join(tmp, "read_data_corrected.txt"), os.path.join(dst, "read_data_corrected.txt"))
     with open(os.path.join(dst, "manifest.json"), "w") as f:
-        json.dump(dict(manifest, first_k=first_k, last_k=last_k, per_k=per_k), f, indent=1, sort_keys=True)
+        json.dump(dict(manifest, first_k=first_k, last_k=last_k, per_k=per_k, **({"ks": sorted(int(x) for x in per_k)} if snapshot_ks is not None else {})),
+                  f, indent=1, sort_keys=True)
 
 
 def make_multik(work: str, only_ont: bool = False) -> None:
@@ -384,6 +385,44 @@ def _make_multik_ont(work: str) -> None:
         ins_rate=spec.ins_rate, del_rate=spec.del_rate,
         species_len=spec.species_len, species_weight=spec.species_weight, with_quality=True, fasta_sha256=sha256(fastq),
         K=15, density=0.005, hpc=False, skip_correction=True))
+
+
+DEEP_KS = (12, 13, 14, 15, 16, 24, 31, 32, 33, 48, 64, 65)
+
+
+def make_deepk(work: str, which: str = "both") -> None:
+    """The range of k the reference's DEFAULT `asm` runs: no --max-k, lastK = N50 x density x 2 (Commons.hpp:1726-1741; loop step 1,
+    :1986-1987, pipeline/AssemblyPipeline.hpp:603-671) -- k = 4 .. 100 for 10 kb HiFi reads, 4 .. 200 for 20 kb ONT reads.  The whole
+    loop is run by the reference's own code (graph -> contig -> toMinspace per k); the files `graph` read and the tables it wrote are
+    kept at k in DEEP_KS and at lastK: the generic window hash (odd tails of 1 / 3 words at k = 13, 15, 33), k above the partitioned
+    pass's 32, k above most reads' minimizer count (37 for these HiFi reads: from there on the unitigs carry the table)."""
+    if which in ("both", "hifi"):
+        spec = synth.hifi_spec(1000, seed=29, coverage=40.0)
+        fasta = os.path.join(work, "hifi_deepk.fasta")
+        synth.write_fasta(fasta, spec)
+        params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=True, data_type=0)
+        tmp = run_ref_pipeline(os.path.join(work, "hifi_deepk"), fasta, params, graph=False)
+        stats = formats.parse_read_stats(open(os.path.join(tmp, "read_stats.txt"), "rb").read())
+        last_k = int(subprocess.run([REFDRV, "fn_lastk", "0.005", str(stats["n50"]), "4", "0"], capture_output=True, text=True, check=True).stdout)
+        run_ref_multik(tmp, params, last_k, os.path.join(HERE, "hifi_deepk"), dict(
+            kind="hifi", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate, n50=int(stats["n50"]),
+            species_len=spec.species_len, species_weight=spec.species_weight, fasta_sha256=sha256(fasta), K=15, density=0.005, hpc=True),
+            snapshot_ks=set(DEEP_KS) | {last_k})
+    if which in ("both", "ont"):
+        spec = synth.SynthSpec(n_reads=150, read_len=20_000, seed=23, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
+                               species_len=[50_000, 40_000], species_weight=[0.7, 0.3], with_quality=True, name="ont")
+        fastq = os.path.join(work, "ont_deepk.fastq")
+        synth.write_fasta(fastq, spec)
+        params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=False, data_type=1,
+                                    correction_density=0.025)
+        tmp = run_ref_pipeline(os.path.join(work, "ont_deepk"), fastq, params, extra_rs=["--skip-correction"], graph=False)
+        stats = formats.parse_read_stats(open(os.path.join(tmp, "read_stats.txt"), "rb").read())
+        last_k = int(subprocess.run([REFDRV, "fn_lastk", "0.005", str(stats["n50"]), "4", "0"], capture_output=True, text=True, check=True).stdout)
+        run_ref_multik(tmp, params, last_k, os.path.join(HERE, "ont_deepk"), dict(
+            kind="ont", n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, sub_rate=spec.sub_rate, n50=int(stats["n50"]),
+            ins_rate=spec.ins_rate, del_rate=spec.del_rate, species_len=spec.species_len, species_weight=spec.species_weight,
+            with_quality=True, fasta_sha256=sha256(fastq), K=15, density=0.005, hpc=False, skip_correction=True),
+            snapshot_ks=set(DEEP_KS) | {100, last_k})
 
 
 def edge_reads() -> list[bytes]:
@@ -616,6 +655,9 @@ def main() -> None:
                 make_hifi_1m_multik(work)
             else:
                 make_hifi_1m(work)
+            return
+        if "--deep-k" in sys.argv:       # the reference's loop to lastK(N50): a few minutes of CPU
+            make_deepk(work, "hifi" if "--hifi" in sys.argv else "ont" if "--ont" in sys.argv else "both")
             return
         if "--only-multik" in sys.argv:
             make_multik(work)

@@ -232,6 +232,130 @@ def test_count_first_vs_oracle(ctx, orc, k, min_ab):
     _assert_tables_equal(rec, vec, exp, k)
 
 
+def _genome_reads(rng, genome_len, n_reads, max_len, n_err=40, genome=None):
+    """Minimizer-space reads = substrings of a "genome" of distinct minimizers in either orientation, a quarter of them with one
+    "error"; lengths 0 .. max_len, so reads shorter than k are common."""
+    if genome is None:
+        genome = rng.permutation(genome_len).astype(np.uint32)
+    rl = []
+    for _ in range(n_reads):
+        n = int(rng.integers(0, max_len)); a = int(rng.integers(0, max(1, genome_len - n)))
+        seg = genome[a:a + n]
+        if rng.integers(0, 2): seg = seg[::-1]
+        seg = seg.copy()
+        if len(seg) and rng.integers(0, 4) == 0: seg[int(rng.integers(0, len(seg)))] = genome_len + 1000 + int(rng.integers(0, n_err))
+        rl.append(seg)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in rl])]).astype(np.uint64)
+    return genome, np.concatenate(rl).astype(np.uint32), offs
+
+
+@pytest.mark.parametrize("k", [13, 14, 15, 16, 31, 32, 33, 64, 65, 100, 200])
+@pytest.mark.parametrize("mode", ["auto", "one_table", "partitioned"])
+def test_count_first_deep_k_vs_oracle(ctx, orc, k, mode):
+    """The counting pass at the k the reference's default loop reaches (k = 4 .. N50 x density x 2: Commons.hpp:1726-1741): the generic
+    window hash (csrc/kminmer_dev.hpp: Murmur tails of 1, 2, 3, 0 words at k = 13, 14, 15, 16), k at and above the partitioned pass's
+    limit of 32 (it hands k > 32 to the one-table pass), reads with fewer than k minimizers as the common case, palindromic windows."""
+    rng = np.random.default_rng(900 + k)
+    _, mins, offs = _genome_reads(rng, 3000, 500, int(2.2 * k) + 20)
+    # palindromic and tie-at-first-compare windows (KmerVec::normalize, Commons.hpp:886-916: equal => reversed)
+    half = rng.integers(0, 3000, (k + 1) // 2).astype(np.uint32)
+    pal = np.concatenate([half, half[: k // 2][::-1]])
+    extra = [pal, pal, np.concatenate([pal, pal[1:]]), np.full(k + 3, 7, np.uint32)]
+    mins = np.concatenate([mins] + extra).astype(np.uint32)
+    offs = np.concatenate([offs, offs[-1] + np.cumsum([len(x) for x in extra]).astype(np.uint64)])
+    ctx.set_option("first_pass_mode", {"auto": 0, "one_table": 1, "partitioned": 2}[mode])
+    try:
+        for min_ab in (0, 2):
+            t = ctx.kminmer_count_first(ctx.minimizers_from_host(mins, offs), k, min_ab)
+            if mode == "partitioned":
+                assert ctx.first_pass_info()["path"] == (2 if k <= 32 else 1)
+            rec, vec = t.to_host()
+            exp = orc.kminmer_count_first(mins, offs, k, min_ab)
+            assert t.info()["n_solid"] == exp["n_solid"] and exp["n_solid"] > 0
+            _assert_tables_equal(rec, vec, exp, k)
+    finally:
+        ctx.set_option("first_pass_mode", 0)
+
+
+@pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two", "buckets"])
+@pytest.mark.parametrize("k", [13, 15, 17, 33, 65, 100])
+def test_refined_and_index_deep_k_vs_oracle(ctx, orc, k, form):
+    """The passes above firstK at deep k against the oracle on seeded inputs: previous table at k - 1 (+ a unitig overlay), refined count,
+    index, the small-contig flags (unitigs shorter than k, CreateMdbg.hpp:1330-1352), the pass's table as the next pass's previous
+    table -- with most reads shorter than k and unitigs much longer (what the reference's loop looks like from k = 38 on for 10 kb
+    HiFi reads: the unitigs carry the table)."""
+    rng = np.random.default_rng(1300 + k)
+    genome, mins, offs = _genome_reads(rng, 6000, 500, int(1.6 * k) + 10)
+    # unitigs = disjoint genome segments; eight of exactly k - 1 minimizers (the only length the small-contig branch can flag: no k-min-mer,
+    # one (k-1)-min-mer), some of k - 2, k, k + 1, the rest long
+    lens = [k - 1] * 8 + [k - 2, k, k + 1, 3, 1] + [int(x) for x in rng.integers(k, 6 * k, 12)]
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    assert starts[-1] <= 6000
+    ul = [genome[a:a + n] for a, n in zip(starts[:-1], lens)]
+    uoffs = starts.astype(np.uint64)
+    umins = np.concatenate(ul).astype(np.uint32)
+    allm = np.concatenate([mins, umins]); alloff = np.concatenate([offs, offs[-1] + uoffs[1:]])
+    prev_t = orc.kminmer_count_first(allm, alloff, k - 1, 0)
+    prev_raw = orc.table_abundance_records(prev_t).tobytes()
+    uab = np.concatenate([[0, 1, 2, 3, 4, 5, 2, 9], rng.integers(0, 6, len(lens) - 8)]).astype(np.uint32)
+    oprev = orc.PrevAbundance(prev_raw)
+    oprev.overlay_unitigs([(umins[int(uoffs[i]): int(uoffs[i + 1])], int(uab[i])) for i in range(len(uab)) if uab[i] != 4], k - 1)
+    uab = np.where(uab == 4, 0xFFFFFFFF, uab).astype(np.uint32)
+    d_reads = ctx.minimizers_from_host(mins, offs)
+    d_unitigs = ctx.minimizers_from_host(umins, uoffs)
+    dprev = ctx.prev_from_records(prev_raw)
+    ctx.prev_overlay_unitigs(dprev, d_unitigs, uab, k - 1)
+    ohi, olo, oab = oprev.arrays()
+    assert np.array_equal(dprev.lookup(olo, ohi), oab)
+    with _table_form(ctx, form):
+        rec, vec = ctx.kminmer_count_refined(d_reads, d_unitigs, k, dprev).to_host()
+        exp = orc.kminmer_count_refined(allm, alloff, k, oprev)
+        assert exp["n"] > 0
+        _assert_tables_equal(rec, vec, exp, k)
+        t6 = ctx.kminmer_index(d_reads, d_unitigs, k, dprev)
+        rec, vec = t6.to_host()
+        exp = orc.kminmer_index(allm, alloff, k, oprev)
+        assert exp["n"] > 0
+        _assert_tables_equal(rec, vec, exp, k)
+        exp1 = orc.kminmer_index(allm, alloff, k + 1, orc.PrevAbundance(orc.table_abundance_records(exp).tobytes()))
+        rec, vec = ctx.kminmer_index(d_reads, d_unitigs, k + 1, t6).to_host()
+        _assert_tables_equal(rec, vec, exp1, k + 1)
+    flags = ctx.small_contigs(d_unitigs, k, k - 1, dprev)
+    assert np.array_equal(flags, orc.small_contigs(umins, uoffs, k, k - 1, oprev)) and flags.any() and not flags.all()
+
+
+def test_small_contigs_and_index_with_very_long_unitigs(ctx, orc):
+    """Unitigs of more than 2^16 minimizers (a 16-lane group walks one for thousands of rounds; the instance offsets leave 32 bits of
+    a sequence far behind) next to unitigs shorter than k - 1, k = 12 and 40: the index pass, the previous-abundance look-ups and the
+    small-contig flags against the oracle."""
+    rng = np.random.default_rng(4242)
+    genome = rng.permutation(400_000).astype(np.uint32)
+    lens = [70_000, 3, 150_000, 0, 11, 39, 40, 41, 66_000, 12, 100_000]
+    ul, a = [], 0
+    for n in lens:
+        ul.append(genome[a:a + n][::-1] if n % 2 else genome[a:a + n]); a += n
+    uoffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    umins = np.concatenate(ul).astype(np.uint32)
+    _, mins, offs = _genome_reads(rng, 400_000, 300, 90, genome=genome)
+    allm = np.concatenate([mins, umins]); alloff = np.concatenate([offs, offs[-1] + uoffs[1:]])
+    for k in (12, 40):
+        prev_t = orc.kminmer_count_first(allm, alloff, k - 1, 0)
+        prev_raw = orc.table_abundance_records(prev_t).tobytes()
+        oprev = orc.PrevAbundance(prev_raw)
+        uab = np.array([3, 2, 5, 0, 1, 2, 2, 2, 7, 0, 2], dtype=np.uint32)
+        oprev.overlay_unitigs([(umins[int(uoffs[i]): int(uoffs[i + 1])], int(uab[i])) for i in range(len(uab))], k - 1)
+        d_reads = ctx.minimizers_from_host(mins, offs)
+        d_unitigs = ctx.minimizers_from_host(umins, uoffs)
+        dprev = ctx.prev_from_records(prev_raw)
+        ctx.prev_overlay_unitigs(dprev, d_unitigs, uab, k - 1)
+        rec, vec = ctx.kminmer_index(d_reads, d_unitigs, k, dprev).to_host()
+        exp = orc.kminmer_index(allm, alloff, k, oprev)
+        assert exp["n"] > 300_000
+        _assert_tables_equal(rec, vec, exp, k)
+        flags = ctx.small_contigs(d_unitigs, k, k - 1, dprev)
+        assert np.array_equal(flags, orc.small_contigs(umins, uoffs, k, k - 1, oprev))
+
+
 import contextlib
 
 
@@ -825,7 +949,7 @@ def test_unitig_edge_index_vs_oracle_and_reference_log(ctx, orc, name):
 
 def _multik_cases():
     from tests import multik_fixture as mk
-    return [(s, k) for s in mk.SETS for k in mk.steps(s)]
+    return [(s, k) for s in mk.SETS + mk.DEEP_SETS for k in mk.steps(s)]
 
 
 @pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two_kernels", "slots_round4", "buckets"])
@@ -833,7 +957,9 @@ def _multik_cases():
 def test_next_k_tables_equal_reference_multik(ctx, name, k, form):
     """Rows A13 / A14 against the REFERENCE: previous table + unitig overlay, refined count (k = firstK+1), index
     (k >= firstK+2) and the small-contig branch, on the inputs the reference's `graph` read in its own multi-k loop and
-    the tables it wrote (tests/golden/*_multik)."""
+    the tables it wrote (tests/golden/*_multik: k = 5 .. 11 with --max-k 11; tests/golden/*_deepk: the DEFAULT loop, no --max-k,
+    lastK = N50 x density x 2 (Commons.hpp:1726-1741) = 100 / 200, at k = 12 .. 16, 24, 31 .. 33, 48, 64, 65, 100, lastK -- the generic
+    window hash with Murmur tails of 0 .. 3 words, k above the partitioned pass's 32, k above every read's minimizer count)."""
     from tests import multik_fixture as mk
     fx = mk.load(name, k)
     P = fx["params"]

@@ -301,14 +301,15 @@ def test_tool_graph_next_k_vs_oracle(tmp_path):
 
 def _multik_cases():
     from tests import multik_fixture as mk
-    return [(s, k) for s in mk.SETS for k in mk.steps(s)]
+    return [(s, k) for s in mk.SETS + mk.DEEP_SETS for k in mk.steps(s)]
 
 
 @pytest.mark.parametrize("name,k", _multik_cases())
 def test_tool_graph_next_k_equals_reference(tmp_path, name, k):
     """`mdbg_tool graph` at k = 5..11 on the files the reference's own `graph` read in its multi-k loop (unitig_data.txt,
     *_prev, refined abundances -- products of the reference's contig / toMinspace stages, kept as data under
-    tests/golden/*_multik) against the files it wrote: abundance table, vectors at firstK+1, smallContigs_k<k>.bin."""
+    tests/golden/*_multik) against the files it wrote: abundance table, vectors at firstK+1, smallContigs_k<k>.bin; and at
+    k = 12 .. lastK(N50) = 100 / 200 of the reference's DEFAULT loop (no --max-k; tests/golden/*_deepk)."""
     import shutil
     from tests import multik_fixture as mk
     fx = mk.load(name, k)
@@ -327,7 +328,7 @@ def test_tool_graph_next_k_equals_reference(tmp_path, name, k):
 
 
 @pytest.mark.skipif(not os.path.exists(REFDRV), reason="oracle/_ref/refdrv not built")
-@pytest.mark.parametrize("kind", ["hifi", "ont"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "hifi_default_last_k"])
 def test_handover_into_reference_graph_stage(tmp_path, kind):
     """Closing the loop ("in-process consumer"): the reference's `graph` command builds the unitig graph in
     the same process that made the tables -- createGfa() at k <= firstK+1, computeNextUnitigGraph() querying the in-memory
@@ -335,12 +336,14 @@ def test_handover_into_reference_graph_stage(tmp_path, kind):
     multi-k loop (graph -> contig -> toMinspace, k = 4 .. 11) runs twice: as it is, and with every table written by
     `mdbg_tool graph` (the HIP path) and handed to the reference's own graph stage (`refdrv graph_from_tables`, which fills
     _mdbgNodesLight from the tool's 20-byte records).  Unitig graph files, the inputs of every next k and the tables must be
-    the same at every k: the GPU-made tables are a drop-in for the stage that consumes them."""
+    the same at every k: the GPU-made tables are a drop-in for the stage that consumes them.
+    "hifi_default_last_k": the loop as the reference's `asm` runs it WITHOUT --max-k -- lastK = N50 x density x 2 = 100 for 10 kb reads
+    (Commons.hpp:1726-1741), 97 `graph` passes, every table k = 4 .. 100 made by `mdbg_tool graph`."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_golden as mg
     from tests import handover as ho
-    if kind == "hifi":
+    if kind.startswith("hifi"):
         spec = synth.hifi_spec(260, seed=91, coverage=30.0)
         params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=True, data_type=0)
         extra = []
@@ -355,6 +358,10 @@ def test_handover_into_reference_graph_stage(tmp_path, kind):
     t_ref = mg.run_ref_pipeline(str(tmp_path / "ref"), reads, params, graph=False, extra_rs=extra)
     t_hyb = mg.run_ref_pipeline(str(tmp_path / "hyb"), reads, params, graph=False, extra_rs=extra)
     last_k = 11
+    if kind == "hifi_default_last_k":
+        n50 = formats.parse_read_stats(fbytes(t_ref, "read_stats.txt"))["n50"]
+        last_k = max(int(np.float32(n50) * np.float32(0.005) * np.float32(2.0)), 6)
+        assert last_k == 100
 
     def tool_tables(tmp, k, first_k):
         for name in ("kminmerData_abundance.txt", "kminmerData_min.txt"):      # nothing stale may be picked up
@@ -365,7 +372,7 @@ def test_handover_into_reference_graph_stage(tmp_path, kind):
     ho.run_loop(t_ref, params, last_k, ho.reference_graph, str(tmp_path / "snap_ref"))
     ho.run_loop(t_hyb, params, last_k, ho.tables_then_reference_graph_stage(tool_tables), str(tmp_path / "snap_hyb"))
     seen = ho.compare_dirs(str(tmp_path / "snap_ref"), str(tmp_path / "snap_hyb"), 4, last_k)
-    assert seen["graph_files"] >= 4 * 7 and seen["next_inputs"] == 3 * 7 and seen["tables"] == 8, seen
+    assert seen["graph_files"] >= 4 * (last_k - 4) and seen["next_inputs"] == 3 * (last_k - 4) and seen["tables"] == last_k - 3, seen
     # the checksums the reference logs at the end of a createGfa() pass (graph/CreateMdbg.cpp:574-576) agree as well
     def checksums(tmp):
         log = open(os.path.join(os.path.dirname(tmp), "metaMDBG.log")).read()
