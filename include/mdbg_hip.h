@@ -75,11 +75,14 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
  *                           hash and confirms each with the full hash; a read with a false candidate is re-run.  False
  *                           candidates occur about once in 2^31 positions; this widens the test (units of 2^32 of the
  *                           hash range) so that the re-run path can be exercised.  Default 0; results never depend on it
- *   "index_tuning"          the passes above firstK over the one-slot tables (bits; default 3; negative: the default): 1 = a slot's key and
+ *   "index_tuning"          the passes above firstK over the one-slot tables (bits; default 19; negative: the default): 1 = a slot's key and
  *                           value fetched in one trip, 2 = the insert first looks at a window's home slot with plain loads (a key found
  *                           there is done without an atomic), 4 = two windows of a lane in flight (measured: no gain), 8 = look-up and
- *                           insert in one kernel (measured: slower); 0 = the kernels
+ *                           insert in one kernel (measured: slower), 16 = both slots of a key's home sector fetched at once (look-up
+ *                           and the insert's first look), 32 = 32 lanes a sequence instead of 16; 0 = the kernels
  *                           of rounds 1 - 4.  Results never depend on it
+ *   "keep_index_table"      1 (default) = the hash table an index pass filled stays with its result as the look-up structure the next
+ *                           pass reads; 0 = it is dropped and built again from the rows on first use (rounds 1 - 5)
  *   "index_table_form"      0 = those passes over bucket tables (three keys per 64-byte sector: a third of the bytes, measured no
  *                           faster), 1 or negative = one 32-byte slot per key (default)
  *   "refined_form"          0 = k = firstK+1 done like an index pass (a look-up per (k-1)-window; measured slower), 1 or negative =

@@ -117,6 +117,8 @@ struct TimedLaunch {
 
 }  // namespace mdbg
 
+constexpr uint32_t INDEX_TUNING_DEFAULT = 3u | 16u;
+
 struct mdbg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -163,8 +165,10 @@ struct mdbg_ctx {
     uint32_t refined_form = 1;              // k = firstK + 1: 1 = every distinct key first, then two look-ups per key (default); 0 = like an index pass (a
                                             // look-up per (k-1)-window, only kept keys inserted: 344 M look-ups instead of 78 M -- slower)
     uint32_t scan_quality_beside = 1;       // FASTQ: the per-read quality sums run beside the scan kernel on the side stream (0: in front of it, rounds 1 - 4)
-    uint32_t index_tuning = 3;              // one-slot index passes: bit 0 a slot's key and value in one trip, bit 1 the insert's plain-load first look (both on:
-                                            // 20.5 -> 18.5 ms a pass), bit 2 two windows of a lane in flight (measured, no gain: off), bit 3 look-up and insert in one kernel (measured, slower: off); 0 = the kernels of rounds 1 - 4
+    uint32_t keep_index_table = 1;          // an index pass's hash table stays with its result as the look-up structure of the next pass (round 6)
+    uint32_t index_tuning = INDEX_TUNING_DEFAULT;   // one-slot index passes: bit 0 a slot's key and value in one trip, bit 1 the insert's plain-load first look (both on:
+                                            // 20.5 -> 18.5 ms a pass), bit 2 two windows of a lane in flight (measured, no gain: off), bit 3 look-up and insert in one kernel (measured, slower: off); 0 = the kernels of rounds 1 - 4;
+                                            // round 6: bit 4 the look-up fetches both slots of a key's home sector at once (on; with bit 1 and bit 5 off the insert keeps round 5's first look), bit 5 32 lanes a sequence (measured, slower in the library: off)
     uint64_t part_info[8] = {0};            // last first pass: [0] path (1 one table, 2 partitioned), [1] groups, [2] bucket bits, [3] levels,
                                             // [4] attempts, [5] LDS slots per bucket, [6] buckets, [7] instances
     std::shared_ptr<mdbg::DevPool> pool;                   // device memory cache shared with every buffer handed out

@@ -101,9 +101,9 @@ __device__ __forceinline__ void for_each_instance(const SeqView &s, F f, const u
 // bound by memory-side atomics); beside another context's scan a few resident blocks per CU (mdbg_set_option "table_blocks_per_cu" / MDBG_TABLE_BLOCKS_PER_CU,
 // grid-stride over the reads) keep them from displacing the scan's waves: 3 per CU costs the insert 2.9 -> 3.6 ms and
 // gives the scan back 0.5 ms, which is what the step then runs at.
-static unsigned instance_grid(const mdbg_ctx *ctx, uint32_t n_reads) {
-    if (ctx->table_grid_blocks) return grid_for((uint64_t)n_reads * 16, 256, ctx->table_grid_blocks);
-    return grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * ctx->table_blocks_per_cu);
+static unsigned instance_grid(const mdbg_ctx *ctx, uint32_t n_reads, unsigned lanes = 16) {
+    if (ctx->table_grid_blocks) return grid_for((uint64_t)n_reads * lanes, 256, ctx->table_grid_blocks);
+    return grid_for((uint64_t)n_reads * lanes, 256, (unsigned)ctx->n_cu * ctx->table_blocks_per_cu);
 }
 
 // ---- first pass -----------------------------------------------------------------------------------
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void prev_abundance_u_kernel(SeqView s /* inst
                     v[u] = 1u;
                     if (lo[u] == 0ull || hi[u] == 0ull) { uint32_t x; if (i0 + 16u * (uint32_t)u < n && table_lookup_side(prev, lo[u], hi[u], x)) v[u] = x; }
                     else if (w[u].lo == lo[u] && w[u].hi == hi[u]) v[u] = w[u].val;
-                    else if (w[u].lo != 0ull) { uint32_t x; if (table_lookup_from(prev, (home[u] + 1) & prev.mask, 1, lo[u], hi[u], x)) v[u] = x; }
+                    else if (w[u].lo != 0ull) { uint32_t x; if (table_lookup_from(prev, table_next(home[u], prev.mask), 1, lo[u], hi[u], x)) v[u] = x; }
                 }
             } else {
 #pragma unroll
@@ -415,6 +415,37 @@ __global__ __launch_bounds__(256) void prev_abundance_u_kernel(SeqView s /* inst
             }
 #pragma unroll
             for (int u = 0; u < U; u++) { const uint32_t i = i0 + 16u * (uint32_t)u; if (i < n) out[base + i] = v[u]; }
+        }
+    }
+}
+
+// Round 6: the look-up with BOTH slots of a window's home sector fetched at once (a table's probe sequences start at the even slot of a
+// 64-byte sector, table.hpp) and LANES lanes a sequence.  What tools/ubench/lookup_ablate.hip measured on 320 M look-ups into 14 M keys:
+// the first slot alone and the second by a dependent trip 38.5 G/s at load 0.39, both at once 42.1, with 32 lanes 43.2, the same at load
+// 0.2: 47.0 -- against 47 - 50 for the same kernel WITHOUT its hash or without its store: the rate at which this part serves random sectors.
+template <int LANES>
+__global__ __launch_bounds__(256) void prev_abundance_pair_kernel(SeqView s /* instances of size k-1 */, uint32_t km1, TableView prev, uint32_t *out) {
+    const unsigned sub = threadIdx.x & (LANES - 1);
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / LANES;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        const uint64_t base = s.inst_off[r];
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - base);
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i = sub; i < n; i += LANES) {
+            uint64_t hi, lo;
+            window_hash_uniform(m0 + i, km1, hi, lo);
+            uint32_t v = 1u, x;
+            if (lo == 0ull || hi == 0ull) { if (table_lookup_side(prev, lo, hi, x)) v = x; }
+            else {
+                const uint64_t home = table_home(lo, hi, prev.mask);
+                SlotPair p = pair_load(&prev.slots[home]);
+                asm volatile("" : "+v"(p.a.val), "+v"(p.b.val));     // all four loads are out before the first compare (see prev_abundance_u_kernel)
+                const int f = pair_verdict(p, lo, hi, x);
+                if (f > 0) v = x;
+                else if (f < 0 && table_lookup_from(prev, table_next(home + 1, prev.mask), 2, lo, hi, x)) v = x;
+            }
+            out[base + i] = v;
         }
     }
 }
@@ -477,6 +508,35 @@ __global__ __launch_bounds__(256) void index_insert_u_kernel(SeqView s /* k */, 
 #pragma unroll
                 for (int u = 0; u < U; u++) if (a[u] > 1u) table_insert_once(t, lo[u], hi[u], a[u]);
             }
+        }
+    }
+}
+
+// Round 6: the insert with the plain-load first look at BOTH slots of the home sector and LANES lanes a sequence.
+template <int LANES>
+__global__ __launch_bounds__(256) void index_insert_pair_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab, uint32_t k, TableView t) {
+    const unsigned sub = threadIdx.x & (LANES - 1);
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / LANES;
+    uint32_t trip = 0;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (t.poll_overflow && (trip++ & 31u) == 0u && __hip_atomic_load(t.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - s.inst_off[r]);
+        const uint32_t *m0 = s.mins + s.off[r];
+        const uint64_t j0 = inst_off_km1[r];
+        for (uint32_t i = sub; i < n; i += LANES) {
+            const uint32_t a0 = prev_ab[j0 + i], a1 = prev_ab[j0 + i + 1];
+            const uint32_t a = a0 < a1 ? a0 : a1;
+            if (a <= 1u) continue;
+            uint64_t hi, lo;
+            window_hash_uniform(m0 + i, k, hi, lo);
+            if (lo != 0ull && hi != 0ull) {
+                const TableSlot *home = &t.slots[table_home(lo, hi, t.mask)];
+                const uint4 ka = *reinterpret_cast<const uint4 *>(home), kb = *reinterpret_cast<const uint4 *>(home + 1);
+                const uint32_t l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32), h0 = (uint32_t)hi, h1 = (uint32_t)(hi >> 32);
+                if ((ka.x == l0 && ka.y == l1 && ka.z == h0 && ka.w == h1) || (kb.x == l0 && kb.y == l1 && kb.z == h0 && kb.w == h1)) continue;
+            }
+            table_insert_once(t, lo, hi, a);
         }
     }
 }
@@ -910,7 +970,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
 static int ensure_lookup(mdbg_ctx *ctx, mdbg_table *t, bool skip_one) {
     if (t->lookup) return MDBG_OK;
     std::unique_ptr<DeviceTable> tab(new DeviceTable());
-    MDBG_TRY(tab->init(ctx, t->n_records * 2 + 1024));
+    MDBG_TRY(tab->init(ctx, table_slots_for(t->n_records)));
     if (t->n_records)
         hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(t->n_records, 256)), dim3(256), 0, ctx->stream,
                            t->d_lo.p, t->d_hi.p, t->d_ab.p, t->n_records, skip_one ? 1 : 0, tab->view());
@@ -936,7 +996,7 @@ extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, u
     }
     // headroom: the unitig overlay may add keys that are not in the record file
     std::unique_ptr<DeviceTable> tab(new DeviceTable());
-    if ((rc = tab->init(ctx, n_records * 3 + 4096))) return fail(rc);
+    if ((rc = tab->init(ctx, table_slots_for(n_records + n_records / 4) + 4096))) return fail(rc);
     if (n_records)
         hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(n_records, 256)), dim3(256), 0, ctx->stream,
                            t->d_lo.p, t->d_hi.p, t->d_ab.p, n_records, 1, tab->view());
@@ -1138,10 +1198,15 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     DevBuf<uint32_t> prev_ab;
     MDBG_TRY(prev_ab.alloc(ctx, ikm1.total));
     SeqView vk = make_view(s, ik), vkm1 = make_view(s, ikm1);
+    // round 6 -- bit 4: the look-up fetches both slots of the home sector at once, bit 5: 32 lanes a sequence instead of 16, bit 6: the
+    // insert's first look at both slots (measured: the look-up gains, the insert does not -- default 16 | 3)
+    const bool pair = ctx->index_tuning & 16u, l32 = ctx->index_tuning & 32u, pair_insert = ctx->index_tuning & 64u;
     {
         LaunchTimer timer(ctx, "kminmer_prev_lookup");
-        const dim3 grid(instance_grid(ctx, vkm1.n_reads)), block(256);
-        if (!ctx->index_tuning) hipLaunchKernelGGL(prev_abundance_kernel<TableView>, grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        const dim3 grid(instance_grid(ctx, vkm1.n_reads, pair && l32 ? 32 : 16)), block(256);
+        if (pair && l32) hipLaunchKernelGGL(prev_abundance_pair_kernel<32>, grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        else if (pair) hipLaunchKernelGGL(prev_abundance_pair_kernel<16>, grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
+        else if (!(ctx->index_tuning & 15u)) hipLaunchKernelGGL(prev_abundance_kernel<TableView>, grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
         else if (two && wide) hipLaunchKernelGGL((prev_abundance_u_kernel<2, true>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
         else if (two) hipLaunchKernelGGL((prev_abundance_u_kernel<2, false>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
         else if (wide) hipLaunchKernelGGL((prev_abundance_u_kernel<1, true>), grid, block, 0, ctx->stream, vkm1, k - 1, pv, prev_ab.p);
@@ -1149,8 +1214,10 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     }
     {
         LaunchTimer timer(ctx, "kminmer_insert");
-        const dim3 grid(instance_grid(ctx, vk.n_reads)), block(256);
-        if (!(fast || two)) hipLaunchKernelGGL(index_insert_kernel, grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        const dim3 grid(instance_grid(ctx, vk.n_reads, pair_insert && l32 ? 32 : 16)), block(256);
+        if (pair_insert && l32) hipLaunchKernelGGL(index_insert_pair_kernel<32>, grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        else if (pair_insert) hipLaunchKernelGGL(index_insert_pair_kernel<16>, grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
+        else if (!(fast || two)) hipLaunchKernelGGL(index_insert_kernel, grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
         else if (two && fast) hipLaunchKernelGGL((index_insert_u_kernel<2, true>), grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
         else if (two) hipLaunchKernelGGL((index_insert_u_kernel<2, false>), grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
         else hipLaunchKernelGGL((index_insert_u_kernel<1, true>), grid, block, 0, ctx->stream, vk, ikm1.off.p, prev_ab.p, k, tv);
@@ -1225,7 +1292,8 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     MDBG_TRY(prev_view(ctx, prev, pv));
     // upper bound on distinct keys: total k-windows
     uint64_t bound = reads->n_min + (unitigs ? unitigs->n_min : 0);
-    DeviceTable tab;
+    std::unique_ptr<DeviceTable> tabp(new DeviceTable());
+    DeviceTable &tab = *tabp;
     uint64_t n_inst = 0;
     MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)bound * ctx->key_ratio_hint[2]), bound, [&](TableView v) {
         n_inst = 0;
@@ -1257,6 +1325,10 @@ extern "C" int mdbg_kminmer_index(mdbg_ctx *ctx, const mdbg_minimizers *reads, c
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { delete t; return set_error(ctx, MDBG_EHIP, "kminmer_index failed: %s", hipGetErrorString(e)); }
+    // The table the pass filled IS the key -> abundance map of its rows (every slot published, every value above 1): it stays with the
+    // result as its look-up structure, so the next pass of the loop -- or mdbg_table_lookup -- does not build one from the rows again
+    // (a clear of the slots and an insert per row: 1 ms of every pass at 10 M reads).  "keep_index_table" = 0: drop it (rounds 1 - 5).
+    if (ctx->keep_index_table) t->lookup = std::move(tabp);
     *out = t;
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)

@@ -8,19 +8,44 @@
 
 namespace mdbg {
 
-// canonical orientation + hash128 of the window m[0..k).  Returns isReversed.
+// canonical orientation + hash128 of the window m[0..k), any k.  Returns isReversed.
+// Round 6: the reference's default loop runs k = 4 .. N50 x density x 2 (100 for 10 kb HiFi reads, Commons.hpp:1726-1741), and every
+// k >= 12 comes here.  The word-at-a-time form of rounds 1 - 5 (Murmur128Stream::push: a four-way switch per minimizer, the window read
+// through m[k - 1 - i] twice) made a pass at k = 13 .. 26 cost 30 - 32 ms against 17 at k = 11 (profiles/round6_*_index_by_k_deep.json);
+// here the orientation is settled from both ends inwards (the first differing pair decides, as KmerVec::normalize's comparison of the
+// vector with its reverse does, Commons.hpp:886-916; equal = palindrome => reversed), then the window is walked ONCE in 16-byte blocks
+// along a per-lane stride of +1 or -1 word -- a block's two key words are mixed independently of the running state, so only the
+// h1 / h2 chain is serial -- and the 0 .. 3 words of the tail are mixed as MurmurHash3_x64_128's tail switch does (MurmurHash3.cpp:369-395).
 __device__ __forceinline__ bool window_hash(const uint32_t *m, uint32_t k, uint64_t &hi, uint64_t &lo) {
     bool reversed = true;  // palindrome => reversed (Commons.hpp:912-913)
-    for (uint32_t i = 0; i < k; i++) {
-        uint32_t a = m[i], b = m[k - 1 - i];
+    for (uint32_t i = 0, j = k - 1; i < j; i++, j--) {
+        const uint32_t a = m[i], b = m[j];
         if (a == b) continue;
-        reversed = !(a < b);
+        reversed = a > b;
         break;
     }
-    Murmur128Stream h;
-    if (reversed) for (uint32_t i = 0; i < k; i++) h.push(m[k - 1 - i]);
-    else          for (uint32_t i = 0; i < k; i++) h.push(m[i]);
-    h.finish(hi, lo);
+    const int step = reversed ? -1 : 1;
+    const uint32_t *p = reversed ? m + (k - 1) : m;
+    uint64_t h1 = 0, h2 = 0;
+    for (uint32_t b = k >> 2; b; b--, p += 4 * step) {
+        uint64_t k1 = (uint64_t)p[0] | ((uint64_t)p[step] << 32), k2 = (uint64_t)p[2 * step] | ((uint64_t)p[3 * step] << 32);
+        k1 *= MDBG_C1; k1 = rotl64(k1, 31); k1 *= MDBG_C2;
+        k2 *= MDBG_C2; k2 = rotl64(k2, 33); k2 *= MDBG_C1;
+        h1 ^= k1; h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        h2 ^= k2; h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint32_t rem = k & 3u;
+    if (rem == 3u) { uint64_t k2 = p[2 * step]; k2 *= MDBG_C2; k2 = rotl64(k2, 33); k2 *= MDBG_C1; h2 ^= k2; }
+    if (rem) {
+        uint64_t k1 = (uint64_t)p[0] | (rem >= 2u ? (uint64_t)p[step] << 32 : 0ull);
+        k1 *= MDBG_C1; k1 = rotl64(k1, 31); k1 *= MDBG_C2; h1 ^= k1;
+    }
+    const uint64_t len = (uint64_t)k * 4;
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    hi = h1; lo = h2;
     return reversed;
 }
 

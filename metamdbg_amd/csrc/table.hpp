@@ -33,7 +33,7 @@ constexpr uint32_t TABLE_MAX_PROBES = 96;   // longer probe sequences mean the t
 
 struct TableView {
     TableSlot *slots;         // cap
-    uint64_t mask;            // cap - 1
+    uint64_t mask;            // cap - 1: the last slot (cap is any even number, see table_home)
     // side list for keys with a zero word
     unsigned long long *exc_lo, *exc_hi;
     uint32_t *exc_val, *exc_rep;
@@ -46,11 +46,17 @@ struct TableView {
 
 #ifdef __HIPCC__
 
+// A table has ANY even number of slots (round 6; it was a power of two): the home slot is a multiply-shift of the folded key, not a mask,
+// so a table is sized for the load the passes run best at whatever the key count (tools/ubench/lookup_ablate.hip: a pass's look-ups run
+// 12 - 18 % faster at load 0.2 than at 0.4, and a power of two leaves the load anywhere in a factor of two).  A probe sequence starts
+// at the EVEN slot of a 64-byte sector: a key's first two probes are one sector, and the look-up kernels fetch both slots at once.
+// `mask` keeps its name: it is the index of the LAST slot (cap - 1).
 __device__ __forceinline__ uint64_t table_home(uint64_t lo, uint64_t hi, uint64_t mask) {
     // the key is already a Murmur3 output; fold both words so owner-rank partitioning by the top
     // bits of `hi` (multi-GPU) does not correlate with the slot
-    return (lo ^ (hi >> 17)) & mask;
+    return __umul64hi(lo ^ (hi >> 17), mask + 1) & ~1ull;
 }
+__device__ __forceinline__ uint64_t table_next(uint64_t s, uint64_t mask) { return s == mask ? 0 : s + 1; }
 
 // Side-list insert (serialised by a spin lock taken one lane at a time).  Returns the entry index.
 __device__ inline uint32_t table_exc_upsert(const TableView &t, uint64_t lo, uint64_t hi, uint32_t add, uint32_t set_val,
@@ -115,7 +121,7 @@ __device__ inline uint32_t table_exc_upsert(const TableView &t, uint64_t lo, uin
 __device__ __forceinline__ uint32_t table_find_or_insert(const TableView &t, uint64_t lo, uint64_t hi, bool create, bool *created = nullptr) {
     uint64_t s = table_home(lo, hi, t.mask);
     const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
-    for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
+    for (uint64_t probes = 0; probes <= limit; probes++, s = table_next(s, t.mask)) {
         unsigned long long cur = __hip_atomic_load(&t.slots[s].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0ull) {
             if (!create) return SLOT_NONE;
@@ -162,7 +168,7 @@ __device__ __forceinline__ bool table_lookup_side(const TableView &t, uint64_t l
 // the probe sequence from slot s on (the key has no zero word)
 __device__ __forceinline__ bool table_lookup_from(const TableView &t, uint64_t s, uint64_t probes, uint64_t lo, uint64_t hi, uint32_t &val) {
     const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
-    for (; probes <= limit; probes++, s = (s + 1) & t.mask) {
+    for (; probes <= limit; probes++, s = table_next(s, t.mask)) {
         const SlotWords w = slot_load(&t.slots[s]);
         if (w.lo == 0ull) return false;
         if (w.lo == lo && w.hi == hi) { val = w.val; return true; }
@@ -170,10 +176,31 @@ __device__ __forceinline__ bool table_lookup_from(const TableView &t, uint64_t s
     return false;   // inserts never place a key beyond the probe limit
 }
 
+// Both slots of a key's home sector in one round trip, and the verdict they allow: 1 found (val set), 0 absent, -1 look further (from
+// the next sector on, two probes done).  A key sits in the second slot only if the first was taken when it arrived, and slots are never
+// emptied: an empty first slot ends the search.
+struct SlotPair { SlotWords a, b; };
+__device__ __forceinline__ SlotPair pair_load(const TableSlot *home) {
+    SlotPair p;
+    p.a = slot_load(home);
+    p.b = slot_load(home + 1);
+    return p;
+}
+__device__ __forceinline__ int pair_verdict(const SlotPair &p, uint64_t lo, uint64_t hi, uint32_t &val) {
+    if (p.a.lo == lo && p.a.hi == hi) { val = p.a.val; return 1; }
+    if (p.a.lo == 0ull) return 0;
+    if (p.b.lo == lo && p.b.hi == hi) { val = p.b.val; return 1; }
+    if (p.b.lo == 0ull) return 0;
+    return -1;
+}
+
 // Read-only lookup after the build kernel completed (plain loads are safe across a kernel boundary).
 __device__ __forceinline__ bool table_lookup(const TableView &t, uint64_t lo, uint64_t hi, uint32_t &val) {
     if (lo == 0ull || hi == 0ull) return table_lookup_side(t, lo, hi, val);
-    return table_lookup_from(t, table_home(lo, hi, t.mask), 0, lo, hi, val);
+    const uint64_t s = table_home(lo, hi, t.mask);
+    const int v = pair_verdict(pair_load(&t.slots[s]), lo, hi, val);
+    if (v >= 0) return v != 0;
+    return table_lookup_from(t, table_next(s + 1, t.mask), 2, lo, hi, val);
 }
 
 // (the field-by-field form, kept for A/B timing: mdbg_set_option "index_tuning")
@@ -181,7 +208,7 @@ __device__ __forceinline__ bool table_lookup_narrow(const TableView &t, uint64_t
     if (lo == 0ull || hi == 0ull) return table_lookup_side(t, lo, hi, val);
     uint64_t s = table_home(lo, hi, t.mask);
     const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
-    for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
+    for (uint64_t probes = 0; probes <= limit; probes++, s = table_next(s, t.mask)) {
         const TableSlot &sl = t.slots[s];
         unsigned long long cur = sl.lo;
         if (cur == 0ull) return false;
@@ -200,7 +227,7 @@ __device__ __forceinline__ uint32_t table_lookup_slot(const TableView &t, uint64
     }
     uint64_t s = table_home(lo, hi, t.mask);
     const uint64_t limit = t.mask < TABLE_MAX_PROBES ? t.mask : (uint64_t)TABLE_MAX_PROBES;
-    for (uint64_t probes = 0; probes <= limit; probes++, s = (s + 1) & t.mask) {
+    for (uint64_t probes = 0; probes <= limit; probes++, s = table_next(s, t.mask)) {
         const TableSlot &sl = t.slots[s];
         unsigned long long cur = sl.lo;
         if (cur == 0ull) return SLOT_NONE;
@@ -340,8 +367,7 @@ struct DeviceTable {
     DevBuf<uint32_t> exc_val, exc_rep, ctl;  // ctl: [0]=exc_n [1]=exc_lock [2]=overflow [4..4+TABLE_OCC_WAYS)=occupied counts
 
     int init(mdbg_ctx *ctx, uint64_t min_slots) {
-        cap = 1024;
-        while (cap < min_slots) cap <<= 1;
+        cap = min_slots < 1024 ? 1024 : (min_slots + 255) / 256 * 256;     // (a multiple of 256: whole blocks walk whole sectors)
         if (cap > (1ull << 31)) return set_error(ctx, MDBG_ERANGE, "hash table of %llu slots exceeds 2^31", (unsigned long long)cap);
         MDBG_TRY(slots.alloc(ctx, cap));
         MDBG_TRY(exc_lo.alloc(ctx, TABLE_EXC_CAP));
@@ -392,9 +418,17 @@ struct DeviceTable {
 
 // Build a table with a capacity guessed from `expected` keys and grow x4 until `fill` (which launches
 // the insert kernels) completes without a probe sequence exceeding TABLE_MAX_PROBES.
+// slots for `keys` keys at the load the passes run best at (MDBG_TABLE_LOAD_PCT, default 22: DESIGN.md 4.2), never more than the 2^31
+// a table may have (then the load is what it is; inserts report an overflow when a probe sequence gets too long)
+inline uint64_t table_slots_for(uint64_t keys) {
+    static const unsigned pct = [] { const char *e = getenv("MDBG_TABLE_LOAD_PCT"); const int v = e ? atoi(e) : 0; return v >= 5 && v <= 60 ? (unsigned)v : 22u; }();
+    const uint64_t want = keys * 100 / pct + 1024;
+    return want > (1ull << 31) ? (1ull << 31) : want;
+}
+
 template <typename Fill>
 int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uint64_t upper_bound, Fill fill) {
-    uint64_t want = expected * 2 + 1024;
+    uint64_t want = table_slots_for(expected);
     const uint64_t most = upper_bound + upper_bound / 2 + 1024;   // load <= 2/3 even if every key is distinct
     if (want > most) want = most;
     for (;;) {
