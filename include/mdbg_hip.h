@@ -329,6 +329,35 @@ int  mdbg_table_keys_to_host(mdbg_ctx *ctx, const mdbg_table *t, uint64_t *keys_
 int  mdbg_unitig_edge_index(mdbg_ctx *ctx, const mdbg_minimizers *unitigs, uint32_t k, mdbg_table **edges, uint64_t *checksum);
 void mdbg_table_free(mdbg_table *t);
 
+/* ---- files of records handed over as BYTES (round 6) ---------------------------------------------------------------------------
+ * What `graph` reads at every k -- read_data_corrected.txt and unitig_data.txt (`u32 n; u8 circular; u32 m[n]` per record,
+ * readSelection/ReadSelection.hpp:1420-1426, read back by KminmerParserParallel under one critical section, Commons.hpp:7394-7424)
+ * and kminmerData_abundance_prev.txt (20-byte records, loaded by CreateMdbg::loadRefinedAbundances, graph/CreateMdbg.cpp:3401-3491) --
+ * need not be parsed into arrays on the host first: the file's bytes travel as they are, in pieces, from page-locked slabs
+ * (mdbg_host_alloc) beside whatever else the process does, and the records are taken apart on the device.  One `graph` process per k
+ * is how the reference runs the loop (pipeline/AssemblyPipeline.hpp:763-792): 97 of them in a default assembly of 10 kb reads.
+ *
+ * mdbg_bytes_create       a device buffer of n_bytes.
+ * mdbg_bytes_upload_async `n` bytes from `host` to offset `at`, queued on the context's upload stream; returns at once when `host` is
+ *                         page-locked.  *ticket (optional) names the copy: `host` may be reused once mdbg_bytes_upload_done(ticket) says so.
+ * mdbg_bytes_upload_done  1 = the copy named by `ticket` (and every earlier one) is complete, 0 = not yet (wait != 0: block until it is).
+ * mdbg_minimizers_from_record_bytes
+ *                         the minimizer-space read set of a record file whose bytes are in `records`: `offsets` (host, n_reads + 1) are
+ *                         the minimizers before each read, as the caller's walk over the record headers found them -- record r then
+ *                         starts at byte 5 r + 4 offsets[r].  Every record's own count is checked against the offsets on the device
+ *                         (MDBG_EINVAL on a mismatch: the bytes are not that file).  circular (optional, host, n_reads) receives the
+ *                         records' flag bytes.  Uploads still in flight are waited for on the device, not by the host.
+ * mdbg_prev_from_record_bytes
+ *                         mdbg_prev_from_records for a table file whose bytes are in `records`. */
+typedef struct mdbg_bytes mdbg_bytes;
+int  mdbg_bytes_create(mdbg_ctx *ctx, uint64_t n_bytes, mdbg_bytes **out);
+int  mdbg_bytes_upload_async(mdbg_ctx *ctx, mdbg_bytes *b, uint64_t at, const void *host, uint64_t n, uint64_t *ticket);
+int  mdbg_bytes_upload_done(mdbg_ctx *ctx, mdbg_bytes *b, uint64_t ticket, int wait);
+void mdbg_bytes_free(mdbg_bytes *b);
+int  mdbg_minimizers_from_record_bytes(mdbg_ctx *ctx, const mdbg_bytes *records, const uint64_t *offsets, uint32_t n_reads,
+                                       uint8_t *circular, mdbg_minimizers **out);
+int  mdbg_prev_from_record_bytes(mdbg_ctx *ctx, const mdbg_bytes *records, uint64_t n_records, mdbg_table **out);
+
 /* Page-locked host memory for read batches handed to mdbg_reads_from_ascii / _from_packed: uploads from it
  * run at PCIe rate instead of through the driver's staging copies.  Release with mdbg_host_free. */
 int  mdbg_host_alloc(mdbg_ctx *ctx, size_t bytes, void **out);

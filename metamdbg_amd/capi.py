@@ -116,6 +116,12 @@ SIGNATURES = {
     "mdbg_shard_abort": (C.c_int, [_P, _P, C.c_int]),
     "mdbg_kminmer_count_first_sharded": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "mdbg_shard_exchange": (C.c_int, [_P, _P, _P, _P, _u64p, C.POINTER(_P)]),
+    "mdbg_bytes_create": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "mdbg_bytes_upload_async": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _u64p]),
+    "mdbg_bytes_upload_done": (C.c_int, [_P, _P, C.c_uint64, C.c_int]),
+    "mdbg_bytes_free": (None, [_P]),
+    "mdbg_minimizers_from_record_bytes": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.POINTER(_P)]),
+    "mdbg_prev_from_record_bytes": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P)]),
 }
 
 _lib = None
@@ -327,6 +333,38 @@ class Context:
         ck = C.c_uint64()
         self.check(lib().mdbg_unitig_edge_index(self.h, unitigs.h, k, C.byref(h), C.byref(ck)))
         return Table(self, h), ck.value
+
+    # -- record files handed over as bytes (mdbg_bytes_*) ------------------------------------------
+    def bytes_from_host(self, raw: bytes, piece: int = 1 << 22) -> "DeviceBytes":
+        """A file's bytes on the device, uploaded in pieces (tests: from ordinary memory, so every piece is a blocking copy)."""
+        h = C.c_void_p()
+        self.check(lib().mdbg_bytes_create(self.h, len(raw), C.byref(h)))
+        b = DeviceBytes(self, h)
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        last = C.c_uint64(0)
+        for at in range(0, len(raw), piece):
+            n = min(piece, len(raw) - at)
+            self.check(lib().mdbg_bytes_upload_async(self.h, h, at, buf[at:].ctypes.data_as(C.c_void_p), n, C.byref(last)))
+        if last.value:
+            rc = lib().mdbg_bytes_upload_done(self.h, h, last.value, 1)
+            if rc != 1:
+                self.check(rc if rc < 0 else -1)
+        return b
+
+    def minimizers_from_record_bytes(self, b: "DeviceBytes", offsets: np.ndarray, want_circular: bool = False):
+        """read_data_corrected.txt / unitig_data.txt records taken apart on the device (mdbg_minimizers_from_record_bytes)."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        circ = np.zeros(n, dtype=np.uint8) if want_circular else None
+        h = C.c_void_p()
+        self.check(lib().mdbg_minimizers_from_record_bytes(self.h, b.h, _ptr(offs), n, _ptr(circ), C.byref(h)))
+        m = Minimizers(self, h)
+        return (m, circ) if want_circular else m
+
+    def prev_from_record_bytes(self, b: "DeviceBytes", n_records: int) -> "Table":
+        h = C.c_void_p()
+        self.check(lib().mdbg_prev_from_record_bytes(self.h, b.h, n_records, C.byref(h)))
+        return Table(self, h)
 
     def small_contigs(self, unitigs: "Minimizers", k: int, k_prev: int, prev: "Table") -> np.ndarray:
         """1 per unitig that IndexKminmerFunctor writes to smallContigs_k<k>.bin instead of indexing (k > 8 is the caller's test)."""
@@ -561,6 +599,22 @@ class Reads:
     def free(self) -> None:
         if self.h:
             lib().mdbg_reads_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceBytes:
+    def __init__(self, ctx: "Context", h):
+        self.ctx, self.h = ctx, h
+
+    def free(self) -> None:
+        if self.h:
+            lib().mdbg_bytes_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -789,11 +789,8 @@ __global__ void interleave_keys_kernel(const uint64_t *lo, const uint64_t *hi, u
 __global__ void unpack_records_kernel(const uint8_t *rec, uint64_t n, uint64_t *lo, uint64_t *hi, uint32_t *ab) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint8_t *p = rec + 20 * i;
-    uint64_t l = 0, h = 0; uint32_t a = 0;
-    for (int b = 0; b < 8; b++) { l |= (uint64_t)p[b] << (8 * b); h |= (uint64_t)p[8 + b] << (8 * b); }
-    for (int b = 0; b < 4; b++) a |= (uint32_t)p[16 + b] << (8 * b);
-    lo[i] = l; hi[i] = h; ab[i] = a;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(rec) + 5 * i;      // (records are 20 bytes from a 256-byte aligned start)
+    lo[i] = (uint64_t)p[0] | ((uint64_t)p[1] << 32); hi[i] = (uint64_t)p[2] | ((uint64_t)p[3] << 32); ab[i] = p[4];
 }
 
 __global__ void pack_records_kernel(const uint64_t *lo, const uint64_t *hi, const uint32_t *ab, uint64_t n, uint8_t *rec) {
@@ -1005,6 +1002,31 @@ extern "C" int mdbg_prev_from_records(mdbg_ctx *ctx, const uint8_t *records20, u
     if ((rc = tab->check_overflow(ctx))) return fail(rc);
     t->lookup = std::move(tab);
     *out = t;
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+namespace mdbg { int bytes_ready_on(mdbg_ctx *ctx, const mdbg_bytes *b); }
+
+extern "C" int mdbg_prev_from_record_bytes(mdbg_ctx *ctx, const mdbg_bytes *records, uint64_t n_records, mdbg_table **out) try {
+    if (!ctx || !out || !records) return set_error(ctx, MDBG_EINVAL, "mdbg_prev_from_record_bytes: bad argument");
+    if (n_records * 20 != records->n) return set_error(ctx, MDBG_EINVAL, "mdbg_prev_from_record_bytes: %llu records are not the buffer's %llu bytes",
+                                                       (unsigned long long)n_records, (unsigned long long)records->n);
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<mdbg_table> t(new mdbg_table());
+    MDBG_TRY(alloc_rows(ctx, t.get(), n_records, false));
+    MDBG_TRY(bytes_ready_on(ctx, records));
+    if (n_records)
+        hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for(n_records, 256)), dim3(256), 0, ctx->stream, records->d.p, n_records,
+                           t->d_lo.p, t->d_hi.p, t->d_ab.p);
+    std::unique_ptr<DeviceTable> tab(new DeviceTable());
+    MDBG_TRY(tab->init(ctx, table_slots_for(n_records + n_records / 4) + 4096));      // headroom: the unitig overlay may add keys
+    if (n_records)
+        hipLaunchKernelGGL(rows_insert_kernel, dim3(grid_for(n_records, 256)), dim3(256), 0, ctx->stream,
+                           t->d_lo.p, t->d_hi.p, t->d_ab.p, n_records, 1, tab->view());
+    MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MDBG_TRY(tab->check_overflow(ctx));
+    t->lookup = std::move(tab);
+    *out = t.release();
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 

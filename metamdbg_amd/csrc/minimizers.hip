@@ -319,6 +319,134 @@ extern "C" int mdbg_minimizers_from_host(mdbg_ctx *ctx, const uint32_t *minimize
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
+// ---- a file's bytes on the device (mdbg_bytes_*) and the records taken apart there --------------------------------------------------
+extern "C" int mdbg_bytes_create(mdbg_ctx *ctx, uint64_t n_bytes, mdbg_bytes **out) try {
+    if (!ctx || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_bytes_create: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<mdbg_bytes> b(new mdbg_bytes());
+    b->n = n_bytes;
+    b->owner = ctx;
+    MDBG_TRY(b->d.alloc(ctx, n_bytes + 16));            // (the gather reads whole aligned words around a record's values)
+    if (!ctx->upload_stream) MDBG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    // the block comes from the pool, whose reuse is ordered by the context's stream: the first upload starts after what that stream has queued so far
+    hipEvent_t ev = nullptr;
+    MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->upload_stream, ev, 0);
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "mdbg_bytes_create: %s", hipGetErrorString(e));
+    *out = b.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_bytes_upload_async(mdbg_ctx *ctx, mdbg_bytes *b, uint64_t at, const void *host, uint64_t n, uint64_t *ticket) try {
+    if (!ctx || !b || (n && !host)) return set_error(ctx, MDBG_EINVAL, "mdbg_bytes_upload_async: null argument");
+    if (at > b->n || n > b->n - at) return set_error(ctx, MDBG_EINVAL, "mdbg_bytes_upload_async: [%llu, +%llu) lies outside the %llu bytes of the buffer",
+                                                     (unsigned long long)at, (unsigned long long)n, (unsigned long long)b->n);
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev = nullptr;
+    MDBG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    std::lock_guard<std::mutex> g(b->mu);               // several feeder threads: copy and event stay together
+    hipError_t e = n ? hipMemcpyAsync(b->d.p + at, host, n, hipMemcpyHostToDevice, ctx->upload_stream) : hipSuccess;
+    if (e == hipSuccess) e = hipEventRecord(ev, ctx->upload_stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); return set_error(ctx, MDBG_EHIP, "mdbg_bytes_upload_async: %s", hipGetErrorString(e)); }
+    b->events.push_back(ev);
+    if (ticket) *ticket = b->events.size();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
+extern "C" int mdbg_bytes_upload_done(mdbg_ctx *ctx, mdbg_bytes *b, uint64_t ticket, int wait) try {
+    if (!ctx || !b) return set_error(ctx, MDBG_EINVAL, "mdbg_bytes_upload_done: null argument");
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> g(b->mu);
+        if (ticket == 0 || ticket <= b->done_upto) return 1;
+        if (ticket > b->events.size()) return set_error(ctx, MDBG_EINVAL, "mdbg_bytes_upload_done: no such ticket");
+        ev = b->events[ticket - 1];
+    }
+    const hipError_t e = wait ? hipEventSynchronize(ev) : hipEventQuery(ev);
+    if (e == hipErrorNotReady) return 0;
+    if (e != hipSuccess) return set_error(ctx, MDBG_EHIP, "mdbg_bytes_upload_done: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> g(b->mu);
+    if (ticket > b->done_upto) b->done_upto = ticket;
+    return 1;
+} MDBG_API_CATCH(ctx)
+
+extern "C" void mdbg_bytes_free(mdbg_bytes *b) { delete b; }
+
+namespace mdbg {
+// the kernels `ctx` queues next see every piece uploaded so far
+int bytes_ready_on(mdbg_ctx *ctx, const mdbg_bytes *b) {
+    mdbg_bytes *mb = const_cast<mdbg_bytes *>(b);
+    std::lock_guard<std::mutex> g(mb->mu);
+    if (!mb->events.empty()) MDBG_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, mb->events.back(), 0));
+    return MDBG_OK;
+}
+}
+
+// Record r of a `u32 n; u8 circular; u32 m[n]` file starts at byte 5 r + 4 off[r]; its values sit 5 bytes further: at a misalignment
+// of (r + 1) mod 4 that is the same for the whole record, so a value is two aligned words and one v_alignbyte.  16 lanes a record.
+__global__ __launch_bounds__(256) void records_gather_kernel(const uint8_t *raw, uint64_t n_bytes, const uint64_t *off, uint32_t n_reads, uint32_t *mins,
+                                                             uint8_t *circ, uint32_t *bad) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(raw);
+    for (uint64_t r = group; r < n_reads; r += ngroups) {
+        const uint64_t o0 = off[r], n = off[r + 1] - o0;
+        const uint64_t at = 5 * r + 4 * o0;                         // the record's first byte
+        if (at + 5 + 4 * n > n_bytes) { if (sub == 0) atomicExch(bad, 1u); continue; }
+        if (sub == 0) {
+            uint32_t cnt = 0;
+            for (int j = 0; j < 4; j++) cnt |= (uint32_t)raw[at + j] << (8 * j);
+            if (cnt != (uint32_t)n || n >> 32) atomicExch(bad, 1u);
+            if (circ) circ[r] = raw[at + 4];
+        }
+        const uint64_t v0 = at + 5;
+        const uint32_t sh = (uint32_t)(v0 & 3u);
+        const uint64_t w0 = v0 >> 2;
+        for (uint64_t j = sub; j < n; j += 16) {
+            const uint32_t a = words[w0 + j];
+            const uint32_t b = sh ? words[w0 + j + 1] : 0u;
+            mins[o0 + j] = sh ? __builtin_amdgcn_alignbyte(b, a, sh) : a;
+        }
+    }
+}
+
+extern "C" int mdbg_minimizers_from_record_bytes(mdbg_ctx *ctx, const mdbg_bytes *records, const uint64_t *offsets, uint32_t n_reads,
+                                                 uint8_t *circular, mdbg_minimizers **out) try {
+    if (!ctx || !records || !offsets || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_record_bytes: null argument");
+    MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (size_t i = 1; i <= n_reads; i++)
+        if (offsets[i] < offsets[i - 1]) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_record_bytes: offsets must be non-decreasing");
+    if (offsets[0] != 0) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_record_bytes: offsets[0] must be 0");
+    const uint64_t n_min = offsets[n_reads];
+    if (5ull * n_reads + 4ull * n_min != records->n)
+        return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_record_bytes: %u records of %llu minimizers are %llu bytes, the buffer holds %llu",
+                         n_reads, (unsigned long long)n_min, (unsigned long long)(5ull * n_reads + 4ull * n_min), (unsigned long long)records->n);
+    std::unique_ptr<mdbg_minimizers> m(new mdbg_minimizers());
+    m->n_reads = n_reads;
+    m->n_min = n_min;
+    MDBG_TRY(m->d_off.alloc(ctx, (size_t)n_reads + 1));
+    MDBG_TRY(m->d_min.alloc(ctx, n_min));
+    DevBuf<uint8_t> d_circ;
+    DevBuf<uint32_t> d_bad;
+    if (circular) MDBG_TRY(d_circ.alloc(ctx, n_reads));
+    MDBG_TRY(d_bad.alloc(ctx, 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(d_bad.p, 0, 4, ctx->stream));
+    MDBG_HIP_CHECK(ctx, hipMemcpyAsync(m->d_off.p, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    MDBG_TRY(bytes_ready_on(ctx, records));
+    if (n_reads)
+        hipLaunchKernelGGL(records_gather_kernel, dim3(grid_for((uint64_t)n_reads * 16, 256, (unsigned)ctx->n_cu * 16)), dim3(256), 0, ctx->stream,
+                           records->d.p, records->n, m->d_off.p, n_reads, m->d_min.p, circular ? d_circ.p : nullptr, d_bad.p);
+    uint32_t bad = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+    if (circular && n_reads) MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, circular, d_circ.p, n_reads, hipMemcpyDeviceToHost));
+    if (bad) return set_error(ctx, MDBG_EINVAL, "mdbg_minimizers_from_record_bytes: a record's count does not agree with the offsets (not this file's bytes?)");
+    *out = m.release();
+    return MDBG_OK;
+} MDBG_API_CATCH(ctx)
+
 extern "C" int mdbg_minimizers_device_ptrs(const mdbg_minimizers *m, const uint64_t **d_offsets, const uint32_t **d_minimizers) {
     if (!m) return MDBG_EINVAL;
     if (m->scattered) { int rc = ensure_canonical(m->owner, m); if (rc) return rc; }

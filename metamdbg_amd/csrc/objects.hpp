@@ -55,6 +55,21 @@ inline hipError_t reads_ready_on(mdbg_ctx *ctx, const mdbg_reads *r) {
 inline hipError_t reads_ready_host(const mdbg_reads *r) { return r && r->ready ? hipEventSynchronize(r->ready) : hipSuccess; }
 }
 
+// A file's bytes on the device, uploaded in pieces on the context's upload stream (mdbg_bytes_*).  Every piece records an event behind
+// itself; a ticket is the piece's ordinal (copies on one stream complete in order, so "ticket t done" covers every earlier one).
+struct mdbg_bytes {
+    uint64_t n = 0;
+    mdbg::DevBuf<uint8_t> d;
+    std::mutex mu;
+    std::vector<hipEvent_t> events;     // events[t - 1] behind piece t
+    uint64_t done_upto = 0;             // tickets <= done_upto are known complete
+    mdbg_ctx *owner = nullptr;
+    mdbg_bytes() = default;
+    mdbg_bytes(const mdbg_bytes &) = delete;
+    mdbg_bytes &operator=(const mdbg_bytes &) = delete;
+    ~mdbg_bytes() { for (hipEvent_t e : events) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } }   // before the buffer goes
+};
+
 // Minimizer-space sequences in HBM as CSR.  Per-minimizer side arrays exist only for scan output.
 struct mdbg_minimizers {
     uint32_t n_reads = 0;

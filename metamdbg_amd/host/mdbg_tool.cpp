@@ -19,6 +19,7 @@
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -45,6 +46,7 @@
 #include "../../include/mdbg_hip.h"
 #include "fastx.hpp"
 #include "hostfeed.hpp"
+#include "records.hpp"
 
 namespace {
 
@@ -71,6 +73,25 @@ struct Trace {
     Trace() : t0(now()) {}
     void mark(const char *what) { if (getenv("MDBG_TRACE")) fprintf(stderr, "[mdbg_tool] %8.3f s  %s\n", now() - t0, what); }
 } g_trace;
+// The process the caller waits for is a thin launcher (main): this one -- the worker, its child -- tells it through a pipe that every
+// output file is written and closed, and the launcher exits at once with the status byte.  What the worker still has to do then is
+// die: 0.11 - 0.28 s in which the kernel releases its GPU state (tools/exit_cost.py, profiles/round5_k_tool_exit_cost_*.json: whatever
+// the tool tears down first), a quarter of a `graph` process at k >= 5 -- it now passes beside the caller's next step instead of in
+// front of it.  The worker's stdout / stderr are closed first so that a caller reading them through pipes sees their end.
+// MDBG_TOOL_NO_DETACH=1: one process, as before.
+int g_done_fd = -1;
+void signal_done(int status) {
+    if (g_done_fd < 0) return;
+    fflush(nullptr);
+    const char c = (char)status;
+    ssize_t w;
+    do w = write(g_done_fd, &c, 1); while (w < 0 && errno == EINTR);
+    close(g_done_fd);
+    g_done_fd = -1;
+    const int nul = open("/dev/null", O_WRONLY);
+    if (nul >= 0) { dup2(nul, 1); dup2(nul, 2); if (nul > 2) close(nul); }
+}
+
 [[noreturn]] void finish() {
     fflush(nullptr);
     // (measuring aid: what part of the time between "done" and the parent's wait() returning is the first context's teardown)
@@ -88,6 +109,7 @@ struct Trace {
         if (how == 5) { usleep(200000); g_trace.mark("exit trace: idle for 0.2 s"); }
         fprintf(stderr, "[mdbg_tool] exit trace: clock started at %.6f, _exit at %.6f (epoch seconds)\n", g_trace.t0, Trace::now());
     }
+    signal_done(0);
     _exit(0);
 }
 void check(int rc, const char *what) {
@@ -961,14 +983,14 @@ void parse_minimizer_reads(const std::vector<uint8_t> &raw, std::vector<uint32_t
 struct MappedFile {
     const uint8_t *p = nullptr;
     size_t n = 0;
-    explicit MappedFile(const std::string &path) {
+    explicit MappedFile(const std::string &path, bool populate = true, bool required = true) {
         const int fd = open(path.c_str(), O_RDONLY);
-        if (fd < 0) die("File not found: " + path);
+        if (fd < 0) { if (required) die("File not found: " + path); return; }
         struct stat st;
         if (fstat(fd, &st) != 0) die("cannot stat " + path);
         n = (size_t)st.st_size;
         if (n) {
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | (populate ? MAP_POPULATE : 0), fd, 0);   // (not populated: the threads that walk it fault it in, each its own part)
             if (m == MAP_FAILED) die("cannot map " + path);
             p = (const uint8_t *)m;
         }
@@ -979,9 +1001,60 @@ struct MappedFile {
     MappedFile &operator=(const MappedFile &) = delete;
 };
 
+// A file's bytes to the device as they are (mdbg_bytes_*): `workers` threads copy pieces of the mapped file into page-locked slabs of their
+// own (two each: one travels while the other is filled) and queue them on the library's upload stream.  The 1.55 GB of configs[2]'s
+// read_data_corrected.txt go over in the time the link needs; through one pageable hipMemcpy of a parsed copy they took three times that,
+// after 0.5 s of parsing (profiles/round6_*_graph_per_k_*.json).
+// page-locked slabs of 8 MB, kept from one upload to the next (locking 128 MB of pages costs as much as sending them)
+struct SlabPool {
+    static size_t bytes() { static const size_t b = [] { const char *e = getenv("MDBG_TOOL_SLAB_MB"); const int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 256 ? v : 8) << 20; }(); return b; }
+    std::mutex mu;
+    std::vector<void *> idle;
+    void *get(mdbg_ctx *ctx) {
+        { std::lock_guard<std::mutex> g(mu); if (!idle.empty()) { void *p = idle.back(); idle.pop_back(); return p; } }
+        void *p = nullptr;
+        return mdbg_host_alloc(ctx, bytes(), &p) == MDBG_OK ? p : nullptr;
+    }
+    void put(void *p) { if (p) { std::lock_guard<std::mutex> g(mu); idle.push_back(p); } }
+} g_slabs;
+
+mdbg_bytes *upload_file_bytes(mdbg_ctx *ctx, const uint8_t *p, size_t n, int threads) {
+    mdbg_bytes *b = nullptr;
+    check_on(ctx, mdbg_bytes_create(ctx, n, &b), "mdbg_bytes_create");
+    if (!n) return b;
+    const size_t piece = SlabPool::bytes();
+    const size_t nPieces = (n + piece - 1) / piece;
+    static const size_t maxW = [] { const char *e = getenv("MDBG_TOOL_UPLOAD_WORKERS"); const int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 8); }();
+    const unsigned W = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(1, threads), maxW, nPieces}));
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        void *slab[2] = {nullptr, nullptr};
+        uint64_t ticket[2] = {0, 0};
+        for (int s = 0; s < 2; s++) if (!(slab[s] = g_slabs.get(ctx))) { failed = 1; return; }
+        for (int turn = 0;; turn ^= 1) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nPieces || failed) break;
+            if (ticket[turn] && mdbg_bytes_upload_done(ctx, b, ticket[turn], 1) != 1) { failed = 1; break; }
+            const size_t at = i * piece, cnt = std::min(piece, n - at);
+            memcpy(slab[turn], p + at, cnt);
+            if (mdbg_bytes_upload_async(ctx, b, at, slab[turn], cnt, &ticket[turn]) != MDBG_OK) { failed = 1; break; }
+        }
+        for (int s = 0; s < 2; s++) {
+            if (ticket[s] && mdbg_bytes_upload_done(ctx, b, ticket[s], 1) != 1) failed = 1;
+            g_slabs.put(slab[s]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < W; w++) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+    if (failed) die(std::string("upload of a record file failed: ") + mdbg_last_error(ctx));
+    return b;
+}
+
 // What `graph` reads besides the reads when k > firstK, parsed once on the host (every rank builds its own device copy).
 struct PrevInputs {
-    std::vector<uint8_t> prevRec;                 // kminmerData_abundance_prev.txt
+    std::unique_ptr<MappedFile> prevRec;          // kminmerData_abundance_prev.txt, mapped: its bytes travel as they are (mdbg_prev_from_record_bytes)
     std::vector<uint32_t> um, uab;                // unitigGraph_prev.nodes.bin sequences + the refined abundance of each (0xFFFFFFFF = none)
     std::vector<uint64_t> uoff{0};
     std::vector<uint32_t> unitigMins;             // unitig_data.txt
@@ -992,7 +1065,8 @@ struct PrevInputs {
 
 void load_prev_inputs(const std::string &dir, PrevInputs &in) {
     // loadRefinedAbundances (graph/CreateMdbg.cpp:3401-3709)
-    in.prevRec = read_file(dir + "/kminmerData_abundance_prev.txt");
+    in.prevRec.reset(new MappedFile(dir + "/kminmerData_abundance_prev.txt"));
+    if (in.prevRec->n % 20) die("kminmerData_abundance_prev.txt is not a whole number of 20-byte records");
     // unitigGraph.nodes.refined_abundances.bin: (u32 unitigName, u32 abundance)*
     std::vector<uint8_t> ab = read_file(dir + "/unitigGraph.nodes.refined_abundances.bin", false);
     std::vector<std::pair<uint32_t, uint32_t>> name2ab(ab.size() / 8);
@@ -1036,9 +1110,13 @@ struct RankTable {
 struct PrevOnDevice {
     mdbg_table *prev = nullptr;
     mdbg_minimizers *unitigs = nullptr;
-    void build(mdbg_ctx *ctx, const Parameters &P, const PrevInputs &in, bool withUnitigs, std::string &smallContigs) {
+    void build(mdbg_ctx *ctx, const Parameters &P, const PrevInputs &in, bool withUnitigs, std::string &smallContigs, int threads = 4) {
         const uint32_t k = (uint32_t)P.kminmerSize;
-        check_on(ctx, mdbg_prev_from_records(ctx, in.prevRec.data(), in.prevRec.size() / 20, &prev), "mdbg_prev_from_records");
+        {
+            mdbg_bytes *rb = upload_file_bytes(ctx, in.prevRec->p, in.prevRec->n, threads);
+            check_on(ctx, mdbg_prev_from_record_bytes(ctx, rb, in.prevRec->n / 20, &prev), "mdbg_prev_from_record_bytes");
+            mdbg_bytes_free(rb);
+        }
         if (!in.uab.empty()) {
             mdbg_minimizers *un = nullptr;
             check_on(ctx, mdbg_minimizers_from_host(ctx, in.um.data(), in.uoff.data(), (uint32_t)in.uab.size(), &un), "mdbg_minimizers_from_host");
@@ -1088,7 +1166,8 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
         else check_on(ctx, mdbg_kminmer_count_first(ctx, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first");
     } else {
         PrevOnDevice dev;
-        dev.build(ctx, P, in, rank == 0, out.smallContigs);
+        dev.build(ctx, P, in, rank == 0, out.smallContigs, a.threads);
+        if (rank == 0) g_trace.mark("graph: the previous table on the device");
         mdbg_table *prev = dev.prev;
         mdbg_minimizers *unitigs = dev.unitigs;
         mdbg_table *local = nullptr;
@@ -1109,6 +1188,7 @@ void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, c
     }
     mdbg_table_info(table, nullptr, &out.n, &out.nSolid, &out.hasVec);
     check_on(ctx, mdbg_table_checksum(ctx, table, out.sums), "mdbg_table_checksum");
+    if (rank == 0) g_trace.mark("graph: the pass done, the table on the device");
     if (sink) sink(ctx, table);            // the rows go straight to their files (one rank: run_graph)
     else if (rowsToHost) {
         out.rec.resize(out.n * 20);
@@ -1131,13 +1211,16 @@ void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const s
     mdbg_table_info(table, nullptr, &n, nullptr, &hasVec);
     const bool vec = hasVec && !vecFile.empty();
     std::vector<int> recFd, vecFd;
+    // The files of the k before are overwritten IN PLACE and cut to their new length at the end (ftruncate below): truncating a 300 MB
+    // file of the page cache first gives its pages back one by one only for the writes to ask for them again (0.03 - 0.05 s a file at
+    // configs[2]'s size).  What the next stage finds is the same: these bytes, this length.
     for (const std::string &f : recFiles) {
-        const int fd = open(f.c_str(), O_CREAT | (firstShare ? O_TRUNC : 0) | O_WRONLY, 0644);
+        const int fd = open(f.c_str(), O_CREAT | O_WRONLY, 0644);
         if (fd < 0) die("cannot write " + f);
         recFd.push_back(fd);
     }
     if (vec) {
-        const int fd = open(vecFile.c_str(), O_CREAT | (firstShare ? O_TRUNC : 0) | O_WRONLY, 0644);
+        const int fd = open(vecFile.c_str(), O_CREAT | O_WRONLY, 0644);
         if (fd < 0) die("cannot write " + vecFile);
         vecFd.push_back(fd);
     }
@@ -1164,12 +1247,21 @@ void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const s
         check_on(ctx, mdbg_table_to_host_range(ctx, table, first, cnt, b.rec, vec ? b.vec : nullptr), "mdbg_table_to_host_range");
         for (auto &t : writers) t.join();        // the other buffer is free again, this one is full
         writers.clear();
-        for (int fd : recFd) writers.emplace_back(put, fd, (const void *)b.rec, (size_t)(cnt * 20), (rowBase + first) * 20);
-        for (int fd : vecFd) writers.emplace_back(put, fd, (const void *)b.vec, (size_t)(cnt * k * 4), (rowBase + first) * k * 4);
+        // a piece of a file by four threads (round 6: one thread a file wrote the 322 MB of configs[2]'s table at k >= 6 in 0.1 s -- page
+        // allocation in the page cache, not the copy -- half of what was left of a `graph` process)
+        auto spread = [&](int fd, const void *data, size_t bytes, uint64_t at) {
+            const size_t parts = bytes > ((size_t)8 << 20) ? 4 : 1;
+            for (size_t q = 0; q < parts; q++) {
+                const size_t a = bytes * q / parts / 4096 * 4096, e = q + 1 == parts ? bytes : bytes * (q + 1) / parts / 4096 * 4096;
+                writers.emplace_back(put, fd, (const void *)((const char *)data + a), e - a, at + a);
+            }
+        };
+        for (int fd : recFd) spread(fd, (const void *)b.rec, (size_t)(cnt * 20), (rowBase + first) * 20);
+        for (int fd : vecFd) spread(fd, (const void *)b.vec, (size_t)(cnt * k * 4), (rowBase + first) * k * 4);
     }
     for (auto &t : writers) t.join();
-    for (int fd : recFd) if (close(fd) != 0) die("closing a table file failed");
-    for (int fd : vecFd) if (close(fd) != 0) die("closing a table file failed");
+    for (int fd : recFd) if (ftruncate(fd, (off_t)((rowBase + n) * 20)) != 0 || close(fd) != 0) die("closing a table file failed");
+    for (int fd : vecFd) if (ftruncate(fd, (off_t)((rowBase + n) * k * 4)) != 0 || close(fd) != 0) die("closing a table file failed");
     for (Buf &b : buf) { if (b.rec) mdbg_host_free(ctx, b.rec); if (b.vec) mdbg_host_free(ctx, b.vec); }
 }
 
@@ -1204,7 +1296,7 @@ void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Ve
     std::vector<const uint64_t *> dRows(n, nullptr), dReplies(n, nullptr);
     std::vector<uint64_t> counts((size_t)n * n + 64, 0);
     PrevOnDevice dev;
-    if (!a.firstPass) dev.build(ctx, P, in, true, out.smallContigs);
+    if (!a.firstPass) dev.build(ctx, P, in, true, out.smallContigs, a.threads);
     for (uint32_t p = 0; p < n; p++) {
         std::vector<uint64_t> rel(offs.begin() + (long)cuts[p], offs.begin() + (long)cuts[p + 1] + 1);
         check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(cuts[p + 1] - cuts[p]), &reads[p]), "mdbg_minimizers_from_host");
@@ -1272,11 +1364,25 @@ int run_graph(int argc, char **argv) {
     if (!sharded && !g_ctx) ctxThread = std::thread([&] { ctxRc = mdbg_create(0, &g_ctx); });
     U32Vec mins;
     std::vector<uint64_t> offs{0};
+    // One rank (the reference's own call): read_data_corrected.txt is not parsed into an array here.  Its record headers are walked by
+    // several threads (host/records.hpp: exact) while the context comes up, its bytes then travel as they are and the records are taken
+    // apart on the device (mdbg_minimizers_from_record_bytes).  MDBG_TOOL_PARSE_ON_HOST=1: the way of rounds 1 - 5 (one walk, a host copy
+    // of the values, one pageable upload); several ranks slice the host array and keep it.
+    const bool byBytes = !resident && !sharded && !getenv("MDBG_TOOL_PARSE_ON_HOST");
+    std::unique_ptr<MappedFile> corrected;
     if (!resident) {
         offs.clear();
-        MappedFile corrected(dir + "/read_data_corrected.txt");
-        parse_minimizer_reads(corrected.p, corrected.n, mins, offs, nullptr, std::max(1, a.threads));
-        g_trace.mark("graph: read_data_corrected.txt read and parsed");
+        corrected.reset(new MappedFile(dir + "/read_data_corrected.txt", !byBytes));
+        if (byBytes) {
+            mdbgfeed::RecordIndex idx = mdbgfeed::index_records(corrected->p, corrected->n, std::max(1, std::min(a.threads, 16)));
+            if (idx.truncated) die("truncated minimizer read file");
+            offs = std::move(idx.offs);
+            g_trace.mark("graph: read_data_corrected.txt mapped, its records indexed");
+        } else {
+            parse_minimizer_reads(corrected->p, corrected->n, mins, offs, nullptr, std::max(1, a.threads));
+            corrected.reset();
+            g_trace.mark("graph: read_data_corrected.txt read and parsed");
+        }
     }
     const size_t nReads = offs.size() - 1;
     PrevInputs in;
@@ -1300,6 +1406,17 @@ int run_graph(int argc, char **argv) {
             if (offs[r + 1] - offs[first] > maxMins) { cuts.push_back(r); first = r; }
         }
         cuts.push_back(nReads);
+        if (byBytes && cuts.size() > 2) {            // the pass in pieces slices a host array
+            parse_minimizer_reads(corrected->p, corrected->n, mins, offs, nullptr, std::max(1, a.threads));
+            corrected.reset();
+        } else if (byBytes) {
+            mdbg_bytes *rb = upload_file_bytes(g_ctx, corrected->p, corrected->n, a.threads);
+            g_trace.mark("graph: the records' bytes on the device");
+            check_on(g_ctx, mdbg_minimizers_from_record_bytes(g_ctx, rb, offs.data(), (uint32_t)nReads, nullptr, &resident), "mdbg_minimizers_from_record_bytes");
+            mdbg_bytes_free(rb);
+            corrected.reset();
+            g_trace.mark("graph: the records taken apart there");
+        }
         if (cuts.size() > 2) {
             g_log.line("\tThe pass runs in " + std::to_string(cuts.size() - 1) + " pieces of at most " + std::to_string(maxMins) + " minimizers");
             graph_pieces(g_ctx, P, a, mins, offs, cuts, in, parts[0], [&](mdbg_ctx *c, mdbg_table *t, uint64_t rowBase, bool firstShare) {
@@ -1400,6 +1517,25 @@ int main(int argc, char **argv) {
     if (argc < 2) die("usage: mdbg_tool <readSelection|graph> ...");
     setenv("GPU_MAX_HW_QUEUES", "8", 0);   // two contexts must not share a hardware queue; before HIP starts
     const std::string cmd = argv[1];
+    if (!getenv("MDBG_TOOL_NO_DETACH") && (cmd == "readSelection" || cmd == "graph" || cmd == "asmStep")) {
+        // launcher and worker (see signal_done); before anything of HIP exists in this process
+        int fds[2];
+        if (pipe(fds) == 0) {
+            const pid_t pid = fork();
+            if (pid > 0) {
+                close(fds[1]);
+                char c = 0;
+                ssize_t r;
+                do r = read(fds[0], &c, 1); while (r < 0 && errno == EINTR);
+                if (r == 1) _exit((unsigned char)c);          // the worker's files are complete
+                int st = 0;                                    // the worker ended without saying so: its status is the command's
+                while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+                _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
+            }
+            if (pid == 0) { close(fds[0]); g_done_fd = fds[1]; fcntl(g_done_fd, F_SETFD, FD_CLOEXEC); }
+            else { close(fds[0]); close(fds[1]); }             // no fork: one process
+        }
+    }
     if (cmd == "readSelection") return run_read_selection(argc, argv);
     if (cmd == "graph") return run_graph(argc, argv);
     if (cmd == "asmStep") return run_read_selection(argc, argv, true);          // readSelection + graph --firstpass in one process, one context

@@ -19,6 +19,7 @@ struct mdbg_ctx { std::string err; };
 struct mdbg_reads { std::vector<uint32_t> len; };
 struct mdbg_minimizers { std::vector<uint64_t> off; std::vector<uint32_t> m, pos, len; std::vector<uint8_t> dir, qual, flags; };
 struct mdbg_table { uint32_t k = 0; std::vector<uint8_t> rec; std::vector<uint32_t> vec; };
+struct mdbg_bytes { std::vector<uint8_t> d; std::atomic<uint64_t> tickets{0}; };
 struct mdbg_census {};
 struct mdbg_comm {};
 struct mdbg_shard {};
@@ -98,6 +99,34 @@ int mdbg_minimizers_from_host(mdbg_ctx *, const uint32_t *mins, const uint64_t *
     return MDBG_OK;
 }
 void mdbg_minimizers_free(mdbg_minimizers *m) { delete m; }
+// a record file handed over as bytes: the double copies at once and takes the records apart on the host
+int mdbg_bytes_create(mdbg_ctx *, uint64_t n, mdbg_bytes **out) { *out = new mdbg_bytes(); (*out)->d.resize(n); return MDBG_OK; }
+int mdbg_bytes_upload_async(mdbg_ctx *, mdbg_bytes *b, uint64_t at, const void *host, uint64_t n, uint64_t *ticket) {
+    if (at > b->d.size() || n > b->d.size() - at) return MDBG_EINVAL;
+    jitter();
+    if (n) memcpy(b->d.data() + at, host, n);
+    const uint64_t t = b->tickets.fetch_add(1) + 1;
+    if (ticket) *ticket = t;
+    return MDBG_OK;
+}
+int mdbg_bytes_upload_done(mdbg_ctx *, mdbg_bytes *, uint64_t, int) { return 1; }
+void mdbg_bytes_free(mdbg_bytes *b) { delete b; }
+int mdbg_minimizers_from_record_bytes(mdbg_ctx *, const mdbg_bytes *b, const uint64_t *off, uint32_t n, uint8_t *circ, mdbg_minimizers **out) {
+    if (5ull * n + 4ull * off[n] != b->d.size()) return MDBG_EINVAL;
+    mdbg_minimizers *m = new mdbg_minimizers();
+    m->off.assign(off, off + n + 1);
+    m->m.resize(off[n]);
+    for (uint32_t r = 0; r < n; r++) {
+        const uint8_t *p = b->d.data() + 5ull * r + 4ull * off[r];
+        uint32_t cnt; memcpy(&cnt, p, 4);
+        if (cnt != off[r + 1] - off[r]) { delete m; return MDBG_EINVAL; }
+        if (circ) circ[r] = p[4];
+        if (cnt) memcpy(m->m.data() + off[r], p + 5, (size_t)cnt * 4);
+    }
+    *out = m;
+    return MDBG_OK;
+}
+int mdbg_prev_from_record_bytes(mdbg_ctx *, const mdbg_bytes *, uint64_t, mdbg_table **) { return MDBG_ENODEV; }
 int mdbg_minimizers_concat(mdbg_ctx *, const mdbg_minimizers *const *parts, uint32_t n_parts, mdbg_minimizers **out) {
     jitter();
     mdbg_minimizers *m = new mdbg_minimizers();

@@ -1673,6 +1673,53 @@ def test_table_rows_in_pieces(ctx):
             table.to_host_range(n, 1)
 
 
+def test_record_files_taken_apart_on_the_device(ctx, orc):
+    """mdbg_bytes_* + mdbg_minimizers_from_record_bytes / mdbg_prev_from_record_bytes: read_data_corrected.txt / unitig_data.txt records
+    (`u32 n; u8 circular; u32 m[n]`, ReadSelection.hpp:1420-1426) and kminmerData_abundance_prev.txt records handed over as the files'
+    BYTES, in pieces, equal the same files parsed on the host and uploaded as arrays -- every misalignment of a record's values (record r
+    starts at byte 5 r + 4 off[r]), empty records, the flag bytes; bytes that are not the file the offsets describe are refused."""
+    from metamdbg_amd import capi
+    rng = np.random.default_rng(606)
+    lens = np.concatenate([rng.integers(0, 60, 5000), [0, 0, 1, 70000, 3, 0]])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    mins = rng.integers(0, 2**32, int(offs[-1]), dtype=np.uint64).astype(np.uint32)
+    circ = rng.integers(0, 2, len(lens)).astype(np.uint8)
+    raw = bytearray(formats.write_minimizer_reads(mins, offs))
+    for r in range(len(lens)):
+        raw[5 * r + 4 * int(offs[r]) + 4] = int(circ[r])
+    raw = bytes(raw)
+    b = ctx.bytes_from_host(raw, piece=100_003)          # pieces that end anywhere
+    m, got_circ = ctx.minimizers_from_record_bytes(b, offs, want_circular=True)
+    h = m.to_host(full=False)
+    assert np.array_equal(h["minimizers"], mins) and np.array_equal(h["offsets"], offs) and np.array_equal(got_circ, circ)
+    # the table over it is the table over the uploaded arrays
+    rec1, _ = ctx.kminmer_count_first(m, 4, 0).to_host()
+    rec2, _ = ctx.kminmer_count_first(ctx.minimizers_from_host(mins, offs), 4, 0).to_host()
+    assert np.array_equal(formats.sorted_abundance_records(rec1), formats.sorted_abundance_records(rec2))
+    # offsets that do not describe these bytes: same total, another split -> a record's own count disagrees
+    bad = offs.copy(); bad[10] += 1
+    with pytest.raises(capi.MdbgError):
+        ctx.minimizers_from_record_bytes(b, bad)
+    with pytest.raises(capi.MdbgError):                  # another size altogether
+        ctx.minimizers_from_record_bytes(b, offs[:-1])
+    b.free()
+    # empty file
+    e = ctx.bytes_from_host(b"")
+    assert ctx.minimizers_from_record_bytes(e, np.zeros(1, np.uint64)).info() == dict(n_reads=0, n_minimizers=0)
+    # a previous table from its file's bytes answers like one from the records
+    t = orc.kminmer_count_first(mins % 50, offs, 3, 0)
+    recs = orc.table_abundance_records(t).tobytes()
+    p1 = ctx.prev_from_records(recs)
+    tb = ctx.bytes_from_host(recs, piece=77_777)
+    p2 = ctx.prev_from_record_bytes(tb, len(recs) // 20)
+    r = formats.parse_abundance_table(recs)
+    lo, hi = r["lo"].astype(np.uint64), r["hi"].astype(np.uint64)
+    assert np.array_equal(p1.lookup(lo, hi), p2.lookup(lo, hi))
+    assert np.array_equal(p2.lookup(lo, hi), np.where(r["abundance"] == 1, p2.lookup(lo, hi), r["abundance"]))
+    with pytest.raises(capi.MdbgError):
+        ctx.prev_from_record_bytes(tb, len(recs) // 20 + 1)
+
+
 def test_bad_arguments_are_refused_with_a_code_and_a_message(ctx):
     """include/mdbg_hip.h: every entry returns MDBG_E* with a message in mdbg_last_error instead of crashing, and the context goes on
     working -- null handles, null outputs, parameters outside what the path defines (l > 16, k < 2, a row range past the table, vectors of

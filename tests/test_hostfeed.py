@@ -268,6 +268,18 @@ def test_inflate_against_zlib(tmp_path):
     assert r.stdout.startswith("ok 30 streams")
 
 
+def test_record_files_indexed_on_several_threads(tmp_path):
+    """metamdbg_amd/host/records.hpp -- read_data_corrected.txt / unitig_data.txt walked by several threads that GUESS a record start
+    in their chunk and are joined exactly -- against the serial walk: random files, values that read as record headers (false guesses),
+    records longer than a chunk, empty records, all-zero files, truncation; 1 - 64 threads; address and UB sanitizers."""
+    out = str(tmp_path / "test_records")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    os.path.join(ROOT, "tests", "host", "test_records.cpp"), "-o", out, "-lpthread"], check=True)
+    r = subprocess.run([out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert r.stdout.startswith("ok: 180 cases")
+
+
 @pytest.fixture(scope="module")
 def big_gz(tmp_path_factory):
     """A few MB of gzip so that the several-threads decoder has chunks to cut: FASTQ at three levels, three members with
