@@ -1,0 +1,1042 @@
+#!/usr/bin/env python3
+"""bench_legs.py -- what bench.py runs AROUND its timed region (round-5 VERDICT item 9: bench.py was benchmark, leg runner, verification and
+multi-rank protocol in one 118 KB file): the reference beside the library on BASELINE.json configs[1] whole (`cpu_baseline`, `parity`,
+`end_to_end`), the self-check of the table against the union of its shards, the passes of configs[2]'s loop and their rooflines, the
+reference's own multi-k loop, the link, configs[3] at its stated size, `graph` as one process per k from files, and the look-up of committed
+PMC collections for the `traffic` fields.  bench.py keeps the arguments, the timed region, the multi-rank protocol and the one JSON line."""
+from __future__ import annotations
+
+import contextlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
+
+
+_PHASE = ["start"]          # where the run is (the deadline below names it)
+
+
+def _phase(name: str) -> None:
+    _PHASE[0] = name
+
+
+REFDRV = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+TOOL = os.path.join(ROOT, "metamdbg_amd", "bin", "mdbg_tool")
+
+
+def _make_tmp(work: str, name: str, params, inputs: list) -> str:
+    """<work>/<name>/tmp laid out as AssemblyPipeline leaves it for the two child processes."""
+    tmp = os.path.join(work, name, "tmp")
+    for d in ("", "filter", "smallContigs", "checkpoints"):
+        os.makedirs(os.path.join(tmp, d), exist_ok=True)
+    params.save(os.path.join(tmp, "parameters.gz"))
+    with open(os.path.join(tmp, "input.txt"), "w") as f:
+        f.write("\n".join(inputs) + "\n")
+    return tmp
+
+
+def _cpu_quota() -> float | None:
+    """CPUs the container may use at once (cgroup cpu.max / cfs quota), None when unlimited: the GPU boxes show 256 hardware threads
+    and grant 16 CPU-seconds per second, so this -- not the thread count -- is what a CPU baseline ran on."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else int(quota) / int(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def _cores_used(threads: int) -> int:
+    q = _cpu_quota()
+    return threads if q is None else max(1, min(threads, int(q + 0.5)))
+
+
+def _run_two_commands(exe: str, tmp: str, threads: int, extra_rs=(), timeout: int = 1800, stop_after_tables: bool = False) -> dict:
+    """`readSelection` then `graph --firstpass` with the reference's argv (AssemblyPipeline.hpp:733-737, :770-783), timed.
+    `tables_s` = seconds into `graph` at which kminmerData_abundance_init.txt appears: the reference copies it right after
+    the tables are complete and closed, before it goes on to build the graph (graph/CreateMdbg.cpp:515-553), so
+    read_selection_s + tables_s is the time of the path alone, measured on the reference's own code from outside.
+    stop_after_tables: the process is ended once that copy is complete (same size as kminmerData_abundance.txt) -- the rest of
+    the command is graph construction, out of scope, and at a million reads it is minutes of it; graph_s is then None."""
+    t0 = time.perf_counter()
+    subprocess.run([exe, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
+                    "--threads", str(threads), "--min-read-quality", "0.000000", *extra_rs], check=True, timeout=timeout,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t1 = time.perf_counter()
+    marker = os.path.join(tmp, "kminmerData_abundance_init.txt")
+    source = os.path.join(tmp, "kminmerData_abundance.txt")
+    proc = subprocess.Popen([exe, "graph", tmp, "--threads", str(threads), "--min-abundance", "0", "--firstpass"],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    seen = None
+    stopped = False
+    try:
+        while proc.poll() is None:
+            now = time.perf_counter()
+            if seen is None and os.path.exists(marker):
+                seen = now
+            if seen is not None and stop_after_tables and os.path.getsize(marker) == os.path.getsize(source):
+                proc.kill()                      # this very process, by its handle
+                proc.wait()
+                stopped = True
+                break
+            if now - t1 > timeout:
+                proc.kill(); proc.wait()
+                raise subprocess.TimeoutExpired("graph", timeout)
+            time.sleep(0.002)
+        if not stopped and proc.returncode != 0:
+            raise subprocess.CalledProcessError(proc.returncode, "graph")
+    finally:
+        if proc.poll() is None:
+            proc.kill(); proc.wait()
+    t2 = time.perf_counter()
+    if seen is None and os.path.exists(marker):
+        seen = t2
+    return {"read_selection_s": t1 - t0, "graph_s": None if stopped else t2 - t1, "tables_s": (seen - t1) if seen else None}
+
+
+def _fbytes(tmp: str, name: str) -> bytes:
+    with open(os.path.join(tmp, name), "rb") as f:
+        return f.read()
+
+
+def _tables_equal(tmp_a: str, tmp_b: str, k: int) -> bool:
+    import numpy as np
+    from metamdbg_amd import formats
+    return bool(np.array_equal(formats.sorted_abundance_records(_fbytes(tmp_a, "kminmerData_abundance.txt")),
+                               formats.sorted_abundance_records(_fbytes(tmp_b, "kminmerData_abundance.txt"))) and
+                np.array_equal(formats.sorted_vector_records(_fbytes(tmp_a, "kminmerData_min.txt"), k),
+                               formats.sorted_vector_records(_fbytes(tmp_b, "kminmerData_min.txt"), k)))
+
+
+def _sample_that_fits(n_reads: int, bytes_per_read: float, what: str) -> int:
+    """The sample size the scratch disk can hold (files of the sample, of the reference and of the tool): the wanted one, or fewer."""
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    fit = int(0.6 * free / bytes_per_read)
+    if fit < n_reads:
+        print(f"[bench] {what}: {n_reads} reads need {n_reads * bytes_per_read / 1e9:.0f} GB of scratch, {free / 1e9:.0f} GB free: {fit} reads", file=sys.stderr)
+    return max(0, min(n_reads, fit))
+
+
+def _write_fasta_from_device(path: str, reads, n_reads: int, chunk: int = 50_000, with_quality: bool = False) -> int:
+    """The resident reads as a FASTA file (">r<index>" + one line) or, with their qualities, as FASTQ, exported from HBM in pieces;
+    returns the bases written."""
+    nbases = 0
+    with open(path, "wb") as f:
+        for r0 in range(0, n_reads, chunk):
+            n = min(chunk, n_reads - r0)
+            bases, offs = reads.export_ascii(r0, n)
+            nbases += int(offs[n])
+            if with_quality:
+                q = reads.export_qualities(r0, n)
+                f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (r0 + r, bases[int(offs[r]): int(offs[r + 1])].tobytes(),
+                                                          q[int(offs[r]): int(offs[r + 1])].tobytes()) for r in range(n)))
+            else:
+                f.write(b"".join(b">r%d\n%s\n" % (r0 + r, bases[int(offs[r]): int(offs[r + 1])].tobytes()) for r in range(n)))
+    return nbases
+
+
+def sample_legs(ctx, n_sample: int, read_len: int, with_tool: bool, keep_dir: list | None = None) -> dict:
+    """cpu_baseline + parity (+ end_to_end) on a HiFi read set of its own: n_sample reads at 50x over the metagenome of
+    synth.hifi_spec -- with the default 1 000 000 reads that is BASELINE.json configs[1] ("1 M synthetic HiFi reads (10 kb),
+    single k iteration, 1 x MI355X vs CPU OpenMP") at its stated size, whole.
+
+    The reads are generated in HBM and written as FASTA; the REFERENCE's own code (oracle/_ref/refdrv) runs its two commands
+    on the file with the threads its README uses.  Its files are the expected values: the HIP path, run through the library on
+    exactly those reads as they sit in HBM, must give read_data_init.txt byte for byte, read_data_corrected.txt as a multiset
+    of reads and the k-min-mer table as a multiset of records and vectors (the reference's own record order depends on its
+    thread timing).  When tests/golden/hifi_1m/manifest.json describes this very read set, the digests committed there (made
+    by the reference in the build container) are compared as well.  A mismatch raises."""
+    import hashlib
+    import numpy as np
+    from metamdbg_amd import formats, synth
+    out: dict = {}
+    n_sample = _sample_that_fits(n_sample, read_len * 1.35, "cpu_baseline / parity read set")     # FASTA + the products, twice
+    if n_sample <= 0 or not os.path.exists(REFDRV):
+        return out
+    # the reference's thread scaling collapses past a few dozen threads (its graph command did not finish
+    # in 60 s with 256 threads on a 0.2 Gbp sample, 0.8 s with 8): use what its README / test scripts use
+    cores = min(os.cpu_count() or 1, 32)
+    work = tempfile.mkdtemp(prefix="mdbg_cpu_")
+    if keep_dir is not None:
+        keep_dir.append(work)
+    try:
+        sspec = synth.hifi_spec(n_sample, seed=42, read_len=read_len, coverage=50.0)
+        sub = ctx.reads_synthetic(sspec)
+        fasta = os.path.join(work, "sample.fasta")
+        nbases = _write_fasta_from_device(fasta, sub, n_sample)
+        P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
+                               hpc=True, data_type=0)
+        t_ref = _make_tmp(work, "ref", P, [fasta])
+        big = n_sample > 300_000       # the rest of `graph` (graph construction, out of scope) is minutes at this size
+        try:
+            tr = _run_two_commands(REFDRV, t_ref, cores, stop_after_tables=big)
+        except Exception as exc:  # the baseline is reported, never required
+            out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": _cores_used(cores), "threads": cores, "kind": "reference", "sample": f"failed: {exc}"}
+            return out
+        path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
+        whole = None if tr["graph_s"] is None else tr["read_selection_s"] + tr["graph_s"]
+        whole_cmds = None if whole is None else {"reads": n_sample, "seconds": whole, "gbps": nbases / 1e9 / whole}
+        if big:
+            # the time a user of the reference sees -- both commands to their end, graph construction included -- on the first 200 000 reads
+            # of the set, where that is seconds (round-3 VERDICT: the path-only split is argued, the whole commands cost nothing there)
+            try:
+                n_whole = 200_000
+                fasta_w = os.path.join(work, "sample_200k.fasta")
+                nb_w = _write_fasta_from_device(fasta_w, sub, n_whole)
+                t_w = _make_tmp(work, "ref_whole", P, [fasta_w])
+                tw = _run_two_commands(REFDRV, t_w, cores, stop_after_tables=False)
+                ws = tw["read_selection_s"] + tw["graph_s"]
+                whole_cmds = {"reads": n_whole, "seconds": ws, "gbps": nb_w / 1e9 / ws, "read_selection_s": tw["read_selection_s"], "graph_s": tw["graph_s"],
+                              "tables_s": tw["tables_s"], "path_only_gbps": nb_w / 1e9 / (tw["read_selection_s"] + (tw["tables_s"] if tw["tables_s"] is not None else tw["graph_s"])),
+                              "note": "readSelection + the whole graph --firstpass command (tables, then graph construction: out of this repository's scope) on the "
+                                      "first 200 000 reads of the set"}
+                shutil.rmtree(t_w, ignore_errors=True)
+                os.unlink(fasta_w)
+            except Exception as exc:
+                whole_cmds = {"error": f"{type(exc).__name__}: {exc}"}
+        out["cpu_baseline"] = {
+            "value": nbases / 1e9 / path, "unit": "Gbp/s", "cores": _cores_used(cores), "threads": cores, "cpu_quota": _cpu_quota(), "kind": "reference",
+            # (<= 200 characters: the line's copy is cut there)
+            "sample": f"{n_sample} HiFi reads x {read_len} bp ({nbases / 1e9:.0f} Gbp{', configs[1] whole' if n_sample == 1_000_000 and read_len == 10_000 else ''}), FASTA on disk; "
+                      f"refdrv --threads {cores}{'' if _cpu_quota() is None else f', quota {_cpu_quota():g} CPUs'}; path only: readSelection {tr['read_selection_s']:.1f} s + graph "
+                      f"until tables closed {(tr['tables_s'] if tr['tables_s'] is not None else float('nan')):.1f} s",
+            "graph_command": "ended once its tables were written and closed (what follows is graph construction)" if tr["graph_s"] is None else
+                             f"the whole graph command, which goes on to build the graph, takes {tr['graph_s']:.2f} s",
+            "hardware_threads": os.cpu_count(),
+            "path_only": {"read_selection_s": tr["read_selection_s"], "tables_s": tr["tables_s"], "gbps": nbases / 1e9 / path},
+            "whole_commands": whole_cmds,
+            "read_selection_gbps": nbases / 1e9 / tr["read_selection_s"]}
+        # ---- parity: the library on the same reads as they sit in HBM
+        t0 = time.perf_counter()
+        mins = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        init_bytes = formats.build_read_data_init(mins.to_host())
+        ref_init = _fbytes(t_ref, "read_data_init.txt")
+        init_equal = init_bytes == ref_init
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        hc = corr.to_host(full=False)
+        ref_m, ref_o = formats.parse_minimizer_reads(_fbytes(t_ref, "read_data_corrected.txt"))
+        # read_data_corrected.txt: the reference writes its records in thread order -> compare as multisets of reads
+        corrected_equal = formats.minimizer_reads_equal_as_multisets(hc["minimizers"], hc["offsets"], ref_m, ref_o)
+        table = ctx.kminmer_count_first(corr, KMINMER, 0)
+        rec, vec = table.to_host()
+        ti = table.info()
+        ref_rec = _fbytes(t_ref, "kminmerData_abundance.txt")
+        table_equal = bool(
+            np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(ref_rec)) and
+            np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), KMINMER),
+                           formats.sorted_vector_records(_fbytes(t_ref, "kminmerData_min.txt"), KMINMER)))
+        # the checksum the reference logs when it loads this table again (graph/CreateMdbg.cpp:3321, :3397), from ITS records
+        rr = formats.parse_abundance_table(ref_rec)
+        with np.errstate(over="ignore"):
+            ref_checksum = int((rr["abundance"].astype(np.uint64) * rr["lo"]).sum(dtype=np.uint64))
+        checksum_equal = table.checksum()[0] == ref_checksum
+        out["parity"] = {"reads": n_sample, "bases": nbases, "minimizers": int(mins.info()["n_minimizers"]),
+                         "kminmer_records": int(len(rec)), "solid": int(ti["n_solid"]), "init_bytes_equal": bool(init_equal),
+                         "init_bytes": len(ref_init),
+                         "corrected_multiset_equal": bool(corrected_equal), "table_multiset_equal": table_equal,
+                         "abundance_checksum_equal": bool(checksum_equal), "abundance_checksum": ref_checksum,
+                         "against": "oracle/_ref/refdrv (the reference's own code) on the same reads, this run",
+                         "check_seconds": None}
+        ok = init_equal and corrected_equal and table_equal and checksum_equal
+        # ---- the digests committed with the repository (tests/golden/hifi_1m: made by the reference in the build container)
+        gpath = os.path.join(ROOT, "tests", "golden", "hifi_1m", "manifest.json")
+        if os.path.exists(gpath):
+            g = json.load(open(gpath))
+            if g["n_reads"] == n_sample and g["read_len"] == read_len and g["seed"] == 42:
+                mine = {"read_data_init_sha256": hashlib.sha256(init_bytes).hexdigest(),
+                        "read_data_corrected_digest": formats.minimizer_reads_digest(hc["minimizers"], hc["offsets"]),
+                        "n_records": int(len(rec)), "abundance_checksum": table.checksum()[0],
+                        **formats.table_digests(rec, vec.astype("<u4").tobytes(), KMINMER)}
+                same = all(g[key] == v for key, v in mine.items()) and g["reference_log"].get("n_solid") == ti["n_solid"]
+                out["parity"]["golden"] = {"fixture": "tests/golden/hifi_1m/manifest.json", "digests_equal": bool(same)}
+                ok = ok and same
+        out["parity"]["check_seconds"] = time.perf_counter() - t0
+        del init_bytes, ref_init
+        for o in (table, corr, mins, sub):
+            o.free()
+        if not ok:
+            raise SystemExit(f"bench.py: PARITY FAILURE against the reference: {out['parity']}")
+        # ---- end to end from the file: the C++ drop-in for the two child processes against the reference
+        if with_tool and os.path.exists(TOOL):
+            t_gpu = _make_tmp(work, "gpu", P, [fasta])
+            tg = _run_two_commands(TOOL, t_gpu, min(os.cpu_count() or 1, 16))
+            tool_s = tg["read_selection_s"] + tg["graph_s"]
+            e2e_init = _fbytes(t_gpu, "read_data_init.txt") == _fbytes(t_ref, "read_data_init.txt")
+            e2e_stats = _fbytes(t_gpu, "read_stats.txt") == _fbytes(t_ref, "read_stats.txt")
+            e2e_table = _tables_equal(t_gpu, t_ref, KMINMER)
+            out["end_to_end"] = {
+                "workload": f"{n_sample} reads ({nbases / 1e9:.2f} Gbp) from one FASTA file on local disk: readSelection + graph --firstpass, "
+                            "same argv, same files written",
+                "mdbg_tool_s": tool_s, "mdbg_tool_gbps": nbases / 1e9 / tool_s, "mdbg_tool_read_selection_s": tg["read_selection_s"],
+                "reference_path_only_s": path, "reference_whole_commands_s": whole,
+                "speedup_vs_reference_path_only": path / tool_s,
+                "init_bytes_equal": bool(e2e_init), "read_stats_equal": bool(e2e_stats), "table_multiset_equal": bool(e2e_table)}
+            if not (e2e_init and e2e_stats and e2e_table):
+                raise SystemExit(f"bench.py: PARITY FAILURE of mdbg_tool against the reference: {out['end_to_end']}")
+            # ... and the two commands as ONE process (`mdbg_tool asmStep`: one library context, the corrected minimizers handed to the first
+            # pass on the device instead of being written, read and parsed back) -- the same files
+            t_one = _make_tmp(work, "gpu_one", P, [fasta])
+            t_a = time.perf_counter()
+            subprocess.run([TOOL, "asmStep", t_one, os.path.join(t_one, "read_data_init.txt"), os.path.join(t_one, "input.txt"), "--threads", str(min(os.cpu_count() or 1, 16)),
+                            "--min-read-quality", "0.000000", "--min-abundance", "0"], check=True, timeout=1800, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            one_s = time.perf_counter() - t_a
+            one_same = all(_fbytes(t_one, f) == _fbytes(t_ref, f) for f in ("read_data_init.txt", "read_stats.txt")) and \
+                _fbytes(t_one, "read_data_corrected.txt") == _fbytes(t_gpu, "read_data_corrected.txt") and _tables_equal(t_one, t_ref, KMINMER)
+            out["end_to_end"].update(asm_step_s=one_s, asm_step_gbps=nbases / 1e9 / one_s, asm_step_files_equal=bool(one_same))
+            if not one_same:
+                raise SystemExit(f"bench.py: PARITY FAILURE of mdbg_tool asmStep against the reference: {out['end_to_end']}")
+        return out
+    finally:
+        if keep_dir is None:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def _table_summary(t) -> dict:
+    i = t.info()
+    return {"records": int(i["n_records"]), "solid": int(i["n_solid"]), "sums": [int(x) for x in t.checksum()]}
+
+
+def _add_summaries(parts: list) -> dict:
+    out = {"records": 0, "solid": 0, "sums": [0, 0, 0, 0]}
+    for p in parts:
+        out["records"] += p["records"]; out["solid"] += p["solid"]
+        out["sums"] = [(a + b) & 0xFFFFFFFFFFFFFFFF for a, b in zip(out["sums"], p["sums"])]
+    return out
+
+
+def shard_self_check(ctx, corr, ks, n_shards: int = 2) -> dict:
+    """Full-size check of the tables of a read set WITHOUT the reference (it cannot run at these sizes): shard invariance.  The reads
+    are cut into `n_shards` contiguous ranges (mdbg_minimizers_slice); at every k of `ks` the table over the whole set must equal the
+    union of the shards' shares -- record count, solid count and the four order-independent sums of mdbg_table_checksum (sums[0] is
+    the `Checksum kminmer abundance` the reference logs, graph/CreateMdbg.cpp:3321, :3397).  k = firstK: the whole set takes
+    mdbg_kminmer_count_first (the partitioned pass at these sizes), the shards the sharded pass (mdbg_shard_begin -> exchange ->
+    _finish: counts summed by key owner), their local passes alternating between one table in HBM and the partitioned pass -- so the whole
+    set's table is also checked against an implementation that shares no counting code with it.  k > firstK: every
+    shard runs the refined / index pass over its own reads against the WHOLE previous table and the shards settle who lists a key
+    (mdbg_shard_from_table -> exchange -> _keep), as the ranks of an N-GPU job do.  The exchanges are the library's, with
+    device-to-device copies for the wire (mdbg_shard_exchange_local)."""
+    from metamdbg_amd import capi
+    n = corr.info()["n_reads"]
+    cuts = [n * i // n_shards for i in range(n_shards + 1)]
+    halves = [ctx.minimizers_slice(corr, cuts[i], cuts[i + 1] - cuts[i]) for i in range(n_shards)]
+    per_k, prev, ok = {}, None, True
+    t0 = time.perf_counter()
+    try:
+        for k in ks:
+            if k == ks[0]:
+                whole = ctx.kminmer_count_first(corr, k, 0)
+                shards = []
+                for i, h in enumerate(halves):                 # the shards' local passes alternate: one table in HBM, partitioned
+                    ctx.set_option("first_pass_mode", 1 if i % 2 == 0 else 2)
+                    shards.append(ctx.shard_begin(h, k, n_shards))
+                ctx.set_option("first_pass_mode", 0)
+                replies = capi.exchange_local(ctx, shards)
+                shares = [sh.finish(rep, 0) for sh, rep in zip(shards, replies)]
+            else:
+                make = ctx.kminmer_count_refined if k == ks[0] + 1 else ctx.kminmer_index
+                whole = make(corr, None, k, prev)
+                local = [make(h, None, k, prev) for h in halves]
+                shards = [ctx.shard_from_table(t, n_shards) for t in local]
+                replies = capi.exchange_local(ctx, shards)
+                shares = [sh.keep(rep) for sh, rep in zip(shards, replies)]
+                for t in local:
+                    t.free()
+            w, u = _table_summary(whole), _add_summaries([_table_summary(t) for t in shares])
+            flags = {"records_equal": w["records"] == u["records"], "solid_equal": w["solid"] == u["solid"],
+                     "abundance_checksum_equal": w["sums"][0] == u["sums"][0], "sum_abundance_equal": w["sums"][1] == u["sums"][1],
+                     "key_sum_equal": w["sums"][2] == u["sums"][2], "vector_sum_equal": w["sums"][3] == u["sums"][3]}
+            per_k[str(k)] = {**flags, "records": w["records"], "solid": w["solid"], "abundance_checksum": w["sums"][0]}
+            ok = ok and all(flags.values())
+            for o in shares + shards:
+                o.free()
+            if prev is not None:
+                prev.free()
+            prev = whole
+    finally:
+        if prev is not None:
+            prev.free()
+        for h in halves:
+            h.free()
+    return {"all_equal": ok, "reads": int(n), "shards": n_shards, "k": list(ks), "per_k": per_k, "seconds": time.perf_counter() - t0,
+            "mode": "table of the whole set against the union of the shards' shares (sharded passes, exchanges on the device), at every k"}
+
+
+def multik_rooflines(ctx, reads, last_k: int) -> dict:
+    """The passes of the multi-k loop on the record, each alone on the device, HIP events around its kernels: algorithmic bytes
+    4 M + 16 I + 20 D (minimizers read, one 128-bit identity per instance, 20-byte rows out) over the kernels' time.
+    k = firstK + 1 (refined): distinct keys of all windows, then two look-ups of the previous table per distinct key.  k >= firstK + 2
+    (index): per (k-1)-window one look-up of the previous table (kminmer_prev_lookup), per k-window whose abundance is > 1 an
+    insert-if-absent (kminmer_insert): two random 32-byte slots per instance, in tables of 20 M / 34 M slots that no cache holds."""
+    names = ("kminmer_split", "kminmer_prev_lookup", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
+    mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    mins.free()
+    out = {}
+    prev = None
+    for k in range(4, last_k + 1):
+        best = None
+        for it in range(2):
+            ctx.synchronize()
+            ctx.timing(True); ctx.timing_reset()
+            t = ctx.kminmer_count_first(corr, 4, 0) if k == 4 else (ctx.kminmer_count_refined(corr, None, k, prev) if k == 5 else ctx.kminmer_index(corr, None, k, prev))
+            ctx.synchronize()
+            ctx.timing(False)
+            ms = {n: ctx.timing_get(n)[0] for n in names if ctx.timing_get(n)[1]}
+            if best is None or sum(ms.values()) < sum(best[0].values()):
+                if best is not None:
+                    best[1].free()
+                best = (ms, t)
+            else:
+                t.free()
+        ms, t = best
+        st, D = t.stats(), t.info()["n_records"]
+        alg = 4.0 * st["minimizers"] + 16.0 * st["instances"] + 20.0 * D
+        total = sum(ms.values())
+        out[str(k)] = {"bound": "hbm", "pass": "first (partitioned, counted in LDS)" if k == 4 else ("refined" if k == 5 else "index"),
+                       "achieved": alg / (total / 1e3) / 1e9 if total > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg / (total / 1e3) / 1e9 / HBM_PEAK_GBS if total > 0 else 0.0, "algorithmic_bytes": alg,
+                       "minimizers_M": st["minimizers"], "instances_I": st["instances"], "rows_D": D, "table_slots": st["slots"],
+                       "kernel_ms": ms, "kernel_ms_total": total,
+                       "random_slot_accesses_per_instance": None if k == 4 else (None if k == 5 else 2.0),
+                       "instances_per_second_G": st["instances"] / (total / 1e3) / 1e9 if total > 0 else None}
+        if prev is not None:
+            prev.free()
+        prev = t
+    prev.free(); corr.free()
+    info = reads.info()
+    traffic, note = index_traffic(info["n_reads"], info["n_bases"] // max(1, info["n_reads"]))
+    for k, v in out.items():
+        kind = "refined" if v["pass"] == "refined" else ("index" if v["pass"] == "index" else None)
+        v["traffic"] = traffic[kind] if traffic and kind and traffic[kind] else None
+        v["traffic_over_algorithmic"] = v["traffic"] / v["algorithmic_bytes"] if v["traffic"] else None
+        v["traffic_source"] = note if kind else "see roofline_kminmer (the first pass)"
+    return out
+
+
+def multik_leg(ctx, reads, n_bases: int, last_k: int = 11) -> dict:
+    """BASELINE.json configs[2]: the full multi-k loop k = 4 .. 11 over the resident batch, benchmark mode (SURVEY.md
+    8(d): reads only, previous table = the own k-1 output; the reference's loop pipeline/AssemblyPipeline.hpp:603-671
+    interleaves out-of-scope graph stages).  Timed once after one untimed pass."""
+    def one_pass():
+        ms = {}
+        t0 = time.perf_counter()
+        mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        ms["scan_purge"] = (t1 - t0) * 1e3
+        n_min = mins.info()["n_minimizers"]
+        mins.free()
+        prev = ctx.kminmer_count_first(corr, 4, 0)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        ms["k4"] = (t2 - t1) * 1e3
+        records = {"4": prev.info()["n_records"]}
+        for k in range(5, last_k + 1):
+            tk = time.perf_counter()
+            nxt = ctx.kminmer_count_refined(corr, None, k, prev) if k == 5 else ctx.kminmer_index(corr, None, k, prev)
+            ctx.synchronize()
+            ms[f"k{k}"] = (time.perf_counter() - tk) * 1e3
+            records[str(k)] = nxt.info()["n_records"]
+            prev.free()
+            prev = nxt
+        prev.free(); corr.free()
+        total = time.perf_counter() - t0
+        return {"seconds": total, "gbps": n_bases / 1e9 / total, "ms": ms, "records": records, "minimizers": int(n_min)}
+    one_pass()
+    r = one_pass()
+    r["workload"] = (f"scan + purge + k-min-mer tables k = 4..{last_k} over the resident batch ({n_bases / 1e9:.0f} Gbp), one context, "
+                     "benchmark mode (reads only, previous table = own k-1 output)")
+    r["roofline_per_k"] = multik_rooflines(ctx, reads, last_k)
+    # the tables of the whole 10 M-read set at every k, checked at full size (round-3 VERDICT: nothing looked at k > 4 beyond 200 000 reads)
+    mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    mins.free()
+    r["self_check"] = shard_self_check(ctx, corr, list(range(4, last_k + 1)))
+    corr.free()
+    for k, v in r["self_check"]["per_k"].items():
+        if v["records"] != r["records"][k]:
+            r["self_check"]["all_equal"] = False
+            v["records_equal_timed_pass"] = False
+    if not r["self_check"]["all_equal"]:
+        raise SystemExit(f"bench.py: SELF-CHECK FAILURE (multi-k leg, whole set against its shards): {r['self_check']}")
+    return r
+
+
+def multik_reference_leg(ctx, n_sample: int, read_len: int, last_k: int = 11, budget_s: float = 300.0) -> dict:
+    """BASELINE.json configs[2] in the reference's OWN mode, beyond fixture size: the real multi-k loop -- `graph` -> `contig` ->
+    `toMinspace` per k, k = 4 .. 11, as AssemblyPipeline::executePass chains them (pipeline/AssemblyPipeline.hpp:603-671,
+    :1080-1089) -- run by the reference's code (oracle/_ref/refdrv) on a HiFi read set of n_sample reads at 50x, and at EVERY k
+    the C++ drop-in `mdbg_tool graph` run on a copy of exactly the files the reference's `graph` is about to read (reads,
+    unitig_data.txt, the previous table, the previous unitig graph with its refined abundances): tables equal as multisets of
+    records (and of vectors for k <= 5), smallContigs_k<k>.bin equal.  One flag per k; a mismatch fails the run.  The loop stops
+    early once `budget_s` seconds are spent (the reference's graph construction dominates) and says how far it got."""
+    import dataclasses
+    import numpy as np
+    from metamdbg_amd import formats, synth
+    if n_sample <= 0 or not (os.path.exists(REFDRV) and os.path.exists(TOOL)):
+        return {"skipped": "needs oracle/_ref/refdrv and metamdbg_amd/bin/mdbg_tool"}
+    cores = min(os.cpu_count() or 1, 32)
+    work = tempfile.mkdtemp(prefix="mdbg_multik_")
+    t_start = time.perf_counter()
+
+    def run(cmd, timeout=1200):
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd[:3])} failed: {r.stderr.decode(errors='replace')[-500:]}")
+
+    try:
+        sspec = synth.hifi_spec(n_sample, seed=42, read_len=read_len, coverage=50.0)
+        sub = ctx.reads_synthetic(sspec)
+        fasta = os.path.join(work, "sample.fasta")
+        nbases = _write_fasta_from_device(fasta, sub, n_sample)
+        sub.free()
+        P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4, hpc=True, data_type=0)
+        tmp = _make_tmp(work, "ref", P, [fasta])
+        run([REFDRV, "readSelection", tmp, os.path.join(tmp, "read_data_init.txt"), os.path.join(tmp, "input.txt"),
+             "--threads", str(cores), "--min-read-quality", "0.000000"])
+        scratch = os.path.join(work, "tool", "tmp")
+        per_k, prev_k = {}, 4
+        for k in range(4, last_k + 1):
+            if time.perf_counter() - t_start > budget_s:
+                break
+            dataclasses.replace(P, kminmer_size=k, prev_k=prev_k, last_k=last_k).save(os.path.join(tmp, "parameters.gz"))
+            # ---- the tool on a copy of what the reference's `graph` is about to read
+            shutil.rmtree(os.path.dirname(scratch), ignore_errors=True)
+            for d in ("", "filter", "smallContigs", "checkpoints"):
+                os.makedirs(os.path.join(scratch, d), exist_ok=True)
+            for name in ("parameters.gz", "read_data_corrected.txt", "read_stats.txt", "kminmerData_abundance_prev.txt",
+                         "unitigGraph.nodes.refined_abundances.bin", "unitigGraph_prev.nodes.bin", "unitig_data.txt"):
+                if os.path.exists(os.path.join(tmp, name)) and (k > 4 or name.startswith(("parameters", "read_"))):
+                    try:
+                        os.link(os.path.join(tmp, name), os.path.join(scratch, name))
+                    except OSError:
+                        shutil.copy(os.path.join(tmp, name), os.path.join(scratch, name))
+            args = ["--threads", str(cores)] + (["--min-abundance", "0", "--firstpass"] if k == 4 else [])
+            t0 = time.perf_counter()
+            run([TOOL, "graph", scratch] + args)
+            t1 = time.perf_counter()
+            run([REFDRV, "graph", tmp] + args)
+            t2 = time.perf_counter()
+            eq = bool(np.array_equal(formats.sorted_abundance_records(_fbytes(tmp, "kminmerData_abundance.txt")),
+                                     formats.sorted_abundance_records(_fbytes(scratch, "kminmerData_abundance.txt"))))
+            n_rec = os.path.getsize(os.path.join(tmp, "kminmerData_abundance.txt")) // 20
+            if k <= 5:
+                eq = eq and bool(np.array_equal(formats.sorted_vector_records(_fbytes(tmp, "kminmerData_min.txt"), k),
+                                                formats.sorted_vector_records(_fbytes(scratch, "kminmerData_min.txt"), k)))
+            sc = os.path.join("smallContigs", f"smallContigs_k{k}.bin")
+
+            def small(d):       # records `u32 n; u8 circular; u32 m[n]` as a sorted list (the reference writes them in thread order)
+                raw, o, out = _fbytes(d, sc) if os.path.exists(os.path.join(d, sc)) else b"", 0, []
+                while o + 5 <= len(raw):
+                    n = int.from_bytes(raw[o:o + 4], "little")
+                    out.append(raw[o:o + 5 + 4 * n]); o += 5 + 4 * n
+                return sorted(out)
+            small_eq = small(tmp) == small(scratch)
+            per_k[str(k)] = {"tables_equal": eq, "small_contigs_equal": bool(small_eq), "records": int(n_rec),
+                             "mdbg_tool_graph_s": t1 - t0, "reference_graph_s": t2 - t1}
+            if not (eq and small_eq):
+                raise SystemExit(f"bench.py: PARITY FAILURE in the reference's multi-k loop at k = {k}: {per_k[str(k)]}")
+            if k == last_k:
+                break
+            run([REFDRV, "contig", tmp, "--threads", str(cores), "--max-bubble-length", "50000", "--max-tip-length", "50000"])
+            run([REFDRV, "toMinspace", tmp, os.path.join(tmp, "contigs.nodepath"), os.path.join(tmp, "unitig_data.txt"),
+                 os.path.join(tmp, "unitigGraph.nodes.bin"), "--threads", str(cores)])
+            prev_k = k
+        ks = sorted(int(k) for k in per_k)
+        return {"workload": f"{n_sample} synthetic HiFi reads x {read_len} bp at 50x ({nbases / 1e9:.1f} Gbp): the reference's own loop graph -> contig -> "
+                            f"toMinspace, k = 4..{last_k} (refdrv, --threads {cores}); at every k mdbg_tool graph on a copy of the files the "
+                            "reference's graph reads, tables compared as multisets",
+                "k_done": ks, "complete": ks == list(range(4, last_k + 1)), "all_tables_equal": all(v["tables_equal"] and v["small_contigs_equal"] for v in per_k.values()),
+                "per_k": per_k, "seconds": time.perf_counter() - t_start, "budget_s": budget_s}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def pcie_leg(ctx, reads, spec, device: int, n_sub: int = 200_000, repeats: int = 8) -> dict:
+    """The step when the reads arrive over PCIe (never `value`): the first n_sub reads of the batch are brought to page-locked
+    host memory (2-bit packed as the host feed delivers them, and as ASCII), then uploaded through the boundary's own entry
+    points (mdbg_reads_from_packed / _from_ascii) and put through scan + purge + table, `repeats` times: one context doing
+    upload and step in turn, and two contexts on two host threads so that one's upload runs under the other's kernels."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    from metamdbg_amd import capi
+    n_sub = min(n_sub, reads.info()["n_reads"])
+    bases, offs = reads.export_ascii(0, n_sub)
+    lens = np.diff(offs).astype(np.uint32)
+    L = int(lens[0])
+    assert (lens == L).all()
+    wpr = ((L + 31) // 32 + 1) & ~1                                    # words per read, even: reads start on 16-byte boundaries
+    codes = (bases.reshape(n_sub, L) >> 1) & 3
+    bits = np.zeros((n_sub, wpr * 32, 2), dtype=np.uint8)
+    bits[:, :L, 0] = codes & 1
+    bits[:, :L, 1] = codes >> 1
+    packed = np.packbits(bits.reshape(n_sub, -1), axis=1, bitorder="little").view("<u8").reshape(-1)
+    del bits, codes
+    word_off = (np.arange(n_sub + 1, dtype=np.uint64) * np.uint64(wpr))
+
+    def pinned_copy(arr: np.ndarray):
+        p = C.c_void_p()
+        ctx.check(capi.lib().mdbg_host_alloc(ctx.h, arr.nbytes, C.byref(p)))
+        view = np.frombuffer((C.c_uint8 * arr.nbytes).from_address(p.value), dtype=arr.dtype)
+        view[:] = arr.reshape(-1)
+        return p, view
+    p_words, h_words = pinned_copy(packed)
+    p_ascii, h_ascii = pinned_copy(bases)
+    n_bases = int(lens.sum())
+
+    def step(c, ascii_input: bool):
+        h = C.c_void_p()
+        if ascii_input:
+            c.check(capi.lib().mdbg_reads_from_ascii(c.h, p_ascii, None, capi._ptr(offs), n_sub, C.byref(h)))
+        else:
+            c.check(capi.lib().mdbg_reads_from_packed(c.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
+        r = capi.Reads(c, h)
+        m = c.scan(r, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = c.purge_palindromes(m, 4, 100)
+        t = c.kminmer_count_first(corr, KMINMER, 0)
+        c.synchronize()
+        out = (int(m.info()["n_minimizers"]), int(t.info()["n_records"]))
+        for o in (t, corr, m, r):
+            o.free()
+        return out
+
+    res = {"workload": f"{n_sub} reads ({n_bases / 1e9:.1f} Gbp) in page-locked host memory, uploaded and put through scan + purge + k=4 table "
+                       f"{repeats} times", "packed_bytes": int(packed.nbytes), "ascii_bytes": int(bases.nbytes)}
+    # what the same reads give as they were generated in HBM
+    sub = ctx.reads_synthetic(spec, first_read=0, n_reads=n_sub)
+    m = ctx.scan(sub, K=K_MINIMIZER, density=DENSITY, hpc=True)
+    corr = ctx.purge_palindromes(m, 4, 100)
+    t = ctx.kminmer_count_first(corr, KMINMER, 0)
+    want = (int(m.info()["n_minimizers"]), int(t.info()["n_records"]))
+    for o in (t, corr, m, sub):
+        o.free()
+    for name, ascii_input in (("packed", False), ("ascii", True)):
+        got = step(ctx, ascii_input)                                   # warm-up, and the results must be the resident form's
+        if got != want:
+            raise SystemExit(f"pcie leg ({name}): {got} != {want}")
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            step(ctx, ascii_input)
+        dt = time.perf_counter() - t0
+        res[f"{name}_one_context_gbps"] = n_bases * repeats / 1e9 / dt
+    # ---- one context, the uploads of batches i+1 and i+2 queued (mdbg_reads_from_packed_async: the context's upload stream, a copy
+    # engine) before batch i is put through its kernels: the link and the kernels work at the same time
+    def upload_async(c):
+        h = C.c_void_p()
+        c.check(capi.lib().mdbg_reads_from_packed_async(c.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
+        return capi.Reads(c, h)
+
+    def kernels(c, r):
+        m = c.scan(r, K=K_MINIMIZER, density=DENSITY, hpc=True)
+        corr = c.purge_palindromes(m, 4, 100)
+        t = c.kminmer_count_first(corr, KMINMER, 0)
+        c.synchronize()
+        out = (int(m.info()["n_minimizers"]), int(t.info()["n_records"]))
+        for o in (t, corr, m):
+            o.free()
+        return out
+
+    def pipelined(c, n, ahead=2):
+        """`ahead` uploads queued beyond the batch being processed: the link is the longer half, and with a second upload already
+        behind the first it does not idle while the host gets round to issuing the next."""
+        from collections import deque
+        queue = deque(upload_async(c) for _ in range(min(ahead, n)))
+        issued, got = len(queue), None
+        for i in range(n):
+            cur = queue.popleft()
+            if issued < n:
+                queue.append(upload_async(c))
+                issued += 1
+            got = kernels(c, cur)
+            cur.free()
+        return got
+    if pipelined(ctx, 2) != want:
+        raise SystemExit("pcie leg (pipelined): results differ from the resident form's")
+    t0 = time.perf_counter()
+    pipelined(ctx, repeats)
+    dt_pipe = time.perf_counter() - t0
+    res["packed_one_context_pipelined_gbps"] = n_bases * repeats / 1e9 / dt_pipe
+    # the two halves alone: the upload (waited for) and the kernels on reads already there
+    r0 = upload_async(ctx); ctx.check(capi.lib().mdbg_reads_wait(ctx.h, r0.h))
+    t0 = time.perf_counter()
+    for _ in range(4):
+        r1 = upload_async(ctx); ctx.check(capi.lib().mdbg_reads_wait(ctx.h, r1.h)); r1.free()
+    upload_ms = (time.perf_counter() - t0) / 4 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(4):
+        kernels(ctx, r0)
+    kernel_ms = (time.perf_counter() - t0) / 4 * 1e3
+    r0.free()
+    step_ms = dt_pipe / repeats * 1e3
+    res.update(upload_ms=upload_ms, kernel_ms=kernel_ms, pipelined_step_ms=step_ms,
+               # 1 = the shorter half is hidden completely behind the longer one, 0 = they run one after the other
+               overlap=(upload_ms + kernel_ms - step_ms) / min(upload_ms, kernel_ms) if min(upload_ms, kernel_ms) > 0 else None,
+               link_ceiling_gbps=n_bases / 1e9 / (upload_ms / 1e3))
+    other = capi.Context(device)
+    step(other, False)
+    def worker(c, n):
+        for _ in range(n):
+            step(c, False)
+    threads = [threading.Thread(target=worker, args=(c, repeats // 2)) for c in (ctx, other)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    res["packed_two_contexts_gbps"] = n_bases * (repeats // 2) * 2 / 1e9 / dt
+    other.close()
+    # the upload alone
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        ctx.check(capi.lib().mdbg_reads_from_packed(ctx.h, p_words, capi._ptr(word_off), capi._ptr(lens), n_sub, C.byref(h)))
+        capi.lib().mdbg_reads_free(h)
+    res["upload_packed_GBps"] = packed.nbytes * 4 / 1e9 / (time.perf_counter() - t0)
+    del h_words, h_ascii
+    capi.lib().mdbg_host_free(ctx.h, p_words)
+    capi.lib().mdbg_host_free(ctx.h, p_ascii)
+    return res
+
+
+def ont_leg(ctx, n_reads: int, sample: int, piece_reads: int = 3_400_000) -> dict:
+    """BASELINE.json configs[3]: 10 M synthetic ONT R10 reads x 20 kb with qualities (1 % substitutions + 0.5 % insertions + 0.5 %
+    deletions, phred 10..39), no HPC, l = 15, density 0.005, repetitive-minimizer filter from the census of the first 1,000,001
+    reads at density 0.025 (nanoMDBG parameters: pipeline/AssemblyPipeline.hpp:309-325, ReadSelection.hpp:497-561, :508-510),
+    --skip-correction path: purge + k = 4 table over ALL the reads.  With their qualities 10 M reads are 250 GB, so they are
+    resident in pieces of `piece_reads` (3.4 M = 85 GB; the k = 4 table of 10 M such reads and what is built around it take
+    125 GB of their own) one after the other, each scanned as it sits in HBM; the pieces' minimizers (10 bytes each) are
+    appended on the device (mdbg_minimizers_concat) and purge + table run once over the whole set.  The time is the sum of
+    the path's parts (census, scans, concat + purge + table); producing the next piece of synthetic input in between is not
+    part of it (`generate_s`)."""
+    import numpy as np
+    from metamdbg_amd import formats, synth
+    spec = synth.ont_spec(n_reads, seed=43, read_len=20_000, coverage=50.0)
+    pieces = [(f, min(piece_reads, n_reads - f)) for f in range(0, n_reads, piece_reads)]
+    n_census = min(n_reads, 1_000_001)
+    ctx.set_option("pool_cache_percent", 90)       # this context has the device to itself: every block of a pass is there for the next
+
+    def one_pass(check: bool = False):
+        r = {"census_ms": 0.0, "scan_ms": 0.0, "generate_s": 0.0}
+        outs, n_bases = [], 0
+        # the census: the first 1,000,001 reads at the correction density, no filters, qualities ignored
+        t0 = time.perf_counter()
+        head = ctx.reads_synthetic(spec, first_read=0, n_reads=n_census)
+        ctx.synchronize()
+        r["generate_s"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pre = ctx.scan(head, K=K_MINIMIZER, density=0.025, hpc=False, apply_read_filters=False, ignore_qualities=True)
+        rep = ctx.repetitive_minimizers(pre)
+        pre.free()
+        r["census_ms"] = (time.perf_counter() - t0) * 1e3
+        head.free()
+        for first, n in pieces:
+            t0 = time.perf_counter()
+            reads = ctx.reads_synthetic(spec, first_read=first, n_reads=n)
+            ctx.synchronize()
+            r["generate_s"] += time.perf_counter() - t0
+            n_bases += reads.info()["n_bases"]
+            t0 = time.perf_counter()
+            outs.append(ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep))
+            ctx.synchronize()
+            r["scan_ms"] += (time.perf_counter() - t0) * 1e3
+            reads.free()
+        t0 = time.perf_counter()
+        mins = outs[0] if len(outs) == 1 else ctx.minimizers_concat(outs)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        corr = ctx.purge_palindromes(mins, 4, 100)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        table = ctx.kminmer_count_first(corr, KMINMER, 0)
+        ctx.synchronize()
+        t3 = time.perf_counter()
+        r["purge_table_ms"] = (t3 - t0) * 1e3
+        r["purge_table_parts_ms"] = {"concat": (t1 - t0) * 1e3, "purge": (t2 - t1) * 1e3, "table": (t3 - t2) * 1e3}
+        r["seconds"] = (r["census_ms"] + r["scan_ms"] + r["purge_table_ms"]) / 1e3
+        r.update(gbps=n_bases / 1e9 / r["seconds"], bases=n_bases, repetitive=int(len(rep)), minimizers=int(mins.info()["n_minimizers"]),
+                 kminmer_records=int(table.info()["n_records"]), solid=int(table.info()["n_solid"]), abundance_checksum=table.checksum()[0],
+                 table_stats=table.stats(), first_pass=ctx.first_pass_info())
+        for o in [table, mins] + (outs if len(outs) > 1 else []):
+            o.free()
+        if check:
+            # the table of all 10 M reads -- 968 M instances, 752 M distinct keys -- against the union of the shares of its halves
+            # (round-3 VERDICT: at full size this table was compared with nothing)
+            ctx.timing(False)
+            r["self_check"] = shard_self_check(ctx, corr, [KMINMER])
+            sc = r["self_check"]["per_k"][str(KMINMER)]
+            if sc["records"] != r["kminmer_records"] or sc["abundance_checksum"] != r["abundance_checksum"]:
+                r["self_check"]["all_equal"] = False
+        corr.free()
+        return r
+    one_pass()
+    ctx.timing(True); ctx.timing_reset()
+    r = one_pass(check=True)
+    ctx.timing(False)
+    if not r["self_check"]["all_equal"]:
+        raise SystemExit(f"bench.py: SELF-CHECK FAILURE (ONT leg, whole set against its shards): {r['self_check']}")
+    r["kernel_ms"] = {k: ctx.timing_get(k)[0] for k in ("scan", "quality_sum", "scan_compact", "complexity_exact", "minimizer_census",
+                                                      "purge_palindromes", "kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit",
+                                                      "table_clear", "prefix_scan") if ctx.timing_get(k)[1]}
+    km = r["kernel_ms"]
+    ts = r["table_stats"]
+    scan_alg = 1.25 * r["bases"] + 10.0 * r["minimizers"]          # 2-bit bases + 1 byte of quality per base in, 10 B per minimizer out
+    scan_ms = km.get("scan", 0.0) - 0.0
+    tab_ms = sum(km.get(n, 0.0) for n in ("kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan"))
+    tab_alg = 4.0 * ts["minimizers"] + 16.0 * ts["instances"] + 20.0 * r["kminmer_records"]
+    r["roofline"] = {
+        "scan": {"bound": "valu", "kernel": "scan_fast_kernel<HPC=0,QUAL=1,APPROX=1>, the launches over the resident pieces summed (the census scan at density 0.025 is "
+                                            "in minimizer_census)", "algorithmic_bytes": scan_alg, "kernel_ms": scan_ms,
+                 "achieved": scan_alg / (scan_ms / 1e3) / 1e9 if scan_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": scan_alg / (scan_ms / 1e3) / 1e9 / HBM_PEAK_GBS if scan_ms > 0 else 0.0,
+                 "quality_sum_ms": km.get("quality_sum"), "quality_sum_GBps": r["bases"] / (km["quality_sum"] / 1e3) / 1e9 if km.get("quality_sum") else None,
+                 "note": "no homopolymer compression: one Murmur3 per base (1.33 x the positions of a HiFi base); the same VALU-bound kernel as the headline's"},
+        "kminmer": {"bound": "hbm", "kernel": "k = 4 first pass over all the reads: " + ("partitioned (three radix levels), counted in LDS" if r["first_pass"]["path"] == 2 else "one table"),
+                    "algorithmic_bytes": tab_alg, "minimizers_M": ts["minimizers"], "instances_I": ts["instances"], "rows_D": r["kminmer_records"],
+                    "distinct_keys": ts["keys"], "kernel_ms": {n: km[n] for n in ("kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan") if n in km},
+                    "kernel_ms_total": tab_ms, "achieved": tab_alg / (tab_ms / 1e3) / 1e9 if tab_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": tab_alg / (tab_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tab_ms > 0 else 0.0, "first_pass": r["first_pass"],
+                    "atomic_ceiling_ms_of_the_one_table_pass": ts["instances"] / (ATOMIC_RATE_GOPS * 1e9) * 1e3,
+                    "note": "nine keys in ten are singletons (2 % errors): 752 M rows of 36 bytes leave the pass, most of them rescued reads' windows"}}
+    r["workload"] = (f"{n_reads} synthetic ONT R10 reads x 20 kb with qualities ({r['bases'] / 1e9:.0f} Gbp; 1 % sub + 0.5 % ins + 0.5 % del), "
+                     f"resident in HBM {len(pieces)} x {pieces[0][1]} reads at a time (2-bit bases + 1 byte per quality), no HPC, l=15, density 0.005, "
+                     f"repetitive filter from the 0.025 census of the first {n_census} reads, minimizers of the pieces appended on the device, "
+                     "purge + k=4 table over all the reads (--skip-correction path)")
+    r["pieces"] = len(pieces)
+    # parity on a sample against the reference's own run (qualities, mean read quality, repetitive filter pinned to
+    # the reference's pick: which of several equally frequent minimizers std::sort leaves first is not defined); the sample is
+    # scanned in two pieces and appended, like the leg
+    sample = _sample_that_fits(sample, 20_000 * 2.3, "ont parity sample")
+    if sample > 0 and os.path.exists(REFDRV):
+        work = tempfile.mkdtemp(prefix="mdbg_ont_")
+        try:
+            sspec = synth.SynthSpec(**{**spec.__dict__, "n_reads": sample})
+            fq = os.path.join(work, "ont.fastq")
+            whole = ctx.reads_synthetic(sspec)           # written from the device: the host generator makes 15 MB/s of it
+            _write_fasta_from_device(fq, whole, sample, chunk=20_000, with_quality=True)
+            whole.free()
+            P = formats.Parameters(minimizer_size=K_MINIMIZER, kminmer_size=KMINMER, density=DENSITY, first_k=4, prev_k=4,
+                                   hpc=False, data_type=1, correction_density=0.025)
+            t_ref = _make_tmp(work, "ref", P, [fq])
+            cores = min(os.cpu_count() or 1, 32)
+            tr = _run_two_commands(REFDRV, t_ref, cores, extra_rs=["--skip-correction"], stop_after_tables=sample > 20_000)
+            rep_ref = np.frombuffer(_fbytes(t_ref, "repetitiveMinimizers.bin"), "<u4")
+            cut = sample // 2
+            halves = [ctx.scan(ctx.reads_synthetic(sspec, first_read=f, n_reads=n), K=K_MINIMIZER, density=DENSITY, hpc=False, repetitive=rep_ref)
+                      for f, n in ((0, cut), (cut, sample - cut))]
+            mins = ctx.minimizers_concat(halves)
+            init_equal = formats.build_read_data_init(mins.to_host()) == _fbytes(t_ref, "read_data_init.txt")
+            st = formats.parse_read_stats(_fbytes(t_ref, "read_stats.txt"))
+            last_k = max(int(np.float32(st["n50"]) * np.float32(DENSITY) * np.float32(2)), 6)      # Commons::computeLastK (Commons.hpp:1726-1741)
+            corr = ctx.purge_palindromes(mins, 4, last_k)
+            rec, vec = ctx.kminmer_count_first(corr, KMINMER, 0).to_host()
+            table_equal = bool(
+                np.array_equal(formats.sorted_abundance_records(rec), formats.sorted_abundance_records(_fbytes(t_ref, "kminmerData_abundance.txt"))) and
+                np.array_equal(formats.sorted_vector_records(vec.astype("<u4").tobytes(), KMINMER),
+                               formats.sorted_vector_records(_fbytes(t_ref, "kminmerData_min.txt"), KMINMER)))
+            nb = sample * 20_000
+            path = tr["read_selection_s"] + (tr["tables_s"] if tr["tables_s"] is not None else tr["graph_s"])
+            r["parity"] = {"reads": sample, "init_bytes_equal": bool(init_equal), "table_multiset_equal": table_equal,
+                           "kminmer_records": int(len(rec)),
+                           "against": "oracle/_ref/refdrv on the same reads as FASTQ, --skip-correction, this run"}
+            r["cpu_reference"] = {"gbps_path_only": nb / 1e9 / path, "cores": _cores_used(cores), "threads": cores, "read_selection_s": tr["read_selection_s"],
+                                  "tables_s": tr["tables_s"], "sample_gbp": nb / 1e9}
+            if not (init_equal and table_equal):
+                raise SystemExit(f"bench.py: PARITY FAILURE (ONT preset) against the reference: {r['parity']}")
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return r
+
+
+def git_blob_hash(path: str) -> str:
+    """What `git hash-object` prints for the file: identifies the version of a source the way the repository does."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def measured_traffic(reads: int, read_len: int):
+    """(HBM bytes per scan launch, note) from the committed rocprofv3 PMC passes (profiles/*_scan_traffic.json): valid only for
+    the workload AND the kernel source they were collected on -- the file records the git blob hash of csrc/scan.hip, and a
+    collection made on another version of the kernel is not reported (None, with the reason)."""
+    import glob
+    here = git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", "scan.hip"))
+    best, stale = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_scan_traffic.json")), key=os.path.getmtime):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("reads") == reads and d.get("read_len") == read_len:
+            if d.get("scan_hip_blob") == here:
+                best = (d, os.path.basename(path))
+            else:
+                stale = os.path.basename(path)
+    if best is not None:
+        return best[0]["traffic_bytes_per_launch"], f"profiles/{best[1]} (collected on this version of csrc/scan.hip, blob {here[:12]})"
+    return None, (f"profiles/{stale} was collected on another version of csrc/scan.hip (the tree has blob {here[:12]}): not reported"
+                  if stale else "no PMC collection for this workload under profiles/")
+
+
+# random 4-byte device-scope atomics on gfx950, whatever the table size (1 MB .. 1 GB) or the XCD locality of the address:
+# tools/ubench/atomic_rates.hip, profiles/r01c_atomic_rates_gfx950.txt (25-27 G/s)
+ATOMIC_RATE_GOPS = 26.0
+
+
+def run_alone(ctx) -> None:
+    """The context is the only one working on the device from here on: no footprint limits."""
+    ctx.set_option("table_blocks_per_cu", 0)
+    ctx.set_option("table_grid_blocks", 0)
+    ctx.set_option("table_cu_count", 0)
+    ctx.set_option("scan_lds_pad", 0)
+    ctx.set_option("scan_lds_reserve", 0)
+    ctx.set_option("partition_tile", 0)
+    ctx.set_option("partition_slot_list", 1)
+    ctx.set_option("partition_lds_slots", 0)
+
+
+def kminmer_traffic(reads: int, read_len: int):
+    """(HBM bytes per first pass, note) from the committed rocprofv3 PMC passes (profiles/*_kminmer_traffic.json): valid only for the workload and
+    the kernel sources they were collected on (git blob hashes of csrc/partition.hip and csrc/kminmer.hip), like measured_traffic."""
+    import glob
+    here = {f: git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", f)) for f in ("partition.hip", "kminmer.hip")}
+    best, stale = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kminmer_traffic.json")), key=os.path.getmtime):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("reads") == reads and d.get("read_len") == read_len:
+            if d.get("blobs") == here:
+                best = (d, os.path.basename(path))
+            else:
+                stale = os.path.basename(path)
+    if best is not None:
+        return best[0]["traffic_bytes_per_pass"], f"profiles/{best[1]} (collected on this version of csrc/partition.hip and csrc/kminmer.hip)"
+    return None, (f"profiles/{stale} was collected on another version of the k-min-mer kernels: not reported" if stale
+                  else "no PMC collection for this workload under profiles/")
+
+
+def index_traffic(reads: int, read_len: int):
+    """({"refined": bytes, "index": bytes} per pass -- the two kernels that make the pass: distinct_insert + refine_slots, prev_abundance +
+    index_insert --, note) from the committed rocprofv3 PMC passes (profiles/*_index_traffic.json, tools/index_traffic.sh): FETCH_SIZE + WRITE_SIZE
+    as reported (these kernels read random 32-byte slots, not wide coalesced streams: no doubling), averaged over the launches of the loop; valid
+    only for the workload and the sources they were collected on (git blob hashes), like measured_traffic."""
+    import glob
+    here = {f: git_blob_hash(os.path.join(ROOT, "metamdbg_amd", "csrc", f)) for f in ("kminmer.hip", "table.hpp", "kminmer_dev.hpp")}
+    best, stale = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_index_traffic.json")), key=os.path.getmtime):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("reads") == reads and d.get("read_len") == read_len:
+            if d.get("blobs") == here:
+                best = (d, os.path.basename(path))
+            else:
+                stale = os.path.basename(path)
+    if best is None:
+        return None, (f"profiles/{stale} was collected on another version of the k-min-mer kernels: not reported" if stale
+                      else "no PMC collection for this workload under profiles/")
+    def of(*needles):
+        return sum(v["traffic_bytes_uncorrected"] for kern, v in best[0]["per_kernel"].items() if any(nd in kern for nd in needles))
+    return ({"refined": of("distinct_insert", "refine_slots"), "index": of("prev_abundance", "index_insert")},
+            f"profiles/{best[1]} (collected on this version of csrc/kminmer.hip and csrc/table.hpp)")
+
+
+def kminmer_roofline(ctx, reads, n_reads: int = 0, read_len: int = 0) -> dict:
+    """The k-min-mer step (first pass, k = 4) of the bench workload on the record: algorithmic bytes 4 M + 16 I + 20 D
+    (minimizers read, one 128-bit key per instance, output rows) over the HIP-event time of its kernels with
+    the context ALONE on the device -- the partitioned pass the library takes at this size (csrc/partition.hip: instances split by
+    key, buckets counted in LDS), and beside it the one-table pass it replaced (one device-scope atomic per instance: the ceiling
+    that pass was judged against is I over the part's random-atomic rate)."""
+    run_alone(ctx)
+    names = ("kminmer_split", "kminmer_insert", "kminmer_rescue", "kminmer_emit", "table_clear", "prefix_scan")
+    out = {}
+    st = ti = fp = None
+    reps = 2
+    mins = ctx.scan(reads, K=K_MINIMIZER, density=DENSITY, hpc=True)
+    corr = ctx.purge_palindromes(mins, 4, 100)
+    for mode in (0, 1):
+        ctx.set_option("first_pass_mode", mode)
+        acc = {n: 0.0 for n in names}
+        for it in range(reps + 1):
+            ctx.synchronize()
+            if it:
+                ctx.timing(True); ctx.timing_reset()
+            t = ctx.kminmer_count_first(corr, KMINMER, 0)
+            ctx.synchronize()
+            if it:
+                ctx.timing(False)
+                for n in names:
+                    acc[n] += ctx.timing_get(n)[0] / reps
+            if mode == 0:
+                st, ti, fp = t.stats(), t.info(), ctx.first_pass_info()
+            t.free()
+        out[mode] = acc
+    ctx.set_option("first_pass_mode", 0)
+    for o in (corr, mins):
+        o.free()
+    acc = out[0]
+    M, I, D = st["minimizers"], st["instances"], ti["n_records"]
+    alg = 4.0 * M + 16.0 * I + 20.0 * D
+    total_ms = sum(acc.values())
+    one_table_ms = sum(out[1].values())
+    ceiling_ms = I / (ATOMIC_RATE_GOPS * 1e9) * 1e3
+    achieved = alg / (total_ms / 1e3) / 1e9 if total_ms > 0 else 0.0
+    traffic, traffic_note = kminmer_traffic(n_reads, read_len) if n_reads else (None, "not looked up")
+    return {"bound": "hbm", "kernel": "k-min-mer first pass, k = 4 (one context alone on the device): " +
+                     ("mark_starts, split_hist / split_scatter per level, bucket_count (LDS), emit_bucket_rows, rescue_count_p, emit_rescued_p, prefix scans"
+                      if fp["path"] == 2 else "count_insert_kernel, slot_flag_kernel, emit_slots_kernel, rescue_count_kernel, emit_rescued_kernel, table clears, prefix scans"),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_note": traffic_note, "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+            "algorithmic_bytes": alg, "minimizers_M": M, "instances_I": I, "rows_D": D, "distinct_keys": st["keys"], "table_slots": st["slots"],
+            "first_pass": fp, "kernel_ms": acc, "kernel_ms_total": total_ms,
+            "one_table_pass": {"kernel_ms": out[1], "kernel_ms_total": one_table_ms, "atomic_ceiling_ms": ceiling_ms, "atomic_rate_gops": ATOMIC_RATE_GOPS,
+                               "insert_ms_over_atomic_ceiling": out[1]["kminmer_insert"] / ceiling_ms if ceiling_ms > 0 else None},
+            "speedup_over_one_table": one_table_ms / total_ms if total_ms > 0 else None,
+            "note": "the partitioned pass streams 20-byte instance records through two radix levels and counts them in LDS: its traffic is "
+                    "sequential and a multiple of the algorithmic bytes by construction (records written and read once per level); the one-table "
+                    "pass moved fewer streams but one random 64-byte sector and one device-scope atomic per instance (I over 26 G atomics/s = "
+                    "`atomic_ceiling_ms`, profiles/r01c_atomic_rates_gfx950.txt)"}
+
+
+
+def graph_per_k_leg(ctx, n_reads: int, read_len: int, ks=(4, 5, 6, 11), reps: int = 2) -> dict:
+    """The drop-in as the reference calls it: one `graph` process per k, from files (pipeline/AssemblyPipeline.hpp:763-792,
+    graph/CreateMdbg.cpp:391-468), on the headline's own read set -- read_data_corrected.txt (1.55 GB at 10 M reads) and the previous table of
+    each k written to shared memory, `mdbg_tool graph` run as a child per k, its wall time, its own trace split into phases, and its table
+    checked against the in-process pass (tools/graph_per_k.py)."""
+    if read_len != 10_000:
+        return {"skipped": "the leg writes the files of 10 kb reads"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import graph_per_k
+    need = n_reads * 3 * 160                      # the corrected reads, two tables, their copies
+    scratch = next((os.path.join(d, f"mdbg_graph_per_k_{os.getpid()}") for d in ("/dev/shm", tempfile.gettempdir())
+                    if os.path.isdir(d) and shutil.disk_usage(d).free > 2 * need), None)
+    if scratch is None:
+        return {"skipped": f"no scratch directory with {2 * need / 1e9:.0f} GB free"}
+    out = graph_per_k.run(n_reads, ks, reps, scratch=scratch, ctx=ctx)
+    out["note"] = ("seconds of one `mdbg_tool graph` process per k from files in shared memory, launcher to exit; k = 4 is --firstpass; the previous tables are "
+                   "the library's own (benchmark mode, empty unitig files)")
+    if not out["all_tables_equal"]:
+        raise SystemExit(f"[bench] graph_per_k: a table written by the tool differs from the in-process pass: {out}")
+    return out

@@ -106,7 +106,7 @@ struct PeerLink {
     std::vector<void *> retired;             // staging buffers this rank has replaced by larger ones: freed with the communicator (see exchange_peer, phase 3)
     DevBuf<uint64_t> test_reply;             // the self-test's replies
     uint64_t exchange = 0;
-    double timeout_s = 120.0;
+    double timeout_s = 120.0, late_s = 0.0;
 };
 
 }  // namespace mdbg
@@ -448,12 +448,26 @@ void peer_set_aside(PeerView &v) {
 }
 
 // rank r's staging buffer as published in `w`, reachable from this rank's device
+// drawn once per process (time, pid and the address of a static mixed: two processes do not meet in it)
+uint64_t process_token() {
+    static const uint64_t token = [] {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        uint64_t x = (uint64_t)ts.tv_sec * 1000000007ull ^ (uint64_t)ts.tv_nsec << 20 ^ (uint64_t)getpid() << 44 ^ (uint64_t)(uintptr_t)&ts;
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (f) { uint64_t r = 0; if (fread(&r, 8, 1, f) == 1) x ^= r; fclose(f); }
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33;
+        return x ? x : 1;
+    }();
+    return token;
+}
+
 int peer_map(mdbg_ctx *ctx, PeerLink *L, int r, const PeerBufWords &w, PeerView &v, void **out) {
     if (v.generation == w.generation && v.p) { *out = v.p; return MDBG_OK; }
     peer_set_aside(v);
     if (w.generation == 0 || w.pointer == 0) return set_error(ctx, MDBG_EPEER, "rank %d published no staging buffer", r);
     PeerSlot *ps = L->ctl.slot(r);
-    if (ps->pid == (int32_t)getpid()) {              // a thread of this process: its pointer is ours (one address space)
+    if (ps->pid == (int32_t)getpid() && ps->process_token == process_token()) {     // a thread of this process: its pointer is ours (one address space)
         if (ps->device != ctx->device) {
             hipError_t e = hipDeviceEnablePeerAccess(ps->device, 0);     // (without it the copy is staged by the runtime: slower, still right)
             if (e != hipSuccess) (void)hipGetLastError();
@@ -481,7 +495,7 @@ int peer_phase(mdbg_ctx *ctx, mdbg_comm *comm, uint64_t E, int phase, int rc, co
     L->ctl.words(comm->rank, E)->status[phase] = rc;
     L->ctl.arrive(PeerCtl::tick_of(E, phase));
     int late;
-    { MsInto w(comm->wait_ms); late = L->ctl.wait_all(PeerCtl::tick_of(E, phase), L->timeout_s); }
+    { MsInto w(comm->wait_ms); late = L->ctl.wait_all(PeerCtl::tick_of(E, phase), L->timeout_s, L->late_s); }
     if (late >= 0) {
         comm->broken = true;
         const std::string own = rc != MDBG_OK ? ctx->err : "";
@@ -684,6 +698,9 @@ int peer_setup(mdbg_ctx *ctx, mdbg_comm *c, const uint8_t *id128) {
     c->link.reset(new PeerLink());
     PeerLink *L = c->link.get();
     L->timeout_s = peer_timeout_s();
+    // a rank that is late but ALIVE is waited for this long in all (MDBG_PEER_LATE_S, default an hour; 0: the deadline is the deadline)
+    L->late_s = 3600.0;
+    if (const char *e = getenv("MDBG_PEER_LATE_S")) L->late_s = atof(e);
     double setup_s = 30.0;
     if (const char *e = getenv("MDBG_PEER_SETUP_TIMEOUT_S")) { const double v = atof(e); if (v > 0) setup_s = v; }
     // (tests: MDBG_PEER_TEST_NO_SHM -- rank 1 cannot reach the control block, as when /dev/shm is not shared between the ranks' containers)
@@ -693,6 +710,7 @@ int peer_setup(mdbg_ctx *ctx, mdbg_comm *c, const uint8_t *id128) {
     PeerSlot *ps = L->ctl.mine();
     ps->pid = (int32_t)getpid();
     ps->device = ctx->device;
+    ps->process_token = process_token();
     L->ctl.arrive(PeerCtl::TICK_ATTACHED);
     const int late = L->ctl.wait_all(PeerCtl::TICK_ATTACHED, setup_s);
     L->ctl.unlink_name();
@@ -714,10 +732,26 @@ __global__ void peer_test_reply_kernel(const uint64_t *rows, uint64_t n, uint32_
 
 // A small exchange of known rows through the very buffers, copies and hand-shakes a job will use; then every rank says whether what
 // came back was right, so that all of them take the same decision ("auto": peer copies or RCCL).  Collective.
-int peer_self_test(mdbg_ctx *ctx, mdbg_comm *c) {
+int peer_self_test(mdbg_ctx *ctx, mdbg_comm *c, bool ask_the_runtime_first) {
     PeerLink *L = c->link.get();
     const int n = c->n_ranks, me = c->rank;
     const uint32_t rw = mdbg_row_words(4);
+    // "auto" (round-5 ADVICE): a pull from a device this one cannot address ends in a GPU memory fault -- the process is gone, nothing falls
+    // back.  So before the first byte is pulled every rank asks the runtime whether its device reaches every other rank's
+    // (hipDeviceCanAccessPeer; ranks on one device need not ask); a rank that hears "no" enters the test with that as its failure, and
+    // the test's phases carry it to all the others: they fall back to RCCL together.  A forced MDBG_COMM_PEER does not ask.
+    int can_rc = MDBG_OK;
+    if (ask_the_runtime_first)
+        for (int r = 0; r < n && can_rc == MDBG_OK; r++) {
+            const int dev = L->ctl.slot(r)->device;
+            if (r == me || dev == ctx->device) continue;
+            int can = 0;
+            const hipError_t e = hipDeviceCanAccessPeer(&can, ctx->device, dev);
+            if (e != hipSuccess || !can) {
+                (void)hipGetLastError();
+                can_rc = set_error(ctx, MDBG_EHIP, "peer copies: device %d (rank %d) cannot address device %d (rank %d) directly (hipDeviceCanAccessPeer)", ctx->device, me, dev, r);
+            }
+        }
     auto cnt = [&](int r, int d) { return (uint64_t)(3 + ((r + d) % 5)); };
     std::vector<uint64_t> counts((size_t)n), h;
     uint64_t total = 0;
@@ -727,7 +761,8 @@ int peer_self_test(mdbg_ctx *ctx, mdbg_comm *c) {
     for (int d = 0; d < n; d++)
         for (uint64_t i = 0; i < counts[d]; i++, at++) { h[at * rw] = (uint64_t)me + 1; h[at * rw + 1] = (uint64_t)d + 1; h[at * rw + 2] = at; }
     DevBuf<uint64_t> d_rows;
-    int rc = d_rows.alloc(ctx, h.size());
+    int rc = can_rc;
+    if (rc == MDBG_OK) rc = d_rows.alloc(ctx, h.size());
     if (rc == MDBG_OK && memcpy_sync(ctx, d_rows.p, h.data(), h.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = set_error(ctx, MDBG_EHIP, "peer-copy self-test: upload failed");
     bool rows_right = true;
     const ReduceFn check = [&](const uint64_t *d_recv, uint64_t n_recv, const uint64_t **d_reply) -> int {
@@ -853,7 +888,7 @@ extern "C" int mdbg_comm_create_mode(mdbg_ctx *ctx, const uint8_t *id128, int ra
         // unless the copies are not to be had
         c->mode = MDBG_COMM_PEER;
         int rc = peer_setup(ctx, c.get(), id128);
-        if (rc == MDBG_OK) rc = peer_self_test(ctx, c.get());
+        if (rc == MDBG_OK) rc = peer_self_test(ctx, c.get(), mode == MDBG_COMM_AUTO);
         if (rc == MDBG_OK) { *out = c.release(); return MDBG_OK; }
         if (mode == MDBG_COMM_PEER) return rc;
         c->fallback_note = ctx->err;

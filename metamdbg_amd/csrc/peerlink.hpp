@@ -21,6 +21,8 @@
 // No HIP in this header: tests/host/test_peerlink.cpp drives it with plain processes and threads on a CPU.
 #pragma once
 #include <atomic>
+#include <cerrno>
+#include <signal.h>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -59,7 +61,9 @@ struct PeerWords {
 struct alignas(64) PeerSlot {
     std::atomic<uint64_t> tick;          // the last phase this rank has arrived at (monotonic; see PeerCtl::tick_of); TICK_CLOSING when it leaves
     std::atomic<uint64_t> reached;       // the last phase of an exchange it arrived at (what `tick` was before it left)
-    int32_t pid, device;                 // written before the attach tick: ranks with the same pid are threads of one process (plain pointers)
+    int32_t pid, device;                 // written before the attach tick
+    uint64_t process_token;              // a number drawn once per process: ranks with the same token are threads of ONE process (plain pointers).  (The pid
+                                         // alone said so until round 5: two containers that share /dev/shm but not their pid namespaces can hold equal pids.)
     PeerWords words[2];
 };
 
@@ -169,7 +173,25 @@ class PeerCtl {
 
     // Until every rank has arrived at `tick` (or beyond).  Returns -1 when all have, else the first rank that had not when the
     // deadline passed.  Busy for a few microseconds, then yielding, then sleeping: ranks in step meet within the busy part.
-    int wait_all(uint64_t tick, double timeout_s) {
+    // a process that can be seen from here and has not ended (a zombie -- ended, not yet reaped by its parent -- still answers kill(pid, 0))
+    static bool process_alive(int pid) {
+        if (pid <= 0 || !(kill(pid, 0) == 0 || errno == EPERM)) return false;
+        char path[64], buf[512];
+        snprintf(path, sizeof path, "/proc/%d/stat", pid);
+        FILE *f = fopen(path, "r");
+        if (!f) return true;                                     // no /proc: kill's word stands
+        const size_t n = fread(buf, 1, sizeof buf - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        const char *p = strrchr(buf, ')');                       // "pid (comm) S ..."
+        return !(p && p[1] == ' ' && (p[2] == 'Z' || p[2] == 'X'));
+    }
+
+    // `late_s` > 0 tells LATE from DEAD (round-5 ADVICE): once the deadline has passed, a rank whose process can still be seen
+    // (kill(pid, 0)) is given until `late_s` -- a rank that is merely slow (a terabase shard, a table growing, a debugger) should not end
+    // the job where RCCL would simply wait; a rank whose process is gone, or cannot be seen from here (another pid namespace), ends the
+    // wait at the deadline as before.  Liveness only ever EXTENDS a wait, it never ends one early.
+    int wait_all(uint64_t tick, double timeout_s, double late_s = 0.0) {
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
         for (int r = 0; r < n_; r++) {
@@ -180,7 +202,14 @@ class PeerCtl {
 #endif
                     continue;
                 }
-                if ((spins & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return r;
+                if ((spins & 63) == 0) {
+                    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (waited > timeout_s) {
+                        const int pid = slot(r)->pid;
+                        const bool alive = late_s > timeout_s && waited <= late_s && process_alive(pid);
+                        if (!alive) return r;
+                    }
+                }
                 if (spins < 65536) sched_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
         }

@@ -1649,6 +1649,7 @@ extern "C" int mdbg_scan(mdbg_ctx *ctx, const mdbg_reads *reads, const mdbg_scan
                 (void)hipEventRecord(ev, ctx->stream);
                 (void)hipStreamWaitEvent(ctx->side_stream, ev, 0);
             }
+            side_guard.s = ctx->side_stream;     // from here on every way out waits for the side stream before d_slo / d_shi / d_qtab go back to the pool (round-5 ADVICE)
             {
                 LaunchTimer timer(ctx, "quality_sum", qs);
                 unsigned blocks = grid_for((uint64_t)n * 64, 256, (unsigned)ctx->n_cu * 8u);

@@ -420,15 +420,18 @@ struct DeviceTable {
 // the insert kernels) completes without a probe sequence exceeding TABLE_MAX_PROBES.
 // slots for `keys` keys at the load the passes run best at (MDBG_TABLE_LOAD_PCT, default 22: DESIGN.md 4.2), never more than the 2^31
 // a table may have (then the load is what it is; inserts report an overflow when a probe sequence gets too long)
-inline uint64_t table_slots_for(uint64_t keys) {
+// (dense = true: a table whose every slot is walked afterwards more than once -- the refined pass looks two keys up per slot, flags and
+// emits; the counting passes likewise -- is sized for load 0.45: at 0.22 the refined pass of configs[2] took 22.9 ms instead of 20.7, the
+// walks over twice the slots costing more than the inserts gained, profiles/round6_a_index_passes_table_load_*.json)
+inline uint64_t table_slots_for(uint64_t keys, bool dense = false) {
     static const unsigned pct = [] { const char *e = getenv("MDBG_TABLE_LOAD_PCT"); const int v = e ? atoi(e) : 0; return v >= 5 && v <= 60 ? (unsigned)v : 22u; }();
-    const uint64_t want = keys * 100 / pct + 1024;
+    const uint64_t want = keys * 100 / (dense ? 45u : pct) + 1024;
     return want > (1ull << 31) ? (1ull << 31) : want;
 }
 
 template <typename Fill>
-int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uint64_t upper_bound, Fill fill) {
-    uint64_t want = table_slots_for(expected);
+int build_table_adaptive(mdbg_ctx *ctx, DeviceTable &tab, uint64_t expected, uint64_t upper_bound, Fill fill, bool dense = false) {
+    uint64_t want = table_slots_for(expected, dense);
     const uint64_t most = upper_bound + upper_bound / 2 + 1024;   // load <= 2/3 even if every key is distinct
     if (want > most) want = most;
     for (;;) {

@@ -232,6 +232,83 @@ def make_hifi_1m_multik(work: str, threads: int = 8, last_k: int = 11) -> None:
         json.dump(manifest, f, indent=1, sort_keys=True)
 
 
+_SHARED_GENOME = None
+
+
+def _write_fastx_range(args) -> str:
+    """reads [r0, r1) of `spec` to their own file (a worker process of make_ont_1m)"""
+    path, spec, r0, r1 = args
+    genome = _SHARED_GENOME          # made once by the parent, inherited through fork (400 MB; a copy per worker plus genome_codes' 64-bit
+                                     # temporaries was 6 GB a worker)
+    with open(path, "wb") as f:
+        for a in range(r0, r1, 2000):
+            b = min(a + 2000, r1)
+            asc = synth.codes_to_ascii(synth.read_codes(spec, a, b, genome))
+            qual = synth.read_qualities(spec, a, b)
+            for j in range(b - a):
+                f.write(b"@r%d\n" % (a + j)); f.write(asc[j].tobytes()); f.write(b"\n+\n"); f.write(qual[j].tobytes()); f.write(b"\n")
+    return path
+
+
+def make_ont_1m(work: str, threads: int = 8) -> None:
+    """BASELINE.json configs[3]'s kind of input tied to the reference AT SIZE: 1,000,100 synthetic ONT reads x 20 kb with qualities
+    (synth.ont_spec: 2 % errors, phred 10..39), ONE file -- so that the repetitive-minimizer census meets its cap of 1,000,001 reads per
+    file (readSelection/ReadSelection.hpp:497-561, Commons.hpp:5873: the last 99 reads are scanned but not counted) -- through the
+    reference's own `readSelection --skip-correction` and `graph --firstpass` (ended once its tables are closed).  40 GB of FASTQ and
+    the products do not go into the repository: their digests do (tests/golden/ont_1m/manifest.json), with the few u32 the census
+    chose (std::sort's order among equal counts at the cut is the one thing the reference leaves open: the test checks that the pick
+    is A valid one against the device's counts, then scans with exactly it).  The reads are regenerated on the device from the seed."""
+    import multiprocessing as mp
+    global _SHARED_GENOME
+    spec = synth.ont_spec(1_000_100, seed=42, read_len=20_000, coverage=50.0)
+    g_len = int(spec.genome_offsets()[-1])
+    _SHARED_GENOME = np.concatenate([synth.genome_codes(spec, a, min(a + (1 << 25), g_len)) for a in range(0, g_len, 1 << 25)])
+    fastq = os.path.join(work, "ont_1m.fastq")
+    cuts = [spec.n_reads * i // (4 * threads) for i in range(4 * threads + 1)]
+    jobs = [(os.path.join(work, f"part{i:03d}.fastq"), spec, cuts[i], cuts[i + 1]) for i in range(4 * threads)]
+    head = hashlib.sha256()
+    with mp.get_context("fork").Pool(min(threads, 6)) as pool, open(fastq, "wb") as out:
+        for i, part in enumerate(pool.imap(_write_fastx_range, jobs)):
+            with open(part, "rb") as f:
+                first = True
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    if i == 0 and first:
+                        head.update(blk[: 1 << 20])
+                    first = False
+                    out.write(blk)
+            os.unlink(part)
+            print(f"[make_golden] ont_1m: part {i + 1} / {len(jobs)} written", flush=True)
+    params = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, last_k=0, hpc=False, data_type=1,
+                                correction_density=0.025)
+    tmp = run_ref_pipeline(os.path.join(work, "ont_1m"), fastq, params, threads=threads, extra_rs=["--skip-correction"], graph=False)
+    fastq_bytes = os.path.getsize(fastq)
+    os.unlink(fastq)
+    print("[make_golden] ont_1m: readSelection done", flush=True)
+    _graph_until_tables(tmp, threads, first_pass=True, timeout=4 * 3600)
+    rec = formats.parse_abundance_table(open(os.path.join(tmp, "kminmerData_abundance.txt"), "rb").read())
+    with np.errstate(over="ignore"):
+        checksum = int((rec["abundance"].astype(np.uint64) * rec["lo"]).sum(dtype=np.uint64))
+    cm, co = formats.parse_minimizer_reads(open(os.path.join(tmp, "read_data_corrected.txt"), "rb").read())
+    rep = np.fromfile(os.path.join(tmp, "repetitiveMinimizers.bin"), "<u4")
+    manifest = dict(
+        kind="ont", config="BASELINE.json configs[3]'s input at 1,000,100 reads (one file: the census cap of 1,000,001 reads is crossed)",
+        n_reads=spec.n_reads, read_len=spec.read_len, seed=spec.seed, coverage=50.0, sub_rate=spec.sub_rate, ins_rate=spec.ins_rate, del_rate=spec.del_rate,
+        species_len=spec.species_len, species_weight=spec.species_weight, with_quality=True, fastq_bytes=fastq_bytes, fastq_first_mib_sha256=head.hexdigest(),
+        K=15, density=0.005, correction_density=0.025, hpc=False, skip_correction=True, k=4, min_abundance=0, reference_threads=threads,
+        repetitive_minimizers=[int(x) for x in rep],
+        read_data_init_sha256=sha256(os.path.join(tmp, "read_data_init.txt")), read_data_init_bytes=os.path.getsize(os.path.join(tmp, "read_data_init.txt")),
+        read_stats_hex=open(os.path.join(tmp, "read_stats.txt"), "rb").read().hex(),
+        read_data_corrected_digest=formats.minimizer_reads_digest(cm, co), n_corrected_minimizers=int(len(cm)),
+        n_records=int(len(rec)), abundance_checksum=checksum, sum_abundance=int(rec["abundance"].astype(np.uint64).sum()),
+        reference_log=log_known_answers(tmp),
+        **formats.table_digests(rec, open(os.path.join(tmp, "kminmerData_min.txt"), "rb").read(), 4))
+    dst = os.path.join(HERE, "ont_1m")
+    os.makedirs(dst, exist_ok=True)
+    with open(os.path.join(dst, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("[make_golden] ont_1m: manifest written", flush=True)
+
+
 def make_ont(work: str) -> None:
     # SURVEY 8(d) ONT R10 error model: 1 % substitutions + 0.5 % insertions + 0.5 % deletions, phred 10..39
     spec = synth.SynthSpec(n_reads=100, read_len=20_000, seed=11, sub_rate=0.01, ins_rate=0.005, del_rate=0.005,
@@ -644,7 +721,7 @@ def make_fn() -> None:
 def main() -> None:
     if not os.path.exists(REFDRV):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
-    work = tempfile.mkdtemp(prefix="mdbg_golden_")
+    work = tempfile.mkdtemp(prefix="mdbg_golden_", dir=os.environ.get("MDBG_GOLDEN_SCRATCH"))
     try:
         if "--only-1m" not in sys.argv:
             make_fn()
@@ -655,6 +732,9 @@ def main() -> None:
                 make_hifi_1m_multik(work)
             else:
                 make_hifi_1m(work)
+            return
+        if "--only-ont-1m" in sys.argv:  # about half an hour of CPU and 80 GB of scratch
+            make_ont_1m(work)
             return
         if "--deep-k" in sys.argv:       # the reference's loop to lastK(N50): a few minutes of CPU
             make_deepk(work, "hifi" if "--hifi" in sys.argv else "ont" if "--ont" in sys.argv else "both")

@@ -118,6 +118,43 @@ static int run_threads(int n, uint64_t exchanges, uint64_t fail_at, const char *
     return bad;
 }
 
+// LATE is not DEAD (round-5 ADVICE): with a `late_s` behind the deadline, rank 1 that is alive and merely slow (1.2 s for a 0.3 s deadline) is
+// waited for; rank 1 that has ENDED -- a zombie its parent has not reaped yet still answers kill(pid, 0) -- ends the wait at the deadline.
+static int run_late_and_dead() {
+    int bad = 0;
+    for (int dead = 0; dead < 2; dead++) {
+        const std::string name = fresh_name(dead ? "z1" : "l1");
+        const pid_t kid = fork();
+        if (kid == 0) {
+            PeerCtl c;
+            if (!c.attach(name, 1, 2, 10.0).empty()) _exit(2);
+            c.mine()->pid = (int32_t)getpid();
+            c.arrive(PeerCtl::TICK_ATTACHED);
+            if (c.wait_all(PeerCtl::TICK_ATTACHED, 10.0) >= 0) _exit(3);
+            if (dead) _exit(0);                                  // gone without a word (the parent below does not reap it before its own wait is over)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1200));
+            c.arrive(PeerCtl::tick_of(1, 0));
+            c.arrive(PeerCtl::TICK_CLOSING);
+            _exit(0);
+        }
+        PeerCtl c;
+        if (!c.attach(name, 0, 2, 10.0).empty()) return 1;
+        c.mine()->pid = (int32_t)getpid();
+        c.arrive(PeerCtl::TICK_ATTACHED);
+        if (c.wait_all(PeerCtl::TICK_ATTACHED, 10.0) >= 0) return 1;
+        c.unlink_name();
+        c.arrive(PeerCtl::tick_of(1, 0));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int late = c.wait_all(PeerCtl::tick_of(1, 0), 0.3, 20.0);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dead ? (late != 1 || waited < 0.25 || waited > 3.0) : (late != -1 || waited < 0.8)) { fprintf(stderr, "late/dead case %d: late %d after %.2f s\n", dead, late, waited); bad++; }
+        int st = 0;
+        waitpid(kid, &st, 0);
+        c.arrive(PeerCtl::TICK_CLOSING);
+    }
+    return bad;
+}
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4;
     const uint64_t ex = argc > 2 ? strtoull(argv[2], nullptr, 10) : 300;
@@ -126,6 +163,7 @@ int main(int argc, char **argv) {
     bad += run_threads(n, ex, ex / 2 + 1, "t1");               // threads of one process
     bad += run_processes(1, 20, 5, 0, "s1");                   // a communicator of one
     bad += run_processes(n, 12, 0, 9, "d1");                   // a rank that never arrives, then leaves
+    bad += run_late_and_dead();                                // a rank that is late but alive is waited for, a rank that has ended is not
     // two names from two ids differ; one id gives one name
     uint8_t a[128] = {0}, b[128] = {0};
     b[127] = 1;

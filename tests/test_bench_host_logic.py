@@ -143,7 +143,9 @@ def test_counter_traffic_is_reported_only_for_the_sources_it_was_collected_on(tm
                   "_ZN4mdbg16slot_flag_kernelE": {"traffic_bytes_uncorrected": 1.9e9}}
     prof = tmp_path / "profiles"
     prof.mkdir()
+    import bench_legs
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench_legs, "ROOT", str(tmp_path))          # (the look-up of committed PMC collections lives there since round 6)
     os.makedirs(tmp_path / "metamdbg_amd" / "csrc")
     for f in here:
         (tmp_path / "metamdbg_amd" / "csrc" / f).write_bytes(open(os.path.join(ROOT, "metamdbg_amd", "csrc", f), "rb").read())
