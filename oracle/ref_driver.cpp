@@ -22,6 +22,8 @@
  * Built as oracle/_ref/refdrv_hip (with ref_binding.cpp, linked against libmdbg_hip.so) it also has
  *   refdrv_hip readSelection_hip ... / refdrv_hip graph_hip ...
  *        the reference's own tools with the hot path replaced by calls through include/mdbg_hip.h, as INTEGRATION.md describes.
+ *   refdrv_hip fn_corrscan_hip ... / refdrv_hip edges_hip ...
+ *        SURVEY 8(f) N1 / N2 at the seams that link here (ref_binding.cpp says which and why)
  * Function-level probes (text on stdin -> text on stdout), used by tests/golden/make_golden.py:
  *   refdrv fn_scan <K> <density> <hpc>     : lines "<seq>"              -> "n v:pos:dir ..."
  *   refdrv fn_scan_notrim <K> <density> <hpc> : same with MinimizerParser::_trimBps = 0 (GenerateGfa's unitig scan)
@@ -234,6 +236,9 @@ int main(int argc, char **argv)
     if (cmd == "fn_corrscan") return fn_corrscan(argc, argv);
     if (cmd == "fn_kminmer") return fn_kminmer(argc, argv);
     if (cmd == "fn_murmur") return fn_murmur();
+#ifdef MDBG_WITH_HIP_BINDING
+    if (cmd == "fn_corrscan_hip") return fn_corrscan_hip(argc, argv);
+#endif
     if (cmd == "fn_lastk") {
         if (argc < 6) return 2;
         std::cout << Commons::computeLastK(std::stof(argv[2]), std::stoul(argv[3]), std::stoul(argv[4]), std::stoul(argv[5])) << "\n";
@@ -251,6 +256,7 @@ int main(int argc, char **argv)
 #ifdef MDBG_WITH_HIP_BINDING
     else if (cmd == "readSelection_hip") return read_selection_hip(n, args.data());
     else if (cmd == "graph_hip") return graph_hip(n, args.data());
+    else if (cmd == "edges_hip") return edges_hip(n, args.data());
 #endif
     else { std::cerr << "unknown sub-command " << cmd << "\n"; return 2; }
     return 0;

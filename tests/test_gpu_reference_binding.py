@@ -117,3 +117,49 @@ def test_reference_multi_k_loop_with_the_binding(tmp_path, last_k):
     ho.run_loop(t_hip, params, last_k, lambda tmp, k, first_k: run(REFDRV_HIP, "graph_hip", *ho.graph_args(tmp, k, first_k)), str(tmp_path / "snap_hip"))
     seen = ho.compare_dirs(str(tmp_path / "snap_ref"), str(tmp_path / "snap_hip"), 4, last_k)
     assert seen["graph_files"] >= 4 * (last_k - 4) and seen["next_inputs"] == 3 * (last_k - 4) and seen["tables"] == last_k - 3, seen
+
+
+def test_correction_scan_inside_the_reference(tmp_path):
+    """SURVEY 8(f) N1 inside the reference's process: `refdrv_hip fn_corrscan_hip` -- the compute of ReadCorrection::ReadSelectionFunctor
+    (ReadCorrection.hpp:2298-2342: EncoderRLE, MinimizerParser::parse at the correction density, getMinQuality over [rle[pos], rle[pos+l-1]])
+    as ONE mdbg_scan with quality_window = 1 -- prints what `refdrv fn_corrscan`, the reference's own functor code, prints: on the
+    homopolymer-rich golden reads at three (l, density) settings with and without HPC, and on the 100 ONT reads of tests/golden/ont_100
+    at the correction density 0.025.  (The functor's sink -- TurboPFor + BGZF partitions -- does not link here: oracle/ref_binding.cpp.)"""
+    import json
+    import subprocess
+    fn = json.load(open(os.path.join(H.GOLDEN, "fn", "fn_golden.json")))["corrscan"]
+    cases = [(c["K"], c["density"], c["hpc"], [f"{r} {q}" for r, q in zip(c["reads"], c["quals"])]) for c in fn.values()]
+    m = H.load_manifest("ont_100")
+    spec = H.spec_from_manifest(m)
+    asc = synth.codes_to_ascii(synth.read_codes(spec, 0, spec.n_reads))
+    qual = synth.read_qualities(spec, 0, spec.n_reads)
+    cases.append((15, 0.025, 0, [asc[i].tobytes().decode() + " " + qual[i].tobytes().decode() for i in range(spec.n_reads)]))
+    n_min = 0
+    for K, dens, hpc, lines in cases:
+        text = "\n".join(lines) + "\n"
+        a = subprocess.run([REFDRV, "fn_corrscan", str(K), str(dens), str(hpc)], input=text, capture_output=True, text=True, timeout=300)
+        b = subprocess.run([REFDRV_HIP, "fn_corrscan_hip", str(K), str(dens), str(hpc)], input=text, capture_output=True, text=True, timeout=300)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr[-500:], b.stderr[-500:])
+        assert a.stdout == b.stdout, (K, dens, hpc)
+        n_min += sum(int(l.split(" ", 1)[0]) for l in a.stdout.splitlines())
+    assert n_min > 40_000
+
+
+def test_edge_index_inside_the_reference(tmp_path):
+    """SURVEY 8(f) N2 inside the reference's process: after `graph_hip --firstpass` left the library's tables in the directory,
+    `refdrv_hip edges_hip` runs the REFERENCE's own EdgeIndexer (graph/CreateMdbg.hpp:4010-4230, constructed on its CreateMdbg as
+    CreateMdbg::indexEdges does, graph/CreateMdbg.cpp:1181-1183) on kminmerData_min.txt and mdbg_edge_index on the same vectors:
+    every 128-bit identity, the count and the checksum the reference logs must agree -- and be what the reference logged when it made the
+    fixture (tests/golden/hifi_200, ont_100)."""
+    for name, extra in (("hifi_200", []), ("ont_100", ["--skip-correction"])):
+        m = H.load_manifest(name)
+        reads = str(tmp_path / f"{name}.fx")
+        synth.write_fasta(reads, H.spec_from_manifest(m))
+        P = formats.Parameters(minimizer_size=15, kminmer_size=4, density=0.005, first_k=4, prev_k=4, hpc=bool(m["hpc"]), data_type=0 if m["hpc"] else 1,
+                               correction_density=0.025)
+        tmp = make_tmp(tmp_path / name, P, [reads])
+        _read_selection(REFDRV, "readSelection", tmp, 1, ["--min-read-quality", "0.0"] + extra)
+        run(REFDRV_HIP, "graph_hip", tmp, "--threads", "2", "--min-abundance", "0", "--firstpass")
+        r = run(REFDRV_HIP, "edges_hip", tmp, "--threads", "2", "--min-abundance", "0", "--firstpass")
+        log = m["reference_log"]
+        assert f"reference EdgeIndexer {log['n_edges']} keys, checksum {log['edge_checksum']}; mdbg_edge_index {log['n_edges']} keys, checksum {log['edge_checksum']}; equal" in r.stdout, r.stdout
