@@ -1080,6 +1080,77 @@ def test_hifi_1m_digests(ctx):
         o.free()
 
 
+def test_ont_1m_digests(ctx):
+    """BASELINE.json configs[3]'s kind of input tied to the reference AT SIZE (round-5 VERDICT item 4): 1,000,100 synthetic ONT reads x 20 kb
+    with qualities, ONE file, so that the repetitive-minimizer census meets its cap -- the first 1,000,001 reads of a file are counted
+    (readSelection/ReadSelection.hpp:497-561; Commons.hpp:5873: `readIndexPerDataset > _maxReads`), the last 99 are scanned but not counted --
+    against the digests of what the reference's own `readSelection --skip-correction` + `graph --firstpass` wrote for this read set in the
+    build container (tests/golden/make_golden.py --only-ont-1m; tests/golden/ont_1m/manifest.json): the census's pick, sha256 of
+    read_data_init.txt (1 GB), the corrected reads, both tables, the counts it logged.  The census's order among equal counts at the cut is
+    the one thing the reference leaves open (std::sort): when the device's pick differs from the reference's, the difference must lie among
+    values whose counts tie at the cut -- checked against an independent count -- and the scan then runs with the reference's pick."""
+    import hashlib
+    path = os.path.join(H.GOLDEN, "ont_1m", "manifest.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/ont_1m/manifest.json not generated")
+    with open(path) as f:
+        g = json.load(f)
+    info = ctx.device_info()
+    if info["hbm_bytes"] < 200e9:
+        pytest.skip("needs an MI355X's HBM")
+    ctx.set_option("pool_trim", 1)
+    spec = synth.ont_spec(g["n_reads"], seed=g["seed"], read_len=g["read_len"], coverage=g["coverage"])
+    assert spec.species_len == g["species_len"] and g["n_reads"] > 1_000_001
+    reads = ctx.reads_synthetic(spec)
+    # the census: the first 1,000,001 reads of the file, at the correction density, qualities not looked at (CountMinimizerFunctor, :565-625)
+    counted = ctx.reads_synthetic(spec, first_read=0, n_reads=1_000_001)
+    cm = ctx.scan(counted, K=g["K"], density=g["correction_density"], hpc=False, apply_read_filters=False, ignore_qualities=True)
+    counted.free()
+    picked = ctx.repetitive_minimizers(cm)
+    rep_ref = np.array(g["repetitive_minimizers"], dtype=np.uint32)
+    assert len(picked) == len(rep_ref)
+    if set(picked.tolist()) != set(rep_ref.tolist()):
+        vals = cm.to_host(full=False)["minimizers"]
+        odd = np.array(sorted(set(picked.tolist()) ^ set(rep_ref.tolist())), dtype=np.uint32)
+        both = np.array(sorted(set(picked.tolist()) | set(rep_ref.tolist())), dtype=np.uint32)
+        at = np.searchsorted(both, vals)
+        at[at == len(both)] = 0
+        cnt = np.bincount(at[both[at] == vals], minlength=len(both))
+        count_of = dict(zip(both.tolist(), cnt.tolist()))
+        cut = min(count_of[int(v)] for v in rep_ref)
+        assert all(count_of[int(v)] == cut for v in odd), ("the picks differ beyond a tie at the cut", [(int(v), count_of[int(v)]) for v in odd][:20], cut)
+        del vals
+    cm.free()
+    # the pass itself, every read, with the reference's pick
+    mins = ctx.scan(reads, K=g["K"], density=g["density"], hpc=False, repetitive=rep_ref)
+    reads.free()
+    init = formats.build_read_data_init(mins.to_host())
+    assert len(init) == g["read_data_init_bytes"]
+    assert hashlib.sha256(init).hexdigest() == g["read_data_init_sha256"]
+    del init
+    # --skip-correction: the purge runs over the scan's output (ReadSelection.hpp:300, :1374-1431)
+    n50 = formats.parse_read_stats(bytes.fromhex(g["read_stats_hex"]))["n50"]
+    last_k = max(int(np.float32(n50) * np.float32(g["density"]) * np.float32(2.0)), 6)          # Commons::computeLastK (Commons.hpp:1726-1741), no --max-k
+    assert last_k == 200
+    corr = ctx.purge_palindromes(mins, 4, last_k)
+    hc = corr.to_host(full=False)
+    assert len(hc["minimizers"]) == g["n_corrected_minimizers"]
+    assert formats.minimizer_reads_digest(hc["minimizers"], hc["offsets"]) == g["read_data_corrected_digest"]
+    del hc
+    table = ctx.kminmer_count_first(corr, g["k"], g["min_abundance"])
+    ti = table.info()
+    assert ti["n_solid"] == g["reference_log"]["n_solid"] and ti["n_records"] - ti["n_solid"] == g["reference_log"]["n_rescued"]
+    assert ti["n_records"] == g["n_records"]
+    sums = table.checksum()
+    assert sums[0] == g["abundance_checksum"] and sums[1] == g["sum_abundance"]
+    rec, vec = table.to_host()
+    d = formats.table_digests(rec, vec.astype("<u4").tobytes(), g["k"])
+    assert d["abundance_sorted_sha256"] == g["abundance_sorted_sha256"] and d["min_sorted_sha256"] == g["min_sorted_sha256"]
+    for o in (table, corr, mins):
+        o.free()
+    ctx.set_option("pool_trim", 1)
+
+
 def test_minimizers_concat(ctx):
     """mdbg_minimizers_concat: a read set scanned in pieces (fresh scattered scan outputs, a piece without reads, qualities) and
     appended on the device is the set scanned whole -- every array of the scan output -- and so are its purge and its table;
