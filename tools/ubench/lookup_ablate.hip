@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void precompute_ids(const uint32_t *mins, uint
     ids[i] = make_ulonglong2(lo, hi);
 }
 
-enum { F_NO_STORE = 1, F_NO_HASH = 2, F_NT_STREAMS = 4, F_NT_TABLE = 8, F_PAIR = 16 };
+enum { F_NO_STORE = 1, F_NO_HASH = 2, F_NT_STREAMS = 4, F_NT_TABLE = 8, F_PAIR = 16, F_STORE8 = 32, F_STORE16 = 64 };
 
 template <typename T> __device__ __forceinline__ T ld(const T *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256) void lookup(const uint32_t *mins, uint32_t n_r
                 if (i < n) {
                     if (FLAGS & F_NO_STORE) acc += v;
                     else if (FLAGS & F_NT_STREAMS) __builtin_nontemporal_store(v, out + base + i);
+                    else if (FLAGS & F_STORE8) reinterpret_cast<uint8_t *>(out)[base + i] = (uint8_t)(v < 255u ? v : 255u);       // a byte per window, 255 = look again
+                    else if (FLAGS & F_STORE16) reinterpret_cast<uint16_t *>(out)[base + i] = (uint16_t)(v < 65535u ? v : 65535u);
                     else out[base + i] = v;
                 }
             }
@@ -241,7 +243,8 @@ int main(int argc, char **argv) {
 #define RUN(name, L, U, F, bpc) run(name, bpc, [&](unsigned grid) { lookup<L, U, F><<<grid, 256>>>(mins, n_reads, len, k, ids, t, out, sink); })
     for (unsigned bpc : {4u, 8u, 16u, 32u}) { if (brief && bpc != 8u) continue; RUN("full", 16, 1, 0, bpc); }
     check("full");
-    if (brief) { RUN("pair_eager", 16, 1, F_PAIR, 8); check("pair_eager"); RUN("pair_e_l32", 32, 1, F_PAIR, 8); check("pair_e_l32"); }
+    if (brief) { RUN("pair_eager", 16, 1, F_PAIR, 8); check("pair_eager"); RUN("pair_e_l32", 32, 1, F_PAIR, 8); check("pair_e_l32");
+                 RUN("pair_store8", 16, 1, F_PAIR | F_STORE8, 8); RUN("pair_store16", 16, 1, F_PAIR | F_STORE16, 8); RUN("pair_nostore", 16, 1, F_PAIR | F_NO_STORE, 8); RUN("pair_eager", 16, 1, F_PAIR, 8); }
     for (unsigned bpc : {8u, 32u}) {
         if (brief) break;
         RUN("no_store", 16, 1, F_NO_STORE, bpc);
