@@ -147,6 +147,7 @@ struct mdbg_ctx {
     // distinct keys per k-min-mer instance seen by the last call OF THE SAME KIND (table sizing): the first pass keeps every
     // key, refined / index only those above abundance 1 -- one shared hint made every first pass after an index pass rebuild its table
     double key_ratio_hint[4] = {0.0625, 0.0625, 0.0625, 0.0625};   // [0] first pass, [1] refined, [2] index, [3] sharded first pass
+    bool key_ratio_known[4] = {false, false, false, false};        // the hint was measured by a call of that kind (a table is sized densely only then)
     // the first pass (k = firstK): instances partitioned by key and counted in LDS (partition.hip) or one global table (kminmer.hip)
     int first_pass_mode = 0;                // 0: by size (partitioned from part_auto_min instances up), 1: one table, 2: partitioned
     uint64_t part_auto_min = 1ull << 17;    // mode 0: fewer minimizers than this take the one-table path (50 000 reads: 0.18 against 0.25 ms)

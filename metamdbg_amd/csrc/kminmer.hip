@@ -806,7 +806,7 @@ __global__ void pack_records_kernel(const uint64_t *lo, const uint64_t *hi, cons
 // Size the next table of this kind for the distinct keys just seen (+12.5 %): build_table_adaptive doubles that and
 // rounds up to a power of two, i.e. 25-45 % load.
 void update_key_hint(mdbg_ctx *ctx, int kind, uint64_t distinct, uint64_t instances) {
-    if (instances) ctx->key_ratio_hint[kind] = 1.125 * (double)distinct / (double)instances;
+    if (instances) { ctx->key_ratio_hint[kind] = 1.125 * (double)distinct / (double)instances; ctx->key_ratio_known[kind] = true; }
 }
 
 struct InstIndex {
@@ -916,7 +916,7 @@ extern "C" int mdbg_kminmer_count_first(mdbg_ctx *ctx, const mdbg_minimizers *re
             hipLaunchKernelGGL(count_insert_kernel, dim3(instance_grid(ctx, sv.n_reads)), dim3(256), 0, ctx->stream, sv, k, v, inst_slot.p, (uint64_t)0);
         }
         return MDBG_OK;
-    }, true));
+    }, ctx->key_ratio_known[0]));
     TableView tv = tab.view();
 
     // solid rows
@@ -1163,7 +1163,7 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
         if (a.n_inst) launch(a, 0);
         if (b.n_inst) launch(b, a.n_min);
         return MDBG_OK;
-    }, true));
+    }, ctx->key_ratio_known[1]));
     TableView tv = tab.view();
     const uint64_t nslots = tab.cap + TABLE_EXC_CAP;
     DevBuf<uint32_t> sflag;
@@ -1773,7 +1773,7 @@ extern "C" int mdbg_shard_begin(mdbg_ctx *ctx, const mdbg_minimizers *reads, uin
             hipLaunchKernelGGL(count_insert_kernel, dim3(instance_grid(ctx, sv.n_reads)), dim3(256), 0, ctx->stream, sv, k, v, sh->inst_slot.p, (uint64_t)0);
         }
         return MDBG_OK;
-    }, true));
+    }, ctx->key_ratio_known[3]));
     TableView tv = sh->local.view();
     const uint64_t nslots = sh->local.cap + TABLE_EXC_CAP;
     const unsigned nb = grid_for(nslots, SHARD_SPB);

@@ -130,6 +130,19 @@ def test_auto_falls_back_to_the_next_transport_on_every_rank(tmp_path):
     assert many["parity"]["table_equal"]
 
 
+def test_a_probe_that_dies_sends_every_rank_to_the_next_transport():
+    """bench.py tries the peer copies in CHILD processes before the ranks themselves create communicators over them (tools/peer_probe.py): what
+    the library cannot turn into an error code -- a GPU memory access fault on the first pull from a device that cannot be addressed -- ends a
+    child.  Here rank 1's probe is killed by a signal: every rank then takes RCCL (which refuses ranks that share a device, so the job, agreeing
+    once more, moves its rows with torch.distributed), says why, and its tables still add up."""
+    n = 40_000
+    common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "2"]
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_PROBE_TEST_CRASH_RANK": "1"}, ["--gpus", "3", "--reads", str(n)] + common, 3)
+    ex = many["config"]["exchange"]
+    assert ex["transport"] == "torch" and "probe failed" in ex["comm_note"] and "library exchange unavailable" in ex["comm_note"], ex
+    assert many["parity"]["table_equal"]
+
+
 def test_strong_scaling_over_one_read_set():
     """--total-reads: ONE read set split over the ranks (north_star's "40 M reads sharded 8 ways at 1 / 2 / 4 / 8 GPUs" is a curve over a
     fixed set): 4 ranks x 30 000 reads give the table of 1 rank x 120 000, and the line carries the single-GPU throughput of rank 0's
