@@ -137,7 +137,7 @@ def test_a_probe_that_dies_sends_every_rank_to_the_next_transport():
     once more, moves its rows with torch.distributed), says why, and its tables still add up."""
     n = 40_000
     common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none", "--in-flight", "2"]
-    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_PROBE_TEST_CRASH_RANK": "1"}, ["--gpus", "3", "--reads", str(n)] + common, 3)
+    many = _bench({"MDBG_BENCH_SHARE_GPU": "1", "MDBG_BENCH_BACKEND": "gloo", "MDBG_PROBE_TEST_CRASH_RANK": "1", "MDBG_PEER_SETUP_TIMEOUT_S": "5"}, ["--gpus", "3", "--reads", str(n)] + common, 3)
     ex = many["config"]["exchange"]
     assert ex["transport"] == "torch" and "probe failed" in ex["comm_note"] and "library exchange unavailable" in ex["comm_note"], ex
     assert many["parity"]["table_equal"]
