@@ -174,7 +174,8 @@ def compact_line(out: dict) -> dict:
                       "multik_reference": _flag(legs.get("multik_reference"), "all_tables_equal"),
                       "ont_parity": _flag(ont.get("parity") if "error" not in ont else ont, "table_multiset_equal") if ont else None,
                       "ont_self_check": _flag(ont.get("self_check") if "error" not in ont else ont) if ont else None}
-    numbers = {"multik_s": (legs.get("multik") or {}).get("seconds"), "ont_gbps": ont.get("gbps"),
+    numbers = {"multik_s": (legs.get("multik") or {}).get("seconds"), "multik_gbps": (legs.get("multik") or {}).get("gbps"),      # configs[2] whole: scan + purge + k = 4 .. 11
+               "ont_gbps": ont.get("gbps"),
                "pcie_gbps": (legs.get("pcie") or {}).get("packed_one_context_pipelined_gbps"),
                "e2e_gbps": (legs.get("end_to_end") or {}).get("mdbg_tool_gbps"), "e2e_one_process_gbps": (legs.get("end_to_end") or {}).get("asm_step_gbps")}
     line["legs"] = {k: _num(v) for k, v in numbers.items() if v is not None}
