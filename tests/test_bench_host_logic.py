@@ -97,7 +97,7 @@ def test_the_stdout_line_is_compact_and_complete():
     assert line["parity"] == {"init_bytes_equal": True, "corrected_multiset_equal": True, "table_multiset_equal": True, "abundance_checksum_equal": True,
                               "reads": 1_000_000, "against": line["parity"]["against"], "golden_digests_equal": True}
     assert line["checks"] == {"self_check": True, "multik_self_check": True, "multik_reference": True, "ont_parity": True, "ont_self_check": True}
-    assert line["legs"] == {"multik_s": 0.272299, "ont_gbps": 382.7, "pcie_gbps": 199.7, "e2e_gbps": 9.55}
+    assert line["legs"] == {"multik_s": 0.272299, "multik_gbps": 367.2, "ont_gbps": 382.7, "pcie_gbps": 199.7, "e2e_gbps": 9.55}
     assert line["roofline_index"]["6"] == {"ms": 19.23, "frac": 0.0425, "traffic": 2.0e10} and sorted(line["roofline_index"], key=int) == [str(k) for k in range(4, 12)]
 
 
