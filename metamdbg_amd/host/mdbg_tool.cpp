@@ -1410,6 +1410,7 @@ int run_graph(int argc, char **argv) {
             parse_minimizer_reads(corrected->p, corrected->n, mins, offs, nullptr, std::max(1, a.threads));
             corrected.reset();
         } else if (byBytes) {
+            if (nReads >= (1ull << 32)) die("graph: more than 2^32 records in read_data_corrected.txt");
             mdbg_bytes *rb = upload_file_bytes(g_ctx, corrected->p, corrected->n, a.threads);
             g_trace.mark("graph: the records' bytes on the device");
             check_on(g_ctx, mdbg_minimizers_from_record_bytes(g_ctx, rb, offs.data(), (uint32_t)nReads, nullptr, &resident), "mdbg_minimizers_from_record_bytes");
