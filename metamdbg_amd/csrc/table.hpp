@@ -421,11 +421,13 @@ struct DeviceTable {
 // slots for `keys` keys at the load the passes run best at (MDBG_TABLE_LOAD_PCT, default 22: DESIGN.md 4.2), never more than the 2^31
 // a table may have (then the load is what it is; inserts report an overflow when a probe sequence gets too long)
 // (dense = true: a table whose every slot is walked afterwards more than once -- the refined pass looks two keys up per slot, flags and
-// emits; the counting passes likewise -- is sized for load 0.45: at 0.22 the refined pass of configs[2] took 22.9 ms instead of 20.7, the
-// walks over twice the slots costing more than the inserts gained, profiles/round6_a_index_passes_table_load_*.json)
+// emits; the counting passes likewise -- is sized for load 0.35: at 0.22 the refined pass of configs[2] took 22.9 ms instead of 20.7, the
+// walks over twice the slots costing more than the inserts gained, profiles/round6_a_index_passes_table_load_*.json.  Not 0.45: with
+// 52 M keys the longest probe sequence of a table that full comes within reach of TABLE_MAX_PROBES -- one build in three then overflowed,
+// grew fourfold and ran again, 165 ms for a 20 ms pass: profiles/round6_i_bench_detail.json `legs.multik.ms.k5`)
 inline uint64_t table_slots_for(uint64_t keys, bool dense = false) {
     static const unsigned pct = [] { const char *e = getenv("MDBG_TABLE_LOAD_PCT"); const int v = e ? atoi(e) : 0; return v >= 5 && v <= 60 ? (unsigned)v : 22u; }();
-    const uint64_t want = keys * 100 / (dense ? 45u : pct) + 1024;
+    const uint64_t want = keys * 100 / (dense ? 35u : pct) + 1024;
     return want > (1ull << 31) ? (1ull << 31) : want;
 }
 

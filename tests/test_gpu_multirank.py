@@ -16,21 +16,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run_with_a_free_port(make_cmd, **kw):
+    """torch.distributed.run on a port found free a moment ago; the moment can be too long (another process takes the port: "EADDRINUSE" once in
+    some hundred runs of the suite) -- then once more on another port."""
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = subprocess.run(make_cmd(port), **kw)
+        if "EADDRINUSE" not in (out.stderr or "") or attempt == 2:
+            return out
+    return out
+
+
 def _bench(extra_env: dict, args: list[str], nproc: int | None, expect_failure: bool = False) -> dict:
     """One bench.py run; returns its FULL result (--detail) after checking that what it printed is the one compact line of it."""
     import tempfile
     env = dict(os.environ, **extra_env)
     detail = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
     args = list(args) + ["--detail", detail]
-    cmd = [sys.executable]
-    if nproc:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-                "--master-port", str(port)]
-    cmd += [os.path.join(ROOT, "bench.py")] + args
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    def make_cmd(port):
+        c = [sys.executable]
+        if nproc:
+            c += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+        return c + [os.path.join(ROOT, "bench.py")] + args
+    out = _run_with_a_free_port(make_cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    cmd = make_cmd(0)
     if (out.returncode != 0) != expect_failure:
         # torchrun's summary of who was killed fills the tail: what the ranks themselves said is further up -- kept whole for the record
         os.makedirs(os.path.join(ROOT, "gpurun_out", "test_failures"), exist_ok=True)
@@ -180,13 +191,11 @@ def test_a_rank_that_fails_in_the_reduction_ends_the_job_of_eight(exchange):
     n = 20_000
     env = dict(os.environ, MDBG_BENCH_SHARE_GPU="1", MDBG_BENCH_BACKEND="gloo", MDBG_BENCH_FAIL_RANK="5", MDBG_BENCH_DEADLINE_S="200", MDBG_BENCH_EXCHANGE=exchange,
                MDBG_COMM_MODE="peer")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--reads", str(n), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none"]
+    def make_cmd(port):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                os.path.join(ROOT, "bench.py"), "--gpus", "8", "--reads", str(n), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--legs", "none"]
     t0 = time.time()
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    out = _run_with_a_free_port(make_cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert out.returncode != 0 and time.time() - t0 < 200
     own = "test failure in the reduction" if exchange == "library" else "test failure on rank 5"
     assert own in out.stderr and "rank 5 failed summing the rows it owns" in out.stderr, out.stderr[-3000:]
@@ -253,12 +262,9 @@ def test_two_ranks_multik_equal_one(tmp_path):
     import numpy as np
     from metamdbg_amd import capi, formats, synth
     n_total, last_k = 6000, 8
-    with _s.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "rank_multik.py"), str(tmp_path), str(n_total), str(last_k)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    r = _run_with_a_free_port(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(port), os.path.join(ROOT, "tests", "rank_multik.py"), str(tmp_path), str(n_total), str(last_k)],
+                              capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     ctx = capi.Context(0)
     spec = synth.hifi_spec(n_total, seed=77, read_len=6000, coverage=25.0)
