@@ -1009,13 +1009,13 @@ struct MappedFile {
 struct SlabPool {
     static size_t bytes() { static const size_t b = [] { const char *e = getenv("MDBG_TOOL_SLAB_MB"); const int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 256 ? v : 8) << 20; }(); return b; }
     std::mutex mu;
-    std::vector<void *> idle;
+    std::map<mdbg_ctx *, std::vector<void *>> idle;      // by the context that locked the pages (the ranks of --gpus G sit on different devices)
     void *get(mdbg_ctx *ctx) {
-        { std::lock_guard<std::mutex> g(mu); if (!idle.empty()) { void *p = idle.back(); idle.pop_back(); return p; } }
+        { std::lock_guard<std::mutex> g(mu); auto &v = idle[ctx]; if (!v.empty()) { void *p = v.back(); v.pop_back(); return p; } }
         void *p = nullptr;
         return mdbg_host_alloc(ctx, bytes(), &p) == MDBG_OK ? p : nullptr;
     }
-    void put(void *p) { if (p) { std::lock_guard<std::mutex> g(mu); idle.push_back(p); } }
+    void put(mdbg_ctx *ctx, void *p) { if (p) { std::lock_guard<std::mutex> g(mu); idle[ctx].push_back(p); } }
 } g_slabs;
 
 mdbg_bytes *upload_file_bytes(mdbg_ctx *ctx, const uint8_t *p, size_t n, int threads) {
@@ -1042,7 +1042,7 @@ mdbg_bytes *upload_file_bytes(mdbg_ctx *ctx, const uint8_t *p, size_t n, int thr
         }
         for (int s = 0; s < 2; s++) {
             if (ticket[s] && mdbg_bytes_upload_done(ctx, b, ticket[s], 1) != 1) failed = 1;
-            g_slabs.put(slab[s]);
+            g_slabs.put(ctx, slab[s]);
         }
     };
     std::vector<std::thread> pool;
@@ -1148,18 +1148,43 @@ struct PrevOnDevice {
     }
 };
 
+// Where the reads of read_data_corrected.txt are: the mapped file itself (the bytes path: any range of whole records is a file of its own --
+// record r of the range starts at byte 5 r + 4 off[r] of the range -- so every rank, piece or self-check takes its reads straight from the
+// file's bytes) or, with MDBG_TOOL_PARSE_ON_HOST, the array a host parse made.
+struct ReadSource {
+    const uint8_t *raw = nullptr;                 // the mapped file, or null
+    const U32Vec *mins = nullptr;                 // the parsed values (raw == null)
+    const std::vector<uint64_t> *offs = nullptr;  // minimizers before each read, n_reads + 1
+    int threads = 4;
+    uint64_t n_minimizers() const { return offs->back(); }
+};
+
+mdbg_minimizers *upload_read_range(mdbg_ctx *ctx, const ReadSource &src, size_t r0, size_t r1) {
+    const std::vector<uint64_t> &offs = *src.offs;
+    std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
+    mdbg_minimizers *reads = nullptr;
+    if (!src.raw) {
+        check_on(ctx, mdbg_minimizers_from_host(ctx, src.mins->data(), rel.data(), (uint32_t)(r1 - r0), &reads), "mdbg_minimizers_from_host");
+        return reads;
+    }
+    const uint64_t base = rel[0];
+    for (uint64_t &o : rel) o -= base;
+    const size_t b0 = 5 * r0 + 4 * (size_t)offs[r0], b1 = 5 * r1 + 4 * (size_t)offs[r1];
+    mdbg_bytes *rb = upload_file_bytes(ctx, src.raw + b0, b1 - b0, src.threads);
+    check_on(ctx, mdbg_minimizers_from_record_bytes(ctx, rb, rel.data(), (uint32_t)(r1 - r0), nullptr, &reads), "mdbg_minimizers_from_record_bytes");
+    mdbg_bytes_free(rb);
+    return reads;
+}
+
 // One rank's part of `graph`: reads [r0, r1) of read_data_corrected.txt on `ctx`; with a communicator the table is built
 // across the ranks (include/mdbg_hip.h "the exchange inside the library") and `out` is this rank's share of it.
 // unitig_data.txt -- sequences, not reads -- goes to rank 0 only.
-void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const U32Vec &mins,
-                const std::vector<uint64_t> &offs, size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true,
+void graph_rank(mdbg_ctx *ctx, mdbg_comm *comm, int rank, const Parameters &P, const Args &a, const ReadSource &src,
+                size_t r0, size_t r1, const PrevInputs &in, RankTable &out, bool rowsToHost = true,
                 const std::function<void(mdbg_ctx *, mdbg_table *)> &sink = nullptr, mdbg_minimizers *resident = nullptr) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     mdbg_minimizers *reads = resident;          // asmStep: the reads are on the device already (freed here like an uploaded set)
-    if (!reads) {
-        std::vector<uint64_t> rel(offs.begin() + (long)r0, offs.begin() + (long)r1 + 1);
-        check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(r1 - r0), &reads), "mdbg_minimizers_from_host");
-    }
+    if (!reads) reads = upload_read_range(ctx, src, r0, r1);
     mdbg_table *table = nullptr;
     if (a.firstPass) {
         if (comm) check_on(ctx, mdbg_kminmer_count_first_sharded(ctx, comm, reads, k, a.minAbundance, &table), "mdbg_kminmer_count_first_sharded");
@@ -1272,7 +1297,7 @@ void stream_table_to_files(mdbg_ctx *ctx, mdbg_table *table, uint32_t k, const s
 // whole set (include/mdbg_hip.h, "sharded first pass"; the reference meets the same limit-free way on disk, `vecHash % _nbPartitions`,
 // graph/CreateMdbg.hpp:3714-3851).  The minimizers of all the pieces stay on the device until the last share is written (4 bytes each).
 // cuts: read indexes, cuts[p] .. cuts[p + 1] = piece p.
-void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Vec &mins, const std::vector<uint64_t> &offs, const std::vector<size_t> &cuts,
+void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const ReadSource &src, const std::vector<size_t> &cuts,
                   const PrevInputs &in, RankTable &out, const std::function<void(mdbg_ctx *, mdbg_table *, uint64_t, bool)> &sink) {
     const uint32_t k = (uint32_t)P.kminmerSize;
     const uint32_t n = (uint32_t)(cuts.size() - 1);
@@ -1285,9 +1310,9 @@ void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Ve
     {
         char arch[64]; int nCu = 0; uint64_t hbm = 0;
         check_on(ctx, mdbg_device_info(ctx, arch, sizeof arch, &nCu, &hbm), "mdbg_device_info");
-        const uint64_t need = (uint64_t)mins.size() * 40ull;
+        const uint64_t need = src.n_minimizers() * 40ull;
         if (hbm && need > hbm - hbm / 8)
-            die("graph: " + std::to_string(mins.size()) + " minimizers in " + std::to_string(n) + " pieces need about " + std::to_string(need >> 30) + " GiB on the device at once, it has " +
+            die("graph: " + std::to_string(src.n_minimizers()) + " minimizers in " + std::to_string(n) + " pieces need about " + std::to_string(need >> 30) + " GiB on the device at once, it has " +
                 std::to_string(hbm >> 30) + " GiB: run the pass over several devices (--gpus G)");
     }
     std::vector<mdbg_minimizers *> reads(n, nullptr);
@@ -1298,8 +1323,7 @@ void graph_pieces(mdbg_ctx *ctx, const Parameters &P, const Args &a, const U32Ve
     PrevOnDevice dev;
     if (!a.firstPass) dev.build(ctx, P, in, true, out.smallContigs, a.threads);
     for (uint32_t p = 0; p < n; p++) {
-        std::vector<uint64_t> rel(offs.begin() + (long)cuts[p], offs.begin() + (long)cuts[p + 1] + 1);
-        check_on(ctx, mdbg_minimizers_from_host(ctx, mins.data(), rel.data(), (uint32_t)(cuts[p + 1] - cuts[p]), &reads[p]), "mdbg_minimizers_from_host");
+        reads[p] = upload_read_range(ctx, src, cuts[p], cuts[p + 1]);
         std::vector<uint64_t> c(64, 0);
         if (a.firstPass) check_on(ctx, mdbg_shard_begin(ctx, reads[p], k, n, &shards[p], &dRows[p], c.data()), "mdbg_shard_begin");
         else {
@@ -1366,9 +1390,9 @@ int run_graph(int argc, char **argv) {
     std::vector<uint64_t> offs{0};
     // One rank (the reference's own call): read_data_corrected.txt is not parsed into an array here.  Its record headers are walked by
     // several threads (host/records.hpp: exact) while the context comes up, its bytes then travel as they are and the records are taken
-    // apart on the device (mdbg_minimizers_from_record_bytes).  MDBG_TOOL_PARSE_ON_HOST=1: the way of rounds 1 - 5 (one walk, a host copy
-    // of the values, one pageable upload); several ranks slice the host array and keep it.
-    const bool byBytes = !resident && !sharded && !getenv("MDBG_TOOL_PARSE_ON_HOST");
+    // apart on the device (mdbg_minimizers_from_record_bytes) -- by every rank of a --gpus G job and every piece of a pass in pieces for its own
+    // range of records.  MDBG_TOOL_PARSE_ON_HOST=1: the way of rounds 1 - 5 (one walk, a host copy of the values, one pageable upload).
+    const bool byBytes = !resident && !getenv("MDBG_TOOL_PARSE_ON_HOST");
     std::unique_ptr<MappedFile> corrected;
     if (!resident) {
         offs.clear();
@@ -1385,6 +1409,9 @@ int run_graph(int argc, char **argv) {
         }
     }
     const size_t nReads = offs.size() - 1;
+    if (nReads >= (1ull << 32)) die("graph: more than 2^32 records in read_data_corrected.txt");
+    ReadSource src;
+    src.raw = byBytes ? corrected->p : nullptr; src.mins = &mins; src.offs = &offs; src.threads = std::max(1, a.threads);
     PrevInputs in;
     if (!a.firstPass) load_prev_inputs(dir, in);
     // every `graph` run truncates smallContigs/smallContigs_k<k>.bin (graph/CreateMdbg.cpp:258-259)
@@ -1406,25 +1433,17 @@ int run_graph(int argc, char **argv) {
             if (offs[r + 1] - offs[first] > maxMins) { cuts.push_back(r); first = r; }
         }
         cuts.push_back(nReads);
-        if (byBytes && cuts.size() > 2) {            // the pass in pieces slices a host array
-            parse_minimizer_reads(corrected->p, corrected->n, mins, offs, nullptr, std::max(1, a.threads));
-            corrected.reset();
-        } else if (byBytes) {
-            if (nReads >= (1ull << 32)) die("graph: more than 2^32 records in read_data_corrected.txt");
-            mdbg_bytes *rb = upload_file_bytes(g_ctx, corrected->p, corrected->n, a.threads);
-            g_trace.mark("graph: the records' bytes on the device");
-            check_on(g_ctx, mdbg_minimizers_from_record_bytes(g_ctx, rb, offs.data(), (uint32_t)nReads, nullptr, &resident), "mdbg_minimizers_from_record_bytes");
-            mdbg_bytes_free(rb);
-            corrected.reset();
-            g_trace.mark("graph: the records taken apart there");
+        if (byBytes && cuts.size() <= 2) {
+            resident = upload_read_range(g_ctx, src, 0, nReads);
+            g_trace.mark("graph: the records' bytes on the device, taken apart there");
         }
         if (cuts.size() > 2) {
             g_log.line("\tThe pass runs in " + std::to_string(cuts.size() - 1) + " pieces of at most " + std::to_string(maxMins) + " minimizers");
-            graph_pieces(g_ctx, P, a, mins, offs, cuts, in, parts[0], [&](mdbg_ctx *c, mdbg_table *t, uint64_t rowBase, bool firstShare) {
+            graph_pieces(g_ctx, P, a, src, cuts, in, parts[0], [&](mdbg_ctx *c, mdbg_table *t, uint64_t rowBase, bool firstShare) {
                 stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt", rowBase, firstShare);
             });
         } else
-            graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, parts[0], false,
+            graph_rank(g_ctx, nullptr, 0, P, a, src, 0, nReads, in, parts[0], false,
                        [&](mdbg_ctx *c, mdbg_table *t) { stream_table_to_files(c, t, k, recFiles, dir + "/kminmerData_min.txt"); }, resident);
         streamed = true;
         g_trace.mark("graph: table built and written");
@@ -1447,7 +1466,7 @@ int run_graph(int argc, char **argv) {
                 if (r == 0 && getenv("MDBG_TRACE"))
                     fprintf(stderr, "[mdbg_tool] exchange among %d ranks: %s%s%s\n", G, mdbg_comm_mode(comm) == MDBG_COMM_PEER ? "peer copies" : "RCCL",
                             *mdbg_comm_note(comm) ? " (no peer copies: " : "", *mdbg_comm_note(comm) ? (std::string(mdbg_comm_note(comm)) + ")").c_str() : "");
-                graph_rank(ctx, comm, r, P, a, mins, offs, nReads * (size_t)r / (size_t)G, nReads * (size_t)(r + 1) / (size_t)G, in, parts[(size_t)r]);
+                graph_rank(ctx, comm, r, P, a, src, nReads * (size_t)r / (size_t)G, nReads * (size_t)(r + 1) / (size_t)G, in, parts[(size_t)r]);
                 mdbg_comm_destroy(comm);
             });
         }
@@ -1470,7 +1489,7 @@ int run_graph(int argc, char **argv) {
         // shares IS the single-GPU table.  A wrong exchange (a lost row, a count summed twice, two listers for one key) fails here,
         // in the run that produced it.  --no-verify skips it.
         RankTable whole;
-        graph_rank(g_ctx, nullptr, 0, P, a, mins, offs, 0, nReads, in, whole, false);
+        graph_rank(g_ctx, nullptr, 0, P, a, src, 0, nReads, in, whole, false);
         const bool same = whole.n == n && whole.nSolid == nSolid && whole.sums[0] == sums[0] && whole.sums[1] == sums[1] &&
                           whole.sums[2] == sums[2] && whole.sums[3] == sums[3];
         const std::string what = "records " + std::to_string(n) + " / " + std::to_string(whole.n) + ", solid " + std::to_string(nSolid) + " / " +
