@@ -365,7 +365,8 @@ static int graph_hip(int argc, char **argv)
  *   refdrv_hip edges_hip <tmpDir> --threads N [--firstpass]      after `graph_hip` left its tables in <tmpDir>: the REFERENCE's own
  *       EdgeIndexer (graph/CreateMdbg.hpp:4010-4230, constructed on the reference's CreateMdbg exactly as indexEdges() does, :1181-1183)
  *       writes edges.bin from kminmerData_min.txt, mdbg_edge_index makes the same set from the same vectors, and the two are compared
- *       key by key (count, the checksum the reference logs, every 128-bit identity). */
+ *       key by key (count, the checksum the reference logs, every 128-bit identity); then the same for the reference's UnitigEdgeIndexer
+ *       (:4234-4512) over the unitigGraph.nodes.bin the graph stage left, against mdbg_unitig_edge_index. */
 static int fn_corrscan_hip(int argc, char **argv)
 {
     if (argc < 5) return 2;
@@ -468,8 +469,49 @@ static int edges_hip(int argc, char **argv)
     const bool same = got == want && ne == ref._nbEdges && checksum == ref._checksum;
     std::cout << "edges_hip: reference EdgeIndexer " << ref._nbEdges << " keys, checksum " << ref._checksum << "; mdbg_edge_index " << ne << " keys, checksum " << checksum
               << "; " << (same ? "equal" : "DIFFERENT") << "\n";
+    /* the second half of N2: the reference's UnitigEdgeIndexer (graph/CreateMdbg.hpp:4234-4512) over unitigGraph.nodes.bin -- left by the graph
+     * stage that `graph_hip` ran on the library's tables -- against mdbg_unitig_edge_index over the same unitigs */
+    bool same_u = true;
+    if (fs::exists(g._outputDir + "/unitigGraph.nodes.bin")) {
+        CreateMdbg::UnitigEdgeIndexer uref(g);
+        uref.execute();
+        std::vector<u_int128_t> uwant;
+        {
+            ifstream f(uref.getOutputFilename(), std::ios::binary);
+            u_int128_t e;
+            while (f.read((char *)&e, sizeof e)) uwant.push_back(e);
+        }
+        fs::remove(uref.getOutputFilename());
+        std::sort(uwant.begin(), uwant.end());
+        const std::vector<uint8_t> nodes = hipbind::file_bytes(g._outputDir + "/unitigGraph.nodes.bin", true);     /* (u32 size; u32 m[size]; u32 unitigIndex)* */
+        std::vector<uint32_t> um;
+        std::vector<uint64_t> uoff{0};
+        for (size_t o = 0; o + 4 <= nodes.size();) {
+            uint32_t sz;
+            memcpy(&sz, nodes.data() + o, 4); o += 4;
+            const size_t base = um.size();
+            um.resize(base + sz);
+            if (sz) memcpy(um.data() + base, nodes.data() + o, (size_t)sz * 4);
+            o += (size_t)sz * 4 + 4;
+            uoff.push_back(um.size());
+        }
+        mdbg_minimizers *unitigs = hipbind::upload(gpu, um, uoff);
+        mdbg_table *uedges = nullptr;
+        hipbind::check(gpu, mdbg_unitig_edge_index(gpu, unitigs, k, &uedges, nullptr), "mdbg_unitig_edge_index");
+        uint64_t nu = 0;
+        mdbg_table_info(uedges, nullptr, &nu, nullptr, nullptr);
+        std::vector<uint64_t> ukeys(nu * 2);
+        hipbind::check(gpu, mdbg_table_keys_to_host(gpu, uedges, ukeys.data()), "mdbg_table_keys_to_host");
+        std::vector<u_int128_t> ugot(nu);
+        for (uint64_t i = 0; i < nu; i++) ugot[i] = ((u_int128_t)ukeys[2 * i + 1] << 64) | ukeys[2 * i];
+        std::sort(ugot.begin(), ugot.end());
+        same_u = ugot == uwant && nu == uref._nbEdges;
+        std::cout << "edges_hip: reference UnitigEdgeIndexer " << uref._nbEdges << " keys over " << (uoff.size() - 1) << " unitigs; mdbg_unitig_edge_index " << nu << " keys; "
+                  << (same_u ? "equal" : "DIFFERENT") << "\n";
+        mdbg_table_free(uedges); mdbg_minimizers_free(unitigs);
+    }
     mdbg_table_free(edges); mdbg_table_free(table); mdbg_minimizers_free(reads); mdbg_destroy(gpu);
-    return same ? 0 : 1;
+    return same && same_u ? 0 : 1;
 }
 
 static int read_selection_hip(int argc, char **argv)

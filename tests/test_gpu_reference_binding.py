@@ -163,3 +163,5 @@ def test_edge_index_inside_the_reference(tmp_path):
         r = run(REFDRV_HIP, "edges_hip", tmp, "--threads", "2", "--min-abundance", "0", "--firstpass")
         log = m["reference_log"]
         assert f"reference EdgeIndexer {log['n_edges']} keys, checksum {log['edge_checksum']}; mdbg_edge_index {log['n_edges']} keys, checksum {log['edge_checksum']}; equal" in r.stdout, r.stdout
+        # ... and UnitigEdgeIndexer over the unitigs the graph stage left, against mdbg_unitig_edge_index
+        assert f"reference UnitigEdgeIndexer {log['n_unitig_edges']} keys" in r.stdout and f"mdbg_unitig_edge_index {log['n_unitig_edges']} keys; equal" in r.stdout, r.stdout
