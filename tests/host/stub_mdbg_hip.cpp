@@ -197,6 +197,7 @@ int mdbg_table_to_host_range(mdbg_ctx *, const mdbg_table *t, uint64_t first, ui
 int mdbg_table_to_host(mdbg_ctx *c, const mdbg_table *t, uint8_t *rec, uint32_t *vec) { return mdbg_table_to_host_range(c, t, 0, t->rec.size() / 20, rec, vec); }
 void mdbg_table_free(mdbg_table *t) { delete t; }
 int mdbg_edge_index(mdbg_ctx *, const mdbg_table *, mdbg_table **, uint64_t *) { return MDBG_ENODEV; }     // (refdrv_hip edges_hip links them; never called against the double)
+int mdbg_unitig_edge_index(mdbg_ctx *, const mdbg_minimizers *, uint32_t, mdbg_table **, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_table_keys_to_host(mdbg_ctx *, const mdbg_table *, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_shard_from_table(mdbg_ctx *, const mdbg_table *, uint32_t, mdbg_shard **, const uint64_t **, uint64_t *) { return MDBG_ENODEV; }
 int mdbg_shard_exchange(mdbg_ctx *, mdbg_comm *, mdbg_shard *, const uint64_t *, const uint64_t *, const uint64_t **) { return MDBG_ENODEV; }

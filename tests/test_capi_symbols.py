@@ -88,3 +88,21 @@ def test_c_example_compiles_links_and_fails_loudly_without_gpu(lib_path, tmp_pat
         pytest.skip("a GPU is present: the GPU tests run the path")
     r = subprocess.run([exe], input="ACGTACGTACGTACGTACGT\n", capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "no CPU path" in r.stderr
+
+
+def test_test_double_covers_what_the_host_programs_import(tmp_path):
+    """tests/host/stub_mdbg_hip.cpp stands in for the library under refdrv_hip and mdbg_tool in the CPU tests: every mdbg_* symbol those
+    programs import must be defined by it, or they stop at start-up with a symbol lookup error (an entry point added to the binding
+    without its line in the double did exactly that)."""
+    stub = str(tmp_path / "libmdbg_hip.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", os.path.join(ROOT, "tests", "host", "stub_mdbg_hip.cpp"), "-o", stub, "-lpthread"], check=True)
+    out = subprocess.run(["nm", "-D", "--defined-only", stub], capture_output=True, text=True, check=True).stdout
+    defined = set(re.findall(r" T (mdbg_[a-z0-9_]+)", out))
+    programs = [p for p in (os.path.join(ROOT, "oracle", "_ref", "refdrv_hip"), os.path.join(ROOT, "metamdbg_amd", "bin", "mdbg_tool")) if os.path.exists(p)]
+    if not programs:
+        pytest.skip("neither refdrv_hip nor mdbg_tool is built here")
+    for prog in programs:
+        und = subprocess.run(["nm", "-D", "--undefined-only", prog], capture_output=True, text=True, check=True).stdout
+        wanted = set(re.findall(r" U (mdbg_[a-z0-9_]+)", und))
+        missing = sorted(wanted - defined)
+        assert not missing, f"{os.path.basename(prog)} imports {missing}: not defined by tests/host/stub_mdbg_hip.cpp"
