@@ -53,6 +53,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CAND_CYCLES_4, CAND_CYCLES_5 = 160.0, 156.0     # cycles per 64 candidate tests per SIMD at 4 / 5 waves (profiles/round6_n_hash_rates_with_the_merged_candidate_test.txt)
 K_MINIMIZER, DENSITY, KMINMER = 15, 0.005, 4
 DEFAULT_TABLE_GRID = 0         # workgroups of the kernels that walk every k-min-mer instance, batches in flight (0: one per CU)
 DEFAULT_TABLE_CUS = 0          # compute units the table kernels of a batch in flight are confined to (0: not confined)
@@ -856,18 +857,19 @@ def main() -> None:
                                               "never overlap each other")
                                              if n_slots > 1 else None,
                          "note": "integer-hash kernel: Murmur3_x64_128 of every HPC position (17 integer multiplies at 4.7 cycles per wave64 "
-                                 "each; the kernel computes the upper half without the carry at every position, 15 multiplies, and the full "
+                                 "each; the kernel computes the upper half with the finalisers' last multiplications merged at every position, 14 multiplies, and the full "
                                  "hash of the selected ones) puts the ceiling at the VALU, far below HBM; the PMC counters show the VALU "
                                  "saturated (profiles/r02w_pmc_scan.txt, DESIGN.md 4.1)",
-                         # the hash alone, measured in isolation (tools/ubench/hash_rates.hip, profiles/r02w_hash_rates.txt): 186 cycles per 64 full
-                         # hashes per SIMD at 8 waves, 168 / 164 per 64 candidate tests at 4 / 5 waves
-                         # round-5 VERDICT item 7: the floor of the variant that RUNS -- the candidate test (kmer_hash32_hi_nocarry) at the occupancy
-                         # in use: 4 waves per SIMD when the scan leaves room for other batches (scan_lds_reserve), 5 alone -- not the full hash at 8
-                         "valu_floor": {"variant": f"kmer_hash32_hi_nocarry (the candidate test every position takes) at {4 if n_slots > 1 else 5} waves per SIMD",
-                                        "cycles_per_64": 168 if n_slots > 1 else 164, "full_hash_cycles_per_64_at_8_waves": 186,
+                         # the hash alone, measured in isolation (tools/ubench/hash_rates.hip, profiles/round6_n_hash_rates_with_the_merged_candidate_test.txt):
+                         # 186 cycles per 64 full hashes per SIMD at 8 waves, 160 / 156 per 64 candidate tests at 4 / 5 waves
+                         # round-5 VERDICT item 7: the floor of the variant that RUNS -- the candidate test (kmer_hash32_hi_merged since round 6: the
+                         # finalisers' last multiplications as one; kmer_hash32_hi_nocarry, 168 / 164 cycles, before) at the occupancy in use:
+                         # 4 waves per SIMD when the scan leaves room for other batches (scan_lds_reserve), 5 alone -- not the full hash at 8
+                         "valu_floor": {"variant": f"kmer_hash32_hi_merged (the candidate test every position takes) at {4 if n_slots > 1 else 5} waves per SIMD",
+                                        "cycles_per_64": CAND_CYCLES_4 if n_slots > 1 else CAND_CYCLES_5, "full_hash_cycles_per_64_at_8_waves": 186,
                                         "hpc_positions_per_launch": hpc_positions, "full_hash_floor_ms": hash_floor_ms,
-                                        "floor_ms": hash_floor_ms * (168.0 if n_slots > 1 else 164.0) / 186.0,
-                                        "frac": hash_floor_ms * (168.0 if n_slots > 1 else 164.0) / 186.0 / (scan_avg_s * 1e3) if scan_avg_s > 0 else None}},
+                                        "floor_ms": hash_floor_ms * (CAND_CYCLES_4 if n_slots > 1 else CAND_CYCLES_5) / 186.0,
+                                        "frac": hash_floor_ms * (CAND_CYCLES_4 if n_slots > 1 else CAND_CYCLES_5) / 186.0 / (scan_avg_s * 1e3) if scan_avg_s > 0 else None}},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()},
             "cpu_baseline": base,
         }

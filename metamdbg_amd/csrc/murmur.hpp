@@ -73,6 +73,29 @@ __host__ __device__ __forceinline__ uint32_t kmer_hash32_hi_nocarry(uint32_t v) 
     return ah + bh;
 }
 
+// The candidate test's value (round 6): the LAST multiplication of either finaliser is linear, so the two can be done as one.
+// With a' and b' the finalisers' states before it,  a'*C + b'*C = (a' + b')*C  (mod 2^64), whose upper half is
+// hi(mix a) + hi(mix b) + c0, c0 = the carry of the two products' LOWER halves -- not the carry the hash itself has (that one
+// comes after each lower half's last xor-shift), but like it 0 or 1.  So with r = upper32((a' + b')*C) + 1:
+//     r - hi(kmer_hash32(v)) is 0, 1 or 2 (mod 2^32)   =>   hash < T  implies  r < hi(T) + 3.
+// One 64-bit add and three multiplier operations where kmer_hash32_hi_nocarry has six and four adds; the + 1 (which keeps a
+// hash whose upper half is 0 from wrapping below zero) rides in the addend of the 32 x 32 -> 64 product.
+__host__ __device__ __forceinline__ uint32_t kmer_hash32_hi_merged(uint32_t v) {
+    const uint64_t p = (uint64_t)v * 0x114253d5u;
+    uint32_t l = (uint32_t)p, h = (uint32_t)(p >> 32) + v * 0x87c37b91u;
+    const uint32_t rl = (l << 31) | (h >> 1), rh = (h << 31) | (l >> 1);
+    l = rl; h = rh;
+    mul64_halves(l, h, 0x2745937fu, 0x4cf5ad43u);
+    const uint64_t h1 = ((((uint64_t)h << 32) | l) ^ 34ull) + 34ull, h2 = h1 + 34ull;
+    uint32_t al = (uint32_t)h1, ah = (uint32_t)(h1 >> 32), bl = (uint32_t)h2, bh = (uint32_t)(h2 >> 32);
+    al ^= ah >> 1; mul64_halves(al, ah, 0xed558ccdu, 0xff51afd7u); al ^= ah >> 1;
+    bl ^= bh >> 1; mul64_halves(bl, bh, 0xed558ccdu, 0xff51afd7u); bl ^= bh >> 1;
+    const uint64_t s = (((uint64_t)ah << 32) | al) + (((uint64_t)bh << 32) | bl);
+    const uint32_t sl = (uint32_t)s, sh = (uint32_t)(s >> 32);
+    const uint64_t q = (uint64_t)sl * 0x1a85ec53u + (1ull << 32);
+    return (uint32_t)(q >> 32) + sl * 0xc4ceb9feu + sh * 0x1a85ec53u;
+}
+
 // Streaming Murmur3 x64-128 over a sequence of u32 words (little-endian), seed 0.
 struct Murmur128Stream {
     uint64_t h1 = 0, h2 = 0;

@@ -772,19 +772,23 @@ struct SpanState {
     uint32_t bits;
 };
 
-// APPROX: the verdict is taken on the upper half of the hash without the carry out of the lower one
-// (kmer_hash32_hi_nocarry): s = that + 1 is hi(hash) or hi(hash) + 1, so  hash < threshold  implies  s < hi(threshold) + 2.
-// The positions recorded are a superset of the selected ones, off by about one in 2^31; every one of them is hashed in
-// full when it is materialised (emit), and a read with a false one is handed to the general kernel.
-template <bool APPROX>
+// APPROX: the verdict is taken on the upper half of the hash with the finalisers' last multiplications merged into one
+// (kmer_hash32_hi_merged, murmur.hpp): s = that is hi(hash), hi(hash) + 1 or hi(hash) + 2, so  hash < threshold  implies
+// s < hi(threshold) + 3.  The positions recorded are a superset of the selected ones, off by about one in 2^31; every one of
+// them is hashed in full when it is materialised (emit), and a read with a false one is handed to the general kernel.
+// (Rounds 2 - 5 took hi(mix a) + hi(mix b) + 1 by two separate multiplications: 9 cycles per position more.)
+// K15 (l = 15, what the reference's presets use): the digit that enters the forward k-mer at this position is the top digit of
+// the PREVIOUS position's 32 stream bits, so the roll is one v_alignbit and a mask instead of shift, field extract and merge.
+template <bool APPROX, bool K15 = false>
 __device__ __forceinline__ void span_step(SpanState &st, uint32_t T, bool first, uint32_t kmask, uint32_t comp_mask, unsigned top_shift,
-                                          unsigned K, uint64_t threshold, uint32_t cand_limit) {
+                                          unsigned K, uint64_t threshold, uint32_t cand_limit, uint32_t Tprev = 0u) {
     const uint32_t rev = (T ^ comp_mask) & kmask;                      // complement of every digit, already in reversed order
     // forward k-mer: digits in reading order; rolled: drop the oldest digit, append the newest (the top digit of T's k-mer)
-    st.fwd = first ? digit_reverse(T & kmask, K) : (((st.fwd << 2) | ((T >> top_shift) & 3u)) & kmask);
+    if (K15) st.fwd = first ? digit_reverse(T & kmask, K) : (__builtin_amdgcn_alignbit(st.fwd, Tprev, 30) & kmask);
+    else st.fwd = first ? digit_reverse(T & kmask, K) : (((st.fwd << 2) | ((T >> top_shift) & 3u)) & kmask);
     const uint32_t val = st.fwd < rev ? st.fwd : rev;
     if (APPROX) {
-        const uint32_t s1 = kmer_hash32_hi_nocarry(val) + 1u;
+        const uint32_t s1 = kmer_hash32_hi_merged(val);
         asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(st.bits) : "v"(s1), "s"(cand_limit) : "vcc");
     } else {
         const uint64_t h = kmer_hash32(val);
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     // APPROX (bump mode only: a read with a false candidate needs the host's re-run): see span_step.  cand_slack widens the
     // superset on purpose (tests of the re-run path)
     // (saturating: a threshold near 2^64 -- densities close to 1 -- must not wrap the limit around to "nothing is a candidate")
-    const uint64_t cand_limit64 = (threshold >> 32) + 2ull + (uint64_t)a.cand_slack;
+    const uint64_t cand_limit64 = (threshold >> 32) + 3ull + (uint64_t)a.cand_slack;
     const uint32_t cand_limit = cand_limit64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cand_limit64;
 
     const uint32_t wave_global = blockIdx.x * FAST_WAVES + wv;
@@ -1059,12 +1063,18 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             const unsigned wb = ((done >> 4) + WPL * lane) & RING_WMASK;
             const uint32_t W0 = S[wb], W1 = S[(wb + 1) & RING_WMASK], W2 = SP > 16 ? S[(wb + 2) & RING_WMASK] : 0u;
             SpanState st{0u, 0u};
+            auto walk = [&](auto k15_tag) {
+                constexpr bool K15 = decltype(k15_tag)::value;
+                uint32_t Tprev = 0u;
 #pragma unroll
-            for (int u = 0; u < SP; u++) {
-                const uint32_t T = u == 0 ? W0 : (u < 16 ? __builtin_amdgcn_alignbit(W1, W0, 2 * u)
-                                                         : (u == 16 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * (u - 16))));
-                span_step<APPROX>(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold, cand_limit);
-            }
+                for (int u = 0; u < SP; u++) {
+                    const uint32_t T = u == 0 ? W0 : (u < 16 ? __builtin_amdgcn_alignbit(W1, W0, 2 * u)
+                                                             : (u == 16 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * (u - 16))));
+                    span_step<APPROX, K15>(st, T, u == 0, kmask, comp_mask, top_shift, K, threshold, cand_limit, Tprev);
+                    Tprev = T;
+                }
+            };
+            if (K == 15u) walk(std::true_type()); else walk(std::false_type());
             emit(st.bits, (unsigned)SP, 64u * (unsigned)SP);
             wave_lds_sync();
             done += 64u * (unsigned)SP;
@@ -1506,7 +1516,8 @@ static int launch_scan(mdbg_ctx *ctx, ScanArgs &a, bool hpc, bool has_q, bool ha
             // bump mode: candidates by the upper half of the hash (span_step<APPROX>); the host's re-run of a read covers a false one
             const dim3 g((unsigned)blocks), b(FAST_BLOCK);
             using FastKernel = void (*)(ScanArgs);
-            const bool approx = a.cursor && !no_approx;
+            // (not when the candidate limit would saturate -- a threshold within a few 2^32 of 2^64, density 1.0f: the full verdict then)
+            const bool approx = a.cursor && !no_approx && (a.threshold >> 32) + 3ull + (uint64_t)a.cand_slack < 0xFFFFFFFFull;
             const FastKernel fk = approx ? (hpc ? (has_q ? scan_fast_kernel<true, true, true> : scan_fast_kernel<true, false, true>)
                                                 : (has_q ? scan_fast_kernel<false, true, true> : scan_fast_kernel<false, false, true>))
                                          : (hpc ? (has_q ? scan_fast_kernel<true, true, false> : scan_fast_kernel<true, false, false>)

@@ -729,7 +729,8 @@ def main() -> None:
             return
         if "--only-1m" in sys.argv:      # minutes of CPU and 10 GB of scratch: not part of the default regeneration
             if "--multik" in sys.argv:   # ... and the loop k = 4 .. 11 on the same reads (benchmark mode), digests into the same manifest
-                make_hifi_1m_multik(work)
+                # (--last-k N: further, e.g. 24 -- the generic window hash behind k >= 12 against the reference at a million reads)
+                make_hifi_1m_multik(work, last_k=int(sys.argv[sys.argv.index("--last-k") + 1]) if "--last-k" in sys.argv else 11)
             else:
                 make_hifi_1m(work)
             return

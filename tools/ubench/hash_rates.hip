@@ -65,6 +65,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
                 v[c] = v[c] * 1664525u + 1013904223u + (s1 >> 28);
                 continue;
             }
+            if (V == 4) {         // round 6: the finalisers' last multiplications merged into one (kmer_hash32_hi_merged): what the kernel runs now
+                const uint32_t s1 = kmer_hash32_hi_merged(v[c]);
+                acc += (s1 < (uint32_t)(92233718306963448ull >> 32) + 3u) ? 1u : 0u;
+                v[c] = v[c] * 1664525u + 1013904223u + (s1 >> 28);
+                continue;
+            }
             uint64_t h = V == 0 ? kmer_hash32(v[c]) : (V == 1 ? hash_v1(v[c]) : hash_v2(v[c]));
             acc += (h < 92233718306963448ull) ? 1u : 0u;
             v[c] = v[c] * 1664525u + 1013904223u + (uint32_t)(h >> 60);   // next input (cheap, dependent)
@@ -99,6 +105,7 @@ int main() {
         run<1, 1>("mad_u64", d, w);  run<1, 2>("mad_u64", d, w);
         run<2, 1>("mul_lo_hi", d, w); run<2, 2>("mul_lo_hi", d, w);
         run<3, 1>("hi_nocarry", d, w); run<3, 2>("hi_nocarry", d, w);
+        run<4, 1>("hi_merged", d, w); run<4, 2>("hi_merged", d, w);
     }
     return 0;
 }
