@@ -96,6 +96,34 @@ __host__ __device__ __forceinline__ uint32_t kmer_hash32_hi_merged(uint32_t v) {
     return (uint32_t)(q >> 32) + sl * 0xc4ceb9feu + sh * 0x1a85ec53u;
 }
 
+// Two of them side by side, statement by statement: the compiler keeps the order it is given, and a SIMD that holds 4 - 5 waves
+// has an independent instruction to issue while a multiply's result is on its way (tools/ubench/hash_rates.hip: chains=2).
+__host__ __device__ __forceinline__ void kmer_hash32_hi_merged_x2(uint32_t va, uint32_t vb, uint32_t &ra, uint32_t &rb) {
+    const uint64_t pa = (uint64_t)va * 0x114253d5u, pb = (uint64_t)vb * 0x114253d5u;
+    uint32_t la = (uint32_t)pa, lb = (uint32_t)pb;
+    uint32_t ha = (uint32_t)(pa >> 32) + va * 0x87c37b91u, hb = (uint32_t)(pb >> 32) + vb * 0x87c37b91u;
+    const uint32_t rla = (la << 31) | (ha >> 1), rlb = (lb << 31) | (hb >> 1);
+    const uint32_t rha = (ha << 31) | (la >> 1), rhb = (hb << 31) | (lb >> 1);
+    la = rla; lb = rlb; ha = rha; hb = rhb;
+    const uint64_t qa = (uint64_t)la * 0x2745937fu, qb = (uint64_t)lb * 0x2745937fu;
+    const uint32_t nha = (uint32_t)(qa >> 32) + la * 0x4cf5ad43u + ha * 0x2745937fu, nhb = (uint32_t)(qb >> 32) + lb * 0x4cf5ad43u + hb * 0x2745937fu;
+    const uint64_t h1a = ((((uint64_t)nha << 32) | (uint32_t)qa) ^ 34ull) + 34ull, h1b = ((((uint64_t)nhb << 32) | (uint32_t)qb) ^ 34ull) + 34ull;
+    const uint64_t h2a = h1a + 34ull, h2b = h1b + 34ull;
+    uint32_t ala = (uint32_t)h1a, aha = (uint32_t)(h1a >> 32), alb = (uint32_t)h1b, ahb = (uint32_t)(h1b >> 32);
+    uint32_t bla = (uint32_t)h2a, bha = (uint32_t)(h2a >> 32), blb = (uint32_t)h2b, bhb = (uint32_t)(h2b >> 32);
+    ala ^= aha >> 1; alb ^= ahb >> 1;
+    mul64_halves(ala, aha, 0xed558ccdu, 0xff51afd7u); mul64_halves(alb, ahb, 0xed558ccdu, 0xff51afd7u);
+    ala ^= aha >> 1; alb ^= ahb >> 1;
+    bla ^= bha >> 1; blb ^= bhb >> 1;
+    mul64_halves(bla, bha, 0xed558ccdu, 0xff51afd7u); mul64_halves(blb, bhb, 0xed558ccdu, 0xff51afd7u);
+    bla ^= bha >> 1; blb ^= bhb >> 1;
+    const uint64_t sa = (((uint64_t)aha << 32) | ala) + (((uint64_t)bha << 32) | bla), sb = (((uint64_t)ahb << 32) | alb) + (((uint64_t)bhb << 32) | blb);
+    const uint32_t sla = (uint32_t)sa, sha = (uint32_t)(sa >> 32), slb = (uint32_t)sb, shb = (uint32_t)(sb >> 32);
+    const uint64_t ta = (uint64_t)sla * 0x1a85ec53u + (1ull << 32), tb = (uint64_t)slb * 0x1a85ec53u + (1ull << 32);
+    ra = (uint32_t)(ta >> 32) + sla * 0xc4ceb9feu + sha * 0x1a85ec53u;
+    rb = (uint32_t)(tb >> 32) + slb * 0xc4ceb9feu + shb * 0x1a85ec53u;
+}
+
 // Streaming Murmur3 x64-128 over a sequence of u32 words (little-endian), seed 0.
 struct Murmur128Stream {
     uint64_t h1 = 0, h2 = 0;

@@ -763,6 +763,7 @@ constexpr unsigned RING_WORDS = RING_BASES / 16;      // u32
 constexpr unsigned RING_WMASK = RING_WORDS - 1;
 constexpr unsigned SPAN = 32;                         // positions per lane in a full block
 constexpr unsigned BLOCK_POS = 64 * SPAN;             // 2048
+constexpr bool DUAL_CHAIN = true;                      // the unrolled block walks two half spans of a lane side by side (aligned_block)
 constexpr int STAGE_CAP = 384;                        // minimizers of one read staged per wave before a flush
 
 // One position of a lane's span: canonical k-mer from the 32 stream bits T that start at the position, Murmur3, compare,
@@ -1065,6 +1066,35 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
             SpanState st{0u, 0u};
             auto walk = [&](auto k15_tag) {
                 constexpr bool K15 = decltype(k15_tag)::value;
+                if (SP == 32 && DUAL_CHAIN) {
+                    // two independent chains per lane -- positions 0 .. 15 and 16 .. 31 side by side -- so that a wave has another
+                    // instruction to issue while a multiply's result is on its way (at 4 - 5 waves per SIMD one chain leaves gaps:
+                    // tools/ubench/hash_rates.hip, chains=1 against chains=2)
+                    uint32_t fa = 0u, fb = 0u, ba = 0u, bb = 0u, pa = 0u, pb = 0u;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const uint32_t Ta = u == 0 ? W0 : __builtin_amdgcn_alignbit(W1, W0, 2 * u);
+                        const uint32_t Tb = u == 0 ? W1 : __builtin_amdgcn_alignbit(W2, W1, 2 * u);
+                        const uint32_t reva = (Ta ^ comp_mask) & kmask, revb = (Tb ^ comp_mask) & kmask;
+                        if (u == 0) { fa = digit_reverse(Ta & kmask, K); fb = digit_reverse(Tb & kmask, K); }
+                        else if (K15) { fa = __builtin_amdgcn_alignbit(fa, pa, 30) & kmask; fb = __builtin_amdgcn_alignbit(fb, pb, 30) & kmask; }
+                        else { fa = ((fa << 2) | ((Ta >> top_shift) & 3u)) & kmask; fb = ((fb << 2) | ((Tb >> top_shift) & 3u)) & kmask; }
+                        const uint32_t va = fa < reva ? fa : reva, vb = fb < revb ? fb : revb;
+                        if (APPROX) {
+                            uint32_t ra, rb;
+                            kmer_hash32_hi_merged_x2(va, vb, ra, rb);
+                            asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ba) : "v"(ra), "s"(cand_limit) : "vcc");
+                            asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bb) : "v"(rb), "s"(cand_limit) : "vcc");
+                        } else {
+                            const uint64_t ha = kmer_hash32(va), hb = kmer_hash32(vb);
+                            asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ba) : "v"(ha), "s"(threshold) : "vcc");
+                            asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bb) : "v"(hb), "s"(threshold) : "vcc");
+                        }
+                        pa = Ta; pb = Tb;
+                    }
+                    st.bits = (ba << 16) | bb;
+                    return;
+                }
                 uint32_t Tprev = 0u;
 #pragma unroll
                 for (int u = 0; u < SP; u++) {

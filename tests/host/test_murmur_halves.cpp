@@ -38,6 +38,11 @@ int main(int argc, char **argv) {
         const uint32_t dm = m - (uint32_t)(h >> 32);
         if (dm > 2u) { printf("merged upper half off by %u at %u\n", dm, v); return 1; }
         off_m[dm]++;
+        {   // the two-at-a-time form the unrolled block runs is the same function
+            uint32_t ra, rb;
+            mdbg::kmer_hash32_hi_merged_x2(v, v ^ 0x5A5A5A5Au, ra, rb);
+            if (ra != m || rb != mdbg::kmer_hash32_hi_merged(v ^ 0x5A5A5A5Au)) { printf("the paired form differs at %u\n", v); return 1; }
+        }
         const bool cand_m = m < limit_m;
         if (sel && !cand_m) { printf("selected but not a candidate of the merged form: %u\n", v); return 1; }
         candidates_m += cand_m;
