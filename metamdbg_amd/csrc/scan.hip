@@ -197,6 +197,9 @@ __device__ __forceinline__ uint32_t digit_reverse(uint32_t e, unsigned K) {
     return r >> (32u - 2u * K);
 }
 
+constexpr unsigned REP_FILTER_BITS = 4096;            // 512 bytes of LDS a block
+__device__ __forceinline__ uint32_t rep_filter_bit(uint32_t v) { return (v * 0x9E3779B1u) >> 20; }      // 12 bits
+
 __device__ __forceinline__ bool rep_contains(const uint32_t *rep, uint32_t n, uint32_t v) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
@@ -819,10 +822,20 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
     __shared__ uint32_t lds_ring[FAST_WAVES][RING_WORDS];
     __shared__ uint2 lds_stage[FAST_WAVES][STAGE_CAP];
     __shared__ uint8_t lds_lut_b[HPC ? HPC_LUT_SIZE : 1], lds_lut_n[HPC ? HPC_LUT_SIZE : 1];
+    // the repetitive minimizers (ONT: a hundred or so values, sorted, in global memory) behind a filter of REP_FILTER_BITS bits: a
+    // candidate whose bit is clear is not among them, and only the others pay the binary search -- eight dependent loads that a
+    // lane of every block used to wait for (9 % of the ONT scan: profiles/round6_p_scan_ablation_ont_before_the_repetitive_filter_in_lds.txt, round6_q_* after)
+    __shared__ uint32_t lds_rep_filter[REP_FILTER_BITS / 32];
     if (HPC) {
         for (unsigned i = threadIdx.x; i < HPC_LUT_SIZE; i += FAST_BLOCK) { const uint16_t e = hpc_lut_entry(i); lds_lut_b[i] = (uint8_t)e; lds_lut_n[i] = (uint8_t)(e >> 8); }
     }
     for (unsigned i = threadIdx.x; i < FAST_WAVES * RING_WORDS; i += FAST_BLOCK) (&lds_ring[0][0])[i] = 0;
+    for (unsigned i = threadIdx.x; i < REP_FILTER_BITS / 32; i += FAST_BLOCK) lds_rep_filter[i] = 0;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < a.n_rep; i += FAST_BLOCK) {
+        const uint32_t b = rep_filter_bit(a.rep[i]);
+        atomicOr(&lds_rep_filter[b >> 5], 1u << (b & 31u));
+    }
     __syncthreads();
     // the kernel is bound by instruction issue: next to the table kernels of other batches (bound by memory latency) its waves
     // go first on their SIMD
@@ -987,7 +1000,8 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                     const unsigned u = P - 1u - bit;
                     const uint32_t e = ring_window(S, done + lane * P + u) & kmask;
                     const uint32_t rev = e ^ comp_mask, fw = digit_reverse(e, K);
-                    if (rep_contains(a.rep, a.n_rep, fw < rev ? fw : rev)) bits &= ~(1u << bit);
+                    const uint32_t v = fw < rev ? fw : rev, fb = rep_filter_bit(v);
+                    if (((lds_rep_filter[fb >> 5] >> (fb & 31u)) & 1u) && rep_contains(a.rep, a.n_rep, v)) bits &= ~(1u << bit);
                 }
             }
             const unsigned cnt = (unsigned)__popc(bits);
@@ -1205,17 +1219,23 @@ __global__ __launch_bounds__(FAST_BLOCK, 5) void scan_fast_kernel(ScanArgs a) {
                 const unsigned G = (npos + 255u) / 256u;
                 const unsigned P = 4u * G;
                 SpanState st{0u, 0u};
-                for (unsigned g = 0; g < G; g++) {
-                    const unsigned p = done + lane * P + 4u * g;     // ring position of the group's first position
-                    const unsigned b = 2u * p, w = (b >> 5) & RING_WMASK, sh = b & 31u;
-                    const uint32_t w0 = S[w], w1 = S[(w + 1) & RING_WMASK], w2 = S[(w + 2) & RING_WMASK];
-                    const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+                auto tail_walk = [&](auto k15_tag) {
+                    constexpr bool K15 = decltype(k15_tag)::value;
+                    uint32_t Tprev = 0u;               // a lane's positions are consecutive across its groups: the roll of l = 15 carries over
+                    for (unsigned g = 0; g < G; g++) {
+                        const unsigned p = done + lane * P + 4u * g;     // ring position of the group's first position
+                        const unsigned b = 2u * p, w = (b >> 5) & RING_WMASK, sh = b & 31u;
+                        const uint32_t w0 = S[w], w1 = S[(w + 1) & RING_WMASK], w2 = S[(w + 2) & RING_WMASK];
+                        const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t T = u == 0 ? a0 : __builtin_amdgcn_alignbit(a1, a0, 2 * u);
-                        span_step<APPROX>(st, T, g == 0 && u == 0, kmask, comp_mask, top_shift, K, threshold, cand_limit);
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t T = u == 0 ? a0 : __builtin_amdgcn_alignbit(a1, a0, 2 * u);
+                            span_step<APPROX, K15>(st, T, g == 0 && u == 0, kmask, comp_mask, top_shift, K, threshold, cand_limit, Tprev);
+                            Tprev = T;
+                        }
                     }
-                }
+                };
+                if (K == 15u) tail_walk(std::true_type()); else tail_walk(std::false_type());
                 emit(st.bits, P, npos);
             }
             wave_lds_sync();

@@ -157,6 +157,19 @@ def test_scan_random_reads_vs_oracle(ctx, orc, hpc, K, density):
     _check_scan_against_oracle(ctx, orc, seqs, None, K, density, hpc)
 
 
+@pytest.mark.parametrize("hpc", [True, False])
+@pytest.mark.parametrize("K,density", [(15, 1.0), (15, 0.99999994), (13, 1.0), (16, 0.75)])
+def test_scan_densities_at_and_near_one_vs_oracle(ctx, orc, hpc, K, density):
+    """Densities whose threshold lies within a few 2^32 of 2^64 (1.0f: T = 2^64 - 1024, so hi(T) + 3 does not fit 32 bits) take the block
+    kernel's FULL verdict -- the candidate limit of span_step<APPROX> would saturate and a hash with upper half 0xFFFFFFFF slip through --,
+    both half spans of a lane at once (scan.hip, aligned_block); just below (0.99999994f, the float before 1) and at 0.75 the candidate
+    test runs with nearly every position a candidate, more per block than the stage holds.  Reads long enough for several blocks and a tail."""
+    rng = np.random.default_rng(K * 11 + int(hpc) + int(density * 8))
+    seqs = [bytes(synth.CODE2ASCII[rng.integers(0, 4, int(n))]) for n in
+            list(rng.integers(1, 200, 10)) + list(rng.integers(2100, 9000, 10)) + [2048, 2049, 4096 + K, 4096 + K + 1, 6200]]
+    _check_scan_against_oracle(ctx, orc, seqs, None, K, density, hpc)
+
+
 @pytest.mark.parametrize("tag,K,dens,hpc", [("hpc_k15", 15, 0.005, True), ("nohpc_k15", 15, 0.005, False),
                                             ("hpc_k16", 16, 0.005, True), ("nohpc_k13", 13, 0.02, False)])
 def test_scan_edge_reads_golden(ctx, tag, K, dens, hpc):
