@@ -1352,8 +1352,11 @@ constexpr int QSHIFT = 9;
 __global__ __launch_bounds__(256) void quality_sum_kernel(const uint8_t *qual, const uint64_t *qual_off, const uint32_t *len,
                                                           uint32_t n_reads, const uint64_t *tab_shifted,
                                                           uint64_t *sum_lo, uint64_t *sum_hi) {
-    __shared__ uint64_t T[QBINS];
-    if (threadIdx.x < QBINS) T[threadIdx.x] = tab_shifted[threadIdx.x];
+    // the table by the quality CHARACTER itself (256 entries, zero outside 33 .. 127): a byte of the load is an address after one shift
+    // and one mask -- no subtraction, no clamp.  This kernel runs beside the scan, which is bound by the vector unit: what it issues
+    // there the scan pays for (6 ms of a 57 ms ONT scan before, tools/scan_ablate_ont.py)
+    __shared__ uint64_t T[256];
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) T[i] = (i >= 33u && i < 33u + (unsigned)(QBINS - 1)) ? tab_shifted[i - 33u] : 0ull;
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1364,16 +1367,19 @@ __global__ __launch_bounds__(256) void quality_sum_kernel(const uint8_t *qual, c
         uint32_t acc_hi = 0;
         for (uint64_t chunk = (begin & ~15ull) + 16ull * lane; chunk < end; chunk += 16ull * 64ull) {
             const uint4 v = *reinterpret_cast<const uint4 *>(qual + chunk);   // the buffer is 16-byte padded at both ends
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            const bool full = chunk >= begin && chunk + 16 <= end;
-            uint64_t part = 0;
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            if (!(chunk >= begin && chunk + 16 <= end)) {       // a read's first and last chunk: the bytes outside it become character 0
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                uint32_t idx = ((w[b >> 2] >> (8 * (b & 3))) & 0xFFu) - 33u;      // < 33 wraps around
-                idx = idx < (uint32_t)(QBINS - 1) ? idx : (uint32_t)(QBINS - 1);
-                if (!full && (chunk + b < begin || chunk + b >= end)) idx = QBINS - 1;
-                part += T[idx];
+                for (int b = 0; b < 16; b++)
+                    if (chunk + b < begin || chunk + b >= end) w[b >> 2] &= ~(0xFFu << (8 * (b & 3)));
             }
+            uint64_t part = 0, part2 = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b += 2) {
+                part += T[(w[b >> 2] >> (8 * (b & 3))) & 0xFFu];
+                part2 += T[(w[(b + 1) >> 2] >> (8 * ((b + 1) & 3))) & 0xFFu];
+            }
+            part += part2;
             const uint64_t nlo = acc_lo + part;
             acc_hi += nlo < acc_lo ? 1u : 0u;
             acc_lo = nlo;
