@@ -236,7 +236,9 @@ int  mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, uint32_t f
 int  mdbg_repetitive_minimizers(mdbg_ctx *ctx, const mdbg_minimizers *m, uint32_t *out, uint32_t *n_out);
 /* The same census fed batch by batch -- the reads of determineRepetitiveMinimizers arrive in chunks (the first
  * 1 000 001 reads of every input file, ReadSelection.hpp:497-561): mdbg_census_add counts the values of one batch's
- * minimizers on the device (nothing travels), mdbg_census_top is the selection above over everything added so far.
+ * minimizers on the device (nothing travels; one count per possible value -- 4 bytes x the power of two above the largest
+ * value seen: 4 GiB at l = 15, 16 GiB at l = 16 --, one add per minimizer), mdbg_census_top is the selection above over
+ * everything added so far.
  * mdbg_repetitive_minimizers(m) = create, add(m), top, free. */
 typedef struct mdbg_census mdbg_census;
 int  mdbg_census_create(mdbg_ctx *ctx, mdbg_census **out);

@@ -193,7 +193,6 @@ int ensure_canonical(mdbg_ctx *ctx, const mdbg_minimizers *cm) {
     return MDBG_OK;
 }
 
-// ---- u32 value census (open addressing, value+1 as key so 0 marks empty) ----
 // ---- Utils::applyDensityThreshold (Commons.hpp:2507-2550) ----------------------------------------
 __global__ __launch_bounds__(256) void density_flag_kernel(const uint32_t *mins, uint64_t n, uint64_t threshold, uint32_t *flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,45 +214,56 @@ __global__ __launch_bounds__(256) void density_compact_kernel(uint64_t n, const 
     if (mpos) { opos[d] = mpos[i]; odir[d] = dir[i]; oqual[d] = qual[i]; }
 }
 
-__global__ __launch_bounds__(256) void census_insert_kernel(const uint32_t *vals, uint64_t n, unsigned long long *keys,
-                                                            uint32_t *counts, uint64_t mask) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long key = (unsigned long long)vals[i] + 1ull;
-    uint64_t s = (key * 0x9E3779B97F4A7C15ull >> 20) & mask;
-    for (;;) {
-        unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0ull) {
-            cur = atomicCAS(&keys[s], 0ull, key);
-            if (cur == 0ull) cur = key;
-        }
-        if (cur == key) { atomicAdd(&counts[s], 1u); return; }
-        s = (s + 1) & mask;
-    }
+// ---- u32 value census: ONE COUNT PER POSSIBLE VALUE.  A minimizer is a canonical l-mer, l <= 16: its value is below 4^l, so the
+// table of counts is simply indexed by it -- 4 GiB at l = 15, 16 GiB at l = 16, of 288 -- and a value costs one device-scope add
+// without a return.  (Rounds 1 - 5 kept an open-addressing table of 8-byte keys and counts, two random accesses per value and
+// 12.9 GB to clear and sweep at the ONT census: 38.8 ms for 5 x 10^8 values; this form: the rate of random adds, 26 G/s.)
+__global__ __launch_bounds__(256) void census_max_kernel(const uint32_t *vals, uint64_t n, uint32_t *out) {
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) mine = vals[i] > mine ? vals[i] : mine;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(mine, d, 64); mine = o > mine ? o : mine; }
+    if ((threadIdx.x & 63u) == 0u && mine) atomicMax(out, mine);
+}
+
+__global__ __launch_bounds__(256) void census_count_kernel(const uint32_t *vals, uint64_t n, uint32_t *counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[vals[i]], 1u);
 }
 
 // How many distinct values were seen 1, 2, ... CENSUS_BINS-1 (or more) times: the cut-off count of the top fraction is
 // read off this histogram, so only the values at or above it travel to the host (tens to hundreds of 13 M distinct values
-// at the ONT census; downloading and partially sorting all of them took longer than counting them)
+// at the ONT census; downloading and partially sorting all of them took longer than counting them).  `cap` is a multiple of 4:
+// sixteen bytes a lane, and nearly all of them zero.
 constexpr uint32_t CENSUS_BINS = 4096;
-__global__ __launch_bounds__(256) void census_hist_kernel(const unsigned long long *keys, const uint32_t *counts, uint64_t cap,
-                                                          unsigned long long *hist) {
+__global__ __launch_bounds__(256) void census_hist_kernel(const uint32_t *counts, uint64_t cap, unsigned long long *hist) {
     __shared__ uint32_t h[CENSUS_BINS];
     for (uint32_t i = threadIdx.x; i < CENSUS_BINS; i += 256) h[i] = 0;
     __syncthreads();
-    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * 256) {
-        if (keys[s] != 0ull) { const uint32_t c = counts[s]; atomicAdd(&h[c < CENSUS_BINS - 1u ? c : CENSUS_BINS - 1u], 1u); }
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(counts);
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap / 4; s += (uint64_t)gridDim.x * 256) {
+        const uint4 v = c4[s];
+        if ((v.x | v.y | v.z | v.w) == 0u) continue;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (w[j]) atomicAdd(&h[w[j] < CENSUS_BINS - 1u ? w[j] : CENSUS_BINS - 1u], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CENSUS_BINS; i += 256) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-__global__ __launch_bounds__(256) void census_top_kernel(const unsigned long long *keys, const uint32_t *counts, uint64_t cap, uint32_t cut,
+__global__ __launch_bounds__(256) void census_top_kernel(const uint32_t *counts, uint64_t cap, uint32_t cut,
                                                          uint32_t *out_val, uint32_t *out_cnt, unsigned long long *cursor, uint64_t room) {
-    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * 256) {
-        if (keys[s] != 0ull && counts[s] >= cut) {
-            const unsigned long long at = atomicAdd(cursor, 1ull);
-            if (at < room) { out_val[at] = (uint32_t)(keys[s] - 1ull); out_cnt[at] = counts[s]; }
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(counts);
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap / 4; s += (uint64_t)gridDim.x * 256) {
+        const uint4 v = c4[s];
+        if ((v.x | v.y | v.z | v.w) == 0u) continue;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (w[j] >= cut && w[j]) {
+                const unsigned long long at = atomicAdd(cursor, 1ull);
+                if (at < room) { out_val[at] = (uint32_t)(4 * s + (uint64_t)j); out_cnt[at] = w[j]; }
+            }
         }
     }
 }
@@ -675,37 +685,12 @@ extern "C" int mdbg_purge_palindromes(mdbg_ctx *ctx, const mdbg_minimizers *in, 
 
 // The census as an object: determineRepetitiveMinimizers counts the minimizers of the first million reads of every input file
 // (ReadSelection.hpp:497-561); the reads arrive batch by batch, and every batch's values are counted where they are instead of
-// travelling to the host and back.  The table (8-byte key, 4-byte count per slot) is kept at most half full: before a batch
-// is added the number of occupied slots is known exactly, and a table that could not take the whole batch as new values
-// is doubled (or more) and refilled from the old one.
+// travelling to the host and back.  counts[v] for every v below `cap`, a power of two above the largest value seen so far
+// (a batch with a larger one makes the array grow: the counts so far keep their places).
 struct mdbg_census {
-    DevBuf<unsigned long long> keys;
     DevBuf<uint32_t> counts;
     uint64_t cap = 0;
-    uint64_t occupied = 0;      // exact, as of the last add
 };
-
-namespace mdbg {
-__global__ __launch_bounds__(256) void census_occupied_kernel(const unsigned long long *keys, uint64_t cap, unsigned long long *out) {
-    unsigned long long mine = 0;
-    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * 256) mine += keys[s] != 0ull;
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(out, mine);
-}
-
-__global__ __launch_bounds__(256) void census_rehash_kernel(const unsigned long long *old_keys, const uint32_t *old_counts, uint64_t old_cap,
-                                                            unsigned long long *keys, uint32_t *counts, uint64_t mask) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < old_cap; i += (uint64_t)gridDim.x * 256) {
-        const unsigned long long key = old_keys[i];
-        if (key == 0ull) continue;
-        uint64_t s = (key * 0x9E3779B97F4A7C15ull >> 20) & mask;
-        for (;;) {                                   // every key is distinct here: the first free slot is its own
-            if (atomicCAS(&keys[s], 0ull, key) == 0ull) { counts[s] = old_counts[i]; break; }
-            s = (s + 1) & mask;
-        }
-    }
-}
-}  // namespace mdbg
 
 extern "C" int mdbg_census_create(mdbg_ctx *ctx, mdbg_census **out) try {
     if (!ctx || !out) return set_error(ctx, MDBG_EINVAL, "mdbg_census_create: null argument");
@@ -722,36 +707,31 @@ extern "C" int mdbg_census_add(mdbg_ctx *ctx, mdbg_census *c, const mdbg_minimiz
     const uint64_t n = m->n_min;
     if (!n) return MDBG_OK;
     const unsigned sweep_max = (unsigned)ctx->n_cu * 8u;
+    DevBuf<uint32_t> d_max;
+    MDBG_TRY(d_max.alloc(ctx, 1));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(d_max.p, 0, 4, ctx->stream));
+    {
+        LaunchTimer timer(ctx, "minimizer_census");
+        hipLaunchKernelGGL(census_max_kernel, dim3(grid_for(n, 256, sweep_max)), dim3(256), 0, ctx->stream, m->d_min.p, n, d_max.p);
+    }
+    uint32_t vmax = 0;
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &vmax, d_max.p, 4, hipMemcpyDeviceToHost));
     uint64_t want = 1024;
-    while (want < (c->occupied + n) * 2) want <<= 1;
+    while (want <= (uint64_t)vmax) want <<= 1;
     if (want > c->cap) {
-        DevBuf<unsigned long long> keys;
         DevBuf<uint32_t> counts;
-        MDBG_TRY(keys.alloc(ctx, want));
         MDBG_TRY(counts.alloc(ctx, want));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(keys.p, 0, want * 8, ctx->stream));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(counts.p, 0, want * 4, ctx->stream));
-        if (c->occupied) {
-            LaunchTimer timer(ctx, "minimizer_census");
-            hipLaunchKernelGGL(census_rehash_kernel, dim3(grid_for(c->cap, 256, sweep_max)), dim3(256), 0, ctx->stream, c->keys.p, c->counts.p, c->cap,
-                               keys.p, counts.p, want - 1);
-            MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the old table goes back to the pool below
-        }
-        c->keys = std::move(keys);
+        if (c->cap) MDBG_HIP_CHECK(ctx, hipMemcpyAsync(counts.p, c->counts.p, c->cap * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(counts.p + c->cap, 0, (want - c->cap) * 4, ctx->stream));
+        if (c->cap) MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the old array goes back to the pool below
         c->counts = std::move(counts);
         c->cap = want;
     }
-    DevBuf<unsigned long long> d_occ;
-    MDBG_TRY(d_occ.alloc(ctx, 1));
-    MDBG_HIP_CHECK(ctx, hipMemsetAsync(d_occ.p, 0, 8, ctx->stream));
     {
         LaunchTimer timer(ctx, "minimizer_census");
-        hipLaunchKernelGGL(census_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, c->keys.p, c->counts.p, c->cap - 1);
-        hipLaunchKernelGGL(census_occupied_kernel, dim3(grid_for(c->cap, 256, sweep_max)), dim3(256), 0, ctx->stream, c->keys.p, c->cap, d_occ.p);
+        hipLaunchKernelGGL(census_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, c->counts.p);
     }
-    unsigned long long occ = 0;
-    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &occ, d_occ.p, 8, hipMemcpyDeviceToHost));
-    c->occupied = occ;
+    MDBG_HIP_CHECK(ctx, hipGetLastError());
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
@@ -764,11 +744,11 @@ extern "C" int mdbg_census_top(mdbg_ctx *ctx, const mdbg_census *c, uint32_t *ou
     DevBuf<uint32_t> oval, ocnt;
     MDBG_TRY(hist.alloc(ctx, CENSUS_BINS + 1));               // + the cursor of the second pass
     MDBG_HIP_CHECK(ctx, hipMemsetAsync(hist.p, 0, (CENSUS_BINS + 1) * 8, ctx->stream));
-    const unsigned sweep_blocks = grid_for(cap, 256, (unsigned)ctx->n_cu * 8u);
+    const unsigned sweep_blocks = grid_for(cap / 4, 256, (unsigned)ctx->n_cu * 16u);
     std::vector<unsigned long long> h_hist(CENSUS_BINS);
     {
         LaunchTimer timer(ctx, "minimizer_census");
-        hipLaunchKernelGGL(census_hist_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, c->keys.p, c->counts.p, cap, hist.p);
+        hipLaunchKernelGGL(census_hist_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, c->counts.p, cap, hist.p);
     }
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h_hist.data(), hist.p, CENSUS_BINS * 8, hipMemcpyDeviceToHost));
     uint64_t distinct = 0;
@@ -789,7 +769,7 @@ extern "C" int mdbg_census_top(mdbg_ctx *ctx, const mdbg_census *c, uint32_t *ou
         MDBG_TRY(ocnt.alloc(ctx, n_top));
         {
             LaunchTimer timer(ctx, "minimizer_census");
-            hipLaunchKernelGGL(census_top_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, c->keys.p, c->counts.p, cap, cut, oval.p, ocnt.p,
+            hipLaunchKernelGGL(census_top_kernel, dim3(sweep_blocks), dim3(256), 0, ctx->stream, c->counts.p, cap, cut, oval.p, ocnt.p,
                                hist.p + CENSUS_BINS, n_top);
         }
         MDBG_HIP_CHECK(ctx, hipMemcpyAsync(hv.data(), oval.p, n_top * 4, hipMemcpyDeviceToHost, ctx->stream));

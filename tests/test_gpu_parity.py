@@ -1737,6 +1737,47 @@ def test_census_batch_by_batch(ctx):
     assert picked.tolist() == exp, [(int(v), cnt.get(int(v))) for v in picked][:20] + ["expected"] + [(v, cnt[v]) for v in exp][:20]
 
 
+def test_census_of_any_values_and_growth(ctx):
+    """The census counts in an array indexed by the value itself (4 bytes x the power of two above the largest value seen): values of
+    any size up to 2^32 - 1 (l = 16), a later batch with larger values than the array was made for (it grows, the counts so far keep
+    their places), ties at the cut by the smaller value, counts beyond the histogram's last bin -- against numpy."""
+    rng = np.random.default_rng(77)
+    def batch(hi, n, heavy):
+        v = rng.integers(0, hi, n, dtype=np.uint64).astype(np.uint32)
+        for val, times in heavy:
+            v = np.concatenate([v, np.full(times, val, np.uint32)])
+        rng.shuffle(v)
+        cut = sorted(rng.choice(np.arange(1, len(v)), 40, replace=False).tolist())
+        offs = np.array([0] + cut + [len(v)], np.uint64)
+        return v, offs
+    # first small values only, then a batch reaching 2^30, then one reaching 2^32 - 1; heavy values of 5000+ occurrences (> CENSUS_BINS)
+    # and a tie at the cut: 150 001 distinct values or so -> keep = 1 .. 2
+    b1 = batch(1 << 12, 50_000, [(7, 6000), (9, 6000)])
+    b2 = batch(1 << 30, 400_000, [((1 << 30) - 1, 5000), (123_456_789, 7000)])
+    b3 = batch((1 << 32) - 1, 400_000, [(0xFFFFFFFF, 6500), (0xFFFFFFFE, 100)])
+    for upto in (1, 2, 3):
+        bs = (b1, b2, b3)[:upto]
+        c = ctx.census()
+        for v, offs in bs:
+            m = ctx.minimizers_from_host(v, offs)
+            c.add(m)
+            m.free()
+        picked = c.top()
+        c.free()
+        allv = np.concatenate([v for v, _ in bs])
+        vals, counts = np.unique(allv, return_counts=True)
+        n_keep = max(int(np.float32(0.00001) * np.float32(len(vals))), 1)
+        order = np.lexsort((vals, -counts.astype(np.int64)))[:n_keep]
+        assert picked.tolist() == vals[order].tolist(), (upto, n_keep, picked.tolist(), vals[order].tolist())
+    # every value distinct but two: the cut falls among the ties of count 1, the smaller values win
+    v = np.arange(1000, 301_000, dtype=np.uint32); v = np.concatenate([v, v[-2:]])
+    m = ctx.minimizers_from_host(v, np.array([0, len(v)], np.uint64))
+    picked = ctx.repetitive_minimizers(m)
+    m.free()
+    n_keep = max(int(np.float32(0.00001) * np.float32(300_000)), 1)
+    assert n_keep == 3 and picked.tolist() == [300_998, 300_999, 1000], (n_keep, picked.tolist())
+
+
 def test_table_rows_in_pieces(ctx):
     """mdbg_table_to_host_range: any cut of the rows gives the rows of mdbg_table_to_host (the tool streams large tables through it)."""
     spec = synth.hifi_spec(1500, seed=8, read_len=7000, coverage=25.0)
