@@ -230,6 +230,30 @@ __global__ __launch_bounds__(256) void census_count_kernel(const uint32_t *vals,
     if (i < n) atomicAdd(&counts[vals[i]], 1u);
 }
 
+// The same over a FRESH scan output (mdbg_minimizers::scattered: the rows of read r at [begin[r], begin[r] + cnt[r]), slack between
+// the regions): a census asks for the values, not their order -- bringing 5 x 10^8 rows into CSR order first was 10 GB of copies.
+// 16 lanes per read.
+__global__ __launch_bounds__(256) void census_max_scattered_kernel(const uint64_t *begin, const uint32_t *cnt, uint32_t n_reads, const uint32_t *vals, uint32_t *out) {
+    const unsigned lane = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t mine = 0;
+    for (uint64_t r = group; r < n_reads; r += ngroups) {
+        const uint64_t s = begin[r];
+        for (uint32_t i = lane, n = cnt[r]; i < n; i += 16) mine = vals[s + i] > mine ? vals[s + i] : mine;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(mine, d, 64); mine = o > mine ? o : mine; }
+    if ((threadIdx.x & 63u) == 0u && mine) atomicMax(out, mine);
+}
+
+__global__ __launch_bounds__(256) void census_count_scattered_kernel(const uint64_t *begin, const uint32_t *cnt, uint32_t n_reads, const uint32_t *vals, uint32_t *counts) {
+    const unsigned lane = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t r = group; r < n_reads; r += ngroups) {
+        const uint64_t s = begin[r];
+        for (uint32_t i = lane, n = cnt[r]; i < n; i += 16) atomicAdd(&counts[vals[s + i]], 1u);
+    }
+}
+
 // How many distinct values were seen 1, 2, ... CENSUS_BINS-1 (or more) times: the cut-off count of the top fraction is
 // read off this histogram, so only the values at or above it travel to the host (tens to hundreds of 13 M distinct values
 // at the ONT census; downloading and partially sorting all of them took longer than counting them).  `cap` is a multiple of 4:
@@ -703,16 +727,21 @@ extern "C" void mdbg_census_free(mdbg_census *c) { delete c; }
 extern "C" int mdbg_census_add(mdbg_ctx *ctx, mdbg_census *c, const mdbg_minimizers *m) try {
     if (!ctx || !c || !m) return set_error(ctx, MDBG_EINVAL, "mdbg_census_add: null argument");
     MDBG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    MDBG_TRY(ensure_canonical(ctx, m));
     const uint64_t n = m->n_min;
     if (!n) return MDBG_OK;
-    const unsigned sweep_max = (unsigned)ctx->n_cu * 8u;
+    // a fresh scan output is counted where it lies (census_count_scattered_kernel); nobody may bring it into CSR order meanwhile
+    // (ensure_canonical swaps the arrays under this lock and frees the old rows)
+    std::unique_lock<std::mutex> rows(m->canon_mu);
+    const bool scattered = m->scattered;
+    if (!scattered) rows.unlock();
+    const unsigned sweep_max = (unsigned)ctx->n_cu * 8u, per_read_blocks = grid_for((uint64_t)m->n_reads * 16, 256, (unsigned)ctx->n_cu * 32u);
     DevBuf<uint32_t> d_max;
     MDBG_TRY(d_max.alloc(ctx, 1));
     MDBG_HIP_CHECK(ctx, hipMemsetAsync(d_max.p, 0, 4, ctx->stream));
     {
         LaunchTimer timer(ctx, "minimizer_census");
-        hipLaunchKernelGGL(census_max_kernel, dim3(grid_for(n, 256, sweep_max)), dim3(256), 0, ctx->stream, m->d_min.p, n, d_max.p);
+        if (scattered) hipLaunchKernelGGL(census_max_scattered_kernel, dim3(per_read_blocks), dim3(256), 0, ctx->stream, m->d_begin.p, m->d_cnt.p, m->n_reads, m->d_min.p, d_max.p);
+        else hipLaunchKernelGGL(census_max_kernel, dim3(grid_for(n, 256, sweep_max)), dim3(256), 0, ctx->stream, m->d_min.p, n, d_max.p);
     }
     uint32_t vmax = 0;
     MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, &vmax, d_max.p, 4, hipMemcpyDeviceToHost));
@@ -729,9 +758,11 @@ extern "C" int mdbg_census_add(mdbg_ctx *ctx, mdbg_census *c, const mdbg_minimiz
     }
     {
         LaunchTimer timer(ctx, "minimizer_census");
-        hipLaunchKernelGGL(census_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, c->counts.p);
+        if (scattered) hipLaunchKernelGGL(census_count_scattered_kernel, dim3(per_read_blocks), dim3(256), 0, ctx->stream, m->d_begin.p, m->d_cnt.p, m->n_reads, m->d_min.p, c->counts.p);
+        else hipLaunchKernelGGL(census_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->d_min.p, n, c->counts.p);
     }
     MDBG_HIP_CHECK(ctx, hipGetLastError());
+    if (scattered) MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the rows were read: the lock goes
     return MDBG_OK;
 } MDBG_API_CATCH(ctx)
 
