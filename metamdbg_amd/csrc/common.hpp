@@ -167,6 +167,7 @@ struct mdbg_ctx {
                                             // look-up per (k-1)-window, only kept keys inserted: 344 M look-ups instead of 78 M -- slower)
     uint32_t scan_quality_beside = 1;       // FASTQ: the per-read quality sums run beside the scan kernel on the side stream (0: in front of it, rounds 1 - 4)
     uint32_t keep_index_table = 1;          // an index pass's hash table stays with its result as the look-up structure of the next pass (round 6)
+    double index_last_miss_fraction = -1.0; // the last index pass's sample: k-windows with min(prev[i], prev[i+1]) <= 1 (what chose its form)
     uint32_t index_tuning = INDEX_TUNING_DEFAULT;   // one-slot index passes: bit 0 a slot's key and value in one trip, bit 1 the insert's plain-load first look (both on:
                                             // 20.5 -> 18.5 ms a pass), bit 2 two windows of a lane in flight (measured, no gain: off), bit 3 look-up and insert in one kernel (measured, slower: off); 0 = the kernels of rounds 1 - 4;
                                             // round 6: bit 4 the look-up fetches both slots of a key's home sector at once (on; with bit 1 and bit 5 off the insert keeps round 5's first look), bit 5 32 lanes a sequence (measured, slower in the library: off)

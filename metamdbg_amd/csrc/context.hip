@@ -200,7 +200,7 @@ extern "C" int mdbg_set_option(mdbg_ctx *ctx, const char *name, int64_t value) {
     if (n == "refined_form") { ctx->refined_form = value == 0 ? 0u : 1u; return MDBG_OK; }
     if (n == "scan_quality_stream") { ctx->scan_quality_beside = value == 0 ? 0u : 1u; return MDBG_OK; }
     if (n == "keep_index_table") { ctx->keep_index_table = value != 0; return MDBG_OK; }
-    if (n == "index_tuning") { ctx->index_tuning = value < 0 ? INDEX_TUNING_DEFAULT : (uint32_t)(value & 127); return MDBG_OK; }
+    if (n == "index_tuning") { ctx->index_tuning = value < 0 ? INDEX_TUNING_DEFAULT : (uint32_t)(value & 511); return MDBG_OK; }
     if (n == "test_corrupt_replies") { ctx->test_corrupt_replies = value > 0; return MDBG_OK; }
     return set_error(ctx, MDBG_EINVAL, "mdbg_set_option: unknown option '%s'", name);
 }

@@ -584,6 +584,144 @@ __global__ __launch_bounds__(256) void index_fused_kernel(SeqView s /* k */, uin
     }
 }
 
+// Round 6: INSERT FIRST, ask the previous table only where the answer is needed ("index_tuning" bit 7; chosen per pass by a sample, see
+// index_one_set).  Most k-windows of a read set are instances of a key that is already in the table (coverage), and for those nothing of the
+// previous table is wanted: the abundance min(prev[i], prev[i+1]) only decides whether an ABSENT key is inserted, and with what value.  So a
+// lane hashes its k-window and looks at its home slot of the NEW table first (plain loads, as index_insert_u_kernel<.., FAST>); the (k-1)-window
+// i is looked up only when k-window i or k-window i - 1 was not seen there -- the first instances of a key, and the windows with an error in
+// them (a <= 1: never inserted, so never found: 12 % of the instances of HiFi reads at k = 6, 22 % at k = 11, 42 % at k = 24;
+// tools/index_miss_fraction.py).  Random sectors per instance: 1 + f (1 + 1 / k) instead of 2 - f.  The layout of index_fused_kernel:
+// 16 lanes take 16 consecutive (k-1)-windows, lanes 0 .. 14 own the k-window that starts there, neighbours talk over DPP inside the row.
+// stats[0] += k-windows looked at, stats[1] += those not found at the first look (what the next choice could go by).
+// U chunks of 15 windows of a sequence in flight per group (A/B, MDBG_INDEX_LAZY_U): 11.9 / 12.2 / 13.2 ms a pass at k = 6 for U = 1 / 2 / 3 --
+// the pass is not waiting for the round trips of its few look-ups; U = 1 runs.
+template <int U>
+__global__ __launch_bounds__(256) void index_lazy_kernel(SeqView s /* k */, uint32_t k, TableView prev, TableView t, unsigned long long *stats) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t trip = 0, n_seen = 0, n_need = 0;
+    for (uint64_t r = group; r < s.n_reads; r += ngroups) {
+        if (t.poll_overflow && (trip++ & 31u) == 0u && __hip_atomic_load(t.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - s.inst_off[r]);       // k-windows; the sequence has n + 1 (k-1)-windows when n > 0
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 15u * U) {
+            // ---- every lane's k-windows: hash, first look at the home slot of the NEW table (all loads out before the first compare)
+            uint64_t khi[U], klo[U], home[U];
+            bool need[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + 15u * (uint32_t)u + sub;
+                khi[u] = klo[u] = 0; home[u] = 0;
+                need[u] = sub < 15u && i < n;
+                if (need[u]) {
+                    window_hash_uniform(m0 + i, k, khi[u], klo[u]);
+                    if (klo[u] != 0ull && khi[u] != 0ull) home[u] = table_home(klo[u], khi[u], t.mask);
+                }
+            }
+            {
+                // BOTH slots of the home sector (a key pushed off its home slot sits in the second nine times in ten: with the home slot alone
+                // a tenth of the keys were "not seen" every time they came -- 21.7 % of the instances at k = 6 where 16 % are absent)
+                uint4 wa[U], wb[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {                                               // (a lane without a window reads slot 0 and ignores it)
+                    wa[u] = *reinterpret_cast<const uint4 *>(&t.slots[home[u]]);
+                    wb[u] = *reinterpret_cast<const uint4 *>(&t.slots[home[u]] + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" : "+v"(wa[u].w), "+v"(wb[u].w));
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (need[u]) {
+                        n_seen++;
+                        const uint32_t l0 = (uint32_t)klo[u], l1 = (uint32_t)(klo[u] >> 32), h0 = (uint32_t)khi[u], h1 = (uint32_t)(khi[u] >> 32);
+                        if (klo[u] != 0ull && khi[u] != 0ull &&
+                            ((wa[u].x == l0 && wa[u].y == l1 && wa[u].z == h0 && wa[u].w == h1) || (wb[u].x == l0 && wb[u].y == l1 && wb[u].z == h0 && wb[u].w == h1)))
+                            need[u] = false;
+                        n_need += need[u] ? 1u : 0u;
+                    }
+            }
+            // ---- (k-1)-window i is asked for when k-window i or k-window i - 1 was not seen: both slots of its home sector at once
+            bool ask[U];
+            uint64_t phi[U], plo[U], phome[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + 15u * (uint32_t)u + sub;
+                const int need_left = __builtin_amdgcn_update_dpp(0, need[u] ? 1 : 0, 0x111, 0xf, 0xf, false);     // row_shr:1: the lane below, inside the row of 16
+                ask[u] = i <= n && (need[u] || need_left);
+                phi[u] = plo[u] = 0; phome[u] = 0;
+                if (ask[u]) {
+                    window_hash_uniform(m0 + i, k - 1u, phi[u], plo[u]);
+                    if (plo[u] != 0ull && phi[u] != 0ull) phome[u] = table_home(plo[u], phi[u], prev.mask);
+                }
+            }
+            uint32_t v[U];
+            {
+                SlotPair p[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) p[u] = pair_load(&prev.slots[phome[u]]);
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" : "+v"(p[u].a.val), "+v"(p[u].b.val));
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    v[u] = 1u;                                                    // getPrevAbundances: missing => 1 (graph/CreateMdbg.hpp:1240-1265)
+                    if (ask[u]) {
+                        uint32_t x;
+                        if (plo[u] == 0ull || phi[u] == 0ull) { if (table_lookup_side(prev, plo[u], phi[u], x)) v[u] = x; }
+                        else {
+                            const int f = pair_verdict(p[u], plo[u], phi[u], x);
+                            if (f > 0) v[u] = x;
+                            else if (f < 0 && table_lookup_from(prev, table_next(phome[u] + 1, prev.mask), 2, plo[u], phi[u], x)) v[u] = x;
+                        }
+                    }
+                }
+            }
+            // ---- the k-windows that were not seen: inserted when their abundance says so
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t vn = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)v[u], 0x101, 0xf, 0xf, false);      // row_shl:1: the lane above
+                if (need[u]) {
+                    const uint32_t a = v[u] < vn ? v[u] : vn;
+                    if (a > 1u) table_insert_once(t, klo[u], khi[u], a);
+                }
+            }
+        }
+    }
+    if (stats) {
+        unsigned long long a = n_seen, b = n_need;
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+        if ((threadIdx.x & 63u) == 0u && a) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], b); }
+    }
+}
+
+// What the choice between the two forms goes by: over every `step`-th sequence, how many k-windows there are and how many of them have
+// min(prev[i], prev[i+1]) <= 1 -- the windows that are never inserted, which the insert-first form asks about every time they come.
+__global__ __launch_bounds__(256) void index_miss_sample_kernel(SeqView s /* k */, uint32_t k, TableView prev, uint32_t step, unsigned long long *stats) {
+    const unsigned sub = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t n_seen = 0, n_low = 0;
+    for (uint64_t r = group * step; r < s.n_reads; r += ngroups * step) {
+        const uint32_t n = (uint32_t)(s.inst_off[r + 1] - s.inst_off[r]);
+        const uint32_t *m0 = s.mins + s.off[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 15u) {
+            const uint32_t i = i0 + sub;
+            uint32_t v = 1u;
+            if (i <= n) {
+                uint64_t hi, lo;
+                window_hash_uniform(m0 + i, k - 1u, hi, lo);
+                uint32_t x;
+                if (table_lookup(prev, lo, hi, x)) v = x;
+            }
+            const uint32_t vn = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)v, 0x101, 0xf, 0xf, false);
+            if (sub < 15u && i < n) { n_seen++; n_low += (v < vn ? v : vn) <= 1u ? 1u : 0u; }
+        }
+    }
+    unsigned long long a = n_seen, b = n_low;
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63u) == 0u && a) { atomicAdd(&stats[0], a); atomicAdd(&stats[1], b); }
+}
+
 // the same into a bucket table; rep_base + the flat index of the window's first minimizer names the instance that published the key
 // (kept when the table keeps representatives: k = firstK + 1 writes the vectors of its rows)
 __global__ __launch_bounds__(256) void index_insert_b_kernel(SeqView s /* k */, const uint64_t *inst_off_km1, const uint32_t *prev_ab,
@@ -1207,6 +1345,45 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     // "index_tuning" (A/B): bit 0 a slot's key and value in one trip, bit 1 the plain-load first look of the insert, bit 2 two windows of
     // a lane in flight, bit 3 look-up and insert in one kernel
     const bool wide = ctx->index_tuning & 1u, fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u, fused = ctx->index_tuning & 8u;
+    // round 6 -- bit 7: insert first, look up only where needed (index_lazy_kernel); bit 8: never; neither: a sample of the sequences decides
+    // (the form pays 1 + f (1 + 1 / k) random sectors per instance where the two kernels pay 2 - f, f = the fraction of windows that are never
+    // inserted: better below f = 0.46; HiFi reads stay below to k = 24 and beyond, ONT reads at 2 % errors do not)
+    bool lazy = (ctx->index_tuning & 128u) != 0;
+    if (!lazy && !(ctx->index_tuning & 256u) && !fused && (ctx->index_tuning & 15u) == 3u) {
+        SeqView vk = make_view(s, ik);
+        DevBuf<unsigned long long> st;
+        MDBG_TRY(st.alloc(ctx, 2));
+        MDBG_HIP_CHECK(ctx, hipMemsetAsync(st.p, 0, 16, ctx->stream));
+        const uint32_t step = vk.n_reads > 32768u ? vk.n_reads / 16384u : 1u;
+        {
+            LaunchTimer timer(ctx, "kminmer_prev_lookup");
+            hipLaunchKernelGGL(index_miss_sample_kernel, dim3(instance_grid(ctx, (vk.n_reads + step - 1) / step)), dim3(256), 0, ctx->stream, vk, k, pv, step, st.p);
+        }
+        unsigned long long h[2] = {0, 0};
+        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h, st.p, 16, hipMemcpyDeviceToHost));
+        lazy = h[0] > 0 && (double)h[1] < 0.45 * (double)h[0];
+        ctx->index_last_miss_fraction = h[0] ? (double)h[1] / (double)h[0] : -1.0;
+    }
+    if (lazy) {
+        SeqView vk = make_view(s, ik);
+        LaunchTimer timer(ctx, "kminmer_insert");
+        const dim3 grid(instance_grid(ctx, vk.n_reads)), block(256);
+        static const int lazy_u = getenv("MDBG_INDEX_LAZY_U") ? atoi(getenv("MDBG_INDEX_LAZY_U")) : 1;      // A/B: chunks of a sequence in flight per group
+        static const bool lazy_stats = getenv("MDBG_INDEX_LAZY_STATS") != nullptr;                             // prints k-windows looked at / not seen at the first look
+        DevBuf<unsigned long long> st;
+        if (lazy_stats) { MDBG_TRY(st.alloc(ctx, 2)); MDBG_HIP_CHECK(ctx, hipMemsetAsync(st.p, 0, 16, ctx->stream)); }
+        if (lazy_u >= 3) hipLaunchKernelGGL(index_lazy_kernel<3>, grid, block, 0, ctx->stream, vk, k, pv, tv, st.p);
+        else if (lazy_u == 2) hipLaunchKernelGGL(index_lazy_kernel<2>, grid, block, 0, ctx->stream, vk, k, pv, tv, st.p);
+        else hipLaunchKernelGGL(index_lazy_kernel<1>, grid, block, 0, ctx->stream, vk, k, pv, tv, st.p);
+        MDBG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (lazy_stats) {
+            unsigned long long h[2] = {0, 0};
+            MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h, st.p, 16, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[mdbg] index pass k = %u, insert first: %llu k-windows, %llu not seen at the first look (%.3f); sample said %.3f never inserted\n", k, h[0], h[1],
+                    h[0] ? (double)h[1] / (double)h[0] : 0.0, ctx->index_last_miss_fraction);
+        }
+        return MDBG_OK;
+    }
     if (fused) {
         SeqView vk = make_view(s, ik);
         LaunchTimer timer(ctx, "kminmer_insert");

@@ -290,7 +290,7 @@ def test_count_first_deep_k_vs_oracle(ctx, orc, k, mode):
         ctx.set_option("first_pass_mode", 0)
 
 
-@pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two", "slots_round5", "slots_32_lanes", "buckets"])
+@pytest.mark.parametrize("form", ["slots", "slots_lazy", "slots_never_lazy", "slots_fused", "slots_two", "slots_round5", "slots_32_lanes", "buckets"])
 @pytest.mark.parametrize("k", [13, 15, 17, 33, 65, 100])
 def test_refined_and_index_deep_k_vs_oracle(ctx, orc, k, form):
     """The passes above firstK at deep k against the oracle on seeded inputs: previous table at k - 1 (+ a unitig overlay), refined count,
@@ -379,11 +379,13 @@ def _table_form(ctx, form: str):
     abundance by a DPP move) or in two with an array in between, both with a slot's words in one trip and the insert's plain-load first look --,
     "slots_two" -- two windows of a lane in flight --, "slots_round4" -- the same tables with the kernels of rounds 1 - 4 --, "slots_round5" -- round 5's
     kernels, the pass's own table dropped and rebuilt from the rows --, "slots_pair_insert" / "slots_32_lanes" -- round 6's measured-and-not-taken variants --, "buckets" -- three keys per 64-byte sector,
-    the refined pass by look-ups like an index pass (both measured, neither faster: DESIGN.md 4.2)."""
+    the refined pass by look-ups like an index pass (both measured, neither faster: DESIGN.md 4.2); "slots_lazy" / "slots_never_lazy" -- the index pass
+    that inserts first and asks the previous table only where a key was not seen (index_lazy_kernel), always / never (the default decides by a sample)."""
     ctx.set_option("index_table_form", 0 if form == "buckets" else 1)
     ctx.set_option("refined_form", 0 if form == "buckets" else 1)
-    ctx.set_option("index_tuning", {"slots_round4": 0, "slots_two": 7, "slots_fused": 11, "slots_two_kernels": 3, "slots_round5": 3, "slots_pair_insert": 83,
-                                    "slots_32_lanes": 115}.get(form, -1))
+    # (bit 8 = 256: never the insert-first form, which the default otherwise chooses by a sample; bit 7 = 128: always)
+    ctx.set_option("index_tuning", {"slots_round4": 0, "slots_two": 7, "slots_fused": 11, "slots_two_kernels": 3 | 256, "slots_round5": 3 | 256, "slots_pair_insert": 83,
+                                    "slots_32_lanes": 115, "slots_lazy": 19 | 128, "slots_never_lazy": 19 | 256}.get(form, -1))
     ctx.set_option("keep_index_table", 0 if form == "slots_round5" else 1)
     try:
         yield
@@ -394,7 +396,7 @@ def _table_form(ctx, form: str):
         ctx.set_option("keep_index_table", 1)
 
 
-@pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two_kernels", "slots_two", "slots_round4", "slots_round5", "slots_pair_insert", "slots_32_lanes", "buckets"])
+@pytest.mark.parametrize("form", ["slots", "slots_lazy", "slots_never_lazy", "slots_fused", "slots_two_kernels", "slots_two", "slots_round4", "slots_round5", "slots_pair_insert", "slots_32_lanes", "buckets"])
 @pytest.mark.parametrize("k", [5, 6, 9])
 def test_refined_and_index_vs_oracle(ctx, orc, k, form):
     rng = np.random.default_rng(300 + k)
@@ -969,7 +971,7 @@ def _multik_cases():
     return [(s, k) for s in mk.SETS + mk.DEEP_SETS for k in mk.steps(s)]
 
 
-@pytest.mark.parametrize("form", ["slots", "slots_fused", "slots_two_kernels", "slots_round4", "buckets"])
+@pytest.mark.parametrize("form", ["slots", "slots_lazy", "slots_never_lazy", "slots_fused", "slots_two_kernels", "slots_round4", "buckets"])
 @pytest.mark.parametrize("name,k", _multik_cases())
 def test_next_k_tables_equal_reference_multik(ctx, name, k, form):
     """Rows A13 / A14 against the REFERENCE: previous table + unitig overlay, refined count (k = firstK+1), index
