@@ -413,7 +413,10 @@ def multik_rooflines(ctx, reads, last_k: int) -> dict:
                        "frac": alg / (total / 1e3) / 1e9 / HBM_PEAK_GBS if total > 0 else 0.0, "algorithmic_bytes": alg,
                        "minimizers_M": st["minimizers"], "instances_I": st["instances"], "rows_D": D, "table_slots": st["slots"],
                        "kernel_ms": ms, "kernel_ms_total": total,
-                       "random_slot_accesses_per_instance": None if k == 4 else (None if k == 5 else 2.0),
+                       # index passes: the two-kernel form asks 2 - f random sectors per instance, the insert-first form (round 6, chosen per pass by a
+                       # sample) 1 + f (1 + 1 / k), f = the fraction of windows that are never inserted (profiles/round6_w_index_miss_fraction_1m_reads.txt)
+                       "index_form": None if k <= 5 else ("insert first, look-ups where a key was not seen" if "kminmer_insert" in ms and ms.get("kminmer_prev_lookup", 0.0) < 1.0
+                                                          else "look-up per (k-1)-window, then insert"),
                        "instances_per_second_G": st["instances"] / (total / 1e3) / 1e9 if total > 0 else None}
         if prev is not None:
             prev.free()
@@ -936,8 +939,8 @@ def kminmer_traffic(reads: int, read_len: int):
 
 
 def index_traffic(reads: int, read_len: int):
-    """({"refined": bytes, "index": bytes} per pass -- the two kernels that make the pass: distinct_insert + refine_slots, prev_abundance +
-    index_insert --, note) from the committed rocprofv3 PMC passes (profiles/*_index_traffic.json, tools/index_traffic.sh): FETCH_SIZE + WRITE_SIZE
+    """({"refined": bytes, "index": bytes} per pass -- the two kernels that make the pass: distinct_insert + refine_slots; prev_abundance +
+    index_insert or, insert first, index_miss_sample + index_lazy --, note) from the committed rocprofv3 PMC passes (profiles/*_index_traffic.json, tools/index_traffic.sh): FETCH_SIZE + WRITE_SIZE
     as reported (these kernels read random 32-byte slots, not wide coalesced streams: no doubling), averaged over the launches of the loop; valid
     only for the workload and the sources they were collected on (git blob hashes), like measured_traffic."""
     import glob
@@ -958,7 +961,7 @@ def index_traffic(reads: int, read_len: int):
                       else "no PMC collection for this workload under profiles/")
     def of(*needles):
         return sum(v["traffic_bytes_uncorrected"] for kern, v in best[0]["per_kernel"].items() if any(nd in kern for nd in needles))
-    return ({"refined": of("distinct_insert", "refine_slots"), "index": of("prev_abundance", "index_insert")},
+    return ({"refined": of("distinct_insert", "refine_slots"), "index": of("prev_abundance", "index_insert", "index_lazy", "index_miss_sample")},
             f"profiles/{best[1]} (collected on this version of csrc/kminmer.hip and csrc/table.hpp)")
 
 

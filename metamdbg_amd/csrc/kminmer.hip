@@ -74,6 +74,15 @@ __device__ __forceinline__ uint32_t table_insert_once(const TableView &t, uint64
     return s;
 }
 
+// the same when the rows of the table carry their vectors (k = firstK + 1): the publishing instance also names itself
+__device__ __forceinline__ uint32_t table_insert_once_rep(const TableView &t, uint64_t lo, uint64_t hi, uint32_t v, uint32_t rep) {
+    if (lo == 0ull || hi == 0ull) return table_exc_upsert(t, lo, hi, 0, v, true, rep, true);
+    bool created = false;
+    uint32_t s = table_find_or_insert(t, lo, hi, true, &created);
+    if (s != SLOT_NONE && created) { __hip_atomic_store(&t.slots[s].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); t.slots[s].rep = rep; }
+    return s;
+}
+
 // Visit every instance with 16 lanes per sequence (4 sequences per wave): sequences hold a few dozen
 // windows, the minimizers of neighbouring windows are loaded coalesced, and no per-instance binary search
 // over the offsets is needed.  f(read, global instance id, pointer to the window's first minimizer).
@@ -595,8 +604,10 @@ __global__ __launch_bounds__(256) void index_fused_kernel(SeqView s /* k */, uin
 // stats[0] += k-windows looked at, stats[1] += those not found at the first look (what the next choice could go by).
 // U chunks of 15 windows of a sequence in flight per group (A/B, MDBG_INDEX_LAZY_U): 11.9 / 12.2 / 13.2 ms a pass at k = 6 for U = 1 / 2 / 3 --
 // the pass is not waiting for the round trips of its few look-ups; U = 1 runs.
-template <int U>
-__global__ __launch_bounds__(256) void index_lazy_kernel(SeqView s /* k */, uint32_t k, TableView prev, TableView t, unsigned long long *stats) {
+// REP (the refined pass, k = firstK + 1, whose rows carry their vectors): the instance that publishes a key names itself, rep_base + the flat
+// index of its first minimizer.
+template <int U, bool REP = false>
+__global__ __launch_bounds__(256) void index_lazy_kernel(SeqView s /* k */, uint32_t k, TableView prev, TableView t, unsigned long long *stats, uint64_t rep_base = 0) {
     const unsigned sub = threadIdx.x & 15u;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
@@ -682,7 +693,10 @@ __global__ __launch_bounds__(256) void index_lazy_kernel(SeqView s /* k */, uint
                 const uint32_t vn = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)v[u], 0x101, 0xf, 0xf, false);      // row_shl:1: the lane above
                 if (need[u]) {
                     const uint32_t a = v[u] < vn ? v[u] : vn;
-                    if (a > 1u) table_insert_once(t, klo[u], khi[u], a);
+                    if (a > 1u) {
+                        if (REP) table_insert_once_rep(t, klo[u], khi[u], a, (uint32_t)(rep_base + (uint64_t)(m0 + (i0 + 15u * (uint32_t)u + sub) - s.mins)));
+                        else table_insert_once(t, klo[u], khi[u], a);
+                    }
                 }
             }
         }
@@ -1270,6 +1284,28 @@ static int rows_from_buckets(mdbg_ctx *ctx, BucketTable &tab, uint32_t k, const 
 static int index_pass_buckets(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs, uint32_t k, const mdbg_table *prev,
                               bool vectors, int hint_kind, mdbg_table **out);
 
+// Which form a pass above firstK takes ("index_tuning" bit 7: insert first, look up only where needed -- index_lazy_kernel; bit 8: never;
+// neither: a sample of the sequences decides).  The insert-first form pays 1 + f (1 + 1 / k) random sectors per instance where the two
+// kernels pay 2 - f, f = the fraction of windows that are never inserted: better below f = 0.46 -- HiFi reads stay below to k = 26 and
+// beyond (profiles/round6_w_*, round6_y_*), ONT reads at 2 % errors do not.
+static int choose_insert_first(mdbg_ctx *ctx, const SeqView &vk, uint32_t k, const TableView &pv, bool &lazy) {
+    lazy = (ctx->index_tuning & 128u) != 0;
+    if (lazy || (ctx->index_tuning & 256u) || (ctx->index_tuning & 8u) || (ctx->index_tuning & 15u) != 3u || !vk.n_inst) return MDBG_OK;
+    DevBuf<unsigned long long> st;
+    MDBG_TRY(st.alloc(ctx, 2));
+    MDBG_HIP_CHECK(ctx, hipMemsetAsync(st.p, 0, 16, ctx->stream));
+    const uint32_t step = vk.n_reads > 32768u ? vk.n_reads / 16384u : 1u;
+    {
+        LaunchTimer timer(ctx, "kminmer_prev_lookup");
+        hipLaunchKernelGGL(index_miss_sample_kernel, dim3(instance_grid(ctx, (vk.n_reads + step - 1) / step)), dim3(256), 0, ctx->stream, vk, k, pv, step, st.p);
+    }
+    unsigned long long h[2] = {0, 0};
+    MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h, st.p, 16, hipMemcpyDeviceToHost));
+    lazy = h[0] > 0 && (double)h[1] < 0.45 * (double)h[0];
+    ctx->index_last_miss_fraction = h[0] ? (double)h[1] / (double)h[0] : -1.0;
+    return MDBG_OK;
+}
+
 extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *reads, const mdbg_minimizers *unitigs,
                                           uint32_t k, const mdbg_table *prev, mdbg_table **out) try {
     if (!ctx || !out || k < 3) return set_error(ctx, MDBG_EINVAL, "mdbg_kminmer_count_refined: bad argument");
@@ -1286,9 +1322,19 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     const uint64_t I = ia.total + ib.total;
     if (I >= (1ull << 32) || a.n_min + b.n_min >= (1ull << 32))
         return set_error(ctx, MDBG_ERANGE, "more than 2^32 minimizers / k-min-mer instances in one call");
+    // round 6: the refined pass insert-first like the index passes when the sample says so -- only the keys that are KEPT enter the table
+    // (a third of the distinct ones at 50 x HiFi), with their final value and the instance that names their vector; no walk over the
+    // slots to refine them afterwards
+    bool lazy = false;
+    MDBG_TRY(choose_insert_first(ctx, a, k, pv, lazy));
     DeviceTable tab;
     MDBG_TRY(build_table_adaptive(ctx, tab, (uint64_t)((double)I * ctx->key_ratio_hint[1]), I, [&](TableView v) {
         LaunchTimer timer(ctx, "kminmer_insert");
+        if (lazy) {
+            if (a.n_inst) hipLaunchKernelGGL((index_lazy_kernel<1, true>), dim3(instance_grid(ctx, a.n_reads)), dim3(256), 0, ctx->stream, a, k, pv, v, (unsigned long long *)nullptr, (uint64_t)0);
+            if (b.n_inst) hipLaunchKernelGGL((index_lazy_kernel<1, true>), dim3(instance_grid(ctx, b.n_reads)), dim3(256), 0, ctx->stream, b, k, pv, v, (unsigned long long *)nullptr, (uint64_t)a.n_min);
+            return MDBG_OK;
+        }
         // ("index_tuning" bits 1 and 2, as in the index passes: the plain-load first look, two windows of a lane in flight)
         const bool fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u;
         auto launch = [&](const SeqView &sv, uint64_t rep_base) {
@@ -1310,7 +1356,7 @@ extern "C" int mdbg_kminmer_count_refined(mdbg_ctx *ctx, const mdbg_minimizers *
     MDBG_TRY(spos.alloc(ctx, nslots + 1));
     {
         LaunchTimer timer(ctx, "kminmer_emit");
-        hipLaunchKernelGGL(refine_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, a, b, k, pv);
+        if (!lazy) hipLaunchKernelGGL(refine_slots_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, a, b, k, pv);
         hipLaunchKernelGGL(slot_flag_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, ctx->stream, tv, tab.cap, 0u, 1, sflag.p,
                            (uint8_t *)nullptr, 0u, tv.occ);
     }
@@ -1345,25 +1391,8 @@ static int index_one_set(mdbg_ctx *ctx, const mdbg_minimizers *s, uint32_t k, co
     // "index_tuning" (A/B): bit 0 a slot's key and value in one trip, bit 1 the plain-load first look of the insert, bit 2 two windows of
     // a lane in flight, bit 3 look-up and insert in one kernel
     const bool wide = ctx->index_tuning & 1u, fast = ctx->index_tuning & 2u, two = ctx->index_tuning & 4u, fused = ctx->index_tuning & 8u;
-    // round 6 -- bit 7: insert first, look up only where needed (index_lazy_kernel); bit 8: never; neither: a sample of the sequences decides
-    // (the form pays 1 + f (1 + 1 / k) random sectors per instance where the two kernels pay 2 - f, f = the fraction of windows that are never
-    // inserted: better below f = 0.46; HiFi reads stay below to k = 24 and beyond, ONT reads at 2 % errors do not)
-    bool lazy = (ctx->index_tuning & 128u) != 0;
-    if (!lazy && !(ctx->index_tuning & 256u) && !fused && (ctx->index_tuning & 15u) == 3u) {
-        SeqView vk = make_view(s, ik);
-        DevBuf<unsigned long long> st;
-        MDBG_TRY(st.alloc(ctx, 2));
-        MDBG_HIP_CHECK(ctx, hipMemsetAsync(st.p, 0, 16, ctx->stream));
-        const uint32_t step = vk.n_reads > 32768u ? vk.n_reads / 16384u : 1u;
-        {
-            LaunchTimer timer(ctx, "kminmer_prev_lookup");
-            hipLaunchKernelGGL(index_miss_sample_kernel, dim3(instance_grid(ctx, (vk.n_reads + step - 1) / step)), dim3(256), 0, ctx->stream, vk, k, pv, step, st.p);
-        }
-        unsigned long long h[2] = {0, 0};
-        MDBG_HIP_CHECK(ctx, memcpy_sync(ctx, h, st.p, 16, hipMemcpyDeviceToHost));
-        lazy = h[0] > 0 && (double)h[1] < 0.45 * (double)h[0];
-        ctx->index_last_miss_fraction = h[0] ? (double)h[1] / (double)h[0] : -1.0;
-    }
+    bool lazy = false;
+    if (!fused) MDBG_TRY(choose_insert_first(ctx, make_view(s, ik), k, pv, lazy));
     if (lazy) {
         SeqView vk = make_view(s, ik);
         LaunchTimer timer(ctx, "kminmer_insert");
