@@ -8,7 +8,7 @@
 #   index_traffic.json, index_pmc.txt           the same for the refined and index passes (tools/index_traffic.sh)
 #   exchange_per_rank_workload_one_gpu.txt      the per-rank workload of an 8-GPU job through the library's exchange on one GPU; two processes sharing it
 set -u
-TAG=${1:-round6_final2}
+TAG=${1:-round6_final4}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
