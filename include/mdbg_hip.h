@@ -79,8 +79,10 @@ int  mdbg_device_clock_khz(mdbg_ctx *ctx, int *clock_khz);   /* peak engine cloc
  *                           value fetched in one trip, 2 = the insert first looks at a window's home slot with plain loads (a key found
  *                           there is done without an atomic), 4 = two windows of a lane in flight (measured: no gain), 8 = look-up and
  *                           insert in one kernel (measured: slower), 16 = both slots of a key's home sector fetched at once (look-up
- *                           and the insert's first look), 32 = 32 lanes a sequence instead of 16; 0 = the kernels
- *                           of rounds 1 - 4.  Results never depend on it
+ *                           and the insert's first look), 32 = 32 lanes a sequence instead of 16, 128 = always insert first and look the
+ *                           previous table up only for the k-windows not seen in the new one, 256 = never (neither: a sample of the
+ *                           sequences decides per pass -- insert first when fewer than 0.45 of the windows are never inserted);
+ *                           0 = the kernels of rounds 1 - 4.  Results never depend on it
  *   "keep_index_table"      1 (default) = the hash table an index pass filled stays with its result as the look-up structure the next
  *                           pass reads; 0 = it is dropped and built again from the rows on first use (rounds 1 - 5)
  *   "index_table_form"      0 = those passes over bucket tables (three keys per 64-byte sector: a third of the bytes, measured no
