@@ -961,7 +961,7 @@ def index_traffic(reads: int, read_len: int):
                       else "no PMC collection for this workload under profiles/")
     def of(*needles):
         return sum(v["traffic_bytes_uncorrected"] for kern, v in best[0]["per_kernel"].items() if any(nd in kern for nd in needles))
-    return ({"refined": of("distinct_insert", "refine_slots"), "index": of("prev_abundance", "index_insert", "index_lazy", "index_miss_sample")},
+    return ({"refined": of("distinct_insert", "refine_slots", "index_lazy_kernelILi1ELb1"), "index": of("prev_abundance", "index_insert", "index_lazy_kernelILi1ELb0", "index_miss_sample")},
             f"profiles/{best[1]} (collected on this version of csrc/kminmer.hip and csrc/table.hpp)")
 
 
